@@ -1,0 +1,9 @@
+/* Umbrella include for the hot-path C ABI (reference: c/include/cuvs/core/all.h). */
+#pragma once
+#include <cuvs/core/c_api.h>
+#include <cuvs/distance/distance.h>
+#include <cuvs/neighbors/common.h>
+#include <cuvs/neighbors/brute_force.h>
+#include <cuvs/neighbors/ivf_flat.h>
+#include <cuvs/neighbors/ivf_pq.h>
+#include <cuvs/neighbors/cagra.h>
