@@ -1,0 +1,30 @@
+# Build the MI355X hot-path library (C ABI) and the CPU oracle.
+#   make            -> cuvs_amd/libcuvs_c.so  (hipcc, gfx950)  +  oracle/liboracle.so (gcc)
+# Objects go to build/ (git-ignored); the .so files stay in-tree so they travel to the GPU box.
+HIPCC      ?= hipcc
+ARCH       ?= gfx950
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -Icuvs_amd/csrc \
+              -Wno-unused-result -ffp-contract=off
+CC         ?= gcc
+CFLAGS     := -O3 -march=x86-64-v3 -fPIC -fopenmp -ffp-contract=off -Wall -std=c11
+
+SRCS := $(wildcard cuvs_amd/csrc/*.hip)
+OBJS := $(patsubst cuvs_amd/csrc/%.hip,build/%.o,$(SRCS))
+HDRS := $(wildcard cuvs_amd/csrc/*.hpp) $(wildcard include/cuvs/*/*.h) include/dlpack/dlpack.h
+
+all: cuvs_amd/libcuvs_c.so oracle/liboracle.so
+
+build/%.o: cuvs_amd/csrc/%.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+cuvs_amd/libcuvs_c.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle/liboracle.so: oracle/oracle.c
+	$(CC) $(CFLAGS) -shared -o $@ $< -lm
+
+clean:
+	rm -rf build cuvs_amd/libcuvs_c.so oracle/liboracle.so
+
+.PHONY: all clean

@@ -1,0 +1,247 @@
+// Brute-force kNN: index = (view of the dataset, canonical norms); search = MFMA distance tiles + exact
+// radix select_k per tile + one merge select_k (reference: tiled_brute_force_knn,
+// cpp/src/neighbors/detail/knn_brute_force.cuh:62-326, index build :779-817, C layer
+// c/src/neighbors/brute_force.cpp:143-231). Pre-filters (bitset / bitmap) are applied to the distance tile.
+#include "ops.hpp"
+#include "device_utils.hpp"
+
+#include <cuvs/neighbors/brute_force.h>
+
+#include <algorithm>
+#include <cfloat>
+
+namespace cuvs_amd {
+
+struct bf_index {
+  int metric       = 0;
+  float metric_arg = 2.0f;
+  elem_t dtype     = elem_t::f32;
+  int64_t n = 0, dim = 0, ld = 0;
+  const void* data = nullptr;  // device pointer (view or owned)
+  dev_buf<char> owned;         // set when the dataset had to be copied (F-contiguous / host input)
+  dev_buf<float> norms;        // |x|^2 (L2) or |x| (cosine); empty for inner product
+};
+
+namespace {
+
+// distances of filtered-out samples -> worst value. bits: 1 keeps the sample
+// (reference: cuvs::core::bitset / bitmap_view semantics, sample_filter.cuh)
+__global__ void apply_filter_kernel(float* d, int64_t m, int64_t n_tile, int64_t ldo, int64_t col0,
+                                    int64_t row0, int64_t n_total, const uint32_t* bits, bool bitmap,
+                                    float worst)
+{
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * n_tile) return;
+  int64_t r = idx / n_tile, c = idx % n_tile;
+  int64_t bit = bitmap ? (row0 + r) * n_total + (col0 + c) : (col0 + c);
+  bool keep   = (bits[bit >> 5] >> (bit & 31)) & 1u;
+  if (!keep) d[r * ldo + c] = worst;
+}
+
+template <typename T>
+void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int64_t m, int64_t ldq, int k,
+                     int64_t* neighbors, float* distances, const uint32_t* filter_bits, int filter_type)
+{
+  const int metric      = idx.metric;
+  const bool select_min = metric != M_InnerProduct;
+  const int64_t n       = idx.n;
+  const T* data         = static_cast<const T*>(idx.data);
+  CUVS_EXPECTS(k >= 1 && k <= 2048, "brute_force::search: k must be in [1, 2048]");
+
+  // row tiles bounded by the workspace; column tiles as wide as the workspace allows
+  const int64_t ws_floats = (int64_t)(res.workspace_limit / sizeof(float));
+  int64_t m_tile          = std::min<int64_t>(m, 16384);
+  int64_t n_tile          = std::max<int64_t>(128, (ws_floats / m_tile) / 128 * 128);
+  n_tile                  = std::min<int64_t>(n_tile, round_up(n, 128));
+  const int64_t n_ct      = (n + n_tile - 1) / n_tile;
+
+  dev_buf<float> qn;
+  if (metric != M_InnerProduct) {
+    qn = dev_buf<float>(res, m);
+    row_norms<T>(res, queries, m, idx.dim, ldq, qn.data(), metric == M_CosineExpanded);
+  }
+  dev_buf<float> tile(res, (size_t)m_tile * std::min<int64_t>(n_tile, n));
+  const int64_t ldo = std::min<int64_t>(n_tile, n);
+  dev_buf<float> part_v;
+  dev_buf<int64_t> part_i;
+  if (n_ct > 1) {
+    part_v = dev_buf<float>(res, (size_t)m_tile * n_ct * k);
+    part_i = dev_buf<int64_t>(res, (size_t)m_tile * n_ct * k);
+  }
+  const float worst = select_min ? FLT_MAX : -FLT_MAX;
+
+  for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
+    const int64_t mr = std::min(m_tile, m - r0);
+    for (int64_t ct = 0; ct < n_ct; ++ct) {
+      const int64_t c0 = ct * n_tile;
+      const int64_t nc = std::min(n_tile, n - c0);
+      pairwise_distance<T, T>(res, queries + r0 * ldq, mr, ldq, data + c0 * idx.ld, nc, idx.ld, idx.dim,
+                              qn.data() ? qn.data() + r0 : nullptr,
+                              idx.norms.data() ? idx.norms.data() + c0 : nullptr, metric, tile.data(), ldo);
+      if (filter_type != NO_FILTER) {
+        int64_t total = mr * nc;
+        hipLaunchKernelGGL(apply_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, res.stream,
+                           tile.data(), mr, nc, ldo, c0, r0, n, filter_bits, filter_type == BITMAP, worst);
+      }
+      if (n_ct == 1) {
+        select_k<int64_t, int64_t>(res, tile.data(), nullptr, mr, nc, ldo, k, distances + r0 * k,
+                                   neighbors + r0 * k, select_min, c0);
+      } else {
+        select_k<int64_t, int64_t>(res, tile.data(), nullptr, mr, nc, ldo, k, part_v.data(), part_i.data(),
+                                   select_min, c0, n_ct * k, ct * k);
+      }
+    }
+    if (n_ct > 1) {
+      select_k<int64_t, int64_t>(res, part_v.data(), part_i.data(), mr, n_ct * k, n_ct * k, k,
+                                 distances + r0 * k, neighbors + r0 * k, select_min);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename T>
+void bf_build_typed(resources& res, bf_index& idx)
+{
+  if (idx.metric != M_InnerProduct) {
+    idx.norms = dev_buf<float>(res, idx.n);
+    row_norms<T>(res, static_cast<const T*>(idx.data), idx.n, idx.dim, idx.ld, idx.norms.data(),
+                 idx.metric == M_CosineExpanded);
+  }
+}
+
+__global__ void transpose_copy_kernel(const char* src, char* dst, int64_t rows, int64_t cols, int esz)
+{
+  // src is column-major [rows, cols] (element (r,c) at c*rows + r); dst row-major
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int64_t r = i / cols, c = i % cols;
+  for (int b = 0; b < esz; ++b) dst[i * esz + b] = src[(c * rows + r) * esz + b];
+}
+
+}  // namespace
+}  // namespace cuvs_amd
+
+using namespace cuvs_amd;
+
+extern "C" {
+
+cuvsError_t cuvsBruteForceIndexCreate(cuvsBruteForceIndex_t* index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(index != nullptr, "index is null");
+    *index = new cuvsBruteForceIndex{0, DLDataType{0, 0, 0}};
+  });
+}
+
+cuvsError_t cuvsBruteForceIndexDestroy(cuvsBruteForceIndex_t index_c_ptr)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    if (index_c_ptr == nullptr) return;
+    delete reinterpret_cast<bf_index*>(index_c_ptr->addr);
+    delete index_c_ptr;
+  });
+}
+
+cuvsError_t cuvsBruteForceBuild(cuvsResources_t res_h, DLManagedTensor* dataset_tensor, cuvsDistanceType metric,
+                                float metric_arg, cuvsBruteForceIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(dataset_tensor != nullptr && index != nullptr, "null argument");
+    auto& ds = dataset_tensor->dl_tensor;
+    CUVS_EXPECTS(ds.ndim == 2, "dataset must be a matrix");
+    CUVS_EXPECTS(metric_supported((int)metric), "brute_force: unsupported metric %d", (int)metric);
+    elem_t et = elem_of(ds.dtype);
+    CUVS_EXPECTS(et == elem_t::f32 || et == elem_t::f16, "Unsupported dataset DLtensor dtype: %d and bits: %d",
+                 (int)ds.dtype.code, (int)ds.dtype.bits);
+    auto idx        = std::make_unique<bf_index>();
+    idx->metric     = (int)metric;
+    idx->metric_arg = metric_arg;
+    idx->dtype      = et;
+    idx->n          = ds.shape[0];
+    idx->dim        = ds.shape[1];
+    idx->ld         = idx->dim;
+    const size_t esz = elem_size(et);
+    if (is_device_accessible(ds) && is_c_contiguous(ds)) {
+      idx->data = dl_data(ds);  // non-owning view, as in the reference (brute_force.cu:66-79)
+    } else if (is_device_accessible(ds) && is_f_contiguous(ds)) {
+      idx->owned = dev_buf<char>(res, (size_t)idx->n * idx->dim * esz);
+      int64_t total = idx->n * idx->dim;
+      hipLaunchKernelGGL(transpose_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, res.stream,
+                         static_cast<const char*>(dl_data(ds)), idx->owned.data(), idx->n, idx->dim, (int)esz);
+      idx->data = idx->owned.data();
+    } else if (is_c_contiguous(ds)) {
+      idx->owned = dev_buf<char>(res, (size_t)idx->n * idx->dim * esz);
+      copy_async(res, idx->owned.data(), dl_data(ds), idx->owned.bytes());
+      idx->data = idx->owned.data();
+    } else {
+      CUVS_FAIL("dataset input to cuvsBruteForceBuild must be contiguous (non-strided)");
+    }
+    if (et == elem_t::f32) bf_build_typed<float>(res, *idx); else bf_build_typed<__half>(res, *idx);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = ds.dtype;
+  });
+}
+
+cuvsError_t cuvsBruteForceSearch(cuvsResources_t res_h, cuvsBruteForceIndex_t index_c_ptr,
+                                 DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
+                                 DLManagedTensor* distances_tensor, cuvsFilter prefilter)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index_c_ptr && index_c_ptr->addr, "index is not built");
+    auto& idx       = *reinterpret_cast<bf_index*>(index_c_ptr->addr);
+    auto& queries   = queries_tensor->dl_tensor;
+    auto& neighbors = neighbors_tensor->dl_tensor;
+    auto& distances = distances_tensor->dl_tensor;
+    CUVS_EXPECTS(is_device_accessible(queries), "queries should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(neighbors), "neighbors should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(distances), "distances should have device compatible memory");
+    CUVS_EXPECTS(dtype_is(neighbors.dtype, kDLInt, 64), "neighbors should be of type int64_t");
+    CUVS_EXPECTS(dtype_is(distances.dtype, kDLFloat, 32), "distances should be of type float32");
+    CUVS_EXPECTS(queries.ndim == 2 && neighbors.ndim == 2 && distances.ndim == 2, "tensors must be 2-D");
+    CUVS_EXPECTS(is_c_contiguous(queries) && is_c_contiguous(neighbors) && is_c_contiguous(distances),
+                 "tensors must be C-contiguous");
+    CUVS_EXPECTS(queries.dtype.code == index_c_ptr->dtype.code && queries.dtype.bits == index_c_ptr->dtype.bits,
+                 "Unsupported queries DLtensor dtype: %d and bits: %d", (int)queries.dtype.code,
+                 (int)queries.dtype.bits);
+    CUVS_EXPECTS(queries.shape[1] == idx.dim, "queries dim %ld != index dim %ld", (long)queries.shape[1],
+                 (long)idx.dim);
+    int64_t m = queries.shape[0];
+    int64_t k = neighbors.shape[1];
+    CUVS_EXPECTS(neighbors.shape[0] == m && distances.shape[0] == m && distances.shape[1] == k,
+                 "neighbors/distances shape mismatch");
+    const uint32_t* bits = nullptr;
+    if (prefilter.type != NO_FILTER) {
+      CUVS_EXPECTS(prefilter.type == BITSET || prefilter.type == BITMAP, "unsupported prefilter type");
+      CUVS_EXPECTS(prefilter.addr != 0, "prefilter tensor is null");
+      auto& ft = reinterpret_cast<DLManagedTensor*>(prefilter.addr)->dl_tensor;
+      CUVS_EXPECTS(dtype_is(ft.dtype, kDLUInt, 32) && is_device_accessible(ft),
+                   "prefilter must be a device uint32 tensor");
+      bits = static_cast<const uint32_t*>(dl_data(ft));
+    }
+    if (idx.dtype == elem_t::f32) {
+      bf_search_typed<float>(res, idx, static_cast<const float*>(dl_data(queries)), m, idx.dim, (int)k,
+                             static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)),
+                             bits, (int)prefilter.type);
+    } else {
+      bf_search_typed<__half>(res, idx, static_cast<const __half*>(dl_data(queries)), m, idx.dim, (int)k,
+                              static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)),
+                              bits, (int)prefilter.type);
+    }
+  });
+}
+
+cuvsError_t cuvsBruteForceSerialize(cuvsResources_t, const char*, cuvsBruteForceIndex_t)
+{
+  return (cuvsError_t)translate_exceptions(
+    [=] { CUVS_FAIL("cuvsBruteForceSerialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+}
+
+cuvsError_t cuvsBruteForceDeserialize(cuvsResources_t, const char*, cuvsBruteForceIndex_t)
+{
+  return (cuvsError_t)translate_exceptions(
+    [=] { CUVS_FAIL("cuvsBruteForceDeserialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+}
+
+}  // extern "C"

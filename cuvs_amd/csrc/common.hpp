@@ -1,0 +1,236 @@
+// Shared host-side plumbing for the MI355X hot path: error convention, resources handle,
+// stream-ordered device buffers and DLPack checks.
+//
+// Replaces what the reference gets from RAFT/RMM (raft::resources, rmm::device_uvector,
+// RAFT_EXPECTS) and from c/src/core/{exceptions.hpp,detail/interop.hpp}; none of that code is
+// on disk, so this is written for HIP directly: one hipStream per handle, hipMallocAsync pool.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <dlpack/dlpack.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace cuvs_amd {
+
+// ---------------------------------------------------------------- errors
+struct error : public std::runtime_error {
+  explicit error(const std::string& s) : std::runtime_error(s) {}
+};
+
+[[noreturn]] inline void fail(const char* file, int line, const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  char out[1200];
+  snprintf(out, sizeof(out), "%s (%s:%d)", buf, file, line);
+  throw error(out);
+}
+
+#define CUVS_EXPECTS(cond, ...)                                              \
+  do {                                                                       \
+    if (!(cond)) { ::cuvs_amd::fail(__FILE__, __LINE__, __VA_ARGS__); }      \
+  } while (0)
+#define CUVS_FAIL(...) ::cuvs_amd::fail(__FILE__, __LINE__, __VA_ARGS__)
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      ::cuvs_amd::fail(__FILE__, __LINE__, "HIP error %d (%s) in %s", (int)e__,              \
+                       hipGetErrorString(e__), #expr);                                       \
+    }                                                                                        \
+  } while (0)
+
+// thread-local last-error text (reference: c/src/core/c_api.cpp:187-192)
+std::string& last_error_text();
+
+// body wrapper used by every extern "C" entry point (reference: c/src/core/exceptions.hpp:16-32)
+template <typename Fn>
+int translate_exceptions(Fn&& fn)
+{
+  try {
+    fn();
+    return 1;  // CUVS_SUCCESS
+  } catch (const std::exception& e) {
+    last_error_text() = e.what();
+    return 0;  // CUVS_ERROR
+  } catch (...) {
+    last_error_text() = "unknown exception";
+    return 0;
+  }
+}
+
+// ---------------------------------------------------------------- resources
+struct resources {
+  int device              = 0;
+  hipStream_t stream      = nullptr;  // nullptr == the legacy default stream
+  bool owns_stream        = false;
+  int num_cus             = 256;
+  size_t lds_per_block    = 160 * 1024;
+  size_t workspace_limit  = size_t(2) << 30;  // temporary distance tiles etc.
+  std::vector<int> mg_devices;                // multi-GPU handle: participating devices
+};
+
+inline resources* as_res(uintptr_t h)
+{
+  CUVS_EXPECTS(h != 0, "null cuvsResources_t");
+  return reinterpret_cast<resources*>(h);
+}
+
+// Stream-ordered device allocation (the reference uses rmm::device_uvector on the handle's
+// stream; hipMallocAsync gives the same semantics from the driver's pool).
+void* device_alloc(resources& res, size_t bytes);
+void device_free(resources& res, void* p);
+
+template <typename T>
+struct dev_buf {
+  resources* res = nullptr;
+  T* ptr         = nullptr;
+  size_t n       = 0;
+  dev_buf() = default;
+  dev_buf(resources& r, size_t count) : res(&r), n(count)
+  {
+    ptr = count ? static_cast<T*>(device_alloc(r, count * sizeof(T))) : nullptr;
+  }
+  dev_buf(const dev_buf&)            = delete;
+  dev_buf& operator=(const dev_buf&) = delete;
+  dev_buf(dev_buf&& o) noexcept : res(o.res), ptr(o.ptr), n(o.n) { o.ptr = nullptr; o.n = 0; }
+  dev_buf& operator=(dev_buf&& o) noexcept
+  {
+    if (this != &o) {
+      release();
+      res = o.res; ptr = o.ptr; n = o.n;
+      o.ptr = nullptr; o.n = 0;
+    }
+    return *this;
+  }
+  ~dev_buf() { release(); }
+  void release()
+  {
+    if (ptr) { device_free(*res, ptr); ptr = nullptr; n = 0; }
+  }
+  void resize_discard(resources& r, size_t count)
+  {
+    release();
+    res = &r; n = count;
+    ptr = count ? static_cast<T*>(device_alloc(r, count * sizeof(T))) : nullptr;
+  }
+  T* data() const { return ptr; }
+  size_t size() const { return n; }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+inline void copy_async(resources& res, void* dst, const void* src, size_t bytes)
+{
+  if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, res.stream));
+}
+inline void sync(resources& res) { HIP_TRY(hipStreamSynchronize(res.stream)); }
+
+template <typename T>
+std::vector<T> to_host(resources& res, const T* d, size_t n)
+{
+  std::vector<T> h(n);
+  copy_async(res, h.data(), d, n * sizeof(T));
+  sync(res);
+  return h;
+}
+
+// ---------------------------------------------------------------- DLPack checks
+// Device-accessible = what the reference accepts (kDLCUDA/kDLCUDAHost/kDLCUDAManaged,
+// c/src/core/detail/interop.hpp:49-53) plus the ROCm spellings.
+inline bool is_device_accessible(const DLTensor& t)
+{
+  switch (t.device.device_type) {
+    case kDLCUDA:
+    case kDLCUDAHost:
+    case kDLCUDAManaged:
+    case kDLROCM:
+    case kDLROCMHost: return true;
+    default: return false;
+  }
+}
+inline bool is_host_accessible(const DLTensor& t)
+{
+  switch (t.device.device_type) {
+    case kDLCPU:
+    case kDLCUDAHost:
+    case kDLCUDAManaged:
+    case kDLROCMHost: return true;
+    default: return false;
+  }
+}
+// interop.hpp:61-75
+inline bool is_c_contiguous(const DLTensor& t)
+{
+  if (t.strides == nullptr) return true;
+  int64_t expected = 1;
+  for (int i = t.ndim - 1; i >= 0; --i) {
+    if (t.shape[i] != 1 && t.strides[i] != expected) return false;
+    expected *= t.shape[i];
+  }
+  return true;
+}
+// interop.hpp:77-92
+inline bool is_f_contiguous(const DLTensor& t)
+{
+  if (t.strides == nullptr) return t.ndim <= 1;
+  int64_t expected = 1;
+  for (int i = 0; i < t.ndim; ++i) {
+    if (t.shape[i] != 1 && t.strides[i] != expected) return false;
+    expected *= t.shape[i];
+  }
+  return true;
+}
+inline bool dtype_is(const DLDataType& d, uint8_t code, uint8_t bits)
+{
+  return d.code == code && d.bits == bits && d.lanes == 1;
+}
+inline void* dl_data(const DLTensor& t)
+{
+  return static_cast<char*>(t.data) + t.byte_offset;
+}
+
+enum class elem_t : int { f32 = 0, f16 = 1, i8 = 2, u8 = 3 };
+inline elem_t elem_of(const DLDataType& d)
+{
+  if (dtype_is(d, kDLFloat, 32)) return elem_t::f32;
+  if (dtype_is(d, kDLFloat, 16)) return elem_t::f16;
+  if (dtype_is(d, kDLInt, 8)) return elem_t::i8;
+  if (dtype_is(d, kDLUInt, 8)) return elem_t::u8;
+  CUVS_FAIL("Unsupported DLtensor dtype: %d and bits: %d", (int)d.code, (int)d.bits);
+}
+inline size_t elem_size(elem_t e) { return e == elem_t::f32 ? 4 : (e == elem_t::f16 ? 2 : 1); }
+
+// Fill a caller-allocated DLManagedTensor with a non-owning device view
+// (reference: c/src/core/detail/interop.hpp:148-172 — shape array new[]-ed, freed by deleter).
+void fill_dl_view(DLManagedTensor* out, void* data, DLDataType dt, int64_t rows, int64_t cols,
+                  int ndim, int device_id);
+
+// distance metric ids (include/cuvs/distance/distance.h)
+enum metric_t : int {
+  M_L2Expanded = 0, M_L2SqrtExpanded = 1, M_CosineExpanded = 2, M_L2Unexpanded = 4,
+  M_L2SqrtUnexpanded = 5, M_InnerProduct = 6
+};
+inline bool metric_supported(int m)
+{
+  return m == 0 || m == 1 || m == 2 || m == 4 || m == 5 || m == 6;
+}
+inline bool metric_is_l2(int m) { return m == 0 || m == 1 || m == 4 || m == 5; }
+inline bool metric_is_sqrt(int m) { return m == 1 || m == 5; }
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace cuvs_amd

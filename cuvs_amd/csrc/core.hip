@@ -1,0 +1,287 @@
+// Core C-ABI: resources, stream, allocation, last-error text, matrix copy/slice.
+// Replaces c/src/core/c_api.cpp of the reference (same symbols, same error convention).
+#include "common.hpp"
+
+#include <cuvs/core/c_api.h>
+
+#include <cstdlib>
+#include <mutex>
+
+namespace cuvs_amd {
+
+std::string& last_error_text()
+{
+  thread_local std::string text;
+  return text;
+}
+
+void* device_alloc(resources& res, size_t bytes)
+{
+  void* p = nullptr;
+  hipError_t e = hipMallocAsync(&p, bytes, res.stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    // pool exhausted or unsupported: fall back to a synchronous allocation
+    HIP_TRY(hipStreamSynchronize(res.stream));
+    HIP_TRY(hipMalloc(&p, bytes));
+  }
+  return p;
+}
+
+void device_free(resources& res, void* p)
+{
+  if (!p) return;
+  hipError_t e = hipFreeAsync(p, res.stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(res.stream);
+    (void)hipFree(p);
+  }
+}
+
+void fill_dl_view(DLManagedTensor* out, void* data, DLDataType dt, int64_t rows, int64_t cols,
+                  int ndim, int device_id)
+{
+  CUVS_EXPECTS(out != nullptr, "output DLManagedTensor is null");
+  out->dl_tensor.data        = data;
+  out->dl_tensor.device      = DLDevice{kDLCUDA, device_id};  // what unmodified bindings expect
+  out->dl_tensor.ndim        = ndim;
+  out->dl_tensor.dtype       = dt;
+  out->dl_tensor.shape       = new int64_t[2]{rows, cols};
+  out->dl_tensor.strides     = nullptr;
+  out->dl_tensor.byte_offset = 0;
+  out->manager_ctx           = nullptr;
+  out->deleter               = [](DLManagedTensor* self) {
+    delete[] self->dl_tensor.shape;
+    self->dl_tensor.shape = nullptr;
+  };
+}
+
+static int g_log_level = CUVS_LOG_LEVEL_INFO;
+
+}  // namespace cuvs_amd
+
+using namespace cuvs_amd;
+
+extern "C" {
+
+const char* cuvsGetLastErrorText()
+{
+  auto& t = last_error_text();
+  return t.empty() ? nullptr : t.c_str();
+}
+
+void cuvsSetLastErrorText(const char* error) { last_error_text() = error ? error : ""; }
+
+cuvsLogLevel_t cuvsGetLogLevel() { return (cuvsLogLevel_t)g_log_level; }
+void cuvsSetLogLevel(cuvsLogLevel_t l) { g_log_level = (int)l; }
+
+cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(res != nullptr, "res is null");
+    auto* r = new resources();
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    r->device = dev;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    r->num_cus       = prop.multiProcessorCount;
+    r->lds_per_block = prop.sharedMemPerBlock;
+    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    r->owns_stream = true;
+    // test hook: shrink the temporary-tile budget so tiling/merge logic runs on small inputs
+    // (the reference has max_row_tile_size/max_col_tile_size hooks, knn_brute_force.cuh:90-93)
+    if (const char* ws = getenv("CUVS_AMD_WORKSPACE_MB")) {
+      long mb = atol(ws);
+      if (mb > 0) r->workspace_limit = (size_t)mb << 20;
+    }
+    // keep freed blocks in the pool: search allocates the same temporaries every batch
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+      uint64_t thresh = UINT64_MAX;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thresh);
+    }
+    (void)hipGetLastError();
+    *res = reinterpret_cast<uintptr_t>(r);
+  });
+}
+
+cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto* r = as_res(res);
+    if (r->owns_stream && r->stream) {
+      (void)hipStreamSynchronize(r->stream);
+      (void)hipStreamDestroy(r->stream);
+    }
+    delete r;
+  });
+}
+
+cuvsError_t cuvsStreamSet(cuvsResources_t res, cudaStream_t stream)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto* r = as_res(res);
+    if (r->owns_stream && r->stream) {
+      HIP_TRY(hipStreamSynchronize(r->stream));
+      HIP_TRY(hipStreamDestroy(r->stream));
+    }
+    r->stream      = reinterpret_cast<hipStream_t>(stream);
+    r->owns_stream = false;
+  });
+}
+
+cuvsError_t cuvsStreamGet(cuvsResources_t res, cudaStream_t* stream)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(stream != nullptr, "stream is null");
+    *stream = reinterpret_cast<cudaStream_t>(as_res(res)->stream);
+  });
+}
+
+cuvsError_t cuvsStreamSync(cuvsResources_t res)
+{
+  return (cuvsError_t)translate_exceptions([=] { sync(*as_res(res)); });
+}
+
+cuvsError_t cuvsDeviceIdGet(cuvsResources_t res, int* device_id)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(device_id != nullptr, "device_id is null");
+    *device_id = as_res(res)->device;
+  });
+}
+
+// Single-process multi-GPU handle: records the participating devices. The sharded search path
+// itself runs one process per GPU over RCCL (see cuvs_amd/mg.py); this handle exists so that
+// bindings that create it keep working (reference: c_api.cpp:38-75).
+cuvsError_t cuvsMultiGpuResourcesCreate(cuvsResources_t* res)
+{
+  cuvsError_t e = cuvsResourcesCreate(res);
+  if (e != CUVS_SUCCESS) return e;
+  return (cuvsError_t)translate_exceptions([=] {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    auto* r = as_res(*res);
+    for (int i = 0; i < n; ++i) r->mg_devices.push_back(i);
+  });
+}
+
+cuvsError_t cuvsMultiGpuResourcesCreateWithDeviceIds(cuvsResources_t* res, DLManagedTensor* device_ids)
+{
+  cuvsError_t e = cuvsResourcesCreate(res);
+  if (e != CUVS_SUCCESS) return e;
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(device_ids != nullptr, "device_ids is null");
+    auto& t = device_ids->dl_tensor;
+    CUVS_EXPECTS(dtype_is(t.dtype, kDLInt, 32) && t.ndim == 1 && is_host_accessible(t),
+                 "device_ids must be a host int32 vector");
+    auto* r   = as_res(*res);
+    auto* ids = static_cast<const int32_t*>(dl_data(t));
+    for (int64_t i = 0; i < t.shape[0]; ++i) r->mg_devices.push_back(ids[i]);
+  });
+}
+
+cuvsError_t cuvsMultiGpuResourcesDestroy(cuvsResources_t res) { return cuvsResourcesDestroy(res); }
+
+cuvsError_t cuvsMultiGpuResourcesSetMemoryPool(cuvsResources_t res, int percent_of_free_memory)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    (void)as_res(res);
+    CUVS_EXPECTS(percent_of_free_memory >= 0 && percent_of_free_memory <= 100, "bad percentage");
+  });
+}
+
+cuvsError_t cuvsRMMAlloc(cuvsResources_t res, void** ptr, size_t bytes)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(ptr != nullptr, "ptr is null");
+    *ptr = device_alloc(*as_res(res), bytes);
+  });
+}
+
+cuvsError_t cuvsRMMFree(cuvsResources_t res, void* ptr, size_t)
+{
+  return (cuvsError_t)translate_exceptions([=] { device_free(*as_res(res), ptr); });
+}
+
+cuvsError_t cuvsRMMPoolMemoryResourceEnable(int initial_pool_size_percent, int max_pool_size_percent, bool)
+{
+  // The HIP stream-ordered pool is always on; record nothing, validate arguments.
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(initial_pool_size_percent >= 0 && max_pool_size_percent <= 100 &&
+                   initial_pool_size_percent <= max_pool_size_percent,
+                 "invalid pool percentages");
+  });
+}
+
+cuvsError_t cuvsRMMMemoryResourceReset() { return CUVS_SUCCESS; }
+
+cuvsError_t cuvsRMMHostAlloc(void** ptr, size_t bytes)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(ptr != nullptr, "ptr is null");
+    HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+  });
+}
+
+cuvsError_t cuvsRMMHostFree(void* ptr, size_t)
+{
+  return (cuvsError_t)translate_exceptions([=] { HIP_TRY(hipHostFree(ptr)); });
+}
+
+cuvsError_t cuvsVersionGet(uint16_t* major, uint16_t* minor, uint16_t* patch)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(major && minor && patch, "null output");
+    *major = 26; *minor = 8; *patch = 0;  // reference VERSION 26.08.00
+  });
+}
+
+cuvsError_t cuvsMatrixCopy(cuvsResources_t res, DLManagedTensor* src_m, DLManagedTensor* dst_m)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& r   = *as_res(res);
+    auto& src = src_m->dl_tensor;
+    auto& dst = dst_m->dl_tensor;
+    CUVS_EXPECTS(src.ndim == 2 && dst.ndim == 2, "cuvsMatrixCopy: tensors must be 2-D");
+    CUVS_EXPECTS(src.shape[0] == dst.shape[0] && src.shape[1] == dst.shape[1],
+                 "cuvsMatrixCopy: shape mismatch");
+    CUVS_EXPECTS(src.dtype.code == dst.dtype.code && src.dtype.bits == dst.dtype.bits,
+                 "cuvsMatrixCopy: dtype mismatch");
+    size_t esz     = (src.dtype.bits + 7) / 8;
+    int64_t rows   = src.shape[0], cols = src.shape[1];
+    int64_t s_ld   = src.strides ? src.strides[0] : cols;
+    int64_t d_ld   = dst.strides ? dst.strides[0] : cols;
+    CUVS_EXPECTS((!src.strides || src.strides[1] == 1) && (!dst.strides || dst.strides[1] == 1),
+                 "cuvsMatrixCopy: inner stride must be 1");
+    HIP_TRY(hipMemcpy2DAsync(dl_data(dst), d_ld * esz, dl_data(src), s_ld * esz, cols * esz, rows,
+                             hipMemcpyDefault, r.stream));
+  });
+}
+
+cuvsError_t cuvsMatrixSliceRows(cuvsResources_t res, DLManagedTensor* src_m, int64_t start, int64_t end,
+                                DLManagedTensor* dst)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    (void)as_res(res);
+    auto& src = src_m->dl_tensor;
+    CUVS_EXPECTS(src.ndim == 2, "cuvsMatrixSliceRows: tensor must be 2-D");
+    CUVS_EXPECTS(start >= 0 && end >= start && end <= src.shape[0], "cuvsMatrixSliceRows: bad range");
+    int64_t ld  = src.strides ? src.strides[0] : src.shape[1];
+    size_t esz  = (src.dtype.bits + 7) / 8;
+    dst->dl_tensor            = src;
+    dst->dl_tensor.data       = static_cast<char*>(dl_data(src)) + start * ld * esz;
+    dst->dl_tensor.byte_offset = 0;
+    dst->dl_tensor.shape      = new int64_t[2]{end - start, src.shape[1]};
+    dst->dl_tensor.strides    = new int64_t[2]{ld, 1};
+    dst->manager_ctx          = nullptr;
+    dst->deleter              = [](DLManagedTensor* self) {
+      delete[] self->dl_tensor.shape;
+      delete[] self->dl_tensor.strides;
+    };
+  });
+}
+
+}  // extern "C"

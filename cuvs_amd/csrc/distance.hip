@@ -1,0 +1,358 @@
+// Distance "GEMMs" of the hot path on the fp32 matrix cores (v_mfma_f32_16x16x4_f32):
+//   * pairwise_distance : Q[m,d] x X[n,d] -> D[m,n] with the L2-expanded / IP / cosine epilogue
+//     (reference: cuBLAS/CUTLASS GEMM + map_offset epilogue, knn_brute_force.cuh:183-232,
+//      distance_ops/l2_exp.cuh:36-50; IVF coarse search ivf_pq_search.cuh:143-157, ivf_flat_search.cuh:148-162)
+//   * fused_l2_argmin   : same main loop, running argmin epilogue (reference: fusedDistanceNNMinReduce,
+//     cluster/detail/minClusterDistanceCompute.cu:63-78; predict_core kmeans_balanced.cuh:76)
+//   * row_norms         : canonical squared norms
+// Tile: 128x128x16 per 256-thread workgroup, 2x2 waves, each wave 4x4 MFMA tiles (64 accumulator VGPRs),
+// operands staged k-major in LDS with an XOR swizzle (conflict-free ds_write_b32 and ds_read_b32),
+// global->register prefetch of the next k-tile overlapped with the MFMAs of the current one.
+// fp32 MFMA is a k-ordered fma chain, so every dot product is reproducible bit for bit (oracle: canon_dot).
+#include "ops.hpp"
+#include "device_utils.hpp"
+
+#include <cfloat>
+
+namespace cuvs_amd {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BM  = 128;
+constexpr int BN  = 128;
+constexpr int BK  = 16;
+constexpr int LDT = 144;  // k-major row pitch: 16*k lands lanes 16-31 on banks 16-31
+
+// ------------------------------------------------------------------ row norms
+template <typename T>
+__global__ __launch_bounds__(256) void row_norms_kernel(const T* __restrict__ x, int64_t n, int64_t dim,
+                                                        int64_t ld, float* __restrict__ out, bool sqrt_out)
+{
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  int lane     = lane_id();
+  const T* r   = x + row * ld;
+  float acc    = 0.f;
+  for (int64_t j = lane; j < dim; j += kWave) {
+    float v = to_float(r[j]);
+    acc     = __fmaf_rn(v, v, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
+  if (lane == 0) out[row] = sqrt_out ? sqrtf(acc) : acc;
+}
+
+// ------------------------------------------------------------------ operand staging
+// 4 consecutive elements of a row starting at column k0 (zero beyond dim / beyond the matrix)
+template <typename T, bool VEC>
+__device__ inline void load4(const T* __restrict__ base, int64_t row, int64_t nrows, int64_t ld, int64_t k0,
+                             int64_t dim, float (&v)[4])
+{
+  v[0] = v[1] = v[2] = v[3] = 0.f;
+  if (row >= nrows) return;
+  const T* p = base + row * ld + k0;
+  if constexpr (VEC) {
+    if (k0 + 3 < dim) {
+      if constexpr (sizeof(T) == 4) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else if constexpr (sizeof(T) == 2) {
+        uint2 t = *reinterpret_cast<const uint2*>(p);
+        const __half* h = reinterpret_cast<const __half*>(&t);
+        v[0] = __half2float(h[0]); v[1] = __half2float(h[1]);
+        v[2] = __half2float(h[2]); v[3] = __half2float(h[3]);
+      } else {
+        uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+        const T* b = reinterpret_cast<const T*>(&t);
+        v[0] = (float)b[0]; v[1] = (float)b[1]; v[2] = (float)b[2]; v[3] = (float)b[3];
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (k0 + e < dim) v[e] = to_float(p[e]);
+}
+
+__device__ inline void stage_store(float* __restrict__ S, int r, int c, const float (&v)[4])
+{
+  int col = r ^ (c << 3);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) S[(4 * c + e) * LDT + col] = v[e];
+}
+
+struct epilogue_args {
+  const float* qn;
+  const float* xn;
+  int metric;
+  float clamp_eps;
+};
+
+__device__ inline float finish_distance(float dot, float qn, float xn, int metric, float clamp_eps)
+{
+  if (metric == M_InnerProduct) return dot;
+  if (metric == M_CosineExpanded) return 1.0f - dot / (qn * xn);
+  float val = __fmaf_rn(-2.0f, dot, qn + xn);
+  // reference self-neighbour clamp (l2_exp.cuh:36-50,113-125) + non-negativity of the fused path
+  if (val * val < clamp_eps && qn == xn) val = 0.f;
+  val = val > 0.f ? val : 0.f;
+  if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) val = sqrtf(val);
+  return val;
+}
+
+// MODE 0: write D tile.  MODE 1: running argmin over all column tiles (grid.x = 1).
+template <typename TQ, typename TX, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q, int64_t m, int64_t ldq,
+                                                        const TX* __restrict__ x, int64_t n, int64_t ldx,
+                                                        int64_t dim, epilogue_args ep,
+                                                        float* __restrict__ out, int64_t ldo,
+                                                        uint32_t* __restrict__ labels,
+                                                        float* __restrict__ min_val)
+{
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm   = wave >> 1;
+  const int wn   = wave & 1;
+  const int l15  = lane & 15;
+  const int lg   = lane >> 4;
+
+  const int64_t row0 = (int64_t)blockIdx.y * BM;
+  const int nkt      = (int)((dim + BK - 1) / BK);
+
+  // staging assignment: two (row, chunk) pairs per thread and per operand
+  const int sr0 = tid >> 2, sc0 = tid & 3;          // rows 0..63
+  const int sr1 = (tid + 256) >> 2, sc1 = tid & 3;  // rows 64..127
+
+  float best_v[16];
+  uint32_t best_i[16];
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { best_v[t] = FLT_MAX; best_i[t] = 0xffffffffu; }
+  }
+
+  const int64_t n_col_tiles = (MODE == 1) ? (n + BN - 1) / BN : 1;
+  for (int64_t ct = 0; ct < n_col_tiles; ++ct) {
+    const int64_t col0 = (MODE == 1) ? ct * BN : (int64_t)blockIdx.x * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float ra0[4], ra1[4], rb0[4], rb1[4];
+    load4<TQ, VEC>(q, row0 + sr0, m, ldq, sc0 * 4, dim, ra0);
+    load4<TQ, VEC>(q, row0 + sr1, m, ldq, sc1 * 4, dim, ra1);
+    load4<TX, VEC>(x, col0 + sr0, n, ldx, sc0 * 4, dim, rb0);
+    load4<TX, VEC>(x, col0 + sr1, n, ldx, sc1 * 4, dim, rb1);
+    __syncthreads();  // previous column tile done with the LDS buffers
+    stage_store(As[0], sr0, sc0, ra0);
+    stage_store(As[0], sr1, sc1, ra1);
+    stage_store(Bs[0], sr0, sc0, rb0);
+    stage_store(Bs[0], sr1, sc1, rb1);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nkt) {
+        int64_t k0 = (int64_t)(kt + 1) * BK;
+        load4<TQ, VEC>(q, row0 + sr0, m, ldq, k0 + sc0 * 4, dim, ra0);
+        load4<TQ, VEC>(q, row0 + sr1, m, ldq, k0 + sc1 * 4, dim, ra1);
+        load4<TX, VEC>(x, col0 + sr0, n, ldx, k0 + sc0 * 4, dim, rb0);
+        load4<TX, VEC>(x, col0 + sr1, n, ldx, k0 + sc1 * 4, dim, rb1);
+      }
+      const float* A = As[buf];
+      const float* B = Bs[buf];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k   = 4 * c + lg;
+        const int swz = c << 3;
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = A[k * LDT + ((wm * 64 + i * 16 + l15) ^ swz)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = B[k * LDT + ((wn * 64 + j * 16 + l15) ^ swz)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nkt) {
+        stage_store(As[buf ^ 1], sr0, sc0, ra0);
+        stage_store(As[buf ^ 1], sr1, sc1, ra1);
+        stage_store(Bs[buf ^ 1], sr0, sc0, rb0);
+        stage_store(Bs[buf ^ 1], sr1, sc1, rb1);
+      }
+      __syncthreads();
+    }
+
+    // ---- epilogue: C layout col = lane&15, row = (lane>>4)*4 + e
+    if constexpr (MODE == 0) {
+      float xnv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t col = col0 + wn * 64 + j * 16 + l15;
+        xnv[j]      = (ep.xn != nullptr && col < n) ? ep.xn[col] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
+          if (row >= m) continue;
+          float qnv = ep.qn != nullptr ? ep.qn[row] : 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            int64_t col = col0 + wn * 64 + j * 16 + l15;
+            if (col < n) out[row * ldo + col] = finish_distance(acc[i][j][e], qnv, xnv[j], ep.metric, ep.clamp_eps);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t col = col0 + wn * 64 + j * 16 + l15;
+        if (col >= n) continue;
+        float xnv = ep.xn[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = __fmaf_rn(-2.0f, acc[i][j][e], xnv);
+            int t   = i * 4 + e;
+            // columns are visited in increasing order per lane: strict < keeps the smallest index
+            if (v < best_v[t]) { best_v[t] = v; best_i[t] = (uint32_t)col; }
+          }
+      }
+    }
+  }
+
+  if constexpr (MODE == 1) {
+    // reduce over the 16 lanes that share a row, then over the two column waves
+    __syncthreads();
+    float* red_v    = As[0];                                   // [2][128]
+    uint32_t* red_i = reinterpret_cast<uint32_t*>(Bs[0]);      // [2][128]
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      float v    = best_v[t];
+      uint32_t i = best_i[t];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        float ov    = __shfl_xor(v, off, kWave);
+        uint32_t oi = __shfl_xor(i, off, kWave);
+        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+      }
+      if (l15 == 0) {
+        int r                 = wm * 64 + (t >> 2) * 16 + lg * 4 + (t & 3);
+        red_v[wn * BM + r]    = v;
+        red_i[wn * BM + r]    = i;
+      }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      int64_t row = row0 + tid;
+      if (row < m) {
+        float v0 = red_v[tid], v1 = red_v[BM + tid];
+        uint32_t i0 = red_i[tid], i1 = red_i[BM + tid];
+        bool take1 = (v1 < v0) || (v1 == v0 && i1 < i0);
+        labels[row] = take1 ? i1 : i0;
+        if (min_val != nullptr) min_val[row] = take1 ? v1 : v0;
+      }
+    }
+  }
+}
+
+template <typename T>
+bool vec_ok(const T* p, int64_t ld, int64_t dim)
+{
+  size_t bytes = sizeof(T) * 4;
+  return (dim % 4 == 0) && (ld % 4 == 0) && (reinterpret_cast<uintptr_t>(p) % bytes == 0);
+}
+
+}  // namespace
+
+template <typename T>
+void row_norms(resources& res, const T* x, int64_t n, int64_t dim, int64_t ld, float* out, bool sqrt_out)
+{
+  if (n == 0) return;
+  int64_t blocks = (n + 3) / 4;
+  CUVS_EXPECTS(blocks < (int64_t(1) << 31), "row_norms: too many rows");
+  hipLaunchKernelGGL((row_norms_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, res.stream, x, n, dim, ld,
+                     out, sqrt_out);
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename TQ, typename TX>
+void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n,
+                       int64_t ldx, int64_t dim, const float* qn, const float* xn, int metric,
+                       float* out, int64_t ldo)
+{
+  if (m == 0 || n == 0) return;
+  CUVS_EXPECTS(metric_supported(metric), "pairwise_distance: unsupported metric %d", metric);
+  if (metric != M_InnerProduct) CUVS_EXPECTS(qn && xn, "pairwise_distance: norms required");
+  epilogue_args ep{qn, xn, metric, (sizeof(TX) == 2 ? 1e-3f : 1e-6f)};
+  dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((m + BM - 1) / BM));
+  CUVS_EXPECTS((m + BM - 1) / BM <= 65535, "pairwise_distance: too many query rows per call");
+  bool vec = vec_ok(q, ldq, dim) && vec_ok(x, ldx, dim);
+  if (vec) {
+    hipLaunchKernelGGL((dist_mfma_kernel<TQ, TX, 0, true>), grid, dim3(256), 0, res.stream, q, m, ldq, x, n,
+                       ldx, dim, ep, out, ldo, (uint32_t*)nullptr, (float*)nullptr);
+  } else {
+    hipLaunchKernelGGL((dist_mfma_kernel<TQ, TX, 0, false>), grid, dim3(256), 0, res.stream, q, m, ldq, x, n,
+                       ldx, dim, ep, out, ldo, (uint32_t*)nullptr, (float*)nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename TQ>
+void fused_l2_argmin(resources& res, const TQ* q, int64_t m, int64_t ldq, const float* centers,
+                     int64_t n, int64_t dim, const float* center_norms, uint32_t* labels,
+                     float* min_val)
+{
+  if (m == 0) return;
+  CUVS_EXPECTS(n > 0 && center_norms != nullptr, "fused_l2_argmin: need centers and norms");
+  epilogue_args ep{nullptr, center_norms, M_L2Expanded, 0.f};
+  // grid.y is limited to 65535 blocks: walk the rows in slabs
+  const int64_t max_rows = int64_t(65535) * BM;
+  bool vec = vec_ok(q, ldq, dim) && vec_ok(centers, dim, dim);
+  for (int64_t r0 = 0; r0 < m; r0 += max_rows) {
+    int64_t mr = std::min(max_rows, m - r0);
+    dim3 grid(1, (unsigned)((mr + BM - 1) / BM));
+    const TQ* qq   = q + r0 * ldq;
+    uint32_t* lab  = labels + r0;
+    float* mv      = min_val ? min_val + r0 : nullptr;
+    if (vec) {
+      hipLaunchKernelGGL((dist_mfma_kernel<TQ, float, 1, true>), grid, dim3(256), 0, res.stream, qq, mr, ldq,
+                         centers, n, dim, dim, ep, (float*)nullptr, (int64_t)0, lab, mv);
+    } else {
+      hipLaunchKernelGGL((dist_mfma_kernel<TQ, float, 1, false>), grid, dim3(256), 0, res.stream, qq, mr, ldq,
+                         centers, n, dim, dim, ep, (float*)nullptr, (int64_t)0, lab, mv);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+#define INST_N(T) template void row_norms<T>(resources&, const T*, int64_t, int64_t, int64_t, float*, bool);
+INST_N(float) INST_N(__half) INST_N(int8_t) INST_N(uint8_t)
+#undef INST_N
+
+#define INST_P(TQ, TX)                                                                                    \
+  template void pairwise_distance<TQ, TX>(resources&, const TQ*, int64_t, int64_t, const TX*, int64_t,    \
+                                          int64_t, int64_t, const float*, const float*, int, float*, int64_t);
+INST_P(float, float) INST_P(__half, __half) INST_P(__half, float) INST_P(int8_t, float) INST_P(uint8_t, float)
+#undef INST_P
+
+#define INST_A(TQ)                                                                                        \
+  template void fused_l2_argmin<TQ>(resources&, const TQ*, int64_t, int64_t, const float*, int64_t,       \
+                                    int64_t, const float*, uint32_t*, float*);
+INST_A(float) INST_A(__half) INST_A(int8_t) INST_A(uint8_t)
+#undef INST_A
+
+}  // namespace cuvs_amd

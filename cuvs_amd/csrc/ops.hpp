@@ -1,0 +1,58 @@
+// Internal (C++) interfaces between the hot-path translation units. Everything is asynchronous
+// on res.stream; pointers are device pointers unless stated otherwise.
+#pragma once
+#include "common.hpp"
+
+namespace cuvs_amd {
+
+// ---------------------------------------------------------------- select_k.hip
+// Batched exact top-k, one row per query (reference call sites: knn_brute_force.cuh:267,309;
+// ivf_flat_search.cuh:180,283; ivf_pq_search.cuh:160,620 -> raft::matrix::select_k).
+// in      [rows, len] with row pitch `in_ld` floats
+// in_idx  optional [rows, len] (same pitch); nullptr => index = column + idx_offset
+// out_val [rows, k], out_idx [rows, k]; sorted ascending by (value, index) for select_min,
+// descending by value (ascending index among equals) for !select_min.
+// Tie rule at the k-th boundary: the earliest columns win. Missing entries (len < k) are padded
+// with +/-FLT_MAX and index -1.
+template <typename InIdxT, typename OutIdxT>
+void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t rows, int64_t len,
+              int64_t in_ld, int k, float* out_val, OutIdxT* out_idx, bool select_min,
+              int64_t idx_offset = 0, int64_t out_ld = -1, int64_t out_col_offset = 0);
+
+// ---------------------------------------------------------------- distance.hip
+// Canonical squared row norms: 64 strided fmaf partials + fixed butterfly (oracle/oracle.c
+// `canon_sqnorm`). sqrt_out => writes sqrt of that (cosine).
+template <typename T>
+void row_norms(resources& res, const T* x, int64_t n, int64_t dim, int64_t ld, float* out, bool sqrt_out);
+
+// D[i, j] = epilogue(dot(Q_i, X_j)) for i < m, j < n; out pitch ldo.
+//   metric L2*: max(0, fmaf(-2, dot, qn_i + xn_j)) with the reference's self-neighbour clamp
+//               (distance_ops/l2_exp.cuh:36-50,113-125); sqrt variants take sqrt.
+//   metric IP : dot ; metric cosine: 1 - dot / (qn_i * xn_j) (norms are sqrt norms).
+// dot is one k-ordered fp32 fma chain (MFMA 16x16x4 f32), so results are reproducible bit for bit.
+template <typename TQ, typename TX>
+void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n,
+                       int64_t ldx, int64_t dim, const float* qn, const float* xn, int metric,
+                       float* out, int64_t ldo);
+
+// labels[i] = argmin_j ( xn_j - 2 dot(Q_i, X_j) ) (ties -> smallest j); optional min value out
+// (= squared L2 distance minus |q|^2). The k-means E-step and IVF list assignment.
+template <typename TQ>
+void fused_l2_argmin(resources& res, const TQ* q, int64_t m, int64_t ldq, const float* centers,
+                     int64_t n, int64_t dim, const float* center_norms, uint32_t* labels,
+                     float* min_val);
+
+// ---------------------------------------------------------------- kmeans_balanced.hip
+struct kmeans_params {
+  int n_iters        = 20;
+  bool hierarchical  = true;
+};
+// Balanced k-means fit on float rows (reference: cluster/detail/kmeans_balanced.cuh:986-1148).
+void kmeans_balanced_fit(resources& res, const float* x, int64_t n, int64_t dim, int n_clusters,
+                         const kmeans_params& p, float* centers /*[n_clusters, dim]*/);
+// labels for arbitrary element type
+template <typename T>
+void kmeans_predict(resources& res, const T* x, int64_t n, int64_t dim, const float* centers,
+                    int n_clusters, uint32_t* labels);
+
+}  // namespace cuvs_amd

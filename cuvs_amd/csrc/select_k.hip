@@ -1,0 +1,229 @@
+// Batched exact top-k for wave64 — replaces raft::matrix::select_k, which the reference forwards to
+// (cpp/src/selection/select_k.cuh:13-57; RAFT sources are not vendored). One 256-thread workgroup per
+// row: three LDS-histogram radix passes (11/11/10 bits of an order-preserving key) find the exact k-th
+// key, one collect pass gathers the winners, a bitonic sort in LDS orders them by (value, index).
+// HBM/L2-bound: the row is streamed 4 times; everything else lives in LDS.
+#include "ops.hpp"
+#include "device_utils.hpp"
+
+#include <cfloat>
+
+namespace cuvs_amd {
+
+namespace {
+
+constexpr int kSelThreads = 256;
+constexpr int kBins       = 2048;
+
+template <typename InIdxT, bool HAS_IDX>
+__device__ inline int64_t src_index(const InIdxT* in_idx_row, int64_t i, int64_t idx_offset)
+{
+  if constexpr (HAS_IDX) {
+    return (int64_t)in_idx_row[i];
+  } else {
+    return i + idx_offset;
+  }
+}
+
+template <typename InIdxT, typename OutIdxT, bool HAS_IDX>
+__global__ __launch_bounds__(kSelThreads) void select_k_radix_kernel(const float* __restrict__ in,
+                                                                     const InIdxT* __restrict__ in_idx,
+                                                                     int64_t len,
+                                                                     int64_t in_ld,
+                                                                     int k,
+                                                                     int kp2,
+                                                                     float* __restrict__ out_val,
+                                                                     OutIdxT* __restrict__ out_idx,
+                                                                     bool select_min,
+                                                                     int64_t idx_offset,
+                                                                     int64_t out_ld,
+                                                                     int64_t out_col_offset)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int* hist      = reinterpret_cast<int*>(smem_raw);            // kBins
+  int* scan      = hist + kBins;                                 // 32
+  int* ctrl      = scan + 32;                                    // 8
+  int64_t* s_idx = reinterpret_cast<int64_t*>(ctrl + 8);         // kp2 (8-byte aligned: 8192+160)
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(s_idx + kp2);    // kp2
+
+  const int tid       = threadIdx.x;
+  const int64_t row   = blockIdx.x;
+  const float* r      = in + row * in_ld;
+  const InIdxT* ridx  = HAS_IDX ? in_idx + row * in_ld : nullptr;
+  const uint32_t flip = select_min ? 0u : 0xffffffffu;
+
+  const int k_eff = (int)((int64_t)k < len ? (int64_t)k : len);
+
+  uint32_t prefix = 0, mask = 0;
+  int need = k_eff, cnt_eq = 0;
+
+  if (k_eff > 0 && (int64_t)k_eff < len) {
+    const int shifts[3] = {21, 10, 0};
+    const int nbits[3]  = {11, 11, 10};
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+      const int shift   = shifts[p];
+      const uint32_t dm = (1u << nbits[p]) - 1u;
+      for (int b = tid; b < kBins; b += kSelThreads) hist[b] = 0;
+      __syncthreads();
+      for (int64_t i = tid; i < len; i += kSelThreads) {
+        uint32_t key = float_to_key(r[i]) ^ flip;
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & dm], 1);
+      }
+      __syncthreads();
+      int local[8];
+      int s = 0;
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        local[b] = hist[tid * 8 + b];
+        s += local[b];
+      }
+      int total;
+      int excl = block_exclusive_scan(s, scan, &total);
+      if (need > excl && need <= excl + s) {
+        int c = excl;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          if (need > c && need <= c + local[b]) {
+            ctrl[0] = tid * 8 + b;
+            ctrl[1] = need - c;
+            ctrl[2] = local[b];
+          }
+          c += local[b];
+        }
+      }
+      __syncthreads();
+      int bucket = ctrl[0];
+      need       = ctrl[1];
+      cnt_eq     = ctrl[2];
+      prefix |= ((uint32_t)bucket) << shift;
+      mask |= dm << shift;
+      __syncthreads();
+    }
+  } else {
+    // take everything: kth key = max, all elements are "less or equal"
+    prefix = 0xffffffffu;
+    need   = 0;
+    cnt_eq = 0;
+  }
+
+  const bool take_all  = !(k_eff > 0 && (int64_t)k_eff < len);
+  const uint32_t kth   = prefix;
+  const int n_less     = take_all ? k_eff : (k_eff - need);
+
+  if (tid == 0) { ctrl[3] = 0; ctrl[4] = 0; }
+  for (int j = tid; j < kp2; j += kSelThreads) {
+    s_key[j] = 0xffffffffu;
+    s_idx[j] = INT64_MAX;
+  }
+  __syncthreads();
+
+  if (take_all) {
+    for (int64_t i = tid; i < len; i += kSelThreads) {
+      s_key[i] = float_to_key(r[i]) ^ flip;
+      s_idx[i] = src_index<InIdxT, HAS_IDX>(ridx, i, idx_offset);
+    }
+  } else if (cnt_eq == need) {
+    for (int64_t i = tid; i < len; i += kSelThreads) {
+      uint32_t key = float_to_key(r[i]) ^ flip;
+      if (key < kth) {
+        int pos    = atomicAdd(&ctrl[3], 1);
+        s_key[pos] = key;
+        s_idx[pos] = src_index<InIdxT, HAS_IDX>(ridx, i, idx_offset);
+      } else if (key == kth) {
+        int pos    = n_less + atomicAdd(&ctrl[4], 1);
+        s_key[pos] = key;
+        s_idx[pos] = src_index<InIdxT, HAS_IDX>(ridx, i, idx_offset);
+      }
+    }
+  } else {
+    // more elements equal to the k-th key than we may take: earliest columns win
+    for (int64_t i = tid; i < len; i += kSelThreads) {
+      uint32_t key = float_to_key(r[i]) ^ flip;
+      if (key < kth) {
+        int pos    = atomicAdd(&ctrl[3], 1);
+        s_key[pos] = key;
+        s_idx[pos] = src_index<InIdxT, HAS_IDX>(ridx, i, idx_offset);
+      }
+    }
+    int base = 0;
+    for (int64_t start = 0; start < len && base < need; start += kSelThreads) {
+      int64_t i = start + tid;
+      int flag  = 0;
+      if (i < len) flag = ((float_to_key(r[i]) ^ flip) == kth) ? 1 : 0;
+      int total;
+      int excl = block_exclusive_scan(flag, scan, &total);
+      if (flag && base + excl < need) {
+        int pos    = n_less + base + excl;
+        s_key[pos] = kth;
+        s_idx[pos] = src_index<InIdxT, HAS_IDX>(ridx, i, idx_offset);
+      }
+      base += total;
+    }
+  }
+  __syncthreads();
+
+  block_bitonic_sort<int64_t>(s_key, s_idx, kp2);
+
+  float* ov   = out_val + row * out_ld + out_col_offset;
+  OutIdxT* oi = out_idx + row * out_ld + out_col_offset;
+  for (int j = tid; j < k; j += kSelThreads) {
+    if (j < k_eff) {
+      ov[j] = key_to_float(s_key[j] ^ flip);
+      oi[j] = (OutIdxT)s_idx[j];
+    } else {
+      ov[j] = select_min ? FLT_MAX : -FLT_MAX;
+      oi[j] = (OutIdxT)(-1);
+    }
+  }
+}
+
+}  // namespace
+
+template <typename InIdxT, typename OutIdxT>
+void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t rows, int64_t len,
+              int64_t in_ld, int k, float* out_val, OutIdxT* out_idx, bool select_min,
+              int64_t idx_offset, int64_t out_ld, int64_t out_col_offset)
+{
+  if (rows == 0 || k == 0) return;
+  CUVS_EXPECTS(k > 0 && k <= 2048, "select_k: k must be in [1, 2048], got %d", k);
+  CUVS_EXPECTS(rows < (int64_t(1) << 31), "select_k: too many rows");
+  if (out_ld < 0) out_ld = k;
+  int kp2     = next_pow2(k);
+  size_t smem = (kBins + 32 + 8) * sizeof(int) + (size_t)kp2 * (sizeof(int64_t) + sizeof(uint32_t));
+  dim3 grid((unsigned)rows), block(kSelThreads);
+  if (in_idx != nullptr) {
+    hipLaunchKernelGGL((select_k_radix_kernel<InIdxT, OutIdxT, true>), grid, block, smem, res.stream, in,
+                       in_idx, len, in_ld, k, kp2, out_val, out_idx, select_min, idx_offset, out_ld,
+                       out_col_offset);
+  } else {
+    hipLaunchKernelGGL((select_k_radix_kernel<InIdxT, OutIdxT, false>), grid, block, smem, res.stream, in,
+                       in_idx, len, in_ld, k, kp2, out_val, out_idx, select_min, idx_offset, out_ld,
+                       out_col_offset);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+#define INST(I, O)                                                                                   \
+  template void select_k<I, O>(resources&, const float*, const I*, int64_t, int64_t, int64_t, int,   \
+                               float*, O*, bool, int64_t, int64_t, int64_t);
+INST(uint32_t, uint32_t)
+INST(uint32_t, int64_t)
+INST(int64_t, int64_t)
+#undef INST
+
+}  // namespace cuvs_amd
+
+// Test hook (not part of the reference ABI): exact top-k of a device matrix, used by tests/ to pin the
+// kernel against oracle/oracle.c `oracle_select_k`.
+extern "C" __attribute__((visibility("default"))) int cuvsAmdSelectK(uintptr_t res, const float* in,
+                                                                      const int64_t* in_idx, int64_t rows,
+                                                                      int64_t len, int k, float* out_val,
+                                                                      int64_t* out_idx, int select_min)
+{
+  using namespace cuvs_amd;
+  return translate_exceptions([=] {
+    select_k<int64_t, int64_t>(*as_res(res), in, in_idx, rows, len, len, k, out_val, out_idx,
+                               select_min != 0);
+  });
+}

@@ -1,0 +1,97 @@
+"""numpy front-end of oracle/liboracle.so — the CPU restatement of the reference's hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under cuvs_amd/ imports this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+METRICS = {"sqeuclidean": 0, "euclidean": 1, "l2": 1, "cosine": 2, "inner_product": 6}
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} missing: run `make oracle/liboracle.so`")
+        _LIB = C.CDLL(path)
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _metric(m):
+    return METRICS[m] if isinstance(m, str) else int(m)
+
+
+def num_threads():
+    return lib().oracle_num_threads()
+
+
+def row_norms(x, sqrt=False):
+    x = _f32(x)
+    out = np.empty(x.shape[0], np.float32)
+    lib().oracle_row_norms(_p(x), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]), _p(out), C.c_int(int(sqrt)))
+    return out
+
+
+def pairwise(q, x, metric="sqeuclidean", clamp_eps=1e-6):
+    q, x = _f32(q), _f32(x)
+    out = np.empty((q.shape[0], x.shape[0]), np.float32)
+    lib().oracle_pairwise(_p(q), C.c_int64(q.shape[0]), _p(x), C.c_int64(x.shape[0]), C.c_int64(q.shape[1]),
+                          C.c_int(_metric(metric)), C.c_float(clamp_eps), _p(out))
+    return out
+
+
+def select_k(vals, k, select_min=True, in_idx=None, idx_offset=0):
+    vals = _f32(vals)
+    rows, ln = vals.shape
+    ov = np.empty((rows, k), np.float32)
+    oi = np.empty((rows, k), np.int64)
+    ii = None if in_idx is None else np.ascontiguousarray(in_idx, dtype=np.int64)
+    lib().oracle_select_k(_p(vals), _p(ii) if ii is not None else None, C.c_int64(rows), C.c_int64(ln), C.c_int(k),
+                          C.c_int(int(select_min)), C.c_int64(idx_offset), _p(ov), _p(oi))
+    return ov, oi
+
+
+def brute_force_knn(q, x, k, metric="sqeuclidean", clamp_eps=1e-6, keep_bits=None, bitmap=False):
+    """Bit-for-bit twin of cuvsBruteForceSearch. Returns (distances, indices)."""
+    q, x = _f32(q), _f32(x)
+    oi = np.empty((q.shape[0], k), np.int64)
+    od = np.empty((q.shape[0], k), np.float32)
+    kb = None if keep_bits is None else np.ascontiguousarray(keep_bits, dtype=np.uint32)
+    lib().oracle_brute_force_knn(_p(q), C.c_int64(q.shape[0]), _p(x), C.c_int64(x.shape[0]), C.c_int64(q.shape[1]),
+                                 C.c_int(k), C.c_int(_metric(metric)), C.c_float(clamp_eps),
+                                 _p(kb) if kb is not None else None, C.c_int(int(bitmap)), _p(oi), _p(od))
+    return od, oi
+
+
+def exact_knn(q, x, k, metric="sqeuclidean"):
+    """The reference's CPU path (refine_host with every row as candidate). Returns (distances, indices)."""
+    q, x = _f32(q), _f32(x)
+    oi = np.empty((q.shape[0], k), np.int64)
+    od = np.empty((q.shape[0], k), np.float32)
+    lib().oracle_exact_knn(_p(q), C.c_int64(q.shape[0]), _p(x), C.c_int64(x.shape[0]), C.c_int64(q.shape[1]),
+                           C.c_int(k), C.c_int(_metric(metric)), _p(oi), _p(od))
+    return od, oi
+
+
+def recall(found, truth):
+    """Fraction of true neighbours found (reference: python/cuvs/cuvs/tests/ann_utils.py:24-30)."""
+    found, truth = np.asarray(found), np.asarray(truth)
+    hits = 0
+    for f, t in zip(found, truth):
+        hits += len(np.intersect1d(f, t))
+    return hits / truth.size

@@ -1,0 +1,42 @@
+"""Known-answer vectors held by the reference's own tests (copied as DATA, with their location).
+
+These pin the oracle (tests/test_oracle.py) and the HIP path (tests/test_*_gpu.py).
+"""
+import numpy as np
+
+# c/tests/neighbors/ann_cagra_c.cu:31-50 — 4x2 dataset, 4 queries, k=1, L2Expanded (squared distances).
+CAGRA_C_DATASET = np.array(
+    [[0.74021935, 0.9209938], [0.03902049, 0.9689629], [0.92514056, 0.4463501], [0.6673192, 0.10993068]],
+    dtype=np.float32,
+)
+CAGRA_C_QUERIES = np.array(
+    [[0.48216683, 0.0428398], [0.5084142, 0.6545497], [0.51260436, 0.2643005], [0.05198065, 0.5789965]],
+    dtype=np.float32,
+)
+CAGRA_C_NEIGHBORS = np.array([3, 0, 3, 1], dtype=np.int64)
+CAGRA_C_DISTANCES = np.array([0.03878258, 0.12472608, 0.04776672, 0.15224178], dtype=np.float32)
+# bitset 0b1001: rows 1 and 2 removed
+CAGRA_C_FILTER_WORDS = np.array([0b1001], dtype=np.uint32)
+CAGRA_C_NEIGHBORS_FILTERED = np.array([3, 0, 3, 0], dtype=np.int64)
+CAGRA_C_DISTANCES_FILTERED = np.array([0.03878258, 0.12472608, 0.04776672, 0.59063464], dtype=np.float32)
+CAGRA_C_TOL = 1e-3  # the reference compares with eps 0.001
+
+# cpp/tests/neighbors/brute_force.cu:169-185 — 10 labelled 2-D points; the k=2 neighbours of every
+# point (searching the set against itself) carry the point's own label.
+BF_KAT_POINTS = np.array(
+    [
+        [2.7810836, 2.550537003],
+        [1.465489372, 2.362125076],
+        [3.396561688, 4.400293529],
+        [1.38807019, 1.850220317],
+        [3.06407232, 3.005305973],
+        [7.627531214, 2.759262235],
+        [5.332441248, 2.088626775],
+        [6.922596716, 1.77106367],
+        [8.675418651, -0.242068655],
+        [7.673756466, 3.508563011],
+    ],
+    dtype=np.float32,
+)
+BF_KAT_K = 2
+BF_KAT_LABELS = np.array([0, 0, 0, 0, 0, 1, 1, 1, 1, 1], dtype=np.int32)

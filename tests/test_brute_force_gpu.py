@@ -1,0 +1,133 @@
+"""GPU: cuvsBruteForce* through the C ABI vs the oracle — bit-exact ids and distances.
+
+Shapes follow the reference's brute-force tests (cpp/tests/neighbors/ann_brute_force.cuh:167-197,
+python/cuvs/cuvs/tests/test_brute_force.py) plus edge cases (odd dims, k > 64, tiling, filters).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.golden import reference_fixtures as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(n, d, q, seed, lo=0.1, hi=2.0):
+    # reference generator: uniform [0.1, 2.0) (ann_brute_force.cuh:142-155); stream differs, range same
+    rng = np.random.default_rng(seed)
+    x = (rng.random((n, d), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+    qq = (rng.random((q, d), dtype=np.float32) * (hi - lo) + lo).astype(np.float32)
+    return x, qq
+
+
+def _run(x, q, k, metric, prefilter=None, dtype="float32"):
+    import torch
+    from cuvs_amd.neighbors import brute_force
+
+    tx = torch.from_numpy(x).cuda()
+    tq = torch.from_numpy(q).cuda()
+    if dtype == "float16":
+        tx, tq = tx.half(), tq.half()
+    idx = brute_force.build(tx, metric=metric)
+    d, i = brute_force.search(idx, tq, k, prefilter=prefilter)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy()
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "cosine", "inner_product"])
+@pytest.mark.parametrize("n,d,q,k", [(1000, 32, 100, 10), (10000, 128, 200, 64), (777, 17, 33, 5),
+                                     (500, 1, 20, 3), (2049, 100, 129, 100), (300, 3, 7, 1)])
+def test_bit_exact_vs_oracle(metric, n, d, q, k):
+    x, qq = _gen(n, d, q, seed=n + d)
+    gd, gi = _run(x, qq, k, metric)
+    od, oi = oracle.brute_force_knn(qq, x, k, metric=metric)
+    assert (gi == oi).all(), f"index mismatch rate {(gi != oi).mean()}"
+    assert (gd == od).all(), f"distance max abs diff {np.abs(gd - od).max()}"
+
+
+def test_recall_vs_reference_cpu_path():
+    # vs the refine_host restatement (unexpanded arithmetic): ids may differ only on fp ties
+    x, qq = _gen(5000, 64, 100, seed=5)
+    gd, gi = _run(x, qq, 16, "sqeuclidean")
+    rd, ri = oracle.exact_knn(qq, x, 16)
+    assert oracle.recall(gi, ri) > 0.999
+    np.testing.assert_allclose(gd, rd, atol=1e-3, rtol=1e-3)  # the reference's own eps (ann_brute_force.cuh:97-105)
+
+
+def test_half_dataset():
+    x, qq = _gen(3000, 64, 50, seed=9)
+    xh, qh = x.astype(np.float16), qq.astype(np.float16)
+    gd, gi = _run(xh.astype(np.float32), qh.astype(np.float32), 10, "sqeuclidean", dtype="float16")
+    od, oi = oracle.brute_force_knn(qh.astype(np.float32), xh.astype(np.float32), 10, clamp_eps=1e-3)
+    assert (gi == oi).all() and (gd == od).all()
+
+
+def test_golden_vectors_and_kat():
+    gd, gi = _run(G.CAGRA_C_DATASET, G.CAGRA_C_QUERIES, 1, "sqeuclidean")
+    assert (gi[:, 0] == G.CAGRA_C_NEIGHBORS).all()
+    np.testing.assert_allclose(gd[:, 0], G.CAGRA_C_DISTANCES, atol=G.CAGRA_C_TOL)
+    _, gi = _run(G.BF_KAT_POINTS, G.BF_KAT_POINTS, G.BF_KAT_K, "sqeuclidean")
+    assert (G.BF_KAT_LABELS[gi] == G.BF_KAT_LABELS[:, None]).all()
+
+
+def test_bitset_and_bitmap_prefilter():
+    import torch
+    from cuvs_amd._lib import BITMAP, BITSET
+
+    x, qq = _gen(1000, 16, 40, seed=11)
+    rng = np.random.default_rng(1)
+    keep = rng.random(1000) < 0.3
+    words = np.packbits(keep, bitorder="little").view(np.uint32) if keep.size % 32 == 0 else None
+    if words is None:
+        pad = np.zeros((-keep.size) % 32, bool)
+        words = np.packbits(np.concatenate([keep, pad]), bitorder="little").view(np.uint32)
+    tw = torch.from_numpy(words.view(np.int32)).cuda()
+    gd, gi = _run(x, qq, 8, "sqeuclidean", prefilter=(tw, BITSET))
+    od, oi = oracle.brute_force_knn(qq, x, 8, keep_bits=words)
+    assert (gi == oi).all() and (gd == od).all()
+    assert keep[gi].all()
+    # golden filtered vector (ann_cagra_c.cu:39-44)
+    tw = torch.from_numpy(G.CAGRA_C_FILTER_WORDS.view(np.int32)).cuda()
+    gd, gi = _run(G.CAGRA_C_DATASET, G.CAGRA_C_QUERIES, 1, "sqeuclidean", prefilter=(tw, BITSET))
+    assert (gi[:, 0] == G.CAGRA_C_NEIGHBORS_FILTERED).all()
+    # bitmap: per-query keep masks
+    keep2 = rng.random((40, 1000)) < 0.5
+    flat = keep2.reshape(-1)
+    pad = np.zeros((-flat.size) % 32, bool)
+    words2 = np.packbits(np.concatenate([flat, pad]), bitorder="little").view(np.uint32)
+    tw2 = torch.from_numpy(words2.view(np.int32)).cuda()
+    gd, gi = _run(x, qq, 8, "sqeuclidean", prefilter=(tw2, BITMAP))
+    od, oi = oracle.brute_force_knn(qq, x, 8, keep_bits=words2, bitmap=True)
+    assert (gi == oi).all() and (gd == od).all()
+
+
+def test_column_tiling_and_merge(monkeypatch):
+    # shrink the workspace so the dataset is cut into many column tiles + a merge select_k
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import brute_force
+
+    monkeypatch.setenv("CUVS_AMD_WORKSPACE_MB", "1")
+    res = cuvs_amd.common.Resources()
+    x, qq = _gen(20000, 32, 300, seed=21)
+    tx, tq = torch.from_numpy(x).cuda(), torch.from_numpy(qq).cuda()
+    idx = brute_force.build(tx, resources=res)
+    d, i = brute_force.search(idx, tq, 10, resources=res)
+    res.sync()
+    od, oi = oracle.brute_force_knn(qq, x, 10)
+    assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
+
+
+def test_error_convention():
+    import torch
+    from cuvs_amd._lib import CuvsError
+    from cuvs_amd.neighbors import brute_force
+
+    x, qq = _gen(100, 8, 5, seed=1)
+    idx = brute_force.build(torch.from_numpy(x).cuda())
+    with pytest.raises(CuvsError):
+        brute_force.search(idx, torch.from_numpy(qq[:, :4].copy()).cuda(), 3)  # dim mismatch
+    with pytest.raises(CuvsError):
+        brute_force.build(torch.from_numpy(x).cuda(), metric="l1")  # metric outside the hot path
