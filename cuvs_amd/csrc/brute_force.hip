@@ -103,7 +103,7 @@ template <typename T>
 void bf_build_typed(resources& res, bf_index& idx)
 {
   if (idx.metric != M_InnerProduct) {
-    idx.norms = dev_buf<float>(res, idx.n);
+    idx.norms = dev_buf<float>::persistent(idx.n);
     row_norms<T>(res, static_cast<const T*>(idx.data), idx.n, idx.dim, idx.ld, idx.norms.data(),
                  idx.metric == M_CosineExpanded);
   }
@@ -165,13 +165,13 @@ cuvsError_t cuvsBruteForceBuild(cuvsResources_t res_h, DLManagedTensor* dataset_
     if (is_device_accessible(ds) && is_c_contiguous(ds)) {
       idx->data = dl_data(ds);  // non-owning view, as in the reference (brute_force.cu:66-79)
     } else if (is_device_accessible(ds) && is_f_contiguous(ds)) {
-      idx->owned = dev_buf<char>(res, (size_t)idx->n * idx->dim * esz);
+      idx->owned = dev_buf<char>::persistent((size_t)idx->n * idx->dim * esz);
       int64_t total = idx->n * idx->dim;
       hipLaunchKernelGGL(transpose_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, res.stream,
                          static_cast<const char*>(dl_data(ds)), idx->owned.data(), idx->n, idx->dim, (int)esz);
       idx->data = idx->owned.data();
     } else if (is_c_contiguous(ds)) {
-      idx->owned = dev_buf<char>(res, (size_t)idx->n * idx->dim * esz);
+      idx->owned = dev_buf<char>::persistent((size_t)idx->n * idx->dim * esz);
       copy_async(res, idx->owned.data(), dl_data(ds), idx->owned.bytes());
       idx->data = idx->owned.data();
     } else {

@@ -94,15 +94,28 @@ inline resources* as_res(uintptr_t h)
 void* device_alloc(resources& res, size_t bytes);
 void device_free(resources& res, void* p);
 
+// Two lifetimes: scratch buffers are stream-ordered (freed on the handle's stream); buffers owned by an
+// index outlive the handle that built them, so they use plain hipMalloc/hipFree ("persistent").
 template <typename T>
 struct dev_buf {
-  resources* res = nullptr;
+  resources* res = nullptr;  // nullptr => persistent allocation
   T* ptr         = nullptr;
   size_t n       = 0;
   dev_buf() = default;
   dev_buf(resources& r, size_t count) : res(&r), n(count)
   {
     ptr = count ? static_cast<T*>(device_alloc(r, count * sizeof(T))) : nullptr;
+  }
+  static dev_buf persistent(size_t count)
+  {
+    dev_buf b;
+    b.n = count;
+    if (count) {
+      void* p = nullptr;
+      HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+      b.ptr = static_cast<T*>(p);
+    }
+    return b;
   }
   dev_buf(const dev_buf&)            = delete;
   dev_buf& operator=(const dev_buf&) = delete;
@@ -119,13 +132,10 @@ struct dev_buf {
   ~dev_buf() { release(); }
   void release()
   {
-    if (ptr) { device_free(*res, ptr); ptr = nullptr; n = 0; }
-  }
-  void resize_discard(resources& r, size_t count)
-  {
-    release();
-    res = &r; n = count;
-    ptr = count ? static_cast<T*>(device_alloc(r, count * sizeof(T))) : nullptr;
+    if (ptr) {
+      if (res) device_free(*res, ptr); else (void)hipFree(ptr);
+      ptr = nullptr; n = 0;
+    }
   }
   T* data() const { return ptr; }
   size_t size() const { return n; }
