@@ -1,0 +1,78 @@
+// IVF-PQ index as laid out in MI355X HBM (internal; the C ABI sees it through cuvsIvfPqIndex.addr).
+//
+// Reference: cuvs::neighbors::ivf_pq::index (cpp/include/cuvs/neighbors/ivf_pq.hpp:476-675,
+// cpp/src/neighbors/ivf_pq_index.cu). Differences by design:
+//   * all lists live in ONE flat allocation (288 GB HBM: no per-list allocations / pointer tables);
+//     list L owns rows [list_offsets[L], list_offsets[L] + list_sizes[L]) of it, offsets are multiples of 64;
+//   * codes are interleaved in groups of 64 rows (one wave64 lane per row) instead of the reference's 32
+//     (ivf_pq.hpp:222-224,290-297): byte address of (flat row r, 16-byte chunk c) is
+//         ((r / 64 * n_chunks + c) * 64 + r % 64) * 16
+//     so a wave reads 1 KiB contiguous per chunk. Chunk c holds codes [c*cpc, (c+1)*cpc) bit-packed
+//     little-endian, cpc = 128 / pq_bits (16 for 8-bit codes);
+//   * in-list order is ascending source row id (stable sort), i.e. deterministic, where the reference
+//     allocates slots with atomicAdd (ivf_pq_process_and_fill_codes_impl.cuh:39).
+// The externally visible code format (cuvsIvfPqIndexUnpackContiguousListData) is unchanged.
+#pragma once
+#include "common.hpp"
+
+namespace cuvs_amd {
+
+constexpr uint32_t kPqGroup = 64;  // rows per interleaved group == wave size
+
+struct ivf_pq_index {
+  int metric          = 0;
+  int codebook_kind   = 0;  // PER_SUBSPACE only
+  elem_t dtype        = elem_t::f32;
+  uint32_t n_lists = 0, dim = 0, dim_ext = 0, rot_dim = 0;
+  uint32_t pq_dim = 0, pq_bits = 8, pq_len = 0, pq_book = 256;
+  uint32_t n_chunks = 0;        // 16-byte chunks per encoded vector
+  uint32_t codes_per_chunk = 16;
+  int64_t size         = 0;     // number of indexed vectors
+  int64_t padded_rows  = 0;     // rows of the flat arrays (sum of list capacities)
+
+  dev_buf<float> centers;       // [n_lists, dim_ext]  (column `dim` = |c|^2, as in the reference)
+  dev_buf<float> center_norms;  // [n_lists] canonical |c|^2
+  dev_buf<float> centers_rot;   // [n_lists, rot_dim]
+  dev_buf<float> rotation;      // [rot_dim, dim]
+  dev_buf<float> pq_centers;    // [pq_dim, pq_len, pq_book]
+  dev_buf<uint8_t> codes;       // [padded_rows / 64, n_chunks, 64, 16]
+  dev_buf<int64_t> indices;     // [padded_rows] source ids
+  dev_buf<uint32_t> list_sizes;   // [n_lists]
+  dev_buf<uint32_t> list_offsets; // [n_lists + 1] (rows, multiples of 64)
+  std::vector<uint32_t> h_list_sizes, h_list_offsets;
+
+  float scale() const  // kDivisor(T) / kDivisor(float), ann_utils.cuh:134-160
+  {
+    return dtype == elem_t::u8 ? 256.0f : (dtype == elem_t::i8 ? 128.0f : 1.0f);
+  }
+};
+
+struct ivf_pq_build_params {
+  int metric = 0;
+  uint32_t n_lists = 1024, kmeans_n_iters = 20;
+  double kmeans_trainset_fraction = 0.5;
+  uint32_t pq_bits = 8, pq_dim = 0;
+  int codebook_kind = 0;
+  bool force_random_rotation = false;
+  bool add_data_on_build     = true;
+  uint32_t max_train_points_per_pq_code = 256;
+};
+
+struct ivf_pq_search_params {
+  uint32_t n_probes = 20;
+  int lut_dtype = 0, internal_distance_dtype = 0;  // hipDataType values: 0 = f32, 2 = f16, 8 = u8(fp8)
+  uint32_t max_internal_batch_size = 4096;
+};
+
+// data may be a host or a device pointer (is_host)
+std::unique_ptr<ivf_pq_index> ivf_pq_build(resources& res, const ivf_pq_build_params& p, const void* data,
+                                           elem_t et, int64_t n, int64_t dim, bool is_host);
+void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t et, int64_t n, bool is_host,
+                   const int64_t* new_ids, bool ids_on_host);
+void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_index& idx, const void* queries,
+                   elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances);
+// [n_take, ceil(pq_dim*pq_bits/8)] contiguous bit-packed codes of list `label` starting at `offset`
+void ivf_pq_unpack_list(resources& res, const ivf_pq_index& idx, uint32_t label, uint32_t offset,
+                        uint32_t n_take, uint8_t* out);
+
+}  // namespace cuvs_amd

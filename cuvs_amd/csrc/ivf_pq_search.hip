@@ -1,0 +1,616 @@
+// IVF-PQ search on MI355X: coarse selection (fp32-MFMA distances + radix select_k), then a LIST-MAJOR
+// LUT scan, then the per-query merge.
+//
+// Reference path: cpp/src/neighbors/ivf_pq/ivf_pq_search.cuh (search :881-1050, select_clusters :60-168,
+// ivfpq_search_worker :421-669) and the kernel detail/jit_lto_kernels/compute_similarity_impl.cuh:77-173
+// (create_lut_impl.cuh:17-78, compute_distances_impl.cuh:16-106, compute_score_impl.cuh:20-79).
+// The reference launches one block per (query, probe) pair, each building a private LUT and gathering one
+// LUT entry per code byte. On CDNA4 that loop is bound by LDS gather issue (ds_read_b32: 64 lanes / >=2 clk),
+// not by HBM, so the schedule here is different:
+//   * (query, probe) pairs are grouped by list (stable radix sort by list id) and cut into work items of
+//     QPB pairs that probe the SAME list;
+//   * a 512-thread workgroup builds ONE interleaved LUT for its QPB queries in LDS — entry (s, code) holds
+//     the QPB partial distances side by side (8 bytes: 2 x fp32 or 4 x fp16) — so a single ds_read_b64
+//     gather serves QPB queries, and the list's code bytes are read once per work item (1 KiB coalesced
+//     per wave and chunk from the 64-row interleaved layout, mostly L2/Infinity-Cache hits because work
+//     items of one list are adjacent in the grid);
+//   * candidates below the running k-th distance are appended to per-query LDS buffers with one
+//     wave-aggregated LDS atomic; an owner wave per query drains its buffer into a register-resident
+//     sorted top list (lane i holds rank i; up to 4 ranks per lane for k <= 256) with ballot/readlane
+//     insertion — the wave64 replacement of the reference's warp_sort block queue.
+// Results: exact for the given codes/LUT precision — every (query, probe) pair yields its true top-k by
+// (distance, row) order, independent of scheduling.
+#include "ivf_pq.hpp"
+#include "ops.hpp"
+#include "device_utils.hpp"
+
+#include <cfloat>
+
+namespace cuvs_amd {
+
+void load_range_as_float(resources& res, const void* data, elem_t et, bool is_host, int64_t dim, int64_t r0,
+                         int64_t cnt, float* out);
+
+namespace {
+
+constexpr int kScanThreads = 512;
+constexpr int kScanWaves   = kScanThreads / 64;
+constexpr int kCandCap     = 768;  // per-query candidate buffer (>= tile of 512 + drain threshold 256)
+
+inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+struct work_item {
+  uint32_t list;
+  uint32_t first;  // first position in the list-sorted pair array
+  uint32_t count;  // 1..QPB pairs
+  uint32_t pad;
+};
+
+// per list: number of work items = ceil(cnt / qpb); item_off = exclusive scan (single workgroup)
+__global__ __launch_bounds__(1024) void count_items_kernel(const uint32_t* __restrict__ pair_off, int n_lists,
+                                                           int qpb, uint32_t* __restrict__ item_off)
+{
+  __shared__ int smem[17];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_lists; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = 0;
+    if (i < n_lists) v = ((int)(pair_off[i + 1] - pair_off[i]) + qpb - 1) / qpb;
+    int total;
+    int excl = block_exclusive_scan(v, smem, &total);
+    if (i < n_lists) item_off[i] = (uint32_t)(carry + excl);
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) item_off[n_lists] = (uint32_t)carry;
+}
+
+__global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ item_off,
+                                  int n_lists, int qpb, work_item* __restrict__ items)
+{
+  int L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= n_lists) return;
+  uint32_t b = pair_off[L], e = pair_off[L + 1];
+  uint32_t w = item_off[L];
+  for (uint32_t p = b; p < e; p += qpb, ++w) {
+    work_item it;
+    it.list  = (uint32_t)L;
+    it.first = p;
+    it.count = min((uint32_t)qpb, e - p);
+    it.pad   = 0;
+    items[w] = it;
+  }
+}
+
+// ------------------------------------------------------------------ accumulators over interleaved LUT entries
+template <typename LutT, typename AccT, int QPB>
+struct lut_acc;
+
+template <>
+struct lut_acc<float, float, 1> {
+  using entry_t = float;
+  float a       = 0.f;
+  __device__ inline void add(entry_t e) { a += e; }
+  __device__ inline float get(int) const { return a; }
+  __device__ static inline entry_t pack(const float (&v)[1]) { return v[0]; }
+};
+template <>
+struct lut_acc<float, float, 2> {
+  using entry_t = float2;
+  float2 a      = {0.f, 0.f};
+  __device__ inline void add(entry_t e) { a.x += e.x; a.y += e.y; }
+  __device__ inline float get(int j) const { return j == 0 ? a.x : a.y; }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return make_float2(v[0], v[1]); }
+};
+template <>
+struct lut_acc<__half, float, 2> {
+  using entry_t = __half2;
+  float2 a      = {0.f, 0.f};
+  __device__ inline void add(entry_t e) { float2 f = __half22float2(e); a.x += f.x; a.y += f.y; }
+  __device__ inline float get(int j) const { return j == 0 ? a.x : a.y; }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return __floats2half2_rn(v[0], v[1]); }
+};
+template <>
+struct lut_acc<__half, __half, 2> {
+  using entry_t = __half2;
+  __half2 a     = __floats2half2_rn(0.f, 0.f);
+  __device__ inline void add(entry_t e) { a = __hadd2(a, e); }
+  __device__ inline float get(int j) const { return j == 0 ? __low2float(a) : __high2float(a); }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return __floats2half2_rn(v[0], v[1]); }
+};
+struct alignas(8) half4_t {
+  __half2 lo, hi;
+};
+template <>
+struct lut_acc<__half, float, 4> {
+  using entry_t = half4_t;
+  float a[4]    = {0.f, 0.f, 0.f, 0.f};
+  __device__ inline void add(entry_t e)
+  {
+    float2 l = __half22float2(e.lo), h = __half22float2(e.hi);
+    a[0] += l.x; a[1] += l.y; a[2] += h.x; a[3] += h.y;
+  }
+  __device__ inline float get(int j) const { return a[j]; }
+  __device__ static inline entry_t pack(const float (&v)[4])
+  {
+    return half4_t{__floats2half2_rn(v[0], v[1]), __floats2half2_rn(v[2], v[3])};
+  }
+};
+template <>
+struct lut_acc<__half, __half, 4> {
+  using entry_t = half4_t;
+  __half2 lo = __floats2half2_rn(0.f, 0.f), hi = __floats2half2_rn(0.f, 0.f);
+  __device__ inline void add(entry_t e) { lo = __hadd2(lo, e.lo); hi = __hadd2(hi, e.hi); }
+  __device__ inline float get(int j) const
+  {
+    return j == 0 ? __low2float(lo) : (j == 1 ? __high2float(lo) : (j == 2 ? __low2float(hi) : __high2float(hi)));
+  }
+  __device__ static inline entry_t pack(const float (&v)[4])
+  {
+    return half4_t{__floats2half2_rn(v[0], v[1]), __floats2half2_rn(v[2], v[3])};
+  }
+};
+template <>
+struct lut_acc<__half, float, 1> {
+  using entry_t = __half;
+  float a       = 0.f;
+  __device__ inline void add(entry_t e) { a += __half2float(e); }
+  __device__ inline float get(int) const { return a; }
+  __device__ static inline entry_t pack(const float (&v)[1]) { return __float2half_rn(v[0]); }
+};
+template <>
+struct lut_acc<__half, __half, 1> {
+  using entry_t = __half;
+  __half a      = __float2half_rn(0.f);
+  __device__ inline void add(entry_t e) { a = __hadd(a, e); }
+  __device__ inline float get(int) const { return __half2float(a); }
+  __device__ static inline entry_t pack(const float (&v)[1]) { return __float2half_rn(v[0]); }
+};
+
+// ------------------------------------------------------------------ register-resident sorted top list (one wave)
+// rank r lives in lane r % 64, slot r / 64; sorted ascending by (distance, row).
+template <int E>
+struct wave_top {
+  float d[E];
+  uint32_t i[E];
+  __device__ inline void init()
+  {
+#pragma unroll
+    for (int e = 0; e < E; ++e) { d[e] = INFINITY; i[e] = 0xffffffffu; }
+  }
+  // value at rank r (wave-uniform r)
+  __device__ inline float rank_d(int r) const
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if ((r >> 6) == e) v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d[e]), r & 63));
+    return v;
+  }
+  __device__ inline uint32_t rank_i(int r) const
+  {
+    uint32_t v = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if ((r >> 6) == e) v = __builtin_amdgcn_readlane(i[e], r & 63);
+    return v;
+  }
+  // insert wave-uniform candidate (cd, ci); ranks beyond 64*E fall off
+  __device__ inline void insert(float cd, uint32_t ci, int lane)
+  {
+    int pos = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      bool le = (d[e] < cd) || (d[e] == cd && i[e] <= ci);
+      pos += __popcll(__ballot(le));
+    }
+    float carry_d    = 0.f;
+    uint32_t carry_i = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float up_d    = __shfl_up(d[e], 1, kWave);
+      uint32_t up_i = __shfl_up(i[e], 1, kWave);
+      float last_d    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d[e]), 63));
+      uint32_t last_i = __builtin_amdgcn_readlane(i[e], 63);
+      if (lane == 0) { up_d = carry_d; up_i = carry_i; }
+      int rank = e * 64 + lane;
+      if (rank > pos) { d[e] = up_d; i[e] = up_i; }
+      else if (rank == pos) { d[e] = cd; i[e] = ci; }
+      carry_d = last_d;
+      carry_i = last_i;
+    }
+  }
+};
+
+struct scan_args {
+  const work_item* items;
+  const uint32_t* n_items;       // device scalar (item_off[n_lists])
+  const uint32_t* sorted_pairs;  // pair ids (q * n_probes + probe rank) grouped by list
+  const float* rot_queries;      // [n_queries, rot_dim]
+  const float* centers_rot;      // [n_lists, rot_dim]
+  const float* pq_centers;       // [pq_dim, pq_len, book]
+  const uint8_t* codes;
+  const uint32_t* list_offsets;
+  const uint32_t* list_sizes;
+  float* out_d;                  // [n_pairs, k]
+  uint32_t* out_i;               // [n_pairs, k] flat row
+  uint32_t n_probes, rot_dim, pq_dim, pq_len, pq_bits, n_chunks, cpc, k;
+  int is_ip;
+};
+
+template <typename LutT, typename AccT, int QPB, bool BITS8, int E>
+__global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
+{
+  using acc_t   = lut_acc<LutT, AccT, QPB>;
+  using entry_t = typename acc_t::entry_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const uint32_t w = blockIdx.x;
+  if (w >= *a.n_items) return;
+  const work_item item = a.items[w];
+
+  const uint32_t book      = 1u << a.pq_bits;
+  const uint32_t lut_elems = a.pq_dim * book;
+  // LDS carve (all offsets multiples of 16)
+  entry_t* lut     = reinterpret_cast<entry_t*>(smem);
+  size_t off       = ((size_t)lut_elems * sizeof(entry_t) + 15) & ~size_t(15);
+  float* cand_d    = reinterpret_cast<float*>(smem + off);     off += (size_t)QPB * kCandCap * 4;
+  uint32_t* cand_i = reinterpret_cast<uint32_t*>(smem + off);  off += (size_t)QPB * kCandCap * 4;
+  float* qv        = reinterpret_cast<float*>(smem + off);     off += (size_t)QPB * a.rot_dim * 4;
+  float* cv        = reinterpret_cast<float*>(smem + off);     off += (size_t)a.rot_dim * 4;
+  int* cnt         = reinterpret_cast<int*>(smem + off);       off += 16 * 4;
+  float* kth       = reinterpret_cast<float*>(smem + off);     off += 16 * 4;
+  uint32_t* pid    = reinterpret_cast<uint32_t*>(smem + off);
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  const uint32_t L        = item.list;
+  const uint32_t base_row = a.list_offsets[L];
+  const uint32_t len      = a.list_sizes[L];
+
+  if (tid < QPB) {
+    pid[tid] = tid < (int)item.count ? a.sorted_pairs[item.first + tid] : 0xffffffffu;
+    cnt[tid] = 0;
+    kth[tid] = INFINITY;
+  }
+  __syncthreads();
+  // query residuals (L2) or raw rotated queries + list centre (IP)
+  for (uint32_t t = tid; t < QPB * a.rot_dim; t += kScanThreads) {
+    uint32_t j = t / a.rot_dim, dd = t % a.rot_dim;
+    float v = 0.f;
+    if (j < item.count) {
+      uint32_t q = pid[j] / a.n_probes;
+      v          = a.rot_queries[(size_t)q * a.rot_dim + dd];
+      if (!a.is_ip) v -= a.centers_rot[(size_t)L * a.rot_dim + dd];
+    }
+    qv[t] = v;
+  }
+  for (uint32_t t = tid; t < a.rot_dim; t += kScanThreads) cv[t] = a.centers_rot[(size_t)L * a.rot_dim + t];
+  __syncthreads();
+
+  // ---- LUT (create_lut_impl.cuh:17-78): entry (s, c) = QPB partial scores side by side
+  for (uint32_t e = tid; e < lut_elems; e += kScanThreads) {
+    const uint32_t s = e >> a.pq_bits, c = e & (book - 1);
+    float sc[QPB];
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) sc[j] = 0.f;
+    for (uint32_t l = 0; l < a.pq_len; ++l) {
+      const uint32_t dd = s * a.pq_len + l;
+      const float p     = a.pq_centers[(size_t)dd * book + c];
+      if (!a.is_ip) {
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) {
+          float diff = qv[j * a.rot_dim + dd] - p;
+          sc[j]      = __fmaf_rn(diff, diff, sc[j]);
+        }
+      } else {
+        const float cc = cv[dd];
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) {
+          float q = qv[j * a.rot_dim + dd];
+          sc[j]   = __fmaf_rn(-q, cc, sc[j]);
+          sc[j]   = __fmaf_rn(-q, p, sc[j]);
+        }
+      }
+    }
+    lut[e] = acc_t::pack(sc);
+  }
+  __syncthreads();
+
+  wave_top<E> top;
+  top.init();
+
+  const uint32_t n_iter = (len + kScanThreads - 1) / kScanThreads;
+  const size_t g0       = (size_t)(base_row >> 6);
+  for (uint32_t it = 0; it < n_iter; ++it) {
+    const uint32_t v = it * kScanThreads + tid;  // in-list position
+    const bool valid = v < len;
+    acc_t acc;
+    {
+      const size_t g   = g0 + (size_t)it * kScanWaves + wave;
+      const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + (g * a.n_chunks) * 64 + lane;
+      if (BITS8) {
+        for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+          uint4 cw            = valid ? cp[(size_t)ch * 64] : make_uint4(0, 0, 0, 0);
+          const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+          const uint32_t s0   = ch * 16;
+          if (s0 + 16 <= a.pq_dim) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+              uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+              acc.add(lut[((s0 + b) << 8) + code]);
+            }
+          } else {
+            for (uint32_t b = 0; b < 16 && s0 + b < a.pq_dim; ++b) {
+              uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+              acc.add(lut[((s0 + b) << 8) + code]);
+            }
+          }
+        }
+      } else {
+        const uint32_t msk = book - 1;
+        for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+          uint4 cw             = valid ? cp[(size_t)ch * 64] : make_uint4(0, 0, 0, 0);
+          const uint32_t ws[5] = {cw.x, cw.y, cw.z, cw.w, 0u};
+          for (uint32_t b = 0; b < a.cpc; ++b) {
+            uint32_t s = ch * a.cpc + b;
+            if (s >= a.pq_dim) break;
+            uint32_t bit = b * a.pq_bits;
+            uint64_t two = (uint64_t)ws[bit >> 5] | ((uint64_t)ws[(bit >> 5) + 1] << 32);
+            uint32_t code = (uint32_t)(two >> (bit & 31)) & msk;
+            acc.add(lut[(s << a.pq_bits) + code]);
+          }
+        }
+      }
+    }
+    // ---- filter + append (wave-aggregated)
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) {
+      const float dj  = acc.get(j);
+      const bool pass = valid && (j < (int)item.count) && (dj <= kth[j]);
+      const unsigned long long m = __ballot(pass);
+      if (m != 0ull) {
+        const int n    = __popcll(m);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        int base       = 0;
+        if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&cnt[j], n);
+        base = __shfl(base, (int)__ffsll((long long)m) - 1, kWave);
+        if (pass) {
+          cand_d[j * kCandCap + base + rank] = dj;
+          cand_i[j * kCandCap + base + rank] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- drain by the owner wave of each query
+    if (wave < QPB && wave < (int)item.count) {
+      const int j = wave;
+      const int n = cnt[j];
+      if (n > kCandCap - kScanThreads || it + 1 == n_iter) {
+        float kd    = top.rank_d(a.k - 1);
+        uint32_t ki = top.rank_i(a.k - 1);
+        for (int b0 = 0; b0 < n; b0 += 64) {
+          float md    = INFINITY;
+          uint32_t mi = 0xffffffffu;
+          if (b0 + lane < n) { md = cand_d[j * kCandCap + b0 + lane]; mi = cand_i[j * kCandCap + b0 + lane]; }
+          unsigned long long m = __ballot((md < kd) || (md == kd && mi < ki));
+          while (m != 0ull) {
+            const int src = (int)__ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(md), src));
+            const uint32_t ci = __builtin_amdgcn_readlane(mi, src);
+            if ((cd < kd) || (cd == kd && ci < ki)) {
+              top.insert(cd, ci, lane);
+              kd = top.rank_d(a.k - 1);
+              ki = top.rank_i(a.k - 1);
+            }
+          }
+        }
+        if (lane == 0) { cnt[j] = 0; kth[j] = kd; }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-pair result (pairs of empty lists get all-invalid rows)
+  if (wave < QPB && wave < (int)item.count) {
+    const size_t o = (size_t)pid[wave] * a.k;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      int r = e * 64 + lane;
+      if (r < (int)a.k) {
+        bool ok      = top.i[e] != 0xffffffffu;
+        a.out_d[o + r] = ok ? top.d[e] : FLT_MAX;
+        a.out_i[o + r] = ok ? base_row + top.i[e] : 0xffffffffu;
+      }
+    }
+  }
+}
+
+template <typename LutT, typename AccT, int QPB>
+size_t scan_smem_bytes(const ivf_pq_index& idx)
+{
+  using entry_t = typename lut_acc<LutT, AccT, QPB>::entry_t;
+  size_t lut = ((size_t)idx.pq_dim * idx.pq_book * sizeof(entry_t) + 15) & ~size_t(15);
+  return lut + (size_t)QPB * kCandCap * 8 + (size_t)QPB * idx.rot_dim * 4 + (size_t)idx.rot_dim * 4 + 16 * 4 + 16 * 4 +
+         16 * 4;
+}
+
+template <typename LutT, typename AccT, int QPB, bool BITS8, int E>
+void launch_scan(resources& res, const scan_args& a, size_t smem, unsigned grid)
+{
+  auto kern = pq_scan_kernel<LutT, AccT, QPB, BITS8, E>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), smem, res.stream, a);
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename LutT, typename AccT, int QPB>
+void launch_scan_qpb(resources& res, const scan_args& a, size_t smem, unsigned grid, bool bits8, bool big_k)
+{
+  if (bits8) {
+    if (big_k) launch_scan<LutT, AccT, QPB, true, 4>(res, a, smem, grid);
+    else       launch_scan<LutT, AccT, QPB, true, 1>(res, a, smem, grid);
+  } else {
+    if (big_k) launch_scan<LutT, AccT, QPB, false, 4>(res, a, smem, grid);
+    else       launch_scan<LutT, AccT, QPB, false, 1>(res, a, smem, grid);
+  }
+}
+
+// n_probes clusters closest to each query (select_clusters, ivf_pq_search.cuh:60-168)
+void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, int64_t nq, uint32_t n_probes,
+                     uint32_t* probes)
+{
+  dev_buf<float> dist(res, (size_t)nq * idx.n_lists);
+  dev_buf<float> pd(res, (size_t)nq * n_probes);
+  if (idx.metric == M_InnerProduct) {
+    pairwise_distance<float, float>(res, qf, nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim,
+                                    nullptr, nullptr, M_InnerProduct, dist.data(), idx.n_lists);
+    select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
+                                 probes, false);
+  } else {
+    dev_buf<float> qn(res, nq);
+    row_norms<float>(res, qf, nq, idx.dim, idx.dim, qn.data(), false);
+    pairwise_distance<float, float>(res, qf, nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim,
+                                    qn.data(), idx.center_norms.data(), M_L2Expanded, dist.data(), idx.n_lists);
+    select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
+                                 probes, true);
+  }
+}
+
+// flat row -> source id; distance fix-ups (ivf_common.cuh:114-171 postprocess_neighbors, :176-253)
+__global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float* __restrict__ d_in, int64_t n,
+                                   const int64_t* __restrict__ indices, int metric, float scale2,
+                                   int64_t* __restrict__ neighbors, float* __restrict__ distances)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t p   = pos[i];
+  neighbors[i] = p == 0xffffffffu ? INT64_MAX : indices[p];  // kOutOfBoundsRecord, ivf_common.cuh:31
+  float d      = d_in[i];
+  if (p == 0xffffffffu) {
+    d = FLT_MAX;
+  } else if (metric == M_InnerProduct) {
+    d = -d * scale2;
+  } else if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) {
+    d = sqrtf(d * scale2);
+  } else {
+    d = d * scale2;
+  }
+  distances[i] = d;
+}
+
+}  // namespace
+
+void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_index& idx, const void* queries,
+                   elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances)
+{
+  CUVS_EXPECTS(k > 0, "parameter `k` in top-k must be positive.");
+  CUVS_EXPECTS(k <= 256, "ivf_pq::search: k <= 256 is supported by the fused scan");
+  CUVS_EXPECTS((int64_t)k <= idx.size,
+               "parameter `k` (%d) in top-k must not be larger that the total size of the index (%ld)", k,
+               (long)idx.size);
+  CUVS_EXPECTS(p.n_probes > 0, "n_probes (number of clusters to probe in the search) must be positive.");
+  CUVS_EXPECTS(p.internal_distance_dtype == 0 || p.internal_distance_dtype == 2,
+               "internal_distance_dtype must be either CUDA_R_16F or CUDA_R_32F");
+  CUVS_EXPECTS(p.lut_dtype == 0 || p.lut_dtype == 2 || p.lut_dtype == 8,
+               "lut_dtype must be CUDA_R_16F, CUDA_R_32F or CUDA_R_8U");
+  CUVS_EXPECTS(et == idx.dtype, "queries dtype differs from the index dtype");
+  if (n_queries == 0) return;
+  const uint32_t n_probes = std::min<uint32_t>(p.n_probes, idx.n_lists);
+  const bool lut_half     = p.lut_dtype != 0;  // fp8 LUT requests run on the fp16 LUT (superset precision)
+  const bool acc_half     = lut_half && p.internal_distance_dtype == 2;
+  const bool bits8        = idx.pq_bits == 8;
+  const bool big_k        = k > 64;
+  const size_t lds_cap    = 160 * 1024;
+
+  // choose the widest interleave (queries per work item) whose LUT fits the 160 KiB LDS
+  int qpb = 0;
+  size_t smem = 0;
+  if (!lut_half) {
+    if ((smem = scan_smem_bytes<float, float, 2>(idx)) <= lds_cap) qpb = 2;
+    else if ((smem = scan_smem_bytes<float, float, 1>(idx)) <= lds_cap) qpb = 1;
+  } else {
+    if ((smem = scan_smem_bytes<__half, float, 4>(idx)) <= lds_cap) qpb = 4;
+    else if ((smem = scan_smem_bytes<__half, float, 2>(idx)) <= lds_cap) qpb = 2;
+    else if ((smem = scan_smem_bytes<__half, float, 1>(idx)) <= lds_cap) qpb = 1;
+  }
+  CUVS_EXPECTS(qpb > 0, "ivf_pq::search: the PQ look-up table (pq_dim=%u, pq_bits=%u) does not fit 160 KiB of LDS%s",
+               idx.pq_dim, idx.pq_bits, lut_half ? "" : "; try lut_dtype=CUDA_R_16F");
+
+  // batch of queries per pass (reference: max_internal_batch_size bounds the coarse batch, :814-857)
+  int64_t max_batch = std::max<uint32_t>(1, p.max_internal_batch_size);
+  {
+    // keep the coarse distance matrix and the candidate buffers inside the workspace budget
+    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k * 8 + (int64_t)idx.rot_dim * 4 + idx.dim * 4;
+    int64_t fit   = std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q);
+    max_batch     = std::min(max_batch, fit);
+  }
+  const int64_t bs_alloc = std::min<int64_t>(max_batch, n_queries);
+  const int64_t n_pairs_max = bs_alloc * n_probes;
+  dev_buf<float> qf(res, (size_t)bs_alloc * idx.dim);
+  dev_buf<float> rot_q(res, (size_t)bs_alloc * idx.rot_dim);
+  dev_buf<uint32_t> probes(res, (size_t)n_pairs_max);
+  dev_buf<uint32_t> sorted_pairs(res, (size_t)n_pairs_max), pair_off(res, idx.n_lists + 1),
+    item_off(res, idx.n_lists + 1);
+  const int64_t max_items = n_pairs_max / qpb + idx.n_lists + 1;
+  dev_buf<work_item> items(res, (size_t)max_items);
+  dev_buf<float> cand_d(res, (size_t)n_pairs_max * k);
+  dev_buf<uint32_t> cand_i(res, (size_t)n_pairs_max * k);
+  dev_buf<float> top_d(res, (size_t)bs_alloc * k);
+  dev_buf<uint32_t> top_i(res, (size_t)bs_alloc * k);
+  const bool q_is_host = false;  // the C layer guarantees device-accessible queries
+
+  for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
+    const int64_t nq      = std::min(max_batch, n_queries - q0);
+    const int64_t n_pairs = nq * n_probes;
+    load_range_as_float(res, queries, et, q_is_host, idx.dim, q0, nq, qf.data());
+    select_clusters(res, idx, qf.data(), nq, n_probes, probes.data());
+    // rotation (ivf_pq_search.cuh:1003-1017)
+    pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.rotation.data(), idx.rot_dim, idx.dim, idx.dim,
+                                    nullptr, nullptr, M_InnerProduct, rot_q.data(), idx.rot_dim);
+    // list-major grouping of the (query, probe) pairs
+    group_by_label(res, probes.data(), n_pairs, idx.n_lists, sorted_pairs.data(), pair_off.data());
+    hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off.data(), (int)idx.n_lists, qpb,
+                       item_off.data());
+    hipLaunchKernelGGL(fill_items_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream, pair_off.data(),
+                       item_off.data(), (int)idx.n_lists, qpb, items.data());
+    scan_args a;
+    a.items = items.data(); a.n_items = item_off.data() + idx.n_lists; a.sorted_pairs = sorted_pairs.data();
+    a.rot_queries = rot_q.data(); a.centers_rot = idx.centers_rot.data(); a.pq_centers = idx.pq_centers.data();
+    a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data(); a.list_sizes = idx.list_sizes.data();
+    a.out_d = cand_d.data(); a.out_i = cand_i.data();
+    a.n_probes = n_probes; a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len;
+    a.pq_bits = idx.pq_bits; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.k = (uint32_t)k;
+    a.is_ip = idx.metric == M_InnerProduct;
+    const unsigned grid = (unsigned)(n_pairs / qpb + idx.n_lists + 1);
+    if (!lut_half) {
+      if (qpb == 2) launch_scan_qpb<float, float, 2>(res, a, smem, grid, bits8, big_k);
+      else          launch_scan_qpb<float, float, 1>(res, a, smem, grid, bits8, big_k);
+    } else if (!acc_half) {
+      if (qpb == 4)      launch_scan_qpb<__half, float, 4>(res, a, smem, grid, bits8, big_k);
+      else if (qpb == 2) launch_scan_qpb<__half, float, 2>(res, a, smem, grid, bits8, big_k);
+      else               launch_scan_qpb<__half, float, 1>(res, a, smem, grid, bits8, big_k);
+    } else {
+      if (qpb == 4)      launch_scan_qpb<__half, __half, 4>(res, a, smem, grid, bits8, big_k);
+      else if (qpb == 2) launch_scan_qpb<__half, __half, 2>(res, a, smem, grid, bits8, big_k);
+      else               launch_scan_qpb<__half, __half, 1>(res, a, smem, grid, bits8, big_k);
+    }
+    // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
+    select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
+                                 k, top_d.data(), top_i.data(), true);
+    const float sc = idx.scale();
+    hipLaunchKernelGGL(postprocess_kernel, dim3(nblk(nq * k, 256)), dim3(256), 0, res.stream, top_i.data(),
+                       top_d.data(), nq * k, idx.indices.data(), idx.metric, sc * sc, neighbors + q0 * k,
+                       distances + q0 * k);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cuvs_amd

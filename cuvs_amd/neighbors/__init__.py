@@ -1,1 +1,1 @@
-from . import brute_force  # noqa: F401
+from . import brute_force, ivf_pq  # noqa: F401

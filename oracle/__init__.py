@@ -95,3 +95,37 @@ def recall(found, truth):
     for f, t in zip(found, truth):
         hits += len(np.intersect1d(f, t))
     return hits / truth.size
+
+
+def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.0):
+    """Search an index exported with cuvs_amd.neighbors.ivf_pq.export_for_oracle (fp32 LUT / fp32 scores).
+    Returns (distances, neighbors); bit-for-bit twin of cuvsIvfPqSearch at the default dtypes."""
+    q = _f32(queries)
+    centers = _f32(exported["centers"])
+    centers_rot = _f32(exported["centers_rot"])
+    rotation = _f32(exported["rotation"])
+    pqc = _f32(exported["pq_centers"])
+    sizes = np.ascontiguousarray(exported["list_sizes"], dtype=np.uint32)
+    start = np.zeros(len(sizes) + 1, np.int64)
+    np.cumsum(sizes, out=start[1:])
+    codes = np.ascontiguousarray(np.concatenate(exported["codes"], axis=0), dtype=np.uint8)
+    ids = np.ascontiguousarray(np.concatenate(exported["ids"], axis=0), dtype=np.int64)
+    nq = q.shape[0]
+    nb = np.empty((nq, k), np.int64)
+    ds = np.empty((nq, k), np.float32)
+    lib().oracle_ivf_pq_search(
+        _p(q), C.c_int64(nq), C.c_int(q.shape[1]), _p(centers), _p(centers_rot), _p(rotation), _p(pqc),
+        C.c_int(len(sizes)), C.c_int(rotation.shape[0]), C.c_int(int(exported["pq_dim"])),
+        C.c_int(int(exported["pq_len"])), C.c_int(int(exported["pq_bits"])), _p(sizes), _p(start), _p(codes), _p(ids),
+        C.c_int(_metric(metric)), C.c_int(n_probes), C.c_int(k), C.c_float(scale), _p(nb), _p(ds))
+    return ds, nb
+
+
+def pq_encode(resid, pq_centers, pq_bits):
+    resid = _f32(resid)
+    pqc = _f32(pq_centers)
+    pq_dim, pq_len, _ = pqc.shape
+    out = np.empty((resid.shape[0], pq_dim), np.uint8)
+    lib().oracle_pq_encode(_p(resid), C.c_int64(resid.shape[0]), C.c_int(resid.shape[1]), _p(pqc), C.c_int(pq_dim),
+                           C.c_int(pq_len), C.c_int(pq_bits), _p(out))
+    return out

@@ -289,3 +289,144 @@ EXPORT int oracle_num_threads(void)
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------ IVF-PQ search on an exported index */
+/* Restates ivf_pq_search.cuh:60-168 (select_clusters), :1003-1017 (rotation), create_lut_impl.cuh:17-78 (LUT),
+ * compute_distances_impl.cuh:73-91 / compute_score_impl.cuh:20-79 (score = sum of LUT entries in subspace
+ * order), ivf_pq_search.cuh:646-674 (merge of n_probes*k candidates, distance/neighbour post-processing),
+ * with fp32 LUT and fp32 accumulation. Codes are given in the externally visible contiguous bit-packed
+ * format (ivf_pq_codepacking.cuh:22-52). Tie rules mirror the HIP path: per (query, probe) candidates are
+ * ordered by (score, flat row); the merge picks by (score, buffer position) and orders by (score, flat row),
+ * flat row = 64-padded list offset + in-list position. */
+static uint32_t code_at(const uint8_t* row, int s, int pq_bits)
+{
+  int bit = s * pq_bits;
+  uint32_t v = row[bit >> 3];
+  if ((bit & 7) + pq_bits > 8) v |= (uint32_t)row[(bit >> 3) + 1] << 8;
+  return (v >> (bit & 7)) & ((1u << pq_bits) - 1u);
+}
+
+EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, const float* centers,
+                                 const float* centers_rot, const float* rotation, const float* pq_centers,
+                                 int n_lists, int rot_dim, int pq_dim, int pq_len, int pq_bits,
+                                 const uint32_t* list_sizes, const int64_t* list_start, const uint8_t* codes,
+                                 const int64_t* ids, int metric, int n_probes, int k, float scale,
+                                 int64_t* neighbors, float* distances)
+{
+  const int book = 1 << pq_bits;
+  const int bpr  = (pq_dim * pq_bits + 7) / 8;
+  const int is_ip = metric == M_InnerProduct;
+  if (n_probes > n_lists) n_probes = n_lists;
+  float* cn = (float*)malloc(sizeof(float) * (size_t)n_lists);
+  oracle_row_norms(centers, n_lists, dim, cn, 0);
+  int64_t* pad_off = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_lists + 1));
+  pad_off[0] = 0;
+  for (int L = 0; L < n_lists; ++L) pad_off[L + 1] = pad_off[L] + (((int64_t)list_sizes[L] + 63) / 64) * 64;
+
+#pragma omp parallel
+  {
+    float* cd     = (float*)malloc(sizeof(float) * (size_t)n_lists);
+    cand_t* cc    = (cand_t*)malloc(sizeof(cand_t) * (size_t)n_lists);
+    float* rq     = (float*)malloc(sizeof(float) * (size_t)rot_dim);
+    float* qv     = (float*)malloc(sizeof(float) * (size_t)rot_dim);
+    float* lut    = (float*)malloc(sizeof(float) * (size_t)pq_dim * book);
+    pair_t* best  = (pair_t*)malloc(sizeof(pair_t) * (size_t)k);
+    float* buf_d  = (float*)malloc(sizeof(float) * (size_t)n_probes * k);
+    int64_t* buf_i = (int64_t*)malloc(sizeof(int64_t) * (size_t)n_probes * k);
+    cand_t* mc    = (cand_t*)malloc(sizeof(cand_t) * (size_t)n_probes * k);
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t qi = 0; qi < nq; ++qi) {
+      const float* q = queries + qi * dim;
+      /* coarse */
+      float qn = canon_sqnorm(q, dim);
+      for (int j = 0; j < n_lists; ++j) {
+        float dot = canon_dot(q, centers + (int64_t)j * dim, dim);
+        cd[j]     = is_ip ? dot : finish_distance(dot, qn, cn[j], M_L2Expanded, 1e-6f);
+        uint32_t key = float_to_key(cd[j]);
+        cc[j].key = is_ip ? ~key : key;
+        cc[j].pos = j;
+        cc[j].idx = j;
+      }
+      qsort(cc, (size_t)n_lists, sizeof(cand_t), cmp_key_pos);
+      for (int r = 0; r < rot_dim; ++r) rq[r] = canon_dot(q, rotation + (int64_t)r * dim, dim);
+      for (int p = 0; p < n_probes; ++p) {
+        const int L = (int)cc[p].idx;
+        const float* cr = centers_rot + (int64_t)L * rot_dim;
+        for (int r = 0; r < rot_dim; ++r) qv[r] = is_ip ? rq[r] : rq[r] - cr[r];
+        for (int s = 0; s < pq_dim; ++s)
+          for (int c = 0; c < book; ++c) {
+            float sc = 0.f;
+            for (int l = 0; l < pq_len; ++l) {
+              int dd  = s * pq_len + l;
+              float pc = pq_centers[(int64_t)dd * book + c];
+              if (!is_ip) { float diff = qv[dd] - pc; sc = fmaf(diff, diff, sc); }
+              else        { sc = fmaf(-qv[dd], cr[dd], sc); sc = fmaf(-qv[dd], pc, sc); }
+            }
+            lut[s * book + c] = sc;
+          }
+        for (int j = 0; j < k; ++j) { best[j].d = FLT_MAX; best[j].id = INT64_MAX; }
+        const uint32_t len = list_sizes[L];
+        for (uint32_t v = 0; v < len; ++v) {
+          const uint8_t* row = codes + (list_start[L] + v) * bpr;
+          float acc = 0.f;
+          for (int s = 0; s < pq_dim; ++s) acc = acc + lut[s * book + code_at(row, s, pq_bits)];
+          topk_insert(best, k, acc, pad_off[L] + v);
+        }
+        for (int j = 0; j < k; ++j) {
+          int valid = best[j].id != INT64_MAX;
+          buf_d[p * k + j] = valid ? best[j].d : FLT_MAX;
+          buf_i[p * k + j] = valid ? best[j].id : 0xffffffffLL;
+        }
+      }
+      /* merge */
+      int m = n_probes * k;
+      for (int t = 0; t < m; ++t) { mc[t].key = float_to_key(buf_d[t]); mc[t].pos = t; mc[t].idx = buf_i[t]; }
+      qsort(mc, (size_t)m, sizeof(cand_t), cmp_key_pos);
+      int ke = k < m ? k : m;
+      qsort(mc, (size_t)ke, sizeof(cand_t), cmp_key_idx);
+      for (int j = 0; j < k; ++j) {
+        float d = j < ke ? buf_d[mc[j].pos] : FLT_MAX;
+        int64_t fr = j < ke ? mc[j].idx : 0xffffffffLL;
+        if (fr == 0xffffffffLL) {
+          neighbors[qi * k + j] = INT64_MAX;
+          distances[qi * k + j] = FLT_MAX;
+        } else {
+          /* flat row -> (list, pos) -> id */
+          int lo = 0, hi = n_lists;  /* last L with pad_off[L] <= fr */
+          while (hi - lo > 1) { int mid = (lo + hi) / 2; if (pad_off[mid] <= fr) lo = mid; else hi = mid; }
+          neighbors[qi * k + j] = ids[list_start[lo] + (fr - pad_off[lo])];
+          float s2 = scale * scale;
+          if (is_ip) d = -d * s2;
+          else if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d * s2);
+          else d = d * s2;
+          distances[qi * k + j] = d;
+        }
+      }
+    }
+    free(cd); free(cc); free(rq); free(qv); free(lut); free(best); free(buf_d); free(buf_i); free(mc);
+  }
+  free(cn);
+  free(pad_off);
+}
+
+/* PQ encoding of rotated residuals (encode_vectors, ivf_pq_process_and_fill_codes.cuh:65-112): per subspace
+ * argmin over the codebook of sum_l (r - p)^2, ties -> smaller code. out: [n, pq_dim] one code per byte. */
+EXPORT void oracle_pq_encode(const float* resid, int64_t n, int rot_dim, const float* pq_centers, int pq_dim,
+                             int pq_len, int pq_bits, uint8_t* out)
+{
+  const int book = 1 << pq_bits;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; ++i)
+    for (int s = 0; s < pq_dim; ++s) {
+      float bestd = INFINITY; int code = 0;
+      for (int c = 0; c < book; ++c) {
+        float d = 0.f;
+        for (int l = 0; l < pq_len; ++l) {
+          float t = resid[i * rot_dim + s * pq_len + l] - pq_centers[((int64_t)s * pq_len + l) * book + c];
+          d = fmaf(t, t, d);
+        }
+        if (d < bestd) { bestd = d; code = c; }
+      }
+      out[i * pq_dim + s] = (uint8_t)code;
+    }
+}

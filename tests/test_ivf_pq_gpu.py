@@ -1,0 +1,182 @@
+"""GPU: cuvsIvfPq* through the C ABI.
+
+* search parity: the GPU search of an index vs the CPU oracle searching the SAME index bytes (exported
+  through the reference's own getters / UnpackContiguousListData) — identical ids and distances;
+* build parity: PQ codes vs the oracle's encoder on the same centres/codebooks;
+* recall vs exact kNN with the reference's thresholds (cpp/tests/neighbors/ann_ivf_pq.cuh:639-655,
+  defaults :26-43: n=4096, q=1024, d=64, k=32, n_lists=32) and its structural invariants (:662-678,
+  python test_ivf_pq.py:119-122).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(n, d, q, seed, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    if dtype in (np.int8, np.uint8):
+        x = rng.integers(1, 20, size=(n, d)).astype(dtype)  # reference: uniformInt[1,20)
+        qq = rng.integers(1, 20, size=(q, d)).astype(dtype)
+    else:
+        x = (rng.random((n, d), dtype=np.float32) * 1.9 + 0.1).astype(dtype)
+        qq = (rng.random((q, d), dtype=np.float32) * 1.9 + 0.1).astype(dtype)
+    return x, qq
+
+
+def _build(x, **kw):
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    params = ivf_pq.IndexParams(**kw)
+    return ivf_pq.build(params, torch.from_numpy(x).cuda())
+
+
+def _search(index, q, k, **kw):
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    sp = ivf_pq.SearchParams(**kw)
+    d, i = ivf_pq.search(sp, index, torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy()
+
+
+def _min_recall(n_probes, n_lists, dim, pq_dim, pq_bits, elem_bytes=4):
+    p = n_probes / n_lists
+    compression = dim * 8 * elem_bytes / (pq_dim * pq_bits)
+    return min(math.erfc(0.05 * compression / max(p, 0.5)), p)
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "inner_product"])
+@pytest.mark.parametrize("n,d,n_lists,pq_dim,pq_bits,k,n_probes", [
+    (4096, 64, 32, 32, 8, 32, 8),      # reference defaults
+    (3000, 30, 20, 10, 8, 10, 20),     # pq_len 3, rot_dim == dim
+    (5000, 33, 16, 8, 8, 7, 5),        # rot_dim 40 != dim 33 -> random rotation
+    (4096, 64, 32, 64, 5, 16, 6),      # 5-bit codes (generic bit path), pq_len 1
+    (2048, 128, 8, 64, 8, 100, 8),     # k > 64 (4 ranks per lane)
+])
+def test_search_parity_with_oracle_on_same_index(metric, n, d, n_lists, pq_dim, pq_bits, k, n_probes):
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(n, d, 200, seed=n + d)
+    index = _build(x, n_lists=n_lists, metric=metric, pq_dim=pq_dim, pq_bits=pq_bits, kmeans_n_iters=10)
+    gd, gi = _search(index, q, k, n_probes=n_probes)
+    ex = ivf_pq.export_for_oracle(index)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.4f}"
+    assert (gd == od).all(), f"max |d| diff {np.abs(gd - od).max()}"
+
+
+def test_structure_and_codes_match_oracle_encoder():
+    from cuvs_amd.neighbors import ivf_pq
+
+    n, d = 6000, 48
+    x, _ = _gen(n, d, 1, seed=7)
+    index = _build(x, n_lists=24, pq_dim=16, pq_bits=8, kmeans_n_iters=10)
+    ex = ivf_pq.export_for_oracle(index)
+    sizes = ex["list_sizes"]
+    assert sizes.sum() == n == len(index)
+    all_ids = np.concatenate(ex["ids"])
+    assert np.array_equal(np.sort(all_ids), np.arange(n))  # every source row exactly once
+    # in-list order is ascending source id (deterministic layout)
+    for ids in ex["ids"]:
+        assert (np.diff(ids) > 0).all()
+    # every row sits in the list of its nearest centre (L2 argmin, ties -> smaller list)
+    cd = oracle.pairwise(x, ex["centers"])
+    lab = np.argmin(cd, axis=1)
+    got_lab = np.empty(n, np.int64)
+    for L, ids in enumerate(ex["ids"]):
+        got_lab[ids] = L
+    assert (got_lab == lab).mean() > 0.999  # oracle.pairwise adds |x|^2 (different rounding than the argmin kernel)
+    # codes: rotate with the canonical dot, subtract the rotated centre, encode
+    rx = oracle.pairwise(x, ex["rotation"], metric="inner_product")
+    resid = rx - ex["centers_rot"][got_lab]
+    want = oracle.pq_encode(resid, ex["pq_centers"], 8)
+    got = np.empty_like(want)
+    for L, ids in enumerate(ex["ids"]):
+        got[ids] = ex["codes"][L]
+    assert (got == want).all(), f"code mismatch rate {(got != want).mean():.5f}"
+
+
+@pytest.mark.parametrize("lut,acc", [(np.float32, np.float32), (np.float16, np.float32), (np.float16, np.float16),
+                                     (np.uint8, np.float16)])
+def test_recall_reference_defaults(lut, acc):
+    # ann_ivf_pq.cuh defaults; threshold formula :639-646
+    n, d, nq, k = 4096, 64, 1024, 32
+    x, q = _gen(n, d, nq, seed=1234)
+    index = _build(x, n_lists=32, pq_dim=32, pq_bits=8)
+    _, gi = _search(index, q, k, n_probes=20, lut_dtype=lut, internal_distance_dtype=acc)
+    _, ti = oracle.exact_knn(q, x, k)
+    r = oracle.recall(gi, ti)
+    assert r >= _min_recall(20, 32, d, 32, 8), r
+    assert (gi >= 0).all() and (gi < n).all()  # no out-of-bounds / invalid records (:662-678)
+
+
+def test_fp16_lut_close_to_fp32():
+    x, q = _gen(8000, 64, 300, seed=5)
+    index = _build(x, n_lists=32, pq_dim=32)
+    d32, i32 = _search(index, q, 10, n_probes=16)
+    d16, i16 = _search(index, q, 10, n_probes=16, lut_dtype=np.float16, internal_distance_dtype=np.float16)
+    assert oracle.recall(i16, i32) > 0.9
+    np.testing.assert_allclose(d16, d32, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.int8, np.uint8])
+def test_other_dtypes_recall(dtype):
+    n, d, k = 5000, 32, 10
+    x, q = _gen(n, d, 200, seed=3, dtype=dtype)
+    index = _build(x, n_lists=16, pq_dim=32, pq_bits=8)
+    gd, gi = _search(index, q, k, n_probes=16)  # all lists probed: only PQ error remains
+    td, ti = oracle.exact_knn(q.astype(np.float32), x.astype(np.float32), k)
+    assert oracle.recall(gi, ti) > 0.8
+    # distances are reported in the units of the input (scaling undone, ivf_pq_search.cuh:1043)
+    np.testing.assert_allclose(gd[:, 0], td[:, 0], rtol=0.2, atol=0.2 * td[:, 0].mean())
+
+
+def test_extend_and_probe_all():
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(6000, 32, 100, seed=11)
+    index = _build(x[:4000], n_lists=16, pq_dim=32)
+    ids = torch.arange(4000, 6000, dtype=torch.int64, device="cuda")
+    ivf_pq.extend(index, torch.from_numpy(x[4000:]).cuda(), ids)
+    assert len(index) == 6000
+    gd, gi = _search(index, q, 10, n_probes=1000)  # n_probes is clamped to n_lists
+    _, ti = oracle.exact_knn(q, x, 10)
+    assert oracle.recall(gi, ti) > 0.85
+    ex = ivf_pq.export_for_oracle(index)
+    assert np.array_equal(np.sort(np.concatenate(ex["ids"])), np.arange(6000))
+    od, oi = oracle.ivf_pq_search(ex, q, 10, 16)
+    assert (gi == oi).all() and (gd == od).all()
+
+
+def test_small_lists_pad_with_out_of_bounds_record():
+    # fewer candidates than k: the tail is kOutOfBoundsRecord / FLT_MAX (ivf_common.cuh:25-31)
+    x, q = _gen(600, 16, 20, seed=2)
+    index = _build(x, n_lists=64, pq_dim=8, kmeans_n_iters=5)
+    gd, gi = _search(index, q, 50, n_probes=1)
+    assert ((gi == np.iinfo(np.int64).max) == (gd == np.finfo(np.float32).max)).all()
+    assert (gi == np.iinfo(np.int64).max).any()
+
+
+def test_errors():
+    import torch
+    from cuvs_amd._lib import CuvsError
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(1000, 16, 5, seed=1)
+    with pytest.raises(CuvsError):
+        _build(x, n_lists=2000)  # rows < n_lists
+    with pytest.raises(CuvsError):
+        _build(x, n_lists=8, pq_bits=9)
+    index = _build(x, n_lists=8, pq_dim=8)
+    with pytest.raises(CuvsError):
+        _search(index, q[:, :8].copy(), 3)
+    with pytest.raises(CuvsError):
+        ivf_pq.extend(index, torch.from_numpy(x).cuda(), None)  # ids required for a non-empty index
