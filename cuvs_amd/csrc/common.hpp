@@ -240,6 +240,11 @@ inline bool metric_supported(int m)
 inline bool metric_is_l2(int m) { return m == 0 || m == 1 || m == 4 || m == 5; }
 inline bool metric_is_sqrt(int m) { return m == 1 || m == 5; }
 
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+// Disabled by default; cuvsAmdProfileEnable(1) turns it on, cuvsAmdProfileCollect reads and resets it.
+void profile_begin(resources& res, const char* name);
+void profile_end(resources& res, const char* name);
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

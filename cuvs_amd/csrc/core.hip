@@ -59,6 +59,34 @@ void fill_dl_view(DLManagedTensor* out, void* data, DLDataType dt, int64_t rows,
 
 static int g_log_level = CUVS_LOG_LEVEL_INFO;
 
+// ---- per-kernel HIP-event timing (off unless enabled)
+struct prof_rec {
+  std::string name;
+  hipEvent_t start, stop;
+};
+static bool g_prof_on = false;
+static std::vector<prof_rec> g_prof;
+static std::mutex g_prof_mu;
+
+void profile_begin(resources& res, const char* name)
+{
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_rec r;
+  r.name = name;
+  HIP_TRY(hipEventCreate(&r.start));
+  HIP_TRY(hipEventCreate(&r.stop));
+  HIP_TRY(hipEventRecord(r.start, res.stream));
+  g_prof.push_back(r);
+}
+void profile_end(resources& res, const char* name)
+{
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto it = g_prof.rbegin(); it != g_prof.rend(); ++it)
+    if (it->name == name) { HIP_TRY(hipEventRecord(it->stop, res.stream)); return; }
+}
+
 }  // namespace cuvs_amd
 
 using namespace cuvs_amd;
@@ -229,6 +257,32 @@ cuvsError_t cuvsRMMHostAlloc(void** ptr, size_t bytes)
 cuvsError_t cuvsRMMHostFree(void* ptr, size_t)
 {
   return (cuvsError_t)translate_exceptions([=] { HIP_TRY(hipHostFree(ptr)); });
+}
+
+// extension (not in the reference ABI): kernel timing for bench.py
+__attribute__((visibility("default"))) void cuvsAmdProfileEnable(int on) { g_prof_on = on != 0; }
+// sums the elapsed ms of every recorded launch called `name`; returns the launch count; resets those records
+__attribute__((visibility("default"))) int cuvsAmdProfileCollect(const char* name, double* total_ms)
+{
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int count = 0;
+  double total = 0;
+  std::vector<prof_rec> keep;
+  for (auto& r : g_prof) {
+    if (r.name == name) {
+      if (hipEventSynchronize(r.stop) == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) { total += ms; ++count; }
+      }
+      (void)hipEventDestroy(r.start);
+      (void)hipEventDestroy(r.stop);
+    } else {
+      keep.push_back(r);
+    }
+  }
+  g_prof.swap(keep);
+  if (total_ms) *total_ms = total;
+  return count;
 }
 
 cuvsError_t cuvsVersionGet(uint16_t* major, uint16_t* minor, uint16_t* patch)

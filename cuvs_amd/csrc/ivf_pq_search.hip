@@ -9,7 +9,7 @@
 // not by HBM, so the schedule here is different:
 //   * (query, probe) pairs are grouped by list (stable radix sort by list id) and cut into work items of
 //     QPB pairs that probe the SAME list;
-//   * a 512-thread workgroup builds ONE interleaved LUT for its QPB queries in LDS — entry (s, code) holds
+//   * a 1024-thread workgroup builds ONE interleaved LUT for its QPB queries in LDS — entry (s, code) holds
 //     the QPB partial distances side by side (8 bytes: 2 x fp32 or 4 x fp16) — so a single ds_read_b64
 //     gather serves QPB queries, and the list's code bytes are read once per work item (1 KiB coalesced
 //     per wave and chunk from the 64-row interleaved layout, mostly L2/Infinity-Cache hits because work
@@ -25,6 +25,7 @@
 #include "device_utils.hpp"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace cuvs_amd {
 
@@ -33,9 +34,8 @@ void load_range_as_float(resources& res, const void* data, elem_t et, bool is_ho
 
 namespace {
 
-constexpr int kScanThreads = 512;
+constexpr int kScanThreads = 1024;
 constexpr int kScanWaves   = kScanThreads / 64;
-constexpr int kCandCap     = 768;  // per-query candidate buffer (>= tile of 512 + drain threshold 256)
 
 inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
@@ -89,6 +89,12 @@ __global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const u
 template <typename LutT, typename AccT, int QPB>
 struct lut_acc;
 
+// native vector types: one LUT entry is ONE LDS load (b16/b32/b64) and accumulates with packed adds
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
 template <>
 struct lut_acc<float, float, 1> {
   using entry_t = float;
@@ -99,75 +105,81 @@ struct lut_acc<float, float, 1> {
 };
 template <>
 struct lut_acc<float, float, 2> {
-  using entry_t = float2;
-  float2 a      = {0.f, 0.f};
-  __device__ inline void add(entry_t e) { a.x += e.x; a.y += e.y; }
+  using entry_t = f32x2_t;
+  f32x2_t a     = {0.f, 0.f};
+  __device__ inline void add(entry_t e) { a += e; }
   __device__ inline float get(int j) const { return j == 0 ? a.x : a.y; }
-  __device__ static inline entry_t pack(const float (&v)[2]) { return make_float2(v[0], v[1]); }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return f32x2_t{v[0], v[1]}; }
+};
+template <>
+struct lut_acc<__half, float, 1> {
+  using entry_t = _Float16;
+  float a       = 0.f;
+  __device__ inline void add(entry_t e) { a += (float)e; }
+  __device__ inline float get(int) const { return a; }
+  __device__ static inline entry_t pack(const float (&v)[1]) { return (_Float16)v[0]; }
+};
+template <>
+struct lut_acc<__half, __half, 1> {
+  using entry_t = _Float16;
+  _Float16 a    = (_Float16)0.f;
+  __device__ inline void add(entry_t e) { a += e; }
+  __device__ inline float get(int) const { return (float)a; }
+  __device__ static inline entry_t pack(const float (&v)[1]) { return (_Float16)v[0]; }
 };
 template <>
 struct lut_acc<__half, float, 2> {
-  using entry_t = __half2;
-  float2 a      = {0.f, 0.f};
-  __device__ inline void add(entry_t e) { float2 f = __half22float2(e); a.x += f.x; a.y += f.y; }
+  using entry_t = f16x2_t;
+  f32x2_t a     = {0.f, 0.f};
+  __device__ inline void add(entry_t e) { a += __builtin_convertvector(e, f32x2_t); }
   __device__ inline float get(int j) const { return j == 0 ? a.x : a.y; }
-  __device__ static inline entry_t pack(const float (&v)[2]) { return __floats2half2_rn(v[0], v[1]); }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return f16x2_t{(_Float16)v[0], (_Float16)v[1]}; }
 };
 template <>
 struct lut_acc<__half, __half, 2> {
-  using entry_t = __half2;
-  __half2 a     = __floats2half2_rn(0.f, 0.f);
-  __device__ inline void add(entry_t e) { a = __hadd2(a, e); }
-  __device__ inline float get(int j) const { return j == 0 ? __low2float(a) : __high2float(a); }
-  __device__ static inline entry_t pack(const float (&v)[2]) { return __floats2half2_rn(v[0], v[1]); }
-};
-struct alignas(8) half4_t {
-  __half2 lo, hi;
+  using entry_t = f16x2_t;
+  f16x2_t a     = {(_Float16)0.f, (_Float16)0.f};
+  __device__ inline void add(entry_t e) { a += e; }
+  __device__ inline float get(int j) const { return j == 0 ? (float)a.x : (float)a.y; }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return f16x2_t{(_Float16)v[0], (_Float16)v[1]}; }
 };
 template <>
 struct lut_acc<__half, float, 4> {
-  using entry_t = half4_t;
-  float a[4]    = {0.f, 0.f, 0.f, 0.f};
+  using entry_t = f16x4_t;
+  f32x4_t a     = {0.f, 0.f, 0.f, 0.f};
   __device__ inline void add(entry_t e)
   {
-    float2 l = __half22float2(e.lo), h = __half22float2(e.hi);
-    a[0] += l.x; a[1] += l.y; a[2] += h.x; a[3] += h.y;
+    a += __builtin_convertvector(e, f32x4_t);
+    // materialise all four partial sums here (see lut_acc<__half, __half, 4>)
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
   }
   __device__ inline float get(int j) const { return a[j]; }
   __device__ static inline entry_t pack(const float (&v)[4])
   {
-    return half4_t{__floats2half2_rn(v[0], v[1]), __floats2half2_rn(v[2], v[3])};
+    return f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
   }
 };
 template <>
 struct lut_acc<__half, __half, 4> {
-  using entry_t = half4_t;
-  __half2 lo = __floats2half2_rn(0.f, 0.f), hi = __floats2half2_rn(0.f, 0.f);
-  __device__ inline void add(entry_t e) { lo = __hadd2(lo, e.lo); hi = __hadd2(hi, e.hi); }
+  using entry_t = f16x4_t;
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  u32x2_t a     = {0u, 0u};  // four fp16 partial distances
+  // Both packed adds are pinned with volatile asm: left to itself hipcc sinks the upper-half chain
+  // below the scan loop and spills every gathered entry to scratch.
+  __device__ inline void add(entry_t e)
+  {
+    u32x2_t ev = __builtin_bit_cast(u32x2_t, e);
+    asm volatile("v_pk_add_f16 %0, %0, %2\n\tv_pk_add_f16 %1, %1, %3" : "+v"(a.x), "+v"(a.y) : "v"(ev.x), "v"(ev.y));
+  }
   __device__ inline float get(int j) const
   {
-    return j == 0 ? __low2float(lo) : (j == 1 ? __high2float(lo) : (j == 2 ? __low2float(hi) : __high2float(hi)));
+    f16x4_t h = __builtin_bit_cast(f16x4_t, a);
+    return (float)h[j];
   }
   __device__ static inline entry_t pack(const float (&v)[4])
   {
-    return half4_t{__floats2half2_rn(v[0], v[1]), __floats2half2_rn(v[2], v[3])};
+    return f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
   }
-};
-template <>
-struct lut_acc<__half, float, 1> {
-  using entry_t = __half;
-  float a       = 0.f;
-  __device__ inline void add(entry_t e) { a += __half2float(e); }
-  __device__ inline float get(int) const { return a; }
-  __device__ static inline entry_t pack(const float (&v)[1]) { return __float2half_rn(v[0]); }
-};
-template <>
-struct lut_acc<__half, __half, 1> {
-  using entry_t = __half;
-  __half a      = __float2half_rn(0.f);
-  __device__ inline void add(entry_t e) { a = __hadd(a, e); }
-  __device__ inline float get(int) const { return __half2float(a); }
-  __device__ static inline entry_t pack(const float (&v)[1]) { return __float2half_rn(v[0]); }
 };
 
 // ------------------------------------------------------------------ register-resident sorted top list (one wave)
@@ -198,7 +210,8 @@ struct wave_top {
       if ((r >> 6) == e) v = __builtin_amdgcn_readlane(i[e], r & 63);
     return v;
   }
-  // insert wave-uniform candidate (cd, ci); ranks beyond 64*E fall off
+  // insert wave-uniform candidate (cd, ci); ranks beyond 64*E fall off.
+  // The one-lane shift is a DPP wave_shr:1 move (lane 0 takes the carry from the previous slot).
   __device__ inline void insert(float cd, uint32_t ci, int lane)
   {
     int pos = 0;
@@ -207,20 +220,17 @@ struct wave_top {
       bool le = (d[e] < cd) || (d[e] == cd && i[e] <= ci);
       pos += __popcll(__ballot(le));
     }
-    float carry_d    = 0.f;
-    uint32_t carry_i = 0;
+    uint32_t carry_d = 0, carry_i = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      float up_d    = __shfl_up(d[e], 1, kWave);
-      uint32_t up_i = __shfl_up(i[e], 1, kWave);
-      float last_d    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d[e]), 63));
-      uint32_t last_i = __builtin_amdgcn_readlane(i[e], 63);
-      if (lane == 0) { up_d = carry_d; up_i = carry_i; }
-      int rank = e * 64 + lane;
-      if (rank > pos) { d[e] = up_d; i[e] = up_i; }
+      const uint32_t du   = __float_as_uint(d[e]);
+      const uint32_t up_d = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_d, (int)du, 0x138, 0xf, 0xf, false);
+      const uint32_t up_i = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_i, (int)i[e], 0x138, 0xf, 0xf, false);
+      carry_d = __builtin_amdgcn_readlane(du, 63);
+      carry_i = __builtin_amdgcn_readlane(i[e], 63);
+      const int rank = e * 64 + lane;
+      if (rank > pos) { d[e] = __uint_as_float(up_d); i[e] = up_i; }
       else if (rank == pos) { d[e] = cd; i[e] = ci; }
-      carry_d = last_d;
-      carry_i = last_i;
     }
   }
 };
@@ -239,9 +249,34 @@ struct scan_args {
   uint32_t* out_i;               // [n_pairs, k] flat row
   uint32_t n_probes, rot_dim, pq_dim, pq_len, pq_bits, n_chunks, cpc, k;
   int is_ip;
+  uint32_t* query_kth;  // [n_queries] order-preserving key of the best known k-th distance (shared by probes)
+  int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k, 8 no code loads
 };
 
-template <typename LutT, typename AccT, int QPB, bool BITS8, int E>
+// gathers of one 16-byte chunk of 8-bit codes, issued 8 at a time (8 independent ds_reads in flight;
+// 16 at a time spills at the 128-VGPR budget of a 1024-thread workgroup)
+template <typename acc_t>
+__device__ inline void gather16(acc_t& acc, const typename acc_t::entry_t* __restrict__ lut_chunk, const uint4 cw)
+{
+  using entry_t = typename acc_t::entry_t;
+  const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    entry_t e[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int bb  = h * 8 + b;
+      uint32_t code = (ws[bb >> 2] >> ((bb & 3) * 8)) & 0xffu;
+      e[b]          = lut_chunk[(bb << 8) + code];
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc.add(e[b]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// FAST4: pq_bits == 8, pq_dim == 64 (4 full chunks): the four chunk loads of a tile are issued back to back. Otherwise the generic path handles any pq_dim / pq_bits.
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
 __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
 {
   using acc_t   = lut_acc<LutT, AccT, QPB>;
@@ -257,13 +292,14 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   // LDS carve (all offsets multiples of 16)
   entry_t* lut     = reinterpret_cast<entry_t*>(smem);
   size_t off       = ((size_t)lut_elems * sizeof(entry_t) + 15) & ~size_t(15);
-  float* cand_d    = reinterpret_cast<float*>(smem + off);     off += (size_t)QPB * kCandCap * 4;
-  uint32_t* cand_i = reinterpret_cast<uint32_t*>(smem + off);  off += (size_t)QPB * kCandCap * 4;
-  float* qv        = reinterpret_cast<float*>(smem + off);     off += (size_t)QPB * a.rot_dim * 4;
-  float* cv        = reinterpret_cast<float*>(smem + off);     off += (size_t)a.rot_dim * 4;
-  int* cnt         = reinterpret_cast<int*>(smem + off);       off += 16 * 4;
-  float* kth       = reinterpret_cast<float*>(smem + off);     off += 16 * 4;
-  uint32_t* pid    = reinterpret_cast<uint32_t*>(smem + off);
+  {
+    size_t mg = (size_t)QPB * kScanWaves * a.k * 8;  // merge area reuses the LUT region after the scan
+    if (mg > off) off = (mg + 15) & ~size_t(15);
+  }
+  float* qv      = reinterpret_cast<float*>(smem + off);     off += (((size_t)QPB * a.rot_dim * 4) + 15) & ~size_t(15);
+  float* cv      = reinterpret_cast<float*>(smem + off);     off += (((size_t)a.rot_dim * 4) + 15) & ~size_t(15);
+  uint32_t* kthb = reinterpret_cast<uint32_t*>(smem + off);  off += 16 * 4;
+  uint32_t* pid  = reinterpret_cast<uint32_t*>(smem + off);
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -274,9 +310,9 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   const uint32_t len      = a.list_sizes[L];
 
   if (tid < QPB) {
-    pid[tid] = tid < (int)item.count ? a.sorted_pairs[item.first + tid] : 0xffffffffu;
-    cnt[tid] = 0;
-    kth[tid] = INFINITY;
+    const uint32_t p = tid < (int)item.count ? a.sorted_pairs[item.first + tid] : 0xffffffffu;
+    pid[tid]         = p;
+    kthb[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
   }
   __syncthreads();
   // query residuals (L2) or raw rotated queries + list centre (IP)
@@ -294,7 +330,8 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   __syncthreads();
 
   // ---- LUT (create_lut_impl.cuh:17-78): entry (s, c) = QPB partial scores side by side
-  for (uint32_t e = tid; e < lut_elems; e += kScanThreads) {
+#pragma unroll 2
+  for (uint32_t e = tid; e < ((a.dbg & 1) ? 0u : lut_elems); e += kScanThreads) {
     const uint32_t s = e >> a.pq_bits, c = e & (book - 1);
     float sc[QPB];
 #pragma unroll
@@ -322,30 +359,46 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   }
   __syncthreads();
 
-  wave_top<E> top;
-  top.init();
+  // ---- scan: every wave keeps a private sorted top list per query in registers; no workgroup barrier in
+  // the loop. kthb[j] (LDS) is the tightest k-th bound any wave (or an earlier probe of the same query)
+  // has established; only candidates at or below it are looked at.
+  wave_top<E> top[QPB];
+#pragma unroll
+  for (int j = 0; j < QPB; ++j) top[j].init();
 
   const uint32_t n_iter = (len + kScanThreads - 1) / kScanThreads;
   const size_t g0       = (size_t)(base_row >> 6);
+  const uint4* codes16  = reinterpret_cast<const uint4*>(a.codes);
+  const int kr          = (int)a.k - 1;
+
   for (uint32_t it = 0; it < n_iter; ++it) {
-    const uint32_t v = it * kScanThreads + tid;  // in-list position
-    const bool valid = v < len;
+    const uint32_t tile0 = (it * kScanWaves + wave) * 64;  // in-list position of lane 0
+    const uint32_t v     = tile0 + lane;
+    const bool valid     = v < len;
+    if (tile0 >= len) break;  // wave-uniform
     acc_t acc;
-    {
-      const size_t g   = g0 + (size_t)it * kScanWaves + wave;
-      const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + (g * a.n_chunks) * 64 + lane;
-      if (BITS8) {
-        for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-          uint4 cw            = valid ? cp[(size_t)ch * 64] : make_uint4(0, 0, 0, 0);
-          const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
-          const uint32_t s0   = ch * 16;
-          if (s0 + 16 <= a.pq_dim) {
+    if (FAST4) {
+      uint4 cur[4];
+      const uint4* cp = codes16 + ((g0 + (size_t)it * kScanWaves + wave) * 4) * 64 + lane;
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-              uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-              acc.add(lut[((s0 + b) << 8) + code]);
-            }
+      for (int ch = 0; ch < 4; ++ch) cur[ch] = (valid && !(a.dbg & 8)) ? cp[ch * 64] : make_uint4(lane, tid, it, ch);
+      if (!(a.dbg & 2)) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) gather16(acc, lut + ((ch * 16) << 8), cur[ch]);
+      } else {
+        acc.add(lut[cur[0].x & 0xff]);
+      }
+    } else {
+      const size_t g  = g0 + (size_t)it * kScanWaves + wave;
+      const uint4* cp = codes16 + (g * a.n_chunks) * 64 + lane;
+      if (a.pq_bits == 8) {
+        for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+          uint4 cw          = valid ? cp[(size_t)ch * 64] : make_uint4(0, 0, 0, 0);
+          const uint32_t s0 = ch * 16;
+          if (s0 + 16 <= a.pq_dim) {
+            gather16(acc, lut + (s0 << 8), cw);
           } else {
+            const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
             for (uint32_t b = 0; b < 16 && s0 + b < a.pq_dim; ++b) {
               uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
               acc.add(lut[((s0 + b) << 8) + code]);
@@ -360,94 +413,118 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
           for (uint32_t b = 0; b < a.cpc; ++b) {
             uint32_t s = ch * a.cpc + b;
             if (s >= a.pq_dim) break;
-            uint32_t bit = b * a.pq_bits;
-            uint64_t two = (uint64_t)ws[bit >> 5] | ((uint64_t)ws[(bit >> 5) + 1] << 32);
+            uint32_t bit  = b * a.pq_bits;
+            uint64_t two  = (uint64_t)ws[bit >> 5] | ((uint64_t)ws[(bit >> 5) + 1] << 32);
             uint32_t code = (uint32_t)(two >> (bit & 31)) & msk;
             acc.add(lut[(s << a.pq_bits) + code]);
           }
         }
       }
     }
-    // ---- filter + append (wave-aggregated)
+
+    if (a.dbg & 4) continue;
 #pragma unroll
     for (int j = 0; j < QPB; ++j) {
-      const float dj  = acc.get(j);
-      const bool pass = valid && (j < (int)item.count) && (dj <= kth[j]);
-      const unsigned long long m = __ballot(pass);
-      if (m != 0ull) {
-        const int n    = __popcll(m);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        int base       = 0;
-        if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&cnt[j], n);
-        base = __shfl(base, (int)__ffsll((long long)m) - 1, kWave);
-        if (pass) {
-          cand_d[j * kCandCap + base + rank] = dj;
-          cand_i[j * kCandCap + base + rank] = v;
+      if (j >= (int)item.count) break;
+      const float dj       = acc.get(j);
+      const uint32_t bound = kthb[j];  // LDS broadcast read
+      unsigned long long m = __ballot(valid && float_to_key(dj) <= bound);
+      if (m == 0ull) continue;
+      float kd    = top[j].rank_d(kr);
+      uint32_t ki = top[j].rank_i(kr);
+      bool improved = false;
+      while (m != 0ull) {
+        const int src = (int)__ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), src));
+        const uint32_t ci = tile0 + (uint32_t)src;
+        if ((cd < kd) || (cd == kd && ci < ki)) {
+          top[j].insert(cd, ci, lane);
+          kd       = top[j].rank_d(kr);
+          ki       = top[j].rank_i(kr);
+          improved = true;
         }
       }
+      // this wave's k-th best bounds the list's k-th best from above: publish it
+      if (improved && lane == 0 && kd < INFINITY) atomicMin(&kthb[j], float_to_key(kd));
     }
-    __syncthreads();
-    // ---- drain by the owner wave of each query
-    if (wave < QPB && wave < (int)item.count) {
-      const int j = wave;
-      const int n = cnt[j];
-      if (n > kCandCap - kScanThreads || it + 1 == n_iter) {
-        float kd    = top.rank_d(a.k - 1);
-        uint32_t ki = top.rank_i(a.k - 1);
-        for (int b0 = 0; b0 < n; b0 += 64) {
-          float md    = INFINITY;
-          uint32_t mi = 0xffffffffu;
-          if (b0 + lane < n) { md = cand_d[j * kCandCap + b0 + lane]; mi = cand_i[j * kCandCap + b0 + lane]; }
-          unsigned long long m = __ballot((md < kd) || (md == kd && mi < ki));
-          while (m != 0ull) {
-            const int src = (int)__ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(md), src));
-            const uint32_t ci = __builtin_amdgcn_readlane(mi, src);
-            if ((cd < kd) || (cd == kd && ci < ki)) {
-              top.insert(cd, ci, lane);
-              kd = top.rank_d(a.k - 1);
-              ki = top.rank_i(a.k - 1);
-            }
-          }
-        }
-        if (lane == 0) { cnt[j] = 0; kth[j] = kd; }
-      }
-    }
-    __syncthreads();
   }
 
-  // ---- per-pair result (pairs of empty lists get all-invalid rows)
+  // ---- merge the 16 wave lists of every query (the LUT region is free now)
+  __syncthreads();
+  float* mg_d    = reinterpret_cast<float*>(smem);
+  uint32_t* mg_i = reinterpret_cast<uint32_t*>(smem + (size_t)QPB * kScanWaves * a.k * 4);
+#pragma unroll
+  for (int j = 0; j < QPB; ++j) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int r = e * 64 + lane;
+      if (r < (int)a.k) {
+        mg_d[((size_t)j * kScanWaves + wave) * a.k + r] = top[j].d[e];
+        mg_i[((size_t)j * kScanWaves + wave) * a.k + r] = top[j].i[e];
+      }
+    }
+  }
+  __syncthreads();
   if (wave < QPB && wave < (int)item.count) {
-    const size_t o = (size_t)pid[wave] * a.k;
+    const int j = wave;
+    wave_top<E> fin;
+    fin.init();
+    float kd    = INFINITY;
+    uint32_t ki = 0xffffffffu;
+    const int n = kScanWaves * (int)a.k;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+      float md    = INFINITY;
+      uint32_t mi = 0xffffffffu;
+      if (b0 + lane < n) { md = mg_d[(size_t)j * n + b0 + lane]; mi = mg_i[(size_t)j * n + b0 + lane]; }
+      unsigned long long m = __ballot(mi != 0xffffffffu && ((md < kd) || (md == kd && mi < ki)));
+      while (m != 0ull) {
+        const int src = (int)__ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(md), src));
+        const uint32_t ci = __builtin_amdgcn_readlane(mi, src);
+        if ((cd < kd) || (cd == kd && ci < ki)) {
+          fin.insert(cd, ci, lane);
+          kd = fin.rank_d(kr);
+          ki = fin.rank_i(kr);
+        }
+      }
+    }
+    // per-pair result (pairs of empty lists get all-invalid rows)
+    const size_t o = (size_t)pid[j] * a.k;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       int r = e * 64 + lane;
       if (r < (int)a.k) {
-        bool ok      = top.i[e] != 0xffffffffu;
-        a.out_d[o + r] = ok ? top.d[e] : FLT_MAX;
-        a.out_i[o + r] = ok ? base_row + top.i[e] : 0xffffffffu;
+        bool ok        = fin.i[e] != 0xffffffffu;
+        a.out_d[o + r] = ok ? fin.d[e] : FLT_MAX;
+        a.out_i[o + r] = ok ? base_row + fin.i[e] : 0xffffffffu;
       }
     }
+    // tighten the bound shared by the other probes of this query
+    if (lane == 0 && kd < INFINITY) atomicMin(&a.query_kth[pid[j] / a.n_probes], float_to_key(kd));
   }
 }
 
 template <typename LutT, typename AccT, int QPB>
-size_t scan_smem_bytes(const ivf_pq_index& idx)
+size_t scan_smem_bytes(const ivf_pq_index& idx, int k)
 {
   using entry_t = typename lut_acc<LutT, AccT, QPB>::entry_t;
   size_t lut = ((size_t)idx.pq_dim * idx.pq_book * sizeof(entry_t) + 15) & ~size_t(15);
-  return lut + (size_t)QPB * kCandCap * 8 + (size_t)QPB * idx.rot_dim * 4 + (size_t)idx.rot_dim * 4 + 16 * 4 + 16 * 4 +
-         16 * 4;
+  size_t mg  = ((size_t)QPB * kScanWaves * k * 8 + 15) & ~size_t(15);
+  return std::max(lut, mg) + ((((size_t)QPB * idx.rot_dim * 4) + 15) & ~size_t(15)) +
+         ((((size_t)idx.rot_dim * 4) + 15) & ~size_t(15)) + 2 * 16 * 4;
 }
 
-template <typename LutT, typename AccT, int QPB, bool BITS8, int E>
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
 void launch_scan(resources& res, const scan_args& a, size_t smem, unsigned grid)
 {
-  auto kern = pq_scan_kernel<LutT, AccT, QPB, BITS8, E>;
+  auto kern = pq_scan_kernel<LutT, AccT, QPB, FAST4, E>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem));
+  profile_begin(res, "pq_scan_kernel");
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), smem, res.stream, a);
+  profile_end(res, "pq_scan_kernel");
   HIP_TRY(hipGetLastError());
 }
 
@@ -526,7 +603,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const uint32_t n_probes = std::min<uint32_t>(p.n_probes, idx.n_lists);
   const bool lut_half     = p.lut_dtype != 0;  // fp8 LUT requests run on the fp16 LUT (superset precision)
   const bool acc_half     = lut_half && p.internal_distance_dtype == 2;
-  const bool bits8        = idx.pq_bits == 8;
+  const bool bits8        = idx.pq_bits == 8 && idx.pq_dim == 64;  // FAST4 path: 4 full 16-byte chunks
   const bool big_k        = k > 64;
   const size_t lds_cap    = 160 * 1024;
 
@@ -534,12 +611,12 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   int qpb = 0;
   size_t smem = 0;
   if (!lut_half) {
-    if ((smem = scan_smem_bytes<float, float, 2>(idx)) <= lds_cap) qpb = 2;
-    else if ((smem = scan_smem_bytes<float, float, 1>(idx)) <= lds_cap) qpb = 1;
+    if ((smem = scan_smem_bytes<float, float, 2>(idx, k)) <= lds_cap) qpb = 2;
+    else if ((smem = scan_smem_bytes<float, float, 1>(idx, k)) <= lds_cap) qpb = 1;
   } else {
-    if ((smem = scan_smem_bytes<__half, float, 4>(idx)) <= lds_cap) qpb = 4;
-    else if ((smem = scan_smem_bytes<__half, float, 2>(idx)) <= lds_cap) qpb = 2;
-    else if ((smem = scan_smem_bytes<__half, float, 1>(idx)) <= lds_cap) qpb = 1;
+    if ((smem = scan_smem_bytes<__half, float, 4>(idx, k)) <= lds_cap) qpb = 4;
+    else if ((smem = scan_smem_bytes<__half, float, 2>(idx, k)) <= lds_cap) qpb = 2;
+    else if ((smem = scan_smem_bytes<__half, float, 1>(idx, k)) <= lds_cap) qpb = 1;
   }
   CUVS_EXPECTS(qpb > 0, "ivf_pq::search: the PQ look-up table (pq_dim=%u, pq_bits=%u) does not fit 160 KiB of LDS%s",
                idx.pq_dim, idx.pq_bits, lut_half ? "" : "; try lut_dtype=CUDA_R_16F");
@@ -565,6 +642,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<uint32_t> cand_i(res, (size_t)n_pairs_max * k);
   dev_buf<float> top_d(res, (size_t)bs_alloc * k);
   dev_buf<uint32_t> top_i(res, (size_t)bs_alloc * k);
+  dev_buf<uint32_t> query_kth(res, (size_t)bs_alloc);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -581,7 +659,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                        item_off.data());
     hipLaunchKernelGGL(fill_items_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream, pair_off.data(),
                        item_off.data(), (int)idx.n_lists, qpb, items.data());
+    HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     scan_args a;
+    a.query_kth = query_kth.data();
     a.items = items.data(); a.n_items = item_off.data() + idx.n_lists; a.sorted_pairs = sorted_pairs.data();
     a.rot_queries = rot_q.data(); a.centers_rot = idx.centers_rot.data(); a.pq_centers = idx.pq_centers.data();
     a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data(); a.list_sizes = idx.list_sizes.data();
@@ -589,6 +669,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.n_probes = n_probes; a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len;
     a.pq_bits = idx.pq_bits; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.k = (uint32_t)k;
     a.is_ip = idx.metric == M_InnerProduct;
+    a.dbg   = getenv("CUVS_AMD_SCAN_DEBUG") ? atoi(getenv("CUVS_AMD_SCAN_DEBUG")) : 0;
     const unsigned grid = (unsigned)(n_pairs / qpb + idx.n_lists + 1);
     if (!lut_half) {
       if (qpb == 2) launch_scan_qpb<float, float, 2>(res, a, smem, grid, bits8, big_k);
