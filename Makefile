@@ -21,8 +21,8 @@ build/%.o: cuvs_amd/csrc/%.hip $(HDRS)
 cuvs_amd/libcuvs_c.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-oracle/liboracle.so: oracle/oracle.c
-	$(CC) $(CFLAGS) -shared -o $@ $< -lm
+oracle/liboracle.so: $(wildcard oracle/*.c)
+	$(CC) $(CFLAGS) -shared -o $@ $^ -lm
 
 clean:
 	rm -rf build cuvs_amd/libcuvs_c.so oracle/liboracle.so

@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--lut", choices=["f32", "f16"], default="f16",
                     help="LUT / internal distance dtype (both are reference search_params settings)")
+    ap.add_argument("--refine-ratio", type=int, default=2,
+                    help="IVF-PQ returns ratio*k candidates that cuvsRefine re-ranks exactly (reference bench grids "
+                         "use refine_ratio 1..4, python/cuvs_bench/.../cuvs_ivf_pq.yaml); 1 disables refinement")
     ap.add_argument("--trainset-fraction", type=float, default=0.02)
     ap.add_argument("--gt-queries", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,7 +84,7 @@ def main():
 
     import cuvs_amd
     from cuvs_amd._lib import lib
-    from cuvs_amd.neighbors import brute_force, ivf_pq
+    from cuvs_amd.neighbors import brute_force, ivf_pq, refine
 
     res = cuvs_amd.common.Resources()
 
@@ -104,9 +107,20 @@ def main():
     neighbors = torch.empty((args.batch, args.k), dtype=torch.int64, device=dev)
     distances = torch.empty((args.batch, args.k), dtype=torch.float32, device=dev)
 
+    kk = args.k * max(1, args.refine_ratio)
+    cand_i = torch.empty((args.batch, kk), dtype=torch.int64, device=dev)
+    cand_d = torch.empty((args.batch, kk), dtype=torch.float32, device=dev)
+
+    def step():
+        if args.refine_ratio > 1:
+            ivf_pq.search(sp, index, queries, kk, neighbors=cand_i, distances=cand_d, resources=res)
+            refine(data, queries, cand_i, indices=neighbors, distances=distances, metric="sqeuclidean", resources=res)
+        else:
+            ivf_pq.search(sp, index, queries, args.k, neighbors=neighbors, distances=distances, resources=res)
+
     # ------------------------------------------------------------------ timed region
     for _ in range(args.warmup):
-        ivf_pq.search(sp, index, queries, args.k, neighbors=neighbors, distances=distances, resources=res)
+        step()
     lib().cuvsAmdProfileEnable(1)
     torch.cuda.synchronize()
     if world > 1:
@@ -114,7 +128,7 @@ def main():
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        ivf_pq.search(sp, index, queries, args.k, neighbors=neighbors, distances=distances, resources=res)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -200,7 +214,7 @@ def main():
             "config": {"workload": f"IVF-PQ {args.rows}x{args.dim} fp32, pq_dim={args.pq_dim} pq_bits=8 "
                                    f"n_lists={args.n_lists} n_probes={args.n_probes} batch={args.batch} k={args.k}",
                        "parallelism": "replicated index, queries split across ranks" if world > 1 else "single GPU",
-                       "lut_dtype": args.lut, "build_seconds": round(build_s, 1)},
+                       "lut_dtype": args.lut, "refine_ratio": args.refine_ratio, "build_seconds": round(build_s, 1)},
             "recall_at_10": round(recall, 4),
             "roofline": roofline,
             "cpu_baseline": cpu,

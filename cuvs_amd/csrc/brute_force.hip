@@ -30,12 +30,13 @@ __global__ void apply_filter_kernel(float* d, int64_t m, int64_t n_tile, int64_t
                                     int64_t row0, int64_t n_total, const uint32_t* bits, bool bitmap,
                                     float worst)
 {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= m * n_tile) return;
-  int64_t r = idx / n_tile, c = idx % n_tile;
-  int64_t bit = bitmap ? (row0 + r) * n_total + (col0 + c) : (col0 + c);
-  bool keep   = (bits[bit >> 5] >> (bit & 31)) & 1u;
-  if (!keep) d[r * ldo + c] = worst;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < m * n_tile;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx / n_tile, c = idx % n_tile;
+    int64_t bit = bitmap ? (row0 + r) * n_total + (col0 + c) : (col0 + c);
+    bool keep   = (bits[bit >> 5] >> (bit & 31)) & 1u;
+    if (!keep) d[r * ldo + c] = worst;
+  }
 }
 
 template <typename T>
@@ -80,7 +81,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
                               idx.norms.data() ? idx.norms.data() + c0 : nullptr, metric, tile.data(), ldo);
       if (filter_type != NO_FILTER) {
         int64_t total = mr * nc;
-        hipLaunchKernelGGL(apply_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, res.stream,
+        hipLaunchKernelGGL(apply_filter_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 22)), dim3(256), 0, res.stream,
                            tile.data(), mr, nc, ldo, c0, r0, n, filter_bits, filter_type == BITMAP, worst);
       }
       if (n_ct == 1) {
@@ -112,10 +113,11 @@ void bf_build_typed(resources& res, bf_index& idx)
 __global__ void transpose_copy_kernel(const char* src, char* dst, int64_t rows, int64_t cols, int esz)
 {
   // src is column-major [rows, cols] (element (r,c) at c*rows + r); dst row-major
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * cols) return;
-  int64_t r = i / cols, c = i % cols;
-  for (int b = 0; b < esz; ++b) dst[i * esz + b] = src[(c * rows + r) * esz + b];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i / cols, c = i % cols;
+    for (int b = 0; b < esz; ++b) dst[i * esz + b] = src[(c * rows + r) * esz + b];
+  }
 }
 
 }  // namespace
@@ -167,7 +169,7 @@ cuvsError_t cuvsBruteForceBuild(cuvsResources_t res_h, DLManagedTensor* dataset_
     } else if (is_device_accessible(ds) && is_f_contiguous(ds)) {
       idx->owned = dev_buf<char>::persistent((size_t)idx->n * idx->dim * esz);
       int64_t total = idx->n * idx->dim;
-      hipLaunchKernelGGL(transpose_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, res.stream,
+      hipLaunchKernelGGL(transpose_copy_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 22)), dim3(256), 0, res.stream,
                          static_cast<const char*>(dl_data(ds)), idx->owned.data(), idx->n, idx->dim, (int)esz);
       idx->data = idx->owned.data();
     } else if (is_c_contiguous(ds)) {

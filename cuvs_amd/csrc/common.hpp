@@ -245,6 +245,15 @@ inline bool metric_is_sqrt(int m) { return m == 1 || m == 5; }
 void profile_begin(resources& res, const char* name);
 void profile_end(resources& res, const char* name);
 
+// 1-D grid size for 256-thread (or smaller) workgroups. HIP silently truncates launches whose
+// gridDim.x * blockDim.x reaches 2^32 threads, so refuse them here (callers batch or grid-stride).
+inline unsigned grid_blocks(int64_t n_items, int per_block)
+{
+  int64_t b = (n_items + per_block - 1) / per_block;
+  CUVS_EXPECTS(b < (int64_t(1) << 24), "launch of %ld workgroups exceeds the 2^32-thread HIP grid limit", (long)b);
+  return (unsigned)(b > 0 ? b : 1);
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

@@ -30,18 +30,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void row_norms_kernel(const T* __restrict__ x, int64_t n, int64_t dim,
                                                         int64_t ld, float* __restrict__ out, bool sqrt_out)
 {
-  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  int lane     = lane_id();
-  const T* r   = x + row * ld;
-  float acc    = 0.f;
-  for (int64_t j = lane; j < dim; j += kWave) {
-    float v = to_float(r[j]);
-    acc     = __fmaf_rn(v, v, acc);
-  }
+  // grid-stride over rows: HIP limits gridDim.x * blockDim.x to < 2^32 threads, so 100M+ rows cannot get
+  // one wave each from the grid alone
+  const int lane = lane_id();
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+    const T* r = x + row * ld;
+    float acc  = 0.f;
+    for (int64_t j = lane; j < dim; j += kWave) {
+      float v = to_float(r[j]);
+      acc     = __fmaf_rn(v, v, acc);
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
-  if (lane == 0) out[row] = sqrt_out ? sqrtf(acc) : acc;
+    for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
+    if (lane == 0) out[row] = sqrt_out ? sqrtf(acc) : acc;
+  }
 }
 
 // ------------------------------------------------------------------ operand staging
@@ -282,8 +284,7 @@ template <typename T>
 void row_norms(resources& res, const T* x, int64_t n, int64_t dim, int64_t ld, float* out, bool sqrt_out)
 {
   if (n == 0) return;
-  int64_t blocks = (n + 3) / 4;
-  CUVS_EXPECTS(blocks < (int64_t(1) << 31), "row_norms: too many rows");
+  int64_t blocks = std::min<int64_t>((n + 3) / 4, int64_t(1) << 22);  // <= 2^30 threads (HIP grid limit 2^32)
   hipLaunchKernelGGL((row_norms_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, res.stream, x, n, dim, ld,
                      out, sqrt_out);
   HIP_TRY(hipGetLastError());

@@ -14,7 +14,7 @@ namespace cuvs_amd {
 
 namespace {
 
-inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+inline unsigned nblk(int64_t n, int per) { return grid_blocks(n, per); }
 
 // ------------------------------------------------------------------ loading rows as float
 template <typename T>

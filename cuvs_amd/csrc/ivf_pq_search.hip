@@ -37,7 +37,7 @@ namespace {
 constexpr int kScanThreads = 1024;
 constexpr int kScanWaves   = kScanThreads / 64;
 
-inline unsigned nblk(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+inline unsigned nblk(int64_t n, int per) { return grid_blocks(n, per); }
 
 struct work_item {
   uint32_t list;

@@ -131,7 +131,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ x, int64_t ld, int 
   for (int d = threadIdx.x & 63; d < dim; d += 64) out[row * dim + d] = src[d];
 }
 
-inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+inline unsigned blocks_for(int64_t n, int per) { return grid_blocks(n, per); }
 
 int bits_for(uint32_t n)
 {

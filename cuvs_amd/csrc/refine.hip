@@ -1,0 +1,133 @@
+// Exact re-ranking of candidate lists (reference: cpp/src/neighbors/refine/refine_device.cuh builds a
+// throw-away IVF-Flat index to reuse its scan kernel; refine_host.hpp:353-462 is the CPU form).
+// Here: one 256-thread workgroup per query; each wave takes candidates round-robin, its 64 lanes stride over
+// the row (coalesced 256-byte reads) and butterfly-reduce; the n_cand exact distances are then bitonic-sorted
+// in LDS by (distance, id) — the refine_host ordering (std::sort of (distance, id) tuples, :430-460).
+#include "ops.hpp"
+#include "device_utils.hpp"
+
+#include <cuvs/neighbors/refine.h>
+
+#include <cfloat>
+
+namespace cuvs_amd {
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void refine_kernel(const T* __restrict__ data, int64_t n, int64_t dim,
+                                                     const T* __restrict__ queries,
+                                                     const int64_t* __restrict__ cand, int n_cand, int np2, int k,
+                                                     int metric, int64_t* __restrict__ out_i,
+                                                     float* __restrict__ out_d)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int64_t* s_idx  = reinterpret_cast<int64_t*>(smem);           // np2
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(s_idx + np2);   // np2
+  const int64_t q = blockIdx.x;
+  const int lane  = threadIdx.x & 63;
+  const int wave  = threadIdx.x >> 6;
+  const T* qv     = queries + q * dim;
+  const bool ip   = metric == M_InnerProduct;
+  for (int c = threadIdx.x; c < np2; c += 256) { s_key[c] = 0xffffffffu; s_idx[c] = INT64_MAX; }
+  __syncthreads();
+  for (int c = wave; c < n_cand; c += 4) {
+    const int64_t id = cand[q * n_cand + c];
+    if (id < 0 || id >= n) continue;  // wave-uniform
+    const T* row = data + id * dim;
+    float acc    = 0.f;
+    for (int64_t j = lane; j < dim; j += kWave) {
+      float a = to_float(qv[j]), b = to_float(row[j]);
+      if (ip) {
+        acc = __fmaf_rn(a, b, acc);
+      } else {
+        float t = a - b;
+        acc     = __fmaf_rn(t, t, acc);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
+    if (lane == 0) {
+      s_key[c] = ip ? ~float_to_key(acc) : float_to_key(acc);  // inner product: larger is better
+      s_idx[c] = id;
+    }
+  }
+  __syncthreads();
+  block_bitonic_sort<int64_t>(s_key, s_idx, np2);
+  for (int j = threadIdx.x; j < k; j += 256) {
+    const bool ok = s_idx[j] != INT64_MAX;
+    uint32_t key  = ip ? ~s_key[j] : s_key[j];
+    float d       = key_to_float(key);
+    if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d);
+    out_i[q * k + j] = ok ? s_idx[j] : INT64_MAX;
+    out_d[q * k + j] = ok ? d : FLT_MAX;
+  }
+}
+
+template <typename T>
+void refine_typed(resources& res, const void* data, int64_t n, int64_t dim, const void* queries, int64_t m,
+                  const int64_t* cand, int n_cand, int k, int metric, int64_t* out_i, float* out_d)
+{
+  int np2     = next_pow2(n_cand);
+  size_t smem = (size_t)np2 * 12;
+  CUVS_EXPECTS(smem <= 64 * 1024, "refine: too many candidates per query (%d)", n_cand);
+  CUVS_EXPECTS(m < (int64_t(1) << 24), "refine: too many queries in one call");
+  hipLaunchKernelGGL((refine_kernel<T>), dim3((unsigned)m), dim3(256), smem, res.stream,
+                     static_cast<const T*>(data), n, dim, static_cast<const T*>(queries), cand, n_cand, np2, k,
+                     metric, out_i, out_d);
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+void refine(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, const void* queries, int64_t m,
+            const int64_t* cand, int n_cand, int k, int metric, int64_t* out_i, float* out_d)
+{
+  if (m == 0) return;
+  CUVS_EXPECTS(k <= n_cand, "refine: k (%d) must not exceed the number of candidates (%d)", k, n_cand);
+  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct, "refine: unsupported metric %d", metric);
+  switch (et) {
+    case elem_t::f32: refine_typed<float>(res, data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+    case elem_t::f16: refine_typed<__half>(res, data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+    case elem_t::i8: refine_typed<int8_t>(res, data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+    case elem_t::u8: refine_typed<uint8_t>(res, data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+  }
+}
+
+}  // namespace cuvs_amd
+
+using namespace cuvs_amd;
+
+extern "C" cuvsError_t cuvsRefine(cuvsResources_t res_h, DLManagedTensor* dataset_tensor,
+                                  DLManagedTensor* queries_tensor, DLManagedTensor* candidates_tensor,
+                                  cuvsDistanceType metric, DLManagedTensor* indices_tensor,
+                                  DLManagedTensor* distances_tensor)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(dataset_tensor && queries_tensor && candidates_tensor && indices_tensor && distances_tensor,
+                 "null argument");
+    auto& ds = dataset_tensor->dl_tensor;
+    auto& qs = queries_tensor->dl_tensor;
+    auto& cs = candidates_tensor->dl_tensor;
+    auto& is = indices_tensor->dl_tensor;
+    auto& dd = distances_tensor->dl_tensor;
+    CUVS_EXPECTS(is_device_accessible(ds) && is_device_accessible(qs) && is_device_accessible(cs) &&
+                   is_device_accessible(is) && is_device_accessible(dd),
+                 "cuvsRefine: all tensors must be device accessible in this build (the reference's host path is "
+                 "restated in oracle/ only)");
+    CUVS_EXPECTS(ds.ndim == 2 && qs.ndim == 2 && cs.ndim == 2 && is.ndim == 2 && dd.ndim == 2, "tensors must be 2-D");
+    CUVS_EXPECTS(is_c_contiguous(ds) && is_c_contiguous(qs) && is_c_contiguous(cs) && is_c_contiguous(is) &&
+                   is_c_contiguous(dd),
+                 "tensors must be C-contiguous");
+    CUVS_EXPECTS(dtype_is(cs.dtype, kDLInt, 64) && dtype_is(is.dtype, kDLInt, 64), "candidates/indices must be int64");
+    CUVS_EXPECTS(dtype_is(dd.dtype, kDLFloat, 32), "distances should be of type float32");
+    CUVS_EXPECTS(ds.dtype.code == qs.dtype.code && ds.dtype.bits == qs.dtype.bits, "dataset/queries dtype mismatch");
+    CUVS_EXPECTS(ds.shape[1] == qs.shape[1], "dataset/queries dim mismatch");
+    CUVS_EXPECTS(cs.shape[0] == qs.shape[0] && is.shape[0] == qs.shape[0] && dd.shape[0] == qs.shape[0] &&
+                   is.shape[1] == dd.shape[1],
+                 "shape mismatch");
+    refine(res, dl_data(ds), elem_of(ds.dtype), ds.shape[0], ds.shape[1], dl_data(qs), qs.shape[0],
+           static_cast<const int64_t*>(dl_data(cs)), (int)cs.shape[1], (int)is.shape[1], (int)metric,
+           static_cast<int64_t*>(dl_data(is)), static_cast<float*>(dl_data(dd)));
+  });
+}

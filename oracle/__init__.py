@@ -129,3 +129,14 @@ def pq_encode(resid, pq_centers, pq_bits):
     lib().oracle_pq_encode(_p(resid), C.c_int64(resid.shape[0]), C.c_int(resid.shape[1]), _p(pqc), C.c_int(pq_dim),
                            C.c_int(pq_len), C.c_int(pq_bits), _p(out))
     return out
+
+
+def refine(dataset, queries, candidates, k, metric="sqeuclidean"):
+    """CPU twin of cuvsRefine. Returns (distances, indices)."""
+    x, q = _f32(dataset), _f32(queries)
+    cand = np.ascontiguousarray(candidates, dtype=np.int64)
+    oi = np.empty((q.shape[0], k), np.int64)
+    od = np.empty((q.shape[0], k), np.float32)
+    lib().oracle_refine(_p(x), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]), _p(q), C.c_int64(q.shape[0]), _p(cand),
+                        C.c_int(cand.shape[1]), C.c_int(k), C.c_int(_metric(metric)), _p(oi), _p(od))
+    return od, oi
