@@ -1,0 +1,123 @@
+// Pieces shared by the list-major IVF scans (ivf_pq_search.hip, ivf_flat.hip): work-item construction from the
+// (query, probe) pairs grouped by list, and the register-resident per-wave top-k list.
+#pragma once
+#include "ops.hpp"
+#include "device_utils.hpp"
+
+namespace cuvs_amd {
+namespace {
+
+struct work_item {
+  uint32_t list;
+  uint32_t first;  // first position in the list-sorted pair array
+  uint32_t count;  // 1..QPB pairs
+  uint32_t pad;
+};
+
+// per list: number of work items = ceil(cnt / qpb); item_off = exclusive scan (single workgroup)
+__global__ __launch_bounds__(1024) void count_items_kernel(const uint32_t* __restrict__ pair_off, int n_lists,
+                                                           int qpb, uint32_t* __restrict__ item_off)
+{
+  __shared__ int smem[17];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n_lists; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = 0;
+    if (i < n_lists) v = ((int)(pair_off[i + 1] - pair_off[i]) + qpb - 1) / qpb;
+    int total;
+    int excl = block_exclusive_scan(v, smem, &total);
+    if (i < n_lists) item_off[i] = (uint32_t)(carry + excl);
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) item_off[n_lists] = (uint32_t)carry;
+}
+
+__global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ item_off,
+                                  int n_lists, int qpb, work_item* __restrict__ items)
+{
+  int L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= n_lists) return;
+  uint32_t b = pair_off[L], e = pair_off[L + 1];
+  uint32_t w = item_off[L];
+  for (uint32_t p = b; p < e; p += qpb, ++w) {
+    work_item it;
+    it.list  = (uint32_t)L;
+    it.first = p;
+    it.count = min((uint32_t)qpb, e - p);
+    it.pad   = 0;
+    items[w] = it;
+  }
+}
+
+// ------------------------------------------------------------------ register-resident sorted top list (one wave)
+// rank r lives in lane r % 64, slot r / 64; sorted ascending by (distance, row).
+template <int E>
+struct wave_top {
+  float d[E];
+  uint32_t i[E];
+  __device__ inline void init()
+  {
+#pragma unroll
+    for (int e = 0; e < E; ++e) { d[e] = INFINITY; i[e] = 0xffffffffu; }
+  }
+  // value at rank r (wave-uniform r)
+  __device__ inline float rank_d(int r) const
+  {
+    float v = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if ((r >> 6) == e) v = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d[e]), r & 63));
+    return v;
+  }
+  __device__ inline uint32_t rank_i(int r) const
+  {
+    uint32_t v = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if ((r >> 6) == e) v = __builtin_amdgcn_readlane(i[e], r & 63);
+    return v;
+  }
+  // insert wave-uniform candidate (cd, ci); ranks beyond 64*E fall off.
+  // The one-lane shift is a DPP wave_shr:1 move (lane 0 takes the carry from the previous slot).
+  __device__ inline void insert(float cd, uint32_t ci, int lane)
+  {
+    int pos = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      bool le = (d[e] < cd) || (d[e] == cd && i[e] <= ci);
+      pos += __popcll(__ballot(le));
+    }
+    uint32_t carry_d = 0, carry_i = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t du   = __float_as_uint(d[e]);
+      const uint32_t up_d = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_d, (int)du, 0x138, 0xf, 0xf, false);
+      const uint32_t up_i = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_i, (int)i[e], 0x138, 0xf, 0xf, false);
+      carry_d = __builtin_amdgcn_readlane(du, 63);
+      carry_i = __builtin_amdgcn_readlane(i[e], 63);
+      const int rank = e * 64 + lane;
+      if (rank > pos) { d[e] = __uint_as_float(up_d); i[e] = up_i; }
+      else if (rank == pos) { d[e] = cd; i[e] = ci; }
+    }
+  }
+};
+
+
+// (query, probe) pairs grouped by list and cut into work items of up to `qpb` pairs of ONE list.
+// probes: [n_pairs] list id of pair p (p = query * n_probes + probe rank). Outputs: sorted_pairs[n_pairs],
+// items[<= n_pairs / qpb + n_lists + 1], item_off[n_lists] = number of items (device scalar).
+inline void build_work_items(resources& res, const uint32_t* probes, int64_t n_pairs, uint32_t n_lists, int qpb,
+                             uint32_t* sorted_pairs, uint32_t* pair_off, uint32_t* item_off, work_item* items)
+{
+  group_by_label(res, probes, n_pairs, n_lists, sorted_pairs, pair_off);
+  hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off, (int)n_lists, qpb, item_off);
+  hipLaunchKernelGGL(fill_items_kernel, dim3(grid_blocks(n_lists, 256)), dim3(256), 0, res.stream, pair_off,
+                     item_off, (int)n_lists, qpb, items);
+}
+
+}  // namespace
+}  // namespace cuvs_amd

@@ -1,0 +1,693 @@
+// IVF-Flat on MI355X: index build/extend, list-major scan, C ABI (drop-in for c/src/neighbors/ivf_flat.cpp).
+//
+// Reference: cpp/src/neighbors/ivf_flat/ivf_flat_build.cuh (build :394-446, extend :163-390, interleave
+// pattern ivf_flat.hpp:184-200), ivf_flat_search.cuh (search_impl :41-309), the scan kernel
+// detail/jit_lto_kernels/interleaved_scan_impl.cuh:71-206 with load_and_compute_dist_impl.cuh:690-738 and
+// metric_impl.cuh:12-49 (distance accumulated in dimension order with fma, unexpanded L2 for both L2
+// variants, ivf_flat_interleaved_scan_jit.cuh:267-278).
+//
+// MI355X design (same schedule as ivf_pq_search.hip): all lists in one flat allocation, rows interleaved in
+// groups of 64 (one wave64 lane per row, 16-byte chunks -> 1 KiB coalesced per wave load); (query, probe)
+// pairs are grouped by list and 8 queries that probe the same list share one pass over its rows: the query
+// tile sits in LDS as [dim][8] so two broadcast ds_read_b128 feed 8 fma chains per loaded element. Per-wave
+// register top lists + shared k-th bounds as in the PQ scan. In-list order is ascending source id.
+#include "ivf_common.hpp"
+
+#include <cuvs/neighbors/ivf_flat.h>
+
+#include <algorithm>
+#include <cfloat>
+
+namespace cuvs_amd {
+
+void load_range_as_float(resources& res, const void* data, elem_t et, bool is_host, int64_t dim, int64_t r0,
+                         int64_t cnt, float* out);
+void load_gather_as_float(resources& res, const void* data, elem_t et, bool is_host, int64_t dim,
+                          const uint32_t* d_ids, int64_t cnt, float* out);
+
+struct ivf_flat_index {
+  int metric   = 0;
+  elem_t dtype = elem_t::f32;
+  uint32_t n_lists = 0, dim = 0;
+  uint32_t veclen = 4, n_chunks = 0;  // elements per 16-byte chunk; chunks per row
+  int64_t size = 0, padded_rows = 0;
+  dev_buf<float> centers;       // [n_lists, dim]
+  dev_buf<float> center_norms;  // [n_lists]
+  dev_buf<uint8_t> data;        // [padded_rows / 64, n_chunks, 64, 16 bytes]
+  dev_buf<int64_t> indices;     // [padded_rows]
+  dev_buf<uint32_t> list_sizes, list_offsets;
+  std::vector<uint32_t> h_list_sizes, h_list_offsets;
+};
+
+namespace {
+
+constexpr int kFlatThreads = 512;
+constexpr int kFlatWaves   = kFlatThreads / 64;
+constexpr int kFlatQPB     = 8;
+
+__global__ void strided_ids_kernel2(uint32_t* ids, int64_t n, int64_t stride)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = (uint32_t)(i * stride);
+}
+
+struct pack_args {
+  const void* src;           // device rows [*, dim] of T
+  const uint32_t* perm;      // sorted new-row ids (whole extend call); src row = perm[j] - src_row0 when src_is_batch
+  const uint32_t* labels;
+  const uint32_t* new_off;
+  const uint32_t* old_sizes;
+  const uint32_t* list_off;
+  const int64_t* new_ids;
+  int64_t id_base, j0, batch;
+  int src_is_batch;          // 1: src holds rows j0.. in sorted order (host staging); 0: src is the full device array
+  uint32_t dim, veclen, n_chunks;
+  uint8_t* data;
+  int64_t* indices;
+};
+
+// one thread per (sorted row, chunk): 16 bytes of the row -> interleaved slot
+template <typename T>
+__global__ void pack_rows_kernel(pack_args a)
+{
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.batch * a.n_chunks) return;
+  int64_t jb  = t / a.n_chunks;
+  uint32_t ch = (uint32_t)(t % a.n_chunks);
+  int64_t j   = a.j0 + jb;
+  uint32_t row = a.perm[j];
+  uint32_t L   = a.labels[row];
+  int64_t fr   = (int64_t)a.list_off[L] + a.old_sizes[L] + (j - (int64_t)a.new_off[L]);
+  const T* src = static_cast<const T*>(a.src) + (a.src_is_batch ? jb : (int64_t)row) * a.dim;
+  alignas(16) T tmp[16 / sizeof(T)];
+#pragma unroll
+  for (uint32_t e = 0; e < 16 / sizeof(T); ++e) {
+    uint32_t d = ch * a.veclen + e;
+    tmp[e]     = d < a.dim ? src[d] : T(0);
+  }
+  size_t addr = (((size_t)(fr >> 6) * a.n_chunks + ch) * 64 + (size_t)(fr & 63)) * 16;
+  *reinterpret_cast<uint4*>(a.data + addr) = *reinterpret_cast<const uint4*>(tmp);
+  if (ch == 0) a.indices[fr] = a.new_ids ? a.new_ids[row] : a.id_base + (int64_t)row;
+}
+
+__global__ void relocate_flat_lists_kernel(const uint8_t* __restrict__ old_data, const int64_t* __restrict__ old_ids,
+                                           const uint32_t* __restrict__ old_off, const uint32_t* __restrict__ old_sizes,
+                                           const uint32_t* __restrict__ new_off, uint32_t n_chunks,
+                                           uint8_t* __restrict__ data, int64_t* __restrict__ ids)
+{
+  const uint32_t L  = blockIdx.x;
+  const uint32_t sz = old_sizes[L];
+  const int64_t so = old_off[L], dn = new_off[L];
+  for (uint32_t i = threadIdx.x; i < sz; i += blockDim.x) ids[dn + i] = old_ids[so + i];
+  const size_t n16 = (size_t)((sz + 63) / 64) * n_chunks * 64;
+  const uint4* s = reinterpret_cast<const uint4*>(old_data + (size_t)(so >> 6) * n_chunks * 1024);
+  uint4* d       = reinterpret_cast<uint4*>(data + (size_t)(dn >> 6) * n_chunks * 1024);
+  for (size_t i = threadIdx.x; i < n16; i += blockDim.x) d[i] = s[i];
+}
+
+struct flat_scan_args {
+  const work_item* items;
+  const uint32_t* n_items;
+  const uint32_t* sorted_pairs;
+  const void* queries;  // [n_queries, dim] of T (raw values)
+  const uint8_t* data;
+  const uint32_t* list_offsets;
+  const uint32_t* list_sizes;
+  float* out_d;
+  uint32_t* out_i;
+  uint32_t* query_kth;
+  uint32_t n_probes, dim, veclen, n_chunks, k;
+  int is_ip;
+};
+
+template <typename T, int E>
+__global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_args a)
+{
+  constexpr int QPB = kFlatQPB;
+  constexpr int VL  = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t w = blockIdx.x;
+  if (w >= *a.n_items) return;
+  const work_item item = a.items[w];
+
+  const uint32_t dim_pad = a.n_chunks * VL;
+  size_t off             = (size_t)dim_pad * QPB * 4;
+  {
+    size_t mg = (size_t)QPB * kFlatWaves * a.k * 8;
+    if (mg > off) off = (mg + 15) & ~size_t(15);
+  }
+  float* qs      = reinterpret_cast<float*>(smem);  // [dim_pad][QPB]
+  uint32_t* kthb = reinterpret_cast<uint32_t*>(smem + off);
+  uint32_t* pid  = kthb + 16;
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t L        = item.list;
+  const uint32_t base_row = a.list_offsets[L];
+  const uint32_t len      = a.list_sizes[L];
+
+  if (tid < QPB) {
+    const uint32_t p = tid < (int)item.count ? a.sorted_pairs[item.first + tid] : 0xffffffffu;
+    pid[tid]         = p;
+    kthb[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
+  }
+  __syncthreads();
+  for (uint32_t t = tid; t < dim_pad * QPB; t += kFlatThreads) {
+    uint32_t d = t / QPB, j = t % QPB;
+    float v = 0.f;
+    if (j < item.count && d < a.dim) {
+      uint32_t q = pid[j] / a.n_probes;
+      v          = to_float(static_cast<const T*>(a.queries)[(size_t)q * a.dim + d]);
+    }
+    qs[t] = v;
+  }
+  __syncthreads();
+
+  wave_top<E> top[QPB];
+#pragma unroll
+  for (int j = 0; j < QPB; ++j) top[j].init();
+  const int kr          = (int)a.k - 1;
+  const size_t g0       = (size_t)(base_row >> 6);
+  const uint4* data16   = reinterpret_cast<const uint4*>(a.data);
+  const float4* qs4     = reinterpret_cast<const float4*>(qs);
+  const uint32_t n_tile = (len + 63) / 64;
+
+  for (uint32_t tile = wave; tile < n_tile; tile += kFlatWaves) {
+    const uint32_t tile0 = tile * 64;
+    const uint32_t v     = tile0 + lane;
+    const bool valid     = v < len;
+    float acc[QPB];
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) acc[j] = 0.f;
+    const uint4* cp = data16 + ((g0 + tile) * a.n_chunks) * 64 + lane;
+    for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+      const uint4 cw = cp[(size_t)ch * 64];  // padded rows of a group are zero-filled: always readable
+      const T* el    = reinterpret_cast<const T*>(&cw);
+#pragma unroll
+      for (int e = 0; e < VL; ++e) {
+        const float x   = to_float(el[e]);
+        const float4 qa = qs4[(ch * VL + e) * 2];
+        const float4 qb = qs4[(ch * VL + e) * 2 + 1];
+        const float qv[QPB] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        if (!a.is_ip) {
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) {
+            float t = x - qv[j];
+            acc[j]  = __fmaf_rn(t, t, acc[j]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) acc[j] = __fmaf_rn(x, qv[j], acc[j]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) {
+      if (j >= (int)item.count) break;
+      const float dj       = a.is_ip ? -acc[j] : acc[j];  // smaller is better
+      const uint32_t bound = kthb[j];
+      unsigned long long m = __ballot(valid && float_to_key(dj) <= bound);
+      if (m == 0ull) continue;
+      float kd      = top[j].rank_d(kr);
+      uint32_t ki   = top[j].rank_i(kr);
+      bool improved = false;
+      while (m != 0ull) {
+        const int src = (int)__ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), src));
+        const uint32_t ci = tile0 + (uint32_t)src;
+        if ((cd < kd) || (cd == kd && ci < ki)) {
+          top[j].insert(cd, ci, lane);
+          kd       = top[j].rank_d(kr);
+          ki       = top[j].rank_i(kr);
+          improved = true;
+        }
+      }
+      if (improved && lane == 0 && kd < INFINITY) atomicMin(&kthb[j], float_to_key(kd));
+    }
+  }
+
+  // ---- merge the wave lists (the query tile is no longer needed)
+  __syncthreads();
+  float* mg_d    = reinterpret_cast<float*>(smem);
+  uint32_t* mg_i = reinterpret_cast<uint32_t*>(smem + (size_t)QPB * kFlatWaves * a.k * 4);
+#pragma unroll
+  for (int j = 0; j < QPB; ++j) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int r = e * 64 + lane;
+      if (r < (int)a.k) {
+        mg_d[((size_t)j * kFlatWaves + wave) * a.k + r] = top[j].d[e];
+        mg_i[((size_t)j * kFlatWaves + wave) * a.k + r] = top[j].i[e];
+      }
+    }
+  }
+  __syncthreads();
+  if (wave < QPB && wave < (int)item.count) {
+    const int j = wave;
+    wave_top<E> fin;
+    fin.init();
+    float kd    = INFINITY;
+    uint32_t ki = 0xffffffffu;
+    const int n = kFlatWaves * (int)a.k;
+    for (int b0 = 0; b0 < n; b0 += 64) {
+      float md    = INFINITY;
+      uint32_t mi = 0xffffffffu;
+      if (b0 + lane < n) { md = mg_d[(size_t)j * n + b0 + lane]; mi = mg_i[(size_t)j * n + b0 + lane]; }
+      unsigned long long m = __ballot(mi != 0xffffffffu && ((md < kd) || (md == kd && mi < ki)));
+      while (m != 0ull) {
+        const int src = (int)__ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(md), src));
+        const uint32_t ci = __builtin_amdgcn_readlane(mi, src);
+        if ((cd < kd) || (cd == kd && ci < ki)) {
+          fin.insert(cd, ci, lane);
+          kd = fin.rank_d(kr);
+          ki = fin.rank_i(kr);
+        }
+      }
+    }
+    const size_t o = (size_t)pid[j] * a.k;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      int r = e * 64 + lane;
+      if (r < (int)a.k) {
+        bool ok        = fin.i[e] != 0xffffffffu;
+        a.out_d[o + r] = ok ? fin.d[e] : FLT_MAX;
+        a.out_i[o + r] = ok ? base_row + fin.i[e] : 0xffffffffu;
+      }
+    }
+    if (lane == 0 && kd < INFINITY) atomicMin(&a.query_kth[pid[j] / a.n_probes], float_to_key(kd));
+  }
+}
+
+__global__ void flat_postprocess_kernel(const uint32_t* __restrict__ pos, const float* __restrict__ d_in, int64_t n,
+                                        const int64_t* __restrict__ indices, int metric,
+                                        int64_t* __restrict__ neighbors, float* __restrict__ distances)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t p   = pos[i];
+  neighbors[i] = p == 0xffffffffu ? INT64_MAX : indices[p];
+  float d      = d_in[i];
+  if (p == 0xffffffffu) d = FLT_MAX;
+  else if (metric == M_InnerProduct) d = -d;
+  else if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d);
+  distances[i] = d;
+}
+
+template <typename T>
+void launch_flat_scan(resources& res, const flat_scan_args& a, size_t smem, unsigned grid, bool big_k)
+{
+  if (big_k) {
+    auto kern = ivf_flat_scan_kernel<T, 4>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatThreads), smem, res.stream, a);
+  } else {
+    auto kern = ivf_flat_scan_kernel<T, 1>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatThreads), smem, res.stream, a);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename T>
+void launch_pack(resources& res, const pack_args& a)
+{
+  int64_t total = a.batch * a.n_chunks;
+  hipLaunchKernelGGL((pack_rows_kernel<T>), dim3(grid_blocks(total, 256)), dim3(256), 0, res.stream, a);
+}
+
+}  // namespace
+
+void ivf_flat_extend(resources& res, ivf_flat_index& idx, const void* data, elem_t et, int64_t n_new, bool is_host,
+                     const int64_t* new_ids, bool ids_on_host)
+{
+  if (n_new == 0) return;
+  CUVS_EXPECTS(et == idx.dtype, "extend: vector dtype differs from the index dtype");
+  CUVS_EXPECTS(new_ids != nullptr || idx.size == 0, "You must pass data indices when the index is non-empty.");
+  CUVS_EXPECTS(idx.size + n_new < (int64_t(1) << 32) - 64 * (int64_t)idx.n_lists, "index too large for 32-bit row offsets");
+  const int64_t dim = idx.dim;
+  const size_t esz  = elem_size(et);
+  dev_buf<int64_t> ids_dev;
+  if (new_ids && ids_on_host) {
+    ids_dev = dev_buf<int64_t>(res, n_new);
+    copy_async(res, ids_dev.data(), new_ids, n_new * sizeof(int64_t));
+    new_ids = ids_dev.data();
+  }
+  // labels (L2 argmin on mapped floats; ivf_flat_build.cuh:179-200 predicts with the index metric, the coarse
+  // quantizer here is always trained and queried in L2 like ivf_pq's)
+  dev_buf<uint32_t> labels(res, n_new);
+  const int64_t batch_rows = std::max<int64_t>(1024, std::min<int64_t>(n_new, (int64_t(1) << 28) / dim));
+  {
+    dev_buf<float> xb(res, (size_t)std::min(batch_rows, n_new) * dim);
+    for (int64_t r0 = 0; r0 < n_new; r0 += batch_rows) {
+      int64_t cnt = std::min(batch_rows, n_new - r0);
+      load_range_as_float(res, data, et, is_host, dim, r0, cnt, xb.data());
+      fused_l2_argmin<float>(res, xb.data(), cnt, dim, idx.centers.data(), idx.n_lists, dim, idx.center_norms.data(),
+                             labels.data() + r0, nullptr);
+    }
+  }
+  dev_buf<uint32_t> perm(res, n_new), new_off(res, idx.n_lists + 1);
+  group_by_label(res, labels.data(), n_new, idx.n_lists, perm.data(), new_off.data());
+  std::vector<uint32_t> h_new_off = to_host(res, new_off.data(), idx.n_lists + 1);
+  std::vector<uint32_t> sizes(idx.n_lists), offs(idx.n_lists + 1);
+  int64_t total = 0;
+  for (uint32_t L = 0; L < idx.n_lists; ++L) {
+    sizes[L] = idx.h_list_sizes[L] + (h_new_off[L + 1] - h_new_off[L]);
+    offs[L]  = (uint32_t)total;
+    total += round_up(sizes[L], 64);
+  }
+  offs[idx.n_lists] = (uint32_t)total;
+  auto ndata    = dev_buf<uint8_t>::persistent((size_t)total * idx.n_chunks * 16);
+  auto nindices = dev_buf<int64_t>::persistent((size_t)total);
+  HIP_TRY(hipMemsetAsync(ndata.data(), 0, ndata.bytes(), res.stream));
+  HIP_TRY(hipMemsetAsync(nindices.data(), 0xff, nindices.bytes(), res.stream));
+  dev_buf<uint32_t> d_list_off(res, idx.n_lists + 1);
+  copy_async(res, d_list_off.data(), offs.data(), offs.size() * sizeof(uint32_t));
+  if (idx.size > 0) {
+    hipLaunchKernelGGL(relocate_flat_lists_kernel, dim3(idx.n_lists), dim3(256), 0, res.stream, idx.data.data(),
+                       idx.indices.data(), idx.list_offsets.data(), idx.list_sizes.data(), d_list_off.data(),
+                       idx.n_chunks, ndata.data(), nindices.data());
+  }
+  pack_args a;
+  a.perm = perm.data(); a.labels = labels.data(); a.new_off = new_off.data(); a.old_sizes = idx.list_sizes.data();
+  a.list_off = d_list_off.data(); a.new_ids = new_ids; a.id_base = idx.size;
+  a.dim = idx.dim; a.veclen = idx.veclen; a.n_chunks = idx.n_chunks; a.data = ndata.data(); a.indices = nindices.data();
+  auto launch = [&](const pack_args& pa) {
+    switch (et) {
+      case elem_t::f32: launch_pack<float>(res, pa); break;
+      case elem_t::f16: launch_pack<__half>(res, pa); break;
+      case elem_t::i8: launch_pack<int8_t>(res, pa); break;
+      case elem_t::u8: launch_pack<uint8_t>(res, pa); break;
+    }
+  };
+  const int64_t pb = std::max<int64_t>(64, (int64_t(1) << 22));  // rows per pack launch
+  if (!is_host) {
+    a.src = data; a.src_is_batch = 0;
+    for (int64_t j0 = 0; j0 < n_new; j0 += pb) {
+      a.j0 = j0; a.batch = std::min(pb, n_new - j0);
+      launch(a);
+    }
+  } else {
+    std::vector<uint32_t> h_perm = to_host(res, perm.data(), n_new);
+    const int64_t hb = std::max<int64_t>(1, std::min<int64_t>(n_new, (int64_t(1) << 28) / (dim * (int64_t)esz)));
+    std::vector<char> host((size_t)hb * dim * esz);
+    dev_buf<char> stage(res, host.size());
+    const char* src = static_cast<const char*>(data);
+    for (int64_t j0 = 0; j0 < n_new; j0 += hb) {
+      int64_t cnt = std::min(hb, n_new - j0);
+      for (int64_t i = 0; i < cnt; ++i)
+        memcpy(host.data() + (size_t)i * dim * esz, src + (size_t)h_perm[j0 + i] * dim * esz, dim * esz);
+      copy_async(res, stage.data(), host.data(), (size_t)cnt * dim * esz);
+      a.src = stage.data(); a.src_is_batch = 1; a.j0 = j0; a.batch = cnt;
+      launch(a);
+      sync(res);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  sync(res);
+  idx.data    = std::move(ndata);
+  idx.indices = std::move(nindices);
+  copy_async(res, idx.list_sizes.data(), sizes.data(), sizes.size() * sizeof(uint32_t));
+  copy_async(res, idx.list_offsets.data(), offs.data(), offs.size() * sizeof(uint32_t));
+  sync(res);
+  idx.h_list_sizes   = sizes;
+  idx.h_list_offsets = offs;
+  idx.size += n_new;
+  idx.padded_rows = total;
+}
+
+std::unique_ptr<ivf_flat_index> ivf_flat_build(resources& res, const cuvsIvfFlatIndexParams& p, const void* data,
+                                               elem_t et, int64_t n, int64_t dim, bool is_host)
+{
+  CUVS_EXPECTS(n > 0 && dim > 0, "empty dataset");
+  CUVS_EXPECTS(n >= p.n_lists, "number of rows can't be less than n_lists");
+  const int metric = (int)p.metric;
+  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct,
+               "ivf_flat: unsupported metric %d (L2 and inner product are built)", metric);
+  auto idx      = std::make_unique<ivf_flat_index>();
+  idx->metric   = metric;
+  idx->dtype    = et;
+  idx->n_lists  = p.n_lists;
+  idx->dim      = (uint32_t)dim;
+  idx->veclen   = (uint32_t)(16 / elem_size(et));
+  idx->n_chunks = (uint32_t)ceil_div(dim, idx->veclen);
+  idx->list_sizes   = dev_buf<uint32_t>::persistent(p.n_lists);
+  idx->list_offsets = dev_buf<uint32_t>::persistent(p.n_lists + 1);
+  HIP_TRY(hipMemsetAsync(idx->list_sizes.data(), 0, idx->list_sizes.bytes(), res.stream));
+  HIP_TRY(hipMemsetAsync(idx->list_offsets.data(), 0, idx->list_offsets.bytes(), res.stream));
+  idx->h_list_sizes.assign(p.n_lists, 0);
+  idx->h_list_offsets.assign(p.n_lists + 1, 0);
+  // trainset: every ratio-th row (ivf_flat_build.cuh:409-425 uses a strided subsample as well)
+  const int64_t ratio   = std::max<int64_t>(1, n / std::max<int64_t>((int64_t)(p.kmeans_trainset_fraction * n), p.n_lists));
+  const int64_t n_train = n / ratio;
+  dev_buf<float> trainset(res, (size_t)n_train * dim);
+  {
+    dev_buf<uint32_t> ids(res, n_train);
+    hipLaunchKernelGGL(strided_ids_kernel2, dim3(grid_blocks(n_train, 256)), dim3(256), 0, res.stream, ids.data(),
+                       n_train, ratio);
+    load_gather_as_float(res, data, et, is_host, dim, ids.data(), n_train, trainset.data());
+  }
+  idx->centers      = dev_buf<float>::persistent((size_t)p.n_lists * dim);
+  idx->center_norms = dev_buf<float>::persistent(p.n_lists);
+  kmeans_params kp;
+  kp.n_iters = (int)p.kmeans_n_iters;
+  kmeans_balanced_fit(res, trainset.data(), n_train, dim, (int)p.n_lists, kp, idx->centers.data());
+  row_norms<float>(res, idx->centers.data(), p.n_lists, dim, dim, idx->center_norms.data(), false);
+  trainset.release();
+  if (p.add_data_on_build) ivf_flat_extend(res, *idx, data, et, n, is_host, nullptr, false);
+  sync(res);
+  return idx;
+}
+
+void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probes_in, const void* queries, elem_t et,
+                     int64_t n_queries, int k, int64_t* neighbors, float* distances)
+{
+  CUVS_EXPECTS(k > 0 && k <= 256, "ivf_flat::search: k must be in [1, 256]");
+  CUVS_EXPECTS(n_probes_in > 0, "n_probes must be positive");
+  CUVS_EXPECTS(et == idx.dtype, "queries dtype differs from the index dtype");
+  if (n_queries == 0) return;
+  const uint32_t n_probes = std::min<uint32_t>(n_probes_in, idx.n_lists);
+  const int qpb           = kFlatQPB;
+  const bool big_k        = k > 64;
+  const uint32_t dim_pad  = idx.n_chunks * idx.veclen;
+  size_t smem = std::max<size_t>((size_t)dim_pad * qpb * 4, (((size_t)qpb * kFlatWaves * k * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;
+  CUVS_EXPECTS(smem <= 160 * 1024, "ivf_flat::search: dim %u too large for the LDS query tile", idx.dim);
+
+  int64_t max_batch = 1 << 15;
+  {
+    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k * 8 + idx.dim * 4;
+    max_batch     = std::min(max_batch, std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q));
+  }
+  const int64_t bs = std::min<int64_t>(max_batch, n_queries);
+  const int64_t np_max = bs * n_probes;
+  dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
+  dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, idx.n_lists + 1),
+    item_off(res, idx.n_lists + 1), cand_i(res, (size_t)np_max * k), top_i(res, (size_t)bs * k), query_kth(res, bs);
+  dev_buf<work_item> items(res, (size_t)(np_max / qpb + idx.n_lists + 1));
+  dev_buf<float> cand_d(res, (size_t)np_max * k), top_d(res, (size_t)bs * k);
+  const size_t esz = elem_size(et);
+
+  for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
+    const int64_t nq      = std::min(max_batch, n_queries - q0);
+    const int64_t n_pairs = nq * n_probes;
+    const char* qptr      = static_cast<const char*>(queries) + (size_t)q0 * idx.dim * esz;
+    load_range_as_float(res, queries, et, false, idx.dim, q0, nq, qf.data());
+    // coarse search (ivf_flat_search.cuh:104-187)
+    if (idx.metric == M_InnerProduct) {
+      pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim, idx.dim,
+                                      nullptr, nullptr, M_InnerProduct, dist.data(), idx.n_lists);
+      select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
+                                   probes.data(), false);
+    } else {
+      row_norms<float>(res, qf.data(), nq, idx.dim, idx.dim, qn.data(), false);
+      pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim, idx.dim,
+                                      qn.data(), idx.center_norms.data(), M_L2Expanded, dist.data(), idx.n_lists);
+      select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
+                                   probes.data(), true);
+    }
+    build_work_items(res, probes.data(), n_pairs, idx.n_lists, qpb, sorted_pairs.data(), pair_off.data(),
+                     item_off.data(), items.data());
+    HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
+    flat_scan_args a;
+    a.items = items.data(); a.n_items = item_off.data() + idx.n_lists; a.sorted_pairs = sorted_pairs.data();
+    a.queries = qptr; a.data = idx.data.data(); a.list_offsets = idx.list_offsets.data();
+    a.list_sizes = idx.list_sizes.data(); a.out_d = cand_d.data(); a.out_i = cand_i.data();
+    a.query_kth = query_kth.data(); a.n_probes = n_probes; a.dim = idx.dim; a.veclen = idx.veclen;
+    a.n_chunks = idx.n_chunks; a.k = (uint32_t)k; a.is_ip = idx.metric == M_InnerProduct;
+    const unsigned grid = (unsigned)(n_pairs / qpb + idx.n_lists + 1);
+    profile_begin(res, "ivf_flat_scan_kernel");
+    switch (et) {
+      case elem_t::f32: launch_flat_scan<float>(res, a, smem, grid, big_k); break;
+      case elem_t::f16: launch_flat_scan<__half>(res, a, smem, grid, big_k); break;
+      case elem_t::i8: launch_flat_scan<int8_t>(res, a, smem, grid, big_k); break;
+      case elem_t::u8: launch_flat_scan<uint8_t>(res, a, smem, grid, big_k); break;
+    }
+    profile_end(res, "ivf_flat_scan_kernel");
+    select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
+                                 k, top_d.data(), top_i.data(), true);
+    hipLaunchKernelGGL(flat_postprocess_kernel, dim3(grid_blocks(nq * k, 256)), dim3(256), 0, res.stream, top_i.data(),
+                       top_d.data(), nq * k, idx.indices.data(), idx.metric, neighbors + q0 * k, distances + q0 * k);
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cuvs_amd
+
+using namespace cuvs_amd;
+
+namespace {
+ivf_flat_index& get_flat(cuvsIvfFlatIndex_t index)
+{
+  CUVS_EXPECTS(index != nullptr && index->addr != 0, "IVF-Flat index is not built");
+  return *reinterpret_cast<ivf_flat_index*>(index->addr);
+}
+}  // namespace
+
+extern "C" {
+
+cuvsError_t cuvsIvfFlatIndexParamsCreate(cuvsIvfFlatIndexParams_t* params)
+{
+  return (cuvsError_t)translate_exceptions(
+    [=] { *params = new cuvsIvfFlatIndexParams{L2Expanded, 2.0f, true, 1024, 20, 0.5, false, false}; });
+}
+cuvsError_t cuvsIvfFlatIndexParamsDestroy(cuvsIvfFlatIndexParams_t params)
+{
+  return (cuvsError_t)translate_exceptions([=] { delete params; });
+}
+cuvsError_t cuvsIvfFlatSearchParamsCreate(cuvsIvfFlatSearchParams_t* params)
+{
+  return (cuvsError_t)translate_exceptions([=] { *params = new cuvsIvfFlatSearchParams{20}; });
+}
+cuvsError_t cuvsIvfFlatSearchParamsDestroy(cuvsIvfFlatSearchParams_t params)
+{
+  return (cuvsError_t)translate_exceptions([=] { delete params; });
+}
+cuvsError_t cuvsIvfFlatIndexCreate(cuvsIvfFlatIndex_t* index)
+{
+  return (cuvsError_t)translate_exceptions([=] { *index = new cuvsIvfFlatIndex{0, DLDataType{0, 0, 0}}; });
+}
+cuvsError_t cuvsIvfFlatIndexDestroy(cuvsIvfFlatIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    if (!index) return;
+    delete reinterpret_cast<ivf_flat_index*>(index->addr);
+    delete index;
+  });
+}
+cuvsError_t cuvsIvfFlatIndexGetNLists(cuvsIvfFlatIndex_t index, int64_t* n_lists)
+{
+  return (cuvsError_t)translate_exceptions([=] { *n_lists = get_flat(index).n_lists; });
+}
+cuvsError_t cuvsIvfFlatIndexGetDim(cuvsIvfFlatIndex_t index, int64_t* dim)
+{
+  return (cuvsError_t)translate_exceptions([=] { *dim = get_flat(index).dim; });
+}
+cuvsError_t cuvsIvfFlatIndexGetCenters(cuvsIvfFlatIndex_t index, DLManagedTensor* centers)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& idx = get_flat(index);
+    fill_dl_view(centers, idx.centers.data(), DLDataType{kDLFloat, 32, 1}, idx.n_lists, idx.dim, 2, 0);
+  });
+}
+
+cuvsError_t cuvsIvfFlatBuild(cuvsResources_t res_h, cuvsIvfFlatIndexParams_t params, DLManagedTensor* dataset_tensor,
+                             cuvsIvfFlatIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(params && dataset_tensor && index, "null argument");
+    auto& ds = dataset_tensor->dl_tensor;
+    CUVS_EXPECTS(ds.ndim == 2 && is_c_contiguous(ds), "dataset must be a row-major matrix");
+    auto idx = ivf_flat_build(res, *params, dl_data(ds), elem_of(ds.dtype), ds.shape[0], ds.shape[1],
+                              !is_device_accessible(ds));
+    delete reinterpret_cast<ivf_flat_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = ds.dtype;
+  });
+}
+
+cuvsError_t cuvsIvfFlatSearch(cuvsResources_t res_h, cuvsIvfFlatSearchParams_t params, cuvsIvfFlatIndex_t index_c,
+                              DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
+                              DLManagedTensor* distances_tensor, cuvsFilter filter)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_flat(index_c);
+    CUVS_EXPECTS(params && queries_tensor && neighbors_tensor && distances_tensor, "null argument");
+    CUVS_EXPECTS(filter.type == NO_FILTER, "cuvsIvfFlatSearch: pre-filters are not built yet (SURVEY 8f N4)");
+    auto& queries   = queries_tensor->dl_tensor;
+    auto& neighbors = neighbors_tensor->dl_tensor;
+    auto& distances = distances_tensor->dl_tensor;
+    CUVS_EXPECTS(is_device_accessible(queries), "queries should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(neighbors), "neighbors should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(distances), "distances should have device compatible memory");
+    CUVS_EXPECTS(dtype_is(neighbors.dtype, kDLInt, 64), "neighbors should be of type int64_t");
+    CUVS_EXPECTS(dtype_is(distances.dtype, kDLFloat, 32), "distances should be of type float32");
+    CUVS_EXPECTS(queries.ndim == 2 && neighbors.ndim == 2 && distances.ndim == 2, "tensors must be 2-D");
+    CUVS_EXPECTS(is_c_contiguous(queries) && is_c_contiguous(neighbors) && is_c_contiguous(distances),
+                 "tensors must be C-contiguous");
+    CUVS_EXPECTS(queries.dtype.code == index_c->dtype.code && queries.dtype.bits == index_c->dtype.bits,
+                 "Unsupported queries DLtensor dtype: %d and bits: %d", (int)queries.dtype.code,
+                 (int)queries.dtype.bits);
+    CUVS_EXPECTS(queries.shape[1] == idx.dim, "queries dim %ld != index dim %u", (long)queries.shape[1], idx.dim);
+    int64_t m = queries.shape[0], k = neighbors.shape[1];
+    CUVS_EXPECTS(neighbors.shape[0] == m && distances.shape[0] == m && distances.shape[1] == k,
+                 "neighbors/distances shape mismatch");
+    ivf_flat_search(res, idx, params->n_probes, dl_data(queries), elem_of(queries.dtype), m, (int)k,
+                    static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)));
+  });
+}
+
+cuvsError_t cuvsIvfFlatExtend(cuvsResources_t res_h, DLManagedTensor* new_vectors, DLManagedTensor* new_indices,
+                              cuvsIvfFlatIndex_t index_c)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_flat(index_c);
+    CUVS_EXPECTS(new_vectors != nullptr, "new_vectors is null");
+    auto& v = new_vectors->dl_tensor;
+    CUVS_EXPECTS(v.ndim == 2 && is_c_contiguous(v) && v.shape[1] == idx.dim, "new_vectors must be [n, dim] row-major");
+    const int64_t* ids = nullptr;
+    bool ids_host      = false;
+    if (new_indices != nullptr) {
+      auto& t = new_indices->dl_tensor;
+      CUVS_EXPECTS(dtype_is(t.dtype, kDLInt, 64) && t.shape[0] == v.shape[0], "new_indices must be int64 [n]");
+      ids      = static_cast<const int64_t*>(dl_data(t));
+      ids_host = !is_device_accessible(t);
+    }
+    ivf_flat_extend(res, idx, dl_data(v), elem_of(v.dtype), v.shape[0], !is_device_accessible(v), ids, ids_host);
+  });
+}
+
+cuvsError_t cuvsIvfFlatSerialize(cuvsResources_t, const char*, cuvsIvfFlatIndex_t)
+{
+  return (cuvsError_t)translate_exceptions(
+    [=] { CUVS_FAIL("cuvsIvfFlatSerialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+}
+cuvsError_t cuvsIvfFlatDeserialize(cuvsResources_t, const char*, cuvsIvfFlatIndex_t)
+{
+  return (cuvsError_t)translate_exceptions(
+    [=] { CUVS_FAIL("cuvsIvfFlatDeserialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+}
+
+// test hook: raw interleaved list bytes -> row-major [size, dim] of T for list `label` (device pointer out)
+__attribute__((visibility("default"))) int cuvsAmdIvfFlatListInfo(cuvsIvfFlatIndex_t index, uint32_t label,
+                                                                    uint32_t* size, uint32_t* offset,
+                                                                    const int64_t** ids, const uint8_t** data,
+                                                                    uint32_t* n_chunks)
+{
+  return translate_exceptions([=] {
+    auto& idx = get_flat(index);
+    CUVS_EXPECTS(label < idx.n_lists, "label out of range");
+    *size     = idx.h_list_sizes[label];
+    *offset   = idx.h_list_offsets[label];
+    *ids      = idx.indices.data();
+    *data     = idx.data.data();
+    *n_chunks = idx.n_chunks;
+  });
+}
+
+}  // extern "C"
