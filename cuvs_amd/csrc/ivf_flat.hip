@@ -297,6 +297,19 @@ __global__ void flat_postprocess_kernel(const uint32_t* __restrict__ pos, const 
   distances[i] = d;
 }
 
+__global__ void unpack_flat_list_kernel(const uint8_t* __restrict__ data, uint32_t n_chunks, uint32_t veclen,
+                                        uint32_t esz, uint32_t dim, int64_t flat_row0, uint32_t n_rows,
+                                        uint8_t* __restrict__ out)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_rows * dim) return;
+  int64_t r  = i / dim;
+  uint32_t d = (uint32_t)(i % dim);
+  int64_t fr = flat_row0 + r;
+  size_t addr = (((size_t)(fr >> 6) * n_chunks + d / veclen) * 64 + (size_t)(fr & 63)) * 16 + (size_t)(d % veclen) * esz;
+  for (uint32_t b = 0; b < esz; ++b) out[i * esz + b] = data[addr + b];
+}
+
 template <typename T>
 void launch_flat_scan(resources& res, const flat_scan_args& a, size_t smem, unsigned grid, bool big_k)
 {
@@ -673,20 +686,32 @@ cuvsError_t cuvsIvfFlatDeserialize(cuvsResources_t, const char*, cuvsIvfFlatInde
     [=] { CUVS_FAIL("cuvsIvfFlatDeserialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
 }
 
-// test hook: raw interleaved list bytes -> row-major [size, dim] of T for list `label` (device pointer out)
-__attribute__((visibility("default"))) int cuvsAmdIvfFlatListInfo(cuvsIvfFlatIndex_t index, uint32_t label,
-                                                                    uint32_t* size, uint32_t* offset,
-                                                                    const int64_t** ids, const uint8_t** data,
-                                                                    uint32_t* n_chunks)
+// test hooks (not in the reference ABI): list size, and a row-major copy of one list + its source ids
+__attribute__((visibility("default"))) int cuvsAmdIvfFlatListSize(cuvsIvfFlatIndex_t index, uint32_t label,
+                                                                    uint32_t* size)
 {
   return translate_exceptions([=] {
     auto& idx = get_flat(index);
     CUVS_EXPECTS(label < idx.n_lists, "label out of range");
-    *size     = idx.h_list_sizes[label];
-    *offset   = idx.h_list_offsets[label];
-    *ids      = idx.indices.data();
-    *data     = idx.data.data();
-    *n_chunks = idx.n_chunks;
+    *size = idx.h_list_sizes[label];
+  });
+}
+
+__attribute__((visibility("default"))) int cuvsAmdIvfFlatUnpackList(cuvsResources_t res_h, cuvsIvfFlatIndex_t index,
+                                                                      uint32_t label, void* out_rows, int64_t* out_ids)
+{
+  return translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_flat(index);
+    CUVS_EXPECTS(label < idx.n_lists, "label out of range");
+    uint32_t sz = idx.h_list_sizes[label];
+    if (sz == 0) return;
+    int64_t total = (int64_t)sz * idx.dim;
+    hipLaunchKernelGGL(unpack_flat_list_kernel, dim3(grid_blocks(total, 256)), dim3(256), 0, res.stream,
+                       idx.data.data(), idx.n_chunks, idx.veclen, (uint32_t)elem_size(idx.dtype), idx.dim,
+                       (int64_t)idx.h_list_offsets[label], sz, static_cast<uint8_t*>(out_rows));
+    copy_async(res, out_ids, idx.indices.data() + idx.h_list_offsets[label], (size_t)sz * sizeof(int64_t));
+    HIP_TRY(hipGetLastError());
   });
 }
 

@@ -140,3 +140,23 @@ def refine(dataset, queries, candidates, k, metric="sqeuclidean"):
     lib().oracle_refine(_p(x), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]), _p(q), C.c_int64(q.shape[0]), _p(cand),
                         C.c_int(cand.shape[1]), C.c_int(k), C.c_int(_metric(metric)), _p(oi), _p(od))
     return od, oi
+
+
+def ivf_flat_search(exported, queries, k, n_probes, metric="sqeuclidean", coarse_scale=1.0):
+    """Search an index exported with cuvs_amd.neighbors.ivf_flat.export_for_oracle. `queries` in the index dtype;
+    coarse_scale = 1/128 (int8) or 1/256 (uint8): the coarse quantizer sees mapped floats (ann_utils.cuh:134-196)."""
+    q_raw = _f32(np.asarray(queries).astype(np.float32))
+    q_coarse = _f32(q_raw * np.float32(coarse_scale))
+    centers = _f32(exported["centers"])
+    sizes = np.ascontiguousarray(exported["list_sizes"], dtype=np.uint32)
+    start = np.zeros(len(sizes) + 1, np.int64)
+    np.cumsum(sizes, out=start[1:])
+    rows = _f32(np.concatenate([r.astype(np.float32) for r in exported["rows"]], axis=0))
+    ids = np.ascontiguousarray(np.concatenate(exported["ids"], axis=0), dtype=np.int64)
+    nq = q_raw.shape[0]
+    nb = np.empty((nq, k), np.int64)
+    ds = np.empty((nq, k), np.float32)
+    lib().oracle_ivf_flat_search(_p(q_coarse), _p(q_raw), C.c_int64(nq), C.c_int(q_raw.shape[1]), _p(centers),
+                                 C.c_int(len(sizes)), _p(sizes), _p(start), _p(rows), _p(ids), C.c_int(_metric(metric)),
+                                 C.c_int(n_probes), C.c_int(k), _p(nb), _p(ds))
+    return ds, nb
