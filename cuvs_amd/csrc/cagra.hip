@@ -1,0 +1,786 @@
+// CAGRA on MI355X: graph build (kNN graph + rank-based prune + reverse-edge merge), graph search, C ABI
+// (drop-in for c/src/neighbors/cagra.cpp).
+//
+// Reference: cpp/src/neighbors/detail/cagra/graph_core.cuh (kern_fused_prune :206-330 — 2-hop detour
+// counting, kern_make_rev_graph_k :178-200, kern_merge_graph :375-470, optimize :1706-1809),
+// cagra_build.cuh:1629-1760 (kNN graph by IVF-PQ + refine), search_plan.cuh:199-245 (max_iterations rule),
+// search_single_cta_jit.cuh:105-452 (search loop), device_common_jit.cuh:36-181 (seeding, child distances),
+// hashmap.hpp:23-148 (open addressing), compute_distance_impl.cuh:23-64 (team distance).
+//
+// MI355X design of the search: ONE wave64 per query (the reference's "single CTA" sized for 32-lane warps
+// does not transfer): the wave keeps the sorted internal top list and the candidate list in LDS, dedups
+// children with a small LDS hash (reset every few iterations like the reference's SMALL hash mode), computes
+// child distances with 8 teams of 8 lanes (each team streams one dataset row in 128-byte pieces, 16 B per
+// lane, so 8 rows are in flight per wave) and merges with a wave-level bitonic sort. ~12 KB of LDS per query
+// lets a CU hold 13+ concurrent queries, which is what hides the dependent-gather latency of the walk.
+#include "ivf_pq.hpp"
+#include "ops.hpp"
+#include "device_utils.hpp"
+
+#include <cuvs/neighbors/cagra.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace cuvs_amd {
+
+struct cagra_index {
+  int metric   = 0;
+  elem_t dtype = elem_t::f32;
+  int64_t n = 0, dim = 0;
+  uint32_t degree = 0;
+  const void* data = nullptr;  // device rows [n, dim]
+  dev_buf<char> owned;
+  dev_buf<uint32_t> graph;     // [n, degree]
+};
+
+namespace {
+
+constexpr uint32_t kInvalidNode = 0xffffffffu;
+constexpr uint32_t kParentFlag  = 0x80000000u;
+
+// ------------------------------------------------------------------ graph optimisation
+// kern_fused_prune restated: one wave per node.
+__global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__ knn, int64_t n, uint32_t K,
+                                                    uint32_t out_degree, uint32_t* __restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* s_idx = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 2 * K;
+  uint32_t* s_det = s_idx + K;
+  const int64_t nid = (int64_t)blockIdx.x * 4 + wave;
+  if (nid >= n) return;
+  for (uint32_t k = lane; k < K; k += 64) {
+    uint32_t v = knn[nid * K + k];
+    s_idx[k]   = v;
+    s_det[k]   = (v == (uint32_t)nid) ? K : 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t kAD = 0; kAD + 1 < K; ++kAD) {
+    const uint32_t iD = s_idx[kAD];
+    if (iD >= n) continue;
+    for (uint32_t kDB = lane; kDB < K; kDB += 64) {
+      const uint32_t cand = knn[(int64_t)iD * K + kDB];
+      for (uint32_t kAB = kAD + 1; kAB < K; ++kAB) {
+        if (s_idx[kAB] == cand) {
+          atomicAdd(&s_det[kAB], 1u);
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (uint32_t k = lane; k < K; k += 64) {
+    uint32_t d = min(s_det[k], 0xffffu);
+    if (s_idx[k] >= n) d = 0xffffu;
+    s_det[k] = d;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = 0; i < out_degree; ++i) {
+    uint32_t best = 0xffffffffu;
+    for (uint32_t k = lane; k < K; k += 64) {
+      uint32_t tag = (s_det[k] << 16) | k;
+      if (s_det[k] < 0xffffu && tag < best) best = tag;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off, kWave));
+    uint32_t sel = kInvalidNode;
+    if (best != 0xffffffffu) {
+      sel = s_idx[best & 0xffffu];
+      for (uint32_t k = lane; k < K; k += 64)
+        if (s_idx[k] == sel) s_det[k] = 0xffffu;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) out[nid * out_degree + i] = sel;
+  }
+}
+
+// edge list in (rank-major, source-ascending) order: dest[e], e = k * n + src
+__global__ void edge_dest_kernel(const uint32_t* __restrict__ g, int64_t n, uint32_t degree, uint32_t* dest)
+{
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * degree) return;
+  int64_t k = e / n, src = e % n;
+  uint32_t d = g[src * degree + k];
+  dest[e]    = d < n ? d : (uint32_t)(n);  // invalid edges go to the extra bucket n
+}
+
+// kern_merge_graph restated (no MST): keep the first degree/2 forward edges, insert reverse edges behind them.
+__global__ __launch_bounds__(256) void merge_graph_kernel(uint32_t* __restrict__ g, int64_t n, uint32_t degree,
+                                                          const uint32_t* __restrict__ rev_perm,
+                                                          const uint32_t* __restrict__ rev_off)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* row  = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * degree;
+  const int64_t nid = (int64_t)blockIdx.x * 4 + wave;
+  if (nid >= n) return;
+  for (uint32_t i = lane; i < degree; i += 64) row[i] = g[nid * degree + i];
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t prot = degree / 2;
+  if (prot < degree) {
+    const uint32_t b = rev_off[nid], e = rev_off[nid + 1];
+    uint32_t kr = min(e - b, degree);
+    while (kr) {
+      kr -= 1;
+      const uint32_t rv = rev_perm[b + kr] % (uint32_t)n;  // source node of the kr-th reverse edge
+      // position of rv in the row (degree if absent)
+      uint32_t pos = degree;
+      for (uint32_t i = lane; i < degree; i += 64)
+        if (row[i] == rv) pos = i;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) pos = min(pos, (uint32_t)__shfl_xor((int)pos, off, kWave));
+      if (pos < prot) continue;
+      uint32_t num_shift = pos - prot;
+      if (pos >= degree) num_shift = degree - prot - 1;
+      // shift row[prot .. prot + num_shift) one to the right
+      uint32_t tmp[4];
+      for (uint32_t c = 0, i = lane; c < 4; ++c, i += 64) tmp[c] = (i < num_shift) ? row[prot + i] : 0;
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t c = 0, i = lane; c < 4; ++c, i += 64)
+        if (i < num_shift) row[prot + i + 1] = tmp[c];
+      if (lane == 0) row[prot] = rv;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  for (uint32_t i = lane; i < degree; i += 64) g[nid * degree + i] = row[i];
+}
+
+// drop the self match from [n_rows, K + 1] kNN results (rows r0..): keep the first K ids != row
+__global__ void strip_self_kernel(const int64_t* __restrict__ ids, int64_t n_rows, int64_t r0, uint32_t K,
+                                  uint32_t kp1, uint32_t* __restrict__ knn)
+{
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  uint32_t o = 0;
+  for (uint32_t j = 0; j < kp1 && o < K; ++j) {
+    int64_t v = ids[r * kp1 + j];
+    if (v == r0 + r) continue;
+    knn[(r0 + r) * K + o++] = (v < 0 || v == INT64_MAX) ? kInvalidNode : (uint32_t)v;
+  }
+  for (; o < K; ++o) knn[(r0 + r) * K + o] = kInvalidNode;
+}
+
+template <typename T>
+__global__ void to_float_kernel(const T* __restrict__ in, int64_t n, float* __restrict__ out)
+{
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = to_float(in[i]);
+}
+
+// exact kNN graph by tiled brute force (small datasets)
+template <typename T>
+void knn_graph_bruteforce(resources& res, const T* data, int64_t n, int64_t dim, uint32_t K, int metric,
+                          uint32_t* knn)
+{
+  const uint32_t kp1    = (uint32_t)std::min<int64_t>(K + 1, n);
+  const bool select_min = metric != M_InnerProduct;
+  dev_buf<float> norms;
+  if (metric != M_InnerProduct) {
+    norms = dev_buf<float>(res, n);
+    row_norms<T>(res, data, n, dim, dim, norms.data(), false);
+  }
+  const int64_t m_tile = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(res.workspace_limit / 4) / n));
+  dev_buf<float> tile(res, (size_t)m_tile * n), dv(res, (size_t)m_tile * kp1);
+  dev_buf<int64_t> di(res, (size_t)m_tile * kp1);
+  for (int64_t r0 = 0; r0 < n; r0 += m_tile) {
+    int64_t mr = std::min(m_tile, n - r0);
+    pairwise_distance<T, T>(res, data + r0 * dim, mr, dim, data, n, dim, dim, norms.data() ? norms.data() + r0 : nullptr,
+                            norms.data(), metric == M_InnerProduct ? M_InnerProduct : M_L2Expanded, tile.data(), n);
+    select_k<int64_t, int64_t>(res, tile.data(), nullptr, mr, n, n, (int)kp1, dv.data(), di.data(), select_min);
+    hipLaunchKernelGGL(strip_self_kernel, dim3(grid_blocks(mr, 256)), dim3(256), 0, res.stream, di.data(), mr, r0, K,
+                       kp1, knn);
+  }
+}
+
+// approximate kNN graph: IVF-PQ search of the dataset against itself + exact refine (cagra_build.cuh:1629-1760)
+void knn_graph_ivf_pq(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, uint32_t K, int metric,
+                      uint32_t* knn)
+{
+  ivf_pq_build_params bp;
+  bp.metric                   = metric == M_InnerProduct ? M_InnerProduct : M_L2Expanded;
+  bp.n_lists                  = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(65536, (int64_t)std::sqrt((double)n)));
+  bp.kmeans_n_iters           = 10;
+  bp.kmeans_trainset_fraction = std::min(1.0, std::max(0.02, 2.0e6 / (double)n));
+  bp.pq_bits                  = 8;
+  bp.pq_dim                   = (uint32_t)std::max<int64_t>(8, std::min<int64_t>(64, round_up(dim / 2, 8)));
+  auto pq = ivf_pq_build(res, bp, data, et, n, dim, false);
+  ivf_pq_search_params sp;
+  sp.n_probes                = std::max<uint32_t>(8, bp.n_lists / 50);
+  sp.lut_dtype               = 2;
+  sp.internal_distance_dtype = 2;
+  sp.max_internal_batch_size = 16384;
+  const int kp1   = (int)K + 1;
+  const int k_pq  = std::min(256, 2 * kp1);
+  const int64_t b = 16384;
+  dev_buf<int64_t> cand(res, (size_t)b * k_pq), ri(res, (size_t)b * kp1);
+  dev_buf<float> cd(res, (size_t)b * k_pq), rd(res, (size_t)b * kp1);
+  const size_t esz = elem_size(et);
+  for (int64_t r0 = 0; r0 < n; r0 += b) {
+    int64_t mr      = std::min(b, n - r0);
+    const void* qry = static_cast<const char*>(data) + (size_t)r0 * dim * esz;
+    ivf_pq_search(res, sp, *pq, qry, et, mr, k_pq, cand.data(), cd.data());
+    refine(res, data, et, n, dim, qry, mr, cand.data(), k_pq, std::min(kp1, k_pq), bp.metric, ri.data(), rd.data());
+    hipLaunchKernelGGL(strip_self_kernel, dim3(grid_blocks(mr, 256)), dim3(256), 0, res.stream, ri.data(), mr, r0, K,
+                       (uint32_t)std::min(kp1, k_pq), knn);
+  }
+  sync(res);
+}
+
+// graph::optimize (graph_core.cuh:1706-1809) without the MST step
+void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, uint32_t degree, uint32_t* graph)
+{
+  CUVS_EXPECTS(degree <= K, "graph_degree (%u) must not exceed intermediate_graph_degree (%u)", degree, K);
+  CUVS_EXPECTS(degree <= 256 && K <= 1024, "cagra: degree <= 256 and intermediate degree <= 1024 supported");
+  CUVS_EXPECTS(n * (int64_t)degree < (int64_t(1) << 32), "cagra: n * degree must be below 2^32");
+  size_t smem = (size_t)4 * 2 * K * sizeof(uint32_t);
+  hipLaunchKernelGGL(prune_kernel, dim3(grid_blocks(n, 4)), dim3(256), smem, res.stream, knn, n, K, degree, graph);
+  // reverse edges grouped by destination, ordered by (rank, source)
+  const int64_t n_edges = n * degree;
+  dev_buf<uint32_t> dest(res, n_edges), perm(res, n_edges), off(res, n + 2);
+  hipLaunchKernelGGL(edge_dest_kernel, dim3(grid_blocks(n_edges, 256)), dim3(256), 0, res.stream, graph, n, degree,
+                     dest.data());
+  group_by_label(res, dest.data(), n_edges, (uint32_t)(n + 1), perm.data(), off.data());
+  hipLaunchKernelGGL(merge_graph_kernel, dim3(grid_blocks(n, 4)), dim3(256), (size_t)4 * degree * sizeof(uint32_t),
+                     res.stream, graph, n, degree, perm.data(), off.data());
+  HIP_TRY(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ search
+struct search_args {
+  const void* data;
+  const uint32_t* graph;
+  const void* queries;
+  const uint32_t* filter_bits;  // optional bitset (1 keeps)
+  void* out_idx;                // uint32 or int64 [nq, k]
+  float* out_dist;
+  int64_t n, dim;
+  uint32_t degree, itopk, width, max_iter, min_iter, k, np2, hash_bits, reset_interval;
+  uint64_t rand_xor_mask;
+  int is_ip, idx64;
+};
+
+__device__ inline uint32_t hash_slot(uint32_t key, uint32_t bits) { return (key ^ (key >> bits)) & ((1u << bits) - 1u); }
+
+// returns true when `key` was not in the table (and is now)
+__device__ inline bool hash_insert(uint32_t* table, uint32_t bits, uint32_t key)
+{
+  const uint32_t mask = (1u << bits) - 1u;
+  uint32_t pos        = hash_slot(key, bits);
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    uint32_t old = atomicCAS(&table[pos], kInvalidNode, key);
+    if (old == kInvalidNode) return true;
+    if (old == key) return false;
+    pos = (pos + 1) & mask;
+  }
+  return false;  // table full: treat as seen
+}
+
+__device__ inline uint64_t xorshift64(uint64_t u)
+{
+  u ^= u >> 12;
+  u ^= u << 25;
+  u ^= u >> 27;
+  return u * 0x2545F4914F6CDD1DULL;
+}
+
+// distances of the nodes idx[first .. first+count) to the query; 8 teams of 8 lanes, one row per team.
+// Arithmetic (oracle twin: oracle_cagra.c): team lane t accumulates the elements of its 16-byte pieces in
+// order with fmaf, then the 8 partial sums are combined by the xor butterfly (1, 2, 4).
+template <typename T>
+__device__ inline void team_distances(const T* __restrict__ data, int64_t dim, const float* __restrict__ qf,
+                                      uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t first,
+                                      uint32_t count, bool is_ip, int lane)
+{
+  constexpr int VL = 16 / sizeof(T);
+  const int team = lane >> 3, tl = lane & 7;
+  const bool vec = (dim % VL == 0) && ((reinterpret_cast<uintptr_t>(data) & 15) == 0);
+  for (uint32_t c0 = 0; c0 < count; c0 += 8) {
+    const uint32_t c    = c0 + team;
+    const uint32_t node = c < count ? (idx[first + c] & ~kParentFlag) : kInvalidNode;
+    const bool ok       = c < count && idx[first + c] != kInvalidNode;
+    float acc           = 0.f;
+    if (ok) {
+      const T* row = data + (int64_t)node * dim;
+      for (int64_t d0 = (int64_t)tl * VL; d0 < dim; d0 += 8 * VL) {
+        T el[VL];
+        if (vec) {
+          *reinterpret_cast<uint4*>(el) = *reinterpret_cast<const uint4*>(row + d0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VL; ++e) el[e] = d0 + e < dim ? row[d0 + e] : T(0);
+        }
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+          if (d0 + e < dim) {
+            const float x = to_float(el[e]), q = qf[d0 + e];
+            if (is_ip) {
+              acc = __fmaf_rn(x, q, acc);
+            } else {
+              float t = x - q;
+              acc     = __fmaf_rn(t, t, acc);
+            }
+          }
+        }
+      }
+    }
+    acc = acc + __shfl_xor(acc, 1, kWave);
+    acc = acc + __shfl_xor(acc, 2, kWave);
+    acc = acc + __shfl_xor(acc, 4, kWave);
+    if (tl == 0 && c < count) keys[first + c] = ok ? float_to_key(is_ip ? -acc : acc) : 0xffffffffu;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane   = threadIdx.x;
+  const int64_t qi = blockIdx.x;
+  float* qf        = reinterpret_cast<float*>(smem);
+  uint32_t* keys   = reinterpret_cast<uint32_t*>(qf + ((a.dim + 3) & ~int64_t(3)));
+  uint32_t* idx    = keys + a.np2;
+  uint32_t* table  = idx + a.np2;
+  const uint32_t hsize = 1u << a.hash_bits;
+  const T* data    = static_cast<const T*>(a.data);
+
+  for (int64_t d = lane; d < a.dim; d += 64) qf[d] = to_float(static_cast<const T*>(a.queries)[qi * a.dim + d]);
+  for (uint32_t i = lane; i < a.np2; i += 64) { keys[i] = 0xffffffffu; idx[i] = kInvalidNode; }
+  for (uint32_t i = lane; i < hsize; i += 64) table[i] = kInvalidNode;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- seeds: itopk pseudo-random nodes (device_common_jit.cuh:36-104: xorshift64(gid ^ mask) % n)
+  for (uint32_t i = lane; i < a.itopk; i += 64) {
+    uint64_t gid  = (uint64_t)qi * a.itopk + i;
+    uint32_t node = (uint32_t)(xorshift64(gid ^ a.rand_xor_mask) % (uint64_t)a.n);
+    idx[i]        = hash_insert(table, a.hash_bits, node) ? node : kInvalidNode;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  team_distances<T>(data, a.dim, qf, keys, idx, 0, a.itopk, a.is_ip, lane);
+
+  const uint32_t n_cand = a.width * a.degree;
+  uint32_t iter         = 0;
+  while (true) {
+    wave_bitonic_sort<uint32_t>(keys, idx, (int)a.np2);
+    if (iter >= a.max_iter) break;
+    // hash reset (SMALL hash mode of the reference): keep only the current top list
+    if (iter > 0 && a.reset_interval > 0 && (iter % a.reset_interval) == 0) {
+      for (uint32_t i = lane; i < hsize; i += 64) table[i] = kInvalidNode;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < a.itopk; i += 64)
+        if (idx[i] != kInvalidNode) hash_insert(table, a.hash_bits, idx[i] & ~kParentFlag);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- pick up to `width` best entries that were not parents yet (pickup_next_parents)
+    uint32_t n_parents = 0;
+    uint32_t parents[8];
+    for (uint32_t base = 0; base < a.itopk && n_parents < a.width; base += 64) {
+      const uint32_t i = base + lane;
+      const bool cand  = i < a.itopk && idx[i] != kInvalidNode && !(idx[i] & kParentFlag);
+      unsigned long long m = __ballot(cand);
+      while (m != 0ull && n_parents < a.width) {
+        const int src = (int)__ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const uint32_t pos = base + src;
+        parents[n_parents++] = idx[pos];
+        if (lane == 0) idx[pos] |= kParentFlag;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (n_parents == 0 && iter >= a.min_iter) break;
+    // ---- children -> candidate region (dedup through the hash)
+    for (uint32_t i = lane; i < n_cand; i += 64) {
+      const uint32_t w = i / a.degree, c = i % a.degree;
+      uint32_t child   = kInvalidNode;
+      if (w < n_parents) {
+        child = a.graph[(int64_t)parents[w] * a.degree + c];
+        if (child >= a.n || !hash_insert(table, a.hash_bits, child)) child = kInvalidNode;
+      }
+      idx[a.itopk + i]  = child;
+      keys[a.itopk + i] = 0xffffffffu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    team_distances<T>(data, a.dim, qf, keys, idx, a.itopk, n_cand, a.is_ip, lane);
+    ++iter;
+  }
+
+  // ---- results: first k entries of the sorted list that pass the filter
+  uint32_t written = 0;
+  for (uint32_t base = 0; base < a.itopk && written < a.k; base += 64) {
+    const uint32_t i = base + lane;
+    bool ok          = i < a.itopk && idx[i] != kInvalidNode;
+    uint32_t node    = ok ? (idx[i] & ~kParentFlag) : 0;
+    if (ok && a.filter_bits) ok = (a.filter_bits[node >> 5] >> (node & 31)) & 1u;
+    const unsigned long long m = __ballot(ok);
+    const uint32_t rank        = written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (ok && rank < a.k) {
+      float d = key_to_float(keys[i]);
+      if (a.is_ip) d = -d;
+      a.out_dist[qi * a.k + rank] = d;
+      if (a.idx64) static_cast<int64_t*>(a.out_idx)[qi * a.k + rank] = node;
+      else         static_cast<uint32_t*>(a.out_idx)[qi * a.k + rank] = node;
+    }
+    written += (uint32_t)__popcll(m);
+  }
+  for (uint32_t r = min(written, a.k) + lane; r < a.k; r += 64) {
+    a.out_dist[qi * a.k + r] = FLT_MAX;
+    if (a.idx64) static_cast<int64_t*>(a.out_idx)[qi * a.k + r] = -1;
+    else         static_cast<uint32_t*>(a.out_idx)[qi * a.k + r] = kInvalidNode;
+  }
+}
+
+template <typename T>
+void launch_search(resources& res, const search_args& a, int64_t nq, size_t smem)
+{
+  auto kern = cagra_search_kernel<T>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  profile_begin(res, "cagra_search_kernel");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64), smem, res.stream, a);
+  profile_end(res, "cagra_search_kernel");
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchParams& p, const void* queries,
+                  int64_t nq, int k, void* out_idx, bool idx64, float* out_dist, const uint32_t* filter_bits)
+{
+  if (nq == 0) return;
+  CUVS_EXPECTS(idx.graph.data() != nullptr && idx.data != nullptr, "cagra index has no graph/dataset");
+  CUVS_EXPECTS(k >= 1, "k must be positive");
+  CUVS_EXPECTS(nq < (int64_t(1) << 24), "cagra::search: split the query batch (max 2^24 queries per call)");
+  search_args a;
+  a.data = idx.data; a.graph = idx.graph.data(); a.queries = queries; a.filter_bits = filter_bits;
+  a.out_idx = out_idx; a.out_dist = out_dist; a.n = idx.n; a.dim = idx.dim; a.degree = idx.degree;
+  a.width = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, p.search_width));
+  uint32_t itopk = (uint32_t)std::max<size_t>(p.itopk_size ? p.itopk_size : 64, (size_t)k);
+  if (itopk % 32) itopk += 32 - itopk % 32;  // search_plan.cuh:236-244
+  CUVS_EXPECTS(itopk <= 1024, "cagra::search: itopk_size up to 1024 is supported");
+  a.itopk = itopk;
+  // search_plan.cuh:199-215
+  uint32_t max_iter = (uint32_t)p.max_iterations;
+  if (max_iter == 0) {
+    max_iter        = itopk / a.width;
+    int64_t reach   = 1;
+    while (reach < idx.n) { reach *= std::max<int64_t>(2, idx.degree / 2); max_iter += 1; }
+  }
+  a.min_iter = (uint32_t)p.min_iterations;
+  a.max_iter = std::max(max_iter, a.min_iter);
+  a.k        = (uint32_t)k;
+  a.np2      = (uint32_t)next_pow2((int)(itopk + a.width * idx.degree));
+  // small hash, reset every few iterations: at most itopk + interval * width * degree keys at <= 50 % fill
+  uint32_t bits = 11;
+  while ((1u << bits) < 2 * (itopk + 2 * a.width * idx.degree)) ++bits;
+  bits = std::max<uint32_t>(bits, (uint32_t)p.hashmap_min_bitlen);
+  CUVS_EXPECTS(bits <= 15, "cagra::search: hash table does not fit the LDS budget");
+  a.hash_bits      = bits;
+  a.reset_interval = std::max<uint32_t>(1, ((1u << bits) / 2 - itopk) / (a.width * idx.degree));
+  a.rand_xor_mask  = p.rand_xor_mask;
+  a.is_ip          = idx.metric == M_InnerProduct;
+  a.idx64          = idx64 ? 1 : 0;
+  size_t smem = (size_t)((idx.dim + 3) & ~int64_t(3)) * 4 + (size_t)a.np2 * 8 + ((size_t)4 << bits);
+  CUVS_EXPECTS(smem <= 160 * 1024, "cagra::search: dim/itopk too large for LDS");
+  switch (idx.dtype) {
+    case elem_t::f32: launch_search<float>(res, a, nq, smem); break;
+    case elem_t::f16: launch_search<__half>(res, a, nq, smem); break;
+    case elem_t::i8: launch_search<int8_t>(res, a, nq, smem); break;
+    case elem_t::u8: launch_search<uint8_t>(res, a, nq, smem); break;
+  }
+}
+
+std::unique_ptr<cagra_index> cagra_build(resources& res, const cuvsCagraIndexParams& p, const void* data, elem_t et,
+                                         int64_t n, int64_t dim, bool is_host)
+{
+  const int metric = (int)p.metric;
+  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct, "cagra: unsupported metric %d", metric);
+  CUVS_EXPECTS(n > 1, "cagra: need at least two rows");
+  auto idx    = std::make_unique<cagra_index>();
+  idx->metric = metric;
+  idx->dtype  = et;
+  idx->n      = n;
+  idx->dim    = dim;
+  const size_t esz = elem_size(et);
+  if (is_host) {
+    idx->owned = dev_buf<char>::persistent((size_t)n * dim * esz);
+    copy_async(res, idx->owned.data(), data, idx->owned.bytes());
+    sync(res);
+    idx->data = idx->owned.data();
+  } else {
+    idx->data = data;  // non-owning view of the caller's device dataset (cagra.hpp: update_dataset semantics)
+  }
+  uint32_t degree = (uint32_t)std::min<int64_t>((int64_t)p.graph_degree, n - 1);
+  uint32_t K      = (uint32_t)std::min<int64_t>(std::max<size_t>(p.intermediate_graph_degree, degree), n - 1);
+  idx->degree     = degree;
+  dev_buf<uint32_t> knn(res, (size_t)n * K);
+  const bool small = n <= 200000 || p.build_algo == ITERATIVE_CAGRA_SEARCH;
+  if (small) {
+    if (et == elem_t::f32) {
+      knn_graph_bruteforce<float>(res, static_cast<const float*>(idx->data), n, dim, K, metric, knn.data());
+    } else if (et == elem_t::f16) {
+      knn_graph_bruteforce<__half>(res, static_cast<const __half*>(idx->data), n, dim, K, metric, knn.data());
+    } else {
+      dev_buf<float> f(res, (size_t)n * dim);
+      if (et == elem_t::i8)
+        hipLaunchKernelGGL((to_float_kernel<int8_t>), dim3(grid_blocks(n * dim, 256)), dim3(256), 0, res.stream,
+                           static_cast<const int8_t*>(idx->data), n * dim, f.data());
+      else
+        hipLaunchKernelGGL((to_float_kernel<uint8_t>), dim3(grid_blocks(n * dim, 256)), dim3(256), 0, res.stream,
+                           static_cast<const uint8_t*>(idx->data), n * dim, f.data());
+      knn_graph_bruteforce<float>(res, f.data(), n, dim, K, metric, knn.data());
+      sync(res);
+    }
+  } else {
+    knn_graph_ivf_pq(res, idx->data, et, n, dim, K, metric, knn.data());
+  }
+  idx->graph = dev_buf<uint32_t>::persistent((size_t)n * degree);
+  optimize_graph(res, knn.data(), n, K, degree, idx->graph.data());
+  sync(res);
+  return idx;
+}
+
+}  // namespace cuvs_amd
+
+using namespace cuvs_amd;
+
+namespace {
+cagra_index& get_cagra(cuvsCagraIndex_t index)
+{
+  CUVS_EXPECTS(index != nullptr && index->addr != 0, "CAGRA index is not built");
+  return *reinterpret_cast<cagra_index*>(index->addr);
+}
+}  // namespace
+
+extern "C" {
+
+cuvsError_t cuvsCagraIndexParamsCreate(cuvsCagraIndexParams_t* params)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    *params                       = new cuvsCagraIndexParams{L2Expanded, 128, 64, IVF_PQ, 20, nullptr, nullptr};
+    (*params)->graph_build_params = new cuvsIvfPqParams{nullptr, nullptr, 1};
+  });
+}
+cuvsError_t cuvsCagraIndexParamsDestroy(cuvsCagraIndexParams_t params)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    if (!params) return;
+    if (params->graph_build_params != nullptr) {
+      if (params->build_algo == ACE) {
+        auto* ace = static_cast<cuvsAceParams*>(params->graph_build_params);
+        if (ace->build_dir) free(const_cast<char*>(ace->build_dir));
+        delete ace;
+      } else if (params->build_algo == IVF_PQ) {
+        delete static_cast<cuvsIvfPqParams*>(params->graph_build_params);
+      }
+    }
+    delete params;
+  });
+}
+cuvsError_t cuvsCagraCompressionParamsCreate(cuvsCagraCompressionParams_t* params)
+{
+  return (cuvsError_t)translate_exceptions([=] { *params = new cuvsCagraCompressionParams{8, 0, 0, 25, 0, 0}; });
+}
+cuvsError_t cuvsCagraCompressionParamsDestroy(cuvsCagraCompressionParams_t params)
+{
+  return (cuvsError_t)translate_exceptions([=] { delete params; });
+}
+cuvsError_t cuvsAceParamsCreate(cuvsAceParams_t* params)
+{
+  return (cuvsError_t)translate_exceptions([=] { *params = new cuvsAceParams{1, 120, nullptr, false, 0, 0}; });
+}
+cuvsError_t cuvsAceParamsDestroy(cuvsAceParams_t params)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    if (params && params->build_dir) free(const_cast<char*>(params->build_dir));
+    delete params;
+  });
+}
+cuvsError_t cuvsCagraIndexParamsFromHnswParams(cuvsCagraIndexParams_t params, int64_t, int64_t, int M, int,
+                                               enum cuvsCagraHnswHeuristicType, cuvsDistanceType metric)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(params != nullptr, "params is null");
+    params->metric                    = metric;
+    params->graph_degree              = (size_t)std::max(2, 2 * M);
+    params->intermediate_graph_degree = (size_t)std::max(4, 3 * M);
+  });
+}
+cuvsError_t cuvsCagraExtendParamsCreate(cuvsCagraExtendParams_t* params)
+{
+  return (cuvsError_t)translate_exceptions([=] { *params = new cuvsCagraExtendParams{0}; });
+}
+cuvsError_t cuvsCagraExtendParamsDestroy(cuvsCagraExtendParams_t params)
+{
+  return (cuvsError_t)translate_exceptions([=] { delete params; });
+}
+cuvsError_t cuvsCagraSearchParamsCreate(cuvsCagraSearchParams_t* params)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto* p                  = new cuvsCagraSearchParams{};
+    p->itopk_size            = 64;
+    p->search_width          = 1;
+    p->algo                  = AUTO;
+    p->hashmap_mode          = AUTO_HASH;
+    p->hashmap_max_fill_rate = 0.5f;
+    p->num_random_samplings  = 1;
+    p->rand_xor_mask         = 0x128394;
+    p->persistent            = false;
+    p->persistent_lifetime   = 2;
+    p->persistent_device_usage = 1.0f;
+    *params                  = p;
+  });
+}
+cuvsError_t cuvsCagraSearchParamsDestroy(cuvsCagraSearchParams_t params)
+{
+  return (cuvsError_t)translate_exceptions([=] { delete params; });
+}
+cuvsError_t cuvsCagraIndexCreate(cuvsCagraIndex_t* index)
+{
+  return (cuvsError_t)translate_exceptions([=] { *index = new cuvsCagraIndex{0, DLDataType{0, 0, 0}}; });
+}
+cuvsError_t cuvsCagraIndexDestroy(cuvsCagraIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    if (!index) return;
+    delete reinterpret_cast<cagra_index*>(index->addr);
+    delete index;
+  });
+}
+cuvsError_t cuvsCagraIndexGetDims(cuvsCagraIndex_t index, int64_t* dim)
+{
+  return (cuvsError_t)translate_exceptions([=] { *dim = get_cagra(index).dim; });
+}
+cuvsError_t cuvsCagraIndexGetSize(cuvsCagraIndex_t index, int64_t* size)
+{
+  return (cuvsError_t)translate_exceptions([=] { *size = get_cagra(index).n; });
+}
+cuvsError_t cuvsCagraIndexGetGraphDegree(cuvsCagraIndex_t index, int64_t* graph_degree)
+{
+  return (cuvsError_t)translate_exceptions([=] { *graph_degree = get_cagra(index).degree; });
+}
+cuvsError_t cuvsCagraIndexGetDataset(cuvsCagraIndex_t index, DLManagedTensor* dataset)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& idx = get_cagra(index);
+    fill_dl_view(dataset, const_cast<void*>(idx.data), index->dtype, idx.n, idx.dim, 2, 0);
+  });
+}
+cuvsError_t cuvsCagraIndexGetGraph(cuvsCagraIndex_t index, DLManagedTensor* graph)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& idx = get_cagra(index);
+    fill_dl_view(graph, idx.graph.data(), DLDataType{kDLUInt, 32, 1}, idx.n, idx.degree, 2, 0);
+  });
+}
+
+cuvsError_t cuvsCagraBuild(cuvsResources_t res_h, cuvsCagraIndexParams_t params, DLManagedTensor* dataset_tensor,
+                           cuvsCagraIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(params && dataset_tensor && index, "null argument");
+    CUVS_EXPECTS(params->compression == nullptr, "cagra: VPQ compression is outside the hot path (SURVEY 2.1 #17)");
+    auto& ds = dataset_tensor->dl_tensor;
+    CUVS_EXPECTS(ds.ndim == 2 && is_c_contiguous(ds), "dataset must be a row-major matrix");
+    auto idx = cagra_build(res, *params, dl_data(ds), elem_of(ds.dtype), ds.shape[0], ds.shape[1],
+                           !is_device_accessible(ds));
+    delete reinterpret_cast<cagra_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = ds.dtype;
+  });
+}
+
+cuvsError_t cuvsCagraIndexFromArgs(cuvsResources_t res_h, cuvsDistanceType metric, DLManagedTensor* graph_tensor,
+                                   DLManagedTensor* dataset_tensor, cuvsCagraIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(graph_tensor && dataset_tensor && index, "null argument");
+    auto& g  = graph_tensor->dl_tensor;
+    auto& ds = dataset_tensor->dl_tensor;
+    CUVS_EXPECTS(dtype_is(g.dtype, kDLUInt, 32) && g.ndim == 2 && is_c_contiguous(g), "graph must be uint32 [n, degree]");
+    CUVS_EXPECTS(ds.ndim == 2 && is_c_contiguous(ds) && ds.shape[0] == g.shape[0], "dataset/graph shape mismatch");
+    auto idx    = std::make_unique<cagra_index>();
+    idx->metric = (int)metric;
+    idx->dtype  = elem_of(ds.dtype);
+    idx->n      = ds.shape[0];
+    idx->dim    = ds.shape[1];
+    idx->degree = (uint32_t)g.shape[1];
+    const size_t esz = elem_size(idx->dtype);
+    if (is_device_accessible(ds)) {
+      idx->data = dl_data(ds);
+    } else {
+      idx->owned = dev_buf<char>::persistent((size_t)idx->n * idx->dim * esz);
+      copy_async(res, idx->owned.data(), dl_data(ds), idx->owned.bytes());
+      idx->data = idx->owned.data();
+    }
+    idx->graph = dev_buf<uint32_t>::persistent((size_t)idx->n * idx->degree);
+    copy_async(res, idx->graph.data(), dl_data(g), idx->graph.bytes());
+    sync(res);
+    delete reinterpret_cast<cagra_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = ds.dtype;
+  });
+}
+
+cuvsError_t cuvsCagraSearch(cuvsResources_t res_h, cuvsCagraSearchParams_t params, cuvsCagraIndex_t index_c,
+                            DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
+                            DLManagedTensor* distances_tensor, cuvsFilter filter)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_cagra(index_c);
+    CUVS_EXPECTS(params && queries_tensor && neighbors_tensor && distances_tensor, "null argument");
+    auto& queries   = queries_tensor->dl_tensor;
+    auto& neighbors = neighbors_tensor->dl_tensor;
+    auto& distances = distances_tensor->dl_tensor;
+    CUVS_EXPECTS(is_device_accessible(queries), "queries should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(neighbors), "neighbors should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(distances), "distances should have device compatible memory");
+    const bool idx64 = dtype_is(neighbors.dtype, kDLInt, 64);
+    CUVS_EXPECTS(idx64 || dtype_is(neighbors.dtype, kDLUInt, 32), "neighbors should be of type uint32_t or int64_t");
+    CUVS_EXPECTS(dtype_is(distances.dtype, kDLFloat, 32), "distances should be of type float32");
+    CUVS_EXPECTS(queries.ndim == 2 && neighbors.ndim == 2 && distances.ndim == 2, "tensors must be 2-D");
+    CUVS_EXPECTS(is_c_contiguous(queries) && is_c_contiguous(neighbors) && is_c_contiguous(distances),
+                 "tensors must be C-contiguous");
+    CUVS_EXPECTS(queries.dtype.code == index_c->dtype.code && queries.dtype.bits == index_c->dtype.bits,
+                 "Unsupported queries DLtensor dtype: %d and bits: %d", (int)queries.dtype.code,
+                 (int)queries.dtype.bits);
+    CUVS_EXPECTS(queries.shape[1] == idx.dim, "queries dim mismatch");
+    int64_t m = queries.shape[0], k = neighbors.shape[1];
+    CUVS_EXPECTS(neighbors.shape[0] == m && distances.shape[0] == m && distances.shape[1] == k,
+                 "neighbors/distances shape mismatch");
+    const uint32_t* bits = nullptr;
+    if (filter.type != NO_FILTER) {
+      CUVS_EXPECTS(filter.type == BITSET && filter.addr != 0, "cagra: only BITSET filters are supported");
+      auto& ft = reinterpret_cast<DLManagedTensor*>(filter.addr)->dl_tensor;
+      CUVS_EXPECTS(dtype_is(ft.dtype, kDLUInt, 32) && is_device_accessible(ft), "filter must be a device uint32 tensor");
+      bits = static_cast<const uint32_t*>(dl_data(ft));
+    }
+    cagra_search(res, idx, *params, dl_data(queries), m, (int)k, dl_data(neighbors), idx64,
+                 static_cast<float*>(dl_data(distances)), bits);
+  });
+}
+
+#define CAGRA_UNBUILT(NAME, SIG, WHY)                                                                   \
+  cuvsError_t NAME SIG { return (cuvsError_t)translate_exceptions([=] { CUVS_FAIL(#NAME ": " WHY); }); }
+CAGRA_UNBUILT(cuvsCagraExtend, (cuvsResources_t, cuvsCagraExtendParams_t, DLManagedTensor*, cuvsCagraIndex_t),
+              "add_nodes is outside the north-star search path (SURVEY 2.1 #5)")
+CAGRA_UNBUILT(cuvsCagraSerialize, (cuvsResources_t, const char*, cuvsCagraIndex_t, bool),
+              "index (de)serialization is not built yet (SURVEY 8f N2)")
+CAGRA_UNBUILT(cuvsCagraSerializeToHnswlib, (cuvsResources_t, const char*, cuvsCagraIndex_t),
+              "hnswlib export is outside the hot path (SURVEY 2.1 #5)")
+CAGRA_UNBUILT(cuvsCagraDeserialize, (cuvsResources_t, const char*, cuvsCagraIndex_t),
+              "index (de)serialization is not built yet (SURVEY 8f N2)")
+CAGRA_UNBUILT(cuvsCagraMerge, (cuvsResources_t, cuvsCagraIndexParams_t, cuvsCagraIndex_t*, size_t, cuvsFilter,
+                               cuvsCagraIndex_t),
+              "index merge is outside the north-star search path (SURVEY 2.1 #5)")
+#undef CAGRA_UNBUILT
+
+}  // extern "C"

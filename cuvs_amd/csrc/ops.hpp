@@ -61,4 +61,9 @@ template <typename T>
 void kmeans_predict(resources& res, const T* x, int64_t n, int64_t dim, const float* centers,
                     int n_clusters, uint32_t* labels);
 
+// ---------------------------------------------------------------- refine.hip
+// exact re-ranking of candidate ids; out sorted by (distance, id). All pointers device.
+void refine(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, const void* queries, int64_t m,
+            const int64_t* cand, int n_cand, int k, int metric, int64_t* out_i, float* out_d);
+
 }  // namespace cuvs_amd

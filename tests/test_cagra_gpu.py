@@ -1,0 +1,103 @@
+"""GPU: cuvsCagra* through the C ABI — the reference's golden vectors (c/tests/neighbors/ann_cagra_c.cu:31-50),
+its recall thresholds (cpp/tests/neighbors/ann_cagra.cuh:1416-1470: n=1000, q=100, k=16, min_recall 0.995) and
+graph invariants."""
+import numpy as np
+import pytest
+
+import oracle
+from tests.golden import reference_fixtures as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(x, **kw):
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    return cagra.build(cagra.IndexParams(**kw), torch.from_numpy(x).cuda())
+
+
+def _search(index, q, k, filter=None, **kw):
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    d, i = cagra.search(cagra.SearchParams(**kw), index, torch.from_numpy(q).cuda(), k, filter=filter)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+
+
+def test_golden_vectors():
+    index = _build(G.CAGRA_C_DATASET)
+    d, i = _search(index, G.CAGRA_C_QUERIES, 1)
+    assert (i[:, 0] == G.CAGRA_C_NEIGHBORS).all()
+    np.testing.assert_allclose(d[:, 0], G.CAGRA_C_DISTANCES, atol=G.CAGRA_C_TOL)
+
+
+def test_golden_vectors_filtered():
+    import torch
+    from cuvs_amd._lib import BITSET
+
+    index = _build(G.CAGRA_C_DATASET)
+    tw = torch.from_numpy(G.CAGRA_C_FILTER_WORDS.view(np.int32)).cuda()
+    d, i = _search(index, G.CAGRA_C_QUERIES, 1, filter=(tw, BITSET))
+    assert (i[:, 0] == G.CAGRA_C_NEIGHBORS_FILTERED).all()
+    np.testing.assert_allclose(d[:, 0], G.CAGRA_C_DISTANCES_FILTERED, atol=G.CAGRA_C_TOL)
+
+
+@pytest.mark.parametrize("dim", [1, 16])
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+def test_recall_reference_config(dim, metric):
+    if dim == 1 and metric == "inner_product":
+        pytest.skip("1-d inner product ranks every row identically")
+    rng = np.random.default_rng(1234)
+    x = (rng.random((1000, dim), dtype=np.float32) * 1.9 + 0.1).astype(np.float32)
+    q = (rng.random((100, dim), dtype=np.float32) * 1.9 + 0.1).astype(np.float32)
+    index = _build(x, metric=metric, intermediate_graph_degree=64, graph_degree=32)
+    d, i = _search(index, q, 16, itopk_size=256)
+    td, ti = oracle.exact_knn(q, x, 16, metric=metric)
+    hits = sum(len(np.intersect1d(a, b)) for a, b in zip(i, ti))
+    # the reference counts a distance match as a hit too (eval_neighbours); ids alone must already be close
+    assert hits / ti.size >= 0.98, hits / ti.size
+    close = np.isclose(d, td, rtol=1e-3, atol=1e-3).mean()
+    assert max(hits / ti.size, close) >= 0.995
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8, np.uint8])
+def test_dtypes_and_larger_dim(dtype):
+    rng = np.random.default_rng(7)
+    if dtype in (np.int8, np.uint8):
+        x = rng.integers(1, 20, size=(5000, 96)).astype(dtype)
+        q = rng.integers(1, 20, size=(200, 96)).astype(dtype)
+    else:
+        x = rng.standard_normal((5000, 96)).astype(dtype)
+        q = rng.standard_normal((200, 96)).astype(dtype)
+    index = _build(x, intermediate_graph_degree=64, graph_degree=32)
+    d, i = _search(index, q, 10, itopk_size=64)
+    _, ti = oracle.exact_knn(q.astype(np.float32), x.astype(np.float32), 10)
+    assert oracle.recall(i, ti) > 0.9
+
+
+def test_graph_invariants_and_int64_neighbors():
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3000, 32)).astype(np.float32)
+    index = _build(x, intermediate_graph_degree=48, graph_degree=24)
+    assert len(index) == 3000 and index.dim == 32 and index.graph_degree == 24
+    g = index.graph.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert g.shape == (3000, 24)
+    assert (g < 3000).all()                                   # no invalid edges
+    assert (g != np.arange(3000)[:, None]).all()              # no self loops
+    assert all(len(np.unique(r)) == 24 for r in g[:200])      # no duplicate edges
+    q = rng.standard_normal((50, 32)).astype(np.float32)
+    nb = torch.empty((50, 10), dtype=torch.int64, device="cuda")
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64), index, torch.from_numpy(q).cuda(), 10, neighbors=nb)
+    torch.cuda.synchronize()
+    _, ti = oracle.exact_knn(q, x, 10)
+    assert oracle.recall(i.cpu().numpy(), ti) > 0.95
+    # same index through cuvsCagraIndexFromArgs
+    idx2 = cagra.from_graph(index.graph, torch.from_numpy(x).cuda())
+    d2, i2 = cagra.search(cagra.SearchParams(itopk_size=64), idx2, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    assert ((i2.cpu().numpy().astype(np.int64) & 0xFFFFFFFF) == i.cpu().numpy()).all()
