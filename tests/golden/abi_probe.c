@@ -1,0 +1,53 @@
+/* Prints sizes/offsets of the C-ABI structs callers mutate directly. Compiled twice: against the reference's
+ * c/include (tests/golden/gen_abi_layout.sh -> abi_layout.txt, committed) and against this repo's include/. */
+#include <stddef.h>
+#include <stdio.h>
+#include <cuvs/neighbors/brute_force.h>
+#include <cuvs/neighbors/ivf_flat.h>
+#include <cuvs/neighbors/ivf_pq.h>
+#include <cuvs/neighbors/cagra.h>
+#define SZ(T) printf("sizeof " #T " %zu\n", sizeof(T))
+#define OFF(T, F) printf("offsetof " #T "." #F " %zu\n", offsetof(T, F))
+int main(void)
+{
+  SZ(struct cuvsIvfFlatIndexParams);
+  OFF(struct cuvsIvfFlatIndexParams, metric); OFF(struct cuvsIvfFlatIndexParams, metric_arg);
+  OFF(struct cuvsIvfFlatIndexParams, add_data_on_build); OFF(struct cuvsIvfFlatIndexParams, n_lists);
+  OFF(struct cuvsIvfFlatIndexParams, kmeans_n_iters); OFF(struct cuvsIvfFlatIndexParams, kmeans_trainset_fraction);
+  OFF(struct cuvsIvfFlatIndexParams, adaptive_centers); OFF(struct cuvsIvfFlatIndexParams, conservative_memory_allocation);
+  SZ(struct cuvsIvfFlatSearchParams);
+  SZ(struct cuvsIvfPqIndexParams);
+  OFF(struct cuvsIvfPqIndexParams, n_lists); OFF(struct cuvsIvfPqIndexParams, kmeans_trainset_fraction);
+  OFF(struct cuvsIvfPqIndexParams, pq_bits); OFF(struct cuvsIvfPqIndexParams, pq_dim);
+  OFF(struct cuvsIvfPqIndexParams, codebook_kind); OFF(struct cuvsIvfPqIndexParams, force_random_rotation);
+  OFF(struct cuvsIvfPqIndexParams, conservative_memory_allocation);
+  OFF(struct cuvsIvfPqIndexParams, max_train_points_per_pq_code); OFF(struct cuvsIvfPqIndexParams, codes_layout);
+  SZ(struct cuvsIvfPqSearchParams);
+  OFF(struct cuvsIvfPqSearchParams, n_probes); OFF(struct cuvsIvfPqSearchParams, lut_dtype);
+  OFF(struct cuvsIvfPqSearchParams, internal_distance_dtype); OFF(struct cuvsIvfPqSearchParams, coarse_search_dtype);
+  OFF(struct cuvsIvfPqSearchParams, max_internal_batch_size); OFF(struct cuvsIvfPqSearchParams, preferred_shmem_carveout);
+  SZ(struct cuvsCagraIndexParams);
+  OFF(struct cuvsCagraIndexParams, intermediate_graph_degree); OFF(struct cuvsCagraIndexParams, graph_degree);
+  OFF(struct cuvsCagraIndexParams, build_algo); OFF(struct cuvsCagraIndexParams, nn_descent_niter);
+  OFF(struct cuvsCagraIndexParams, compression); OFF(struct cuvsCagraIndexParams, graph_build_params);
+  SZ(struct cuvsCagraSearchParams);
+  OFF(struct cuvsCagraSearchParams, itopk_size); OFF(struct cuvsCagraSearchParams, max_iterations);
+  OFF(struct cuvsCagraSearchParams, algo); OFF(struct cuvsCagraSearchParams, team_size);
+  OFF(struct cuvsCagraSearchParams, search_width); OFF(struct cuvsCagraSearchParams, hashmap_mode);
+  OFF(struct cuvsCagraSearchParams, hashmap_max_fill_rate); OFF(struct cuvsCagraSearchParams, num_random_samplings);
+  OFF(struct cuvsCagraSearchParams, rand_xor_mask); OFF(struct cuvsCagraSearchParams, persistent);
+  OFF(struct cuvsCagraSearchParams, persistent_lifetime); OFF(struct cuvsCagraSearchParams, persistent_device_usage);
+  SZ(struct cuvsCagraCompressionParams); SZ(struct cuvsIvfPqParams); SZ(struct cuvsAceParams);
+  SZ(struct cuvsCagraExtendParams);
+  SZ(cuvsFilter); SZ(cuvsBruteForceIndex); SZ(cuvsIvfFlatIndex); SZ(cuvsIvfPqIndex); SZ(cuvsCagraIndex);
+  SZ(cuvsResources_t);
+  printf("enum CUVS_ERROR %d CUVS_SUCCESS %d\n", (int)CUVS_ERROR, (int)CUVS_SUCCESS);
+  printf("enum L2Expanded %d L2SqrtExpanded %d CosineExpanded %d L2Unexpanded %d InnerProduct %d\n", (int)L2Expanded,
+         (int)L2SqrtExpanded, (int)CosineExpanded, (int)L2Unexpanded, (int)InnerProduct);
+  printf("enum NO_FILTER %d BITSET %d BITMAP %d\n", (int)NO_FILTER, (int)BITSET, (int)BITMAP);
+  printf("enum IVF_PQ %d NN_DESCENT %d SINGLE_CTA %d MULTI_CTA %d AUTO %d\n", (int)IVF_PQ, (int)NN_DESCENT,
+         (int)SINGLE_CTA, (int)MULTI_CTA, (int)AUTO);
+  printf("enum CUDA_R_32F %d CUDA_R_16F %d CUDA_R_8I %d CUDA_R_8U %d\n", (int)CUDA_R_32F, (int)CUDA_R_16F,
+         (int)CUDA_R_8I, (int)CUDA_R_8U);
+  return 0;
+}

@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads and exports every symbol that include/cuvs/**.h declares; struct layouts that
+callers mutate directly have the reference's sizes/offsets (c/include/cuvs/neighbors/*.h)."""
+import ctypes as C
+import glob
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "cuvs_amd", "libcuvs_c.so")
+
+
+def _declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "cuvs", "**", "*.h"), recursive=True):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"CUVS_EXPORT\s+[\w\s\*]+?\b(cuvs\w+)\s*\(", text):
+            names.add(m.group(1))
+    return sorted(names)
+
+
+def test_library_exists_and_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "run `make` first"
+    syms = _declared_symbols()
+    assert len(syms) > 80
+    lib = C.CDLL(LIB)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+
+
+def test_error_text_convention_without_gpu():
+    lib = C.CDLL(LIB)
+    lib.cuvsGetLastErrorText.restype = C.c_char_p
+    lib.cuvsSetLastErrorText(b"boom")
+    assert lib.cuvsGetLastErrorText() == b"boom"
+    lib.cuvsSetLastErrorText(b"")
+    assert lib.cuvsGetLastErrorText() is None
+    major, minor, patch = C.c_uint16(), C.c_uint16(), C.c_uint16()
+    assert lib.cuvsVersionGet(C.byref(major), C.byref(minor), C.byref(patch)) == 1  # CUVS_SUCCESS
+    assert (major.value, minor.value) == (26, 8)
+    assert lib.cuvsVersionGet(None, None, None) == 0  # CUVS_ERROR, text set
+    assert lib.cuvsGetLastErrorText() is not None
+
+
+def test_param_struct_layouts_match_the_reference_headers(tmp_path):
+    # tests/golden/abi_layout.txt was produced by compiling tests/golden/abi_probe.c against the REFERENCE's
+    # c/include (tests/golden/gen_abi_layout.sh); the same probe against our include/ must print the same.
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "golden", "abi_probe.c"),
+                           "-o", str(exe)])
+    ours = subprocess.check_output([str(exe)]).decode()
+    want = open(os.path.join(ROOT, "tests", "golden", "abi_layout.txt")).read()
+    assert ours == want
