@@ -152,7 +152,7 @@ struct scan_args {
   uint32_t n_probes, rot_dim, pq_dim, pq_len, pq_bits, n_chunks, cpc, k;
   int is_ip;
   uint32_t* query_kth;  // [n_queries] order-preserving key of the best known k-th distance (shared by probes)
-  int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k, 8 no code loads
+  int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k
 };
 
 // gathers of one 16-byte chunk of 8-bit codes, issued 8 at a time (8 independent ds_reads in flight;
@@ -179,15 +179,11 @@ __device__ inline void gather16(acc_t& acc, const typename acc_t::entry_t* __res
 
 // FAST4: pq_bits == 8, pq_dim == 64 (4 full chunks): the four chunk loads of a tile are issued back to back. Otherwise the generic path handles any pq_dim / pq_bits.
 template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
-__global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
+__device__ inline void pq_scan_item(const scan_args& a, const work_item item, char* smem,
+                                    const float (&pqreg)[4][2][4], const bool pq_in_regs)
 {
   using acc_t   = lut_acc<LutT, AccT, QPB>;
   using entry_t = typename acc_t::entry_t;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const uint32_t w = blockIdx.x;
-  if (w >= *a.n_items) return;
-  const work_item item = a.items[w];
 
   const uint32_t book      = 1u << a.pq_bits;
   const uint32_t lut_elems = a.pq_dim * book;
@@ -232,32 +228,105 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   __syncthreads();
 
   // ---- LUT (create_lut_impl.cuh:17-78): entry (s, c) = QPB partial scores side by side
-#pragma unroll 2
-  for (uint32_t e = tid; e < ((a.dbg & 1) ? 0u : lut_elems); e += kScanThreads) {
-    const uint32_t s = e >> a.pq_bits, c = e & (book - 1);
-    float sc[QPB];
+  if (pq_in_regs && !(a.dbg & 1)) {
+    // pq_dim 64 x pq_len 2 x 256 codes: this thread's 32 codebook values stay in registers for the whole
+    // persistent launch (pq_scan_kernel), so the LUT build touches no global memory at all
 #pragma unroll
-    for (int j = 0; j < QPB; ++j) sc[j] = 0.f;
-    for (uint32_t l = 0; l < a.pq_len; ++l) {
-      const uint32_t dd = s * a.pq_len + l;
-      const float p     = a.pq_centers[(size_t)dd * book + c];
-      if (!a.is_ip) {
+    for (int sg = 0; sg < 4; ++sg) {
+      const uint32_t s = wave + sg * kScanWaves;
+      float q[2][QPB];
 #pragma unroll
-        for (int j = 0; j < QPB; ++j) {
-          float diff = qv[j * a.rot_dim + dd] - p;
-          sc[j]      = __fmaf_rn(diff, diff, sc[j]);
-        }
-      } else {
-        const float cc = cv[dd];
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) q[l][j] = qv[j * a.rot_dim + s * 2 + l];
+      const float cc0 = cv[s * 2], cc1 = cv[s * 2 + 1];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float sc[QPB];
 #pragma unroll
         for (int j = 0; j < QPB; ++j) {
-          float q = qv[j * a.rot_dim + dd];
-          sc[j]   = __fmaf_rn(-q, cc, sc[j]);
-          sc[j]   = __fmaf_rn(-q, p, sc[j]);
+          if (!a.is_ip) {
+            float d0 = q[0][j] - pqreg[sg][0][t];
+            float d1 = q[1][j] - pqreg[sg][1][t];
+            sc[j]    = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+          } else {
+            float v = __fmaf_rn(-q[0][j], cc0, 0.f);
+            v       = __fmaf_rn(-q[0][j], pqreg[sg][0][t], v);
+            v       = __fmaf_rn(-q[1][j], cc1, v);
+            sc[j]   = __fmaf_rn(-q[1][j], pqreg[sg][1][t], v);
+          }
         }
+        lut[(s << 8) + t * 64 + lane] = acc_t::pack(sc);
       }
     }
-    lut[e] = acc_t::pack(sc);
+  } else if (book >= 64 && !(a.dbg & 1)) {
+    // wave-per-subspace: the QPB query residuals of subspace s are read from LDS once per wave (they are the
+    // same for all 64 lanes) and reused for the book/64 code blocks; the codebook loads of a subspace are
+    // independent and in flight together
+    for (uint32_t s = wave; s < a.pq_dim; s += kScanWaves) {
+      for (uint32_t c0 = 0; c0 < book; c0 += 256) {
+        float sc[4][QPB];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) sc[t][j] = 0.f;
+        for (uint32_t l = 0; l < a.pq_len; ++l) {
+          const uint32_t dd = s * a.pq_len + l;
+          float q[QPB];
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) q[j] = qv[j * a.rot_dim + dd];
+          const float cc   = cv[dd];
+          const float* pqr = a.pq_centers + (size_t)dd * book + c0 + lane;
+          float p[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) p[t] = (c0 + t * 64 < book) ? pqr[t * 64] : 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int j = 0; j < QPB; ++j) {
+              if (!a.is_ip) {
+                float diff = q[j] - p[t];
+                sc[t][j]   = __fmaf_rn(diff, diff, sc[t][j]);
+              } else {
+                sc[t][j] = __fmaf_rn(-q[j], cc, sc[t][j]);
+                sc[t][j] = __fmaf_rn(-q[j], p[t], sc[t][j]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (c0 + t * 64 < book) lut[(s << a.pq_bits) + c0 + t * 64 + lane] = acc_t::pack(sc[t]);
+      }
+    }
+  } else {
+#pragma unroll 2
+    for (uint32_t e = tid; e < ((a.dbg & 1) ? 0u : lut_elems); e += kScanThreads) {
+      const uint32_t s = e >> a.pq_bits, c = e & (book - 1);
+      float sc[QPB];
+#pragma unroll
+      for (int j = 0; j < QPB; ++j) sc[j] = 0.f;
+      for (uint32_t l = 0; l < a.pq_len; ++l) {
+        const uint32_t dd = s * a.pq_len + l;
+        const float p     = a.pq_centers[(size_t)dd * book + c];
+        if (!a.is_ip) {
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) {
+            float diff = qv[j * a.rot_dim + dd] - p;
+            sc[j]      = __fmaf_rn(diff, diff, sc[j]);
+          }
+        } else {
+          const float cc = cv[dd];
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) {
+            float q = qv[j * a.rot_dim + dd];
+            sc[j]   = __fmaf_rn(-q, cc, sc[j]);
+            sc[j]   = __fmaf_rn(-q, p, sc[j]);
+          }
+        }
+      }
+      lut[e] = acc_t::pack(sc);
+    }
   }
   __syncthreads();
 
@@ -283,7 +352,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
       uint4 cur[4];
       const uint4* cp = codes16 + ((g0 + (size_t)it * kScanWaves + wave) * 4) * 64 + lane;
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) cur[ch] = (valid && !(a.dbg & 8)) ? cp[ch * 64] : make_uint4(lane, tid, it, ch);
+      for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];  // padded rows of a group are zero-filled: readable
       if (!(a.dbg & 2)) {
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) gather16(acc, lut + ((ch * 16) << 8), cur[ch]);
@@ -295,7 +364,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
       const uint4* cp = codes16 + (g * a.n_chunks) * 64 + lane;
       if (a.pq_bits == 8) {
         for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-          uint4 cw          = valid ? cp[(size_t)ch * 64] : make_uint4(0, 0, 0, 0);
+          uint4 cw          = cp[(size_t)ch * 64];
           const uint32_t s0 = ch * 16;
           if (s0 + 16 <= a.pq_dim) {
             gather16(acc, lut + (s0 << 8), cw);
@@ -310,7 +379,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
       } else {
         const uint32_t msk = book - 1;
         for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-          uint4 cw             = valid ? cp[(size_t)ch * 64] : make_uint4(0, 0, 0, 0);
+          uint4 cw             = cp[(size_t)ch * 64];
           const uint32_t ws[5] = {cw.x, cw.y, cw.z, cw.w, 0u};
           for (uint32_t b = 0; b < a.cpc; ++b) {
             uint32_t s = ch * a.cpc + b;
@@ -330,7 +399,9 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
       if (j >= (int)item.count) break;
       const float dj       = acc.get(j);
       const uint32_t bound = kthb[j];  // LDS broadcast read
-      unsigned long long m = __ballot(valid && float_to_key(dj) <= bound);
+      // L2 scores are >= 0: their order-preserving key is just the sign bit set
+      const uint32_t djk   = a.is_ip ? float_to_key(dj) : (__float_as_uint(dj) | 0x80000000u);
+      unsigned long long m = __ballot(valid && djk <= bound);
       if (m == 0ull) continue;
       float kd    = top[j].rank_d(kr);
       uint32_t ki = top[j].rank_i(kr);
@@ -405,6 +476,36 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
     }
     // tighten the bound shared by the other probes of this query
     if (lane == 0 && kd < INFINITY) atomicMin(&a.query_kth[pid[j] / a.n_probes], float_to_key(kd));
+  }
+}
+
+// Persistent launch: one 1024-thread workgroup per CU walks the work items. Items are sorted by list, and the
+// observed dispatch places workgroup b on XCD b % 8 (used for speed only): XCD x takes the x-th eighth of the
+// item array and its 32 CUs work on 32 consecutive items, so the ~20 work items of a list run on ONE XCD at
+// about the same time and share its 4 MiB L2 instead of pulling the list into all eight L2s.
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
+__global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t n_items = *a.n_items;
+  const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const uint32_t chunk = (n_items + 7u) / 8u;
+  float pqreg[4][2][4];
+  const bool pq_in_regs = FAST4 && a.pq_len == 2;  // FAST4: pq_dim 64, 8-bit codes
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          pqreg[sg][l][t] = pq_in_regs ? a.pq_centers[(size_t)((wave + sg * kScanWaves) * 2 + l) * 256 + t * 64 + lane] : 0.f;
+  }
+  for (uint32_t local = lb; local < chunk; local += per) {
+    const uint32_t w = xcd * chunk + local;
+    if (w < n_items) pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, a.items[w], smem, pqreg, pq_in_regs);
+    __syncthreads();
   }
 }
 
@@ -569,7 +670,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.pq_bits = idx.pq_bits; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.k = (uint32_t)k;
     a.is_ip = idx.metric == M_InnerProduct;
     a.dbg   = getenv("CUVS_AMD_SCAN_DEBUG") ? atoi(getenv("CUVS_AMD_SCAN_DEBUG")) : 0;
-    const unsigned grid = (unsigned)(n_pairs / qpb + idx.n_lists + 1);
+    const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);  // persistent: one workgroup per CU
     if (!lut_half) {
       if (qpb == 2) launch_scan_qpb<float, float, 2>(res, a, smem, grid, bits8, big_k);
       else          launch_scan_qpb<float, float, 1>(res, a, smem, grid, bits8, big_k);
