@@ -196,6 +196,7 @@ struct encode_args {
   int64_t id_base;            // used when new_ids == nullptr
   int64_t j0, batch;          // sorted positions [j0, j0 + batch)
   uint32_t rot_dim, pq_dim, pq_len, pq_bits, book, n_chunks, cpc;
+  uint32_t dc_sub;            // subspaces staged in LDS per pass (column tile of the residuals)
   uint8_t* codes;
   int64_t* indices;
 };
@@ -204,8 +205,9 @@ struct encode_args {
 __global__ __launch_bounds__(256) void encode_kernel(encode_args a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int ldr     = a.rot_dim + 1;
-  float* r_tile     = reinterpret_cast<float*>(smem);                       // [64][rot_dim + 1]
+  const int dc      = a.dc_sub * a.pq_len;                                  // columns staged per pass
+  const int ldr     = dc + 1;
+  float* r_tile     = reinterpret_cast<float*>(smem);                       // [64][dc + 1]
   int64_t* flat_row = reinterpret_cast<int64_t*>(r_tile + (((size_t)64 * ldr + 1) & ~size_t(1)));  // [64]
   uint32_t* lab     = reinterpret_cast<uint32_t*>(flat_row + 64);           // [64]
   uint8_t* ctile    = reinterpret_cast<uint8_t*>(lab + 64);                 // [64][pq_dim]
@@ -231,48 +233,53 @@ __global__ __launch_bounds__(256) void encode_kernel(encode_args a)
     }
   }
   __syncthreads();
-  for (int t = tid; t < 64 * (int)a.rot_dim; t += 256) {
-    int r = t / a.rot_dim, d = t % a.rot_dim;
-    float v = 0.f;
-    if (flat_row[r] >= 0) v = a.rx[(jb0 + r) * a.rot_dim + d] - a.centers_rot[(int64_t)lab[r] * a.rot_dim + d];
-    r_tile[r * ldr + d] = v;
-  }
-  __syncthreads();
-
-  for (uint32_t s0 = wave; s0 < a.pq_dim; s0 += 4) {
-    const uint32_t s    = __builtin_amdgcn_readfirstlane(s0);
-    const float* pq     = a.pq_centers + (size_t)s * a.pq_len * a.book;
-    const float* rrow   = r_tile + lane * ldr + s * a.pq_len;
-    float best          = INFINITY;
-    uint32_t code       = 0;
-    if (a.pq_len <= 8) {
-      float rv[8];
+  for (uint32_t sub0 = 0; sub0 < a.pq_dim; sub0 += a.dc_sub) {
+    const int col0  = sub0 * a.pq_len;
+    const int ncols = min((int)a.rot_dim - col0, dc);
+    for (int t = tid; t < 64 * ncols; t += 256) {
+      int r = t / ncols, d = t % ncols;
+      float v = 0.f;
+      if (flat_row[r] >= 0)
+        v = a.rx[(jb0 + r) * a.rot_dim + col0 + d] - a.centers_rot[(int64_t)lab[r] * a.rot_dim + col0 + d];
+      r_tile[r * ldr + d] = v;
+    }
+    __syncthreads();
+    const uint32_t sub_end = min(a.pq_dim, sub0 + a.dc_sub);
+    for (uint32_t s0 = sub0 + wave; s0 < sub_end; s0 += 4) {
+      const uint32_t s    = __builtin_amdgcn_readfirstlane(s0);
+      const float* pq     = a.pq_centers + (size_t)s * a.pq_len * a.book;
+      const float* rrow   = r_tile + lane * ldr + (s - sub0) * a.pq_len;
+      float best          = INFINITY;
+      uint32_t code       = 0;
+      if (a.pq_len <= 8) {
+        float rv[8];
 #pragma unroll
-      for (int l = 0; l < 8; ++l) rv[l] = l < (int)a.pq_len ? rrow[l] : 0.f;
-      for (uint32_t c = 0; c < a.book; ++c) {
-        float d = 0.f;
+        for (int l = 0; l < 8; ++l) rv[l] = l < (int)a.pq_len ? rrow[l] : 0.f;
+        for (uint32_t c = 0; c < a.book; ++c) {
+          float d = 0.f;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) {
-          if (l < (int)a.pq_len) {
-            float t = rv[l] - pq[l * a.book + c];
+          for (int l = 0; l < 8; ++l) {
+            if (l < (int)a.pq_len) {
+              float t = rv[l] - pq[l * a.book + c];
+              d       = __fmaf_rn(t, t, d);
+            }
+          }
+          if (d < best) { best = d; code = c; }
+        }
+      } else {
+        for (uint32_t c = 0; c < a.book; ++c) {
+          float d = 0.f;
+          for (uint32_t l = 0; l < a.pq_len; ++l) {
+            float t = rrow[l] - pq[l * a.book + c];
             d       = __fmaf_rn(t, t, d);
           }
+          if (d < best) { best = d; code = c; }
         }
-        if (d < best) { best = d; code = c; }
       }
-    } else {
-      for (uint32_t c = 0; c < a.book; ++c) {
-        float d = 0.f;
-        for (uint32_t l = 0; l < a.pq_len; ++l) {
-          float t = rrow[l] - pq[l * a.book + c];
-          d       = __fmaf_rn(t, t, d);
-        }
-        if (d < best) { best = d; code = c; }
-      }
+      ctile[lane * a.pq_dim + s] = (uint8_t)code;
     }
-    ctile[lane * a.pq_dim + s] = (uint8_t)code;
+    __syncthreads();
   }
-  __syncthreads();
 
   // pack: one thread per (row, chunk)
   for (uint32_t t = tid; t < 64 * a.n_chunks; t += 256) {
@@ -517,9 +524,11 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
   {
     const int64_t eb = std::max<int64_t>(64, std::min<int64_t>(n_new, (int64_t(1) << 27) / std::max<int64_t>(dim, idx.rot_dim)) / 64 * 64);
     dev_buf<float> xb(res, (size_t)eb * dim), rx(res, (size_t)eb * idx.rot_dim);
-    size_t smem = ((size_t)64 * (idx.rot_dim + 1) + 2) * sizeof(float) + 64 * sizeof(int64_t) + 64 * sizeof(uint32_t) +
-                  (size_t)64 * idx.pq_dim;
-    CUVS_EXPECTS(smem <= 160 * 1024, "encode: rot_dim too large for the LDS tile");
+    CUVS_EXPECTS(idx.pq_len <= 240, "encode: pq_len %u too large", idx.pq_len);
+    const uint32_t dc_sub = std::min<uint32_t>(idx.pq_dim, std::max<uint32_t>(1, 240 / idx.pq_len));
+    size_t smem = ((size_t)64 * (dc_sub * idx.pq_len + 1) + 2) * sizeof(float) + 64 * sizeof(int64_t) +
+                  64 * sizeof(uint32_t) + (size_t)64 * idx.pq_dim;
+    CUVS_EXPECTS(smem <= 160 * 1024, "encode: tile does not fit LDS");
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     for (int64_t j0 = 0; j0 < n_new; j0 += eb) {
@@ -533,7 +542,7 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
       a.centers_rot = idx.centers_rot.data(); a.pq_centers = idx.pq_centers.data();
       a.new_ids = new_ids; a.id_base = idx.size; a.j0 = j0; a.batch = cnt;
       a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len; a.pq_bits = idx.pq_bits;
-      a.book = idx.pq_book; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk;
+      a.book = idx.pq_book; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.dc_sub = dc_sub;
       a.codes = codes.data(); a.indices = indices.data();
       hipLaunchKernelGGL(encode_kernel, dim3(nblk(cnt, 64)), dim3(256), smem, res.stream, a);
     }

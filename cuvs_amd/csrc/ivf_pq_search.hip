@@ -212,13 +212,13 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     pid[tid]         = p;
     kthb[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
   }
-  __syncthreads();
-  // query residuals (L2) or raw rotated queries + list centre (IP)
+  // query residuals (L2) or raw rotated queries + list centre (IP); every thread resolves its pair id itself so
+  // that this phase needs no barrier after the header loads above
   for (uint32_t t = tid; t < QPB * a.rot_dim; t += kScanThreads) {
     uint32_t j = t / a.rot_dim, dd = t % a.rot_dim;
     float v = 0.f;
     if (j < item.count) {
-      uint32_t q = pid[j] / a.n_probes;
+      uint32_t q = a.sorted_pairs[item.first + j] / a.n_probes;
       v          = a.rot_queries[(size_t)q * a.rot_dim + dd];
       if (!a.is_ip) v -= a.centers_rot[(size_t)L * a.rot_dim + dd];
     }
@@ -394,14 +394,23 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     }
 
     if (a.dbg & 4) continue;
+    // ---- candidate filter: one ballot over "any query passes" first (almost always empty once the bounds
+    // are warm), then per query
+    float dj[QPB];
+    uint32_t djk[QPB];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) {
+      dj[j]  = acc.get(j);
+      // L2 scores are >= 0: their order-preserving key is just the sign bit set
+      djk[j] = a.is_ip ? float_to_key(dj[j]) : (__float_as_uint(dj[j]) | 0x80000000u);
+      any    = any || (j < (int)item.count && djk[j] <= kthb[j]);  // kthb: LDS broadcast reads
+    }
+    if (__ballot(valid && any) == 0ull) continue;
 #pragma unroll
     for (int j = 0; j < QPB; ++j) {
       if (j >= (int)item.count) break;
-      const float dj       = acc.get(j);
-      const uint32_t bound = kthb[j];  // LDS broadcast read
-      // L2 scores are >= 0: their order-preserving key is just the sign bit set
-      const uint32_t djk   = a.is_ip ? float_to_key(dj) : (__float_as_uint(dj) | 0x80000000u);
-      unsigned long long m = __ballot(valid && djk <= bound);
+      unsigned long long m = __ballot(valid && djk[j] <= kthb[j]);
       if (m == 0ull) continue;
       float kd    = top[j].rank_d(kr);
       uint32_t ki = top[j].rank_i(kr);
@@ -409,7 +418,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
       while (m != 0ull) {
         const int src = (int)__ffsll((long long)m) - 1;
         m &= m - 1ull;
-        const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), src));
+        const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[j]), src));
         const uint32_t ci = tile0 + (uint32_t)src;
         if ((cd < kd) || (cd == kd && ci < ki)) {
           top[j].insert(cd, ci, lane);
@@ -502,10 +511,16 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
         for (int t = 0; t < 4; ++t)
           pqreg[sg][l][t] = pq_in_regs ? a.pq_centers[(size_t)((wave + sg * kScanWaves) * 2 + l) * 256 + t * 64 + lane] : 0.f;
   }
+  work_item cur{0, 0, 0, 0};
+  if (lb < chunk && xcd * chunk + lb < n_items) cur = a.items[xcd * chunk + lb];
   for (uint32_t local = lb; local < chunk; local += per) {
-    const uint32_t w = xcd * chunk + local;
-    if (w < n_items) pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, a.items[w], smem, pqreg, pq_in_regs);
+    const uint32_t w  = xcd * chunk + local;
+    const uint32_t wn = w + per;  // header of the next item: loaded now, needed after this item
+    work_item nxt     = cur;
+    if (local + per < chunk && wn < n_items) nxt = a.items[wn];
+    if (w < n_items) pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, cur, smem, pqreg, pq_in_regs);
     __syncthreads();
+    cur = nxt;
   }
 }
 
