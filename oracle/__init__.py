@@ -160,3 +160,51 @@ def ivf_flat_search(exported, queries, k, n_probes, metric="sqeuclidean", coarse
                                  C.c_int(len(sizes)), _p(sizes), _p(start), _p(rows), _p(ids), C.c_int(_metric(metric)),
                                  C.c_int(n_probes), C.c_int(k), _p(nb), _p(ds))
     return ds, nb
+
+
+def cagra_search(dataset, graph, queries, k, itopk_size=64, search_width=1, max_iterations=0, min_iterations=0,
+                 hashmap_min_bitlen=0, rand_xor_mask=0x128394, metric="sqeuclidean", filter_words=None):
+    """CPU twin of cuvsCagraSearch (same parameter derivation as cuvs_amd/csrc/cagra.hip: search_plan.cuh:199-245).
+    dataset/queries in the index dtype; graph uint32 [n, degree]. Returns (distances, neighbors)."""
+    raw = np.asarray(dataset)
+    vl = 16 // raw.dtype.itemsize
+    x, q = _f32(raw.astype(np.float32)), _f32(np.asarray(queries).astype(np.float32))
+    g = np.ascontiguousarray(graph, dtype=np.uint32)
+    n, degree = g.shape
+    width = max(1, min(8, int(search_width)))
+    itopk = max(int(itopk_size) if itopk_size else 64, k)
+    if itopk % 32:
+        itopk += 32 - itopk % 32
+    max_iter = int(max_iterations)
+    if max_iter == 0:
+        max_iter = itopk // width
+        reach = 1
+        while reach < n:
+            reach *= max(2, degree // 2)
+            max_iter += 1
+    max_iter = max(max_iter, int(min_iterations))
+    bits = 11
+    while (1 << bits) < 2 * (itopk + 2 * width * degree):
+        bits += 1
+    bits = max(bits, int(hashmap_min_bitlen))
+    reset = max(1, ((1 << bits) // 2 - itopk) // (width * degree))
+    nq = q.shape[0]
+    oi = np.empty((nq, k), np.int64)
+    od = np.empty((nq, k), np.float32)
+    fw = None if filter_words is None else np.ascontiguousarray(filter_words, dtype=np.uint32)
+    lib().oracle_cagra_search(_p(x), C.c_int64(n), C.c_int64(x.shape[1]), C.c_int(vl), _p(g), C.c_int(degree), _p(q),
+                              C.c_int64(nq), C.c_int(k), C.c_int(itopk), C.c_int(width), C.c_int(max_iter),
+                              C.c_int(int(min_iterations)), C.c_int(bits), C.c_int(reset), C.c_uint64(rand_xor_mask),
+                              C.c_int(int(_metric(metric) == 6)), _p(fw) if fw is not None else None, _p(oi), _p(od))
+    return od, oi
+
+
+def kmeans_balanced_fit(x, n_clusters, n_iters=20, hierarchical=True):
+    """CPU twin of the balanced k-means (cuvs_amd/csrc/kmeans_balanced.hip). Returns (centers, labels)."""
+    x = _f32(x)
+    n, dim = x.shape
+    centers = np.empty((n_clusters, dim), np.float32)
+    labels = np.empty(n, np.uint32)
+    lib().oracle_kmeans_balanced_fit(_p(x), C.c_int64(n), C.c_int(dim), C.c_int(n_clusters), C.c_int(n_iters),
+                                     C.c_int(int(hierarchical)), _p(centers), _p(labels))
+    return centers, labels

@@ -61,7 +61,7 @@ if "flat" in what:  # C2: 10M x 128 fp32, nlist 4096, nprobe 64, batch 10k
 
 if "cagra" in what:  # C4 scaled: N x 768 fp16, degree 64, itopk 64, batch 10k
     n = cagra_rows
-    x = bench.gen_rows(n, 768, 1234, dev, latent=64).half(); q = bench.gen_rows(10000, 768, 4321, dev, latent=64).half()
+    x = bench.gen_rows(n, 768, 1234, dev, latent=64, n_modes=1).half(); q = bench.gen_rows(10000, 768, 4321, dev, latent=64, n_modes=1).half()  # one broad mode: the kNN graph of well-separated tight modes is disconnected and no graph walk from random seeds can cross modes
     t0 = time.time(); idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res); res.sync()
     build_s = time.time() - t0
     sp = cagra.SearchParams(itopk_size=64)

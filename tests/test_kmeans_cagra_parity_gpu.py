@@ -1,0 +1,66 @@
+"""GPU: bit-level parity of the balanced k-means and of the CAGRA graph walk with their CPU twins."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_kmeans(x, k, n_iters, hierarchical):
+    import torch
+    import cuvs_amd
+    from cuvs_amd._lib import check, lib
+
+    res = cuvs_amd.common.Resources()
+    tx = torch.from_numpy(x).cuda()
+    centers = torch.empty((k, x.shape[1]), dtype=torch.float32, device="cuda")
+    labels = torch.empty((x.shape[0],), dtype=torch.int32, device="cuda")
+    fn = lib().cuvsAmdKMeansBalancedFit
+    fn.argtypes = [C.c_size_t, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    check(fn(res.get_c_obj(), tx.data_ptr(), x.shape[0], x.shape[1], k, n_iters, int(hierarchical), centers.data_ptr(),
+             labels.data_ptr()))
+    res.sync()
+    return centers.cpu().numpy(), labels.cpu().numpy().astype(np.uint32)
+
+
+@pytest.mark.parametrize("n,d,k,hier", [(3000, 16, 12, False), (5000, 32, 64, True), (2000, 5, 30, True),
+                                        (4096, 2, 256, False)])
+def test_kmeans_bit_exact_and_balanced(n, d, k, hier):
+    rng = np.random.default_rng(n + k)
+    modes = rng.standard_normal((max(4, k // 3), d)).astype(np.float32) * 3
+    x = (modes[rng.integers(0, len(modes), n)] + rng.standard_normal((n, d)).astype(np.float32)).astype(np.float32)
+    gc, gl = _gpu_kmeans(x, k, 10, hier)
+    oc, ol = oracle.kmeans_balanced_fit(x, k, 10, hier)
+    assert (gc == oc).all(), f"centre mismatch: max abs {np.abs(gc - oc).max()}"
+    assert (gl == ol).all()
+    sizes = np.bincount(gl, minlength=k)
+    assert sizes.min() > 0  # balancing leaves no empty cluster (reference: adjust_centers, :464-580)
+    assert sizes.max() < 12 * n / k
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8])
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+def test_cagra_search_walk_matches_oracle(dtype, metric):
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(5)
+    if dtype == np.int8:
+        x = rng.integers(-20, 20, size=(3000, 40)).astype(dtype)
+        q = rng.integers(-20, 20, size=(120, 40)).astype(dtype)
+    else:
+        x = rng.standard_normal((3000, 40)).astype(dtype)
+        q = rng.standard_normal((120, 40)).astype(dtype)
+    index = cagra.build(cagra.IndexParams(metric=metric, intermediate_graph_degree=48, graph_degree=24),
+                        torch.from_numpy(x).cuda())
+    graph = index.graph.cpu().numpy().view(np.uint32)
+    for itopk, width in [(64, 1), (96, 2)]:
+        d, i = cagra.search(cagra.SearchParams(itopk_size=itopk, search_width=width), index, torch.from_numpy(q).cuda(), 10)
+        torch.cuda.synchronize()
+        gi = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+        od, oi = oracle.cagra_search(x, graph, q, 10, itopk_size=itopk, search_width=width, metric=metric)
+        assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.4f}"
+        assert (d.cpu().numpy() == od).all()
