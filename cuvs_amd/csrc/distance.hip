@@ -357,3 +357,33 @@ INST_A(float) INST_A(__half) INST_A(int8_t) INST_A(uint8_t)
 #undef INST_A
 
 }  // namespace cuvs_amd
+
+// Test/bench hooks (not in the reference ABI): the fp32 distance GEMM and the fused argmin on device floats.
+extern "C" __attribute__((visibility("default"))) int cuvsAmdPairwiseDistance(uintptr_t res, const float* q,
+                                                                               int64_t m, const float* x, int64_t n,
+                                                                               int64_t dim, int metric, float* out)
+{
+  using namespace cuvs_amd;
+  return translate_exceptions([=] {
+    auto& r = *as_res(res);
+    dev_buf<float> qn(r, m), xn(r, n);
+    if (metric != M_InnerProduct) {
+      row_norms<float>(r, q, m, dim, dim, qn.data(), metric == M_CosineExpanded);
+      row_norms<float>(r, x, n, dim, dim, xn.data(), metric == M_CosineExpanded);
+    }
+    pairwise_distance<float, float>(r, q, m, dim, x, n, dim, dim, qn.data(), xn.data(), metric, out, n);
+  });
+}
+
+extern "C" __attribute__((visibility("default"))) int cuvsAmdFusedArgmin(uintptr_t res, const float* q, int64_t m,
+                                                                          const float* centers, int64_t n, int64_t dim,
+                                                                          uint32_t* labels)
+{
+  using namespace cuvs_amd;
+  return translate_exceptions([=] {
+    auto& r = *as_res(res);
+    dev_buf<float> cn(r, n);
+    row_norms<float>(r, centers, n, dim, dim, cn.data(), false);
+    fused_l2_argmin<float>(r, q, m, dim, centers, n, dim, cn.data(), labels, nullptr);
+  });
+}
