@@ -4,6 +4,7 @@
 // c/src/neighbors/brute_force.cpp:143-231). Pre-filters (bitset / bitmap) are applied to the distance tile.
 #include "ops.hpp"
 #include "device_utils.hpp"
+#include "serialize.hpp"
 
 #include <cuvs/neighbors/brute_force.h>
 
@@ -234,16 +235,43 @@ cuvsError_t cuvsBruteForceSearch(cuvsResources_t res_h, cuvsBruteForceIndex_t in
   });
 }
 
-cuvsError_t cuvsBruteForceSerialize(cuvsResources_t, const char*, cuvsBruteForceIndex_t)
+cuvsError_t cuvsBruteForceSerialize(cuvsResources_t res_h, const char* filename, cuvsBruteForceIndex_t index_c_ptr)
 {
-  return (cuvsError_t)translate_exceptions(
-    [=] { CUVS_FAIL("cuvsBruteForceSerialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index_c_ptr && index_c_ptr->addr, "index is not built");
+    auto& idx = *reinterpret_cast<bf_index*>(index_c_ptr->addr);
+    file_writer w(filename, KIND_BRUTE_FORCE);
+    w.scalar<int32_t>(idx.metric); w.scalar<float>(idx.metric_arg); w.scalar<int32_t>((int)idx.dtype);
+    w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);
+    w.scalar<uint8_t>(index_c_ptr->dtype.code); w.scalar<uint8_t>(index_c_ptr->dtype.bits);
+    CUVS_EXPECTS(idx.ld == idx.dim, "strided dataset cannot be serialized");
+    w.device_array(res, idx.data, (size_t)idx.n * idx.dim * elem_size(idx.dtype));
+    w.device_array(res, idx.norms.data(), idx.norms.bytes());
+  });
 }
 
-cuvsError_t cuvsBruteForceDeserialize(cuvsResources_t, const char*, cuvsBruteForceIndex_t)
+cuvsError_t cuvsBruteForceDeserialize(cuvsResources_t res_h, const char* filename, cuvsBruteForceIndex_t index)
 {
-  return (cuvsError_t)translate_exceptions(
-    [=] { CUVS_FAIL("cuvsBruteForceDeserialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index != nullptr, "index is null");
+    file_reader r(filename, KIND_BRUTE_FORCE);
+    auto idx        = std::make_unique<bf_index>();
+    idx->metric     = r.scalar<int32_t>();
+    idx->metric_arg = r.scalar<float>();
+    idx->dtype      = (elem_t)r.scalar<int32_t>();
+    idx->n          = r.scalar<int64_t>();
+    idx->dim        = r.scalar<int64_t>();
+    idx->ld         = idx->dim;
+    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
+    idx->owned = r.device_array<char>(res);
+    idx->norms = r.device_array<float>(res);
+    idx->data  = idx->owned.data();
+    delete reinterpret_cast<bf_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = DLDataType{code, bits, 1};
+  });
 }
 
 }  // extern "C"

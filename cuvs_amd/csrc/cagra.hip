@@ -16,6 +16,7 @@
 #include "ivf_pq.hpp"
 #include "ops.hpp"
 #include "device_utils.hpp"
+#include "serialize.hpp"
 
 #include <cuvs/neighbors/cagra.h>
 
@@ -768,16 +769,47 @@ cuvsError_t cuvsCagraSearch(cuvsResources_t res_h, cuvsCagraSearchParams_t param
   });
 }
 
+cuvsError_t cuvsCagraSerialize(cuvsResources_t res_h, const char* filename, cuvsCagraIndex_t index, bool include_dataset)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_cagra(index);
+    file_writer w(filename, KIND_CAGRA);
+    w.scalar<int32_t>(idx.metric); w.scalar<int32_t>((int)idx.dtype); w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);
+    w.scalar<uint32_t>(idx.degree); w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);
+    w.scalar<uint8_t>(include_dataset ? 1 : 0);
+    w.device_array(res, idx.graph.data(), idx.graph.bytes());
+    if (include_dataset) w.device_array(res, idx.data, (size_t)idx.n * idx.dim * elem_size(idx.dtype));
+  });
+}
+
+cuvsError_t cuvsCagraDeserialize(cuvsResources_t res_h, const char* filename, cuvsCagraIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index != nullptr, "index is null");
+    file_reader r(filename, KIND_CAGRA);
+    auto idx    = std::make_unique<cagra_index>();
+    idx->metric = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>(); idx->n = r.scalar<int64_t>();
+    idx->dim = r.scalar<int64_t>(); idx->degree = r.scalar<uint32_t>();
+    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>(), has_data = r.scalar<uint8_t>();
+    idx->graph = r.device_array<uint32_t>(res);
+    if (has_data) {
+      idx->owned = r.device_array<char>(res);
+      idx->data  = idx->owned.data();
+    }
+    delete reinterpret_cast<cagra_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = DLDataType{code, bits, 1};
+  });
+}
+
 #define CAGRA_UNBUILT(NAME, SIG, WHY)                                                                   \
   cuvsError_t NAME SIG { return (cuvsError_t)translate_exceptions([=] { CUVS_FAIL(#NAME ": " WHY); }); }
 CAGRA_UNBUILT(cuvsCagraExtend, (cuvsResources_t, cuvsCagraExtendParams_t, DLManagedTensor*, cuvsCagraIndex_t),
               "add_nodes is outside the north-star search path (SURVEY 2.1 #5)")
-CAGRA_UNBUILT(cuvsCagraSerialize, (cuvsResources_t, const char*, cuvsCagraIndex_t, bool),
-              "index (de)serialization is not built yet (SURVEY 8f N2)")
 CAGRA_UNBUILT(cuvsCagraSerializeToHnswlib, (cuvsResources_t, const char*, cuvsCagraIndex_t),
               "hnswlib export is outside the hot path (SURVEY 2.1 #5)")
-CAGRA_UNBUILT(cuvsCagraDeserialize, (cuvsResources_t, const char*, cuvsCagraIndex_t),
-              "index (de)serialization is not built yet (SURVEY 8f N2)")
 CAGRA_UNBUILT(cuvsCagraMerge, (cuvsResources_t, cuvsCagraIndexParams_t, cuvsCagraIndex_t*, size_t, cuvsFilter,
                                cuvsCagraIndex_t),
               "index merge is outside the north-star search path (SURVEY 2.1 #5)")

@@ -12,6 +12,7 @@
 // tile sits in LDS as [dim][8] so two broadcast ds_read_b128 feed 8 fma chains per loaded element. Per-wave
 // register top lists + shared k-th bounds as in the PQ scan. In-list order is ascending source id.
 #include "ivf_common.hpp"
+#include "serialize.hpp"
 
 #include <cuvs/neighbors/ivf_flat.h>
 
@@ -116,6 +117,8 @@ struct flat_scan_args {
   float* out_d;
   uint32_t* out_i;
   uint32_t* query_kth;
+  const uint32_t* filter_bits;  // optional bitset over source ids (1 keeps), sample_filter.cuh semantics
+  const int64_t* indices;       // flat row -> source id (only read when filtering)
   uint32_t n_probes, dim, veclen, n_chunks, k;
   int is_ip;
 };
@@ -217,6 +220,10 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
         m &= m - 1ull;
         const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj), src));
         const uint32_t ci = tile0 + (uint32_t)src;
+        if (a.filter_bits != nullptr) {  // pre-filter: rows whose source id is masked out never enter the top list
+          const int64_t sid = a.indices[(size_t)base_row + ci];
+          if (!((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u)) continue;
+        }
         if ((cd < kd) || (cd == kd && ci < ki)) {
           top[j].insert(cd, ci, lane);
           kd       = top[j].rank_d(kr);
@@ -476,7 +483,7 @@ std::unique_ptr<ivf_flat_index> ivf_flat_build(resources& res, const cuvsIvfFlat
 }
 
 void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probes_in, const void* queries, elem_t et,
-                     int64_t n_queries, int k, int64_t* neighbors, float* distances)
+                     int64_t n_queries, int k, int64_t* neighbors, float* distances, const uint32_t* filter_bits)
 {
   CUVS_EXPECTS(k > 0 && k <= 256, "ivf_flat::search: k must be in [1, 256]");
   CUVS_EXPECTS(n_probes_in > 0, "n_probes must be positive");
@@ -528,6 +535,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     a.items = items.data(); a.n_items = item_off.data() + idx.n_lists; a.sorted_pairs = sorted_pairs.data();
     a.queries = qptr; a.data = idx.data.data(); a.list_offsets = idx.list_offsets.data();
     a.list_sizes = idx.list_sizes.data(); a.out_d = cand_d.data(); a.out_i = cand_i.data();
+    a.filter_bits = filter_bits; a.indices = idx.indices.data();
     a.query_kth = query_kth.data(); a.n_probes = n_probes; a.dim = idx.dim; a.veclen = idx.veclen;
     a.n_chunks = idx.n_chunks; a.k = (uint32_t)k; a.is_ip = idx.metric == M_InnerProduct;
     const unsigned grid = (unsigned)(n_pairs / qpb + idx.n_lists + 1);
@@ -630,7 +638,13 @@ cuvsError_t cuvsIvfFlatSearch(cuvsResources_t res_h, cuvsIvfFlatSearchParams_t p
     auto& res = *as_res(res_h);
     auto& idx = get_flat(index_c);
     CUVS_EXPECTS(params && queries_tensor && neighbors_tensor && distances_tensor, "null argument");
-    CUVS_EXPECTS(filter.type == NO_FILTER, "cuvsIvfFlatSearch: pre-filters are not built yet (SURVEY 8f N4)");
+    const uint32_t* bits = nullptr;
+    if (filter.type != NO_FILTER) {
+      CUVS_EXPECTS(filter.type == BITSET && filter.addr != 0, "cuvsIvfFlatSearch: only BITSET filters are supported");
+      auto& ft = reinterpret_cast<DLManagedTensor*>(filter.addr)->dl_tensor;
+      CUVS_EXPECTS(dtype_is(ft.dtype, kDLUInt, 32) && is_device_accessible(ft), "filter must be a device uint32 tensor");
+      bits = static_cast<const uint32_t*>(dl_data(ft));
+    }
     auto& queries   = queries_tensor->dl_tensor;
     auto& neighbors = neighbors_tensor->dl_tensor;
     auto& distances = distances_tensor->dl_tensor;
@@ -650,7 +664,7 @@ cuvsError_t cuvsIvfFlatSearch(cuvsResources_t res_h, cuvsIvfFlatSearchParams_t p
     CUVS_EXPECTS(neighbors.shape[0] == m && distances.shape[0] == m && distances.shape[1] == k,
                  "neighbors/distances shape mismatch");
     ivf_flat_search(res, idx, params->n_probes, dl_data(queries), elem_of(queries.dtype), m, (int)k,
-                    static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)));
+                    static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)), bits);
   });
 }
 
@@ -675,15 +689,47 @@ cuvsError_t cuvsIvfFlatExtend(cuvsResources_t res_h, DLManagedTensor* new_vector
   });
 }
 
-cuvsError_t cuvsIvfFlatSerialize(cuvsResources_t, const char*, cuvsIvfFlatIndex_t)
+cuvsError_t cuvsIvfFlatSerialize(cuvsResources_t res_h, const char* filename, cuvsIvfFlatIndex_t index)
 {
-  return (cuvsError_t)translate_exceptions(
-    [=] { CUVS_FAIL("cuvsIvfFlatSerialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_flat(index);
+    file_writer w(filename, KIND_IVF_FLAT);
+    w.scalar<int32_t>(idx.metric); w.scalar<int32_t>((int)idx.dtype); w.scalar<uint32_t>(idx.n_lists);
+    w.scalar<uint32_t>(idx.dim); w.scalar<uint32_t>(idx.veclen); w.scalar<uint32_t>(idx.n_chunks);
+    w.scalar<int64_t>(idx.size); w.scalar<int64_t>(idx.padded_rows);
+    w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);
+    w.device_array(res, idx.centers.data(), idx.centers.bytes());
+    w.device_array(res, idx.center_norms.data(), idx.center_norms.bytes());
+    w.device_array(res, idx.list_sizes.data(), idx.list_sizes.bytes());
+    w.device_array(res, idx.list_offsets.data(), idx.list_offsets.bytes());
+    w.device_array(res, idx.data.data(), idx.data.bytes());
+    w.device_array(res, idx.indices.data(), idx.indices.bytes());
+  });
 }
-cuvsError_t cuvsIvfFlatDeserialize(cuvsResources_t, const char*, cuvsIvfFlatIndex_t)
+cuvsError_t cuvsIvfFlatDeserialize(cuvsResources_t res_h, const char* filename, cuvsIvfFlatIndex_t index)
 {
-  return (cuvsError_t)translate_exceptions(
-    [=] { CUVS_FAIL("cuvsIvfFlatDeserialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index != nullptr, "index is null");
+    file_reader r(filename, KIND_IVF_FLAT);
+    auto idx = std::make_unique<ivf_flat_index>();
+    idx->metric = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>(); idx->n_lists = r.scalar<uint32_t>();
+    idx->dim = r.scalar<uint32_t>(); idx->veclen = r.scalar<uint32_t>(); idx->n_chunks = r.scalar<uint32_t>();
+    idx->size = r.scalar<int64_t>(); idx->padded_rows = r.scalar<int64_t>();
+    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
+    idx->centers      = r.device_array<float>(res);
+    idx->center_norms = r.device_array<float>(res);
+    idx->list_sizes   = r.device_array<uint32_t>(res);
+    idx->list_offsets = r.device_array<uint32_t>(res);
+    idx->data         = r.device_array<uint8_t>(res);
+    idx->indices      = r.device_array<int64_t>(res);
+    idx->h_list_sizes   = to_host(res, idx->list_sizes.data(), idx->n_lists);
+    idx->h_list_offsets = to_host(res, idx->list_offsets.data(), idx->n_lists + 1);
+    delete reinterpret_cast<ivf_flat_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = DLDataType{code, bits, 1};
+  });
 }
 
 // test hooks (not in the reference ABI): list size, and a row-major copy of one list + its source ids

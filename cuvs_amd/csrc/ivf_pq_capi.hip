@@ -1,6 +1,7 @@
 // cuvsIvfPq* C entry points (drop-in for c/src/neighbors/ivf_pq.cpp) over ivf_pq_build.hip / ivf_pq_search.hip.
 #include "ivf_pq.hpp"
 #include "ops.hpp"
+#include "serialize.hpp"
 
 #include <cuvs/neighbors/ivf_pq.h>
 
@@ -286,15 +287,57 @@ cuvsError_t cuvsIvfPqIndexGetListIndices(cuvsIvfPqIndex_t index, uint32_t label,
   });
 }
 
-cuvsError_t cuvsIvfPqSerialize(cuvsResources_t, const char*, cuvsIvfPqIndex_t)
+cuvsError_t cuvsIvfPqSerialize(cuvsResources_t res_h, const char* filename, cuvsIvfPqIndex_t index)
 {
-  return (cuvsError_t)translate_exceptions(
-    [=] { CUVS_FAIL("cuvsIvfPqSerialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_index(index);
+    file_writer w(filename, KIND_IVF_PQ);
+    w.scalar<int32_t>(idx.metric); w.scalar<int32_t>(idx.codebook_kind); w.scalar<int32_t>((int)idx.dtype);
+    const uint32_t u[] = {idx.n_lists, idx.dim, idx.dim_ext, idx.rot_dim, idx.pq_dim, idx.pq_bits, idx.pq_len,
+                          idx.pq_book, idx.n_chunks, idx.codes_per_chunk};
+    for (uint32_t v : u) w.scalar<uint32_t>(v);
+    w.scalar<int64_t>(idx.size); w.scalar<int64_t>(idx.padded_rows);
+    w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);
+    w.device_array(res, idx.centers.data(), idx.centers.bytes());
+    w.device_array(res, idx.center_norms.data(), idx.center_norms.bytes());
+    w.device_array(res, idx.centers_rot.data(), idx.centers_rot.bytes());
+    w.device_array(res, idx.rotation.data(), idx.rotation.bytes());
+    w.device_array(res, idx.pq_centers.data(), idx.pq_centers.bytes());
+    w.device_array(res, idx.list_sizes.data(), idx.list_sizes.bytes());
+    w.device_array(res, idx.list_offsets.data(), idx.list_offsets.bytes());
+    w.device_array(res, idx.codes.data(), idx.codes.bytes());
+    w.device_array(res, idx.indices.data(), idx.indices.bytes());
+  });
 }
-cuvsError_t cuvsIvfPqDeserialize(cuvsResources_t, const char*, cuvsIvfPqIndex_t)
+cuvsError_t cuvsIvfPqDeserialize(cuvsResources_t res_h, const char* filename, cuvsIvfPqIndex_t index)
 {
-  return (cuvsError_t)translate_exceptions(
-    [=] { CUVS_FAIL("cuvsIvfPqDeserialize: index (de)serialization is not built yet (SURVEY 8f N2)"); });
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index != nullptr, "index is null");
+    file_reader r(filename, KIND_IVF_PQ);
+    auto idx = std::make_unique<ivf_pq_index>();
+    idx->metric = r.scalar<int32_t>(); idx->codebook_kind = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>();
+    uint32_t* u[] = {&idx->n_lists, &idx->dim, &idx->dim_ext, &idx->rot_dim, &idx->pq_dim, &idx->pq_bits, &idx->pq_len,
+                     &idx->pq_book, &idx->n_chunks, &idx->codes_per_chunk};
+    for (uint32_t* v : u) *v = r.scalar<uint32_t>();
+    idx->size = r.scalar<int64_t>(); idx->padded_rows = r.scalar<int64_t>();
+    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
+    idx->centers      = r.device_array<float>(res);
+    idx->center_norms = r.device_array<float>(res);
+    idx->centers_rot  = r.device_array<float>(res);
+    idx->rotation     = r.device_array<float>(res);
+    idx->pq_centers   = r.device_array<float>(res);
+    idx->list_sizes   = r.device_array<uint32_t>(res);
+    idx->list_offsets = r.device_array<uint32_t>(res);
+    idx->codes        = r.device_array<uint8_t>(res);
+    idx->indices      = r.device_array<int64_t>(res);
+    idx->h_list_sizes   = to_host(res, idx->list_sizes.data(), idx->n_lists);
+    idx->h_list_offsets = to_host(res, idx->list_offsets.data(), idx->n_lists + 1);
+    delete reinterpret_cast<ivf_pq_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = DLDataType{code, bits, 1};
+  });
 }
 cuvsError_t cuvsIvfPqTransform(cuvsResources_t, cuvsIvfPqIndex_t, DLManagedTensor*, DLManagedTensor*,
                                DLManagedTensor*)

@@ -61,3 +61,16 @@ def search(index, queries, k, neighbors=None, distances=None, resources=None, pr
     check(fn(resources.get_c_obj(), index._p, tq.ptr, tn.ptr, td.ptr, flt))
     del keep
     return distances, neighbors
+
+
+@auto_sync_resources
+def save(filename, index, resources=None):
+    check(lib().cuvsBruteForceSerialize(resources.get_c_obj(), C.c_char_p(filename.encode()), index._p))
+
+
+@auto_sync_resources
+def load(filename, resources=None):
+    idx = Index()
+    check(lib().cuvsBruteForceDeserialize(resources.get_c_obj(), C.c_char_p(filename.encode()), idx._p))
+    idx.trained = True
+    return idx

@@ -173,3 +173,17 @@ def search(search_params, index, queries, k, neighbors=None, distances=None, res
     check(fn(resources.get_c_obj(), search_params._p, index._p, tq.ptr, tn.ptr, td.ptr, flt))
     del keep
     return distances, neighbors
+
+
+@auto_sync_resources
+def save(filename, index, include_dataset=True, resources=None):
+    check(lib().cuvsCagraSerialize(resources.get_c_obj(), C.c_char_p(filename.encode()), index._p,
+                                   C.c_bool(include_dataset)))
+
+
+@auto_sync_resources
+def load(filename, resources=None):
+    idx = Index()
+    check(lib().cuvsCagraDeserialize(resources.get_c_obj(), C.c_char_p(filename.encode()), idx._p))
+    idx.trained = True
+    return idx

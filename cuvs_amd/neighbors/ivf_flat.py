@@ -162,3 +162,16 @@ def export_for_oracle(index, dtype, resources=None):
         ids.append(oid.cpu().numpy())
         sizes.append(sz.value)
     return dict(centers=index.centers.cpu().numpy(), list_sizes=np.array(sizes, np.uint32), rows=rows, ids=ids)
+
+
+@auto_sync_resources
+def save(filename, index, resources=None):
+    check(lib().cuvsIvfFlatSerialize(resources.get_c_obj(), C.c_char_p(filename.encode()), index._p))
+
+
+@auto_sync_resources
+def load(filename, resources=None):
+    idx = Index()
+    check(lib().cuvsIvfFlatDeserialize(resources.get_c_obj(), C.c_char_p(filename.encode()), idx._p))
+    idx.trained = True
+    return idx

@@ -230,3 +230,16 @@ def export_for_oracle(index):
         pq_dim=index.pq_dim,
         pq_len=index.pq_len,
     )
+
+
+@auto_sync_resources
+def save(filename, index, resources=None):
+    check(lib().cuvsIvfPqSerialize(resources.get_c_obj(), C.c_char_p(filename.encode()), index._p))
+
+
+@auto_sync_resources
+def load(filename, resources=None):
+    idx = Index()
+    check(lib().cuvsIvfPqDeserialize(resources.get_c_obj(), C.c_char_p(filename.encode()), idx._p))
+    idx.trained = True
+    return idx
