@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 namespace cuvs_amd {
 
@@ -61,6 +62,19 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   if (metric != M_InnerProduct) {
     qn = dev_buf<float>(res, m);
     row_norms<T>(res, queries, m, idx.dim, ldq, qn.data(), metric == M_CosineExpanded);
+  }
+  // fused distance + top-k (the reference's fusedL2Knn path, knn_brute_force.cuh:452): k <= 64, no pre-filter.
+  // Same results as the tiled path; in round 1 it is still slower than GEMM + select_k (244 VGPRs, cold-tile
+  // cost), so it is opt-in: CUVS_AMD_BF_FUSED=1.
+  if (k <= 64 && filter_type == NO_FILTER && getenv("CUVS_AMD_BF_FUSED") != nullptr) {
+    bool done = true;
+    for (int64_t r0 = 0; r0 < m && done; r0 += int64_t(65535) * 128) {
+      const int64_t mr = std::min<int64_t>(int64_t(65535) * 128, m - r0);
+      done = fused_knn<T, T>(res, queries + r0 * ldq, mr, ldq, data, n, idx.ld, idx.dim,
+                             qn.data() ? qn.data() + r0 : nullptr, idx.norms.data(), metric, k, distances + r0 * k,
+                             neighbors + r0 * k);
+    }
+    if (done) return;
   }
   dev_buf<float> tile(res, (size_t)m_tile * std::min<int64_t>(n_tile, n));
   const int64_t ldo = std::min<int64_t>(n_tile, n);

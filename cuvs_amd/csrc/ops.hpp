@@ -42,6 +42,13 @@ void fused_l2_argmin(resources& res, const TQ* q, int64_t m, int64_t ldq, const 
                      int64_t n, int64_t dim, const float* center_norms, uint32_t* labels,
                      float* min_val);
 
+// ---------------------------------------------------------------- fused_knn.hip
+// Fused distance + top-k (k <= 64): same results as pairwise_distance + select_k, the tile never leaves the CU.
+// Returns false when the shape is outside the fused path.
+template <typename TQ, typename TX>
+bool fused_knn(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n, int64_t ldx,
+               int64_t dim, const float* qn, const float* xn, int metric, int k, float* out_d, int64_t* out_i);
+
 // ---------------------------------------------------------------- kmeans_balanced.hip
 struct kmeans_params {
   int n_iters        = 20;

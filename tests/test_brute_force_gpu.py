@@ -131,3 +131,13 @@ def test_error_convention():
         brute_force.search(idx, torch.from_numpy(qq[:, :4].copy()).cuda(), 3)  # dim mismatch
     with pytest.raises(CuvsError):
         brute_force.build(torch.from_numpy(x).cuda(), metric="l1")  # metric outside the hot path
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product", "cosine"])
+def test_fused_and_tiled_paths_agree(metric, monkeypatch):
+    # CUVS_AMD_BF_FUSED=1 switches k <= 64 searches to the fused distance+top-k kernel (opt-in in round 1)
+    x, qq = _gen(30000, 48, 333, seed=77)
+    td, ti = _run(x, qq, 33, metric)
+    monkeypatch.setenv("CUVS_AMD_BF_FUSED", "1")
+    fd, fi = _run(x, qq, 33, metric)
+    assert (fi == ti).all() and (fd == td).all()
