@@ -162,19 +162,27 @@ def main():
         dmat = cn[None, :] - 2.0 * (qq @ centers.T)
         pr = torch.topk(dmat, min(args.n_probes, args.n_lists), dim=1, largest=False).indices
         probe_bytes += int(sizes[pr].sum().item()) * (args.pq_dim * 8 // 8)
+    # one search = a small head launch (nearest probe of every query) + the tail launch; both are the same kernel,
+    # so bytes and time are averaged over all its launches (sum of bytes / sum of time)
+    per_step = max(n_launch, 1) / max(args.steps, 1)
+    bytes_per_launch = probe_bytes / per_step
     avg_ms = scan_ms.value / max(n_launch, 1)
-    achieved = probe_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "r01_pq_scan_traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            # PMC pass (profiles/README.md): HBM bytes of the kernel's launches of one search, averaged per launch
+            traffic = tj.get("hbm_bytes_per_step", tj.get("hbm_bytes_per_launch"))
+            traffic = int(traffic / per_step) if traffic else None
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "pq_scan_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": probe_bytes, "avg_launch_ms": round(avg_ms, 3),
-                "launches": n_launch,
+                "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 3),
+                "launches": n_launch, "launches_per_step": per_step,
+                "algorithmic_bytes_per_step": probe_bytes, "kernel_ms_per_step": round(avg_ms * per_step, 3),
                 "note": "logical code bytes scanned per launch / HIP-event kernel time; the list-major schedule "
                         "re-serves list bytes from L2/Infinity Cache and is LDS-gather bound, so this may exceed "
                         "HBM peak (DESIGN.md)"}

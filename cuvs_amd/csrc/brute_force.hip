@@ -5,6 +5,7 @@
 #include "ops.hpp"
 #include "device_utils.hpp"
 #include "serialize.hpp"
+#include "npy_io.hpp"
 
 #include <cuvs/neighbors/brute_force.h>
 
@@ -114,6 +115,8 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   }
   HIP_TRY(hipGetLastError());
 }
+
+constexpr int kBfRefVersion = 0;  // brute_force_serialize.cu:19
 
 template <typename T>
 void bf_build_typed(resources& res, bf_index& idx)
@@ -255,13 +258,35 @@ cuvsError_t cuvsBruteForceSerialize(cuvsResources_t res_h, const char* filename,
     auto& res = *as_res(res_h);
     CUVS_EXPECTS(index_c_ptr && index_c_ptr->addr, "index is not built");
     auto& idx = *reinterpret_cast<bf_index*>(index_c_ptr->addr);
-    file_writer w(filename, KIND_BRUTE_FORCE);
-    w.scalar<int32_t>(idx.metric); w.scalar<float>(idx.metric_arg); w.scalar<int32_t>((int)idx.dtype);
-    w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);
-    w.scalar<uint8_t>(index_c_ptr->dtype.code); w.scalar<uint8_t>(index_c_ptr->dtype.bits);
-    CUVS_EXPECTS(idx.ld == idx.dim, "strided dataset cannot be serialized");
-    w.device_array(res, idx.data, (size_t)idx.n * idx.dim * elem_size(idx.dtype));
-    w.device_array(res, idx.norms.data(), idx.norms.bytes());
+    if (write_native_container()) {
+      file_writer w(filename, KIND_BRUTE_FORCE);
+      w.scalar<int32_t>(idx.metric); w.scalar<float>(idx.metric_arg); w.scalar<int32_t>((int)idx.dtype);
+      w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);
+      w.scalar<uint8_t>(index_c_ptr->dtype.code); w.scalar<uint8_t>(index_c_ptr->dtype.bits);
+      CUVS_EXPECTS(idx.ld == idx.dim, "strided dataset cannot be serialized");
+      w.device_array(res, idx.data, (size_t)idx.n * idx.dim * elem_size(idx.dtype));
+      w.device_array(res, idx.norms.data(), idx.norms.bytes());
+      return;
+    }
+    // the reference's record sequence (brute_force_serialize.cu:30-45): dtype prefix, version, rows, dim,
+    // metric, metric_arg, include_dataset, dataset [rows, dim], has_norms, norms [rows]
+    npy_writer w(filename);
+    char prefix[4];
+    elem_prefix(idx.dtype, prefix);
+    w.raw(prefix, 4);
+    w.scalar<int32_t>(kBfRefVersion);
+    w.scalar<uint64_t>((uint64_t)idx.n);
+    w.scalar<uint64_t>((uint64_t)idx.dim);
+    w.scalar<int32_t>(idx.metric);
+    w.scalar<float>(idx.metric_arg);
+    w.scalar<bool>(true);
+    const size_t es = elem_size(idx.dtype);
+    w.device_array(res, idx.dtype == elem_t::f32 ? 'f' : 'e', (uint32_t)es, {idx.n, idx.dim}, idx.data,
+                   (size_t)idx.dim * es, (size_t)idx.ld * es);
+    const bool has_norms = idx.norms.size() > 0;
+    w.scalar<bool>(has_norms);
+    if (has_norms) w.device_array(res, 'f', 4, {idx.n}, idx.norms.data());
+    w.close();
   });
 }
 
@@ -270,21 +295,52 @@ cuvsError_t cuvsBruteForceDeserialize(cuvsResources_t res_h, const char* filenam
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     CUVS_EXPECTS(index != nullptr, "index is null");
-    file_reader r(filename, KIND_BRUTE_FORCE);
-    auto idx        = std::make_unique<bf_index>();
-    idx->metric     = r.scalar<int32_t>();
-    idx->metric_arg = r.scalar<float>();
-    idx->dtype      = (elem_t)r.scalar<int32_t>();
-    idx->n          = r.scalar<int64_t>();
-    idx->dim        = r.scalar<int64_t>();
-    idx->ld         = idx->dim;
-    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
-    idx->owned = r.device_array<char>(res);
-    idx->norms = r.device_array<float>(res);
-    idx->data  = idx->owned.data();
+    auto idx = std::make_unique<bf_index>();
+    DLDataType dl;
+    if (is_native_container(filename)) {
+      file_reader r(filename, KIND_BRUTE_FORCE);
+      idx->metric     = r.scalar<int32_t>();
+      idx->metric_arg = r.scalar<float>();
+      idx->dtype      = (elem_t)r.scalar<int32_t>();
+      idx->n          = r.scalar<int64_t>();
+      idx->dim        = r.scalar<int64_t>();
+      idx->ld         = idx->dim;
+      uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
+      idx->owned = r.device_array<char>(res);
+      idx->norms = r.device_array<float>(res);
+      idx->data  = idx->owned.data();
+      dl         = DLDataType{code, bits, 1};
+    } else {
+      // reference format (brute_force_serialize.cu:82-140; dtype dispatch c/src/neighbors/brute_force.cpp:239-262)
+      npy_reader r(filename);
+      char prefix[4];
+      r.raw(prefix, 4);
+      CUVS_EXPECTS(parse_elem_prefix(prefix, &idx->dtype) && (idx->dtype == elem_t::f32 || idx->dtype == elem_t::f16),
+                   "Unsupported index dtype in file %s", filename);
+      int ver = r.scalar<int32_t>();
+      CUVS_EXPECTS(ver == kBfRefVersion, "serialization version mismatch, expected %d, got %d ", kBfRefVersion, ver);
+      idx->n   = (int64_t)r.scalar<uint64_t>();
+      idx->dim = (int64_t)r.scalar<uint64_t>();
+      idx->ld  = idx->dim;
+      CUVS_EXPECTS(idx->n >= 0 && idx->dim > 0, "brute_force::deserialize: bad shape");
+      idx->metric     = r.scalar<int32_t>();
+      idx->metric_arg = r.scalar<float>();
+      CUVS_EXPECTS(metric_supported(idx->metric), "brute_force::deserialize: invalid metric value %d", idx->metric);
+      bool include_dataset = r.scalar<bool>();
+      CUVS_EXPECTS(include_dataset, "%s holds no dataset: a brute-force index cannot be searched without one", filename);
+      idx->owned = r.device_bytes(res, (uint32_t)elem_size(idx->dtype), idx->n * idx->dim);
+      idx->data = idx->owned.data();
+      // norms are recomputed canonically (distance.hip row_norms) instead of trusting the file's rounding, so a
+      // loaded index answers bit-identically to one built here from the same rows
+      bool has_norms = r.scalar<bool>();
+      (void)has_norms;
+      if (idx->dtype == elem_t::f32) bf_build_typed<float>(res, *idx); else bf_build_typed<__half>(res, *idx);
+      sync(res);
+      dl = dl_of(idx->dtype);
+    }
     delete reinterpret_cast<bf_index*>(index->addr);
     index->addr  = reinterpret_cast<uintptr_t>(idx.release());
-    index->dtype = DLDataType{code, bits, 1};
+    index->dtype = dl;
   });
 }
 

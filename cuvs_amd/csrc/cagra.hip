@@ -17,6 +17,7 @@
 #include "ops.hpp"
 #include "device_utils.hpp"
 #include "serialize.hpp"
+#include "npy_io.hpp"
 
 #include <cuvs/neighbors/cagra.h>
 
@@ -769,17 +770,52 @@ cuvsError_t cuvsCagraSearch(cuvsResources_t res_h, cuvsCagraSearchParams_t param
   });
 }
 
+namespace {
+constexpr int kCagraRefVersion = 5;  // cagra_serialize.cuh:30
+// cudaDataType_t codes the reference stores in front of a strided dataset (dataset_serialize.hpp:82-101)
+inline uint32_t cuda_dtype_code(elem_t e) { return e == elem_t::f32 ? 0u : e == elem_t::f16 ? 2u : e == elem_t::i8 ? 3u : 8u; }
+inline char npy_kind(elem_t e) { return e == elem_t::f32 ? 'f' : e == elem_t::f16 ? 'e' : e == elem_t::i8 ? 'i' : 'u'; }
+}  // namespace
+
 cuvsError_t cuvsCagraSerialize(cuvsResources_t res_h, const char* filename, cuvsCagraIndex_t index, bool include_dataset)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     auto& idx = get_cagra(index);
-    file_writer w(filename, KIND_CAGRA);
-    w.scalar<int32_t>(idx.metric); w.scalar<int32_t>((int)idx.dtype); w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);
-    w.scalar<uint32_t>(idx.degree); w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);
-    w.scalar<uint8_t>(include_dataset ? 1 : 0);
-    w.device_array(res, idx.graph.data(), idx.graph.bytes());
-    if (include_dataset) w.device_array(res, idx.data, (size_t)idx.n * idx.dim * elem_size(idx.dtype));
+    if (write_native_container()) {
+      file_writer w(filename, KIND_CAGRA);
+      w.scalar<int32_t>(idx.metric); w.scalar<int32_t>((int)idx.dtype); w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);
+      w.scalar<uint32_t>(idx.degree); w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);
+      w.scalar<uint8_t>(include_dataset ? 1 : 0);
+      w.device_array(res, idx.graph.data(), idx.graph.bytes());
+      if (include_dataset) w.device_array(res, idx.data, (size_t)idx.n * idx.dim * elem_size(idx.dtype));
+      return;
+    }
+    // reference record sequence (cagra_serialize.cuh:49-75, dataset_serialize.hpp:38-60,82-87): dtype prefix,
+    // version, size (IdxT = uint32), dim, graph_degree, metric, graph [n, degree], content_map (bit 0 = dataset,
+    // bit 1 = source_indices), then the dataset: tag 2 (strided), cudaDataType, n_rows (int64), dim, stride, rows
+    npy_writer w(filename);
+    char prefix[4];
+    elem_prefix(idx.dtype, prefix);
+    w.raw(prefix, 4);
+    w.scalar<int32_t>(kCagraRefVersion);
+    w.scalar<uint32_t>((uint32_t)idx.n);
+    w.scalar<uint32_t>((uint32_t)idx.dim);
+    w.scalar<uint32_t>(idx.degree);
+    w.scalar<int32_t>(idx.metric);
+    w.device_array(res, 'u', 4, {idx.n, idx.degree}, idx.graph.data());
+    const bool with_data = include_dataset && idx.data != nullptr && idx.n > 0;
+    w.scalar<uint32_t>(with_data ? 1u : 0u);
+    if (with_data) {
+      const size_t es = elem_size(idx.dtype);
+      w.scalar<uint32_t>(2u);
+      w.scalar<uint32_t>(cuda_dtype_code(idx.dtype));
+      w.scalar<int64_t>(idx.n);
+      w.scalar<uint32_t>((uint32_t)idx.dim);
+      w.scalar<uint32_t>((uint32_t)(round_up(idx.dim * (int64_t)es, 16) / es));  // 16-byte aligned row stride
+      w.device_array(res, npy_kind(idx.dtype), (uint32_t)es, {idx.n, idx.dim}, idx.data);
+    }
+    w.close();
   });
 }
 
@@ -788,19 +824,113 @@ cuvsError_t cuvsCagraDeserialize(cuvsResources_t res_h, const char* filename, cu
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     CUVS_EXPECTS(index != nullptr, "index is null");
-    file_reader r(filename, KIND_CAGRA);
-    auto idx    = std::make_unique<cagra_index>();
-    idx->metric = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>(); idx->n = r.scalar<int64_t>();
-    idx->dim = r.scalar<int64_t>(); idx->degree = r.scalar<uint32_t>();
-    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>(), has_data = r.scalar<uint8_t>();
-    idx->graph = r.device_array<uint32_t>(res);
-    if (has_data) {
-      idx->owned = r.device_array<char>(res);
-      idx->data  = idx->owned.data();
+    auto idx = std::make_unique<cagra_index>();
+    DLDataType dl;
+    if (is_native_container(filename)) {
+      file_reader r(filename, KIND_CAGRA);
+      idx->metric = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>(); idx->n = r.scalar<int64_t>();
+      idx->dim = r.scalar<int64_t>(); idx->degree = r.scalar<uint32_t>();
+      uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>(), has_data = r.scalar<uint8_t>();
+      idx->graph = r.device_array<uint32_t>(res);
+      if (has_data) {
+        idx->owned = r.device_array<char>(res);
+        idx->data  = idx->owned.data();
+      }
+      dl = DLDataType{code, bits, 1};
+    } else {
+      // reference format (cagra_serialize.cuh:270-330; dtype dispatch c/src/neighbors/cagra.cpp:876-900)
+      npy_reader r(filename);
+      char prefix[4];
+      r.raw(prefix, 4);
+      CUVS_EXPECTS(parse_elem_prefix(prefix, &idx->dtype), "Unsupported index dtype in file %s", filename);
+      int ver = r.scalar<int32_t>();
+      CUVS_EXPECTS(ver == kCagraRefVersion, "serialization version mismatch, expected %d, got %d ", kCagraRefVersion, ver);
+      idx->n      = (int64_t)r.scalar<uint32_t>();
+      idx->dim    = (int64_t)r.scalar<uint32_t>();
+      idx->degree = r.scalar<uint32_t>();
+      idx->metric = r.scalar<int32_t>();
+      CUVS_EXPECTS(metric_is_l2(idx->metric) || idx->metric == M_InnerProduct,
+                   "cagra::deserialize: unsupported metric value %d", idx->metric);
+      CUVS_EXPECTS(idx->degree > 0 && idx->degree <= 1024, "cagra::deserialize: graph_degree=%u exceeds maximum %u",
+                   idx->degree, 1024u);
+      idx->graph = r.device_array<uint32_t>(res, idx->n * (int64_t)idx->degree);
+      uint32_t content = r.scalar<uint32_t>();
+      if (content & 1u) {
+        uint32_t tag = r.scalar<uint32_t>();
+        if (tag == 1u) {
+          (void)r.scalar<uint32_t>();  // empty dataset: suggested dim only
+        } else {
+          CUVS_EXPECTS(tag == 2u, "Failed to deserialize dataset: instance tag %u (VPQ-compressed datasets are not built)", tag);
+          uint32_t code = r.scalar<uint32_t>();
+          CUVS_EXPECTS(code == cuda_dtype_code(idx->dtype), "cagra::deserialize: dataset element type %u does not match the index dtype", code);
+          int64_t rows = r.scalar<int64_t>();
+          uint32_t dim = r.scalar<uint32_t>();
+          (void)r.scalar<uint32_t>();  // stride: rows are stored unpadded
+          CUVS_EXPECTS(rows == idx->n && dim == idx->dim, "cagra::deserialize: dataset shape does not match the graph");
+          idx->owned = r.device_bytes(res, (uint32_t)elem_size(idx->dtype), rows * (int64_t)dim);
+          idx->data  = idx->owned.data();
+        }
+      }
+      CUVS_EXPECTS((content & 2u) == 0, "cagra::deserialize: source_indices are not supported");
+      dl = dl_of(idx->dtype);
     }
     delete reinterpret_cast<cagra_index*>(index->addr);
     index->addr  = reinterpret_cast<uintptr_t>(idx.release());
-    index->dtype = DLDataType{code, bits, 1};
+    index->dtype = dl;
+  });
+}
+
+// hnswlib "base layer only" export (cagra_serialize.cuh:98-258): 96-byte header, then per node
+// {int degree, uint32 links[degree], T row[dim], size_t label}, then one zero int per node (no upper levels).
+cuvsError_t cuvsCagraSerializeToHnswlib(cuvsResources_t res_h, const char* filename, cuvsCagraIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_cagra(index);
+    CUVS_EXPECTS(idx.data != nullptr && idx.n > 0, "Invalid CAGRA dataset of size 0 during serialization");
+    CUVS_EXPECTS(filename != nullptr, "filename is null");
+    FILE* f = fopen(filename, "wb");
+    CUVS_EXPECTS(f != nullptr, "Cannot open file %s", filename);
+    struct closer { FILE* f; ~closer() { if (f) fclose(f); } } guard{f};
+    auto put = [&](const void* p, size_t n) { CUVS_EXPECTS(fwrite(p, 1, n, f) == n, "Error writing HNSW file"); };
+    const size_t es = elem_size(idx.dtype), n = (size_t)idx.n, dim = (size_t)idx.dim, deg = idx.degree;
+    const size_t per_elem = deg * 4 + 4 + dim * es + 8;
+    const size_t hdr[6]   = {0, n, n, per_elem, per_elem - 8, deg * 4 + 4};
+    put(hdr, sizeof(hdr));            // offset_level_0, max_element, curr_element_count, size_data_per_element,
+                                      // label_offset, offset_data
+    const int max_level = 1, entry = (int)(n / 2);
+    put(&max_level, 4);
+    put(&entry, 4);
+    const size_t m[3] = {deg / 2, deg, deg / 2};  // max_M, max_M0, M
+    put(m, sizeof(m));
+    const double mult = 0.42424242;
+    put(&mult, 8);
+    const size_t ef_construction = 500;
+    put(&ef_construction, 8);
+    const size_t step = std::max<size_t>(1, (size_t(64) << 20) / (dim * es + deg * 4));
+    std::vector<uint32_t> g(step * deg);
+    std::vector<char> rows(step * dim * es), out(step * per_elem);
+    for (size_t r0 = 0; r0 < n; r0 += step) {
+      const size_t nr = std::min(step, n - r0);
+      copy_async(res, g.data(), idx.graph.data() + r0 * deg, nr * deg * 4);
+      copy_async(res, rows.data(), static_cast<const char*>(idx.data) + r0 * dim * es, nr * dim * es);
+      sync(res);
+      char* o = out.data();
+      for (size_t i = 0; i < nr; ++i) {
+        const int d32 = (int)deg;
+        const size_t label = r0 + i;
+        memcpy(o, &d32, 4); o += 4;
+        memcpy(o, g.data() + i * deg, deg * 4); o += deg * 4;
+        memcpy(o, rows.data() + i * dim * es, dim * es); o += dim * es;
+        memcpy(o, &label, 8); o += 8;
+      }
+      put(out.data(), nr * per_elem);
+    }
+    std::vector<int> zeros(std::min<size_t>(n, 1 << 20), 0);
+    for (size_t r0 = 0; r0 < n; r0 += zeros.size()) put(zeros.data(), std::min(zeros.size(), n - r0) * 4);
+    int rc  = fclose(f);
+    guard.f = nullptr;
+    CUVS_EXPECTS(rc == 0, "Error writing output %s", filename);
   });
 }
 
@@ -808,8 +938,6 @@ cuvsError_t cuvsCagraDeserialize(cuvsResources_t res_h, const char* filename, cu
   cuvsError_t NAME SIG { return (cuvsError_t)translate_exceptions([=] { CUVS_FAIL(#NAME ": " WHY); }); }
 CAGRA_UNBUILT(cuvsCagraExtend, (cuvsResources_t, cuvsCagraExtendParams_t, DLManagedTensor*, cuvsCagraIndex_t),
               "add_nodes is outside the north-star search path (SURVEY 2.1 #5)")
-CAGRA_UNBUILT(cuvsCagraSerializeToHnswlib, (cuvsResources_t, const char*, cuvsCagraIndex_t),
-              "hnswlib export is outside the hot path (SURVEY 2.1 #5)")
 CAGRA_UNBUILT(cuvsCagraMerge, (cuvsResources_t, cuvsCagraIndexParams_t, cuvsCagraIndex_t*, size_t, cuvsFilter,
                                cuvsCagraIndex_t),
               "index merge is outside the north-star search path (SURVEY 2.1 #5)")

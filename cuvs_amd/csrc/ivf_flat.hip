@@ -13,6 +13,7 @@
 // register top lists + shared k-th bounds as in the PQ scan. In-list order is ascending source id.
 #include "ivf_common.hpp"
 #include "serialize.hpp"
+#include "npy_io.hpp"
 
 #include <cuvs/neighbors/ivf_flat.h>
 
@@ -689,22 +690,193 @@ cuvsError_t cuvsIvfFlatExtend(cuvsResources_t res_h, DLManagedTensor* new_vector
   });
 }
 
+}  // extern "C"
+
+namespace {
+constexpr int kFlatRefVersion = 4;  // ivf_flat_serialize.cuh:30
+
+// the reference's interleave inside one list record [rows32, dim] (ivf_flat.hpp:184-200): groups of 32 rows,
+// chunks of `vr` consecutive components; element offset of (row r, component d):
+inline size_t ref_flat_offset(uint32_t r, uint32_t d, uint32_t dim, uint32_t vr)
+{
+  return (size_t)(r / 32) * 32 * dim + (size_t)(d / vr) * 32 * vr + (size_t)(r % 32) * vr + d % vr;
+}
+// ivf_flat.hpp:284-294
+inline uint32_t ref_flat_veclen(uint32_t dim, size_t es)
+{
+  uint32_t v = std::max<uint32_t>(1, (uint32_t)(16 / es));
+  return dim % v != 0 ? 1 : v;
+}
+
+void flat_write_native(resources& res, const char* filename, const ivf_flat_index& idx, DLDataType dl)
+{
+  file_writer w(filename, KIND_IVF_FLAT);
+  w.scalar<int32_t>(idx.metric); w.scalar<int32_t>((int)idx.dtype); w.scalar<uint32_t>(idx.n_lists);
+  w.scalar<uint32_t>(idx.dim); w.scalar<uint32_t>(idx.veclen); w.scalar<uint32_t>(idx.n_chunks);
+  w.scalar<int64_t>(idx.size); w.scalar<int64_t>(idx.padded_rows);
+  w.scalar<uint8_t>(dl.code); w.scalar<uint8_t>(dl.bits);
+  w.device_array(res, idx.centers.data(), idx.centers.bytes());
+  w.device_array(res, idx.center_norms.data(), idx.center_norms.bytes());
+  w.device_array(res, idx.list_sizes.data(), idx.list_sizes.bytes());
+  w.device_array(res, idx.list_offsets.data(), idx.list_offsets.bytes());
+  w.device_array(res, idx.data.data(), idx.data.bytes());
+  w.device_array(res, idx.indices.data(), idx.indices.bytes());
+}
+
+std::unique_ptr<ivf_flat_index> flat_read_native(resources& res, const char* filename, DLDataType* dl)
+{
+  file_reader r(filename, KIND_IVF_FLAT);
+  auto idx = std::make_unique<ivf_flat_index>();
+  idx->metric = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>(); idx->n_lists = r.scalar<uint32_t>();
+  idx->dim = r.scalar<uint32_t>(); idx->veclen = r.scalar<uint32_t>(); idx->n_chunks = r.scalar<uint32_t>();
+  idx->size = r.scalar<int64_t>(); idx->padded_rows = r.scalar<int64_t>();
+  uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
+  idx->centers      = r.device_array<float>(res);
+  idx->center_norms = r.device_array<float>(res);
+  idx->list_sizes   = r.device_array<uint32_t>(res);
+  idx->list_offsets = r.device_array<uint32_t>(res);
+  idx->data         = r.device_array<uint8_t>(res);
+  idx->indices      = r.device_array<int64_t>(res);
+  idx->h_list_sizes   = to_host(res, idx->list_sizes.data(), idx->n_lists);
+  idx->h_list_offsets = to_host(res, idx->list_offsets.data(), idx->n_lists + 1);
+  *dl = DLDataType{code, bits, 1};
+  return idx;
+}
+
+// Reference record sequence (ivf_flat_serialize.cuh:42-77, ivf_list.cuh:108-131): dtype prefix, version, size,
+// dim, n_lists, metric, adaptive_centers, conservative_memory_allocation, centers, has_norms [, center_norms],
+// list_sizes, then per list: rows32 = roundUp(size, 32) [, data [rows32, dim] in the reference's 32-row
+// interleave, ids [rows32]]. Our lists are stored in 64-row groups, so each list is re-interleaved on the host.
+void flat_write_ref(resources& res, const char* filename, const ivf_flat_index& idx)
+{
+  npy_writer w(filename);
+  char prefix[4];
+  elem_prefix(idx.dtype, prefix);
+  w.raw(prefix, 4);
+  w.scalar<int32_t>(kFlatRefVersion);
+  w.scalar<int64_t>(idx.size);
+  w.scalar<uint32_t>(idx.dim);
+  w.scalar<uint32_t>(idx.n_lists);
+  w.scalar<int32_t>(idx.metric);
+  w.scalar<bool>(false);  // adaptive_centers
+  w.scalar<bool>(true);   // conservative_memory_allocation: lists hold no slack beyond their group padding
+  w.device_array(res, 'f', 4, {idx.n_lists, idx.dim}, idx.centers.data());
+  const bool has_norms = idx.metric != M_InnerProduct;  // ivf_flat_index.cpp:179-191
+  w.scalar<bool>(has_norms);
+  if (has_norms) w.device_array(res, 'f', 4, {idx.n_lists}, idx.center_norms.data());
+  w.host_array<uint32_t>(idx.h_list_sizes.data(), {idx.n_lists});
+  const size_t es   = elem_size(idx.dtype);
+  const uint32_t vr = ref_flat_veclen(idx.dim, es);
+  const char kind   = idx.dtype == elem_t::f32 ? 'f' : idx.dtype == elem_t::f16 ? 'e' : idx.dtype == elem_t::i8 ? 'i' : 'u';
+  std::vector<uint8_t> ours, theirs;
+  std::vector<int64_t> ids;
+  for (uint32_t L = 0; L < idx.n_lists; ++L) {
+    const uint32_t size = idx.h_list_sizes[L], rows32 = (uint32_t)round_up(size, 32);
+    w.scalar<uint32_t>(rows32);
+    if (rows32 == 0) continue;
+    const uint32_t cap = idx.h_list_offsets[L + 1] - idx.h_list_offsets[L];
+    ours.resize((size_t)cap * idx.n_chunks * 16);
+    ids.assign(rows32, -1);
+    copy_async(res, ours.data(), idx.data.data() + (size_t)idx.h_list_offsets[L] * idx.n_chunks * 16, ours.size());
+    copy_async(res, ids.data(), idx.indices.data() + idx.h_list_offsets[L], (size_t)size * sizeof(int64_t));
+    sync(res);
+    theirs.assign((size_t)rows32 * idx.dim * es, 0);
+    for (uint32_t r = 0; r < size; ++r) {
+      const uint8_t* row = ours.data() + ((size_t)(r / 64) * idx.n_chunks * 64 + r % 64) * 16;
+      for (uint32_t d = 0; d < idx.dim; ++d)
+        memcpy(theirs.data() + ref_flat_offset(r, d, idx.dim, vr) * es,
+               row + (size_t)(d / idx.veclen) * 64 * 16 + (d % idx.veclen) * es, es);
+    }
+    w.header(kind, (uint32_t)es, {rows32, idx.dim});
+    w.raw(theirs.data(), theirs.size());
+    w.host_array<int64_t>(ids.data(), {rows32});
+  }
+  w.close();
+}
+
+std::unique_ptr<ivf_flat_index> flat_read_ref(resources& res, const char* filename, DLDataType* dl)
+{
+  npy_reader r(filename);
+  auto idx = std::make_unique<ivf_flat_index>();
+  char prefix[4];
+  r.raw(prefix, 4);
+  CUVS_EXPECTS(parse_elem_prefix(prefix, &idx->dtype), "Unsupported dtype in file %s", filename);
+  int ver = r.scalar<int32_t>();
+  CUVS_EXPECTS(ver == kFlatRefVersion, "serialization version mismatch, expected %d, got %d ", kFlatRefVersion, ver);
+  idx->size    = r.scalar<int64_t>();
+  idx->dim     = r.scalar<uint32_t>();
+  idx->n_lists = r.scalar<uint32_t>();
+  idx->metric  = r.scalar<int32_t>();
+  (void)r.scalar<bool>();  // adaptive_centers
+  (void)r.scalar<bool>();  // conservative_memory_allocation
+  CUVS_EXPECTS(metric_is_l2(idx->metric) || idx->metric == M_InnerProduct,
+               "ivf_flat::deserialize: unsupported metric value %d", idx->metric);
+  CUVS_EXPECTS(idx->dim > 0 && idx->n_lists > 0 && idx->n_lists <= (1u << 24), "ivf_flat::deserialize: bad header");
+  const size_t es = elem_size(idx->dtype);
+  idx->veclen     = (uint32_t)(16 / es);
+  idx->n_chunks   = (uint32_t)ceil_div((int64_t)idx->dim, (int64_t)idx->veclen);
+  idx->centers    = r.device_array<float>(res, (int64_t)idx->n_lists * idx->dim);
+  if (r.scalar<bool>()) (void)r.host_array<float>(idx->n_lists);
+  // canonical |c|^2 (the build's own rounding) rather than the file's
+  idx->center_norms = dev_buf<float>::persistent(idx->n_lists);
+  row_norms<float>(res, idx->centers.data(), idx->n_lists, idx->dim, idx->dim, idx->center_norms.data(), false);
+  idx->h_list_sizes = r.host_array<uint32_t>(idx->n_lists);
+  idx->h_list_offsets.assign(idx->n_lists + 1, 0);
+  int64_t total = 0, live = 0;
+  for (uint32_t L = 0; L < idx->n_lists; ++L) {
+    idx->h_list_offsets[L] = (uint32_t)total;
+    total += round_up(idx->h_list_sizes[L], 64);
+    live += idx->h_list_sizes[L];
+  }
+  CUVS_EXPECTS(total < (int64_t(1) << 32), "ivf_flat::deserialize: index too large");
+  CUVS_EXPECTS(live == idx->size, "ivf_flat::deserialize: list sizes (%ld) do not add up to the index size (%ld)",
+               (long)live, (long)idx->size);
+  idx->h_list_offsets[idx->n_lists] = (uint32_t)total;
+  idx->padded_rows                  = total;
+  idx->list_sizes   = dev_buf<uint32_t>::persistent(idx->n_lists);
+  idx->list_offsets = dev_buf<uint32_t>::persistent(idx->n_lists + 1);
+  copy_async(res, idx->list_sizes.data(), idx->h_list_sizes.data(), idx->n_lists * sizeof(uint32_t));
+  copy_async(res, idx->list_offsets.data(), idx->h_list_offsets.data(), (idx->n_lists + 1) * sizeof(uint32_t));
+  idx->data    = dev_buf<uint8_t>::persistent((size_t)total * idx->n_chunks * 16);
+  idx->indices = dev_buf<int64_t>::persistent((size_t)total);
+  HIP_TRY(hipMemsetAsync(idx->data.data(), 0, idx->data.bytes(), res.stream));
+  HIP_TRY(hipMemsetAsync(idx->indices.data(), 0xff, idx->indices.bytes(), res.stream));
+  sync(res);
+  const uint32_t vr = ref_flat_veclen(idx->dim, es);
+  std::vector<uint8_t> ours;
+  std::vector<char> theirs;
+  for (uint32_t L = 0; L < idx->n_lists; ++L) {
+    const uint32_t rows = r.scalar<uint32_t>(), size = idx->h_list_sizes[L];
+    CUVS_EXPECTS(rows >= size, "ivf_flat::deserialize: list %u holds %u rows, list_sizes says %u", L, rows, size);
+    if (rows == 0) continue;
+    r.array((uint32_t)es, (int64_t)rows * idx->dim, theirs);
+    std::vector<int64_t> ids = r.host_array<int64_t>(rows);
+    if (size == 0) continue;
+    const uint32_t cap = (uint32_t)round_up(size, 64);
+    ours.assign((size_t)cap * idx->n_chunks * 16, 0);
+    for (uint32_t rr = 0; rr < size; ++rr) {
+      uint8_t* row = ours.data() + ((size_t)(rr / 64) * idx->n_chunks * 64 + rr % 64) * 16;
+      for (uint32_t d = 0; d < idx->dim; ++d)
+        memcpy(row + (size_t)(d / idx->veclen) * 64 * 16 + (d % idx->veclen) * es,
+               theirs.data() + ref_flat_offset(rr, d, idx->dim, vr) * es, es);
+    }
+    copy_async(res, idx->data.data() + (size_t)idx->h_list_offsets[L] * idx->n_chunks * 16, ours.data(), ours.size());
+    copy_async(res, idx->indices.data() + idx->h_list_offsets[L], ids.data(), (size_t)size * sizeof(int64_t));
+    sync(res);
+  }
+  *dl = dl_of(idx->dtype);
+  return idx;
+}
+}  // namespace
+
+extern "C" {
 cuvsError_t cuvsIvfFlatSerialize(cuvsResources_t res_h, const char* filename, cuvsIvfFlatIndex_t index)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     auto& idx = get_flat(index);
-    file_writer w(filename, KIND_IVF_FLAT);
-    w.scalar<int32_t>(idx.metric); w.scalar<int32_t>((int)idx.dtype); w.scalar<uint32_t>(idx.n_lists);
-    w.scalar<uint32_t>(idx.dim); w.scalar<uint32_t>(idx.veclen); w.scalar<uint32_t>(idx.n_chunks);
-    w.scalar<int64_t>(idx.size); w.scalar<int64_t>(idx.padded_rows);
-    w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);
-    w.device_array(res, idx.centers.data(), idx.centers.bytes());
-    w.device_array(res, idx.center_norms.data(), idx.center_norms.bytes());
-    w.device_array(res, idx.list_sizes.data(), idx.list_sizes.bytes());
-    w.device_array(res, idx.list_offsets.data(), idx.list_offsets.bytes());
-    w.device_array(res, idx.data.data(), idx.data.bytes());
-    w.device_array(res, idx.indices.data(), idx.indices.bytes());
+    if (write_native_container()) flat_write_native(res, filename, idx, index->dtype);
+    else flat_write_ref(res, filename, idx);
   });
 }
 cuvsError_t cuvsIvfFlatDeserialize(cuvsResources_t res_h, const char* filename, cuvsIvfFlatIndex_t index)
@@ -712,23 +884,11 @@ cuvsError_t cuvsIvfFlatDeserialize(cuvsResources_t res_h, const char* filename, 
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     CUVS_EXPECTS(index != nullptr, "index is null");
-    file_reader r(filename, KIND_IVF_FLAT);
-    auto idx = std::make_unique<ivf_flat_index>();
-    idx->metric = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>(); idx->n_lists = r.scalar<uint32_t>();
-    idx->dim = r.scalar<uint32_t>(); idx->veclen = r.scalar<uint32_t>(); idx->n_chunks = r.scalar<uint32_t>();
-    idx->size = r.scalar<int64_t>(); idx->padded_rows = r.scalar<int64_t>();
-    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
-    idx->centers      = r.device_array<float>(res);
-    idx->center_norms = r.device_array<float>(res);
-    idx->list_sizes   = r.device_array<uint32_t>(res);
-    idx->list_offsets = r.device_array<uint32_t>(res);
-    idx->data         = r.device_array<uint8_t>(res);
-    idx->indices      = r.device_array<int64_t>(res);
-    idx->h_list_sizes   = to_host(res, idx->list_sizes.data(), idx->n_lists);
-    idx->h_list_offsets = to_host(res, idx->list_offsets.data(), idx->n_lists + 1);
+    DLDataType dl;
+    auto idx = is_native_container(filename) ? flat_read_native(res, filename, &dl) : flat_read_ref(res, filename, &dl);
     delete reinterpret_cast<ivf_flat_index*>(index->addr);
     index->addr  = reinterpret_cast<uintptr_t>(idx.release());
-    index->dtype = DLDataType{code, bits, 1};
+    index->dtype = dl;
   });
 }
 

@@ -23,6 +23,7 @@ struct ivf_pq_index {
   int metric          = 0;
   int codebook_kind   = 0;  // PER_SUBSPACE only
   elem_t dtype        = elem_t::f32;
+  bool dtype_known    = true;   // false after loading a reference-format file (the reference's index is untyped)
   uint32_t n_lists = 0, dim = 0, dim_ext = 0, rot_dim = 0;
   uint32_t pq_dim = 0, pq_bits = 8, pq_len = 0, pq_book = 256;
   uint32_t n_chunks = 0;        // 16-byte chunks per encoded vector
@@ -41,9 +42,9 @@ struct ivf_pq_index {
   dev_buf<uint32_t> list_offsets; // [n_lists + 1] (rows, multiples of 64)
   std::vector<uint32_t> h_list_sizes, h_list_offsets;
 
-  float scale() const  // kDivisor(T) / kDivisor(float), ann_utils.cuh:134-160
+  static float scale(elem_t et)  // kDivisor(T) / kDivisor(float), ann_utils.cuh:134-160
   {
-    return dtype == elem_t::u8 ? 256.0f : (dtype == elem_t::i8 ? 128.0f : 1.0f);
+    return et == elem_t::u8 ? 256.0f : (et == elem_t::i8 ? 128.0f : 1.0f);
   }
 };
 

@@ -467,6 +467,7 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
                    const int64_t* new_ids, bool ids_on_host)
 {
   if (n_new == 0) return;
+  if (!idx.dtype_known) { idx.dtype = et; idx.dtype_known = true; }
   CUVS_EXPECTS(et == idx.dtype, "extend: vector dtype differs from the index dtype");
   CUVS_EXPECTS(new_ids != nullptr || idx.size == 0, "You must pass data indices when the index is non-empty.");
   CUVS_EXPECTS(idx.size + n_new < (int64_t(1) << 32) - 64 * (int64_t)idx.n_lists, "index too large for 32-bit row offsets");

@@ -2,6 +2,7 @@
 #include "ivf_pq.hpp"
 #include "ops.hpp"
 #include "serialize.hpp"
+#include "npy_io.hpp"
 
 #include <cuvs/neighbors/ivf_pq.h>
 
@@ -156,7 +157,8 @@ cuvsError_t cuvsIvfPqSearch(cuvsResources_t res_h, cuvsIvfPqSearchParams_t param
     CUVS_EXPECTS(queries.ndim == 2 && neighbors.ndim == 2 && distances.ndim == 2, "tensors must be 2-D");
     CUVS_EXPECTS(is_c_contiguous(queries) && is_c_contiguous(neighbors) && is_c_contiguous(distances),
                  "tensors must be C-contiguous");
-    CUVS_EXPECTS(queries.dtype.code == index_c->dtype.code && queries.dtype.bits == index_c->dtype.bits,
+    CUVS_EXPECTS(index_c->dtype.bits == 0 ||
+                   (queries.dtype.code == index_c->dtype.code && queries.dtype.bits == index_c->dtype.bits),
                  "Unsupported queries DLtensor dtype: %d and bits: %d", (int)queries.dtype.code,
                  (int)queries.dtype.bits);
     CUVS_EXPECTS(queries.shape[1] == idx.dim, "queries dim %ld != index dim %u", (long)queries.shape[1], idx.dim);
@@ -190,6 +192,8 @@ cuvsError_t cuvsIvfPqExtend(cuvsResources_t res_h, DLManagedTensor* new_vectors,
       ids      = static_cast<const int64_t*>(dl_data(t));
       ids_host = !is_device_accessible(t);
     }
+    // an untyped handle (reference-format load) takes the dtype of the first vectors (c/src/neighbors/ivf_pq.cpp:412-416)
+    if (index_c->dtype.code == 0 && index_c->dtype.bits == 0) index_c->dtype = v.dtype;
     ivf_pq_extend(res, idx, dl_data(v), elem_of(v.dtype), v.shape[0], !is_device_accessible(v), ids, ids_host);
   });
 }
@@ -287,27 +291,206 @@ cuvsError_t cuvsIvfPqIndexGetListIndices(cuvsIvfPqIndex_t index, uint32_t label,
   });
 }
 
+}  // extern "C"
+
+namespace {
+constexpr int kPqRefVersion = 4;  // ivf_pq_serialize.cuh:28
+
+void pq_write_native(resources& res, const char* filename, const ivf_pq_index& idx, DLDataType dl)
+{
+  file_writer w(filename, KIND_IVF_PQ);
+  w.scalar<int32_t>(idx.metric); w.scalar<int32_t>(idx.codebook_kind); w.scalar<int32_t>((int)idx.dtype);
+  const uint32_t u[] = {idx.n_lists, idx.dim, idx.dim_ext, idx.rot_dim, idx.pq_dim, idx.pq_bits, idx.pq_len,
+                        idx.pq_book, idx.n_chunks, idx.codes_per_chunk};
+  for (uint32_t v : u) w.scalar<uint32_t>(v);
+  w.scalar<int64_t>(idx.size); w.scalar<int64_t>(idx.padded_rows);
+  w.scalar<uint8_t>(dl.code); w.scalar<uint8_t>(dl.bits);
+  w.device_array(res, idx.centers.data(), idx.centers.bytes());
+  w.device_array(res, idx.center_norms.data(), idx.center_norms.bytes());
+  w.device_array(res, idx.centers_rot.data(), idx.centers_rot.bytes());
+  w.device_array(res, idx.rotation.data(), idx.rotation.bytes());
+  w.device_array(res, idx.pq_centers.data(), idx.pq_centers.bytes());
+  w.device_array(res, idx.list_sizes.data(), idx.list_sizes.bytes());
+  w.device_array(res, idx.list_offsets.data(), idx.list_offsets.bytes());
+  w.device_array(res, idx.codes.data(), idx.codes.bytes());
+  w.device_array(res, idx.indices.data(), idx.indices.bytes());
+}
+
+std::unique_ptr<ivf_pq_index> pq_read_native(resources& res, const char* filename, DLDataType* dl)
+{
+  file_reader r(filename, KIND_IVF_PQ);
+  auto idx = std::make_unique<ivf_pq_index>();
+  idx->metric = r.scalar<int32_t>(); idx->codebook_kind = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>();
+  uint32_t* u[] = {&idx->n_lists, &idx->dim, &idx->dim_ext, &idx->rot_dim, &idx->pq_dim, &idx->pq_bits, &idx->pq_len,
+                   &idx->pq_book, &idx->n_chunks, &idx->codes_per_chunk};
+  for (uint32_t* v : u) *v = r.scalar<uint32_t>();
+  idx->size = r.scalar<int64_t>(); idx->padded_rows = r.scalar<int64_t>();
+  uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
+  idx->centers      = r.device_array<float>(res);
+  idx->center_norms = r.device_array<float>(res);
+  idx->centers_rot  = r.device_array<float>(res);
+  idx->rotation     = r.device_array<float>(res);
+  idx->pq_centers   = r.device_array<float>(res);
+  idx->list_sizes   = r.device_array<uint32_t>(res);
+  idx->list_offsets = r.device_array<uint32_t>(res);
+  idx->codes        = r.device_array<uint8_t>(res);
+  idx->indices      = r.device_array<int64_t>(res);
+  idx->h_list_sizes   = to_host(res, idx->list_sizes.data(), idx->n_lists);
+  idx->h_list_offsets = to_host(res, idx->list_offsets.data(), idx->n_lists + 1);
+  *dl = DLDataType{code, bits, 1};
+  return idx;
+}
+
+// Reference record sequence (ivf_pq_serialize.cuh:49-85, ivf_list.cuh:108-131): version, size, dim, pq_bits,
+// pq_dim, conservative_memory_allocation, metric, codebook_kind, codes_layout, n_lists, pq_centers, centers
+// [n_lists, dim_ext], centers_rot, rotation_matrix, list_sizes, then per list: size [, codes
+// [ceil(size/32), n_chunks, 32, 16], ids [size]]. A 16-byte chunk has the same content in both libraries
+// (ivf_pq_codepacking.cuh:106-137); only the row grouping differs (32 there, 64 here), so lists are regrouped
+// chunk by chunk on the host. The file carries no dataset dtype (the reference's index is untyped).
+void pq_write_ref(resources& res, const char* filename, const ivf_pq_index& idx)
+{
+  npy_writer w(filename);
+  w.scalar<int32_t>(kPqRefVersion);
+  w.scalar<int64_t>(idx.size);
+  w.scalar<uint32_t>(idx.dim);
+  w.scalar<uint32_t>(idx.pq_bits);
+  w.scalar<uint32_t>(idx.pq_dim);
+  w.scalar<bool>(true);  // conservative_memory_allocation
+  w.scalar<int32_t>(idx.metric);
+  w.scalar<int32_t>(idx.codebook_kind);
+  w.scalar<int32_t>(1);  // list_layout::INTERLEAVED (ivf_pq.hpp:40-45)
+  w.scalar<uint32_t>(idx.n_lists);
+  const int64_t pqc0 = idx.codebook_kind == 0 ? idx.pq_dim : idx.n_lists;
+  w.device_array(res, 'f', 4, {pqc0, idx.pq_len, idx.pq_book}, idx.pq_centers.data());
+  w.device_array(res, 'f', 4, {idx.n_lists, idx.dim_ext}, idx.centers.data());
+  w.device_array(res, 'f', 4, {idx.n_lists, idx.rot_dim}, idx.centers_rot.data());
+  w.device_array(res, 'f', 4, {idx.rot_dim, idx.dim}, idx.rotation.data());
+  w.host_array<uint32_t>(idx.h_list_sizes.data(), {idx.n_lists});
+  std::vector<uint8_t> ours, theirs;
+  std::vector<int64_t> ids;
+  const uint32_t nc = idx.n_chunks;
+  for (uint32_t L = 0; L < idx.n_lists; ++L) {
+    const uint32_t size = idx.h_list_sizes[L];
+    w.scalar<uint32_t>(size);
+    if (size == 0) continue;
+    const uint32_t cap = idx.h_list_offsets[L + 1] - idx.h_list_offsets[L], g32 = (size + 31) / 32;
+    ours.resize((size_t)cap * nc * 16);
+    ids.resize(size);
+    copy_async(res, ours.data(), idx.codes.data() + (size_t)idx.h_list_offsets[L] * nc * 16, ours.size());
+    copy_async(res, ids.data(), idx.indices.data() + idx.h_list_offsets[L], (size_t)size * sizeof(int64_t));
+    sync(res);
+    theirs.assign((size_t)g32 * nc * 32 * 16, 0);
+    for (uint32_t r = 0; r < size; ++r)
+      for (uint32_t c = 0; c < nc; ++c)
+        memcpy(theirs.data() + (((size_t)(r / 32) * nc + c) * 32 + r % 32) * 16,
+               ours.data() + (((size_t)(r / 64) * nc + c) * 64 + r % 64) * 16, 16);
+    w.header('u', 1, {g32, nc, 32, 16});
+    w.raw(theirs.data(), theirs.size());
+    w.host_array<int64_t>(ids.data(), {size});
+  }
+  w.close();
+}
+
+std::unique_ptr<ivf_pq_index> pq_read_ref(resources& res, const char* filename)
+{
+  npy_reader r(filename);
+  int ver = r.scalar<int32_t>();
+  CUVS_EXPECTS(ver == kPqRefVersion, "serialization version mismatch %d vs. %d", ver, kPqRefVersion);
+  ivf_pq_build_params p;
+  int64_t n_rows  = r.scalar<int64_t>();
+  uint32_t dim    = r.scalar<uint32_t>();
+  p.pq_bits       = r.scalar<uint32_t>();
+  p.pq_dim        = r.scalar<uint32_t>();
+  (void)r.scalar<bool>();  // conservative_memory_allocation
+  p.metric        = r.scalar<int32_t>();
+  p.codebook_kind = r.scalar<int32_t>();
+  int layout      = r.scalar<int32_t>();
+  p.n_lists       = r.scalar<uint32_t>();
+  CUVS_EXPECTS(layout == 0 || layout == 1, "ivf_pq::deserialize: invalid list_layout value %d", layout);
+  CUVS_EXPECTS(p.codebook_kind == 0 || p.codebook_kind == 1, "ivf_pq::deserialize: invalid codebook_gen value %d",
+               p.codebook_kind);
+  CUVS_EXPECTS(dim > 0 && p.pq_dim > 0 && p.n_lists > 0 && p.n_lists <= (1u << 24), "ivf_pq::deserialize: bad header");
+  auto idx = ivf_pq_make_empty(res, p, elem_t::f32, dim);
+  idx->dtype_known = false;
+  const int64_t pqc0 = idx->codebook_kind == 0 ? idx->pq_dim : idx->n_lists;
+  idx->pq_centers  = r.device_array<float>(res, pqc0 * idx->pq_len * idx->pq_book);
+  std::vector<float> h_centers = r.host_array<float>((int64_t)idx->n_lists * idx->dim_ext);
+  idx->centers     = dev_buf<float>::persistent(h_centers.size());
+  copy_async(res, idx->centers.data(), h_centers.data(), h_centers.size() * sizeof(float));
+  std::vector<float> h_norms(idx->n_lists);
+  for (uint32_t L = 0; L < idx->n_lists; ++L) h_norms[L] = h_centers[(size_t)L * idx->dim_ext + idx->dim];
+  idx->center_norms = dev_buf<float>::persistent(idx->n_lists);
+  copy_async(res, idx->center_norms.data(), h_norms.data(), h_norms.size() * sizeof(float));
+  sync(res);
+  idx->centers_rot = r.device_array<float>(res, (int64_t)idx->n_lists * idx->rot_dim);
+  idx->rotation    = r.device_array<float>(res, (int64_t)idx->rot_dim * idx->dim);
+  idx->h_list_sizes = r.host_array<uint32_t>(idx->n_lists);
+  int64_t total = 0, live = 0;
+  for (uint32_t L = 0; L < idx->n_lists; ++L) {
+    idx->h_list_offsets[L] = (uint32_t)total;
+    total += round_up(idx->h_list_sizes[L], 64);
+    live += idx->h_list_sizes[L];
+  }
+  CUVS_EXPECTS(total < (int64_t(1) << 32), "ivf_pq::deserialize: index too large");
+  CUVS_EXPECTS(live == n_rows, "ivf_pq::deserialize: list sizes (%ld) do not add up to the index size (%ld)",
+               (long)live, (long)n_rows);
+  idx->h_list_offsets[idx->n_lists] = (uint32_t)total;
+  idx->size = n_rows; idx->padded_rows = total;
+  copy_async(res, idx->list_sizes.data(), idx->h_list_sizes.data(), idx->n_lists * sizeof(uint32_t));
+  copy_async(res, idx->list_offsets.data(), idx->h_list_offsets.data(), (idx->n_lists + 1) * sizeof(uint32_t));
+  const uint32_t nc = idx->n_chunks, cpc = idx->codes_per_chunk, bits = idx->pq_bits;
+  idx->codes   = dev_buf<uint8_t>::persistent((size_t)total * nc * 16);
+  idx->indices = dev_buf<int64_t>::persistent((size_t)total);
+  HIP_TRY(hipMemsetAsync(idx->codes.data(), 0, idx->codes.bytes(), res.stream));
+  HIP_TRY(hipMemsetAsync(idx->indices.data(), 0xff, idx->indices.bytes(), res.stream));
+  sync(res);
+  const uint32_t bpv = (idx->pq_dim * bits + 7) / 8;
+  std::vector<uint8_t> ours;
+  std::vector<char> theirs;
+  for (uint32_t L = 0; L < idx->n_lists; ++L) {
+    const uint32_t size = r.scalar<uint32_t>();
+    CUVS_EXPECTS(size == idx->h_list_sizes[L], "ivf_pq::deserialize: list %u holds %u rows, list_sizes says %u", L,
+                 size, idx->h_list_sizes[L]);
+    if (size == 0) continue;
+    const uint32_t g32 = (size + 31) / 32, cap = (uint32_t)round_up(size, 64);
+    r.array(1, layout == 1 ? (int64_t)g32 * nc * 32 * 16 : (int64_t)size * bpv, theirs);
+    std::vector<int64_t> ids = r.host_array<int64_t>(size);
+    ours.assign((size_t)cap * nc * 16, 0);
+    if (layout == 1) {
+      for (uint32_t rr = 0; rr < size; ++rr)
+        for (uint32_t c = 0; c < nc; ++c)
+          memcpy(ours.data() + (((size_t)(rr / 64) * nc + c) * 64 + rr % 64) * 16,
+                 theirs.data() + (((size_t)(rr / 32) * nc + c) * 32 + rr % 32) * 16, 16);
+    } else {
+      // FLAT layout: one contiguous little-endian bitstream per row (ivf_pq.hpp:302-338) -> 16-byte chunks of
+      // codes_per_chunk codes, each chunk starting at bit 0
+      for (uint32_t rr = 0; rr < size; ++rr) {
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(theirs.data()) + (size_t)rr * bpv;
+        for (uint32_t j = 0; j < idx->pq_dim; ++j) {
+          uint32_t ib = j * bits, code = 0;
+          for (uint32_t b = 0; b < bits; ++b, ++ib) code |= (uint32_t)((src[ib >> 3] >> (ib & 7)) & 1u) << b;
+          uint8_t* dst = ours.data() + (((size_t)(rr / 64) * nc + j / cpc) * 64 + rr % 64) * 16;
+          uint32_t ob  = (j % cpc) * bits;
+          for (uint32_t b = 0; b < bits; ++b, ++ob) dst[ob >> 3] |= (uint8_t)(((code >> b) & 1u) << (ob & 7));
+        }
+      }
+    }
+    copy_async(res, idx->codes.data() + (size_t)idx->h_list_offsets[L] * nc * 16, ours.data(), ours.size());
+    copy_async(res, idx->indices.data() + idx->h_list_offsets[L], ids.data(), (size_t)size * sizeof(int64_t));
+    sync(res);
+  }
+  return idx;
+}
+}  // namespace
+
+extern "C" {
 cuvsError_t cuvsIvfPqSerialize(cuvsResources_t res_h, const char* filename, cuvsIvfPqIndex_t index)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     auto& idx = get_index(index);
-    file_writer w(filename, KIND_IVF_PQ);
-    w.scalar<int32_t>(idx.metric); w.scalar<int32_t>(idx.codebook_kind); w.scalar<int32_t>((int)idx.dtype);
-    const uint32_t u[] = {idx.n_lists, idx.dim, idx.dim_ext, idx.rot_dim, idx.pq_dim, idx.pq_bits, idx.pq_len,
-                          idx.pq_book, idx.n_chunks, idx.codes_per_chunk};
-    for (uint32_t v : u) w.scalar<uint32_t>(v);
-    w.scalar<int64_t>(idx.size); w.scalar<int64_t>(idx.padded_rows);
-    w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);
-    w.device_array(res, idx.centers.data(), idx.centers.bytes());
-    w.device_array(res, idx.center_norms.data(), idx.center_norms.bytes());
-    w.device_array(res, idx.centers_rot.data(), idx.centers_rot.bytes());
-    w.device_array(res, idx.rotation.data(), idx.rotation.bytes());
-    w.device_array(res, idx.pq_centers.data(), idx.pq_centers.bytes());
-    w.device_array(res, idx.list_sizes.data(), idx.list_sizes.bytes());
-    w.device_array(res, idx.list_offsets.data(), idx.list_offsets.bytes());
-    w.device_array(res, idx.codes.data(), idx.codes.bytes());
-    w.device_array(res, idx.indices.data(), idx.indices.bytes());
+    if (write_native_container()) pq_write_native(res, filename, idx, index->dtype);
+    else pq_write_ref(res, filename, idx);
   });
 }
 cuvsError_t cuvsIvfPqDeserialize(cuvsResources_t res_h, const char* filename, cuvsIvfPqIndex_t index)
@@ -315,28 +498,13 @@ cuvsError_t cuvsIvfPqDeserialize(cuvsResources_t res_h, const char* filename, cu
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     CUVS_EXPECTS(index != nullptr, "index is null");
-    file_reader r(filename, KIND_IVF_PQ);
-    auto idx = std::make_unique<ivf_pq_index>();
-    idx->metric = r.scalar<int32_t>(); idx->codebook_kind = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>();
-    uint32_t* u[] = {&idx->n_lists, &idx->dim, &idx->dim_ext, &idx->rot_dim, &idx->pq_dim, &idx->pq_bits, &idx->pq_len,
-                     &idx->pq_book, &idx->n_chunks, &idx->codes_per_chunk};
-    for (uint32_t* v : u) *v = r.scalar<uint32_t>();
-    idx->size = r.scalar<int64_t>(); idx->padded_rows = r.scalar<int64_t>();
-    uint8_t code = r.scalar<uint8_t>(), bits = r.scalar<uint8_t>();
-    idx->centers      = r.device_array<float>(res);
-    idx->center_norms = r.device_array<float>(res);
-    idx->centers_rot  = r.device_array<float>(res);
-    idx->rotation     = r.device_array<float>(res);
-    idx->pq_centers   = r.device_array<float>(res);
-    idx->list_sizes   = r.device_array<uint32_t>(res);
-    idx->list_offsets = r.device_array<uint32_t>(res);
-    idx->codes        = r.device_array<uint8_t>(res);
-    idx->indices      = r.device_array<int64_t>(res);
-    idx->h_list_sizes   = to_host(res, idx->list_sizes.data(), idx->n_lists);
-    idx->h_list_offsets = to_host(res, idx->list_offsets.data(), idx->n_lists + 1);
+    // a reference-format file carries no dataset dtype: the handle's dtype stays 0/0 until the first search or
+    // extend names one (c/src/neighbors/ivf_pq.cpp:389-395,412-416)
+    DLDataType dl{0, 0, 1};
+    auto idx = is_native_container(filename) ? pq_read_native(res, filename, &dl) : pq_read_ref(res, filename);
     delete reinterpret_cast<ivf_pq_index*>(index->addr);
     index->addr  = reinterpret_cast<uintptr_t>(idx.release());
-    index->dtype = DLDataType{code, bits, 1};
+    index->dtype = dl;
   });
 }
 cuvsError_t cuvsIvfPqTransform(cuvsResources_t, cuvsIvfPqIndex_t, DLManagedTensor*, DLManagedTensor*,

@@ -139,7 +139,9 @@ struct lut_acc<__half, __half, 4> {
 
 struct scan_args {
   const work_item* items;
-  const uint32_t* n_items;       // device scalar (item_off[n_lists])
+  const uint32_t* item_begin;    // device scalars: this launch walks items [*item_begin, *item_end)
+  const uint32_t* item_end;      //   (item_begin == nullptr: from 0)
+  uint32_t n_lists;              // item.list >= n_lists: tail-phase label of list item.list - n_lists
   const uint32_t* sorted_pairs;  // pair ids (q * n_probes + probe rank) grouped by list
   const float* rot_queries;      // [n_queries, rot_dim]
   const float* centers_rot;      // [n_lists, rot_dim]
@@ -152,7 +154,7 @@ struct scan_args {
   uint32_t n_probes, rot_dim, pq_dim, pq_len, pq_bits, n_chunks, cpc, k;
   int is_ip;
   uint32_t* query_kth;  // [n_queries] order-preserving key of the best known k-th distance (shared by probes)
-  int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k
+  int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k, 8 no early stop
 };
 
 // gathers of one 16-byte chunk of 8-bit codes, issued 8 at a time (8 independent ds_reads in flight;
@@ -203,7 +205,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
-  const uint32_t L        = item.list;
+  const uint32_t L        = item.list >= a.n_lists ? item.list - a.n_lists : item.list;
   const uint32_t base_row = a.list_offsets[L];
   const uint32_t len      = a.list_sizes[L];
 
@@ -341,6 +343,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   const size_t g0       = (size_t)(base_row >> 6);
   const uint4* codes16  = reinterpret_cast<const uint4*>(a.codes);
   const int kr          = (int)a.k - 1;
+  const bool prune      = FAST4 && !a.is_ip && !(a.dbg & 8);  // dbg 8: early stop off (ablation)
 
   for (uint32_t it = 0; it < n_iter; ++it) {
     const uint32_t tile0 = (it * kScanWaves + wave) * 64;  // in-list position of lane 0
@@ -353,7 +356,30 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
       const uint4* cp = codes16 + ((g0 + (size_t)it * kScanWaves + wave) * 4) * 64 + lane;
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];  // padded rows of a group are zero-filled: readable
-      if (!(a.dbg & 2)) {
+      if (!(a.dbg & 2) && prune) {
+        // early stop (compute_score_impl.cuh:70-71): L2 LUT entries are >= 0, so a row whose partial sums
+        // already exceed the k-th bound of every query of the item cannot enter any top list. Its lane sits out
+        // the remaining chunks - fewer active lanes mean fewer LDS bank conflicts - and a wave whose 64 rows are
+        // all out skips them entirely. The bounds are read once per tile; they only ever decrease, so a lane
+        // dropped against these is also rejected by the (fresher) filter below.
+        float bf[QPB];
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) {
+          const uint32_t kk = __builtin_amdgcn_readfirstlane(kthb[j]);
+          bf[j] = j >= (int)item.count ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
+        }
+        bool alive = valid;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          if (alive) gather16(acc, lut + ((ch * 16) << 8), cur[ch]);
+          if (ch < 3) {
+            bool below = false;
+#pragma unroll
+            for (int j = 0; j < QPB; ++j) below = below || (acc.get(j) <= bf[j]);
+            alive = alive && below;
+          }
+        }
+      } else if (!(a.dbg & 2)) {
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) gather16(acc, lut + ((ch * 16) << 8), cur[ch]);
       } else {
@@ -496,7 +522,8 @@ template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
 __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t n_items = *a.n_items;
+  const uint32_t item0   = a.item_begin ? *a.item_begin : 0u;
+  const uint32_t n_items = *a.item_end - item0;
   const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, per = gridDim.x >> 3;
   const uint32_t chunk = (n_items + 7u) / 8u;
   float pqreg[4][2][4];
@@ -512,12 +539,12 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
           pqreg[sg][l][t] = pq_in_regs ? a.pq_centers[(size_t)((wave + sg * kScanWaves) * 2 + l) * 256 + t * 64 + lane] : 0.f;
   }
   work_item cur{0, 0, 0, 0};
-  if (lb < chunk && xcd * chunk + lb < n_items) cur = a.items[xcd * chunk + lb];
+  if (lb < chunk && xcd * chunk + lb < n_items) cur = a.items[item0 + xcd * chunk + lb];
   for (uint32_t local = lb; local < chunk; local += per) {
     const uint32_t w  = xcd * chunk + local;
     const uint32_t wn = w + per;  // header of the next item: loaded now, needed after this item
     work_item nxt     = cur;
-    if (local + per < chunk && wn < n_items) nxt = a.items[wn];
+    if (local + per < chunk && wn < n_items) nxt = a.items[item0 + wn];
     if (w < n_items) pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, cur, smem, pqreg, pq_in_regs);
     __syncthreads();
     cur = nxt;
@@ -580,6 +607,14 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
 }
 
 // flat row -> source id; distance fix-ups (ivf_common.cuh:114-171 postprocess_neighbors, :176-253)
+// label of pair p for the two-phase schedule: head probes keep their list id, the others move to n_lists + list
+__global__ void phase_labels_kernel(const uint32_t* __restrict__ probes, int64_t n_pairs, uint32_t n_probes,
+                                    uint32_t head, uint32_t n_lists, uint32_t* __restrict__ out)
+{
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x)
+    out[p] = probes[p] + ((uint32_t)(p % n_probes) < head ? 0u : n_lists);
+}
+
 __global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float* __restrict__ d_in, int64_t n,
                                    const int64_t* __restrict__ indices, int metric, float scale2,
                                    int64_t* __restrict__ neighbors, float* __restrict__ distances)
@@ -616,7 +651,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                "internal_distance_dtype must be either CUDA_R_16F or CUDA_R_32F");
   CUVS_EXPECTS(p.lut_dtype == 0 || p.lut_dtype == 2 || p.lut_dtype == 8,
                "lut_dtype must be CUDA_R_16F, CUDA_R_32F or CUDA_R_8U");
-  CUVS_EXPECTS(et == idx.dtype, "queries dtype differs from the index dtype");
+  CUVS_EXPECTS(!idx.dtype_known || et == idx.dtype, "queries dtype differs from the index dtype");
   if (n_queries == 0) return;
   const uint32_t n_probes = std::min<uint32_t>(p.n_probes, idx.n_lists);
   const bool lut_half     = p.lut_dtype != 0;  // fp8 LUT requests run on the fp16 LUT (superset precision)
@@ -652,9 +687,17 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<float> qf(res, (size_t)bs_alloc * idx.dim);
   dev_buf<float> rot_q(res, (size_t)bs_alloc * idx.rot_dim);
   dev_buf<uint32_t> probes(res, (size_t)n_pairs_max);
-  dev_buf<uint32_t> sorted_pairs(res, (size_t)n_pairs_max), pair_off(res, idx.n_lists + 1),
-    item_off(res, idx.n_lists + 1);
-  const int64_t max_items = n_pairs_max / qpb + idx.n_lists + 1;
+  // Two-phase schedule: the `head` nearest probes of every query are scanned first (labels 0..n_lists-1), the
+  // rest afterwards (labels n_lists..2 n_lists-1). After the head phase each query's k-th bound (query_kth) is
+  // already close to final, which is what makes the early stop in the scan loop bite. Results do not depend on
+  // the order in which pairs are scanned.
+  uint32_t head = n_probes > 8 ? 1u : 0u;
+  if (const char* e = getenv("CUVS_AMD_PQ_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
+  if (idx.metric == M_InnerProduct) head = 0;  // no early stop for inner product (LUT entries are signed)
+  const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
+  dev_buf<uint32_t> sorted_pairs(res, (size_t)n_pairs_max), pair_off(res, n_labels + 1), item_off(res, n_labels + 1);
+  dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)n_pairs_max : 0);
+  const int64_t max_items = n_pairs_max / qpb + n_labels + 1;
   dev_buf<work_item> items(res, (size_t)max_items);
   dev_buf<float> cand_d(res, (size_t)n_pairs_max * k);
   dev_buf<uint32_t> cand_i(res, (size_t)n_pairs_max * k);
@@ -672,12 +715,18 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.rotation.data(), idx.rot_dim, idx.dim, idx.dim,
                                     nullptr, nullptr, M_InnerProduct, rot_q.data(), idx.rot_dim);
     // list-major grouping of the (query, probe) pairs
-    build_work_items(res, probes.data(), n_pairs, idx.n_lists, qpb, sorted_pairs.data(), pair_off.data(),
-                     item_off.data(), items.data());
+    const uint32_t* labels = probes.data();
+    if (head > 0) {
+      hipLaunchKernelGGL(phase_labels_kernel, dim3(nblk(n_pairs, 256)), dim3(256), 0, res.stream, probes.data(),
+                         n_pairs, n_probes, head, idx.n_lists, phase_labels.data());
+      labels = phase_labels.data();
+    }
+    build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
+                     items.data());
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     scan_args a;
     a.query_kth = query_kth.data();
-    a.items = items.data(); a.n_items = item_off.data() + idx.n_lists; a.sorted_pairs = sorted_pairs.data();
+    a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
     a.rot_queries = rot_q.data(); a.centers_rot = idx.centers_rot.data(); a.pq_centers = idx.pq_centers.data();
     a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data(); a.list_sizes = idx.list_sizes.data();
     a.out_d = cand_d.data(); a.out_i = cand_i.data();
@@ -686,22 +735,33 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.is_ip = idx.metric == M_InnerProduct;
     a.dbg   = getenv("CUVS_AMD_SCAN_DEBUG") ? atoi(getenv("CUVS_AMD_SCAN_DEBUG")) : 0;
     const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);  // persistent: one workgroup per CU
-    if (!lut_half) {
-      if (qpb == 2) launch_scan_qpb<float, float, 2>(res, a, smem, grid, bits8, big_k);
-      else          launch_scan_qpb<float, float, 1>(res, a, smem, grid, bits8, big_k);
-    } else if (!acc_half) {
-      if (qpb == 4)      launch_scan_qpb<__half, float, 4>(res, a, smem, grid, bits8, big_k);
-      else if (qpb == 2) launch_scan_qpb<__half, float, 2>(res, a, smem, grid, bits8, big_k);
-      else               launch_scan_qpb<__half, float, 1>(res, a, smem, grid, bits8, big_k);
+    auto launch = [&](const scan_args& sa) {
+      if (!lut_half) {
+        if (qpb == 2) launch_scan_qpb<float, float, 2>(res, sa, smem, grid, bits8, big_k);
+        else          launch_scan_qpb<float, float, 1>(res, sa, smem, grid, bits8, big_k);
+      } else if (!acc_half) {
+        if (qpb == 4)      launch_scan_qpb<__half, float, 4>(res, sa, smem, grid, bits8, big_k);
+        else if (qpb == 2) launch_scan_qpb<__half, float, 2>(res, sa, smem, grid, bits8, big_k);
+        else               launch_scan_qpb<__half, float, 1>(res, sa, smem, grid, bits8, big_k);
+      } else {
+        if (qpb == 4)      launch_scan_qpb<__half, __half, 4>(res, sa, smem, grid, bits8, big_k);
+        else if (qpb == 2) launch_scan_qpb<__half, __half, 2>(res, sa, smem, grid, bits8, big_k);
+        else               launch_scan_qpb<__half, __half, 1>(res, sa, smem, grid, bits8, big_k);
+      }
+    };
+    if (head > 0) {
+      a.item_begin = nullptr;                        a.item_end = item_off.data() + idx.n_lists;
+      launch(a);  // head phase: the nearest probes, cold bounds
+      a.item_begin = item_off.data() + idx.n_lists;  a.item_end = item_off.data() + 2 * idx.n_lists;
+      launch(a);  // tail phase: warm bounds
     } else {
-      if (qpb == 4)      launch_scan_qpb<__half, __half, 4>(res, a, smem, grid, bits8, big_k);
-      else if (qpb == 2) launch_scan_qpb<__half, __half, 2>(res, a, smem, grid, bits8, big_k);
-      else               launch_scan_qpb<__half, __half, 1>(res, a, smem, grid, bits8, big_k);
+      a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
+      launch(a);
     }
     // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
     select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
                                  k, top_d.data(), top_i.data(), true);
-    const float sc = idx.scale();
+    const float sc = ivf_pq_index::scale(et);
     hipLaunchKernelGGL(postprocess_kernel, dim3(nblk(nq * k, 256)), dim3(256), 0, res.stream, top_i.data(),
                        top_d.data(), nq * k, idx.indices.data(), idx.metric, sc * sc, neighbors + q0 * k,
                        distances + q0 * k);

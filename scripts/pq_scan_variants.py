@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Build the bench.py IVF-PQ index once, then time the search under several scan-kernel settings
+(environment switches read per call: CUVS_AMD_SCAN_DEBUG, CUVS_AMD_PQ_HEAD_PROBES). Prints one line per variant:
+search ms (k*refine candidates), pq_scan_kernel ms per search, and whether the results equal variant 0's.
+
+  python scripts/pq_scan_variants.py [--rows N --n-lists L --n-probes P] "DBG=8,HEAD=0" "DBG=0,HEAD=0" "DBG=0,HEAD=1"
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=100_000_000)
+    ap.add_argument("--n-lists", type=int, default=16384)
+    ap.add_argument("--n-probes", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("variants", nargs="+")
+    args = ap.parse_args()
+
+    import cuvs_amd
+    from cuvs_amd._lib import lib
+    from cuvs_amd.neighbors import ivf_pq
+
+    dev = torch.device("cuda", 0)
+    res = cuvs_amd.common.Resources()
+    data = bench.gen_rows(args.rows, 128, seed=1234, device=dev)
+    queries = bench.gen_rows(args.batch, 128, seed=4321, device=dev)
+    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=args.n_lists, pq_dim=64, pq_bits=8, kmeans_n_iters=20,
+                                            kmeans_trainset_fraction=0.02), data, resources=res)
+    res.sync()
+    del data
+    sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=np.float16, internal_distance_dtype=np.float16,
+                             max_internal_batch_size=args.batch)
+    nb = torch.empty((args.batch, args.k), dtype=torch.int64, device=dev)
+    ds = torch.empty((args.batch, args.k), dtype=torch.float32, device=dev)
+    first = None
+    for v in args.variants:
+        for kv in v.split(","):
+            key, val = kv.split("=")
+            os.environ[{"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES"}[key]] = val
+        for _ in range(2):
+            ivf_pq.search(sp, index, queries, args.k, neighbors=nb, distances=ds, resources=res)
+        res.sync()
+        lib().cuvsAmdProfileEnable(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ivf_pq.search(sp, index, queries, args.k, neighbors=nb, distances=ds, resources=res)
+        res.sync()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / args.steps
+        lib().cuvsAmdProfileEnable(0)
+        scan = C.c_double(0)
+        n = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan))
+        cur = (nb.clone(), ds.clone())
+        same = "ref" if first is None else str(bool(torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])))
+        if first is None:
+            first = cur
+        print(f"{v:24s} search {ms:8.3f} ms  scan {scan.value / args.steps:8.3f} ms ({n // args.steps} launches)  "
+              f"same_as_first={same}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
