@@ -179,6 +179,63 @@ __device__ inline void gather16(acc_t& acc, const typename acc_t::entry_t* __res
   }
 }
 
+// ---- code-major LUT (FAST4 kernels): entry (s, code) lives at byte  code * kRow + s * sizeof(entry),
+// kRow = 64 entries + 8 bytes of padding. The byte address of a gather is then ONE VALU instruction - a 24-bit
+// multiply whose operand is a byte of the code word picked by SDWA - plus an immediate offset in the ds_read,
+// instead of bit-field extract + shift-add (the subspace-major layout needs the 17-bit s * 2048 in the address
+// register). The padding keeps both the LUT writes (64 consecutive codes of one subspace: stride kRow) and the
+// random gathers spread over all banks. The LUT must start at LDS address 0 (checked once per launch): the
+// FAST4 kernels use no static LDS.
+template <typename entry_t>
+struct cm_lut {
+  static constexpr uint32_t esz  = sizeof(entry_t);
+  static constexpr uint32_t kRow = 64 * esz + 8;
+  typedef __attribute__((address_space(3))) const entry_t* rd_ptr;
+  typedef __attribute__((address_space(3))) entry_t* wr_ptr;
+  static constexpr size_t bytes() { return (size_t)256 * kRow; }
+  __device__ static inline void store(uint32_t s, uint32_t code, entry_t v)
+  {
+    *(wr_ptr)(uintptr_t)(code * kRow + s * esz) = v;
+  }
+};
+
+template <int BYTE>
+__device__ inline uint32_t sdwa_byte_times(uint32_t word, uint32_t factor)
+{
+  uint32_t r;
+  if constexpr (BYTE == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(factor), "v"(word));
+  if constexpr (BYTE == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(factor), "v"(word));
+  if constexpr (BYTE == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(factor), "v"(word));
+  if constexpr (BYTE == 3) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(factor), "v"(word));
+  return r;
+}
+
+// the 16 gathers of chunk CH (subspaces CH*16 .. CH*16+15), 8 at a time
+template <typename acc_t, int CH>
+__device__ inline void gather16_cm(acc_t& acc, const uint4 cw)
+{
+  using entry_t = typename acc_t::entry_t;
+  using L       = cm_lut<entry_t>;
+  const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    entry_t e[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int bb       = h * 8 + b;
+      const uint32_t w   = ws[bb >> 2];
+      const uint32_t row = (bb & 3) == 0 ? sdwa_byte_times<0>(w, L::kRow)
+                         : (bb & 3) == 1 ? sdwa_byte_times<1>(w, L::kRow)
+                         : (bb & 3) == 2 ? sdwa_byte_times<2>(w, L::kRow)
+                                         : sdwa_byte_times<3>(w, L::kRow);
+      e[b] = *(typename L::rd_ptr)(uintptr_t)(row + (uint32_t)(CH * 16 + bb) * L::esz);
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc.add(e[b]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // FAST4: pq_bits == 8, pq_dim == 64 (4 full chunks): the four chunk loads of a tile are issued back to back. Otherwise the generic path handles any pq_dim / pq_bits.
 template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
 __device__ inline void pq_scan_item(const scan_args& a, const work_item item, char* smem,
@@ -191,7 +248,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   const uint32_t lut_elems = a.pq_dim * book;
   // LDS carve (all offsets multiples of 16)
   entry_t* lut     = reinterpret_cast<entry_t*>(smem);
-  size_t off       = ((size_t)lut_elems * sizeof(entry_t) + 15) & ~size_t(15);
+  size_t off       = ((FAST4 ? cm_lut<entry_t>::bytes() : (size_t)lut_elems * sizeof(entry_t)) + 15) & ~size_t(15);
   {
     size_t mg = (size_t)QPB * kScanWaves * a.k * 8;  // merge area reuses the LUT region after the scan
     if (mg > off) off = (mg + 15) & ~size_t(15);
@@ -258,7 +315,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
             sc[j]   = __fmaf_rn(-q[1][j], pqreg[sg][1][t], v);
           }
         }
-        lut[(s << 8) + t * 64 + lane] = acc_t::pack(sc);
+        cm_lut<entry_t>::store(s, t * 64 + lane, acc_t::pack(sc));  // pq_in_regs implies FAST4
       }
     }
   } else if (book >= 64 && !(a.dbg & 1)) {
@@ -298,7 +355,10 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          if (c0 + t * 64 < book) lut[(s << a.pq_bits) + c0 + t * 64 + lane] = acc_t::pack(sc[t]);
+          if (c0 + t * 64 < book) {
+            if (FAST4) cm_lut<entry_t>::store(s, c0 + t * 64 + lane, acc_t::pack(sc[t]));
+            else       lut[(s << a.pq_bits) + c0 + t * 64 + lane] = acc_t::pack(sc[t]);
+          }
       }
     }
   } else {
@@ -369,19 +429,24 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
           bf[j] = j >= (int)item.count ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
         }
         bool alive = valid;
+        auto still_below = [&]() {
+          bool below = false;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-          if (alive) gather16(acc, lut + ((ch * 16) << 8), cur[ch]);
-          if (ch < 3) {
-            bool below = false;
-#pragma unroll
-            for (int j = 0; j < QPB; ++j) below = below || (acc.get(j) <= bf[j]);
-            alive = alive && below;
-          }
-        }
+          for (int j = 0; j < QPB; ++j) below = below || (acc.get(j) <= bf[j]);
+          return below;
+        };
+        if (alive) gather16_cm<acc_t, 0>(acc, cur[0]);
+        alive = alive && still_below();
+        if (alive) gather16_cm<acc_t, 1>(acc, cur[1]);
+        alive = alive && still_below();
+        if (alive) gather16_cm<acc_t, 2>(acc, cur[2]);
+        alive = alive && still_below();
+        if (alive) gather16_cm<acc_t, 3>(acc, cur[3]);
       } else if (!(a.dbg & 2)) {
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) gather16(acc, lut + ((ch * 16) << 8), cur[ch]);
+        gather16_cm<acc_t, 0>(acc, cur[0]);
+        gather16_cm<acc_t, 1>(acc, cur[1]);
+        gather16_cm<acc_t, 2>(acc, cur[2]);
+        gather16_cm<acc_t, 3>(acc, cur[3]);
       } else {
         acc.add(lut[cur[0].x & 0xff]);
       }
@@ -528,6 +593,8 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   const uint32_t chunk = (n_items + 7u) / 8u;
   float pqreg[4][2][4];
   const bool pq_in_regs = FAST4 && a.pq_len == 2;  // FAST4: pq_dim 64, 8-bit codes
+  // the code-major LUT addresses LDS absolutely (see cm_lut): fail loudly if the dynamic LDS does not start at 0
+  if (FAST4 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -555,7 +622,8 @@ template <typename LutT, typename AccT, int QPB>
 size_t scan_smem_bytes(const ivf_pq_index& idx, int k)
 {
   using entry_t = typename lut_acc<LutT, AccT, QPB>::entry_t;
-  size_t lut = ((size_t)idx.pq_dim * idx.pq_book * sizeof(entry_t) + 15) & ~size_t(15);
+  const bool fast4 = idx.pq_bits == 8 && idx.pq_dim == 64;  // code-major LUT: 8 bytes of padding per code row
+  size_t lut = ((fast4 ? cm_lut<entry_t>::bytes() : (size_t)idx.pq_dim * idx.pq_book * sizeof(entry_t)) + 15) & ~size_t(15);
   size_t mg  = ((size_t)QPB * kScanWaves * k * 8 + 15) & ~size_t(15);
   return std::max(lut, mg) + ((((size_t)QPB * idx.rot_dim * 4) + 15) & ~size_t(15)) +
          ((((size_t)idx.rot_dim * 4) + 15) & ~size_t(15)) + 2 * 16 * 4;
