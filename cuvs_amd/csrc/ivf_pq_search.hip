@@ -399,18 +399,24 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 #pragma unroll
   for (int j = 0; j < QPB; ++j) top[j].init();
 
-  const uint32_t n_iter = (len + kScanThreads - 1) / kScanThreads;
+  const uint32_t n_iter = (a.dbg & 16) ? 0u : (len + kScanThreads - 1) / kScanThreads;  // dbg 16: no scan loop
   const size_t g0       = (size_t)(base_row >> 6);
   const uint4* codes16  = reinterpret_cast<const uint4*>(a.codes);
   const int kr          = (int)a.k - 1;
   const bool prune      = FAST4 && !a.is_ip && !(a.dbg & 8);  // dbg 8: early stop off (ablation)
 
-  for (uint32_t it = 0; it < n_iter; ++it) {
+  // The ~20 work items of a list run on ~20 CUs of one XCD at about the same time. Each starts its pass over
+  // the list at a different rotation, so that at any moment the CUs touch different parts of the list: one of them
+  // pulls a line into L2, the others find it there later, instead of all of them missing on it together.
+  const uint32_t rot = (a.dbg & 64) ? 0u : (item.first / QPB);
+  for (uint32_t it0 = 0; it0 < n_iter; ++it0) {
+    const uint32_t it    = (it0 + rot) % n_iter;
     const uint32_t tile0 = (it * kScanWaves + wave) * 64;  // in-list position of lane 0
     const uint32_t v     = tile0 + lane;
     const bool valid     = v < len;
-    if (tile0 >= len) break;  // wave-uniform
+    if (tile0 >= len) continue;  // wave-uniform
     acc_t acc;
+    bool cand = valid;  // lanes that may still hold a candidate for some query of the item
     if (FAST4) {
       uint4 cur[4];
       const uint4* cp = codes16 + ((g0 + (size_t)it * kScanWaves + wave) * 4) * 64 + lane;
@@ -442,6 +448,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         if (alive) gather16_cm<acc_t, 2>(acc, cur[2]);
         alive = alive && still_below();
         if (alive) gather16_cm<acc_t, 3>(acc, cur[3]);
+        cand = alive && still_below();
       } else if (!(a.dbg & 2)) {
         gather16_cm<acc_t, 0>(acc, cur[0]);
         gather16_cm<acc_t, 1>(acc, cur[1]);
@@ -485,6 +492,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     }
 
     if (a.dbg & 4) continue;
+    if (__ballot(cand) == 0ull) continue;  // the usual case once the bounds are warm: nothing in this tile
     // ---- candidate filter: one ballot over "any query passes" first (almost always empty once the bounds
     // are warm), then per query
     float dj[QPB];
@@ -497,11 +505,11 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
       djk[j] = a.is_ip ? float_to_key(dj[j]) : (__float_as_uint(dj[j]) | 0x80000000u);
       any    = any || (j < (int)item.count && djk[j] <= kthb[j]);  // kthb: LDS broadcast reads
     }
-    if (__ballot(valid && any) == 0ull) continue;
+    if (__ballot(cand && any) == 0ull) continue;
 #pragma unroll
     for (int j = 0; j < QPB; ++j) {
       if (j >= (int)item.count) break;
-      unsigned long long m = __ballot(valid && djk[j] <= kthb[j]);
+      unsigned long long m = __ballot(cand && djk[j] <= kthb[j]);
       if (m == 0ull) continue;
       float kd    = top[j].rank_d(kr);
       uint32_t ki = top[j].rank_i(kr);
@@ -523,6 +531,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     }
   }
 
+  if (a.dbg & 32) return;  // dbg 32: no merge / output (workgroup-uniform)
   // ---- merge the 16 wave lists of every query (the LUT region is free now)
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
