@@ -142,6 +142,7 @@ struct scan_args {
   const uint32_t* item_begin;    // device scalars: this launch walks items [*item_begin, *item_end)
   const uint32_t* item_end;      //   (item_begin == nullptr: from 0)
   uint32_t n_lists;              // item.list >= n_lists: tail-phase label of list item.list - n_lists
+  uint32_t* xcd_ticket;          // 8 zeroed counters, 32 words apart: next unclaimed item of each XCD's share
   const uint32_t* sorted_pairs;  // pair ids (q * n_probes + probe rank) grouped by list
   const float* rot_queries;      // [n_queries, rot_dim]
   const float* centers_rot;      // [n_lists, rot_dim]
@@ -239,7 +240,9 @@ __device__ inline void gather16_cm(acc_t& acc, const uint4 cw)
 // FAST4: pq_bits == 8, pq_dim == 64 (4 full chunks): the four chunk loads of a tile are issued back to back. Otherwise the generic path handles any pq_dim / pq_bits.
 template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
 __device__ inline void pq_scan_item(const scan_args& a, const work_item item, char* smem,
-                                    const float (&pqreg)[4][2][4], const bool pq_in_regs)
+                                    const float (&pqreg)[4][2][4], const bool pq_in_regs,
+                                    const work_item* __restrict__ share, const uint32_t share_len,
+                                    const uint32_t next_ticket, const int next_slot_id)
 {
   using acc_t   = lut_acc<LutT, AccT, QPB>;
   using entry_t = typename acc_t::entry_t;
@@ -257,6 +260,9 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   float* cv      = reinterpret_cast<float*>(smem + off);     off += (((size_t)a.rot_dim * 4) + 15) & ~size_t(15);
   uint32_t* kthb = reinterpret_cast<uint32_t*>(smem + off);  off += 16 * 4;
   uint32_t* pid  = reinterpret_cast<uint32_t*>(smem + off);
+  // the two hand-over slots for work-item headers follow (16 words after pid): the FAST4 LUT must sit at LDS
+  // address 0, so the kernel keeps no static LDS
+  work_item* next_slot = reinterpret_cast<work_item*>(pid + 16) + next_slot_id;
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -391,6 +397,11 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     }
   }
   __syncthreads();
+
+  // header of the workgroup's next item: its ticket was drawn at the start of this item and has arrived by
+  // now; the load issued here lands during the scan and is handed over through LDS before the merge barrier
+  work_item next_hdr{0u, 0u, 0u, 0xffffffffu};
+  if (threadIdx.x == 0 && next_ticket < share_len) next_hdr = share[next_ticket];
 
   // ---- scan: every wave keeps a private sorted top list per query in registers; no workgroup barrier in
   // the loop. kthb[j] (LDS) is the tightest k-th bound any wave (or an earlier probe of the same query)
@@ -532,6 +543,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   }
 
   if (a.dbg & 32) return;  // dbg 32: no merge / output (workgroup-uniform)
+  if (threadIdx.x == 0) *next_slot = next_hdr;
   // ---- merge the 16 wave lists of every query (the LUT region is free now)
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
@@ -614,16 +626,39 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
         for (int t = 0; t < 4; ++t)
           pqreg[sg][l][t] = pq_in_regs ? a.pq_centers[(size_t)((wave + sg * kScanWaves) * 2 + l) * 256 + t * 64 + lane] : 0.f;
   }
-  work_item cur{0, 0, 0, 0};
-  if (lb < chunk && xcd * chunk + lb < n_items) cur = a.items[item0 + xcd * chunk + lb];
-  for (uint32_t local = lb; local < chunk; local += per) {
-    const uint32_t w  = xcd * chunk + local;
-    const uint32_t wn = w + per;  // header of the next item: loaded now, needed after this item
-    work_item nxt     = cur;
-    if (local + per < chunk && wn < n_items) nxt = a.items[item0 + wn];
-    if (w < n_items) pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, cur, smem, pqreg, pq_in_regs);
+  // Work distribution: XCD x owns the x-th eighth of the (list-sorted) item array and its workgroups draw
+  // items from it through one ticket counter, so at any moment the XCD's 32 CUs work on ~32 CONSECUTIVE items
+  // (~1.6 lists) and every list is pulled into that XCD's L2 once. A static stride let the CUs drift apart by
+  // many steps over the ~1200 items each one processes, which spread a list's ~20 items over time and had L2
+  // refetch it (TCC hit rate 53 %).
+  using entry_t = typename lut_acc<LutT, AccT, QPB>::entry_t;
+  work_item* sh_item;
+  {
+    size_t off = ((FAST4 ? cm_lut<entry_t>::bytes() : (size_t)a.pq_dim * (1u << a.pq_bits) * sizeof(entry_t)) + 15) & ~size_t(15);
+    size_t mg  = (size_t)QPB * kScanWaves * a.k * 8;
+    if (mg > off) off = (mg + 15) & ~size_t(15);
+    off += (((size_t)QPB * a.rot_dim * 4) + 15) & ~size_t(15);
+    off += (((size_t)a.rot_dim * 4) + 15) & ~size_t(15);
+    sh_item = reinterpret_cast<work_item*>(smem + off + 2 * 16 * 4);  // after kthb[16] and pid[16]
+  }
+  const uint32_t share0     = min(n_items, xcd * chunk);
+  const uint32_t share_len  = min(chunk, n_items - share0);
+  const work_item* share    = a.items + item0 + share0;
+  uint32_t* ticket          = a.xcd_ticket + xcd * 32;
+  (void)lb; (void)per;
+  if (threadIdx.x == 0) {
+    const uint32_t t = atomicAdd(ticket, 1u);
+    sh_item[0]       = t < share_len ? share[t] : work_item{0u, 0u, 0u, 0xffffffffu};
+  }
+  __syncthreads();
+  for (int buf = 0;; buf ^= 1) {
+    const work_item cur = sh_item[buf];
+    if (cur.pad == 0xffffffffu) break;  // workgroup-uniform
+    uint32_t next_ticket = 0xffffffffu;
+    if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
+    pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, cur, smem, pqreg, pq_in_regs, share, share_len, next_ticket,
+                                             buf ^ 1);
     __syncthreads();
-    cur = nxt;
   }
 }
 
@@ -635,7 +670,7 @@ size_t scan_smem_bytes(const ivf_pq_index& idx, int k)
   size_t lut = ((fast4 ? cm_lut<entry_t>::bytes() : (size_t)idx.pq_dim * idx.pq_book * sizeof(entry_t)) + 15) & ~size_t(15);
   size_t mg  = ((size_t)QPB * kScanWaves * k * 8 + 15) & ~size_t(15);
   return std::max(lut, mg) + ((((size_t)QPB * idx.rot_dim * 4) + 15) & ~size_t(15)) +
-         ((((size_t)idx.rot_dim * 4) + 15) & ~size_t(15)) + 2 * 16 * 4;
+         ((((size_t)idx.rot_dim * 4) + 15) & ~size_t(15)) + 2 * 16 * 4 + 2 * sizeof(work_item);
 }
 
 template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
@@ -781,6 +816,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<float> top_d(res, (size_t)bs_alloc * k);
   dev_buf<uint32_t> top_i(res, (size_t)bs_alloc * k);
   dev_buf<uint32_t> query_kth(res, (size_t)bs_alloc);
+  dev_buf<uint32_t> tickets(res, 2 * 8 * 32);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -801,6 +837,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data());
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
+    HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
     scan_args a;
     a.query_kth = query_kth.data();
     a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
@@ -827,11 +864,14 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       }
     };
     if (head > 0) {
+      a.xcd_ticket = tickets.data();
       a.item_begin = nullptr;                        a.item_end = item_off.data() + idx.n_lists;
       launch(a);  // head phase: the nearest probes, cold bounds
+      a.xcd_ticket = tickets.data() + 8 * 32;
       a.item_begin = item_off.data() + idx.n_lists;  a.item_end = item_off.data() + 2 * idx.n_lists;
       launch(a);  // tail phase: warm bounds
     } else {
+      a.xcd_ticket = tickets.data();
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
       launch(a);
     }
