@@ -169,7 +169,7 @@ def main():
     avg_ms = scan_ms.value / max(n_launch, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_pq_scan_traffic.json")
+    tfile = os.path.join(ROOT, "profiles", "r01b_pq_scan_traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))

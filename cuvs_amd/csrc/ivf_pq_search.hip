@@ -542,8 +542,8 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     }
   }
 
-  if (a.dbg & 32) return;  // dbg 32: no merge / output (workgroup-uniform)
   if (threadIdx.x == 0) *next_slot = next_hdr;
+  if (a.dbg & 32) return;  // dbg 32: no merge / output (workgroup-uniform)
   // ---- merge the 16 wave lists of every query (the LUT region is free now)
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
