@@ -14,6 +14,10 @@ HDRS := $(wildcard cuvs_amd/csrc/*.hpp) $(wildcard include/cuvs/*/*.h) include/d
 
 all: cuvs_amd/libcuvs_c.so oracle/liboracle.so
 
+# the PQ scan kernel lives exactly at the 128-VGPR budget of a 1024-thread workgroup: SLP vectorisation of its
+# scalar fp32 LUT arithmetic into packed pairs costs ~50 spilled registers (the codebook goes to scratch)
+build/ivf_pq_search.o: HIPFLAGS += -fno-slp-vectorize
+
 build/%.o: cuvs_amd/csrc/%.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -296,32 +296,66 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   if (pq_in_regs && !(a.dbg & 1)) {
     // pq_dim 64 x pq_len 2 x 256 codes: this thread's 32 codebook values stay in registers for the whole
     // persistent launch (pq_scan_kernel), so the LUT build touches no global memory at all
+    // The metric test sits OUTSIDE the unrolled loops (inside, it became scalar branches around every entry),
+    // and a scheduling fence after every entry keeps the compiler from overlapping entries: that overlap costs
+    // ~45 spilled VGPRs at the 128-register budget, i.e. the codebook registers end up in scratch.
+    if (!a.is_ip) {
 #pragma unroll
-    for (int sg = 0; sg < 4; ++sg) {
-      const uint32_t s = wave + sg * kScanWaves;
-      float q[2][QPB];
+      for (int sg = 0; sg < 4; ++sg) {
+        const uint32_t s = wave + sg * kScanWaves;
+        float q[2][QPB];
 #pragma unroll
-      for (int l = 0; l < 2; ++l)
+        for (int l = 0; l < 2; ++l)
 #pragma unroll
-        for (int j = 0; j < QPB; ++j) q[l][j] = qv[j * a.rot_dim + s * 2 + l];
-      const float cc0 = cv[s * 2], cc1 = cv[s * 2 + 1];
+          for (int j = 0; j < QPB; ++j) q[l][j] = qv[j * a.rot_dim + s * 2 + l];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float sc[QPB];
+        for (int t = 0; t < 4; ++t) {
+          const float p0 = pqreg[sg][0][t], p1 = pqreg[sg][1][t];
+          float sc[QPB];
+          if constexpr (false && QPB % 2 == 0) {  // packed fp32 pairs cost ~50 spilled VGPRs here
+            // two queries per packed fp32 instruction: lane by lane the same IEEE operations as the scalar form
 #pragma unroll
-        for (int j = 0; j < QPB; ++j) {
-          if (!a.is_ip) {
-            float d0 = q[0][j] - pqreg[sg][0][t];
-            float d1 = q[1][j] - pqreg[sg][1][t];
-            sc[j]    = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+            for (int j = 0; j < QPB; j += 2) {
+              const f32x2_t d0 = f32x2_t{q[0][j], q[0][j + 1]} - p0;
+              const f32x2_t d1 = f32x2_t{q[1][j], q[1][j + 1]} - p1;
+              const f32x2_t r  = __builtin_elementwise_fma(d1, d1, d0 * d0);
+              sc[j] = r.x; sc[j + 1] = r.y;
+            }
           } else {
+#pragma unroll
+            for (int j = 0; j < QPB; ++j) {
+              float d0 = q[0][j] - p0;
+              float d1 = q[1][j] - p1;
+              sc[j]    = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+            }
+          }
+          cm_lut<entry_t>::store(s, t * 64 + lane, acc_t::pack(sc));  // pq_in_regs implies FAST4
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        const uint32_t s = wave + sg * kScanWaves;
+        float q[2][QPB];
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) q[l][j] = qv[j * a.rot_dim + s * 2 + l];
+        const float cc0 = cv[s * 2], cc1 = cv[s * 2 + 1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float sc[QPB];
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) {
             float v = __fmaf_rn(-q[0][j], cc0, 0.f);
             v       = __fmaf_rn(-q[0][j], pqreg[sg][0][t], v);
             v       = __fmaf_rn(-q[1][j], cc1, v);
             sc[j]   = __fmaf_rn(-q[1][j], pqreg[sg][1][t], v);
           }
+          cm_lut<entry_t>::store(s, t * 64 + lane, acc_t::pack(sc));
+          __builtin_amdgcn_sched_barrier(0);
         }
-        cm_lut<entry_t>::store(s, t * 64 + lane, acc_t::pack(sc));  // pq_in_regs implies FAST4
       }
     }
   } else if (book >= 64 && !(a.dbg & 1)) {

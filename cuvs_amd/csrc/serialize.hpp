@@ -1,7 +1,8 @@
 // Index (de)serialization container shared by the four index types.
 // File = magic "CUVSAMD1", kind, version, then index-specific scalars and length-prefixed arrays.
-// This is this library's own format (round-trips every index exactly); reading/writing the reference's
-// numpy-header mdspan format (ivf_pq_serialize.cuh:40-85, ivf_list.cuh:108-190) is not built.
+// This is this library's own format (raw device layout, round-trips every index exactly); it is written only
+// when CUVS_AMD_NATIVE_FORMAT=1. The default is the reference's numpy-record format (npy_io.hpp);
+// *Deserialize recognises both by the magic.
 #pragma once
 #include "common.hpp"
 
