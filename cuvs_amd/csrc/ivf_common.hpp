@@ -53,6 +53,17 @@ __global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const u
   }
 }
 
+// Two-phase schedule of the list scans: the `head` nearest probes of every query keep their list id as label, the
+// others move to n_lists + list, so that one grouping yields [head items | tail items]. The head phase runs first
+// and leaves a per-query k-th bound that is already close to final - which is what makes the early stop of the
+// tail phase bite. Results do not depend on the order in which pairs are scanned.
+__global__ void phase_labels_kernel(const uint32_t* __restrict__ probes, int64_t n_pairs, uint32_t n_probes,
+                                    uint32_t head, uint32_t n_lists, uint32_t* __restrict__ out)
+{
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x)
+    out[p] = probes[p] + ((uint32_t)(p % n_probes) < head ? 0u : n_lists);
+}
+
 // ------------------------------------------------------------------ register-resident sorted top list (one wave)
 // rank r lives in lane r % 64, slot r / 64; sorted ascending by (distance, row).
 template <int E>

@@ -43,9 +43,12 @@ struct ivf_flat_index {
 
 namespace {
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 constexpr int kFlatThreads = 512;
 constexpr int kFlatWaves   = kFlatThreads / 64;
 constexpr int kFlatQPB     = 8;
+constexpr int kStopEvery   = 4;  // early-stop test every 4 chunks of 16 bytes (power of two)
 
 __global__ void strided_ids_kernel2(uint32_t* ids, int64_t n, int64_t stride)
 {
@@ -109,7 +112,9 @@ __global__ void relocate_flat_lists_kernel(const uint8_t* __restrict__ old_data,
 
 struct flat_scan_args {
   const work_item* items;
-  const uint32_t* n_items;
+  const uint32_t* item_begin;  // device scalars: this launch covers items [*item_begin, *item_end); nullptr: from 0
+  const uint32_t* item_end;
+  uint32_t n_lists;            // item.list >= n_lists: tail-phase label of list item.list - n_lists
   const uint32_t* sorted_pairs;
   const void* queries;  // [n_queries, dim] of T (raw values)
   const uint8_t* data;
@@ -124,14 +129,17 @@ struct flat_scan_args {
   int is_ip;
 };
 
-template <typename T, int E>
+// IP (inner product) is a template argument: tested at run time inside the unrolled element loop it became a
+// scalar branch per element
+template <typename T, int E, bool IP>
 __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_args a)
 {
   constexpr int QPB = kFlatQPB;
   constexpr int VL  = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t w = blockIdx.x;
-  if (w >= *a.n_items) return;
+  const uint32_t item0 = a.item_begin ? *a.item_begin : 0u;
+  const uint32_t w     = item0 + blockIdx.x;
+  if (w >= *a.item_end) return;
   const work_item item = a.items[w];
 
   const uint32_t dim_pad = a.n_chunks * VL;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const uint32_t L        = item.list;
+  const uint32_t L        = item.list >= a.n_lists ? item.list - a.n_lists : item.list;
   const uint32_t base_row = a.list_offsets[L];
   const uint32_t len      = a.list_sizes[L];
 
@@ -181,11 +189,28 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     const uint32_t tile0 = tile * 64;
     const uint32_t v     = tile0 + lane;
     const bool valid     = v < len;
-    float acc[QPB];
+    // two queries per packed fp32 instruction (v_pk_add_f32 / v_pk_fma_f32): lane by lane the IEEE operations of
+    // the scalar form; (q - x)^2 == (x - q)^2 exactly
+    f32x2_t accv[QPB / 2];
 #pragma unroll
-    for (int j = 0; j < QPB; ++j) acc[j] = 0.f;
+    for (int j = 0; j < QPB / 2; ++j) accv[j] = f32x2_t{0.f, 0.f};
     const uint4* cp = data16 + ((g0 + tile) * a.n_chunks) * 64 + lane;
+    // early stop (L2): partial sums of squares only grow, so once every row of the tile is above the k-th bound of
+    // every query of the item the rest of the row data is neither loaded nor accumulated. Bounds are read once
+    // per tile and only decrease: rows dropped here are also rejected by the filter below.
+    float bf[QPB];
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) {
+      const uint32_t kk = __builtin_amdgcn_readfirstlane(kthb[j]);
+      bf[j] = (IP || j >= (int)item.count) ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
+    }
     for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+      if (!IP && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
+        bool below = false;
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) below = below || (accv[j >> 1][j & 1] <= bf[j]);
+        if (__ballot(valid && below) == 0ull) break;  // wave-uniform
+      }
       const uint4 cw = cp[(size_t)ch * 64];  // padded rows of a group are zero-filled: always readable
       const T* el    = reinterpret_cast<const T*>(&cw);
 #pragma unroll
@@ -193,23 +218,26 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
         const float x   = to_float(el[e]);
         const float4 qa = qs4[(ch * VL + e) * 2];
         const float4 qb = qs4[(ch * VL + e) * 2 + 1];
-        const float qv[QPB] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        if (!a.is_ip) {
+        const f32x2_t qv[QPB / 2] = {f32x2_t{qa.x, qa.y}, f32x2_t{qa.z, qa.w}, f32x2_t{qb.x, qb.y}, f32x2_t{qb.z, qb.w}};
+        const f32x2_t xx = f32x2_t{x, x};
 #pragma unroll
-          for (int j = 0; j < QPB; ++j) {
-            float t = x - qv[j];
-            acc[j]  = __fmaf_rn(t, t, acc[j]);
+        for (int j = 0; j < QPB / 2; ++j) {
+          if (!IP) {
+            const f32x2_t t = qv[j] - xx;
+            accv[j]         = __builtin_elementwise_fma(t, t, accv[j]);
+          } else {
+            accv[j] = __builtin_elementwise_fma(xx, qv[j], accv[j]);
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < QPB; ++j) acc[j] = __fmaf_rn(x, qv[j], acc[j]);
         }
       }
     }
+    float acc[QPB];
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) acc[j] = accv[j >> 1][j & 1];
 #pragma unroll
     for (int j = 0; j < QPB; ++j) {
       if (j >= (int)item.count) break;
-      const float dj       = a.is_ip ? -acc[j] : acc[j];  // smaller is better
+      const float dj       = IP ? -acc[j] : acc[j];  // smaller is better
       const uint32_t bound = kthb[j];
       unsigned long long m = __ballot(valid && float_to_key(dj) <= bound);
       if (m == 0ull) continue;
@@ -318,17 +346,23 @@ __global__ void unpack_flat_list_kernel(const uint8_t* __restrict__ data, uint32
   for (uint32_t b = 0; b < esz; ++b) out[i * esz + b] = data[addr + b];
 }
 
+template <typename T, int E, bool IP>
+void launch_flat_scan_kern(resources& res, const flat_scan_args& a, size_t smem, unsigned grid)
+{
+  auto kern = ivf_flat_scan_kernel<T, E, IP>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatThreads), smem, res.stream, a);
+}
+
 template <typename T>
 void launch_flat_scan(resources& res, const flat_scan_args& a, size_t smem, unsigned grid, bool big_k)
 {
   if (big_k) {
-    auto kern = ivf_flat_scan_kernel<T, 4>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatThreads), smem, res.stream, a);
+    if (a.is_ip) launch_flat_scan_kern<T, 4, true>(res, a, smem, grid);
+    else         launch_flat_scan_kern<T, 4, false>(res, a, smem, grid);
   } else {
-    auto kern = ivf_flat_scan_kernel<T, 1>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatThreads), smem, res.stream, a);
+    if (a.is_ip) launch_flat_scan_kern<T, 1, true>(res, a, smem, grid);
+    else         launch_flat_scan_kern<T, 1, false>(res, a, smem, grid);
   }
   HIP_TRY(hipGetLastError());
 }
@@ -505,9 +539,14 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   const int64_t bs = std::min<int64_t>(max_batch, n_queries);
   const int64_t np_max = bs * n_probes;
   dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
-  dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, idx.n_lists + 1),
-    item_off(res, idx.n_lists + 1), cand_i(res, (size_t)np_max * k), top_i(res, (size_t)bs * k), query_kth(res, bs);
-  dev_buf<work_item> items(res, (size_t)(np_max / qpb + idx.n_lists + 1));
+  // two-phase schedule (ivf_common.hpp): nearest probe of every query first
+  uint32_t head = (n_probes > 8 && idx.metric != M_InnerProduct) ? 1u : 0u;
+  if (const char* e = getenv("CUVS_AMD_FLAT_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
+  const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
+  dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, n_labels + 1),
+    item_off(res, n_labels + 1), cand_i(res, (size_t)np_max * k), top_i(res, (size_t)bs * k), query_kth(res, bs);
+  dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)np_max : 0);
+  dev_buf<work_item> items(res, (size_t)(np_max / qpb + n_labels + 1));
   dev_buf<float> cand_d(res, (size_t)np_max * k), top_d(res, (size_t)bs * k);
   const size_t esz = elem_size(et);
 
@@ -529,25 +568,42 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
                                    probes.data(), true);
     }
-    build_work_items(res, probes.data(), n_pairs, idx.n_lists, qpb, sorted_pairs.data(), pair_off.data(),
-                     item_off.data(), items.data());
+    const uint32_t* labels = probes.data();
+    if (head > 0) {
+      hipLaunchKernelGGL(phase_labels_kernel, dim3(grid_blocks(n_pairs, 256)), dim3(256), 0, res.stream, probes.data(),
+                         n_pairs, n_probes, head, idx.n_lists, phase_labels.data());
+      labels = phase_labels.data();
+    }
+    build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
+                     items.data());
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     flat_scan_args a;
-    a.items = items.data(); a.n_items = item_off.data() + idx.n_lists; a.sorted_pairs = sorted_pairs.data();
+    a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
     a.queries = qptr; a.data = idx.data.data(); a.list_offsets = idx.list_offsets.data();
     a.list_sizes = idx.list_sizes.data(); a.out_d = cand_d.data(); a.out_i = cand_i.data();
     a.filter_bits = filter_bits; a.indices = idx.indices.data();
     a.query_kth = query_kth.data(); a.n_probes = n_probes; a.dim = idx.dim; a.veclen = idx.veclen;
     a.n_chunks = idx.n_chunks; a.k = (uint32_t)k; a.is_ip = idx.metric == M_InnerProduct;
-    const unsigned grid = (unsigned)(n_pairs / qpb + idx.n_lists + 1);
-    profile_begin(res, "ivf_flat_scan_kernel");
-    switch (et) {
-      case elem_t::f32: launch_flat_scan<float>(res, a, smem, grid, big_k); break;
-      case elem_t::f16: launch_flat_scan<__half>(res, a, smem, grid, big_k); break;
-      case elem_t::i8: launch_flat_scan<int8_t>(res, a, smem, grid, big_k); break;
-      case elem_t::u8: launch_flat_scan<uint8_t>(res, a, smem, grid, big_k); break;
+    auto launch = [&](const flat_scan_args& fa, unsigned grid) {
+      profile_begin(res, "ivf_flat_scan_kernel");
+      switch (et) {
+        case elem_t::f32: launch_flat_scan<float>(res, fa, smem, grid, big_k); break;
+        case elem_t::f16: launch_flat_scan<__half>(res, fa, smem, grid, big_k); break;
+        case elem_t::i8: launch_flat_scan<int8_t>(res, fa, smem, grid, big_k); break;
+        case elem_t::u8: launch_flat_scan<uint8_t>(res, fa, smem, grid, big_k); break;
+      }
+      profile_end(res, "ivf_flat_scan_kernel");
+    };
+    // grids are upper bounds of the (device-side) item counts of each phase; surplus workgroups exit at once
+    if (head > 0) {
+      a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
+      launch(a, (unsigned)(nq * head / qpb + idx.n_lists + 1));
+      a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
+      launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
+    } else {
+      a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
+      launch(a, (unsigned)(n_pairs / qpb + idx.n_lists + 1));
     }
-    profile_end(res, "ivf_flat_scan_kernel");
     select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
                                  k, top_d.data(), top_i.data(), true);
     hipLaunchKernelGGL(flat_postprocess_kernel, dim3(grid_blocks(nq * k, 256)), dim3(256), 0, res.stream, top_i.data(),

@@ -753,14 +753,6 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
 }
 
 // flat row -> source id; distance fix-ups (ivf_common.cuh:114-171 postprocess_neighbors, :176-253)
-// label of pair p for the two-phase schedule: head probes keep their list id, the others move to n_lists + list
-__global__ void phase_labels_kernel(const uint32_t* __restrict__ probes, int64_t n_pairs, uint32_t n_probes,
-                                    uint32_t head, uint32_t n_lists, uint32_t* __restrict__ out)
-{
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x)
-    out[p] = probes[p] + ((uint32_t)(p % n_probes) < head ? 0u : n_lists);
-}
-
 __global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float* __restrict__ d_in, int64_t n,
                                    const int64_t* __restrict__ indices, int metric, float scale2,
                                    int64_t* __restrict__ neighbors, float* __restrict__ distances)
