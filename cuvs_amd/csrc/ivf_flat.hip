@@ -117,6 +117,7 @@ struct flat_scan_args {
   uint32_t n_lists;            // item.list >= n_lists: tail-phase label of list item.list - n_lists
   const uint32_t* sorted_pairs;
   const void* queries;  // [n_queries, dim] of T (raw values)
+  const float* qtiles;  // [n_items, dim_pad, QPB] fp32 query tile of every work item (flat_query_tiles_kernel)
   const uint8_t* data;
   const uint32_t* list_offsets;
   const uint32_t* list_sizes;
@@ -128,6 +129,32 @@ struct flat_scan_args {
   uint32_t n_probes, dim, veclen, n_chunks, k;
   int is_ip;
 };
+
+// Query tile of every work item, [dim_pad][QPB] fp32 in HBM. The scan kernel reads it with wave-uniform addresses,
+// i.e. through the scalar cache into SGPRs: the 32 bytes of query values an element step needs then cost no LDS
+// cycles at all (as LDS broadcast reads they occupied the LDS pipe exactly as long as the 8 packed VALU
+// instructions of the step occupy a SIMD, and the two could never fully overlap).
+template <typename T>
+__global__ void flat_query_tiles_kernel(const work_item* __restrict__ items, const uint32_t* __restrict__ n_items,
+                                        const uint32_t* __restrict__ sorted_pairs, const T* __restrict__ queries,
+                                        uint32_t n_probes, uint32_t dim, uint32_t dim_pad, float* __restrict__ tiles)
+{
+  constexpr int QPB = kFlatQPB;
+  const uint32_t w = blockIdx.x;
+  if (w >= *n_items) return;
+  const work_item item = items[w];
+  __shared__ uint32_t qid[QPB];
+  if (threadIdx.x < QPB)
+    qid[threadIdx.x] = threadIdx.x < item.count ? sorted_pairs[item.first + threadIdx.x] / n_probes : 0xffffffffu;
+  __syncthreads();
+  float* out = tiles + (size_t)w * dim_pad * QPB;
+  for (uint32_t t = threadIdx.x; t < dim_pad * QPB; t += blockDim.x) {
+    const uint32_t d = t / QPB, j = t % QPB;
+    float v = 0.f;
+    if (qid[j] != 0xffffffffu && d < dim) v = to_float(queries[(size_t)qid[j] * dim + d]);
+    out[t] = v;
+  }
+}
 
 // IP (inner product) is a template argument: tested at run time inside the unrolled element loop it became a
 // scalar branch per element
@@ -143,12 +170,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
   const work_item item = a.items[w];
 
   const uint32_t dim_pad = a.n_chunks * VL;
-  size_t off             = (size_t)dim_pad * QPB * 4;
-  {
-    size_t mg = (size_t)QPB * kFlatWaves * a.k * 8;
-    if (mg > off) off = (mg + 15) & ~size_t(15);
-  }
-  float* qs      = reinterpret_cast<float*>(smem);  // [dim_pad][QPB]
+  const size_t off = (((size_t)QPB * kFlatWaves * a.k * 8) + 15) & ~size_t(15);  // merge area
   uint32_t* kthb = reinterpret_cast<uint32_t*>(smem + off);
   uint32_t* pid  = kthb + 16;
 
@@ -165,16 +187,8 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     kthb[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
   }
   __syncthreads();
-  for (uint32_t t = tid; t < dim_pad * QPB; t += kFlatThreads) {
-    uint32_t d = t / QPB, j = t % QPB;
-    float v = 0.f;
-    if (j < item.count && d < a.dim) {
-      uint32_t q = pid[j] / a.n_probes;
-      v          = to_float(static_cast<const T*>(a.queries)[(size_t)q * a.dim + d]);
-    }
-    qs[t] = v;
-  }
-  __syncthreads();
+  // wave-uniform pointer: the loads below become s_load_dwordx8 (scalar cache -> SGPRs)
+  const float* __restrict__ qt = a.qtiles + (size_t)w * dim_pad * QPB;
 
   wave_top<E> top[QPB];
 #pragma unroll
@@ -182,7 +196,6 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
   const int kr          = (int)a.k - 1;
   const size_t g0       = (size_t)(base_row >> 6);
   const uint4* data16   = reinterpret_cast<const uint4*>(a.data);
-  const float4* qs4     = reinterpret_cast<const float4*>(qs);
   const uint32_t n_tile = (len + 63) / 64;
 
   for (uint32_t tile = wave; tile < n_tile; tile += kFlatWaves) {
@@ -216,9 +229,8 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
 #pragma unroll
       for (int e = 0; e < VL; ++e) {
         const float x   = to_float(el[e]);
-        const float4 qa = qs4[(ch * VL + e) * 2];
-        const float4 qb = qs4[(ch * VL + e) * 2 + 1];
-        const f32x2_t qv[QPB / 2] = {f32x2_t{qa.x, qa.y}, f32x2_t{qa.z, qa.w}, f32x2_t{qb.x, qb.y}, f32x2_t{qb.z, qb.w}};
+        const float* qr = qt + (size_t)(ch * VL + e) * QPB;
+        const f32x2_t qv[QPB / 2] = {f32x2_t{qr[0], qr[1]}, f32x2_t{qr[2], qr[3]}, f32x2_t{qr[4], qr[5]}, f32x2_t{qr[6], qr[7]}};
         const f32x2_t xx = f32x2_t{x, x};
 #pragma unroll
         for (int j = 0; j < QPB / 2; ++j) {
@@ -528,12 +540,12 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   const int qpb           = kFlatQPB;
   const bool big_k        = k > 64;
   const uint32_t dim_pad  = idx.n_chunks * idx.veclen;
-  size_t smem = std::max<size_t>((size_t)dim_pad * qpb * 4, (((size_t)qpb * kFlatWaves * k * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;
-  CUVS_EXPECTS(smem <= 160 * 1024, "ivf_flat::search: dim %u too large for the LDS query tile", idx.dim);
+  size_t smem = ((((size_t)qpb * kFlatWaves * k * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;
 
   int64_t max_batch = 1 << 15;
   {
-    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k * 8 + idx.dim * 4;
+    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k * 8 + idx.dim * 4 +
+                    ((int64_t)n_probes / qpb + 1) * dim_pad * qpb * 4;  // + the query tiles of its work items
     max_batch     = std::min(max_batch, std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q));
   }
   const int64_t bs = std::min<int64_t>(max_batch, n_queries);
@@ -546,7 +558,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, n_labels + 1),
     item_off(res, n_labels + 1), cand_i(res, (size_t)np_max * k), top_i(res, (size_t)bs * k), query_kth(res, bs);
   dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)np_max : 0);
-  dev_buf<work_item> items(res, (size_t)(np_max / qpb + n_labels + 1));
+  const size_t max_items = (size_t)(np_max / qpb + n_labels + 1);
+  dev_buf<work_item> items(res, max_items);
+  dev_buf<float> qtiles(res, max_items * dim_pad * qpb);
   dev_buf<float> cand_d(res, (size_t)np_max * k), top_d(res, (size_t)bs * k);
   const size_t esz = elem_size(et);
 
@@ -579,6 +593,17 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     flat_scan_args a;
     a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
+    {
+      const uint32_t* n_all = item_off.data() + n_labels;
+      const unsigned g      = (unsigned)(n_pairs / qpb + n_labels + 1);
+      switch (et) {
+        case elem_t::f32: hipLaunchKernelGGL(flat_query_tiles_kernel<float>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const float*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
+        case elem_t::f16: hipLaunchKernelGGL(flat_query_tiles_kernel<__half>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const __half*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
+        case elem_t::i8: hipLaunchKernelGGL(flat_query_tiles_kernel<int8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const int8_t*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
+        case elem_t::u8: hipLaunchKernelGGL(flat_query_tiles_kernel<uint8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const uint8_t*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
+      }
+      a.qtiles = qtiles.data();
+    }
     a.queries = qptr; a.data = idx.data.data(); a.list_offsets = idx.list_offsets.data();
     a.list_sizes = idx.list_sizes.data(); a.out_d = cand_d.data(); a.out_i = cand_i.data();
     a.filter_bits = filter_bits; a.indices = idx.indices.data();
