@@ -438,6 +438,225 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
   }
 }
 
+// ------------------------------------------------------------------ multi-wave search (small batches)
+// The reference's MULTI_CTA mode (search_multi_cta_jit.cuh:33-365) gives every query several CTAs, each with its
+// own 32-entry top list and ONE parent per iteration, which claim parents through a per-query "traversed" hash
+// table in global memory; a final top-k merges the CTAs' lists. Here the unit is a wave: one workgroup per
+// query, W waves, each wave runs the reference's per-CTA loop on its own LDS slice, and the traversed table
+// lives in LDS (waves of one workgroup share it, so no global table and no extra merge kernel). Waves do not
+// synchronise inside the walk; as in the reference the claim order is a race, so results are equal in quality
+// (recall tests) but not bit-reproducible.
+constexpr uint32_t kMwTopk = 32;  // per-wave top list (the reference's multi_cta_itopk_size)
+
+struct mw_args {
+  search_args s;
+  uint32_t n_waves, np2_local, vis_bits, trav_bits, merge_np2;
+};
+
+// hash table with removal (hashmap.hpp:37-134 SUPPORT_REMOVE semantics): a removed key leaves key|MSB behind
+__device__ inline bool trav_insert(uint32_t* table, uint32_t bits, uint32_t key)
+{
+  const uint32_t mask = (1u << bits) - 1u, removed = key | kParentFlag;
+  uint32_t pos = hash_slot(key, bits);
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    uint32_t old = atomicCAS(&table[pos], kInvalidNode, key);
+    if (old == kInvalidNode) return true;
+    if (old == key) return false;
+    old = atomicCAS(&table[pos], removed, key);
+    if (old == removed) return true;
+    if (old == key) return false;
+    pos = (pos + 1) & mask;
+  }
+  return false;
+}
+__device__ inline bool trav_contains(const uint32_t* table, uint32_t bits, uint32_t key)
+{
+  const uint32_t mask = (1u << bits) - 1u, removed = key | kParentFlag;
+  uint32_t pos = hash_slot(key, bits);
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    const uint32_t v = table[pos];
+    if (v == key) return true;
+    if (v == kInvalidNode || v == removed) return false;
+    pos = (pos + 1) & mask;
+  }
+  return false;
+}
+__device__ inline void trav_remove(uint32_t* table, uint32_t bits, uint32_t key)
+{
+  const uint32_t mask = (1u << bits) - 1u;
+  uint32_t pos = hash_slot(key, bits);
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    const uint32_t old = atomicCAS(&table[pos], key, key | kParentFlag);
+    if (old == key || old == kInvalidNode) return;
+    pos = (pos + 1) & mask;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
+{
+  const search_args& a = m.s;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane   = threadIdx.x & 63;
+  const int wave   = threadIdx.x >> 6;
+  const int64_t qi = blockIdx.x;
+  const uint32_t W = m.n_waves, np2 = m.np2_local, vsize = 1u << m.vis_bits, tsize = 1u << m.trav_bits;
+  float* qf        = reinterpret_cast<float*>(smem);
+  uint32_t* trav   = reinterpret_cast<uint32_t*>(qf + ((a.dim + 3) & ~int64_t(3)));
+  uint32_t* mkeys  = trav + tsize;             // merge area [merge_np2]
+  uint32_t* midx   = mkeys + m.merge_np2;
+  uint32_t* wbase  = midx + m.merge_np2 + (size_t)wave * (2 * np2 + vsize);
+  uint32_t* keys   = wbase;                    // this wave's list: [np2] = 32 top + degree candidates
+  uint32_t* idx    = keys + np2;
+  uint32_t* vis    = idx + np2;                // this wave's visited table (rebuilt every iteration)
+  const T* data    = static_cast<const T*>(a.data);
+
+  for (int64_t d = threadIdx.x; d < a.dim; d += blockDim.x) qf[d] = to_float(static_cast<const T*>(a.queries)[qi * a.dim + d]);
+  for (uint32_t i = threadIdx.x; i < tsize; i += blockDim.x) trav[i] = kInvalidNode;
+  for (uint32_t i = lane; i < np2; i += 64) { keys[i] = 0xffffffffu; idx[i] = kInvalidNode; }
+  for (uint32_t i = lane; i < vsize; i += 64) vis[i] = kInvalidNode;
+  __syncthreads();
+
+  // ---- seeds: 32 pseudo-random nodes per wave, a different stream per (query, wave) (device_common_jit.cuh:72)
+  if (lane < (int)kMwTopk) {
+    const uint64_t gid  = ((uint64_t)qi * W + wave) * kMwTopk + lane;
+    const uint32_t node = (uint32_t)(xorshift64(gid ^ a.rand_xor_mask) % (uint64_t)a.n);
+    idx[lane]           = hash_insert(vis, m.vis_bits, node) ? node : kInvalidNode;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  team_distances<T>(data, a.dim, qf, keys, idx, 0, kMwTopk, a.is_ip, lane);
+
+  uint32_t iter = 0;
+  while (true) {
+    wave_bitonic_sort<uint32_t>(keys, idx, (int)np2);
+    if (iter + 1 >= a.max_iter) break;
+    // ---- next parent (pickup_next_parent, search_multi_cta_helpers.cuh:16-80): the best entry of the first 64
+    // that is not a parent yet and that THIS wave manages to claim in the traversed table; entries claimed by
+    // another wave are dropped from this list
+    uint32_t parent = kInvalidNode;
+    {
+      const uint32_t e   = lane < (int)np2 ? idx[lane] : kInvalidNode;
+      unsigned long long c = __ballot(e != kInvalidNode && !(e & kParentFlag));
+      int chosen = -1;
+      while (c != 0ull) {
+        const int src = (int)__ffsll((long long)c) - 1;
+        c &= c - 1ull;
+        const uint32_t node = __builtin_amdgcn_readlane(e, src);
+        bool mine = false;
+        if (lane == 0) mine = trav_insert(trav, m.trav_bits, node);
+        mine = __builtin_amdgcn_readfirstlane((int)mine) != 0;
+        if (mine) { chosen = src; parent = node; break; }
+        if (lane == 0) { idx[src] = kInvalidNode; keys[src] = 0xffffffffu; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (chosen >= 0) {
+        if (chosen < (int)kMwTopk) {
+          if (lane == 0) idx[chosen] = parent | kParentFlag;
+        } else {
+          // parent found in the overflow half: move it into the last free slot of the top half, if any
+          const uint32_t t     = lane < (int)kMwTopk ? idx[lane] : 0u;
+          unsigned long long f = __ballot(lane < (int)kMwTopk && t == kInvalidNode);
+          if (f == 0ull) {
+            if (lane == 0) trav_remove(trav, m.trav_bits, parent);
+            parent = kInvalidNode;
+          } else if (lane == 0) {
+            const int j = 63 - __builtin_clzll(f);
+            idx[j] = parent | kParentFlag; keys[j] = keys[chosen];
+            idx[chosen] = kInvalidNode;    keys[chosen] = 0xffffffffu;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (parent == kInvalidNode && iter >= a.min_iter) break;
+    // ---- rebuild the visited table from the list; parents pushed out of the top half are released
+    for (uint32_t i = lane; i < vsize; i += 64) vis[i] = kInvalidNode;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < np2; i += 64) {
+      const uint32_t e = idx[i];
+      if (e == kInvalidNode) continue;
+      if (i >= kMwTopk && (e & kParentFlag)) {
+        trav_remove(trav, m.trav_bits, e & ~kParentFlag);
+        idx[i] = kInvalidNode; keys[i] = 0xffffffffu;
+      } else {
+        hash_insert(vis, m.vis_bits, e & ~kParentFlag);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- children of the parent -> candidate region
+    for (uint32_t c = lane; c < np2 - kMwTopk; c += 64) {
+      uint32_t child = kInvalidNode;
+      if (parent != kInvalidNode && c < a.degree) {
+        child = a.graph[(int64_t)parent * a.degree + c];
+        if (child >= a.n || !hash_insert(vis, m.vis_bits, child)) child = kInvalidNode;
+      }
+      idx[kMwTopk + c]  = child;
+      keys[kMwTopk + c] = 0xffffffffu;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    team_distances<T>(data, a.dim, qf, keys, idx, kMwTopk, a.degree, a.is_ip, lane);
+    // ---- drop what another wave has expanded meanwhile; a parent that fails the filter leaves the list
+    for (uint32_t i = lane; i < np2; i += 64) {
+      const uint32_t e = idx[i];
+      if (e == kInvalidNode) continue;
+      bool drop = false;
+      if (!(e & kParentFlag)) {
+        drop = trav_contains(trav, m.trav_bits, e);
+      } else if (a.filter_bits != nullptr && (e & ~kParentFlag) == parent) {
+        drop = !((a.filter_bits[parent >> 5] >> (parent & 31)) & 1u);
+      }
+      if (drop) { idx[i] = kInvalidNode; keys[i] = 0xffffffffu; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    ++iter;
+  }
+
+  // ---- this wave's 32 results: parents are unique by construction, the others must win the traversed table
+  // (duplicates across waves lose); filtered-out nodes are dropped
+  {
+    uint32_t e = lane < (int)kMwTopk ? idx[lane] : kInvalidNode;
+    uint32_t kk = lane < (int)kMwTopk ? keys[lane] : 0xffffffffu;
+    bool ok = e != kInvalidNode;
+    const uint32_t node = e & ~kParentFlag;
+    if (ok && a.filter_bits) ok = (a.filter_bits[node >> 5] >> (node & 31)) & 1u;
+    if (ok && !(e & kParentFlag)) ok = trav_insert(trav, m.trav_bits, node);
+    if (lane < (int)kMwTopk) {
+      mkeys[wave * kMwTopk + lane] = ok ? kk : 0xffffffffu;
+      midx[wave * kMwTopk + lane]  = ok ? node : kInvalidNode;
+    }
+  }
+  for (uint32_t i = W * kMwTopk + threadIdx.x; i < m.merge_np2; i += blockDim.x) { mkeys[i] = 0xffffffffu; midx[i] = kInvalidNode; }
+  __syncthreads();
+  if (wave != 0) return;
+  wave_bitonic_sort<uint32_t>(mkeys, midx, (int)m.merge_np2);
+  for (uint32_t r = lane; r < a.k; r += 64) {
+    const bool ok  = r < m.merge_np2 && midx[r] != kInvalidNode;
+    float d        = ok ? key_to_float(mkeys[r]) : FLT_MAX;
+    if (ok && a.is_ip) d = -d;
+    a.out_dist[qi * a.k + r] = d;
+    if (a.idx64) static_cast<int64_t*>(a.out_idx)[qi * a.k + r] = ok ? (int64_t)midx[r] : -1;
+    else         static_cast<uint32_t*>(a.out_idx)[qi * a.k + r] = ok ? midx[r] : kInvalidNode;
+  }
+}
+
+template <typename T>
+void launch_search_multi(resources& res, const mw_args& m, int64_t nq, size_t smem)
+{
+  auto kern = cagra_search_multi_kernel<T>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  profile_begin(res, "cagra_search_multi_kernel");
+  hipLaunchKernelGGL(kern, dim3((unsigned)nq), dim3(64 * m.n_waves), smem, res.stream, m);
+  profile_end(res, "cagra_search_multi_kernel");
+  HIP_TRY(hipGetLastError());
+}
+
 template <typename T>
 void launch_search(resources& res, const search_args& a, int64_t nq, size_t smem)
 {
@@ -487,6 +706,50 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   a.rand_xor_mask  = p.rand_xor_mask;
   a.is_ip          = idx.metric == M_InnerProduct;
   a.idx64          = idx64 ? 1 : 0;
+  // ---- algorithm choice. The reference's AUTO (search_plan.cuh:121-131) keeps one CTA per query once the batch
+  // alone fills the GPU. On MI355X the multi-wave walk measured faster at every batch size from 1 to 10k at equal
+  // recall (1M x 768 fp16, itopk 64, batch 10k: 18.9 vs 26.7 ms; batch 10: 0.68 vs 0.92 ms and recall 0.99 vs
+  // 0.63 because idle CUs run extra walkers), so AUTO takes it whenever its limits allow.
+  int algo = (int)p.algo;
+  if (algo == (int)AUTO)
+    algo = (itopk <= 16 * kMwTopk && idx.degree <= 224 && (size_t)k <= itopk) ? (int)MULTI_CTA : (int)SINGLE_CTA;
+  CUVS_EXPECTS(algo == (int)SINGLE_CTA || algo == (int)MULTI_CTA,
+               "cagra::search: algo must be SINGLE_CTA, MULTI_CTA or AUTO (MULTI_KERNEL is not built)");
+  if (algo == (int)MULTI_CTA && idx.degree <= 224) {
+    mw_args m;
+    m.s = a;
+    // waves per query: the reference's num_cta_per_query = max(search_width, itopk / 32) (search_multi_cta.cuh:124),
+    // raised while the launch would leave most of the GPU idle
+    uint32_t W = (uint32_t)std::max<size_t>(std::max<size_t>(p.search_width, 1), (itopk + kMwTopk - 1) / kMwTopk);
+    while (W < 16 && nq * (int64_t)W * 2 <= 4 * (int64_t)res.num_cus) W *= 2;
+    W = std::min<uint32_t>(W, 16);
+    CUVS_EXPECTS((uint32_t)k <= W * kMwTopk, "`num_cta_per_query` (%u) * 32 must be equal to or greater than `topk` (%d)", W, k);
+    m.n_waves   = W;
+    m.np2_local = (uint32_t)next_pow2((int)(kMwTopk + idx.degree));
+    m.vis_bits  = 8;
+    while ((1u << m.vis_bits) < 2 * (kMwTopk + idx.degree)) ++m.vis_bits;
+    // search_plan.cuh:199-215 with the multi-CTA list size
+    uint32_t mc_iter = (uint32_t)p.max_iterations;
+    if (mc_iter == 0) {
+      mc_iter       = kMwTopk;
+      int64_t reach = 1;
+      while (reach < idx.n) { reach *= std::max<int64_t>(2, idx.degree / 2); mc_iter += 1; }
+    }
+    m.s.max_iter = std::max(mc_iter, a.min_iter);
+    m.trav_bits  = 11;  // every wave claims <= max_iter parents and inserts <= 32 results; keep the fill <= 50 %
+    while ((1u << m.trav_bits) < 2 * W * (m.s.max_iter + kMwTopk)) ++m.trav_bits;
+    m.merge_np2 = (uint32_t)next_pow2((int)(W * kMwTopk));
+    size_t msmem = (size_t)((idx.dim + 3) & ~int64_t(3)) * 4 + ((size_t)4 << m.trav_bits) + (size_t)m.merge_np2 * 8 +
+                   (size_t)W * (2 * m.np2_local + (1u << m.vis_bits)) * 4;
+    CUVS_EXPECTS(msmem <= 160 * 1024, "cagra::search: dim too large for the multi-wave LDS layout");
+    switch (idx.dtype) {
+      case elem_t::f32: launch_search_multi<float>(res, m, nq, msmem); break;
+      case elem_t::f16: launch_search_multi<__half>(res, m, nq, msmem); break;
+      case elem_t::i8: launch_search_multi<int8_t>(res, m, nq, msmem); break;
+      case elem_t::u8: launch_search_multi<uint8_t>(res, m, nq, msmem); break;
+    }
+    return;
+  }
   size_t smem = (size_t)((idx.dim + 3) & ~int64_t(3)) * 4 + (size_t)a.np2 * 8 + ((size_t)4 << bits);
   CUVS_EXPECTS(smem <= 160 * 1024, "cagra::search: dim/itopk too large for LDS");
   switch (idx.dtype) {

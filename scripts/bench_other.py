@@ -64,7 +64,7 @@ if "cagra" in what:  # C4 scaled: N x 768 fp16, degree 64, itopk 64, batch 10k
     x = bench.gen_rows(n, 768, 1234, dev, latent=64, n_modes=1).half(); q = bench.gen_rows(10000, 768, 4321, dev, latent=64, n_modes=1).half()  # one broad mode: the kNN graph of well-separated tight modes is disconnected and no graph walk from random seeds can cross modes
     t0 = time.time(); idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res); res.sync()
     build_s = time.time() - t0
-    sp = cagra.SearchParams(itopk_size=64)
+    sp = cagra.SearchParams(itopk_size=64, algo=os.environ.get("CAGRA_ALGO", "auto"))
     nb = torch.empty((10000, 10), dtype=torch.int32, device=dev); dd = torch.empty((10000, 10), dtype=torch.float32, device=dev)
     dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res))
     bf = brute_force.build(x, resources=res); _, gt = brute_force.search(bf, q[:1000], 10, resources=res); res.sync()

@@ -92,12 +92,54 @@ def test_graph_invariants_and_int64_neighbors():
     assert all(len(np.unique(r)) == 24 for r in g[:200])      # no duplicate edges
     q = rng.standard_normal((50, 32)).astype(np.float32)
     nb = torch.empty((50, 10), dtype=torch.int64, device="cuda")
-    d, i = cagra.search(cagra.SearchParams(itopk_size=64), index, torch.from_numpy(q).cuda(), 10, neighbors=nb)
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64, algo="single_cta"), index, torch.from_numpy(q).cuda(), 10, neighbors=nb)
     torch.cuda.synchronize()
     _, ti = oracle.exact_knn(q, x, 10)
     assert oracle.recall(i.cpu().numpy(), ti) > 0.95
     # same index through cuvsCagraIndexFromArgs
     idx2 = cagra.from_graph(index.graph, torch.from_numpy(x).cuda())
-    d2, i2 = cagra.search(cagra.SearchParams(itopk_size=64), idx2, torch.from_numpy(q).cuda(), 10)
+    d2, i2 = cagra.search(cagra.SearchParams(itopk_size=64, algo="single_cta"), idx2, torch.from_numpy(q).cuda(), 10)
     torch.cuda.synchronize()
     assert ((i2.cpu().numpy().astype(np.int64) & 0xFFFFFFFF) == i.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("algo", ["multi_cta", "auto"])
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+def test_multi_wave_search_small_batch(algo, metric):
+    """MULTI_CTA (search_multi_cta_jit.cuh): several walkers per query sharing a traversed table. AUTO picks it for
+    batches that do not fill the GPU (search_plan.cuh:121-131). Not bit-reproducible (claim races), so checked the
+    way the reference checks it: recall against exact search, valid ids, sorted distances, no duplicates."""
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((20000, 64)).astype(np.float32)
+    q = rng.standard_normal((7, 64)).astype(np.float32)
+    index = _build(x, metric=metric, intermediate_graph_degree=64, graph_degree=32)
+    d, i = _search(index, q, 10, itopk_size=64, algo=algo)
+    td, ti = oracle.exact_knn(q, x, 10, metric=metric)
+    assert oracle.recall(i, ti) >= 0.9, oracle.recall(i, ti)
+    assert (i < 20000).all()
+    assert all(len(np.unique(r)) == 10 for r in i)
+    order = d if metric == "sqeuclidean" else -d
+    assert (np.diff(order, axis=1) >= 0).all()
+    # reported distances are the true distances of the reported ids
+    xd = x[i]
+    true = ((xd - q[:, None, :]) ** 2).sum(-1) if metric == "sqeuclidean" else (xd * q[:, None, :]).sum(-1)
+    np.testing.assert_allclose(d, true, rtol=1e-4, atol=1e-4)
+
+
+def test_multi_wave_search_filter_and_dtypes():
+    import torch
+    from cuvs_amd._lib import BITSET
+
+    rng = np.random.default_rng(12)
+    x = rng.integers(-20, 20, size=(8000, 48)).astype(np.int8)
+    q = rng.integers(-20, 20, size=(5, 48)).astype(np.int8)
+    index = _build(x, intermediate_graph_degree=64, graph_degree=32)
+    keep = np.zeros(8000, bool); keep[::2] = True
+    words = torch.from_numpy(np.packbits(keep, bitorder="little").view(np.int32)).cuda()
+    d, i = _search(index, q, 8, filter=(words, BITSET), itopk_size=128, algo="multi_cta")
+    assert (i % 2 == 0).all() and (i < 8000).all()
+    _, ti = oracle.exact_knn(q.astype(np.float32), x[::2].astype(np.float32), 8)
+    assert oracle.recall(i, ti * 2) >= 0.8
+    # k larger than one walker's list: needs several walkers (num_cta_per_query * 32 >= k)
+    d, i = _search(index, q, 40, itopk_size=64, algo="multi_cta")
+    assert all(len(np.unique(r)) == 40 for r in i)

@@ -58,7 +58,7 @@ def test_cagra_search_walk_matches_oracle(dtype, metric):
                         torch.from_numpy(x).cuda())
     graph = index.graph.cpu().numpy().view(np.uint32)
     for itopk, width in [(64, 1), (96, 2)]:
-        d, i = cagra.search(cagra.SearchParams(itopk_size=itopk, search_width=width), index, torch.from_numpy(q).cuda(), 10)
+        d, i = cagra.search(cagra.SearchParams(itopk_size=itopk, search_width=width, algo="single_cta"), index, torch.from_numpy(q).cuda(), 10)
         torch.cuda.synchronize()
         gi = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
         od, oi = oracle.cagra_search(x, graph, q, 10, itopk_size=itopk, search_width=width, metric=metric)

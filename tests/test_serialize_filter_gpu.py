@@ -42,7 +42,7 @@ def test_roundtrip_all_indexes(tmp_path):
 
     cg = cagra.build(cagra.IndexParams(intermediate_graph_degree=32, graph_degree=16), tx)
     f = str(tmp_path / "cagra.bin"); cagra.save(f, cg)
-    sp = cagra.SearchParams(itopk_size=64)
+    sp = cagra.SearchParams(itopk_size=64, algo="single_cta")  # the multi-wave walk is not bit-reproducible
     assert same(cagra.search(sp, cg, tq, 10), cagra.search(sp, cagra.load(f), tq, 10))
 
 
