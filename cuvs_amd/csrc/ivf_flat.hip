@@ -34,7 +34,8 @@ struct ivf_flat_index {
   uint32_t veclen = 4, n_chunks = 0;  // elements per 16-byte chunk; chunks per row
   int64_t size = 0, padded_rows = 0;
   dev_buf<float> centers;       // [n_lists, dim]
-  dev_buf<float> center_norms;  // [n_lists]
+  dev_buf<float> center_norms;  // [n_lists] canonical |c|^2
+  dev_buf<float> center_norms_sqrt;  // [n_lists] |c| (cosine only: the reference's center_norms for that metric)
   dev_buf<uint8_t> data;        // [padded_rows / 64, n_chunks, 64, 16 bytes]
   dev_buf<int64_t> indices;     // [padded_rows]
   dev_buf<uint32_t> list_sizes, list_offsets;
@@ -49,6 +50,19 @@ constexpr int kFlatThreads = 512;
 constexpr int kFlatWaves   = kFlatThreads / 64;
 constexpr int kFlatQPB     = 8;
 constexpr int kStopEvery   = 4;  // early-stop test every 4 chunks of 16 bytes (power of two)
+
+// cosine: rows are assigned to lists (and the lists trained) on unit-length copies
+__global__ void normalize_rows_kernel(float* x, int64_t n, int64_t dim)
+{
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int64_t d = lane; d < dim; d += 64) s = __fmaf_rn(x[r * dim + d], x[r * dim + d], s);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  const float inv = s > 0.f ? 1.0f / sqrtf(s) : 0.f;
+  for (int64_t d = lane; d < dim; d += 64) x[r * dim + d] *= inv;
+}
 
 __global__ void strided_ids_kernel2(uint32_t* ids, int64_t n, int64_t stride)
 {
@@ -127,7 +141,7 @@ struct flat_scan_args {
   const uint32_t* filter_bits;  // optional bitset over source ids (1 keeps), sample_filter.cuh semantics
   const int64_t* indices;       // flat row -> source id (only read when filtering)
   uint32_t n_probes, dim, veclen, n_chunks, k;
-  int is_ip;
+  int is_ip;  // 0: L2, 1: inner product, 2: cosine
 };
 
 // Query tile of every work item, [dim_pad][QPB] fp32 in HBM. The scan kernel reads it with wave-uniform addresses,
@@ -137,7 +151,8 @@ struct flat_scan_args {
 template <typename T>
 __global__ void flat_query_tiles_kernel(const work_item* __restrict__ items, const uint32_t* __restrict__ n_items,
                                         const uint32_t* __restrict__ sorted_pairs, const T* __restrict__ queries,
-                                        uint32_t n_probes, uint32_t dim, uint32_t dim_pad, float* __restrict__ tiles)
+                                        uint32_t n_probes, uint32_t dim, uint32_t dim_pad, int with_norms,
+                                        float* __restrict__ tiles)
 {
   constexpr int QPB = kFlatQPB;
   const uint32_t w = blockIdx.x;
@@ -147,22 +162,34 @@ __global__ void flat_query_tiles_kernel(const work_item* __restrict__ items, con
   if (threadIdx.x < QPB)
     qid[threadIdx.x] = threadIdx.x < item.count ? sorted_pairs[item.first + threadIdx.x] / n_probes : 0xffffffffu;
   __syncthreads();
-  float* out = tiles + (size_t)w * dim_pad * QPB;
+  float* out = tiles + (size_t)w * (dim_pad + 1) * QPB;  // rows 0..dim_pad-1: components; row dim_pad: |q| (cosine)
   for (uint32_t t = threadIdx.x; t < dim_pad * QPB; t += blockDim.x) {
     const uint32_t d = t / QPB, j = t % QPB;
     float v = 0.f;
     if (qid[j] != 0xffffffffu && d < dim) v = to_float(queries[(size_t)qid[j] * dim + d]);
     out[t] = v;
   }
+  if (threadIdx.x < QPB) {
+    // |q|: squares accumulated in dimension order with fma, like the row norms inside the scan
+    float n2 = 0.f;
+    if (with_norms && qid[threadIdx.x] != 0xffffffffu) {
+      for (uint32_t d = 0; d < dim; ++d) {
+        const float v = to_float(queries[(size_t)qid[threadIdx.x] * dim + d]);
+        n2            = __fmaf_rn(v, v, n2);
+      }
+    }
+    out[(size_t)dim_pad * QPB + threadIdx.x] = sqrtf(n2);
+  }
 }
 
 // IP (inner product) is a template argument: tested at run time inside the unrolled element loop it became a
 // scalar branch per element
-template <typename T, int E, bool IP>
+template <typename T, int E, int METRIC>  // 0: L2, 1: inner product, 2: cosine (inner product + row norms)
 __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_args a)
 {
   constexpr int QPB = kFlatQPB;
   constexpr int VL  = 16 / sizeof(T);
+  constexpr bool IP = METRIC != 0;  // scores that are dot products: no early stop, negated as sort keys
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t item0 = a.item_begin ? *a.item_begin : 0u;
   const uint32_t w     = item0 + blockIdx.x;
@@ -188,7 +215,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
   }
   __syncthreads();
   // wave-uniform pointer: the loads below become s_load_dwordx8 (scalar cache -> SGPRs)
-  const float* __restrict__ qt = a.qtiles + (size_t)w * dim_pad * QPB;
+  const float* __restrict__ qt = a.qtiles + (size_t)w * (dim_pad + 1) * QPB;
 
   wave_top<E> top[QPB];
 #pragma unroll
@@ -207,6 +234,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     f32x2_t accv[QPB / 2];
 #pragma unroll
     for (int j = 0; j < QPB / 2; ++j) accv[j] = f32x2_t{0.f, 0.f};
+    float xn2 = 0.f;  // cosine: |x|^2 of this lane's row, accumulated next to the dot products (metric_impl.cuh)
     const uint4* cp = data16 + ((g0 + tile) * a.n_chunks) * 64 + lane;
     // early stop (L2): partial sums of squares only grow, so once every row of the tile is above the k-th bound of
     // every query of the item the rest of the row data is neither loaded nor accumulated. Bounds are read once
@@ -232,6 +260,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
         const float* qr = qt + (size_t)(ch * VL + e) * QPB;
         const f32x2_t qv[QPB / 2] = {f32x2_t{qr[0], qr[1]}, f32x2_t{qr[2], qr[3]}, f32x2_t{qr[4], qr[5]}, f32x2_t{qr[6], qr[7]}};
         const f32x2_t xx = f32x2_t{x, x};
+        if (METRIC == 2) xn2 = __fmaf_rn(x, x, xn2);
 #pragma unroll
         for (int j = 0; j < QPB / 2; ++j) {
           if (!IP) {
@@ -246,6 +275,12 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     float acc[QPB];
 #pragma unroll
     for (int j = 0; j < QPB; ++j) acc[j] = accv[j >> 1][j & 1];
+    if (METRIC == 2) {
+      // cos = dot / (|q| * |x|); reported later as 1 - cos (post_process_compose)
+      const float xn = sqrtf(xn2);
+#pragma unroll
+      for (int j = 0; j < QPB; ++j) acc[j] = acc[j] / (qt[(size_t)dim_pad * QPB + j] * xn);
+    }
 #pragma unroll
     for (int j = 0; j < QPB; ++j) {
       if (j >= (int)item.count) break;
@@ -341,6 +376,7 @@ __global__ void flat_postprocess_kernel(const uint32_t* __restrict__ pos, const 
   float d      = d_in[i];
   if (p == 0xffffffffu) d = FLT_MAX;
   else if (metric == M_InnerProduct) d = -d;
+  else if (metric == M_CosineExpanded) d = 1.0f + d;  // d = -cos
   else if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d);
   distances[i] = d;
 }
@@ -358,10 +394,10 @@ __global__ void unpack_flat_list_kernel(const uint8_t* __restrict__ data, uint32
   for (uint32_t b = 0; b < esz; ++b) out[i * esz + b] = data[addr + b];
 }
 
-template <typename T, int E, bool IP>
+template <typename T, int E, int METRIC>
 void launch_flat_scan_kern(resources& res, const flat_scan_args& a, size_t smem, unsigned grid)
 {
-  auto kern = ivf_flat_scan_kernel<T, E, IP>;
+  auto kern = ivf_flat_scan_kernel<T, E, METRIC>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatThreads), smem, res.stream, a);
 }
@@ -370,11 +406,13 @@ template <typename T>
 void launch_flat_scan(resources& res, const flat_scan_args& a, size_t smem, unsigned grid, bool big_k)
 {
   if (big_k) {
-    if (a.is_ip) launch_flat_scan_kern<T, 4, true>(res, a, smem, grid);
-    else         launch_flat_scan_kern<T, 4, false>(res, a, smem, grid);
+    if (a.is_ip == 2)      launch_flat_scan_kern<T, 4, 2>(res, a, smem, grid);
+    else if (a.is_ip == 1) launch_flat_scan_kern<T, 4, 1>(res, a, smem, grid);
+    else                   launch_flat_scan_kern<T, 4, 0>(res, a, smem, grid);
   } else {
-    if (a.is_ip) launch_flat_scan_kern<T, 1, true>(res, a, smem, grid);
-    else         launch_flat_scan_kern<T, 1, false>(res, a, smem, grid);
+    if (a.is_ip == 2)      launch_flat_scan_kern<T, 1, 2>(res, a, smem, grid);
+    else if (a.is_ip == 1) launch_flat_scan_kern<T, 1, 1>(res, a, smem, grid);
+    else                   launch_flat_scan_kern<T, 1, 0>(res, a, smem, grid);
   }
   HIP_TRY(hipGetLastError());
 }
@@ -412,6 +450,8 @@ void ivf_flat_extend(resources& res, ivf_flat_index& idx, const void* data, elem
     for (int64_t r0 = 0; r0 < n_new; r0 += batch_rows) {
       int64_t cnt = std::min(batch_rows, n_new - r0);
       load_range_as_float(res, data, et, is_host, dim, r0, cnt, xb.data());
+      if (idx.metric == M_CosineExpanded)
+        hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid_blocks(cnt, 4)), dim3(256), 0, res.stream, xb.data(), cnt, dim);
       fused_l2_argmin<float>(res, xb.data(), cnt, dim, idx.centers.data(), idx.n_lists, dim, idx.center_norms.data(),
                              labels.data() + r0, nullptr);
     }
@@ -486,14 +526,25 @@ void ivf_flat_extend(resources& res, ivf_flat_index& idx, const void* data, elem
   idx.padded_rows = total;
 }
 
+static void flat_set_center_norms(resources& res, ivf_flat_index& idx)
+{
+  idx.center_norms = dev_buf<float>::persistent(idx.n_lists);
+  row_norms<float>(res, idx.centers.data(), idx.n_lists, idx.dim, idx.dim, idx.center_norms.data(), false);
+  if (idx.metric == M_CosineExpanded) {
+    idx.center_norms_sqrt = dev_buf<float>::persistent(idx.n_lists);
+    row_norms<float>(res, idx.centers.data(), idx.n_lists, idx.dim, idx.dim, idx.center_norms_sqrt.data(), true);
+  }
+}
+
 std::unique_ptr<ivf_flat_index> ivf_flat_build(resources& res, const cuvsIvfFlatIndexParams& p, const void* data,
                                                elem_t et, int64_t n, int64_t dim, bool is_host)
 {
   CUVS_EXPECTS(n > 0 && dim > 0, "empty dataset");
   CUVS_EXPECTS(n >= p.n_lists, "number of rows can't be less than n_lists");
   const int metric = (int)p.metric;
-  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct,
-               "ivf_flat: unsupported metric %d (L2 and inner product are built)", metric);
+  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct || metric == M_CosineExpanded,
+               "ivf_flat: unsupported metric %d (L2, inner product and cosine are built)", metric);
+  CUVS_EXPECTS(metric != M_CosineExpanded || dim > 1, "Cosine metric requires more than one dim");
   auto idx      = std::make_unique<ivf_flat_index>();
   idx->metric   = metric;
   idx->dtype    = et;
@@ -518,11 +569,13 @@ std::unique_ptr<ivf_flat_index> ivf_flat_build(resources& res, const cuvsIvfFlat
     load_gather_as_float(res, data, et, is_host, dim, ids.data(), n_train, trainset.data());
   }
   idx->centers      = dev_buf<float>::persistent((size_t)p.n_lists * dim);
-  idx->center_norms = dev_buf<float>::persistent(p.n_lists);
   kmeans_params kp;
   kp.n_iters = (int)p.kmeans_n_iters;
+  if (metric == M_CosineExpanded)
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid_blocks(n_train, 4)), dim3(256), 0, res.stream, trainset.data(),
+                       n_train, dim);
   kmeans_balanced_fit(res, trainset.data(), n_train, dim, (int)p.n_lists, kp, idx->centers.data());
-  row_norms<float>(res, idx->centers.data(), p.n_lists, dim, dim, idx->center_norms.data(), false);
+  flat_set_center_norms(res, *idx);
   trainset.release();
   if (p.add_data_on_build) ivf_flat_extend(res, *idx, data, et, n, is_host, nullptr, false);
   sync(res);
@@ -545,14 +598,14 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   int64_t max_batch = 1 << 15;
   {
     int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k * 8 + idx.dim * 4 +
-                    ((int64_t)n_probes / qpb + 1) * dim_pad * qpb * 4;  // + the query tiles of its work items
+                    ((int64_t)n_probes / qpb + 1) * (dim_pad + 1) * qpb * 4;  // + the query tiles of its work items
     max_batch     = std::min(max_batch, std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q));
   }
   const int64_t bs = std::min<int64_t>(max_batch, n_queries);
   const int64_t np_max = bs * n_probes;
   dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
   // two-phase schedule (ivf_common.hpp): nearest probe of every query first
-  uint32_t head = (n_probes > 8 && idx.metric != M_InnerProduct) ? 1u : 0u;
+  uint32_t head = (n_probes > 8 && metric_is_l2(idx.metric)) ? 1u : 0u;
   if (const char* e = getenv("CUVS_AMD_FLAT_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
   const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
   dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, n_labels + 1),
@@ -560,7 +613,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)np_max : 0);
   const size_t max_items = (size_t)(np_max / qpb + n_labels + 1);
   dev_buf<work_item> items(res, max_items);
-  dev_buf<float> qtiles(res, max_items * dim_pad * qpb);
+  dev_buf<float> qtiles(res, max_items * (dim_pad + 1) * qpb);
   dev_buf<float> cand_d(res, (size_t)np_max * k), top_d(res, (size_t)bs * k);
   const size_t esz = elem_size(et);
 
@@ -575,6 +628,13 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
                                       nullptr, nullptr, M_InnerProduct, dist.data(), idx.n_lists);
       select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
                                    probes.data(), false);
+    } else if (idx.metric == M_CosineExpanded) {
+      // 1 - q.c / (|q| |c|): the same ranking as the reference's -q.c / (|q| |c|) (ivf_flat_search.cuh:130-175)
+      row_norms<float>(res, qf.data(), nq, idx.dim, idx.dim, qn.data(), true);
+      pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim, idx.dim,
+                                      qn.data(), idx.center_norms_sqrt.data(), M_CosineExpanded, dist.data(), idx.n_lists);
+      select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
+                                   probes.data(), true);
     } else {
       row_norms<float>(res, qf.data(), nq, idx.dim, idx.dim, qn.data(), false);
       pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim, idx.dim,
@@ -595,12 +655,13 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
     {
       const uint32_t* n_all = item_off.data() + n_labels;
+      const int with_norms  = idx.metric == M_CosineExpanded;
       const unsigned g      = (unsigned)(n_pairs / qpb + n_labels + 1);
       switch (et) {
-        case elem_t::f32: hipLaunchKernelGGL(flat_query_tiles_kernel<float>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const float*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
-        case elem_t::f16: hipLaunchKernelGGL(flat_query_tiles_kernel<__half>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const __half*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
-        case elem_t::i8: hipLaunchKernelGGL(flat_query_tiles_kernel<int8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const int8_t*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
-        case elem_t::u8: hipLaunchKernelGGL(flat_query_tiles_kernel<uint8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const uint8_t*>(qptr), n_probes, idx.dim, dim_pad, qtiles.data()); break;
+        case elem_t::f32: hipLaunchKernelGGL(flat_query_tiles_kernel<float>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const float*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
+        case elem_t::f16: hipLaunchKernelGGL(flat_query_tiles_kernel<__half>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const __half*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
+        case elem_t::i8: hipLaunchKernelGGL(flat_query_tiles_kernel<int8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const int8_t*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
+        case elem_t::u8: hipLaunchKernelGGL(flat_query_tiles_kernel<uint8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const uint8_t*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
       }
       a.qtiles = qtiles.data();
     }
@@ -608,7 +669,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     a.list_sizes = idx.list_sizes.data(); a.out_d = cand_d.data(); a.out_i = cand_i.data();
     a.filter_bits = filter_bits; a.indices = idx.indices.data();
     a.query_kth = query_kth.data(); a.n_probes = n_probes; a.dim = idx.dim; a.veclen = idx.veclen;
-    a.n_chunks = idx.n_chunks; a.k = (uint32_t)k; a.is_ip = idx.metric == M_InnerProduct;
+    a.n_chunks = idx.n_chunks; a.k = (uint32_t)k; a.is_ip = idx.metric == M_InnerProduct ? 1 : (idx.metric == M_CosineExpanded ? 2 : 0);
     auto launch = [&](const flat_scan_args& fa, unsigned grid) {
       profile_begin(res, "ivf_flat_scan_kernel");
       switch (et) {
@@ -820,6 +881,10 @@ std::unique_ptr<ivf_flat_index> flat_read_native(resources& res, const char* fil
   idx->indices      = r.device_array<int64_t>(res);
   idx->h_list_sizes   = to_host(res, idx->list_sizes.data(), idx->n_lists);
   idx->h_list_offsets = to_host(res, idx->list_offsets.data(), idx->n_lists + 1);
+  if (idx->metric == M_CosineExpanded) {
+    idx->center_norms_sqrt = dev_buf<float>::persistent(idx->n_lists);
+    row_norms<float>(res, idx->centers.data(), idx->n_lists, idx->dim, idx->dim, idx->center_norms_sqrt.data(), true);
+  }
   *dl = DLDataType{code, bits, 1};
   return idx;
 }
@@ -844,7 +909,9 @@ void flat_write_ref(resources& res, const char* filename, const ivf_flat_index& 
   w.device_array(res, 'f', 4, {idx.n_lists, idx.dim}, idx.centers.data());
   const bool has_norms = idx.metric != M_InnerProduct;  // ivf_flat_index.cpp:179-191
   w.scalar<bool>(has_norms);
-  if (has_norms) w.device_array(res, 'f', 4, {idx.n_lists}, idx.center_norms.data());
+  if (has_norms)
+    w.device_array(res, 'f', 4, {idx.n_lists},
+                   idx.metric == M_CosineExpanded ? idx.center_norms_sqrt.data() : idx.center_norms.data());
   w.host_array<uint32_t>(idx.h_list_sizes.data(), {idx.n_lists});
   const size_t es   = elem_size(idx.dtype);
   const uint32_t vr = ref_flat_veclen(idx.dim, es);
@@ -890,7 +957,7 @@ std::unique_ptr<ivf_flat_index> flat_read_ref(resources& res, const char* filena
   idx->metric  = r.scalar<int32_t>();
   (void)r.scalar<bool>();  // adaptive_centers
   (void)r.scalar<bool>();  // conservative_memory_allocation
-  CUVS_EXPECTS(metric_is_l2(idx->metric) || idx->metric == M_InnerProduct,
+  CUVS_EXPECTS(metric_is_l2(idx->metric) || idx->metric == M_InnerProduct || idx->metric == M_CosineExpanded,
                "ivf_flat::deserialize: unsupported metric value %d", idx->metric);
   CUVS_EXPECTS(idx->dim > 0 && idx->n_lists > 0 && idx->n_lists <= (1u << 24), "ivf_flat::deserialize: bad header");
   const size_t es = elem_size(idx->dtype);
@@ -899,8 +966,7 @@ std::unique_ptr<ivf_flat_index> flat_read_ref(resources& res, const char* filena
   idx->centers    = r.device_array<float>(res, (int64_t)idx->n_lists * idx->dim);
   if (r.scalar<bool>()) (void)r.host_array<float>(idx->n_lists);
   // canonical |c|^2 (the build's own rounding) rather than the file's
-  idx->center_norms = dev_buf<float>::persistent(idx->n_lists);
-  row_norms<float>(res, idx->centers.data(), idx->n_lists, idx->dim, idx->dim, idx->center_norms.data(), false);
+  flat_set_center_norms(res, *idx);
   idx->h_list_sizes = r.host_array<uint32_t>(idx->n_lists);
   idx->h_list_offsets.assign(idx->n_lists + 1, 0);
   int64_t total = 0, live = 0;

@@ -59,7 +59,7 @@ EXPORT void oracle_ivf_flat_search(const float* queries_coarse, const float* que
                                    const int64_t* list_start, const float* rows, const int64_t* ids, int metric,
                                    int n_probes, int k, int64_t* neighbors, float* distances)
 {
-  const int is_ip = metric == 6;
+  const int is_ip = metric == 6, is_cos = metric == 2;
   if (n_probes > n_lists) n_probes = n_lists;
   float* cn = (float*)malloc(sizeof(float) * (size_t)n_lists);
   for (int j = 0; j < n_lists; ++j) cn[j] = sqnorm64(centers + (int64_t)j * dim, dim);
@@ -78,11 +78,15 @@ EXPORT void oracle_ivf_flat_search(const float* queries_coarse, const float* que
       const float* qc = queries_coarse + qi * dim;
       const float* qr = queries_raw + qi * dim;
       float qn = sqnorm64(qc, dim);
+      float qn_fine = 0.f;  /* |q| of the raw query, squares accumulated in dimension order */
+      for (int d = 0; d < dim; ++d) qn_fine = fmaf(qr[d], qr[d], qn_fine);
+      qn_fine = sqrtf(qn_fine);
       for (int j = 0; j < n_lists; ++j) {
         float dot = 0.f;
         for (int d = 0; d < dim; ++d) dot = fmaf(qc[d], centers[(int64_t)j * dim + d], dot);
         float v;
         if (is_ip) v = dot;
+        else if (is_cos) v = 1.0f - dot / (sqrtf(qn) * sqrtf(cn[j]));  /* distance_tile.hpp finish_distance */
         else {
           v = fmaf(-2.0f, dot, qn + cn[j]);
           if (v * v < 1e-6f && qn == cn[j]) v = 0.f;
@@ -98,9 +102,14 @@ EXPORT void oracle_ivf_flat_search(const float* queries_coarse, const float* que
         for (uint32_t v = 0; v < list_sizes[L]; ++v) {
           const float* x = rows + (list_start[L] + v) * dim;
           float acc = 0.f;
-          if (!is_ip) for (int d = 0; d < dim; ++d) { float t = x[d] - qr[d]; acc = fmaf(t, t, acc); }
-          else        for (int d = 0; d < dim; ++d) acc = fmaf(x[d], qr[d], acc);
-          ins(best, k, is_ip ? -acc : acc, pad_off[L] + v);
+          if (is_cos) {
+            /* ivf_flat.hip METRIC 2: dot and |x|^2 in dimension order, cos = dot / (|q| * |x|), key -cos */
+            float xn2 = 0.f;
+            for (int d = 0; d < dim; ++d) { xn2 = fmaf(x[d], x[d], xn2); acc = fmaf(x[d], qr[d], acc); }
+            acc = acc / (qn_fine * sqrtf(xn2));
+          } else if (!is_ip) for (int d = 0; d < dim; ++d) { float t = x[d] - qr[d]; acc = fmaf(t, t, acc); }
+          else               for (int d = 0; d < dim; ++d) acc = fmaf(x[d], qr[d], acc);
+          ins(best, k, (is_ip || is_cos) ? -acc : acc, pad_off[L] + v);
         }
         for (int j = 0; j < k; ++j) {
           int valid = best[j].id != INT64_MAX;
@@ -121,6 +130,7 @@ EXPORT void oracle_ivf_flat_search(const float* queries_coarse, const float* que
         while (hi - lo > 1) { int mid = (lo + hi) / 2; if (pad_off[mid] <= fr) lo = mid; else hi = mid; }
         neighbors[qi * k + j] = ids[list_start[lo] + (fr - pad_off[lo])];
         if (is_ip) d = -d;
+        else if (is_cos) d = 1.0f + d;
         else if (metric == 1 || metric == 5) d = sqrtf(d);
         distances[qi * k + j] = d;
       }
