@@ -40,6 +40,22 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const T* __restrict__ x,
   }
 }
 
+// x_r <- x_r * (1 / sqrt(canonical |x_r|^2)) in place; rows of norm 0 become 0 (cosine: ivf_pq_build.cuh:159-166,
+// raft::linalg::row_normalize). Oracle twin: oracle.c `normalize_row`.
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ x, int64_t n, int64_t dim)
+{
+  const int lane = lane_id();
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+    float* r  = x + row * dim;
+    float acc = 0.f;
+    for (int64_t j = lane; j < dim; j += kWave) acc = __fmaf_rn(r[j], r[j], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
+    const float inv = acc > 0.f ? 1.0f / sqrtf(acc) : 0.f;
+    for (int64_t j = lane; j < dim; j += kWave) r[j] = r[j] * inv;
+  }
+}
+
 // MODE 0: write D tile.  MODE 1: running argmin over all column tiles (grid.x = 1).
 template <typename TQ, typename TX, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q, int64_t m, int64_t ldq,
@@ -216,6 +232,14 @@ void row_norms(resources& res, const T* x, int64_t n, int64_t dim, int64_t ld, f
   int64_t blocks = std::min<int64_t>((n + 3) / 4, int64_t(1) << 22);  // <= 2^30 threads (HIP grid limit 2^32)
   hipLaunchKernelGGL((row_norms_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, res.stream, x, n, dim, ld,
                      out, sqrt_out);
+  HIP_TRY(hipGetLastError());
+}
+
+void normalize_rows(resources& res, float* x, int64_t n, int64_t dim)
+{
+  if (n == 0) return;
+  int64_t blocks = std::min<int64_t>((n + 3) / 4, int64_t(1) << 22);
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, res.stream, x, n, dim);
   HIP_TRY(hipGetLastError());
 }
 

@@ -51,19 +51,6 @@ constexpr int kFlatWaves   = kFlatThreads / 64;
 constexpr int kFlatQPB     = 8;
 constexpr int kStopEvery   = 4;  // early-stop test every 4 chunks of 16 bytes (power of two)
 
-// cosine: rows are assigned to lists (and the lists trained) on unit-length copies
-__global__ void normalize_rows_kernel(float* x, int64_t n, int64_t dim)
-{
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
-  if (r >= n) return;
-  const int lane = threadIdx.x & 63;
-  float s = 0.f;
-  for (int64_t d = lane; d < dim; d += 64) s = __fmaf_rn(x[r * dim + d], x[r * dim + d], s);
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-  const float inv = s > 0.f ? 1.0f / sqrtf(s) : 0.f;
-  for (int64_t d = lane; d < dim; d += 64) x[r * dim + d] *= inv;
-}
-
 __global__ void strided_ids_kernel2(uint32_t* ids, int64_t n, int64_t stride)
 {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -451,7 +438,7 @@ void ivf_flat_extend(resources& res, ivf_flat_index& idx, const void* data, elem
       int64_t cnt = std::min(batch_rows, n_new - r0);
       load_range_as_float(res, data, et, is_host, dim, r0, cnt, xb.data());
       if (idx.metric == M_CosineExpanded)
-        hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid_blocks(cnt, 4)), dim3(256), 0, res.stream, xb.data(), cnt, dim);
+        normalize_rows(res, xb.data(), cnt, dim);  // cosine: rows are assigned to lists on unit-length copies
       fused_l2_argmin<float>(res, xb.data(), cnt, dim, idx.centers.data(), idx.n_lists, dim, idx.center_norms.data(),
                              labels.data() + r0, nullptr);
     }
@@ -572,8 +559,7 @@ std::unique_ptr<ivf_flat_index> ivf_flat_build(resources& res, const cuvsIvfFlat
   kmeans_params kp;
   kp.n_iters = (int)p.kmeans_n_iters;
   if (metric == M_CosineExpanded)
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid_blocks(n_train, 4)), dim3(256), 0, res.stream, trainset.data(),
-                       n_train, dim);
+    normalize_rows(res, trainset.data(), n_train, dim);
   kmeans_balanced_fit(res, trainset.data(), n_train, dim, (int)p.n_lists, kp, idx->centers.data());
   flat_set_center_norms(res, *idx);
   trainset.release();

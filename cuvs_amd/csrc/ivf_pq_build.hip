@@ -398,8 +398,8 @@ void ivf_pq_set_centers(resources& res, ivf_pq_index& idx, const float* centers_
 std::unique_ptr<ivf_pq_index> ivf_pq_make_empty(resources& res, const ivf_pq_build_params& p, elem_t et, int64_t dim)
 {
   CUVS_EXPECTS(p.metric == M_L2Expanded || p.metric == M_L2SqrtExpanded || p.metric == M_L2Unexpanded ||
-                 p.metric == M_L2SqrtUnexpanded || p.metric == M_InnerProduct,
-               "ivf_pq: unsupported metric %d (L2 and inner product are built)", p.metric);
+                 p.metric == M_L2SqrtUnexpanded || p.metric == M_InnerProduct || p.metric == M_CosineExpanded,
+               "ivf_pq: unsupported metric %d (L2, inner product and cosine are built)", p.metric);
   CUVS_EXPECTS(p.pq_bits >= 4 && p.pq_bits <= 8, "ivf_pq: pq_bits must be within [4, 8]");
   CUVS_EXPECTS(p.codebook_kind == 0, "ivf_pq: only PER_SUBSPACE codebooks are built");
   auto idx           = std::make_unique<ivf_pq_index>();
@@ -446,11 +446,15 @@ std::unique_ptr<ivf_pq_index> ivf_pq_build(resources& res, const ivf_pq_build_pa
     hipLaunchKernelGGL(strided_ids_kernel, dim3(nblk(n_train, 256)), dim3(256), 0, res.stream, ids.data(), n_train,
                        ratio);
     load_gather_as_float(res, data, et, is_host, dim, ids.data(), n_train, trainset.data());
+    // cosine = inner product on unit-length rows (ivf_pq_build.cuh:159-166,1336-1348): rows are normalised
+    // wherever they are read (training, labelling, encoding), centres after the k-means, queries at search
+    if (p.metric == M_CosineExpanded) normalize_rows(res, trainset.data(), n_train, dim);
   }
   dev_buf<float> centers_flat(res, (size_t)p.n_lists * dim);
   kmeans_params kp;
   kp.n_iters = (int)p.kmeans_n_iters;
   kmeans_balanced_fit(res, trainset.data(), n_train, dim, (int)p.n_lists, kp, centers_flat.data());
+  if (p.metric == M_CosineExpanded) normalize_rows(res, centers_flat.data(), p.n_lists, dim);
   dev_buf<uint32_t> labels(res, n_train);
   kmeans_predict<float>(res, trainset.data(), n_train, dim, centers_flat.data(), (int)p.n_lists, labels.data());
   ivf_pq_set_centers(res, *idx, centers_flat.data());
@@ -491,6 +495,7 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
     for (int64_t r0 = 0; r0 < n_new; r0 += batch_rows) {
       int64_t cnt = std::min(batch_rows, n_new - r0);
       load_range_as_float(res, data, et, is_host, dim, r0, cnt, xb.data());
+      if (idx.metric == M_CosineExpanded) normalize_rows(res, xb.data(), cnt, dim);
       fused_l2_argmin<float>(res, xb.data(), cnt, dim, centers_flat.data(), idx.n_lists, dim,
                              idx.center_norms.data(), labels.data() + r0, nullptr);
     }
@@ -535,6 +540,7 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
     for (int64_t j0 = 0; j0 < n_new; j0 += eb) {
       int64_t cnt = std::min(eb, n_new - j0);
       load_gather_as_float(res, data, et, is_host, dim, perm.data() + j0, cnt, xb.data());
+      if (idx.metric == M_CosineExpanded) normalize_rows(res, xb.data(), cnt, dim);
       pairwise_distance<float, float>(res, xb.data(), cnt, dim, idx.rotation.data(), idx.rot_dim, dim, dim, nullptr,
                                       nullptr, M_InnerProduct, rx.data(), idx.rot_dim);
       encode_args a;

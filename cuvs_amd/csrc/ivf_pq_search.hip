@@ -737,7 +737,7 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
 {
   dev_buf<float> dist(res, (size_t)nq * idx.n_lists);
   dev_buf<float> pd(res, (size_t)nq * n_probes);
-  if (idx.metric == M_InnerProduct) {
+  if (idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) {  // cosine: unit queries x unit centres
     pairwise_distance<float, float>(res, qf, nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim,
                                     nullptr, nullptr, M_InnerProduct, dist.data(), idx.n_lists);
     select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
@@ -766,6 +766,8 @@ __global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float
     d = FLT_MAX;
   } else if (metric == M_InnerProduct) {
     d = -d * scale2;
+  } else if (metric == M_CosineExpanded) {
+    d = 1.0f + d;  // the scan minimised -cos of unit vectors
   } else if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) {
     d = sqrtf(d * scale2);
   } else {
@@ -831,7 +833,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   // the order in which pairs are scanned.
   uint32_t head = n_probes > 8 ? 1u : 0u;
   if (const char* e = getenv("CUVS_AMD_PQ_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
-  if (idx.metric == M_InnerProduct) head = 0;  // no early stop for inner product (LUT entries are signed)
+  if (idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) head = 0;  // signed LUT entries: no early stop
   const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
   dev_buf<uint32_t> sorted_pairs(res, (size_t)n_pairs_max), pair_off(res, n_labels + 1), item_off(res, n_labels + 1);
   dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)n_pairs_max : 0);
@@ -849,6 +851,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     const int64_t nq      = std::min(max_batch, n_queries - q0);
     const int64_t n_pairs = nq * n_probes;
     load_range_as_float(res, queries, et, q_is_host, idx.dim, q0, nq, qf.data());
+    if (idx.metric == M_CosineExpanded) normalize_rows(res, qf.data(), nq, idx.dim);
     select_clusters(res, idx, qf.data(), nq, n_probes, probes.data());
     // rotation (ivf_pq_search.cuh:1003-1017)
     pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.rotation.data(), idx.rot_dim, idx.dim, idx.dim,
@@ -872,7 +875,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.out_d = cand_d.data(); a.out_i = cand_i.data();
     a.n_probes = n_probes; a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len;
     a.pq_bits = idx.pq_bits; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.k = (uint32_t)k;
-    a.is_ip = idx.metric == M_InnerProduct;
+    a.is_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
     a.dbg   = getenv("CUVS_AMD_SCAN_DEBUG") ? atoi(getenv("CUVS_AMD_SCAN_DEBUG")) : 0;
     const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);  // persistent: one workgroup per CU
     auto launch = [&](const scan_args& sa) {

@@ -25,6 +25,9 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
 template <typename T>
 void row_norms(resources& res, const T* x, int64_t n, int64_t dim, int64_t ld, float* out, bool sqrt_out);
 
+// In-place row normalisation of a dense fp32 matrix with the canonical norm (cosine paths).
+void normalize_rows(resources& res, float* x, int64_t n, int64_t dim);
+
 // D[i, j] = epilogue(dot(Q_i, X_j)) for i < m, j < n; out pitch ldo.
 //   metric L2*: max(0, fmaf(-2, dot, qn_i + xn_j)) with the reference's self-neighbour clamp
 //               (distance_ops/l2_exp.cuh:36-50,113-125); sqrt variants take sqrt.

@@ -315,7 +315,8 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
 {
   const int book = 1 << pq_bits;
   const int bpr  = (pq_dim * pq_bits + 7) / 8;
-  const int is_ip = metric == M_InnerProduct;
+  const int is_cos = metric == M_CosineExpanded;         /* inner product of unit vectors, reported as 1 - cos */
+  const int is_ip  = metric == M_InnerProduct || is_cos;
   if (n_probes > n_lists) n_probes = n_lists;
   float* cn = (float*)malloc(sizeof(float) * (size_t)n_lists);
   oracle_row_norms(centers, n_lists, dim, cn, 0);
@@ -329,6 +330,7 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
     cand_t* cc    = (cand_t*)malloc(sizeof(cand_t) * (size_t)n_lists);
     float* rq     = (float*)malloc(sizeof(float) * (size_t)rot_dim);
     float* qv     = (float*)malloc(sizeof(float) * (size_t)rot_dim);
+    float* qh     = (float*)malloc(sizeof(float) * (size_t)dim);
     float* lut    = (float*)malloc(sizeof(float) * (size_t)pq_dim * book);
     pair_t* best  = (pair_t*)malloc(sizeof(pair_t) * (size_t)k);
     float* buf_d  = (float*)malloc(sizeof(float) * (size_t)n_probes * k);
@@ -337,6 +339,11 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
 #pragma omp for schedule(dynamic, 1)
     for (int64_t qi = 0; qi < nq; ++qi) {
       const float* q = queries + qi * dim;
+      if (is_cos) { /* distance.hip normalize_rows_kernel: x * (1 / sqrt(canonical |x|^2)) */
+        const float n2 = canon_sqnorm(q, dim), inv = n2 > 0.f ? 1.0f / sqrtf(n2) : 0.f;
+        for (int d = 0; d < dim; ++d) qh[d] = q[d] * inv;
+        q = qh;
+      }
       /* coarse */
       float qn = canon_sqnorm(q, dim);
       for (int j = 0; j < n_lists; ++j) {
@@ -396,14 +403,15 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
           while (hi - lo > 1) { int mid = (lo + hi) / 2; if (pad_off[mid] <= fr) lo = mid; else hi = mid; }
           neighbors[qi * k + j] = ids[list_start[lo] + (fr - pad_off[lo])];
           float s2 = scale * scale;
-          if (is_ip) d = -d * s2;
+          if (is_cos) d = 1.0f + d;
+          else if (is_ip) d = -d * s2;
           else if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d * s2);
           else d = d * s2;
           distances[qi * k + j] = d;
         }
       }
     }
-    free(cd); free(cc); free(rq); free(qv); free(lut); free(best); free(buf_d); free(buf_i); free(mc);
+    free(cd); free(cc); free(rq); free(qv); free(qh); free(lut); free(best); free(buf_d); free(buf_i); free(mc);
   }
   free(cn);
   free(pad_off);

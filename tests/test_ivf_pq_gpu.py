@@ -180,3 +180,28 @@ def test_errors():
         _search(index, q[:, :8].copy(), 3)
     with pytest.raises(CuvsError):
         ivf_pq.extend(index, torch.from_numpy(x).cuda(), None)  # ids required for a non-empty index
+
+
+@pytest.mark.parametrize("n,d,n_lists,pq_dim,pq_bits,k,n_probes", [(4096, 64, 32, 32, 8, 16, 8), (3000, 30, 20, 10, 8, 10, 20),
+                                                                   (4096, 64, 32, 64, 5, 16, 6)])
+def test_cosine_parity_and_recall(n, d, n_lists, pq_dim, pq_bits, k, n_probes):
+    """CosineExpanded = inner product of unit-length rows / centres / queries, reported as 1 - cos
+    (ivf_pq_build.cuh:159-166,1336-1348; ivf_pq_search.cuh:101-107,1020-1025)."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.5, 3.0, (n, 1)).astype(np.float32)
+    q = rng.standard_normal((150, d)).astype(np.float32)
+    index = _build(x, n_lists=n_lists, metric="cosine", pq_dim=pq_dim, pq_bits=pq_bits, kmeans_n_iters=10)
+    gd, gi = _search(index, q, k, n_probes=n_probes)
+    ex = ivf_pq.export_for_oracle(index)
+    np.testing.assert_allclose(np.linalg.norm(ex["centers"], axis=1), 1.0, rtol=1e-5)   # centres are unit vectors
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric="cosine")
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.4f}"
+    assert (gd == od).all(), f"max |d| diff {np.abs(gd - od).max()}"
+    # recall against exact cosine kNN, the reference's threshold formula
+    xf, qf = x.astype(np.float64), q.astype(np.float64)
+    cosd = 1.0 - (qf @ xf.T) / (np.linalg.norm(qf, axis=1)[:, None] * np.linalg.norm(xf, axis=1)[None, :])
+    truth = np.argsort(cosd, axis=1, kind="stable")[:, :k]
+    assert oracle.recall(gi, truth) >= _min_recall(n_probes, n_lists, d, pq_dim, pq_bits) * 0.9
+    assert (gd > -1e-3).all() and (gd < 2.001).all()
