@@ -35,7 +35,21 @@ struct cagra_index {
   const void* data = nullptr;  // device rows [n, dim]
   dev_buf<char> owned;
   dev_buf<uint32_t> graph;     // [n, degree]
+  dev_buf<float> norms;        // [n] canonical |x| (cosine only; the reference's dataset_norms)
 };
+
+// canonical row norms of the dataset for the cosine metric (no-op otherwise)
+static void cagra_set_norms(resources& res, cagra_index& idx)
+{
+  if (idx.metric != M_CosineExpanded || idx.data == nullptr) return;
+  idx.norms = dev_buf<float>::persistent(idx.n);
+  switch (idx.dtype) {
+    case elem_t::f32: row_norms<float>(res, static_cast<const float*>(idx.data), idx.n, idx.dim, idx.dim, idx.norms.data(), true); break;
+    case elem_t::f16: row_norms<__half>(res, static_cast<const __half*>(idx.data), idx.n, idx.dim, idx.dim, idx.norms.data(), true); break;
+    case elem_t::i8: row_norms<int8_t>(res, static_cast<const int8_t*>(idx.data), idx.n, idx.dim, idx.dim, idx.norms.data(), true); break;
+    case elem_t::u8: row_norms<uint8_t>(res, static_cast<const uint8_t*>(idx.data), idx.n, idx.dim, idx.dim, idx.norms.data(), true); break;
+  }
+}
 
 namespace {
 
@@ -181,7 +195,7 @@ void knn_graph_bruteforce(resources& res, const T* data, int64_t n, int64_t dim,
   dev_buf<float> norms;
   if (metric != M_InnerProduct) {
     norms = dev_buf<float>(res, n);
-    row_norms<T>(res, data, n, dim, dim, norms.data(), false);
+    row_norms<T>(res, data, n, dim, dim, norms.data(), metric == M_CosineExpanded);
   }
   const int64_t m_tile = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t)(res.workspace_limit / 4) / n));
   dev_buf<float> tile(res, (size_t)m_tile * n), dv(res, (size_t)m_tile * kp1);
@@ -189,7 +203,9 @@ void knn_graph_bruteforce(resources& res, const T* data, int64_t n, int64_t dim,
   for (int64_t r0 = 0; r0 < n; r0 += m_tile) {
     int64_t mr = std::min(m_tile, n - r0);
     pairwise_distance<T, T>(res, data + r0 * dim, mr, dim, data, n, dim, dim, norms.data() ? norms.data() + r0 : nullptr,
-                            norms.data(), metric == M_InnerProduct ? M_InnerProduct : M_L2Expanded, tile.data(), n);
+                            norms.data(),
+                            metric == M_InnerProduct ? M_InnerProduct : (metric == M_CosineExpanded ? M_CosineExpanded : M_L2Expanded),
+                            tile.data(), n);
     select_k<int64_t, int64_t>(res, tile.data(), nullptr, mr, n, n, (int)kp1, dv.data(), di.data(), select_min);
     hipLaunchKernelGGL(strip_self_kernel, dim3(grid_blocks(mr, 256)), dim3(256), 0, res.stream, di.data(), mr, r0, K,
                        kp1, knn);
@@ -201,7 +217,7 @@ void knn_graph_ivf_pq(resources& res, const void* data, elem_t et, int64_t n, in
                       uint32_t* knn)
 {
   ivf_pq_build_params bp;
-  bp.metric                   = metric == M_InnerProduct ? M_InnerProduct : M_L2Expanded;
+  bp.metric                   = metric == M_InnerProduct ? M_InnerProduct : (metric == M_CosineExpanded ? M_CosineExpanded : M_L2Expanded);
   bp.n_lists                  = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(65536, (int64_t)std::sqrt((double)n)));
   bp.kmeans_n_iters           = 10;
   bp.kmeans_trainset_fraction = std::min(1.0, std::max(0.02, 2.0e6 / (double)n));
@@ -260,7 +276,8 @@ struct search_args {
   int64_t n, dim;
   uint32_t degree, itopk, width, max_iter, min_iter, k, np2, hash_bits, reset_interval;
   uint64_t rand_xor_mask;
-  int is_ip, idx64;
+  int is_ip, idx64;    // is_ip: 0 L2, 1 inner product, 2 cosine (1 - q.x / (|q| |x|), |x| from `norms`)
+  const float* norms;  // [n] canonical |x| (cosine)
 };
 
 __device__ inline uint32_t hash_slot(uint32_t key, uint32_t bits) { return (key ^ (key >> bits)) & ((1u << bits) - 1u); }
@@ -293,7 +310,8 @@ __device__ inline uint64_t xorshift64(uint64_t u)
 template <typename T>
 __device__ inline void team_distances(const T* __restrict__ data, int64_t dim, const float* __restrict__ qf,
                                       uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t first,
-                                      uint32_t count, bool is_ip, int lane)
+                                      uint32_t count, int is_ip, int lane, const float* __restrict__ norms = nullptr,
+                                      float qn = 1.f)
 {
   constexpr int VL = 16 / sizeof(T);
   const int team = lane >> 3, tl = lane & 7;
@@ -330,8 +348,18 @@ __device__ inline void team_distances(const T* __restrict__ data, int64_t dim, c
     acc = acc + __shfl_xor(acc, 1, kWave);
     acc = acc + __shfl_xor(acc, 2, kWave);
     acc = acc + __shfl_xor(acc, 4, kWave);
-    if (tl == 0 && c < count) keys[first + c] = ok ? float_to_key(is_ip ? -acc : acc) : 0xffffffffu;
+    if (is_ip == 2 && ok) acc = 1.0f - acc / (qn * norms[node]);  // the brute-force cosine epilogue
+    if (tl == 0 && c < count) keys[first + c] = ok ? float_to_key(is_ip == 1 ? -acc : acc) : 0xffffffffu;
   }
+}
+
+__device__ inline float wave_query_norm(const float* qf, int64_t dim, int lane)
+{
+  float s = 0.f;
+  for (int64_t d = lane; d < dim; d += 64) s = __fmaf_rn(qf[d], qf[d], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s = s + __shfl_xor(s, off, kWave);
+  return sqrtf(s);
 }
 
 template <typename T>
@@ -353,6 +381,9 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
+  float qn = 1.f;  // cosine: canonical |q| (64 strided fma partial sums + butterfly, as row_norms)
+  if (a.is_ip == 2) qn = wave_query_norm(qf, a.dim, lane);
+
   // ---- seeds: itopk pseudo-random nodes (device_common_jit.cuh:36-104: xorshift64(gid ^ mask) % n)
   for (uint32_t i = lane; i < a.itopk; i += 64) {
     uint64_t gid  = (uint64_t)qi * a.itopk + i;
@@ -361,7 +392,7 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  team_distances<T>(data, a.dim, qf, keys, idx, 0, a.itopk, a.is_ip, lane);
+  team_distances<T>(data, a.dim, qf, keys, idx, 0, a.itopk, a.is_ip, lane, a.norms, qn);
 
   const uint32_t n_cand = a.width * a.degree;
   uint32_t iter         = 0;
@@ -409,7 +440,7 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    team_distances<T>(data, a.dim, qf, keys, idx, a.itopk, n_cand, a.is_ip, lane);
+    team_distances<T>(data, a.dim, qf, keys, idx, a.itopk, n_cand, a.is_ip, lane, a.norms, qn);
     ++iter;
   }
 
@@ -424,7 +455,7 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
     const uint32_t rank        = written + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (ok && rank < a.k) {
       float d = key_to_float(keys[i]);
-      if (a.is_ip) d = -d;
+      if (a.is_ip == 1) d = -d;
       a.out_dist[qi * a.k + rank] = d;
       if (a.idx64) static_cast<int64_t*>(a.out_idx)[qi * a.k + rank] = node;
       else         static_cast<uint32_t*>(a.out_idx)[qi * a.k + rank] = node;
@@ -517,6 +548,9 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
   for (uint32_t i = lane; i < vsize; i += 64) vis[i] = kInvalidNode;
   __syncthreads();
 
+  float qn = 1.f;
+  if (a.is_ip == 2) qn = wave_query_norm(qf, a.dim, lane);
+
   // ---- seeds: 32 pseudo-random nodes per wave, a different stream per (query, wave) (device_common_jit.cuh:72)
   if (lane < (int)kMwTopk) {
     const uint64_t gid  = ((uint64_t)qi * W + wave) * kMwTopk + lane;
@@ -525,7 +559,7 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  team_distances<T>(data, a.dim, qf, keys, idx, 0, kMwTopk, a.is_ip, lane);
+  team_distances<T>(data, a.dim, qf, keys, idx, 0, kMwTopk, a.is_ip, lane, a.norms, qn);
 
   uint32_t iter = 0;
   while (true) {
@@ -600,7 +634,7 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    team_distances<T>(data, a.dim, qf, keys, idx, kMwTopk, a.degree, a.is_ip, lane);
+    team_distances<T>(data, a.dim, qf, keys, idx, kMwTopk, a.degree, a.is_ip, lane, a.norms, qn);
     // ---- drop what another wave has expanded meanwhile; a parent that fails the filter leaves the list
     for (uint32_t i = lane; i < np2; i += 64) {
       const uint32_t e = idx[i];
@@ -639,7 +673,7 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
   for (uint32_t r = lane; r < a.k; r += 64) {
     const bool ok  = r < m.merge_np2 && midx[r] != kInvalidNode;
     float d        = ok ? key_to_float(mkeys[r]) : FLT_MAX;
-    if (ok && a.is_ip) d = -d;
+    if (ok && a.is_ip == 1) d = -d;
     a.out_dist[qi * a.k + r] = d;
     if (a.idx64) static_cast<int64_t*>(a.out_idx)[qi * a.k + r] = ok ? (int64_t)midx[r] : -1;
     else         static_cast<uint32_t*>(a.out_idx)[qi * a.k + r] = ok ? midx[r] : kInvalidNode;
@@ -704,7 +738,9 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   a.hash_bits      = bits;
   a.reset_interval = std::max<uint32_t>(1, ((1u << bits) / 2 - itopk) / (a.width * idx.degree));
   a.rand_xor_mask  = p.rand_xor_mask;
-  a.is_ip          = idx.metric == M_InnerProduct;
+  a.is_ip          = idx.metric == M_InnerProduct ? 1 : (idx.metric == M_CosineExpanded ? 2 : 0);
+  a.norms          = idx.norms.data();
+  CUVS_EXPECTS(a.is_ip != 2 || a.norms != nullptr, "cagra::search: cosine index without dataset norms");
   a.idx64          = idx64 ? 1 : 0;
   // ---- algorithm choice. The reference's AUTO (search_plan.cuh:121-131) keeps one CTA per query once the batch
   // alone fills the GPU. On MI355X the multi-wave walk measured faster at every batch size from 1 to 10k at equal
@@ -764,7 +800,8 @@ std::unique_ptr<cagra_index> cagra_build(resources& res, const cuvsCagraIndexPar
                                          int64_t n, int64_t dim, bool is_host)
 {
   const int metric = (int)p.metric;
-  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct, "cagra: unsupported metric %d", metric);
+  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct || metric == M_CosineExpanded,
+               "cagra: unsupported metric %d", metric);
   CUVS_EXPECTS(n > 1, "cagra: need at least two rows");
   auto idx    = std::make_unique<cagra_index>();
   idx->metric = metric;
@@ -806,6 +843,7 @@ std::unique_ptr<cagra_index> cagra_build(resources& res, const cuvsCagraIndexPar
   }
   idx->graph = dev_buf<uint32_t>::persistent((size_t)n * degree);
   optimize_graph(res, knn.data(), n, K, degree, idx->graph.data());
+  cagra_set_norms(res, *idx);
   sync(res);
   return idx;
 }
@@ -987,6 +1025,7 @@ cuvsError_t cuvsCagraIndexFromArgs(cuvsResources_t res_h, cuvsDistanceType metri
     }
     idx->graph = dev_buf<uint32_t>::persistent((size_t)idx->n * idx->degree);
     copy_async(res, idx->graph.data(), dl_data(g), idx->graph.bytes());
+    cagra_set_norms(res, *idx);
     sync(res);
     delete reinterpret_cast<cagra_index*>(index->addr);
     index->addr  = reinterpret_cast<uintptr_t>(idx.release());
@@ -1112,7 +1151,7 @@ cuvsError_t cuvsCagraDeserialize(cuvsResources_t res_h, const char* filename, cu
       idx->dim    = (int64_t)r.scalar<uint32_t>();
       idx->degree = r.scalar<uint32_t>();
       idx->metric = r.scalar<int32_t>();
-      CUVS_EXPECTS(metric_is_l2(idx->metric) || idx->metric == M_InnerProduct,
+      CUVS_EXPECTS(metric_is_l2(idx->metric) || idx->metric == M_InnerProduct || idx->metric == M_CosineExpanded,
                    "cagra::deserialize: unsupported metric value %d", idx->metric);
       CUVS_EXPECTS(idx->degree > 0 && idx->degree <= 1024, "cagra::deserialize: graph_degree=%u exceeds maximum %u",
                    idx->degree, 1024u);
@@ -1137,6 +1176,8 @@ cuvsError_t cuvsCagraDeserialize(cuvsResources_t res_h, const char* filename, cu
       CUVS_EXPECTS((content & 2u) == 0, "cagra::deserialize: source_indices are not supported");
       dl = dl_of(idx->dtype);
     }
+    cagra_set_norms(res, *idx);
+    sync(res);
     delete reinterpret_cast<cagra_index*>(index->addr);
     index->addr  = reinterpret_cast<uintptr_t>(idx.release());
     index->dtype = dl;

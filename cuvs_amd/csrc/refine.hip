@@ -28,16 +28,27 @@ __global__ __launch_bounds__(256) void refine_kernel(const T* __restrict__ data,
   const int wave  = threadIdx.x >> 6;
   const T* qv     = queries + q * dim;
   const bool ip   = metric == M_InnerProduct;
+  const bool cosm = metric == M_CosineExpanded;
   for (int c = threadIdx.x; c < np2; c += 256) { s_key[c] = 0xffffffffu; s_idx[c] = INT64_MAX; }
   __syncthreads();
+  float qn = 0.f;  // cosine: |q| with the canonical strided partial sums (every wave computes the same value)
+  if (cosm) {
+    for (int64_t j = lane; j < dim; j += kWave) { float a = to_float(qv[j]); qn = __fmaf_rn(a, a, qn); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) qn = qn + __shfl_xor(qn, off, kWave);
+    qn = sqrtf(qn);
+  }
   for (int c = wave; c < n_cand; c += 4) {
     const int64_t id = cand[q * n_cand + c];
     if (id < 0 || id >= n) continue;  // wave-uniform
     const T* row = data + id * dim;
-    float acc    = 0.f;
+    float acc    = 0.f, xn = 0.f;
     for (int64_t j = lane; j < dim; j += kWave) {
       float a = to_float(qv[j]), b = to_float(row[j]);
-      if (ip) {
+      if (cosm) {
+        acc = __fmaf_rn(a, b, acc);
+        xn  = __fmaf_rn(b, b, xn);
+      } else if (ip) {
         acc = __fmaf_rn(a, b, acc);
       } else {
         float t = a - b;
@@ -46,6 +57,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const T* __restrict__ data,
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
+    if (cosm) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) xn = xn + __shfl_xor(xn, off, kWave);
+      acc = 1.0f - acc / (qn * sqrtf(xn));  // the brute-force epilogue (distance_tile.hpp finish_distance)
+    }
     if (lane == 0) {
       s_key[c] = ip ? ~float_to_key(acc) : float_to_key(acc);  // inner product: larger is better
       s_idx[c] = id;
@@ -84,7 +100,8 @@ void refine(resources& res, const void* data, elem_t et, int64_t n, int64_t dim,
 {
   if (m == 0) return;
   CUVS_EXPECTS(k <= n_cand, "refine: k (%d) must not exceed the number of candidates (%d)", k, n_cand);
-  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct, "refine: unsupported metric %d", metric);
+  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct || metric == M_CosineExpanded,
+               "refine: unsupported metric %d", metric);
   switch (et) {
     case elem_t::f32: refine_typed<float>(res, data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
     case elem_t::f16: refine_typed<__half>(res, data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;

@@ -195,7 +195,7 @@ def cagra_search(dataset, graph, queries, k, itopk_size=64, search_width=1, max_
     lib().oracle_cagra_search(_p(x), C.c_int64(n), C.c_int64(x.shape[1]), C.c_int(vl), _p(g), C.c_int(degree), _p(q),
                               C.c_int64(nq), C.c_int(k), C.c_int(itopk), C.c_int(width), C.c_int(max_iter),
                               C.c_int(int(min_iterations)), C.c_int(bits), C.c_int(reset), C.c_uint64(rand_xor_mask),
-                              C.c_int(int(_metric(metric) == 6)), _p(fw) if fw is not None else None, _p(oi), _p(od))
+                              C.c_int({6: 1, 2: 2}.get(_metric(metric), 0)), _p(fw) if fw is not None else None, _p(oi), _p(od))
     return od, oi
 
 

@@ -82,6 +82,23 @@ static int set_insert(set_t* s, uint32_t key, uint32_t bits)  /* 1 when new */
   return 0;
 }
 
+static float sqnorm64(const float* a, int64_t d)
+{
+  float p[64];
+  for (int l = 0; l < 64; ++l) p[l] = 0.f;
+  for (int64_t j = 0; j < d; ++j) p[j & 63] = fmaf(a[j], a[j], p[j & 63]);
+  for (int off = 32; off > 0; off >>= 1)
+    for (int i = 0; i < off; ++i) p[i] = p[i] + p[i + off];
+  return p[0];
+}
+/* is_ip: 0 L2, 1 inner product, 2 cosine = 1 - q.x / (|q| |x|) with canonical norms (cagra.hip team_distances) */
+static float node_key_value(const float* x, const float* q, int64_t dim, int vl, int is_ip, float qn)
+{
+  float d = team_distance(x, q, dim, vl, is_ip != 0);
+  if (is_ip == 2) d = 1.0f - d / (qn * sqrtf(sqnorm64(x, dim)));
+  return is_ip == 1 ? -d : d;
+}
+
 EXPORT void oracle_cagra_search(const float* data, int64_t n, int64_t dim, int vl, const uint32_t* graph, int degree,
                                 const float* queries, int64_t nq, int k, int itopk, int width, int max_iter,
                                 int min_iter, int hash_bits, int reset_interval, uint64_t rand_xor_mask, int is_ip,
@@ -99,6 +116,7 @@ EXPORT void oracle_cagra_search(const float* data, int64_t n, int64_t dim, int v
 #pragma omp for schedule(dynamic, 4)
     for (int64_t qi = 0; qi < nq; ++qi) {
       const float* q = queries + qi * dim;
+      const float qn = is_ip == 2 ? sqrtf(sqnorm64(q, dim)) : 1.f;
       for (int i = 0; i < np2; ++i) { e[i].key = 0xffffffffu; e[i].idx = INVALID; }
       set_clear(&set);
       for (int i = 0; i < itopk; ++i) {
@@ -106,8 +124,7 @@ EXPORT void oracle_cagra_search(const float* data, int64_t n, int64_t dim, int v
         uint32_t node = (uint32_t)(xorshift64(gid ^ rand_xor_mask) % (uint64_t)n);
         if (set_insert(&set, node, hash_bits)) {
           e[i].idx = node;
-          float d  = team_distance(data + (int64_t)node * dim, q, dim, vl, is_ip);
-          e[i].key = f2key(is_ip ? -d : d);
+          e[i].key = f2key(node_key_value(data + (int64_t)node * dim, q, dim, vl, is_ip, qn));
         }
       }
       int iter = 0;
@@ -133,8 +150,7 @@ EXPORT void oracle_cagra_search(const float* data, int64_t n, int64_t dim, int v
           e[itopk + i].idx = child;
           e[itopk + i].key = 0xffffffffu;
           if (child != INVALID) {
-            float d = team_distance(data + (int64_t)child * dim, q, dim, vl, is_ip);
-            e[itopk + i].key = f2key(is_ip ? -d : d);
+            e[itopk + i].key = f2key(node_key_value(data + (int64_t)child * dim, q, dim, vl, is_ip, qn));
           }
         }
         ++iter;
@@ -146,7 +162,7 @@ EXPORT void oracle_cagra_search(const float* data, int64_t n, int64_t dim, int v
         if (filter_bits && !((filter_bits[node >> 5] >> (node & 31)) & 1u)) continue;
         float d = key2f(e[i].key);
         out_idx[qi * k + written]  = node;
-        out_dist[qi * k + written] = is_ip ? -d : d;
+        out_dist[qi * k + written] = is_ip == 1 ? -d : d;
         ++written;
       }
       for (; written < k; ++written) { out_idx[qi * k + written] = -1; out_dist[qi * k + written] = FLT_MAX; }

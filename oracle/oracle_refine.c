@@ -34,11 +34,12 @@ static float lane_reduce(const float* a, const float* b, int64_t d, int ip)
   return p[0];
 }
 
-/* metric: 0/4 L2 squared, 1/5 L2 sqrt, 6 inner product */
+/* metric: 0/4 L2 squared, 1/5 L2 sqrt, 6 inner product, 2 cosine (1 - q.x / (|q| |x|), all three sums with the
+ * strided partials of lane_reduce) */
 EXPORT void oracle_refine(const float* data, int64_t n, int64_t dim, const float* queries, int64_t m,
                           const int64_t* cand, int n_cand, int k, int metric, int64_t* out_i, float* out_d)
 {
-  const int ip = metric == 6;
+  const int ip = metric == 6, cosm = metric == 2;
 #pragma omp parallel
   {
     rpair_t* buf = (rpair_t*)malloc(sizeof(rpair_t) * (size_t)n_cand);
@@ -48,7 +49,12 @@ EXPORT void oracle_refine(const float* data, int64_t n, int64_t dim, const float
       for (int c = 0; c < n_cand; ++c) {
         int64_t id = cand[q * n_cand + c];
         if (id < 0 || id >= n) continue;
-        float v = lane_reduce(queries + q * dim, data + id * dim, dim, ip);
+        float v = lane_reduce(queries + q * dim, data + id * dim, dim, ip || cosm);
+        if (cosm) {
+          const float qn = sqrtf(lane_reduce(queries + q * dim, queries + q * dim, dim, 1));
+          const float xn = lane_reduce(data + id * dim, data + id * dim, dim, 1);
+          v = 1.0f - v / (qn * sqrtf(xn));
+        }
         buf[cnt].d  = ip ? -v : v;  /* sort key: smaller is better */
         buf[cnt].id = id;
         ++cnt;

@@ -143,3 +143,28 @@ def test_multi_wave_search_filter_and_dtypes():
     # k larger than one walker's list: needs several walkers (num_cta_per_query * 32 >= k)
     d, i = _search(index, q, 40, itopk_size=64, algo="multi_cta")
     assert all(len(np.unique(r)) == 40 for r in i)
+
+
+@pytest.mark.parametrize("algo", ["single_cta", "multi_cta"])
+def test_cosine_metric(algo, tmp_path):
+    """CosineExpanded (reference: python/cuvs/cuvs/tests/test_cagra.py cosine cases, sklearn brute cosine truth)."""
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((6000, 32)) * rng.uniform(0.3, 4.0, (6000, 1))).astype(np.float32)
+    q = rng.standard_normal((40, 32)).astype(np.float32)
+    index = _build(x, metric="cosine", intermediate_graph_degree=64, graph_degree=32)
+    d, i = _search(index, q, 10, itopk_size=64, algo=algo)
+    xf, qf = x.astype(np.float64), q.astype(np.float64)
+    cosd = 1.0 - (qf @ xf.T) / (np.linalg.norm(qf, axis=1)[:, None] * np.linalg.norm(xf, axis=1)[None, :])
+    truth = np.argsort(cosd, axis=1, kind="stable")[:, :10]
+    assert oracle.recall(i, truth) >= 0.95
+    np.testing.assert_allclose(d, np.take_along_axis(cosd, i, axis=1), rtol=1e-3, atol=2e-3)
+    # norms are rebuilt when the index comes back from a file
+    f = str(tmp_path / "cos.bin")
+    cagra.save(f, index)
+    d2, i2 = cagra.search(cagra.SearchParams(itopk_size=64, algo="single_cta"), cagra.load(f), torch.from_numpy(q).cuda(), 10)
+    d1, i1 = cagra.search(cagra.SearchParams(itopk_size=64, algo="single_cta"), index, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    assert torch.equal(i1, i2) and torch.equal(d1, d2)

@@ -42,7 +42,7 @@ def test_kmeans_bit_exact_and_balanced(n, d, k, hier):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8])
-@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product", "cosine"])
 def test_cagra_search_walk_matches_oracle(dtype, metric):
     import torch
     from cuvs_amd.neighbors import cagra

@@ -7,7 +7,7 @@ import oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "inner_product"])
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "inner_product", "cosine"])
 @pytest.mark.parametrize("n,d,m,n_cand,k", [(2000, 64, 50, 40, 10), (500, 7, 20, 100, 100), (3000, 200, 10, 33, 5)])
 def test_refine_matches_oracle(metric, n, d, m, n_cand, k):
     import torch
