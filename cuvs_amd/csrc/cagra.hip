@@ -822,7 +822,10 @@ std::unique_ptr<cagra_index> cagra_build(resources& res, const cuvsCagraIndexPar
   idx->degree     = degree;
   dev_buf<uint32_t> knn(res, (size_t)n * K);
   const bool small = n <= 200000 || p.build_algo == ITERATIVE_CAGRA_SEARCH;
-  if (small) {
+  if (p.build_algo == NN_DESCENT) {
+    cagra_set_norms(res, *idx);  // cosine: the join needs |x|
+    knn_graph_nn_descent(res, idx->data, et, n, dim, K, metric, idx->norms.data(), (int)p.nn_descent_niter, knn.data());
+  } else if (small) {
     if (et == elem_t::f32) {
       knn_graph_bruteforce<float>(res, static_cast<const float*>(idx->data), n, dim, K, metric, knn.data());
     } else if (et == elem_t::f16) {

@@ -71,6 +71,12 @@ template <typename T>
 void kmeans_predict(resources& res, const T* x, int64_t n, int64_t dim, const float* centers,
                     int n_clusters, uint32_t* labels);
 
+// ---------------------------------------------------------------- nn_descent.hip
+// kNN graph [n, K] (uint32 ids sorted by distance, self excluded, 0xffffffff = none) by NN-descent; `norms` = canonical
+// |x| per row for the cosine metric (else unused).
+void knn_graph_nn_descent(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, uint32_t K, int metric,
+                          const float* norms, int n_iters, uint32_t* knn);
+
 // ---------------------------------------------------------------- refine.hip
 // exact re-ranking of candidate ids; out sorted by (distance, id). All pointers device.
 void refine(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, const void* queries, int64_t m,

@@ -1,0 +1,68 @@
+"""GPU: NN-descent kNN-graph builder (CAGRA build_algo = NN_DESCENT; reference cpp/src/neighbors/detail/nn_descent.cuh,
+tests cpp/tests/neighbors/ann_nn_descent.cuh: graph recall against brute force >= min_recall)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _nn_descent(x, K, metric=0, n_iters=20):
+    import torch
+    from cuvs_amd._lib import check, lib
+    from cuvs_amd.common import Resources
+
+    res = Resources()
+    tx = torch.from_numpy(x).cuda()
+    out = torch.empty((x.shape[0], K), dtype=torch.int32, device="cuda")
+    fn = lib().cuvsAmdNnDescent
+    fn.restype = C.c_int
+    check(fn(res.get_c_obj(), C.c_void_p(tx.data_ptr()), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]),
+             C.c_uint32(K), C.c_int(metric), C.c_int(n_iters), C.c_void_p(out.data_ptr())))
+    res.sync()
+    return out.cpu().numpy().view(np.uint32).astype(np.int64)
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product", "cosine"])
+def test_graph_recall(metric):
+    rng = np.random.default_rng(0)
+    n, d, K = 20000, 32, 32
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    g = _nn_descent(x, K, metric={"sqeuclidean": 0, "cosine": 2, "inner_product": 6}[metric])
+    assert g.shape == (n, K) and (g < n).all()
+    assert (g != np.arange(n)[:, None]).all()                    # no self edges
+    assert all(len(np.unique(r)) == K for r in g[:500])          # no duplicate edges
+    rows = rng.choice(n, 300, replace=False)
+    if metric == "cosine":
+        xn = x / np.linalg.norm(x, axis=1, keepdims=True)
+        sim = xn[rows] @ xn.T
+    elif metric == "inner_product":
+        sim = x[rows] @ x.T
+    else:
+        sim = -((x[rows][:, None, :] - x[None, :, :]) ** 2).sum(-1) if n <= 2000 else None
+        if sim is None:
+            sim = -(np.sum(x[rows] ** 2, 1)[:, None] + np.sum(x ** 2, 1)[None, :] - 2 * x[rows] @ x.T)
+    sim[np.arange(len(rows)), rows] = -np.inf
+    truth = np.argsort(-sim, axis=1, kind="stable")[:, :K]
+    rec = np.mean([len(np.intersect1d(g[r], t)) for r, t in zip(rows, truth)]) / K
+    assert rec >= 0.9, rec
+
+
+def test_cagra_build_with_nn_descent():
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((30000, 48)).astype(np.float32)
+    q = rng.standard_normal((200, 48)).astype(np.float32)
+    index = cagra.build(cagra.IndexParams(intermediate_graph_degree=64, graph_degree=32, build_algo="nn_descent",
+                                          nn_descent_niter=20), torch.from_numpy(x).cuda())
+    g = index.graph.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert g.shape == (30000, 32) and (g < 30000).all() and (g != np.arange(30000)[:, None]).all()
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64), index, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    _, ti = oracle.exact_knn(q, x, 10)
+    assert oracle.recall(i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, ti) >= 0.95
