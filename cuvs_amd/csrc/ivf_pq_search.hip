@@ -276,6 +276,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     const uint32_t p = tid < (int)item.count ? a.sorted_pairs[item.first + tid] : 0xffffffffu;
     pid[tid]         = p;
     kthb[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
+    kthb[8 + tid]    = 0u;  // set once any wave inserts a candidate for query `tid` of this item
   }
   // query residuals (L2) or raw rotated queries + list centre (IP); every thread resolves its pair id itself so
   // that this phase needs no barrier after the header loads above
@@ -572,7 +573,10 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         }
       }
       // this wave's k-th best bounds the list's k-th best from above: publish it
-      if (improved && lane == 0 && kd < INFINITY) atomicMin(&kthb[j], float_to_key(kd));
+      if (improved && lane == 0) {
+        kthb[8 + j] = 1u;
+        if (kd < INFINITY) atomicMin(&kthb[j], float_to_key(kd));
+      }
     }
   }
 
@@ -582,8 +586,11 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
   uint32_t* mg_i = reinterpret_cast<uint32_t*>(smem + (size_t)QPB * kScanWaves * a.k * 4);
+  // Queries for which no wave inserted anything (the usual case once the bounds are warm) skip the merge and the
+  // output: the host pre-fills the per-pair candidate rows with "invalid".
 #pragma unroll
   for (int j = 0; j < QPB; ++j) {
+    if (kthb[8 + j] == 0u) continue;  // workgroup-uniform
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int r = e * 64 + lane;
@@ -594,7 +601,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     }
   }
   __syncthreads();
-  if (wave < QPB && wave < (int)item.count) {
+  if (wave < QPB && wave < (int)item.count && kthb[8 + wave] != 0u) {
     const int j = wave;
     wave_top<E> fin;
     fin.init();
@@ -867,6 +874,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                      items.data());
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
+    // per-pair candidate rows start out invalid: the scan only writes the rows of pairs that found something
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)n_pairs * k, res.stream));
+    HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)n_pairs * k * sizeof(uint32_t), res.stream));
     scan_args a;
     a.query_kth = query_kth.data();
     a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
