@@ -588,6 +588,12 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   uint32_t* mg_i = reinterpret_cast<uint32_t*>(smem + (size_t)QPB * kScanWaves * a.k * 4);
   // Queries for which no wave inserted anything (the usual case once the bounds are warm) skip the merge and the
   // output: the host pre-fills the per-pair candidate rows with "invalid".
+  {
+    uint32_t any_ins = 0u;
+#pragma unroll
+    for (int j = 0; j < QPB; ++j) any_ins |= kthb[8 + j];
+    if (any_ins == 0u) return;  // workgroup-uniform: nothing to merge for this item
+  }
 #pragma unroll
   for (int j = 0; j < QPB; ++j) {
     if (kthb[8 + j] == 0u) continue;  // workgroup-uniform
