@@ -21,7 +21,7 @@ constexpr uint32_t kPqGroup = 64;  // rows per interleaved group == wave size
 
 struct ivf_pq_index {
   int metric          = 0;
-  int codebook_kind   = 0;  // PER_SUBSPACE only
+  int codebook_kind   = 0;  // 0 PER_SUBSPACE: one codebook per subspace; 1 PER_CLUSTER: one per list, shared by its subspaces
   elem_t dtype        = elem_t::f32;
   bool dtype_known    = true;   // false after loading a reference-format file (the reference's index is untyped)
   uint32_t n_lists = 0, dim = 0, dim_ext = 0, rot_dim = 0;
@@ -35,7 +35,7 @@ struct ivf_pq_index {
   dev_buf<float> center_norms;  // [n_lists] canonical |c|^2
   dev_buf<float> centers_rot;   // [n_lists, rot_dim]
   dev_buf<float> rotation;      // [rot_dim, dim]
-  dev_buf<float> pq_centers;    // [pq_dim, pq_len, pq_book]
+  dev_buf<float> pq_centers;    // [pq_dim, pq_len, pq_book] (PER_SUBSPACE) or [n_lists, pq_len, pq_book] (PER_CLUSTER)
   dev_buf<uint8_t> codes;       // [padded_rows / 64, n_chunks, 64, 16]
   dev_buf<int64_t> indices;     // [padded_rows] source ids
   dev_buf<uint32_t> list_sizes;   // [n_lists]

@@ -197,6 +197,7 @@ struct encode_args {
   int64_t j0, batch;          // sorted positions [j0, j0 + batch)
   uint32_t rot_dim, pq_dim, pq_len, pq_bits, book, n_chunks, cpc;
   uint32_t dc_sub;            // subspaces staged in LDS per pass (column tile of the residuals)
+  int per_cluster;            // codebook of a row = pq_centers[list] instead of pq_centers[subspace]
   uint8_t* codes;
   int64_t* indices;
 };
@@ -247,7 +248,9 @@ __global__ __launch_bounds__(256) void encode_kernel(encode_args a)
     const uint32_t sub_end = min(a.pq_dim, sub0 + a.dc_sub);
     for (uint32_t s0 = sub0 + wave; s0 < sub_end; s0 += 4) {
       const uint32_t s    = __builtin_amdgcn_readfirstlane(s0);
-      const float* pq     = a.pq_centers + (size_t)s * a.pq_len * a.book;
+      // PER_CLUSTER: every lane (row) reads the codebook of its own list (rows are sorted by list, so a wave
+      // touches one or two codebooks)
+      const float* pq     = a.pq_centers + (size_t)(a.per_cluster ? lab[lane] : s) * a.pq_len * a.book;
       const float* rrow   = r_tile + lane * ldr + (s - sub0) * a.pq_len;
       float best          = INFINITY;
       uint32_t code       = 0;
@@ -378,6 +381,54 @@ void train_per_subset(resources& res, ivf_pq_index& idx, int64_t n_train, const 
                      centers_tmp.data(), idx.pq_centers.data(), (int)idx.pq_dim, (int)idx.pq_len, (int)idx.pq_book);
 }
 
+__global__ void gather_rows_kernel(const float* __restrict__ src, const uint32_t* __restrict__ ids, int64_t cnt,
+                                   int64_t dim, float* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt * dim) out[i] = src[(int64_t)ids[i / dim] * dim + i % dim];
+}
+__global__ void subtract_one_center_kernel(float* __restrict__ resid, int64_t n, int rot_dim,
+                                           const float* __restrict__ center_rot)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * rot_dim) resid[i] -= center_rot[i % rot_dim];
+}
+
+// PER_CLUSTER codebooks (ivf_pq_build.cuh:410-497): for every list, the rotated residuals of its training rows,
+// read as pq_len-dimensional points of ALL subspaces, are clustered into 2^pq_bits codes. Only the first
+// max_train_points_per_pq_code * max(book, pq_dim) points of a list are used, i.e. about that many / pq_dim rows.
+void train_per_cluster(resources& res, ivf_pq_index& idx, int64_t n_train, const float* trainset,
+                       const uint32_t* labels, uint32_t kmeans_n_iters, uint32_t max_train_points_per_pq_code)
+{
+  dev_buf<uint32_t> perm(res, n_train), off(res, idx.n_lists + 1);
+  group_by_label(res, labels, n_train, idx.n_lists, perm.data(), off.data());
+  std::vector<uint32_t> h_off = to_host(res, off.data(), idx.n_lists + 1);
+  const size_t big_enough = (size_t)max_train_points_per_pq_code * std::max<size_t>(idx.pq_book, idx.pq_dim);
+  const int64_t cap_rows  = (int64_t)((big_enough + idx.pq_dim - 1) / idx.pq_dim);
+  dev_buf<float> xb(res, (size_t)cap_rows * idx.dim), rx(res, (size_t)cap_rows * idx.rot_dim);
+  dev_buf<float> centers_tmp(res, (size_t)idx.n_lists * idx.pq_book * idx.pq_len);
+  HIP_TRY(hipMemsetAsync(centers_tmp.data(), 0, centers_tmp.bytes(), res.stream));
+  dev_buf<uint32_t> sub_labels(res, (size_t)cap_rows * idx.pq_dim), sub_sizes(res, idx.pq_book);
+  for (uint32_t l = 0; l < idx.n_lists; ++l) {
+    const int64_t cnt = std::min<int64_t>(h_off[l + 1] - h_off[l], cap_rows);
+    const int64_t pq_n_rows = (int64_t)std::min<size_t>(big_enough, (size_t)cnt * idx.pq_dim);
+    if (pq_n_rows < (int64_t)idx.pq_book) continue;  // too few points for a codebook: it stays zero
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk(cnt * idx.dim, 256)), dim3(256), 0, res.stream, trainset,
+                       perm.data() + h_off[l], cnt, (int64_t)idx.dim, xb.data());
+    pairwise_distance<float, float>(res, xb.data(), cnt, idx.dim, idx.rotation.data(), idx.rot_dim, idx.dim, idx.dim,
+                                    nullptr, nullptr, M_InnerProduct, rx.data(), idx.rot_dim);
+    hipLaunchKernelGGL(subtract_one_center_kernel, dim3(nblk(cnt * idx.rot_dim, 256)), dim3(256), 0, res.stream,
+                       rx.data(), cnt, (int)idx.rot_dim, idx.centers_rot.data() + (size_t)l * idx.rot_dim);
+    kmeans_build_clusters(res, rx.data(), pq_n_rows, idx.pq_len, (int)idx.pq_len, (int)idx.pq_book,
+                          (int)kmeans_n_iters, centers_tmp.data() + (size_t)l * idx.pq_book * idx.pq_len,
+                          sub_labels.data(), sub_sizes.data());
+  }
+  const int64_t total = (int64_t)idx.n_lists * idx.pq_len * idx.pq_book;
+  CUVS_EXPECTS(total < (int64_t(1) << 31), "ivf_pq: PER_CLUSTER codebooks too large");
+  hipLaunchKernelGGL(transpose_pq_centers_kernel, dim3(nblk(total, 256)), dim3(256), 0, res.stream,
+                     centers_tmp.data(), idx.pq_centers.data(), (int)idx.n_lists, (int)idx.pq_len, (int)idx.pq_book);
+}
+
 }  // namespace
 
 void ivf_pq_set_centers(resources& res, ivf_pq_index& idx, const float* centers_flat)
@@ -401,7 +452,7 @@ std::unique_ptr<ivf_pq_index> ivf_pq_make_empty(resources& res, const ivf_pq_bui
                  p.metric == M_L2SqrtUnexpanded || p.metric == M_InnerProduct || p.metric == M_CosineExpanded,
                "ivf_pq: unsupported metric %d (L2, inner product and cosine are built)", p.metric);
   CUVS_EXPECTS(p.pq_bits >= 4 && p.pq_bits <= 8, "ivf_pq: pq_bits must be within [4, 8]");
-  CUVS_EXPECTS(p.codebook_kind == 0, "ivf_pq: only PER_SUBSPACE codebooks are built");
+  CUVS_EXPECTS(p.codebook_kind == 0 || p.codebook_kind == 1, "ivf_pq: invalid codebook_gen value %d", p.codebook_kind);
   auto idx           = std::make_unique<ivf_pq_index>();
   idx->metric        = p.metric;
   idx->codebook_kind = p.codebook_kind;
@@ -420,7 +471,9 @@ std::unique_ptr<ivf_pq_index> ivf_pq_make_empty(resources& res, const ivf_pq_bui
   idx->rotation = dev_buf<float>::persistent(rot.size());
   copy_async(res, idx->rotation.data(), rot.data(), rot.size() * sizeof(float));
   sync(res);
-  idx->pq_centers   = dev_buf<float>::persistent((size_t)idx->pq_dim * idx->pq_len * idx->pq_book);
+  idx->pq_centers   = dev_buf<float>::persistent((size_t)(p.codebook_kind == 1 ? idx->n_lists : idx->pq_dim) * idx->pq_len *
+                                                 idx->pq_book);
+  HIP_TRY(hipMemsetAsync(idx->pq_centers.data(), 0, idx->pq_centers.bytes(), res.stream));
   idx->list_sizes   = dev_buf<uint32_t>::persistent(idx->n_lists);
   idx->list_offsets = dev_buf<uint32_t>::persistent(idx->n_lists + 1);
   HIP_TRY(hipMemsetAsync(idx->list_sizes.data(), 0, idx->list_sizes.bytes(), res.stream));
@@ -458,8 +511,12 @@ std::unique_ptr<ivf_pq_index> ivf_pq_build(resources& res, const ivf_pq_build_pa
   dev_buf<uint32_t> labels(res, n_train);
   kmeans_predict<float>(res, trainset.data(), n_train, dim, centers_flat.data(), (int)p.n_lists, labels.data());
   ivf_pq_set_centers(res, *idx, centers_flat.data());
-  train_per_subset(res, *idx, n_train, trainset.data(), labels.data(), p.kmeans_n_iters,
-                   p.max_train_points_per_pq_code);
+  if (p.codebook_kind == 1)
+    train_per_cluster(res, *idx, n_train, trainset.data(), labels.data(), p.kmeans_n_iters,
+                      p.max_train_points_per_pq_code);
+  else
+    train_per_subset(res, *idx, n_train, trainset.data(), labels.data(), p.kmeans_n_iters,
+                     p.max_train_points_per_pq_code);
   trainset.release();
   labels.release();
   if (p.add_data_on_build) ivf_pq_extend(res, *idx, data, et, n, is_host, nullptr, false);
@@ -550,6 +607,7 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
       a.new_ids = new_ids; a.id_base = idx.size; a.j0 = j0; a.batch = cnt;
       a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len; a.pq_bits = idx.pq_bits;
       a.book = idx.pq_book; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.dc_sub = dc_sub;
+      a.per_cluster = idx.codebook_kind == 1;
       a.codes = codes.data(); a.indices = indices.data();
       hipLaunchKernelGGL(encode_kernel, dim3(nblk(cnt, 64)), dim3(256), smem, res.stream, a);
     }

@@ -111,9 +111,10 @@ cuvsError_t cuvsIvfPqBuildPrecomputed(cuvsResources_t res_h, cuvsIvfPqIndexParam
     CUVS_EXPECTS(dtype_is(pc.dtype, kDLFloat, 32) && dtype_is(ce.dtype, kDLFloat, 32) &&
                    dtype_is(ro.dtype, kDLFloat, 32),
                  "precomputed tensors must be float32");
-    CUVS_EXPECTS(pc.ndim == 3 && pc.shape[0] == idx->pq_dim && pc.shape[1] == idx->pq_len &&
-                   pc.shape[2] == idx->pq_book,
-                 "pq_centers must have shape [pq_dim, pq_len, 2^pq_bits]");
+    CUVS_EXPECTS(pc.ndim == 3 && pc.shape[0] == (idx->codebook_kind == 1 ? idx->n_lists : idx->pq_dim) &&
+                   pc.shape[1] == idx->pq_len && pc.shape[2] == idx->pq_book,
+                 "pq_centers must have shape [pq_dim, pq_len, 2^pq_bits] (PER_SUBSPACE) or [n_lists, pq_len, 2^pq_bits] "
+                 "(PER_CLUSTER)");
     CUVS_EXPECTS(ro.ndim == 2 && ro.shape[0] == idx->rot_dim && ro.shape[1] == idx->dim,
                  "rotation_matrix must have shape [rot_dim, dim]");
     CUVS_EXPECTS(ce.ndim == 2 && ce.shape[0] == idx->n_lists && (ce.shape[1] == idx->dim || ce.shape[1] == idx->dim_ext),
@@ -241,7 +242,8 @@ cuvsError_t cuvsIvfPqIndexGetPqCenters(cuvsIvfPqIndex_t index, DLManagedTensor* 
     auto& idx = get_index(index);
     fill_dl_view(pq_centers, idx.pq_centers.data(), kF32, idx.pq_dim, idx.pq_len, 3, 0);
     delete[] pq_centers->dl_tensor.shape;
-    pq_centers->dl_tensor.shape = new int64_t[3]{(int64_t)idx.pq_dim, (int64_t)idx.pq_len, (int64_t)idx.pq_book};
+    pq_centers->dl_tensor.shape = new int64_t[3]{(int64_t)(idx.codebook_kind == 1 ? idx.n_lists : idx.pq_dim),
+                                                 (int64_t)idx.pq_len, (int64_t)idx.pq_book};
   });
 }
 cuvsError_t cuvsIvfPqIndexGetCentersRot(cuvsIvfPqIndex_t index, DLManagedTensor* centers_rot)

@@ -146,7 +146,8 @@ struct scan_args {
   const uint32_t* sorted_pairs;  // pair ids (q * n_probes + probe rank) grouped by list
   const float* rot_queries;      // [n_queries, rot_dim]
   const float* centers_rot;      // [n_lists, rot_dim]
-  const float* pq_centers;       // [pq_dim, pq_len, book]
+  const float* pq_centers;       // [pq_dim, pq_len, book], or [n_lists, pq_len, book] when per_cluster
+  int per_cluster;
   const uint8_t* codes;
   const uint32_t* list_offsets;
   const uint32_t* list_sizes;
@@ -376,7 +377,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 #pragma unroll
           for (int j = 0; j < QPB; ++j) q[j] = qv[j * a.rot_dim + dd];
           const float cc   = cv[dd];
-          const float* pqr = a.pq_centers + (size_t)dd * book + c0 + lane;
+          const float* pqr = a.pq_centers + (size_t)(a.per_cluster ? L * a.pq_len + l : dd) * book + c0 + lane;
           float p[4];
 #pragma unroll
           for (int t = 0; t < 4; ++t) p[t] = (c0 + t * 64 < book) ? pqr[t * 64] : 0.f;
@@ -411,7 +412,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
       for (int j = 0; j < QPB; ++j) sc[j] = 0.f;
       for (uint32_t l = 0; l < a.pq_len; ++l) {
         const uint32_t dd = s * a.pq_len + l;
-        const float p     = a.pq_centers[(size_t)dd * book + c];
+        const float p     = a.pq_centers[(size_t)(a.per_cluster ? L * a.pq_len + l : dd) * book + c];
         if (!a.is_ip) {
 #pragma unroll
           for (int j = 0; j < QPB; ++j) {
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, per = gridDim.x >> 3;
   const uint32_t chunk = (n_items + 7u) / 8u;
   float pqreg[4][2][4];
-  const bool pq_in_regs = FAST4 && a.pq_len == 2;  // FAST4: pq_dim 64, 8-bit codes
+  const bool pq_in_regs = FAST4 && a.pq_len == 2 && !a.per_cluster;  // FAST4: pq_dim 64, 8-bit codes
   // the code-major LUT addresses LDS absolutely (see cm_lut): fail loudly if the dynamic LDS does not start at 0
   if (FAST4 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   {
@@ -887,6 +888,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.query_kth = query_kth.data();
     a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
     a.rot_queries = rot_q.data(); a.centers_rot = idx.centers_rot.data(); a.pq_centers = idx.pq_centers.data();
+    a.per_cluster = idx.codebook_kind == 1;
     a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data(); a.list_sizes = idx.list_sizes.data();
     a.out_d = cand_d.data(); a.out_i = cand_i.data();
     a.n_probes = n_probes; a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len;

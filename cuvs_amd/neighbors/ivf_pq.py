@@ -206,7 +206,7 @@ def search(search_params, index, queries, k, neighbors=None, distances=None, res
     return distances, neighbors
 
 
-def export_for_oracle(index):
+def export_for_oracle(index, per_cluster=False):
     """Host copy of everything the CPU oracle needs to search the SAME index (tests only)."""
     sizes = index.list_sizes.cpu().numpy().astype(np.uint32)
     codes, ids = [], []
@@ -229,6 +229,7 @@ def export_for_oracle(index):
         pq_bits=index.pq_bits,
         pq_dim=index.pq_dim,
         pq_len=index.pq_len,
+        per_cluster=per_cluster,  # codebook_kind="cluster": pq_centers is [n_lists, pq_len, 2^pq_bits]
     )
 
 

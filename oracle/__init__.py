@@ -117,7 +117,8 @@ def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.
         _p(q), C.c_int64(nq), C.c_int(q.shape[1]), _p(centers), _p(centers_rot), _p(rotation), _p(pqc),
         C.c_int(len(sizes)), C.c_int(rotation.shape[0]), C.c_int(int(exported["pq_dim"])),
         C.c_int(int(exported["pq_len"])), C.c_int(int(exported["pq_bits"])), _p(sizes), _p(start), _p(codes), _p(ids),
-        C.c_int(_metric(metric)), C.c_int(n_probes), C.c_int(k), C.c_float(scale), _p(nb), _p(ds))
+        C.c_int(_metric(metric)), C.c_int(n_probes), C.c_int(k), C.c_float(scale), _p(nb), _p(ds),
+        C.c_int(int(bool(exported.get("per_cluster", False)))))
     return ds, nb
 
 

@@ -311,8 +311,8 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
                                  int n_lists, int rot_dim, int pq_dim, int pq_len, int pq_bits,
                                  const uint32_t* list_sizes, const int64_t* list_start, const uint8_t* codes,
                                  const int64_t* ids, int metric, int n_probes, int k, float scale,
-                                 int64_t* neighbors, float* distances)
-{
+                                 int64_t* neighbors, float* distances, int per_cluster)
+{  /* per_cluster: pq_centers is [n_lists, pq_len, book] (codebook_gen::PER_CLUSTER), else [pq_dim, pq_len, book] */
   const int book = 1 << pq_bits;
   const int bpr  = (pq_dim * pq_bits + 7) / 8;
   const int is_cos = metric == M_CosineExpanded;         /* inner product of unit vectors, reported as 1 - cos */
@@ -365,7 +365,7 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
             float sc = 0.f;
             for (int l = 0; l < pq_len; ++l) {
               int dd  = s * pq_len + l;
-              float pc = pq_centers[(int64_t)dd * book + c];
+              float pc = pq_centers[(int64_t)(per_cluster ? L * pq_len + l : dd) * book + c];
               if (!is_ip) { float diff = qv[dd] - pc; sc = fmaf(diff, diff, sc); }
               else        { sc = fmaf(-qv[dd], cr[dd], sc); sc = fmaf(-qv[dd], pc, sc); }
             }

@@ -205,3 +205,27 @@ def test_cosine_parity_and_recall(n, d, n_lists, pq_dim, pq_bits, k, n_probes):
     truth = np.argsort(cosd, axis=1, kind="stable")[:, :k]
     assert oracle.recall(gi, truth) >= _min_recall(n_probes, n_lists, d, pq_dim, pq_bits) * 0.9
     assert (gd > -1e-3).all() and (gd < 2.001).all()
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+@pytest.mark.parametrize("n,d,n_lists,pq_dim,pq_bits,k,n_probes", [(6000, 64, 8, 32, 8, 16, 4), (8000, 64, 4, 64, 8, 10, 4),
+                                                                   (6000, 40, 6, 20, 5, 10, 6)])
+def test_per_cluster_codebooks(metric, n, d, n_lists, pq_dim, pq_bits, k, n_probes):
+    """codebook_gen::PER_CLUSTER (ivf_pq_build.cuh:410-497): one codebook per list shared by its subspaces; search
+    parity with the oracle on the same index, the reference's recall threshold, pq_centers getter shape."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(n, d, 120, seed=n + pq_dim)
+    index = _build(x, n_lists=n_lists, metric=metric, pq_dim=pq_dim, pq_bits=pq_bits, kmeans_n_iters=10,
+                   codebook_kind="cluster")
+    assert tuple(index.pq_centers.shape) == (n_lists, d // pq_dim if d % pq_dim == 0 else -(-d // pq_dim), 1 << pq_bits)
+    gd, gi = _search(index, q, k, n_probes=n_probes)
+    ex = ivf_pq.export_for_oracle(index, per_cluster=True)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.4f}"
+    assert (gd == od).all(), f"max |d| diff {np.abs(gd - od).max()}"
+    td, ti = oracle.exact_knn(q, x, k, metric=metric)
+    assert oracle.recall(gi, ti) >= _min_recall(n_probes, n_lists, d, pq_dim, pq_bits) * 0.9
+    # every source id is stored exactly once
+    ids = np.concatenate(ex["ids"])
+    assert len(ids) == n and len(np.unique(ids)) == n
