@@ -14,12 +14,8 @@ extern "C" {
 #endif
 /* dataset [n, dim] and queries [m, dim]: fp32 / fp16 / int8 / uint8 (same dtype); candidates int64 [m, n_cand];
  * indices int64 [m, k], distances fp32 [m, k], k <= n_cand. Candidates outside [0, n) are skipped. */
-CUVS_EXPORT cuvsError_t cuvsRefine(cuvsResources_t res,
-                                   DLManagedTensor* dataset,
-                                   DLManagedTensor* queries,
-                                   DLManagedTensor* candidates,
-                                   cuvsDistanceType metric,
-                                   DLManagedTensor* indices,
+CUVS_EXPORT cuvsError_t cuvsRefine(cuvsResources_t res, DLManagedTensor* dataset, DLManagedTensor* queries,
+                                   DLManagedTensor* candidates, cuvsDistanceType metric, DLManagedTensor* indices,
                                    DLManagedTensor* distances);
 #ifdef __cplusplus
 }
