@@ -295,7 +295,7 @@ __global__ void nnd_inverse_perm_kernel(const uint32_t* __restrict__ perm, int64
 
 template <typename T>
 void nnd_run(resources& res, const T* data, elem_t et, int64_t n, int64_t dim, uint32_t K, int mode, const float* norms,
-             int n_iters, uint32_t* knn_out)
+             int n_iters, uint32_t* knn_out, uint32_t* keys_out, float termination_threshold)
 {
   const uint32_t P = std::max<uint32_t>(64, K);
   dev_buf<uint32_t> ids(res, (size_t)n * K), keys(res, (size_t)n * K), worst(res, n), prop_ids(res, (size_t)n * P),
@@ -366,7 +366,7 @@ void nnd_run(resources& res, const T* data, elem_t et, int64_t n, int64_t dim, u
     copy_async(res, &upd, n_updates.data(), sizeof(upd));
     sync(res);
     // nn_descent.cuh: stop when fewer than termination_threshold (1e-4) of the n*K slots changed
-    if (it > 0 && (double)upd < 1e-4 * (double)n * (double)K) break;
+    if (it > 0 && (double)upd < (double)termination_threshold * (double)n * (double)K) break;
     hipLaunchKernelGGL(nnd_sample_kernel, dim3(g4), dim3(256), 0, res.stream, st);
     hipLaunchKernelGGL((nnd_join_kernel<T>), dim3((unsigned)n), dim3(kJoinThreads), 0, res.stream, st, data, dim, mode,
                        norms);
@@ -375,6 +375,7 @@ void nnd_run(resources& res, const T* data, elem_t et, int64_t n, int64_t dim, u
   }
   // ids without flags -> output (invalid entries stay 0xffffffff)
   HIP_TRY(hipMemcpyAsync(knn_out, ids.data(), ids.bytes(), hipMemcpyDeviceToDevice, res.stream));
+  if (keys_out) HIP_TRY(hipMemcpyAsync(keys_out, keys.data(), keys.bytes(), hipMemcpyDeviceToDevice, res.stream));
   sync(res);
 }
 
@@ -395,17 +396,17 @@ __global__ void nnd_strip_flags_kernel(uint32_t* ids, int64_t total)
 // kNN graph [n, K] (uint32, sorted by distance, self excluded) by NN-descent. data: device rows of element type et.
 // metric: L2 family / inner product / cosine (cosine needs canonical row norms |x|).
 void knn_graph_nn_descent(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, uint32_t K, int metric,
-                          const float* norms, int n_iters, uint32_t* knn)
+                          const float* norms, int n_iters, uint32_t* knn, uint32_t* keys_out, float termination_threshold)
 {
   CUVS_EXPECTS(n > (int64_t)K, "nn_descent: need more rows than the graph degree");
   const int mode = metric == M_InnerProduct ? 1 : (metric == M_CosineExpanded ? 2 : 0);
   CUVS_EXPECTS(mode != 2 || norms != nullptr, "nn_descent: cosine needs row norms");
   if (n_iters <= 0) n_iters = 20;
   switch (et) {
-    case elem_t::f32: nnd_run<float>(res, static_cast<const float*>(data), et, n, dim, K, mode, norms, n_iters, knn); break;
-    case elem_t::f16: nnd_run<__half>(res, static_cast<const __half*>(data), et, n, dim, K, mode, norms, n_iters, knn); break;
-    case elem_t::i8: nnd_run<int8_t>(res, static_cast<const int8_t*>(data), et, n, dim, K, mode, norms, n_iters, knn); break;
-    case elem_t::u8: nnd_run<uint8_t>(res, static_cast<const uint8_t*>(data), et, n, dim, K, mode, norms, n_iters, knn); break;
+    case elem_t::f32: nnd_run<float>(res, static_cast<const float*>(data), et, n, dim, K, mode, norms, n_iters, knn, keys_out, termination_threshold); break;
+    case elem_t::f16: nnd_run<__half>(res, static_cast<const __half*>(data), et, n, dim, K, mode, norms, n_iters, knn, keys_out, termination_threshold); break;
+    case elem_t::i8: nnd_run<int8_t>(res, static_cast<const int8_t*>(data), et, n, dim, K, mode, norms, n_iters, knn, keys_out, termination_threshold); break;
+    case elem_t::u8: nnd_run<uint8_t>(res, static_cast<const uint8_t*>(data), et, n, dim, K, mode, norms, n_iters, knn, keys_out, termination_threshold); break;
   }
   hipLaunchKernelGGL(nnd_strip_flags_kernel, dim3(grid_blocks(n * (int64_t)K, 256)), dim3(256), 0, res.stream, knn,
                      n * (int64_t)K);
@@ -431,3 +432,156 @@ extern "C" __attribute__((visibility("default"))) int cuvsAmdNnDescent(uintptr_t
     knn_graph_nn_descent(res, data, elem_t::f32, n, dim, K, metric, norms.data(), n_iters, knn);
   });
 }
+
+// ------------------------------------------------------------------ cuvsNNDescent* C API (c/src/neighbors/nn_descent.cpp)
+#include <cuvs/neighbors/nn_descent.h>
+
+namespace {
+struct nnd_index {
+  int64_t n = 0;
+  uint32_t degree = 0;
+  int metric = 0;
+  cuvs_amd::dev_buf<uint32_t> graph;  // [n, degree]
+  cuvs_amd::dev_buf<float> dist;      // [n, degree] (return_distances)
+};
+
+__global__ void nnd_slice_kernel(const uint32_t* __restrict__ ids, const uint32_t* __restrict__ keys, int64_t n, uint32_t K,
+                                 uint32_t degree, int metric, uint32_t* __restrict__ g, float* __restrict__ d)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * (int64_t)degree) return;
+  const int64_t r = i / degree, c = i % degree;
+  g[i] = ids[r * K + c];
+  if (d != nullptr) {
+    float v = cuvs_amd::key_to_float(keys[r * K + c]);
+    if (metric == cuvs_amd::M_InnerProduct) v = -v;
+    if (metric == cuvs_amd::M_L2SqrtExpanded || metric == cuvs_amd::M_L2SqrtUnexpanded) v = sqrtf(v);
+    d[i] = ids[r * K + c] == 0xffffffffu ? FLT_MAX : v;
+  }
+}
+}  // namespace
+
+extern "C" {
+cuvsError_t cuvsNNDescentIndexParamsCreate(cuvsNNDescentIndexParams_t* params)
+{
+  return (cuvsError_t)cuvs_amd::translate_exceptions([=] {
+    CUVS_EXPECTS(params != nullptr, "params is null");
+    // defaults of cuvs::neighbors::nn_descent::index_params (nn_descent.hpp:62-67)
+    *params = new cuvsNNDescentIndexParams{L2Expanded, 2.0f, 64, 128, 20, 0.0001f, true, NND_DIST_COMP_AUTO};
+  });
+}
+cuvsError_t cuvsNNDescentIndexParamsDestroy(cuvsNNDescentIndexParams_t params)
+{
+  return (cuvsError_t)cuvs_amd::translate_exceptions([=] { delete params; });
+}
+cuvsError_t cuvsNNDescentIndexCreate(cuvsNNDescentIndex_t* index)
+{
+  return (cuvsError_t)cuvs_amd::translate_exceptions([=] {
+    CUVS_EXPECTS(index != nullptr, "index is null");
+    *index = new cuvsNNDescentIndex{0, DLDataType{kDLUInt, 32, 1}};
+  });
+}
+cuvsError_t cuvsNNDescentIndexDestroy(cuvsNNDescentIndex_t index)
+{
+  return (cuvsError_t)cuvs_amd::translate_exceptions([=] {
+    if (index == nullptr) return;
+    delete reinterpret_cast<nnd_index*>(index->addr);
+    delete index;
+  });
+}
+
+cuvsError_t cuvsNNDescentBuild(cuvsResources_t res_h, cuvsNNDescentIndexParams_t params, DLManagedTensor* dataset_tensor,
+                               DLManagedTensor* graph_tensor, cuvsNNDescentIndex_t index)
+{
+  using namespace cuvs_amd;
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *reinterpret_cast<resources*>(res_h);
+    CUVS_EXPECTS(params && dataset_tensor && index, "null argument");
+    auto& ds = dataset_tensor->dl_tensor;
+    CUVS_EXPECTS(ds.ndim == 2 && is_c_contiguous(ds), "dataset must be a row-major matrix");
+    const elem_t et = elem_of(ds.dtype);  // fails for unsupported dtypes
+    const int64_t n = ds.shape[0], dim = ds.shape[1];
+    const int metric = (int)params->metric;
+    CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct || metric == M_CosineExpanded,
+                 "nn_descent: unsupported metric %d", metric);
+    const uint32_t degree = (uint32_t)params->graph_degree;
+    uint32_t K = (uint32_t)std::max(params->intermediate_graph_degree, params->graph_degree);
+    K          = (uint32_t)std::min<int64_t>(K, n - 1);
+    CUVS_EXPECTS(degree >= 1 && degree <= K, "nn_descent: graph_degree must be in [1, min(intermediate_graph_degree, n - 1)]");
+    const void* data = dl_data(ds);
+    dev_buf<char> staged;
+    if (!is_device_accessible(ds)) {
+      staged = dev_buf<char>(res, (size_t)n * dim * elem_size(et));
+      copy_async(res, staged.data(), data, staged.bytes());
+      data = staged.data();
+    }
+    dev_buf<float> norms;
+    if (metric == M_CosineExpanded) {
+      norms = dev_buf<float>(res, n);
+      switch (et) {
+        case elem_t::f32: row_norms<float>(res, static_cast<const float*>(data), n, dim, dim, norms.data(), true); break;
+        case elem_t::f16: row_norms<__half>(res, static_cast<const __half*>(data), n, dim, dim, norms.data(), true); break;
+        case elem_t::i8: row_norms<int8_t>(res, static_cast<const int8_t*>(data), n, dim, dim, norms.data(), true); break;
+        case elem_t::u8: row_norms<uint8_t>(res, static_cast<const uint8_t*>(data), n, dim, dim, norms.data(), true); break;
+      }
+    }
+    dev_buf<uint32_t> ids(res, (size_t)n * K), keys(res, (size_t)n * K);
+    knn_graph_nn_descent(res, data, et, n, dim, K, metric, norms.data(), (int)params->max_iterations, ids.data(),
+                         keys.data(), params->termination_threshold > 0.f ? params->termination_threshold : 1e-4f);
+    auto idx    = std::make_unique<nnd_index>();
+    idx->n      = n;
+    idx->degree = degree;
+    idx->metric = metric;
+    idx->graph  = dev_buf<uint32_t>::persistent((size_t)n * degree);
+    if (params->return_distances) idx->dist = dev_buf<float>::persistent((size_t)n * degree);
+    hipLaunchKernelGGL(nnd_slice_kernel, dim3(grid_blocks(n * (int64_t)degree, 256)), dim3(256), 0, res.stream, ids.data(),
+                       keys.data(), n, K, degree, metric, idx->graph.data(), idx->dist.data());
+    HIP_TRY(hipGetLastError());
+    if (graph_tensor != nullptr) {
+      auto& g = graph_tensor->dl_tensor;
+      CUVS_EXPECTS(dtype_is(g.dtype, kDLUInt, 32) && g.ndim == 2 && g.shape[0] == n && g.shape[1] == degree &&
+                     is_c_contiguous(g),
+                   "graph must be uint32 [n, graph_degree]");
+      copy_async(res, dl_data(g), idx->graph.data(), idx->graph.bytes());
+    }
+    sync(res);
+    delete reinterpret_cast<nnd_index*>(index->addr);
+    index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    index->dtype = DLDataType{kDLUInt, 32, 1};
+  });
+}
+
+cuvsError_t cuvsNNDescentIndexGetGraph(cuvsResources_t res_h, cuvsNNDescentIndex_t index, DLManagedTensor* graph)
+{
+  using namespace cuvs_amd;
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *reinterpret_cast<resources*>(res_h);
+    CUVS_EXPECTS(index && index->addr && graph, "nn-descent index is not built");
+    auto& idx = *reinterpret_cast<nnd_index*>(index->addr);
+    auto& g   = graph->dl_tensor;
+    CUVS_EXPECTS(dtype_is(g.dtype, kDLUInt, 32) && g.ndim == 2 && is_c_contiguous(g), "graph must be a uint32 matrix");
+    CUVS_EXPECTS(g.shape[0] == idx.n, "Output graph has incorrect number of rows");
+    CUVS_EXPECTS(g.shape[1] == idx.degree, "Output graph has incorrect number of cols");
+    copy_async(res, dl_data(g), idx.graph.data(), idx.graph.bytes());
+    sync(res);
+  });
+}
+
+cuvsError_t cuvsNNDescentIndexGetDistances(cuvsResources_t res_h, cuvsNNDescentIndex_t index, DLManagedTensor* distances)
+{
+  using namespace cuvs_amd;
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *reinterpret_cast<resources*>(res_h);
+    CUVS_EXPECTS(index && index->addr && distances, "nn-descent index is not built");
+    auto& idx = *reinterpret_cast<nnd_index*>(index->addr);
+    CUVS_EXPECTS(idx.dist.data() != nullptr,
+                 "nn-descent index doesn't contain distances - set return_distances when building");
+    auto& d = distances->dl_tensor;
+    CUVS_EXPECTS(dtype_is(d.dtype, kDLFloat, 32) && d.ndim == 2 && is_c_contiguous(d), "distances must be a float32 matrix");
+    CUVS_EXPECTS(d.shape[0] == idx.n, "Output distances has incorrect number of rows");
+    CUVS_EXPECTS(d.shape[1] == idx.degree, "Output distances has incorrect number of cols");
+    copy_async(res, dl_data(d), idx.dist.data(), idx.dist.bytes());
+    sync(res);
+  });
+}
+}  // extern "C"

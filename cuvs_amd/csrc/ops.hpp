@@ -74,8 +74,11 @@ void kmeans_predict(resources& res, const T* x, int64_t n, int64_t dim, const fl
 // ---------------------------------------------------------------- nn_descent.hip
 // kNN graph [n, K] (uint32 ids sorted by distance, self excluded, 0xffffffff = none) by NN-descent; `norms` = canonical
 // |x| per row for the cosine metric (else unused).
+// keys_out (optional, [n, K]): order-preserving keys of the distances (device_utils.hpp key_to_float; inner product
+// negated). termination_threshold: stop when fewer than this share of the n*K slots changed in a round.
 void knn_graph_nn_descent(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, uint32_t K, int metric,
-                          const float* norms, int n_iters, uint32_t* knn);
+                          const float* norms, int n_iters, uint32_t* knn, uint32_t* keys_out = nullptr,
+                          float termination_threshold = 1e-4f);
 
 // ---------------------------------------------------------------- refine.hip
 // exact re-ranking of candidate ids; out sorted by (distance, id). All pointers device.

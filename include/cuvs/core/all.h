@@ -7,3 +7,5 @@
 #include <cuvs/neighbors/ivf_flat.h>
 #include <cuvs/neighbors/ivf_pq.h>
 #include <cuvs/neighbors/cagra.h>
+#include <cuvs/neighbors/nn_descent.h>
+#include <cuvs/neighbors/refine.h>

@@ -6,6 +6,7 @@
 #include <cuvs/neighbors/ivf_flat.h>
 #include <cuvs/neighbors/ivf_pq.h>
 #include <cuvs/neighbors/cagra.h>
+#include <cuvs/neighbors/nn_descent.h>
 #define SZ(T) printf("sizeof " #T " %zu\n", sizeof(T))
 #define OFF(T, F) printf("offsetof " #T "." #F " %zu\n", offsetof(T, F))
 int main(void)
@@ -38,6 +39,11 @@ int main(void)
   OFF(struct cuvsCagraSearchParams, rand_xor_mask); OFF(struct cuvsCagraSearchParams, persistent);
   OFF(struct cuvsCagraSearchParams, persistent_lifetime); OFF(struct cuvsCagraSearchParams, persistent_device_usage);
   SZ(struct cuvsCagraCompressionParams); SZ(struct cuvsIvfPqParams); SZ(struct cuvsAceParams);
+  SZ(struct cuvsNNDescentIndexParams); SZ(cuvsNNDescentIndex);
+  OFF(struct cuvsNNDescentIndexParams, metric); OFF(struct cuvsNNDescentIndexParams, graph_degree);
+  OFF(struct cuvsNNDescentIndexParams, intermediate_graph_degree); OFF(struct cuvsNNDescentIndexParams, max_iterations);
+  OFF(struct cuvsNNDescentIndexParams, termination_threshold); OFF(struct cuvsNNDescentIndexParams, return_distances);
+  OFF(struct cuvsNNDescentIndexParams, dist_comp_dtype);
   SZ(struct cuvsCagraExtendParams);
   SZ(cuvsFilter); SZ(cuvsBruteForceIndex); SZ(cuvsIvfFlatIndex); SZ(cuvsIvfPqIndex); SZ(cuvsCagraIndex);
   SZ(cuvsResources_t);

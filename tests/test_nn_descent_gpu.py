@@ -66,3 +66,39 @@ def test_cagra_build_with_nn_descent():
     torch.cuda.synchronize()
     _, ti = oracle.exact_knn(q, x, 10)
     assert oracle.recall(i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, ti) >= 0.95
+
+
+@pytest.mark.parametrize("host_dataset", [False, True])
+def test_standalone_c_api(host_dataset):
+    """cuvsNNDescentBuild / GetGraph / GetDistances (c/include/cuvs/neighbors/nn_descent.h; reference python test
+    python/cuvs/cuvs/tests/test_nn_descent.py: graph recall against brute force)."""
+    import torch
+    from cuvs_amd._lib import CuvsError
+    from cuvs_amd.neighbors import nn_descent
+
+    rng = np.random.default_rng(3)
+    n, d, deg = 12000, 24, 32
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    out_graph = np.zeros((n, deg), np.uint32) if host_dataset else None
+    idx = nn_descent.build(nn_descent.IndexParams(graph_degree=deg, intermediate_graph_degree=48),
+                           x if host_dataset else torch.from_numpy(x).cuda(), graph=out_graph)
+    g = idx.graph.cpu().numpy().view(np.uint32).astype(np.int64)
+    dist = idx.distances.cpu().numpy()
+    assert g.shape == (n, deg) and dist.shape == (n, deg) and (g < n).all()
+    if out_graph is not None:
+        assert (out_graph.astype(np.int64) == g).all()
+    rows = rng.choice(n, 200, replace=False)
+    d2 = np.sum(x[rows] ** 2, 1)[:, None] + np.sum(x ** 2, 1)[None, :] - 2 * x[rows] @ x.T
+    d2[np.arange(len(rows)), rows] = np.inf
+    truth = np.argsort(d2, axis=1, kind="stable")[:, :deg]
+    rec = np.mean([len(np.intersect1d(g[r], t)) for r, t in zip(rows, truth)]) / deg
+    assert rec >= 0.9, rec
+    # distances are the squared L2 distances of the listed neighbours, ascending
+    want = ((x[rows][:, None, :] - x[g[rows]]) ** 2).sum(-1)
+    np.testing.assert_allclose(dist[rows], want, rtol=1e-4, atol=1e-4)
+    assert (np.diff(dist[rows], axis=1) >= 0).all()
+    # no distances when not requested
+    idx2 = nn_descent.build(nn_descent.IndexParams(graph_degree=16, intermediate_graph_degree=32, return_distances=False,
+                                                   max_iterations=3), torch.from_numpy(x[:2000]).cuda())
+    with pytest.raises(CuvsError):
+        idx2.distances
