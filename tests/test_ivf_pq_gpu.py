@@ -229,3 +229,22 @@ def test_per_cluster_codebooks(metric, n, d, n_lists, pq_dim, pq_bits, k, n_prob
     # every source id is stored exactly once
     ids = np.concatenate(ex["ids"])
     assert len(ids) == n and len(np.unique(ids)) == n
+
+
+@pytest.mark.parametrize("lut", [np.float32, np.float16])
+def test_two_phase_schedule_and_early_stop(lut, monkeypatch):
+    """Batches of 256+ queries scan every query's nearest probe first (head launch) and prune the tail launch with
+    the early stop (compute_score_impl.cuh:70-71). Neither may change a result: fp32 LUT = the oracle bit for bit,
+    fp16 LUT = the same kernel with both switched off."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(30000, 128, 400, seed=77)
+    index = _build(x, n_lists=64, pq_dim=64, pq_bits=8, kmeans_n_iters=10)   # pq_dim 64 / 8 bits: the FAST4 kernel
+    gd, gi = _search(index, q, 20, n_probes=16, lut_dtype=lut, internal_distance_dtype=lut)
+    if lut == np.float32:
+        od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, 20, 16)
+        assert (gi == oi).all() and (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_HEAD_PROBES", "0")
+    monkeypatch.setenv("CUVS_AMD_SCAN_DEBUG", "8")
+    pd, pi = _search(index, q, 20, n_probes=16, lut_dtype=lut, internal_distance_dtype=lut)
+    assert (gi == pi).all() and (gd == pd).all()
