@@ -278,6 +278,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     pid[tid]         = p;
     kthb[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
     kthb[8 + tid]    = 0u;  // set once any wave inserts a candidate for query `tid` of this item
+    if (tid == 0) kthb[12] = 0u;  // tile ticket of this item (see the scan loop)
   }
   // query residuals (L2) or raw rotated queries + list centre (IP); every thread resolves its pair id itself so
   // that this phase needs no barrier after the header loads above
@@ -456,17 +457,27 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   // the list at a different rotation, so that at any moment the CUs touch different parts of the list: one of them
   // pulls a line into L2, the others find it there later, instead of all of them missing on it together.
   const uint32_t rot = (a.dbg & 64) ? 0u : (item.first / QPB);
-  for (uint32_t it0 = 0; it0 < n_iter; ++it0) {
-    const uint32_t it    = (it0 + rot) % n_iter;
-    const uint32_t tile0 = (it * kScanWaves + wave) * 64;  // in-list position of lane 0
+  // Tiles (64 rows) are handed to the waves through a ticket in LDS: with the early stop a tile costs anything
+  // between one and four chunks of gathers, and a fixed tile -> wave map left waves idle at the merge barrier.
+  // A wave draws its next ticket before it works on the current tile, so the LDS round trip is off the path.
+  const uint32_t n_tiles = n_iter == 0 ? 0u : (len + 63u) / 64u;
+  const uint32_t rot_t   = n_tiles ? (rot * kScanWaves) % n_tiles : 0u;
+  uint32_t ticket = 0u;
+  if (lane == 0) ticket = atomicAdd(&kthb[12], 1u);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  while (ticket < n_tiles) {
+    const uint32_t tile  = (ticket + rot_t) % n_tiles;
+    uint32_t next = 0u;
+    if (lane == 0) next = atomicAdd(&kthb[12], 1u);
+    const uint32_t tile0 = tile * 64;  // in-list position of lane 0
     const uint32_t v     = tile0 + lane;
     const bool valid     = v < len;
-    if (tile0 >= len) continue;  // wave-uniform
+    struct advance_t { uint32_t& t; uint32_t& n; __device__ ~advance_t() { t = __builtin_amdgcn_readfirstlane(n); } } advance{ticket, next};
     acc_t acc;
     bool cand = valid;  // lanes that may still hold a candidate for some query of the item
     if (FAST4) {
       uint4 cur[4];
-      const uint4* cp = codes16 + ((g0 + (size_t)it * kScanWaves + wave) * 4) * 64 + lane;
+      const uint4* cp = codes16 + ((g0 + (size_t)tile) * 4) * 64 + lane;
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];  // padded rows of a group are zero-filled: readable
       if (!(a.dbg & 2) && prune) {
@@ -505,7 +516,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         acc.add(lut[cur[0].x & 0xff]);
       }
     } else {
-      const size_t g  = g0 + (size_t)it * kScanWaves + wave;
+      const size_t g  = g0 + (size_t)tile;
       const uint4* cp = codes16 + (g * a.n_chunks) * 64 + lane;
       if (a.pq_bits == 8) {
         for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
