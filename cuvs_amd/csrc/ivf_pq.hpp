@@ -72,6 +72,9 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
                    const int64_t* new_ids, bool ids_on_host);
 void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_index& idx, const void* queries,
                    elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances);
+// labels [n] (uint32) and contiguous bit-packed codes [n, ceil(pq_dim*pq_bits/8)] of device rows (cuvsIvfPqTransform)
+void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data, elem_t et, int64_t n, uint32_t* out_labels,
+                      uint8_t* out_codes);
 // [n_take, ceil(pq_dim*pq_bits/8)] contiguous bit-packed codes of list `label` starting at `offset`
 void ivf_pq_unpack_list(resources& res, const ivf_pq_index& idx, uint32_t label, uint32_t offset,
                         uint32_t n_take, uint8_t* out);

@@ -625,6 +625,64 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
   idx.padded_rows = total;
 }
 
+// cuvsIvfPqTransform (c/src/neighbors/ivf_pq.cpp:595-630, ivf_pq::transform): labels[n] = list of every row and
+// codes[n, ceil(pq_dim * pq_bits / 8)] = its PQ code as a contiguous bitstream - the extend path's labelling and
+// encoding, with the codes written row by row (identity placement) instead of into the lists.
+void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data, elem_t et, int64_t n, uint32_t* out_labels,
+                      uint8_t* out_codes)
+{
+  if (n == 0) return;
+  CUVS_EXPECTS(n < (int64_t(1) << 31), "transform: at most 2^31 rows per call");
+  const int64_t dim = idx.dim;
+  dev_buf<float> centers_flat(res, (size_t)idx.n_lists * dim);
+  HIP_TRY(hipMemcpy2DAsync(centers_flat.data(), dim * sizeof(float), idx.centers.data(), idx.dim_ext * sizeof(float),
+                           dim * sizeof(float), idx.n_lists, hipMemcpyDeviceToDevice, res.stream));
+  const int64_t eb = std::max<int64_t>(64, std::min<int64_t>(n, (int64_t(1) << 26) / std::max<int64_t>(dim, idx.rot_dim)) / 64 * 64);
+  dev_buf<float> xb(res, (size_t)eb * dim), rx(res, (size_t)eb * idx.rot_dim);
+  dev_buf<uint32_t> perm(res, eb), zeros(res, idx.n_lists + 1);
+  dev_buf<int64_t> ids_tmp(res, eb);
+  dev_buf<uint8_t> tmp_codes(res, (size_t)eb * idx.n_chunks * 16);
+  HIP_TRY(hipMemsetAsync(zeros.data(), 0, zeros.bytes(), res.stream));
+  {
+    std::vector<uint32_t> h(eb);
+    for (int64_t i = 0; i < eb; ++i) h[i] = (uint32_t)i;
+    copy_async(res, perm.data(), h.data(), eb * sizeof(uint32_t));
+    sync(res);
+  }
+  CUVS_EXPECTS(idx.pq_len <= 240, "encode: pq_len %u too large", idx.pq_len);
+  const uint32_t dc_sub = std::min<uint32_t>(idx.pq_dim, std::max<uint32_t>(1, 240 / idx.pq_len));
+  size_t smem = ((size_t)64 * (dc_sub * idx.pq_len + 1) + 2) * sizeof(float) + 64 * sizeof(int64_t) +
+                64 * sizeof(uint32_t) + (size_t)64 * idx.pq_dim;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem));
+  const uint32_t bpr = (idx.pq_dim * idx.pq_bits + 7) / 8;
+  for (int64_t r0 = 0; r0 < n; r0 += eb) {
+    const int64_t cnt = std::min(eb, n - r0);
+    load_range_as_float(res, data, et, false, dim, r0, cnt, xb.data());
+    if (idx.metric == M_CosineExpanded) normalize_rows(res, xb.data(), cnt, dim);
+    fused_l2_argmin<float>(res, xb.data(), cnt, dim, centers_flat.data(), idx.n_lists, dim, idx.center_norms.data(),
+                           out_labels + r0, nullptr);
+    pairwise_distance<float, float>(res, xb.data(), cnt, dim, idx.rotation.data(), idx.rot_dim, dim, dim, nullptr, nullptr,
+                                    M_InnerProduct, rx.data(), idx.rot_dim);
+    HIP_TRY(hipMemsetAsync(tmp_codes.data(), 0, tmp_codes.bytes(), res.stream));
+    encode_args a;
+    a.rx = rx.data(); a.perm = perm.data(); a.labels = out_labels + r0; a.new_off = zeros.data();
+    a.old_sizes = zeros.data(); a.list_off = zeros.data();  // flat row = position in the batch
+    a.centers_rot = idx.centers_rot.data(); a.pq_centers = idx.pq_centers.data();
+    a.new_ids = nullptr; a.id_base = 0; a.j0 = 0; a.batch = cnt;
+    a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len; a.pq_bits = idx.pq_bits;
+    a.book = idx.pq_book; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.dc_sub = dc_sub;
+    a.per_cluster = idx.codebook_kind == 1;
+    a.codes = tmp_codes.data(); a.indices = ids_tmp.data();
+    hipLaunchKernelGGL(encode_kernel, dim3(nblk(cnt, 64)), dim3(256), smem, res.stream, a);
+    hipLaunchKernelGGL(unpack_list_kernel, dim3(nblk(cnt * (int64_t)bpr, 256)), dim3(256), 0, res.stream, tmp_codes.data(),
+                       idx.n_chunks, idx.codes_per_chunk, idx.pq_bits, idx.pq_dim, (int64_t)0, (uint32_t)cnt, bpr,
+                       out_codes + (size_t)r0 * bpr);
+    HIP_TRY(hipGetLastError());
+  }
+  sync(res);
+}
+
 void ivf_pq_unpack_list(resources& res, const ivf_pq_index& idx, uint32_t label, uint32_t offset, uint32_t n_take,
                         uint8_t* out)
 {

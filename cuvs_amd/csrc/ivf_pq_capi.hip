@@ -509,11 +509,29 @@ cuvsError_t cuvsIvfPqDeserialize(cuvsResources_t res_h, const char* filename, cu
     index->dtype = dl;
   });
 }
-cuvsError_t cuvsIvfPqTransform(cuvsResources_t, cuvsIvfPqIndex_t, DLManagedTensor*, DLManagedTensor*,
-                               DLManagedTensor*)
+cuvsError_t cuvsIvfPqTransform(cuvsResources_t res_h, cuvsIvfPqIndex_t index, DLManagedTensor* input_dataset,
+                               DLManagedTensor* output_labels, DLManagedTensor* output_dataset)
 {
-  return (cuvsError_t)translate_exceptions(
-    [=] { CUVS_FAIL("cuvsIvfPqTransform is outside the search hot path and not built (SURVEY 8b)"); });
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_index(index);
+    CUVS_EXPECTS(input_dataset && output_labels && output_dataset, "null argument");
+    auto& in = input_dataset->dl_tensor;
+    auto& ol = output_labels->dl_tensor;
+    auto& oc = output_dataset->dl_tensor;
+    CUVS_EXPECTS(is_device_accessible(in), "input_dataset should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(ol), "output_labels should have device compatible memory");
+    CUVS_EXPECTS(is_device_accessible(oc), "output_dataset should have device compatible memory");
+    CUVS_EXPECTS(dtype_is(ol.dtype, kDLUInt, 32), "output_labels must have a uint32 dtype ");
+    CUVS_EXPECTS(dtype_is(oc.dtype, kDLUInt, 8), "output_dataset must have a uint8 dtype");
+    CUVS_EXPECTS(in.ndim == 2 && is_c_contiguous(in) && in.shape[1] == idx.dim, "input_dataset must be [n, dim] row-major");
+    const uint32_t bpr = (idx.pq_dim * idx.pq_bits + 7) / 8;
+    CUVS_EXPECTS(ol.shape[0] == in.shape[0] && oc.ndim == 2 && oc.shape[0] == in.shape[0] && oc.shape[1] == bpr &&
+                   is_c_contiguous(oc),
+                 "output_labels must be [n] and output_dataset [n, %u]", bpr);
+    ivf_pq_transform(res, idx, dl_data(in), elem_of(in.dtype), in.shape[0], static_cast<uint32_t*>(dl_data(ol)),
+                     static_cast<uint8_t*>(dl_data(oc)));
+  });
 }
 
 }  // extern "C"

@@ -244,3 +244,18 @@ def load(filename, resources=None):
     check(lib().cuvsIvfPqDeserialize(resources.get_c_obj(), C.c_char_p(filename.encode()), idx._p))
     idx.trained = True
     return idx
+
+
+@auto_sync_resources
+def transform(index, dataset, resources=None):
+    """cuvsIvfPqTransform: (labels [n] uint32 stored in an int32 tensor, codes [n, ceil(pq_dim * pq_bits / 8)] uint8) of
+    device rows: the list each row would go to and its PQ code as a contiguous bitstream."""
+    ds = dataset.contiguous()
+    n = ds.shape[0]
+    bpr = (index.pq_dim * index.pq_bits + 7) // 8
+    labels = torch.empty((n,), dtype=torch.int32, device=ds.device)
+    codes = torch.empty((n, bpr), dtype=torch.uint8, device=ds.device)
+    td, tl, tc = Tensor(ds), Tensor(labels), Tensor(codes)
+    tl.m.dl_tensor.dtype.code = 1  # uint32
+    check(lib().cuvsIvfPqTransform(resources.get_c_obj(), index._p, td.ptr, tl.ptr, tc.ptr))
+    return labels, codes

@@ -248,3 +248,24 @@ def test_two_phase_schedule_and_early_stop(lut, monkeypatch):
     monkeypatch.setenv("CUVS_AMD_SCAN_DEBUG", "8")
     pd, pi = _search(index, q, 20, n_probes=16, lut_dtype=lut, internal_distance_dtype=lut)
     assert (gi == pi).all() and (gd == pd).all()
+
+
+@pytest.mark.parametrize("pq_bits,codebook_kind", [(8, "subspace"), (5, "subspace"), (8, "cluster")])
+def test_transform_matches_the_index_contents(pq_bits, codebook_kind):
+    """cuvsIvfPqTransform (labels + contiguous codes) must reproduce, row by row, what build() stored in the lists."""
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, _ = _gen(5000, 48, 1, seed=5)
+    index = _build(x, n_lists=12, pq_dim=16, pq_bits=pq_bits, kmeans_n_iters=10, codebook_kind=codebook_kind)
+    labels, codes = ivf_pq.transform(index, torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    labels, codes = labels.cpu().numpy().view(np.uint32), codes.cpu().numpy()
+    ex = ivf_pq.export_for_oracle(index, per_cluster=codebook_kind == "cluster")
+    seen = 0
+    for L in range(12):
+        ids = ex["ids"][L]
+        assert (labels[ids] == L).all()
+        assert (codes[ids] == ex["codes"][L]).all()
+        seen += len(ids)
+    assert seen == 5000
