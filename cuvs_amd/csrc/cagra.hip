@@ -796,6 +796,75 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   }
 }
 
+// ------------------------------------------------------------------ extend (add_nodes.cuh)
+// New rows are added chunk by chunk: every new node searches the CURRENT graph (so later chunks can link to
+// earlier ones) and takes the `degree` nearest results as its edges; each existing node that was picked gives its
+// last (weakest-ranked) edges - at most degree/2 of them, one atomic slot counter per node - to the new nodes that
+// picked it, which is how the reference wires the reverse edges (add_nodes.cuh: rev edges replace the tail of the
+// list). The dataset and the graph become storage owned by the index.
+__global__ void extend_rows_kernel(const uint32_t* __restrict__ nb, int64_t m, uint32_t degree, int64_t n_cur,
+                                   uint32_t* __restrict__ graph, uint32_t* __restrict__ rev_cnt)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * (int64_t)degree) return;
+  const int64_t v = i / degree;
+  const uint32_t j = (uint32_t)(i % degree);
+  uint32_t u = nb[i];
+  if (u >= (uint32_t)n_cur) u = (uint32_t)((v * 2654435761ull + j) % (uint64_t)n_cur);  // search gave fewer results
+  graph[(n_cur + v) * degree + j] = u;
+  if (j < degree / 2) {  // the closer half of the new node's neighbours get a reverse edge
+    const uint32_t slot = atomicAdd(&rev_cnt[u], 1u);
+    if (slot < degree / 2) graph[(int64_t)u * degree + (degree - 1 - slot)] = (uint32_t)(n_cur + v);
+  }
+}
+
+void cagra_extend(resources& res, cagra_index& idx, const void* new_rows, bool new_is_host, int64_t m, uint32_t max_chunk)
+{
+  if (m == 0) return;
+  CUVS_EXPECTS(idx.data != nullptr && idx.graph.data() != nullptr, "cagra::extend: index has no graph/dataset");
+  CUVS_EXPECTS((idx.n + m) * (int64_t)idx.degree < (int64_t(1) << 32), "cagra: n * degree must be below 2^32");
+  const size_t esz = elem_size(idx.dtype), row_bytes = (size_t)idx.dim * esz;
+  const int64_t n0 = idx.n, n1 = idx.n + m;
+  auto data  = dev_buf<char>::persistent((size_t)n1 * row_bytes);
+  auto graph = dev_buf<uint32_t>::persistent((size_t)n1 * idx.degree);
+  copy_async(res, data.data(), idx.data, (size_t)n0 * row_bytes);
+  copy_async(res, data.data() + (size_t)n0 * row_bytes, new_rows, (size_t)m * row_bytes);
+  copy_async(res, graph.data(), idx.graph.data(), (size_t)n0 * idx.degree * sizeof(uint32_t));
+  sync(res);
+  (void)new_is_host;
+  idx.owned = std::move(data);
+  idx.data  = idx.owned.data();
+  idx.graph = std::move(graph);
+  const int64_t chunk = std::max<int64_t>(1, max_chunk == 0 ? 8192 : (int64_t)max_chunk);
+  cuvsCagraSearchParams sp{};
+  sp.itopk_size   = std::max<size_t>(64, 2 * (size_t)idx.degree);
+  sp.search_width = 2;
+  sp.algo         = SINGLE_CTA;  // k = degree may exceed what a 32-entry walker list can return
+  sp.hashmap_max_fill_rate = 0.5f;
+  sp.num_random_samplings  = 1;
+  sp.rand_xor_mask         = 0x128394;
+  dev_buf<uint32_t> nb(res, (size_t)chunk * idx.degree), rev_cnt(res, n1);
+  dev_buf<float> nd(res, (size_t)chunk * idx.degree);
+  // reverse-edge slots are counted over the whole call: a later chunk must not overwrite the reverse edges an
+  // earlier chunk placed in the same list tail
+  HIP_TRY(hipMemsetAsync(rev_cnt.data(), 0, rev_cnt.bytes(), res.stream));
+  for (int64_t c0 = 0; c0 < m; c0 += chunk) {
+    const int64_t cm = std::min(chunk, m - c0);
+    idx.n = n0 + c0;              // the graph searched by this chunk: old rows + the chunks before it
+    cagra_set_norms(res, idx);    // cosine: |x| of everything searchable so far
+    const int k = (int)std::min<int64_t>(idx.degree, idx.n);
+    cagra_search(res, idx, sp, static_cast<const char*>(idx.data) + (size_t)idx.n * row_bytes, cm, k, nb.data(), false,
+                 nd.data(), nullptr);
+    if (k < (int)idx.degree) CUVS_FAIL("cagra::extend: the index must hold at least graph_degree rows");
+    hipLaunchKernelGGL(extend_rows_kernel, dim3(grid_blocks(cm * (int64_t)idx.degree, 256)), dim3(256), 0, res.stream,
+                       nb.data(), cm, idx.degree, idx.n, idx.graph.data(), rev_cnt.data());
+    HIP_TRY(hipGetLastError());
+  }
+  idx.n = n1;
+  cagra_set_norms(res, idx);
+  sync(res);
+}
+
 std::unique_ptr<cagra_index> cagra_build(resources& res, const cuvsCagraIndexParams& p, const void* data, elem_t et,
                                          int64_t n, int64_t dim, bool is_host)
 {
@@ -1243,8 +1312,19 @@ cuvsError_t cuvsCagraSerializeToHnswlib(cuvsResources_t res_h, const char* filen
 
 #define CAGRA_UNBUILT(NAME, SIG, WHY)                                                                   \
   cuvsError_t NAME SIG { return (cuvsError_t)translate_exceptions([=] { CUVS_FAIL(#NAME ": " WHY); }); }
-CAGRA_UNBUILT(cuvsCagraExtend, (cuvsResources_t, cuvsCagraExtendParams_t, DLManagedTensor*, cuvsCagraIndex_t),
-              "add_nodes is outside the north-star search path (SURVEY 2.1 #5)")
+cuvsError_t cuvsCagraExtend(cuvsResources_t res_h, cuvsCagraExtendParams_t params, DLManagedTensor* additional_dataset,
+                            cuvsCagraIndex_t index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    auto& idx = get_cagra(index);
+    CUVS_EXPECTS(additional_dataset != nullptr, "additional_dataset is null");
+    auto& t = additional_dataset->dl_tensor;
+    CUVS_EXPECTS(t.ndim == 2 && is_c_contiguous(t) && t.shape[1] == idx.dim, "additional_dataset must be [m, dim] row-major");
+    CUVS_EXPECTS(elem_of(t.dtype) == idx.dtype, "additional_dataset dtype differs from the index dtype");
+    cagra_extend(res, idx, dl_data(t), !is_device_accessible(t), t.shape[0], params ? params->max_chunk_size : 0u);
+  });
+}
 CAGRA_UNBUILT(cuvsCagraMerge, (cuvsResources_t, cuvsCagraIndexParams_t, cuvsCagraIndex_t*, size_t, cuvsFilter,
                                cuvsCagraIndex_t),
               "index merge is outside the north-star search path (SURVEY 2.1 #5)")

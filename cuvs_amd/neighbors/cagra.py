@@ -142,6 +142,27 @@ def build(index_params, dataset, resources=None):
     return idx
 
 
+class _CExtendParams(C.Structure):
+    _fields_ = [("max_chunk_size", C.c_uint32)]
+
+
+@auto_sync_resources
+def extend(index, additional_dataset, max_chunk_size=0, resources=None):
+    """cuvsCagraExtend: add rows to a built index (reference: python/cuvs/cuvs/neighbors/cagra extend). The index
+    owns its dataset afterwards."""
+    ds = additional_dataset.contiguous() if isinstance(additional_dataset, torch.Tensor) else np.ascontiguousarray(additional_dataset)
+    p = C.POINTER(_CExtendParams)()
+    check(lib().cuvsCagraExtendParamsCreate(C.byref(p)))
+    try:
+        p.contents.max_chunk_size = max_chunk_size
+        t = Tensor(ds)
+        check(lib().cuvsCagraExtend(resources.get_c_obj(), p, t.ptr, index._p))
+    finally:
+        lib().cuvsCagraExtendParamsDestroy(p)
+    index._keep = None
+    return index
+
+
 @auto_sync_resources
 def from_graph(graph, dataset, metric="sqeuclidean", resources=None):
     """cuvsCagraIndexFromArgs: index from an existing [n, degree] uint32 graph."""

@@ -168,3 +168,32 @@ def test_cosine_metric(algo, tmp_path):
     d1, i1 = cagra.search(cagra.SearchParams(itopk_size=64, algo="single_cta"), index, torch.from_numpy(q).cuda(), 10)
     torch.cuda.synchronize()
     assert torch.equal(i1, i2) and torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "cosine"])
+def test_extend(metric):
+    """cuvsCagraExtend (add_nodes.cuh): rows added in chunks stay findable, old rows stay findable, graph stays valid."""
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((26000, 32)).astype(np.float32)
+    q = rng.standard_normal((300, 32)).astype(np.float32)
+    index = cagra.build(cagra.IndexParams(metric=metric, intermediate_graph_degree=64, graph_degree=32),
+                        torch.from_numpy(x[:20000]).cuda())
+    cagra.extend(index, torch.from_numpy(x[20000:]).cuda(), max_chunk_size=2048)
+    assert len(index) == 26000
+    g = index.graph.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert g.shape == (26000, 32) and (g < 26000).all()
+    assert (g[:20000] >= 20000).any() and (g[20000:] >= 20000).any()   # reverse edges and links among new rows
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64), index, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    i = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    if metric == "cosine":
+        xn = x / np.linalg.norm(x, axis=1, keepdims=True)
+        truth = np.argsort(-(q @ xn.T), axis=1, kind="stable")[:, :10]
+    else:
+        _, truth = oracle.exact_knn(q, x, 10)
+    assert oracle.recall(i, truth) >= 0.9, oracle.recall(i, truth)
+    # the new rows take their fair share of the answers
+    assert abs((truth >= 20000).mean() - (i >= 20000).mean()) < 0.04
