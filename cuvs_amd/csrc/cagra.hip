@@ -1310,8 +1310,6 @@ cuvsError_t cuvsCagraSerializeToHnswlib(cuvsResources_t res_h, const char* filen
   });
 }
 
-#define CAGRA_UNBUILT(NAME, SIG, WHY)                                                                   \
-  cuvsError_t NAME SIG { return (cuvsError_t)translate_exceptions([=] { CUVS_FAIL(#NAME ": " WHY); }); }
 cuvsError_t cuvsCagraExtend(cuvsResources_t res_h, cuvsCagraExtendParams_t params, DLManagedTensor* additional_dataset,
                             cuvsCagraIndex_t index)
 {
@@ -1325,9 +1323,39 @@ cuvsError_t cuvsCagraExtend(cuvsResources_t res_h, cuvsCagraExtendParams_t param
     cagra_extend(res, idx, dl_data(t), !is_device_accessible(t), t.shape[0], params ? params->max_chunk_size : 0u);
   });
 }
-CAGRA_UNBUILT(cuvsCagraMerge, (cuvsResources_t, cuvsCagraIndexParams_t, cuvsCagraIndex_t*, size_t, cuvsFilter,
-                               cuvsCagraIndex_t),
-              "index merge is outside the north-star search path (SURVEY 2.1 #5)")
-#undef CAGRA_UNBUILT
+
+// Physical merge (cagra_merge.cuh): the datasets of the input indexes are concatenated in order and a new graph is
+// built over all rows with `params`; ids of index i are shifted by the sizes of the indexes before it.
+cuvsError_t cuvsCagraMerge(cuvsResources_t res_h, cuvsCagraIndexParams_t params, cuvsCagraIndex_t* indices,
+                           size_t num_indices, cuvsFilter filter, cuvsCagraIndex_t output_index)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(params && indices && output_index && num_indices > 0, "null argument");
+    CUVS_EXPECTS(filter.type == NO_FILTER, "cagra::merge: filters are not supported");
+    auto& first = get_cagra(indices[0]);
+    int64_t total = 0;
+    for (size_t i = 0; i < num_indices; ++i) {
+      auto& ix = get_cagra(indices[i]);
+      CUVS_EXPECTS(ix.data != nullptr, "cagra::merge: index %zu has no dataset", i);
+      CUVS_EXPECTS(ix.dim == first.dim && ix.dtype == first.dtype, "cagra::merge: indexes differ in dim or dtype");
+      total += ix.n;
+    }
+    const size_t row_bytes = (size_t)first.dim * elem_size(first.dtype);
+    auto all = dev_buf<char>::persistent((size_t)total * row_bytes);
+    size_t off = 0;
+    for (size_t i = 0; i < num_indices; ++i) {
+      auto& ix = get_cagra(indices[i]);
+      copy_async(res, all.data() + off, ix.data, (size_t)ix.n * row_bytes);
+      off += (size_t)ix.n * row_bytes;
+    }
+    sync(res);
+    auto idx   = cagra_build(res, *params, all.data(), first.dtype, total, first.dim, false);
+    idx->owned = std::move(all);  // the merged index owns the concatenated rows (idx->data already points at them)
+    delete reinterpret_cast<cagra_index*>(output_index->addr);
+    output_index->addr  = reinterpret_cast<uintptr_t>(idx.release());
+    output_index->dtype = indices[0]->dtype;
+  });
+}
 
 }  // extern "C"

@@ -208,3 +208,19 @@ def load(filename, resources=None):
     check(lib().cuvsCagraDeserialize(resources.get_c_obj(), C.c_char_p(filename.encode()), idx._p))
     idx.trained = True
     return idx
+
+
+@auto_sync_resources
+def merge(index_params, indices, resources=None):
+    """cuvsCagraMerge: one index over the concatenated datasets of `indices` (ids shifted by the preceding sizes)."""
+    out = Index()
+    arr = (C.POINTER(_CIndex) * len(indices))(*[ix._p for ix in indices])
+
+    class _Filter(C.Structure):
+        _fields_ = [("addr", C.c_size_t), ("type", C.c_int)]
+
+    index_params._p.contents.build_algo = max(index_params._algo, 1) if index_params._algo != 3 else 3
+    check(lib().cuvsCagraMerge(resources.get_c_obj(), index_params._p, arr, C.c_size_t(len(indices)), _Filter(0, 0), out._p))
+    index_params._p.contents.build_algo = 1
+    out.trained = True
+    return out

@@ -197,3 +197,20 @@ def test_extend(metric):
     assert oracle.recall(i, truth) >= 0.9, oracle.recall(i, truth)
     # the new rows take their fair share of the answers
     assert abs((truth >= 20000).mean() - (i >= 20000).mean()) < 0.04
+
+
+def test_merge():
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((9000, 24)).astype(np.float32)
+    q = rng.standard_normal((100, 24)).astype(np.float32)
+    p = cagra.IndexParams(intermediate_graph_degree=48, graph_degree=24)
+    parts = [cagra.build(p, torch.from_numpy(x[a:b]).cuda()) for a, b in ((0, 4000), (4000, 7000), (7000, 9000))]
+    merged = cagra.merge(p, parts)
+    assert len(merged) == 9000 and merged.graph_degree == 24
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64), merged, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    _, truth = oracle.exact_knn(q, x, 10)
+    assert oracle.recall(i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, truth) >= 0.95
