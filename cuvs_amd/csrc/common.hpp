@@ -207,10 +207,10 @@ inline bool dtype_is(const DLDataType& d, uint8_t code, uint8_t bits)
 {
   return d.code == code && d.bits == bits && d.lanes == 1;
 }
-inline void* dl_data(const DLTensor& t)
-{
-  return static_cast<char*>(t.data) + t.byte_offset;
-}
+// The reference never reads DLTensor::byte_offset (c/src/core/detail/interop.hpp builds its mdspans from `data`
+// alone) and its own C tests leave the field uninitialised on the stack (c/tests/neighbors/run_ivf_pq_c.c:24-33),
+// so honouring it would crash callers that work against the reference: `data` is the address, as there.
+inline void* dl_data(const DLTensor& t) { return t.data; }
 
 enum class elem_t : int { f32 = 0, f16 = 1, i8 = 2, u8 = 3 };
 inline elem_t elem_of(const DLDataType& d)

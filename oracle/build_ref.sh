@@ -1,0 +1,17 @@
+#!/bin/bash
+# Compiles the REFERENCE's own C-API test drivers (pure C, they only call cuvs*() entry points) from the sources
+# where they lie under /root/reference against THIS repo's headers and library. Output: oracle/_ref/libref_c_drivers.so
+# (git-ignored, travels to the GPU box). tests/test_reference_c_drivers_gpu.py runs them: the code the reference
+# uses to test its C ABI then drives cuvs_amd/libcuvs_c.so unchanged - source-level proof of the drop-in boundary.
+# These files hold no search algorithm (the reference's hot path is CUDA + un-vendored RAFT and cannot be built
+# here); nothing is copied into the repository.
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd); ROOT=$(cd "$HERE/.." && pwd)
+REF=/root/reference/c/tests/neighbors
+[ -d "$REF" ] || { echo "no reference tree: skipping"; exit 0; }
+mkdir -p "$HERE/_ref"
+gcc -O1 -fPIC -shared -std=c11 -I"$ROOT/include" \
+    "$REF/run_brute_force_c.c" "$REF/run_ivf_flat_c.c" "$REF/run_ivf_pq_c.c" \
+    -L"$ROOT/cuvs_amd" -lcuvs_c -Wl,-rpath,'$ORIGIN/../../cuvs_amd' \
+    -o "$HERE/_ref/libref_c_drivers.so"
+echo "built $HERE/_ref/libref_c_drivers.so"
