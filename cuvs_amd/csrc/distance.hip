@@ -340,3 +340,59 @@ extern "C" __attribute__((visibility("default"))) int cuvsAmdFusedArgmin(uintptr
     fused_l2_argmin<float>(r, q, m, dim, centers, n, dim, cn.data(), labels, nullptr);
   });
 }
+
+#include <cuvs/distance/pairwise_distance.h>
+
+extern "C" cuvsError_t cuvsPairwiseDistance(cuvsResources_t res_h, DLManagedTensor* x_tensor, DLManagedTensor* y_tensor,
+                                            DLManagedTensor* dist_tensor, cuvsDistanceType metric, float metric_arg)
+{
+  using namespace cuvs_amd;
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    (void)metric_arg;
+    CUVS_EXPECTS(x_tensor && y_tensor && dist_tensor, "null argument");
+    auto& x = x_tensor->dl_tensor;
+    auto& y = y_tensor->dl_tensor;
+    auto& d = dist_tensor->dl_tensor;
+    CUVS_EXPECTS(is_device_accessible(x) && is_device_accessible(y) && is_device_accessible(d),
+                 "Inputs to cuvsPairwiseDistance must all have device compatible memory");
+    CUVS_EXPECTS(x.dtype.code == y.dtype.code && x.dtype.bits == y.dtype.bits,
+                 "Inputs to cuvsPairwiseDistance must all have the same dtype");
+    CUVS_EXPECTS(x.ndim == 2 && y.ndim == 2 && d.ndim == 2 && is_c_contiguous(x) && is_c_contiguous(y) && is_c_contiguous(d),
+                 "Inputs to cuvsPairwiseDistance must all have the same layout (row-major is built; col-major is not)");
+    const int64_t m = x.shape[0], n = y.shape[0], dim = x.shape[1];
+    CUVS_EXPECTS(y.shape[1] == dim && d.shape[0] == m && d.shape[1] == n, "cuvsPairwiseDistance: shape mismatch");
+    CUVS_EXPECTS(dtype_is(d.dtype, kDLFloat, 32), "cuvsPairwiseDistance: distances must be float32");
+    CUVS_EXPECTS(metric_supported((int)metric), "cuvsPairwiseDistance: unsupported metric %d", (int)metric);
+    const bool sq = (int)metric == M_CosineExpanded;
+    dev_buf<float> xn(res, m), yn(res, n);
+    float* out = static_cast<float*>(dl_data(d));
+    if (dtype_is(x.dtype, kDLFloat, 32)) {
+      const float* xp = static_cast<const float*>(dl_data(x));
+      const float* yp = static_cast<const float*>(dl_data(y));
+      if ((int)metric != M_InnerProduct) {
+        row_norms<float>(res, xp, m, dim, dim, xn.data(), sq);
+        row_norms<float>(res, yp, n, dim, dim, yn.data(), sq);
+      }
+      for (int64_t r0 = 0; r0 < m; r0 += 32768) {  // the distance kernel takes at most 65535 row tiles per launch
+        const int64_t mr = std::min<int64_t>(32768, m - r0);
+        pairwise_distance<float, float>(res, xp + r0 * dim, mr, dim, yp, n, dim, dim, xn.data() + r0, yn.data(), (int)metric,
+                                        out + r0 * n, n);
+      }
+    } else if (dtype_is(x.dtype, kDLFloat, 16)) {
+      const __half* xp = static_cast<const __half*>(dl_data(x));
+      const __half* yp = static_cast<const __half*>(dl_data(y));
+      if ((int)metric != M_InnerProduct) {
+        row_norms<__half>(res, xp, m, dim, dim, xn.data(), sq);
+        row_norms<__half>(res, yp, n, dim, dim, yn.data(), sq);
+      }
+      for (int64_t r0 = 0; r0 < m; r0 += 32768) {
+        const int64_t mr = std::min<int64_t>(32768, m - r0);
+        pairwise_distance<__half, __half>(res, xp + r0 * dim, mr, dim, yp, n, dim, dim, xn.data() + r0, yn.data(),
+                                          (int)metric, out + r0 * n, n);
+      }
+    } else {
+      CUVS_FAIL("Unsupported DLtensor dtype: %d and bits: %d", (int)x.dtype.code, (int)x.dtype.bits);
+    }
+  });
+}

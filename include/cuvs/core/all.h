@@ -2,6 +2,7 @@
 #pragma once
 #include <cuvs/core/c_api.h>
 #include <cuvs/distance/distance.h>
+#include <cuvs/distance/pairwise_distance.h>
 #include <cuvs/neighbors/common.h>
 #include <cuvs/neighbors/brute_force.h>
 #include <cuvs/neighbors/ivf_flat.h>

@@ -82,3 +82,19 @@ def test_run_ivf_c(driver):
     torch.cuda.synchronize()
     td, ti = oracle.exact_knn(q, x, 8)
     _eval_neighbours(nb.cpu().numpy(), ds.cpu().numpy(), ti, td, 1e-3, n_probes / n_lists)
+
+
+@pytest.mark.parametrize("metric,code", [("sqeuclidean", 0), ("inner_product", 6), ("cosine", 2)])
+def test_run_pairwise_distance_c(metric, code):
+    """c/tests/distance/run_pairwise_distance_c.c through cuvsPairwiseDistance (c/tests/distance/pairwise_distance_c.cu
+    configuration: 8096 x 32 against 128 x 32); result must equal the canonical oracle bit for bit."""
+    import torch
+
+    lib = _drivers()
+    x, q, tx, tq, _, _ = _data()
+    out = torch.empty((8096, 128), dtype=torch.float32, device="cuda")
+    lib.run_pairwise_distance(C.c_int64(8096), C.c_int64(128), C.c_int64(32), C.c_void_p(tx.data_ptr()),
+                              C.c_void_p(tq.data_ptr()), C.c_void_p(out.data_ptr()), None, C.c_int(code))
+    torch.cuda.synchronize()
+    want = oracle.pairwise(x, q, metric=metric)
+    assert (out.cpu().numpy() == want).all()
