@@ -54,3 +54,20 @@ def test_param_struct_layouts_match_the_reference_headers(tmp_path):
     ours = subprocess.check_output([str(exe)]).decode()
     want = open(os.path.join(ROOT, "tests", "golden", "abi_layout.txt")).read()
     assert ours == want
+
+
+def test_reference_c_sources_compile_and_link_against_our_headers(tmp_path):
+    """The reference's pure-C API drivers and its include-guard test compile unchanged against include/ and link
+    against libcuvs_c.so with no unresolved symbol (run on the GPU by tests/test_reference_c_drivers_gpu.py).
+    Needs the reference tree, which only exists in the build container."""
+    ref = "/root/reference/c/tests"
+    if not os.path.isdir(ref):
+        pytest.skip("no reference tree on this machine")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-I", inc, os.path.join(ref, "core", "headers.c")])
+    so = tmp_path / "drivers.so"
+    srcs = [os.path.join(ref, "neighbors", f) for f in ("run_brute_force_c.c", "run_ivf_flat_c.c", "run_ivf_pq_c.c")]
+    srcs.append(os.path.join(ref, "distance", "run_pairwise_distance_c.c"))
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror=implicit-function-declaration", "-fPIC", "-shared", "-I", inc,
+                           *srcs, "-L", os.path.join(ROOT, "cuvs_amd"), "-lcuvs_c", "-Wl,--no-undefined", "-o", str(so)])
+    assert so.exists()
