@@ -8,17 +8,20 @@
 // LUT entry per code byte. On CDNA4 that loop is bound by LDS gather issue (ds_read_b32: 64 lanes / >=2 clk),
 // not by HBM, so the schedule here is different:
 //   * (query, probe) pairs are grouped by list (stable radix sort by list id) and cut into work items of
-//     QPB pairs that probe the SAME list;
-//   * a 1024-thread workgroup builds ONE interleaved LUT for its QPB queries in LDS — entry (s, code) holds
-//     the QPB partial distances side by side (8 bytes: 2 x fp32 or 4 x fp16) — so a single ds_read_b64
-//     gather serves QPB queries, and the list's code bytes are read once per work item (1 KiB coalesced
-//     per wave and chunk from the 64-row interleaved layout, mostly L2/Infinity-Cache hits because work
-//     items of one list are adjacent in the grid);
-//   * candidates below the running k-th distance are appended to per-query LDS buffers with one
-//     wave-aggregated LDS atomic; an owner wave per query drains its buffer into a register-resident
-//     sorted top list (lane i holds rank i; up to 4 ranks per lane for k <= 256) with ballot/readlane
-//     insertion — the wave64 replacement of the reference's warp_sort block queue.
-// Results: exact for the given codes/LUT precision — every (query, probe) pair yields its true top-k by
+//     QPB pairs that probe the SAME list; a batch of 256+ queries is scheduled in two phases (every query's
+//     nearest probe first), so that the per-query k-th bound is warm when the bulk of the probes runs;
+//   * a persistent 1024-thread workgroup per CU draws work items from a per-XCD ticket counter and builds ONE
+//     interleaved LUT for its QPB queries in LDS - entry (s, code) holds the QPB partial distances side by
+//     side (8 bytes: 2 x fp32 or 4 x fp16), code-major with padded rows so that a gather address is a single
+//     SDWA multiply - and a single ds_read_b64 gather serves QPB queries; the list's code bytes are read once
+//     per work item (1 KiB coalesced per wave and chunk from the 64-row interleaved layout, L2 hits for all but
+//     the first item of a list);
+//   * every wave keeps a private sorted top list per query in registers (lane i holds rank i; up to 4 ranks per
+//     lane for k <= 256; DPP insertion) - no workgroup barrier inside the scan; 64-row tiles are handed to the
+//     waves through an LDS ticket; lanes whose partial sums already exceed every k-th bound sit out the rest of
+//     the row (early stop), whole waves skip it; the 16 wave lists of a query are merged once per item, and only
+//     for queries that inserted anything.
+// Results: exact for the given codes/LUT precision - every (query, probe) pair yields its true top-k by
 // (distance, row) order, independent of scheduling.
 #include "ivf_pq.hpp"
 #include "ops.hpp"
