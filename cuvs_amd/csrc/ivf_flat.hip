@@ -9,8 +9,10 @@
 // MI355X design (same schedule as ivf_pq_search.hip): all lists in one flat allocation, rows interleaved in
 // groups of 64 (one wave64 lane per row, 16-byte chunks -> 1 KiB coalesced per wave load); (query, probe)
 // pairs are grouped by list and 8 queries that probe the same list share one pass over its rows: the query
-// tile sits in LDS as [dim][8] so two broadcast ds_read_b128 feed 8 fma chains per loaded element. Per-wave
-// register top lists + shared k-th bounds as in the PQ scan. In-list order is ascending source id.
+// tile of an item ([dim][8] fp32, written by a small pre-kernel) is read with wave-uniform addresses through
+// the scalar cache, so the 8 fma chains per loaded element (4 packed fp32 add + 4 packed fp32 fma) cost no LDS
+// cycles. Per-wave register top lists + shared k-th bounds, two-phase schedule and a per-tile early stop as in
+// the PQ scan. Cosine = dot products + in-kernel row norms. In-list order is ascending source id.
 #include "ivf_common.hpp"
 #include "serialize.hpp"
 #include "npy_io.hpp"
