@@ -89,6 +89,7 @@ def check(status):
 _NP_DT = {
     np.dtype("float32"): (kDLFloat, 32),
     np.dtype("float16"): (kDLFloat, 16),
+    np.dtype("float64"): (kDLFloat, 64),
     np.dtype("int8"): (kDLInt, 8),
     np.dtype("uint8"): (kDLUInt, 8),
     np.dtype("int32"): (kDLInt, 32),

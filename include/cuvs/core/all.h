@@ -1,6 +1,7 @@
 /* Umbrella include for the hot-path C ABI (reference: c/include/cuvs/core/all.h). */
 #pragma once
 #include <cuvs/core/c_api.h>
+#include <cuvs/cluster/kmeans.h>
 #include <cuvs/distance/distance.h>
 #include <cuvs/distance/pairwise_distance.h>
 #include <cuvs/neighbors/common.h>

@@ -209,3 +209,41 @@ def kmeans_balanced_fit(x, n_clusters, n_iters=20, hierarchical=True):
     lib().oracle_kmeans_balanced_fit(_p(x), C.c_int64(n), C.c_int(dim), C.c_int(n_clusters), C.c_int(n_iters),
                                      C.c_int(int(hierarchical)), _p(centers), _p(labels))
     return centers, labels
+
+
+def kmeans_lloyd(x, init_centroids, max_iter=300, tol=1e-4, sample_weights=None):
+    """Lloyd iterations as the reference runs them (cpp/src/cluster/detail/kmeans.cuh:813-925): per iteration the
+    cost against the CURRENT centroids, weighted means (a cluster with zero weight keeps its centroid,
+    kmeans_common.cuh:585-600), squared centroid shift, then the stopping rule of kmeans_common.cuh:629-648 evaluated in
+    float32 like the reference's DataT. Weights are rescaled to sum to n (kmeans.cuh:713-726). Arithmetic is float64
+    here: the HIP path is compared within a stated tolerance, not bit for bit.
+    Returns (centroids float32 [k, d], labels int32 [n], inertia, n_iter)."""
+    x64 = np.asarray(x, dtype=np.float64)
+    cur = np.asarray(init_centroids, dtype=np.float64).copy()
+    n, k = x64.shape[0], cur.shape[0]
+    w = np.ones(n) if sample_weights is None else np.asarray(sample_weights, dtype=np.float64) * n / np.sum(sample_weights)
+
+    def assign(c):
+        d = ((x64 * x64).sum(1)[:, None] - 2.0 * x64 @ c.T) + (c * c).sum(1)[None, :]
+        lab = d.argmin(1)
+        return lab, ((x64 - c[lab]) ** 2).sum(1)
+
+    prior, ran = 0.0, 0
+    for it in range(1, max_iter + 1):
+        lab, dist = assign(cur)
+        cost = float((w * dist).sum())
+        nxt = cur.copy()
+        for c in range(k):
+            m = lab == c
+            ws = w[m].sum()
+            if ws > 0:
+                nxt[c] = (w[m, None] * x64[m]).sum(0) / ws
+        shift = float(((nxt - cur) ** 2).sum())
+        cur, ran = nxt, it
+        done = cost != 0.0 and it > 1 and np.float32(cost / prior) > np.float32(1.0) - np.float32(tol)
+        done = done or np.float32(shift) < np.float32(tol)
+        prior = cost
+        if done:
+            break
+    lab, dist = assign(cur)
+    return cur.astype(np.float32), lab.astype(np.int32), float((w * dist).sum()), ran

@@ -7,6 +7,7 @@
 #include <cuvs/neighbors/ivf_pq.h>
 #include <cuvs/neighbors/cagra.h>
 #include <cuvs/neighbors/nn_descent.h>
+#include <cuvs/cluster/kmeans.h>
 #define SZ(T) printf("sizeof " #T " %zu\n", sizeof(T))
 #define OFF(T, F) printf("offsetof " #T "." #F " %zu\n", offsetof(T, F))
 int main(void)
@@ -55,5 +56,17 @@ int main(void)
          (int)SINGLE_CTA, (int)MULTI_CTA, (int)AUTO);
   printf("enum CUDA_R_32F %d CUDA_R_16F %d CUDA_R_8I %d CUDA_R_8U %d\n", (int)CUDA_R_32F, (int)CUDA_R_16F,
          (int)CUDA_R_8I, (int)CUDA_R_8U);
+  SZ(struct cuvsKMeansParams); SZ(struct cuvsKMeansParams_v2);
+  OFF(struct cuvsKMeansParams, metric); OFF(struct cuvsKMeansParams, n_clusters); OFF(struct cuvsKMeansParams, init);
+  OFF(struct cuvsKMeansParams, max_iter); OFF(struct cuvsKMeansParams, tol); OFF(struct cuvsKMeansParams, n_init);
+  OFF(struct cuvsKMeansParams, oversampling_factor); OFF(struct cuvsKMeansParams, batch_samples);
+  OFF(struct cuvsKMeansParams, batch_centroids); OFF(struct cuvsKMeansParams, inertia_check);
+  OFF(struct cuvsKMeansParams, hierarchical); OFF(struct cuvsKMeansParams, hierarchical_n_iters);
+  OFF(struct cuvsKMeansParams, streaming_batch_size); OFF(struct cuvsKMeansParams, init_size);
+  OFF(struct cuvsKMeansParams_v2, batch_centroids); OFF(struct cuvsKMeansParams_v2, hierarchical);
+  OFF(struct cuvsKMeansParams_v2, hierarchical_n_iters); OFF(struct cuvsKMeansParams_v2, streaming_batch_size);
+  OFF(struct cuvsKMeansParams_v2, init_size);
+  printf("enum KMeansPlusPlus %d Random %d Array %d KMEANS %d KMEANS_BALANCED %d\n", (int)KMeansPlusPlus, (int)Random,
+         (int)Array, (int)CUVS_KMEANS_TYPE_KMEANS, (int)CUVS_KMEANS_TYPE_KMEANS_BALANCED);
   return 0;
 }

@@ -40,3 +40,14 @@ BF_KAT_POINTS = np.array(
 )
 BF_KAT_K = 2
 BF_KAT_LABELS = np.array([0, 0, 0, 0, 0, 1, 1, 1, 1, 1], dtype=np.int32)
+
+# c/tests/cluster/kmeans_c.cu:24-48 — 8 points, 2 clusters, init = Array, max_iter 100, tol 1e-6; the reference
+# compares centroids with 1e-4, labels exactly, inertia / predict inertia / cluster cost with 1e-4 (:157-167).
+KMEANS_C_DATASET = np.array(
+    [[1, 1], [1, 2], [2, 1], [2, 2], [10, 10], [10, 11], [11, 10], [11, 11]], dtype=np.float32
+)
+KMEANS_C_INIT_CENTROIDS = np.array([[0, 0], [12, 12]], dtype=np.float32)
+KMEANS_C_CENTROIDS = np.array([[1.5, 1.5], [10.5, 10.5]], dtype=np.float32)
+KMEANS_C_LABELS = np.array([0, 0, 0, 0, 1, 1, 1, 1], dtype=np.int32)
+KMEANS_C_INERTIA = 4.0
+KMEANS_C_TOL = 1e-4
