@@ -1,5 +1,6 @@
 // Core C-ABI: resources, stream, allocation, last-error text, matrix copy/slice.
 // Replaces c/src/core/c_api.cpp of the reference (same symbols, same error convention).
+#include <cuvs/version_config.h>
 #include "common.hpp"
 
 #include <cuvs/core/c_api.h>
@@ -289,7 +290,7 @@ cuvsError_t cuvsVersionGet(uint16_t* major, uint16_t* minor, uint16_t* patch)
 {
   return (cuvsError_t)translate_exceptions([=] {
     CUVS_EXPECTS(major && minor && patch, "null output");
-    *major = 26; *minor = 8; *patch = 0;  // reference VERSION 26.08.00
+    *major = CUVS_VERSION_MAJOR; *minor = CUVS_VERSION_MINOR; *patch = CUVS_VERSION_PATCH;  // reference VERSION 26.08.00
   });
 }
 

@@ -343,6 +343,61 @@ extern "C" __attribute__((visibility("default"))) int cuvsAmdFusedArgmin(uintptr
 
 #include <cuvs/distance/pairwise_distance.h>
 
+namespace {
+// src: column-major [rows, cols] (element (r, c) at c * rows + r)  ->  dst: row-major [rows, cols]
+template <typename T>
+__global__ void colmajor_to_rowmajor_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t rows, int64_t cols)
+{
+  __shared__ T tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 tile rows per pass
+  for (int j = ty; j < 64; j += 4) {                       // read along r (contiguous in src)
+    const int64_t r = r0 + tx, c = c0 + j;
+    if (r < rows && c < cols) tile[j][tx] = src[c * rows + r];
+  }
+  __syncthreads();
+  for (int j = ty; j < 64; j += 4) {                       // write along c (contiguous in dst)
+    const int64_t r = r0 + j, c = c0 + tx;
+    if (r < rows && c < cols) dst[r * cols + c] = tile[tx][j];
+  }
+}
+
+template <typename T>
+void pairwise_typed(cuvs_amd::resources& res, const T* xp, int64_t m, const T* yp, int64_t n, int64_t dim, int metric,
+                    float* out)
+{
+  using namespace cuvs_amd;
+  const bool sq = metric == M_CosineExpanded;
+  dev_buf<float> xn(res, m), yn(res, n);
+  if (metric != M_InnerProduct) {
+    row_norms<T>(res, xp, m, dim, dim, xn.data(), sq);
+    row_norms<T>(res, yp, n, dim, dim, yn.data(), sq);
+  }
+  for (int64_t r0 = 0; r0 < m; r0 += 32768) {  // the distance kernel takes at most 65535 row tiles per launch
+    const int64_t mr = std::min<int64_t>(32768, m - r0);
+    pairwise_distance<T, T>(res, xp + r0 * dim, mr, dim, yp, n, dim, dim, xn.data() + r0, yn.data(), metric,
+                            out + r0 * n, n);
+  }
+}
+
+// Column-major inputs and output (c/src/distance/pairwise_distance.cpp:93-121): both operands are re-laid row-major,
+// and the column-major [m, n] result is the row-major [n, m] matrix of distance(y, x) - the metrics built are symmetric.
+template <typename T>
+void pairwise_colmajor(cuvs_amd::resources& res, const T* xp, int64_t m, const T* yp, int64_t n, int64_t dim, int metric,
+                       float* out)
+{
+  using namespace cuvs_amd;
+  CUVS_EXPECTS(m <= int64_t(65535) * 64 && n <= int64_t(65535) * 64, "cuvsPairwiseDistance: too many rows for the column-major path");
+  dev_buf<T> xr(res, (size_t)m * dim), yr(res, (size_t)n * dim);
+  hipLaunchKernelGGL((colmajor_to_rowmajor_kernel<T>), dim3((unsigned)((dim + 63) / 64), (unsigned)((m + 63) / 64)),
+                     dim3(256), 0, res.stream, xp, xr.data(), m, dim);
+  hipLaunchKernelGGL((colmajor_to_rowmajor_kernel<T>), dim3((unsigned)((dim + 63) / 64), (unsigned)((n + 63) / 64)),
+                     dim3(256), 0, res.stream, yp, yr.data(), n, dim);
+  HIP_TRY(hipGetLastError());
+  pairwise_typed<T>(res, yr.data(), n, xr.data(), m, dim, metric, out);
+}
+}  // namespace
+
 extern "C" cuvsError_t cuvsPairwiseDistance(cuvsResources_t res_h, DLManagedTensor* x_tensor, DLManagedTensor* y_tensor,
                                             DLManagedTensor* dist_tensor, cuvsDistanceType metric, float metric_arg)
 {
@@ -358,39 +413,26 @@ extern "C" cuvsError_t cuvsPairwiseDistance(cuvsResources_t res_h, DLManagedTens
                  "Inputs to cuvsPairwiseDistance must all have device compatible memory");
     CUVS_EXPECTS(x.dtype.code == y.dtype.code && x.dtype.bits == y.dtype.bits,
                  "Inputs to cuvsPairwiseDistance must all have the same dtype");
-    CUVS_EXPECTS(x.ndim == 2 && y.ndim == 2 && d.ndim == 2 && is_c_contiguous(x) && is_c_contiguous(y) && is_c_contiguous(d),
-                 "Inputs to cuvsPairwiseDistance must all have the same layout (row-major is built; col-major is not)");
+    CUVS_EXPECTS(x.ndim == 2 && y.ndim == 2 && d.ndim == 2, "Inputs to cuvsPairwiseDistance must be matrices");
+    const bool c_order = is_c_contiguous(x) && is_c_contiguous(y) && is_c_contiguous(d);
+    const bool f_order = is_f_contiguous(x) && is_f_contiguous(y) && is_f_contiguous(d);
+    CUVS_EXPECTS(c_order || f_order,
+                 "Inputs to cuvsPairwiseDistance must all have the same layout (row-major or col-major)");
     const int64_t m = x.shape[0], n = y.shape[0], dim = x.shape[1];
     CUVS_EXPECTS(y.shape[1] == dim && d.shape[0] == m && d.shape[1] == n, "cuvsPairwiseDistance: shape mismatch");
     CUVS_EXPECTS(dtype_is(d.dtype, kDLFloat, 32), "cuvsPairwiseDistance: distances must be float32");
     CUVS_EXPECTS(metric_supported((int)metric), "cuvsPairwiseDistance: unsupported metric %d", (int)metric);
-    const bool sq = (int)metric == M_CosineExpanded;
-    dev_buf<float> xn(res, m), yn(res, n);
     float* out = static_cast<float*>(dl_data(d));
     if (dtype_is(x.dtype, kDLFloat, 32)) {
       const float* xp = static_cast<const float*>(dl_data(x));
       const float* yp = static_cast<const float*>(dl_data(y));
-      if ((int)metric != M_InnerProduct) {
-        row_norms<float>(res, xp, m, dim, dim, xn.data(), sq);
-        row_norms<float>(res, yp, n, dim, dim, yn.data(), sq);
-      }
-      for (int64_t r0 = 0; r0 < m; r0 += 32768) {  // the distance kernel takes at most 65535 row tiles per launch
-        const int64_t mr = std::min<int64_t>(32768, m - r0);
-        pairwise_distance<float, float>(res, xp + r0 * dim, mr, dim, yp, n, dim, dim, xn.data() + r0, yn.data(), (int)metric,
-                                        out + r0 * n, n);
-      }
+      if (c_order) pairwise_typed<float>(res, xp, m, yp, n, dim, (int)metric, out);
+      else pairwise_colmajor<float>(res, xp, m, yp, n, dim, (int)metric, out);
     } else if (dtype_is(x.dtype, kDLFloat, 16)) {
       const __half* xp = static_cast<const __half*>(dl_data(x));
       const __half* yp = static_cast<const __half*>(dl_data(y));
-      if ((int)metric != M_InnerProduct) {
-        row_norms<__half>(res, xp, m, dim, dim, xn.data(), sq);
-        row_norms<__half>(res, yp, n, dim, dim, yn.data(), sq);
-      }
-      for (int64_t r0 = 0; r0 < m; r0 += 32768) {
-        const int64_t mr = std::min<int64_t>(32768, m - r0);
-        pairwise_distance<__half, __half>(res, xp + r0 * dim, mr, dim, yp, n, dim, dim, xn.data() + r0, yn.data(),
-                                          (int)metric, out + r0 * n, n);
-      }
+      if (c_order) pairwise_typed<__half>(res, xp, m, yp, n, dim, (int)metric, out);
+      else pairwise_colmajor<__half>(res, xp, m, yp, n, dim, (int)metric, out);
     } else {
       CUVS_FAIL("Unsupported DLtensor dtype: %d and bits: %d", (int)x.dtype.code, (int)x.dtype.bits);
     }

@@ -18,3 +18,11 @@ gcc -O1 -fPIC -shared -std=c11 -I"$ROOT/include" \
     -L"$ROOT/cuvs_amd" -lcuvs_c -Wl,-rpath,'$ORIGIN/../../cuvs_amd' \
     -o "$HERE/_ref/libref_c_drivers.so"
 echo "built $HERE/_ref/libref_c_drivers.so"
+# c/tests/core/c_api.c is a program of its own (resources, stream, RMM alloc/free/pool, pinned host memory, version).
+# It creates its stream with the CUDA runtime; the recipe maps that one call to the HIP runtime, the way a maintainer
+# retargeting the test would (nothing in the library or its headers aliases runtime functions).
+gcc -O1 -std=c11 -Werror=implicit-function-declaration -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include \
+    -include hip/hip_runtime_api.h -DcudaStreamCreate=hipStreamCreate -I"$ROOT/include" \
+    /root/reference/c/tests/core/c_api.c -L"$ROOT/cuvs_amd" -lcuvs_c -L/opt/rocm/lib -lamdhip64 \
+    -Wl,-rpath,'$ORIGIN/../../cuvs_amd' -Wl,-rpath,/opt/rocm/lib -o "$HERE/_ref/ref_core_c_api"
+echo "built $HERE/_ref/ref_core_c_api"

@@ -71,3 +71,10 @@ def test_reference_c_sources_compile_and_link_against_our_headers(tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror=implicit-function-declaration", "-fPIC", "-shared", "-I", inc,
                            *srcs, "-L", os.path.join(ROOT, "cuvs_amd"), "-lcuvs_c", "-Wl,--no-undefined", "-o", str(so)])
     assert so.exists()
+    # c/tests/core/c_api.c: a program; its one CUDA-runtime call (stream creation) is mapped by the recipe
+    exe = tmp_path / "core_c_api"
+    subprocess.check_call(["gcc", "-std=c11", "-Werror=implicit-function-declaration", "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", "-include", "hip/hip_runtime_api.h", "-DcudaStreamCreate=hipStreamCreate",
+                           "-I", inc, os.path.join(ref, "core", "c_api.c"), "-L", os.path.join(ROOT, "cuvs_amd"), "-lcuvs_c",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-o", str(exe)])
+    assert exe.exists()

@@ -98,3 +98,15 @@ def test_run_pairwise_distance_c(metric, code):
     torch.cuda.synchronize()
     want = oracle.pairwise(x, q, metric=metric)
     assert (out.cpu().numpy() == want).all()
+
+
+def test_core_c_api_program():
+    """c/tests/core/c_api.c is a whole program (resources, stream set, device alloc/free with and without the pool,
+    pinned host memory, version == <cuvs/version_config.h>); it exits 0 when every call returned CUVS_SUCCESS."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_core_c_api")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_core_c_api not built (needs /root/reference at build time)")
+    proc = subprocess.run([exe], capture_output=True, timeout=120)
+    assert proc.returncode == 0, proc.stderr.decode()[-400:]
