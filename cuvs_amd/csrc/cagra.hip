@@ -749,8 +749,13 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   int algo = (int)p.algo;
   if (algo == (int)AUTO)
     algo = (itopk <= 16 * kMwTopk && idx.degree <= 224 && (size_t)k <= itopk) ? (int)MULTI_CTA : (int)SINGLE_CTA;
+  // MULTI_KERNEL (search_multi_kernel.cuh) exists in the reference because an itopk list above 512 entries does not
+  // fit one CTA's shared memory there, so the walk is split into sample / top-k / pickup / distance kernels with the
+  // list in global memory. 160 KB of LDS holds the 1024-entry list, its merge buffer and the hash of one walk, so the
+  // same request runs as the single-workgroup walk here: same traversal, no round trips through HBM between steps.
+  if (algo == (int)MULTI_KERNEL) algo = (int)SINGLE_CTA;
   CUVS_EXPECTS(algo == (int)SINGLE_CTA || algo == (int)MULTI_CTA,
-               "cagra::search: algo must be SINGLE_CTA, MULTI_CTA or AUTO (MULTI_KERNEL is not built)");
+               "cagra::search: algo must be SINGLE_CTA, MULTI_CTA, MULTI_KERNEL or AUTO");
   if (algo == (int)MULTI_CTA && idx.degree <= 224) {
     mw_args m;
     m.s = a;

@@ -126,6 +126,21 @@ def test_multi_wave_search_small_batch(algo, metric):
     np.testing.assert_allclose(d, true, rtol=1e-4, atol=1e-4)
 
 
+def test_multi_kernel_request_runs_the_single_workgroup_walk():
+    """MULTI_KERNEL is the reference's mode for itopk lists too large for one CTA (search_plan.cuh:121-131 picks it
+    above 512). The 160 KB LDS keeps such a list on chip, so the request is served by the single-workgroup walk:
+    identical output to SINGLE_CTA, recall of the reference's thresholds."""
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((20000, 48)).astype(np.float32)
+    q = rng.standard_normal((50, 48)).astype(np.float32)
+    index = _build(x, intermediate_graph_degree=64, graph_degree=32)
+    d, i = _search(index, q, 100, itopk_size=768, algo="multi_kernel")
+    d1, i1 = _search(index, q, 100, itopk_size=768, algo="single_cta")
+    assert (i == i1).all() and (d == d1).all()
+    _, ti = oracle.exact_knn(q, x, 100)
+    assert oracle.recall(i, ti) >= 0.995, oracle.recall(i, ti)
+
+
 def test_multi_wave_search_filter_and_dtypes():
     import torch
     from cuvs_amd._lib import BITSET
