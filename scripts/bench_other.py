@@ -10,8 +10,9 @@ from cuvs_amd.neighbors import brute_force, cagra, ivf_flat
 
 dev = torch.device("cuda", 0)
 res = cuvs_amd.common.Resources()
-what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["bf", "flat", "cagra"]
+what = [a for a in sys.argv[1:] if a in ("bf", "flat", "cagra")] or ["bf", "flat", "cagra"]
 cagra_rows = int(sys.argv[sys.argv.index("--cagra-rows") + 1]) if "--cagra-rows" in sys.argv else 1_000_000
+cagra_latent = int(sys.argv[sys.argv.index("--cagra-latent") + 1]) if "--cagra-latent" in sys.argv else 64  # intrinsic dimension of the cloud
 
 
 def timeit(fn, steps=5, warm=2):
@@ -61,7 +62,7 @@ if "flat" in what:  # C2: 10M x 128 fp32, nlist 4096, nprobe 64, batch 10k
 
 if "cagra" in what:  # C4 scaled: N x 768 fp16, degree 64, itopk 64, batch 10k
     n = cagra_rows
-    x = bench.gen_rows(n, 768, 1234, dev, latent=64, n_modes=1).half(); q = bench.gen_rows(10000, 768, 4321, dev, latent=64, n_modes=1).half()  # one broad mode: the kNN graph of well-separated tight modes is disconnected and no graph walk from random seeds can cross modes
+    x = bench.gen_rows(n, 768, 1234, dev, latent=cagra_latent, n_modes=1).half(); q = bench.gen_rows(10000, 768, 4321, dev, latent=cagra_latent, n_modes=1).half()  # one broad mode: the kNN graph of well-separated tight modes is disconnected and no graph walk from random seeds can cross modes
     t0 = time.time(); idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res); res.sync()
     build_s = time.time() - t0
     sp = cagra.SearchParams(itopk_size=64, algo=os.environ.get("CAGRA_ALGO", "auto"))
@@ -69,5 +70,5 @@ if "cagra" in what:  # C4 scaled: N x 768 fp16, degree 64, itopk 64, batch 10k
     dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res))
     bf = brute_force.build(x, resources=res); _, gt = brute_force.search(bf, q[:1000], 10, resources=res); res.sync()
     r = recall(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt.cpu().numpy())
-    print(json.dumps({"case": f"cagra {n} x768 fp16 degree64 itopk64 batch10k k10", "ms": dt * 1e3, "qps": 10000 / dt,
+    print(json.dumps({"case": f"cagra {n} x768 fp16 (latent {cagra_latent}) degree64 itopk64 batch10k k10", "ms": dt * 1e3, "qps": 10000 / dt,
                       "recall": r, "build_s": build_s}))
