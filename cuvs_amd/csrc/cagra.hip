@@ -925,6 +925,15 @@ std::unique_ptr<cagra_index> cagra_build(resources& res, const cuvsCagraIndexPar
   return idx;
 }
 
+// mg.hip: rows held and metric of the index behind a cuvsCagraIndex handle
+void cagra_index_info(uintptr_t addr, int64_t* size, int* metric)
+{
+  CUVS_EXPECTS(addr != 0, "cagra index is empty");
+  auto* idx = reinterpret_cast<const cagra_index*>(addr);
+  *size     = idx->n;
+  *metric   = idx->metric;
+}
+
 }  // namespace cuvs_amd
 
 using namespace cuvs_amd;

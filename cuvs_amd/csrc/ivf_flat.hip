@@ -686,6 +686,15 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   HIP_TRY(hipGetLastError());
 }
 
+// mg.hip: rows held and metric of the index behind a cuvsIvfFlatIndex handle (the C ABI has no getter for them)
+void ivf_flat_index_info(uintptr_t addr, int64_t* size, int* metric)
+{
+  CUVS_EXPECTS(addr != 0, "ivf_flat index is empty");
+  auto* idx = reinterpret_cast<const ivf_flat_index*>(addr);
+  *size     = idx->size;
+  *metric   = idx->metric;
+}
+
 }  // namespace cuvs_amd
 
 using namespace cuvs_amd;

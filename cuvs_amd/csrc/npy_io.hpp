@@ -80,12 +80,23 @@ inline DLDataType dl_of(elem_t e)
   }
 }
 
+// A multi-GPU index file is a short header followed by the streams of its per-device indexes, back to back
+// (cpp/src/neighbors/mg/snmg.cuh:735-757). The per-index writers and readers stay filename based; while mg.hip
+// holds this window open (same thread), a writer appends instead of truncating and a reader starts at
+// `read_offset` and reports where it stopped in `end_offset`.
+struct npy_io_window {
+  bool append      = false;
+  long read_offset = 0;
+  long end_offset  = 0;
+};
+inline thread_local npy_io_window g_npy_io;
+
 class npy_writer {
  public:
   explicit npy_writer(const char* name)
   {
     CUVS_EXPECTS(name != nullptr, "filename is null");
-    f_ = fopen(name, "wb");
+    f_ = fopen(name, g_npy_io.append ? "ab" : "wb");
     CUVS_EXPECTS(f_ != nullptr, "Cannot open file %s", name);
   }
   ~npy_writer() { if (f_) fclose(f_); }
@@ -167,8 +178,16 @@ class npy_reader {
     CUVS_EXPECTS(name != nullptr, "filename is null");
     f_ = fopen(name, "rb");
     CUVS_EXPECTS(f_ != nullptr, "Cannot open file %s", name);
+    if (g_npy_io.read_offset > 0) CUVS_EXPECTS(fseek(f_, g_npy_io.read_offset, SEEK_SET) == 0, "Cannot seek in %s", name);
   }
-  ~npy_reader() { if (f_) fclose(f_); }
+  ~npy_reader()
+  {
+    if (f_) {
+      g_npy_io.end_offset = ftell(f_);
+      fclose(f_);
+    }
+  }
+  long tell() const { return ftell(f_); }
   npy_reader(const npy_reader&) = delete;
   void raw(void* p, size_t n)
   {

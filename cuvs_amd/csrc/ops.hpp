@@ -85,4 +85,8 @@ void knn_graph_nn_descent(resources& res, const void* data, elem_t et, int64_t n
 void refine(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, const void* queries, int64_t m,
             const int64_t* cand, int n_cand, int k, int metric, int64_t* out_i, float* out_d);
 
+// ---------------------------------------------------------------- mg.hip helpers (defined next to the index structs)
+void ivf_flat_index_info(uintptr_t addr, int64_t* size, int* metric);
+void cagra_index_info(uintptr_t addr, int64_t* size, int* metric);
+
 }  // namespace cuvs_amd

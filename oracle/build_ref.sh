@@ -13,7 +13,7 @@ mkdir -p "$HERE/_ref"
 # the reference's include-guard smoke test (c/tests/core/headers.c includes <cuvs/core/all.h> twice): compile only
 gcc -std=c11 -fsyntax-only -I"$ROOT/include" /root/reference/c/tests/core/headers.c
 gcc -O1 -fPIC -shared -std=c11 -I"$ROOT/include" \
-    "$REF/run_brute_force_c.c" "$REF/run_ivf_flat_c.c" "$REF/run_ivf_pq_c.c" \
+    "$REF/run_brute_force_c.c" "$REF/run_ivf_flat_c.c" "$REF/run_ivf_pq_c.c" "$REF/run_mg_c.c" \
     /root/reference/c/tests/distance/run_pairwise_distance_c.c \
     -L"$ROOT/cuvs_amd" -lcuvs_c -Wl,-rpath,'$ORIGIN/../../cuvs_amd' \
     -o "$HERE/_ref/libref_c_drivers.so"

@@ -8,6 +8,9 @@
 #include <cuvs/neighbors/cagra.h>
 #include <cuvs/neighbors/nn_descent.h>
 #include <cuvs/cluster/kmeans.h>
+#include <cuvs/neighbors/mg_ivf_flat.h>
+#include <cuvs/neighbors/mg_ivf_pq.h>
+#include <cuvs/neighbors/mg_cagra.h>
 #define SZ(T) printf("sizeof " #T " %zu\n", sizeof(T))
 #define OFF(T, F) printf("offsetof " #T "." #F " %zu\n", offsetof(T, F))
 int main(void)
@@ -68,5 +71,17 @@ int main(void)
   OFF(struct cuvsKMeansParams_v2, init_size);
   printf("enum KMeansPlusPlus %d Random %d Array %d KMEANS %d KMEANS_BALANCED %d\n", (int)KMeansPlusPlus, (int)Random,
          (int)Array, (int)CUVS_KMEANS_TYPE_KMEANS, (int)CUVS_KMEANS_TYPE_KMEANS_BALANCED);
+  SZ(struct cuvsMultiGpuIvfPqIndexParams); OFF(struct cuvsMultiGpuIvfPqIndexParams, base_params);
+  OFF(struct cuvsMultiGpuIvfPqIndexParams, mode);
+  SZ(struct cuvsMultiGpuIvfPqSearchParams); OFF(struct cuvsMultiGpuIvfPqSearchParams, search_mode);
+  OFF(struct cuvsMultiGpuIvfPqSearchParams, merge_mode); OFF(struct cuvsMultiGpuIvfPqSearchParams, n_rows_per_batch);
+  SZ(struct cuvsMultiGpuIvfFlatIndexParams); SZ(struct cuvsMultiGpuIvfFlatSearchParams);
+  OFF(struct cuvsMultiGpuIvfFlatSearchParams, n_rows_per_batch);
+  SZ(struct cuvsMultiGpuCagraIndexParams); SZ(struct cuvsMultiGpuCagraSearchParams);
+  OFF(struct cuvsMultiGpuCagraSearchParams, n_rows_per_batch);
+  SZ(cuvsMultiGpuIvfPqIndex); SZ(cuvsMultiGpuIvfFlatIndex); SZ(cuvsMultiGpuCagraIndex);
+  printf("enum REPLICATED %d SHARDED %d LOAD_BALANCER %d ROUND_ROBIN %d ON_ROOT %d TREE %d\n",
+         (int)CUVS_NEIGHBORS_MG_REPLICATED, (int)CUVS_NEIGHBORS_MG_SHARDED, (int)CUVS_NEIGHBORS_MG_LOAD_BALANCER,
+         (int)CUVS_NEIGHBORS_MG_ROUND_ROBIN, (int)CUVS_NEIGHBORS_MG_MERGE_ON_ROOT_RANK, (int)CUVS_NEIGHBORS_MG_TREE_MERGE);
   return 0;
 }

@@ -66,7 +66,7 @@ def test_reference_c_sources_compile_and_link_against_our_headers(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-I", inc, os.path.join(ref, "core", "headers.c")])
     so = tmp_path / "drivers.so"
-    srcs = [os.path.join(ref, "neighbors", f) for f in ("run_brute_force_c.c", "run_ivf_flat_c.c", "run_ivf_pq_c.c")]
+    srcs = [os.path.join(ref, "neighbors", f) for f in ("run_brute_force_c.c", "run_ivf_flat_c.c", "run_ivf_pq_c.c", "run_mg_c.c")]
     srcs.append(os.path.join(ref, "distance", "run_pairwise_distance_c.c"))
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror=implicit-function-declaration", "-fPIC", "-shared", "-I", inc,
                            *srcs, "-L", os.path.join(ROOT, "cuvs_amd"), "-lcuvs_c", "-Wl,--no-undefined", "-o", str(so)])
