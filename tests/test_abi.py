@@ -78,3 +78,14 @@ def test_reference_c_sources_compile_and_link_against_our_headers(tmp_path):
                            "-I", inc, os.path.join(ref, "core", "c_api.c"), "-L", os.path.join(ROOT, "cuvs_amd"), "-lcuvs_c",
                            "-L/opt/rocm/lib", "-lamdhip64", "-o", str(exe)])
     assert exe.exists()
+
+
+def test_headers_are_valid_c99_and_cxx17(tmp_path):
+    """The umbrella header (twice, as c/tests/core/headers.c does) and the generated version header compile as strict
+    C99 and as C++17: what cgo/bindgen and C++ callers respectively need."""
+    src = tmp_path / "h.c"
+    src.write_text("#include <cuvs/core/all.h>\n#include <cuvs/core/all.h>\n#include <cuvs/version_config.h>\n"
+                   "int main(void) { cuvsResources_t r = 0; (void)r; return CUVS_VERSION_MAJOR == 26 ? 0 : 1; }\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
