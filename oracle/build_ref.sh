@@ -26,3 +26,28 @@ gcc -O1 -std=c11 -Werror=implicit-function-declaration -D__HIP_PLATFORM_AMD__ -I
     /root/reference/c/tests/core/c_api.c -L"$ROOT/cuvs_amd" -lcuvs_c -L/opt/rocm/lib -lamdhip64 \
     -Wl,-rpath,'$ORIGIN/../../cuvs_amd' -Wl,-rpath,/opt/rocm/lib -o "$HERE/_ref/ref_core_c_api"
 echo "built $HERE/_ref/ref_core_c_api"
+# The reference's C example programs (examples/c/src) call six CUDA runtime names directly (cudaMemcpy and its kinds,
+# cudaError_t, cudaSuccess, cudaGetErrorString). A recipe-local <cuda_runtime.h> maps exactly those to the HIP runtime -
+# the retargeting a maintainer of the examples would do; nothing of it ships in include/ or in the library.
+# Best effort (they are demos, no test depends on them): oracle/_ref/examples/<name>, run them on a GPU box by hand.
+STUB=$(mktemp -d)
+cat > "$STUB/cuda_runtime.h" <<'EOS'
+#pragma once
+#include <hip/hip_runtime_api.h>
+#define cudaError_t hipError_t
+#define cudaSuccess hipSuccess
+#define cudaGetErrorString hipGetErrorString
+#define cudaMemcpy hipMemcpy
+#define cudaMemcpyDefault hipMemcpyDefault
+#define cudaMemcpyHostToDevice hipMemcpyHostToDevice
+#define cudaMemcpyDeviceToHost hipMemcpyDeviceToHost
+EOS
+mkdir -p "$HERE/_ref/examples"
+for ex in L2_c_example bruteforce_c_example ivf_flat_c_example ivf_pq_c_example cagra_c_example; do
+  gcc -O2 -std=c11 -D__HIP_PLATFORM_AMD__ -I"$STUB" -include cuda_runtime.h -I/opt/rocm/include -I"$ROOT/include" \
+      -I/root/reference/examples/c/src "/root/reference/examples/c/src/$ex.c" -L"$ROOT/cuvs_amd" -lcuvs_c \
+      -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,'$ORIGIN/../../../cuvs_amd' -Wl,-rpath,/opt/rocm/lib \
+      -o "$HERE/_ref/examples/$ex" 2>"$STUB/$ex.log" && echo "built examples/$ex" || { echo "examples/$ex not built:"; head -5 "$STUB/$ex.log"; }
+done
+rm -rf "$STUB"
+
