@@ -117,7 +117,10 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     r->num_cus       = prop.multiProcessorCount;
     r->lds_per_block = prop.sharedMemPerBlock;
-    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    // A blocking stream, like the per-thread default stream behind the reference's handle: work issued on the legacy
+    // default stream (a plain hipMemcpy of the results, as the reference's C examples do right after a search) is
+    // ordered after the work queued here. A non-blocking stream would let such callers read results too early.
+    HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamDefault));
     r->owns_stream = true;
     // test hook: shrink the temporary-tile budget so tiling/merge logic runs on small inputs
     // (the reference has max_row_tile_size/max_col_tile_size hooks, knn_brute_force.cuh:90-93)
