@@ -15,8 +15,10 @@ struct work_item {
 };
 
 // per list: number of work items = ceil(cnt / qpb); item_off = exclusive scan (single workgroup)
+// (labels >= split are cut into items of qpb_hi pairs: the two phases of a search may use different kernels)
 __global__ __launch_bounds__(1024) void count_items_kernel(const uint32_t* __restrict__ pair_off, int n_lists,
-                                                           int qpb, uint32_t* __restrict__ item_off)
+                                                           int qpb_lo, uint32_t* __restrict__ item_off, int split,
+                                                           int qpb_hi)
 {
   __shared__ int smem[17];
   __shared__ int carry;
@@ -25,6 +27,7 @@ __global__ __launch_bounds__(1024) void count_items_kernel(const uint32_t* __res
   for (int base = 0; base < n_lists; base += 1024) {
     int i = base + threadIdx.x;
     int v = 0;
+    const int qpb = i < split ? qpb_lo : qpb_hi;
     if (i < n_lists) v = ((int)(pair_off[i + 1] - pair_off[i]) + qpb - 1) / qpb;
     int total;
     int excl = block_exclusive_scan(v, smem, &total);
@@ -37,10 +40,11 @@ __global__ __launch_bounds__(1024) void count_items_kernel(const uint32_t* __res
 }
 
 __global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ item_off,
-                                  int n_lists, int qpb, work_item* __restrict__ items)
+                                  int n_lists, int qpb_lo, work_item* __restrict__ items, int split, int qpb_hi)
 {
   int L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= n_lists) return;
+  const int qpb = L < split ? qpb_lo : qpb_hi;
   uint32_t b = pair_off[L], e = pair_off[L + 1];
   uint32_t w = item_off[L];
   for (uint32_t p = b; p < e; p += qpb, ++w) {
@@ -122,12 +126,15 @@ struct wave_top {
 // probes: [n_pairs] list id of pair p (p = query * n_probes + probe rank). Outputs: sorted_pairs[n_pairs],
 // items[<= n_pairs / qpb + n_lists + 1], item_off[n_lists] = number of items (device scalar).
 inline void build_work_items(resources& res, const uint32_t* probes, int64_t n_pairs, uint32_t n_lists, int qpb,
-                             uint32_t* sorted_pairs, uint32_t* pair_off, uint32_t* item_off, work_item* items)
+                             uint32_t* sorted_pairs, uint32_t* pair_off, uint32_t* item_off, work_item* items,
+                             int split = -1, int qpb_hi = 0)
 {
+  if (split < 0) { split = (int)n_lists; qpb_hi = qpb; }
   group_by_label(res, probes, n_pairs, n_lists, sorted_pairs, pair_off);
-  hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off, (int)n_lists, qpb, item_off);
+  hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off, (int)n_lists, qpb, item_off,
+                     split, qpb_hi);
   hipLaunchKernelGGL(fill_items_kernel, dim3(grid_blocks(n_lists, 256)), dim3(256), 0, res.stream, pair_off,
-                     item_off, (int)n_lists, qpb, items);
+                     item_off, (int)n_lists, qpb, items, split, qpb_hi);
 }
 
 }  // namespace

@@ -40,6 +40,7 @@ namespace {
 
 constexpr int kScanThreads = 1024;
 constexpr int kScanWaves   = kScanThreads / 64;
+constexpr int kQueueRows   = 320;  // survivor queue of a wave: < 64 carried over + a block of 4 tiles
 
 inline unsigned nblk(int64_t n, int per) { return grid_blocks(n, per); }
 
@@ -85,12 +86,26 @@ struct lut_acc<__half, __half, 1> {
   __device__ inline float get(int) const { return (float)a; }
   __device__ static inline entry_t pack(const float (&v)[1]) { return (_Float16)v[0]; }
 };
+// fp16 LUT entries summed in fp32: v_fma_mix_f32 reads one half of a packed pair, widens it exactly and adds it to the
+// fp32 accumulator in ONE instruction ((float)e + a, a single rounding - the same value as convert-then-add)
+__device__ inline void add_lo_half(float& a, uint32_t pair)
+{
+  asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(a) : "v"(pair));
+}
+__device__ inline void add_hi_half(float& a, uint32_t pair)
+{
+  asm volatile("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a) : "v"(pair));
+}
 template <>
 struct lut_acc<__half, float, 2> {
   using entry_t = f16x2_t;
-  f32x2_t a     = {0.f, 0.f};
-  __device__ inline void add(entry_t e) { a += __builtin_convertvector(e, f32x2_t); }
-  __device__ inline float get(int j) const { return j == 0 ? a.x : a.y; }
+  float a0 = 0.f, a1 = 0.f;
+  __device__ inline void add(entry_t e)
+  {
+    const uint32_t ev = __builtin_bit_cast(uint32_t, e);
+    add_lo_half(a0, ev); add_hi_half(a1, ev);
+  }
+  __device__ inline float get(int j) const { return j == 0 ? a0 : a1; }
   __device__ static inline entry_t pack(const float (&v)[2]) { return f16x2_t{(_Float16)v[0], (_Float16)v[1]}; }
 };
 template <>
@@ -104,14 +119,14 @@ struct lut_acc<__half, __half, 2> {
 template <>
 struct lut_acc<__half, float, 4> {
   using entry_t = f16x4_t;
-  f32x4_t a     = {0.f, 0.f, 0.f, 0.f};
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   __device__ inline void add(entry_t e)
   {
-    a += __builtin_convertvector(e, f32x4_t);
-    // materialise all four partial sums here (see lut_acc<__half, __half, 4>)
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+    const u32x2_t ev = __builtin_bit_cast(u32x2_t, e);
+    add_lo_half(a0, ev.x); add_hi_half(a1, ev.x); add_lo_half(a2, ev.y); add_hi_half(a3, ev.y);
   }
-  __device__ inline float get(int j) const { return a[j]; }
+  __device__ inline float get(int j) const { return j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3; }
   __device__ static inline entry_t pack(const float (&v)[4])
   {
     return f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -140,6 +155,10 @@ struct lut_acc<__half, __half, 4> {
   }
 };
 
+// dbg 128 statistics (CUVS_AMD_SCAN_DEBUG=128 prints them per search): wave cycles per phase, rows per stage
+enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QUEUED, ST_S2_CALLS, ST_ALIVE1, ST_ALIVE2,
+                 ST_ALIVE3, ST_CAND, ST_ITEMS, ST_COUNT };
+
 struct scan_args {
   const work_item* items;
   const uint32_t* item_begin;    // device scalars: this launch walks items [*item_begin, *item_end)
@@ -159,6 +178,7 @@ struct scan_args {
   uint32_t n_probes, rot_dim, pq_dim, pq_len, pq_bits, n_chunks, cpc, k;
   int is_ip;
   uint32_t* query_kth;  // [n_queries] order-preserving key of the best known k-th distance (shared by probes)
+  unsigned long long* stats;  // dbg 128: per-phase wave cycles and row counters (see scan_stat)
   int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k, 8 no early stop
 };
 
@@ -241,6 +261,26 @@ __device__ inline void gather16_cm(acc_t& acc, const uint4 cw)
   }
 }
 
+// LDS carve of the scan kernel (all offsets multiples of 16). The FAST4 LUT must sit at LDS address 0, so the kernel
+// keeps no static LDS: [LUT | merge area (reuses the LUT region)] [query residuals] [list centre] [kthb 16 words]
+// [pair ids 16 words] [2 work-item hand-over slots] [per-wave survivor queues: 16 x kQueueRows rows]
+struct scan_layout {
+  size_t qv, cv, kthb, pid, slots, queue, total;
+  __host__ __device__ scan_layout(size_t lut_bytes, int qpb, uint32_t rot_dim, uint32_t k)
+  {
+    size_t off = (lut_bytes + 15) & ~size_t(15);
+    const size_t mg = (size_t)qpb * kScanWaves * k * 8;  // merge area reuses the LUT region after the scan
+    if (mg > off) off = (mg + 15) & ~size_t(15);
+    qv = off;    off += (((size_t)qpb * rot_dim * 4) + 15) & ~size_t(15);
+    cv = off;    off += (((size_t)rot_dim * 4) + 15) & ~size_t(15);
+    kthb = off;  off += 16 * 4;
+    pid = off;   off += 16 * 4;
+    slots = off; off += 2 * 16;
+    queue = off; off += (size_t)kScanWaves * kQueueRows * 4;
+    total = off;
+  }
+};
+
 // FAST4: pq_bits == 8, pq_dim == 64 (4 full chunks): the four chunk loads of a tile are issued back to back. Otherwise the generic path handles any pq_dim / pq_bits.
 template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
 __device__ inline void pq_scan_item(const scan_args& a, const work_item item, char* smem,
@@ -253,24 +293,28 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 
   const uint32_t book      = 1u << a.pq_bits;
   const uint32_t lut_elems = a.pq_dim * book;
-  // LDS carve (all offsets multiples of 16)
+  const scan_layout lay(FAST4 ? cm_lut<entry_t>::bytes() : (size_t)lut_elems * sizeof(entry_t), QPB, a.rot_dim, a.k);
   entry_t* lut     = reinterpret_cast<entry_t*>(smem);
-  size_t off       = ((FAST4 ? cm_lut<entry_t>::bytes() : (size_t)lut_elems * sizeof(entry_t)) + 15) & ~size_t(15);
-  {
-    size_t mg = (size_t)QPB * kScanWaves * a.k * 8;  // merge area reuses the LUT region after the scan
-    if (mg > off) off = (mg + 15) & ~size_t(15);
-  }
-  float* qv      = reinterpret_cast<float*>(smem + off);     off += (((size_t)QPB * a.rot_dim * 4) + 15) & ~size_t(15);
-  float* cv      = reinterpret_cast<float*>(smem + off);     off += (((size_t)a.rot_dim * 4) + 15) & ~size_t(15);
-  uint32_t* kthb = reinterpret_cast<uint32_t*>(smem + off);  off += 16 * 4;
-  uint32_t* pid  = reinterpret_cast<uint32_t*>(smem + off);
-  // the two hand-over slots for work-item headers follow (16 words after pid): the FAST4 LUT must sit at LDS
-  // address 0, so the kernel keeps no static LDS
-  work_item* next_slot = reinterpret_cast<work_item*>(pid + 16) + next_slot_id;
+  float* qv        = reinterpret_cast<float*>(smem + lay.qv);
+  float* cv        = reinterpret_cast<float*>(smem + lay.cv);
+  uint32_t* kthb   = reinterpret_cast<uint32_t*>(smem + lay.kthb);
+  uint32_t* pid    = reinterpret_cast<uint32_t*>(smem + lay.pid);
+  uint4* next_slot = reinterpret_cast<uint4*>(smem + lay.slots) + next_slot_id;
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+
+  const bool stat  = (a.dbg & 128) != 0;  // phase cycles: a few atomics per wave and item
+  const bool statc = (a.dbg & 512) != 0;  // row counters: atomics per tile (slow; counts only)
+  // every wave owns a row of counters (no contention); the host sums the rows
+  auto stat_add = [&](int which, unsigned long long v) {
+    if (lane == 0) a.stats[((size_t)blockIdx.x * kScanWaves + wave) * ST_COUNT + which] += v;
+  };
+  unsigned long long t_prev = stat ? __builtin_readcyclecounter() : 0ull, t_s2 = 0ull;
+  auto stat_phase = [&](int which) {
+    if (stat) { const unsigned long long t = __builtin_readcyclecounter(); stat_add(which, t - t_prev); t_prev = t; }
+  };
 
   const uint32_t L        = item.list >= a.n_lists ? item.list - a.n_lists : item.list;
   const uint32_t base_row = a.list_offsets[L];
@@ -297,6 +341,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   }
   for (uint32_t t = tid; t < a.rot_dim; t += kScanThreads) cv[t] = a.centers_rot[(size_t)L * a.rot_dim + t];
   __syncthreads();
+  stat_phase(ST_HEADER);
 
   // ---- LUT (create_lut_impl.cuh:17-78): entry (s, c) = QPB partial scores side by side
   if (pq_in_regs && !(a.dbg & 1)) {
@@ -437,11 +482,12 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     }
   }
   __syncthreads();
+  stat_phase(ST_LUT);
 
   // header of the workgroup's next item: its ticket was drawn at the start of this item and has arrived by
   // now; the load issued here lands during the scan and is handed over through LDS before the merge barrier
-  work_item next_hdr{0u, 0u, 0u, 0xffffffffu};
-  if (threadIdx.x == 0 && next_ticket < share_len) next_hdr = share[next_ticket];
+  uint4 next_hdr = make_uint4(0u, 0u, 0u, 0xffffffffu);  // plain registers (a struct here lived in scratch)
+  if (threadIdx.x == 0 && next_ticket < share_len) next_hdr = *reinterpret_cast<const uint4*>(share + next_ticket);
 
   // ---- scan: every wave keeps a private sorted top list per query in registers; no workgroup barrier in
   // the loop. kthb[j] (LDS) is the tightest k-th bound any wave (or an earlier probe of the same query)
@@ -456,106 +502,21 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   const int kr          = (int)a.k - 1;
   const bool prune      = FAST4 && !a.is_ip && !(a.dbg & 8);  // dbg 8: early stop off (ablation)
 
-  // The ~20 work items of a list run on ~20 CUs of one XCD at about the same time. Each starts its pass over
-  // the list at a different rotation, so that at any moment the CUs touch different parts of the list: one of them
-  // pulls a line into L2, the others find it there later, instead of all of them missing on it together.
-  const uint32_t rot = (a.dbg & 64) ? 0u : (item.first / QPB);
-  // Tiles (64 rows) are handed to the waves through a ticket in LDS: with the early stop a tile costs anything
-  // between one and four chunks of gathers, and a fixed tile -> wave map left waves idle at the merge barrier.
-  // A wave draws its next ticket before it works on the current tile, so the LDS round trip is off the path.
-  const uint32_t n_tiles = n_iter == 0 ? 0u : (len + 63u) / 64u;
-  const uint32_t rot_t   = n_tiles ? (rot * kScanWaves) % n_tiles : 0u;
-  uint32_t ticket = 0u;
-  if (lane == 0) ticket = atomicAdd(&kthb[12], 1u);
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  while (ticket < n_tiles) {
-    const uint32_t tile  = (ticket + rot_t) % n_tiles;
-    uint32_t next = 0u;
-    if (lane == 0) next = atomicAdd(&kthb[12], 1u);
-    const uint32_t tile0 = tile * 64;  // in-list position of lane 0
-    const uint32_t v     = tile0 + lane;
-    const bool valid     = v < len;
-    struct advance_t { uint32_t& t; uint32_t& n; __device__ ~advance_t() { t = __builtin_amdgcn_readfirstlane(n); } } advance{ticket, next};
-    acc_t acc;
-    bool cand = valid;  // lanes that may still hold a candidate for some query of the item
-    if (FAST4) {
-      uint4 cur[4];
-      const uint4* cp = codes16 + ((g0 + (size_t)tile) * 4) * 64 + lane;
+  // k-th bounds of the item's queries as floats (+inf while a query has fewer than k candidates); read once per
+  // tile - they only ever decrease, so a row dropped against these is also rejected by the (fresher) filter
+  auto load_bounds = [&](float (&bf)[QPB]) {
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];  // padded rows of a group are zero-filled: readable
-      if (!(a.dbg & 2) && prune) {
-        // early stop (compute_score_impl.cuh:70-71): L2 LUT entries are >= 0, so a row whose partial sums
-        // already exceed the k-th bound of every query of the item cannot enter any top list. Its lane sits out
-        // the remaining chunks - fewer active lanes mean fewer LDS bank conflicts - and a wave whose 64 rows are
-        // all out skips them entirely. The bounds are read once per tile; they only ever decrease, so a lane
-        // dropped against these is also rejected by the (fresher) filter below.
-        float bf[QPB];
-#pragma unroll
-        for (int j = 0; j < QPB; ++j) {
-          const uint32_t kk = __builtin_amdgcn_readfirstlane(kthb[j]);
-          bf[j] = j >= (int)item.count ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
-        }
-        bool alive = valid;
-        auto still_below = [&]() {
-          bool below = false;
-#pragma unroll
-          for (int j = 0; j < QPB; ++j) below = below || (acc.get(j) <= bf[j]);
-          return below;
-        };
-        if (alive) gather16_cm<acc_t, 0>(acc, cur[0]);
-        alive = alive && still_below();
-        if (alive) gather16_cm<acc_t, 1>(acc, cur[1]);
-        alive = alive && still_below();
-        if (alive) gather16_cm<acc_t, 2>(acc, cur[2]);
-        alive = alive && still_below();
-        if (alive) gather16_cm<acc_t, 3>(acc, cur[3]);
-        cand = alive && still_below();
-      } else if (!(a.dbg & 2)) {
-        gather16_cm<acc_t, 0>(acc, cur[0]);
-        gather16_cm<acc_t, 1>(acc, cur[1]);
-        gather16_cm<acc_t, 2>(acc, cur[2]);
-        gather16_cm<acc_t, 3>(acc, cur[3]);
-      } else {
-        acc.add(lut[cur[0].x & 0xff]);
-      }
-    } else {
-      const size_t g  = g0 + (size_t)tile;
-      const uint4* cp = codes16 + (g * a.n_chunks) * 64 + lane;
-      if (a.pq_bits == 8) {
-        for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-          uint4 cw          = cp[(size_t)ch * 64];
-          const uint32_t s0 = ch * 16;
-          if (s0 + 16 <= a.pq_dim) {
-            gather16(acc, lut + (s0 << 8), cw);
-          } else {
-            const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
-            for (uint32_t b = 0; b < 16 && s0 + b < a.pq_dim; ++b) {
-              uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-              acc.add(lut[((s0 + b) << 8) + code]);
-            }
-          }
-        }
-      } else {
-        const uint32_t msk = book - 1;
-        for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-          uint4 cw             = cp[(size_t)ch * 64];
-          const uint32_t ws[5] = {cw.x, cw.y, cw.z, cw.w, 0u};
-          for (uint32_t b = 0; b < a.cpc; ++b) {
-            uint32_t s = ch * a.cpc + b;
-            if (s >= a.pq_dim) break;
-            uint32_t bit  = b * a.pq_bits;
-            uint64_t two  = (uint64_t)ws[bit >> 5] | ((uint64_t)ws[(bit >> 5) + 1] << 32);
-            uint32_t code = (uint32_t)(two >> (bit & 31)) & msk;
-            acc.add(lut[(s << a.pq_bits) + code]);
-          }
-        }
-      }
+    for (int j = 0; j < QPB; ++j) {
+      const uint32_t kk = __builtin_amdgcn_readfirstlane(kthb[j]);
+      bf[j] = j >= (int)item.count ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
     }
+  };
 
-    if (a.dbg & 4) continue;
-    if (__ballot(cand) == 0ull) continue;  // the usual case once the bounds are warm: nothing in this tile
-    // ---- candidate filter: one ballot over "any query passes" first (almost always empty once the bounds
-    // are warm), then per query
+  // candidate filter + insertion for the rows held one per lane (v = in-list row of this lane)
+  auto offer = [&](const acc_t& acc, const bool cand, const uint32_t v) {
+    if (a.dbg & 4) return;
+    if (__ballot(cand) == 0ull) return;  // the usual case once the bounds are warm: nothing in this tile
+    // one ballot over "any query passes" first (almost always empty once the bounds are warm), then per query
     float dj[QPB];
     uint32_t djk[QPB];
     bool any = false;
@@ -566,7 +527,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
       djk[j] = a.is_ip ? float_to_key(dj[j]) : (__float_as_uint(dj[j]) | 0x80000000u);
       any    = any || (j < (int)item.count && djk[j] <= kthb[j]);  // kthb: LDS broadcast reads
     }
-    if (__ballot(cand && any) == 0ull) continue;
+    if (__ballot(cand && any) == 0ull) return;
 #pragma unroll
     for (int j = 0; j < QPB; ++j) {
       if (j >= (int)item.count) break;
@@ -579,7 +540,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         const int src = (int)__ffsll((long long)m) - 1;
         m &= m - 1ull;
         const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[j]), src));
-        const uint32_t ci = tile0 + (uint32_t)src;
+        const uint32_t ci = __builtin_amdgcn_readlane(v, src);
         if ((cd < kd) || (cd == kd && ci < ki)) {
           top[j].insert(cd, ci, lane);
           kd       = top[j].rank_d(kr);
@@ -593,8 +554,179 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         if (kd < INFINITY) atomicMin(&kthb[j], float_to_key(kd));
       }
     }
+  };
+
+  // FAST4: all 64 subspaces of the rows held one per lane (any rows of the list: a contiguous tile reads 1 KiB per
+  // chunk, queued survivors read 16 bytes each). With `prune`, the early stop (compute_score_impl.cuh:70-71): L2 LUT
+  // entries are >= 0, so a row whose partial sums already exceed the k-th bound of every query of the item cannot
+  // enter any top list; its lane sits out the remaining chunks - fewer active lanes mean fewer LDS bank conflicts.
+  auto scan_rows4 = [&](const uint32_t v, const bool valid) {
+    acc_t acc;
+    bool cand = valid;  // lanes that may still hold a candidate for some query of the item
+    const uint32_t fr = base_row + (valid ? v : 0u);  // padded rows of a group are zero-filled: readable
+    const uint4* cp   = codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u);
+    uint4 cur[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];
+    if (!(a.dbg & 2) && prune) {
+      float bf[QPB];
+      load_bounds(bf);
+      bool alive = valid;
+      auto still_below = [&]() {
+        bool below = false;
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) below = below || (acc.get(j) <= bf[j]);
+        return below;
+      };
+      if (alive) gather16_cm<acc_t, 0>(acc, cur[0]);
+      alive = alive && still_below();
+      if (alive) gather16_cm<acc_t, 1>(acc, cur[1]);
+      alive = alive && still_below();
+      if (statc) stat_add(ST_ALIVE1, __popcll(__ballot(alive)));
+      if (alive) gather16_cm<acc_t, 2>(acc, cur[2]);
+      alive = alive && still_below();
+      if (statc) stat_add(ST_ALIVE2, __popcll(__ballot(alive)));
+      if (alive) gather16_cm<acc_t, 3>(acc, cur[3]);
+      cand = alive && still_below();
+      if (statc) stat_add(ST_ALIVE3, __popcll(__ballot(cand)));
+    } else if (!(a.dbg & 2)) {
+      gather16_cm<acc_t, 0>(acc, cur[0]);
+      gather16_cm<acc_t, 1>(acc, cur[1]);
+      gather16_cm<acc_t, 2>(acc, cur[2]);
+      gather16_cm<acc_t, 3>(acc, cur[3]);
+    } else {
+      acc.add(lut[cur[0].x & 0xff]);
+    }
+    offer(acc, cand, v);
+  };
+
+  // The ~20 work items of a list run on ~20 CUs of one XCD at about the same time. Each starts its pass over
+  // the list at a different rotation, so that at any moment the CUs touch different parts of the list: one of them
+  // pulls a line into L2, the others find it there later, instead of all of them missing on it together.
+  const uint32_t rot = (a.dbg & 64) ? 0u : (item.first / QPB);
+  // Tiles (64 rows) are handed to the waves through a ticket in LDS: a tile costs anything between a chunk of
+  // gathers and a pass over its survivors, and a fixed tile -> wave map left waves idle at the merge barrier.
+  // A wave draws its next ticket before it works on the current tile, so the LDS round trip is off the path.
+  const uint32_t n_tiles = n_iter == 0 ? 0u : (len + 63u) / 64u;
+  const uint32_t rot_t   = n_tiles ? (rot * kScanWaves) % n_tiles : 0u;
+  uint32_t ticket = 0u;
+  if (lane == 0) ticket = atomicAdd(&kthb[12], 1u);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (FAST4 && prune && !(a.dbg & 256)) {
+    // ---- two stages. Once the bounds are warm (after the head phase) all but ~1 % of the (row, query) pairs are out
+    // after the first 16 subspaces, but a wave only saves work when all 64 of its rows are out. So stage 1 reads
+    // ONLY chunk 0 of the rows (1 KiB per tile instead of 4) - a ticket is a block of 4 tiles, whose four loads are
+    // in flight together: with one load per wave the loop ran at the latency of an L2 hit - and queues the rows
+    // that are still below a bound; stage 2 takes 64 survivors at a time (one per lane, a full wave of useful
+    // gathers) and scores them over all 64 subspaces in the order every other path uses, so the sums are
+    // bit-identical. dbg 256: single stage.
+    uint32_t* wq = reinterpret_cast<uint32_t*>(smem + lay.queue) + wave * kQueueRows;
+    uint32_t qn  = 0u;  // queued rows of this wave (wave-uniform), < 64 between blocks
+    const uint32_t n_blocks = (n_tiles + 3u) / 4u;
+    const uint32_t rot_b    = n_blocks ? (rot * kScanWaves) % n_blocks : 0u;
+    while (ticket < n_blocks) {
+      const uint32_t blk = (ticket + rot_b) % n_blocks;
+      uint32_t next = 0u;
+      if (lane == 0) next = atomicAdd(&kthb[12], 1u);
+      uint4 c0[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t tile = min(blk * 4 + t, n_tiles - 1);
+        c0[t] = codes16[((g0 + (size_t)tile) * 4) * 64 + lane];
+      }
+      float bf[QPB];
+      load_bounds(bf);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t tile = blk * 4 + t;
+        const uint32_t v    = tile * 64 + lane;
+        acc_t acc;
+        gather16_cm<acc_t, 0>(acc, c0[t]);
+        bool alive = false;
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) alive = alive || (acc.get(j) <= bf[j]);
+        alive = alive && v < len;  // also drops the clamped tiles past the end of the list
+        const unsigned long long m = __ballot(alive);
+        if (m != 0ull) {
+          const uint32_t pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (alive) wq[pos] = v;
+          qn += (uint32_t)__popcll(m);
+          if (statc) stat_add(ST_QUEUED, __popcll(m));
+        }
+      }
+      while (qn >= 64u) {  // newest 64 first: no compaction of the queue needed
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        qn -= 64u;
+        const uint32_t r = wq[qn + lane];
+        const unsigned long long t0 = stat ? __builtin_readcyclecounter() : 0ull;
+        scan_rows4(r, true);
+        if (stat) t_s2 += __builtin_readcyclecounter() - t0;
+        if (statc) stat_add(ST_S2_CALLS, 1);
+      }
+      ticket = __builtin_amdgcn_readfirstlane(next);
+    }
+    if (qn != 0u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const bool valid = (uint32_t)lane < qn;
+      const uint32_t r = wq[valid ? lane : 0];
+      const unsigned long long t0 = stat ? __builtin_readcyclecounter() : 0ull;
+      scan_rows4(r, valid);
+      if (stat) t_s2 += __builtin_readcyclecounter() - t0;
+      if (statc) stat_add(ST_S2_CALLS, 1);
+    }
+  } else {
+    while (ticket < n_tiles) {
+      const uint32_t tile  = (ticket + rot_t) % n_tiles;
+      uint32_t next = 0u;
+      if (lane == 0) next = atomicAdd(&kthb[12], 1u);
+      const uint32_t v = tile * 64 + lane;  // in-list position of this lane's row
+      const bool valid = v < len;
+      if (FAST4) {
+        scan_rows4(v, valid);
+      } else {
+        acc_t acc;
+        const size_t g  = g0 + (size_t)tile;
+        const uint4* cp = codes16 + (g * a.n_chunks) * 64 + lane;
+        if (a.pq_bits == 8) {
+          for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+            uint4 cw          = cp[(size_t)ch * 64];
+            const uint32_t s0 = ch * 16;
+            if (s0 + 16 <= a.pq_dim) {
+              gather16(acc, lut + (s0 << 8), cw);
+            } else {
+              const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+              for (uint32_t b = 0; b < 16 && s0 + b < a.pq_dim; ++b) {
+                uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+                acc.add(lut[((s0 + b) << 8) + code]);
+              }
+            }
+          }
+        } else {
+          const uint32_t msk = book - 1;
+          for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+            uint4 cw             = cp[(size_t)ch * 64];
+            const uint32_t ws[5] = {cw.x, cw.y, cw.z, cw.w, 0u};
+            for (uint32_t b = 0; b < a.cpc; ++b) {
+              uint32_t s = ch * a.cpc + b;
+              if (s >= a.pq_dim) break;
+              uint32_t bit  = b * a.pq_bits;
+              uint64_t two  = (uint64_t)ws[bit >> 5] | ((uint64_t)ws[(bit >> 5) + 1] << 32);
+              uint32_t code = (uint32_t)(two >> (bit & 31)) & msk;
+              acc.add(lut[(s << a.pq_bits) + code]);
+            }
+          }
+        }
+        offer(acc, valid, v);
+      }
+      ticket = __builtin_amdgcn_readfirstlane(next);
+    }
   }
 
+  if (stat) {
+    stat_phase(ST_SCAN);
+    stat_add(ST_STAGE2, t_s2);
+    if (wave == 0) { stat_add(ST_ROWS, len); stat_add(ST_ITEMS, 1); }
+  }
   if (threadIdx.x == 0) *next_slot = next_hdr;
   if (a.dbg & 32) return;  // dbg 32: no merge / output (workgroup-uniform)
   // ---- merge the 16 wave lists of every query (the LUT region is free now)
@@ -696,12 +828,9 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   using entry_t = typename lut_acc<LutT, AccT, QPB>::entry_t;
   work_item* sh_item;
   {
-    size_t off = ((FAST4 ? cm_lut<entry_t>::bytes() : (size_t)a.pq_dim * (1u << a.pq_bits) * sizeof(entry_t)) + 15) & ~size_t(15);
-    size_t mg  = (size_t)QPB * kScanWaves * a.k * 8;
-    if (mg > off) off = (mg + 15) & ~size_t(15);
-    off += (((size_t)QPB * a.rot_dim * 4) + 15) & ~size_t(15);
-    off += (((size_t)a.rot_dim * 4) + 15) & ~size_t(15);
-    sh_item = reinterpret_cast<work_item*>(smem + off + 2 * 16 * 4);  // after kthb[16] and pid[16]
+    const scan_layout lay(FAST4 ? cm_lut<entry_t>::bytes() : (size_t)a.pq_dim * (1u << a.pq_bits) * sizeof(entry_t), QPB,
+                          a.rot_dim, a.k);
+    sh_item = reinterpret_cast<work_item*>(smem + lay.slots);
   }
   const uint32_t share0     = min(n_items, xcd * chunk);
   const uint32_t share_len  = min(chunk, n_items - share0);
@@ -718,10 +847,485 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
     if (cur.pad == 0xffffffffu) break;  // workgroup-uniform
     uint32_t next_ticket = 0xffffffffu;
     if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
+    const unsigned long long t0 = (a.dbg & 128) ? __builtin_readcyclecounter() : 0ull;
     pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, cur, smem, pqreg, pq_in_regs, share, share_len, next_ticket,
                                              buf ^ 1);
     __syncthreads();
+    // ST_MERGE accumulates the whole item; the host subtracts the other phases
+    if ((a.dbg & 128) && (threadIdx.x & 63) == 0)
+      a.stats[((size_t)blockIdx.x * kScanWaves + (threadIdx.x >> 6)) * ST_COUNT + ST_MERGE] += __builtin_readcyclecounter() - t0;
   }
+}
+
+// =====================================================================================================================
+// pq_scan2_kernel: the warm-bounds scan (tail phase of a batch; pq_dim 64, 8-bit codes, pq_len 2, L2 metrics, k <= 64).
+//
+// Once every query has a k-th bound (after the head phase), ~96 % of the (row, query) pairs of a probed list are out
+// after the first 16 of the 64 subspaces, but a wave only saves work when all 64 of its rows are out for all queries
+// of the item. So the work item is cut differently here - (list, FQ = 2 x EQ queries) - and runs in three steps:
+//   filter  a LUT of the first 16 subspaces only, 16-byte entries holding FQ partial distances side by side (one
+//           ds_read_b128 serves FQ queries), and ONE pass over chunk 0 of the list's rows (1 KiB per 64 rows, four
+//           tiles in flight per wave). Rows still below the bound of a query of group A (B) go to queue A (B) in LDS;
+//   exact   for group A, then B: the exact 64-subspace LUT of pq_scan_kernel (8-byte entries, EQ queries) replaces
+//           the filter LUT, and the queued rows are scored 64 at a time, one row per lane - a full wave of useful
+//           gathers - over all 64 subspaces in the order every other path uses (bit-identical sums). The code loads of
+//           a wave's first batch are issued BEFORE the LUT build, which hides their latency;
+//   merge   per group, as in pq_scan_kernel.
+// The partial sums of the filter are the exact partial sums (same LUT entries, same order), and fp addition of
+// non-negative terms is monotone, so a dropped row can never have reached a top list: results are identical to
+// pq_scan_kernel's. A queue that overflows (cold bounds) makes the item fall back to scoring every row.
+constexpr int kQCap = 3072;  // rows per survivor queue (two queues per workgroup)
+
+struct scan2_layout {
+  size_t qv, cv, ctrl, pid, slots, queue, total;
+  __host__ __device__ scan2_layout(size_t lut_bytes, int fq, uint32_t rot_dim)
+  {
+    size_t off = (lut_bytes + 15) & ~size_t(15);
+    qv = off;    off += (((size_t)fq * rot_dim * 4) + 15) & ~size_t(15);
+    cv = off;    off += (((size_t)rot_dim * 4) + 15) & ~size_t(15);
+    ctrl = off;  off += 32 * 4;  // [0..7] k-th bound keys, [8..15] "inserted" flags, [16] block ticket, [17..18] queue
+                                 // lengths, [19] spare
+    pid = off;   off += 8 * 4;
+    slots = off; off += 2 * 16;
+    queue = off; off += (size_t)2 * kQCap * 4;
+    total = off;
+  }
+};
+
+template <typename entry_t>
+struct filter_lut {  // code-major, 16 subspaces x 16 bytes + 16 bytes of padding per code row
+  static constexpr uint32_t kRow = 16 * 16 + 16;
+  static constexpr size_t bytes() { return (size_t)256 * kRow; }
+};
+
+template <typename LutT, typename AccT, int EQ, int E>
+__device__ inline void pq_scan2_item(const scan_args& a, const work_item item, char* smem, const float (&pqreg)[4][2][4],
+                                     const work_item* __restrict__ share, const uint32_t share_len,
+                                     const uint32_t next_ticket, const int next_slot_id)
+{
+  constexpr int FQ = 2 * EQ;
+  using acc_t   = lut_acc<LutT, AccT, EQ>;
+  using entry_t = typename acc_t::entry_t;
+  using XL      = cm_lut<entry_t>;
+  using FL      = filter_lut<entry_t>;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+  static_assert(sizeof(entry_t) == 8, "the filter entry is two exact entries side by side");
+
+  const scan2_layout lay(XL::bytes(), FQ, a.rot_dim);
+  entry_t* lut     = reinterpret_cast<entry_t*>(smem);
+  float* qv        = reinterpret_cast<float*>(smem + lay.qv);
+  uint32_t* ctrl   = reinterpret_cast<uint32_t*>(smem + lay.ctrl);
+  uint32_t* pid    = reinterpret_cast<uint32_t*>(smem + lay.pid);
+  uint4* next_slot = reinterpret_cast<uint4*>(smem + lay.slots) + next_slot_id;
+  uint32_t* queue  = reinterpret_cast<uint32_t*>(smem + lay.queue);
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  const bool stat = (a.dbg & 128) != 0;
+  auto stat_add = [&](int which, unsigned long long v) {
+    if (lane == 0) a.stats[((size_t)blockIdx.x * kScanWaves + wave) * ST_COUNT + which] += v;
+  };
+  unsigned long long t_prev = stat ? __builtin_readcyclecounter() : 0ull;
+  auto stat_phase = [&](int which) {
+    if (stat) { const unsigned long long t = __builtin_readcyclecounter(); stat_add(which, t - t_prev); t_prev = t; }
+  };
+
+  const uint32_t L        = item.list >= a.n_lists ? item.list - a.n_lists : item.list;
+  const uint32_t base_row = a.list_offsets[L];
+  const uint32_t len      = a.list_sizes[L];
+
+  if (tid < FQ) {
+    const uint32_t p = tid < (int)item.count ? a.sorted_pairs[item.first + tid] : 0xffffffffu;
+    pid[tid]         = p;
+    ctrl[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
+    ctrl[8 + tid]    = 0u;
+  }
+  if (tid >= 16 && tid < 20) ctrl[tid] = 0u;
+  // query residuals (L2 only here); every thread resolves its pair id itself: no barrier after the header loads
+  for (uint32_t t = tid; t < FQ * a.rot_dim; t += kScanThreads) {
+    const uint32_t j = t / a.rot_dim, dd = t % a.rot_dim;
+    float v = 0.f;
+    if (j < item.count) {
+      const uint32_t q = a.sorted_pairs[item.first + j] / a.n_probes;
+      v = a.rot_queries[(size_t)q * a.rot_dim + dd] - a.centers_rot[(size_t)L * a.rot_dim + dd];
+    }
+    qv[t] = v;
+  }
+  __syncthreads();
+  stat_phase(ST_HEADER);
+
+  // ---- filter LUT: wave w owns subspace w (its codebook values are pqreg[0][.][.]); entry (s, code) at byte
+  // code * 272 + s * 16 holds group A's EQ partial scores, then group B's
+  if (!(a.dbg & 1)) {
+    const uint32_t s = wave;
+    float q[2][FQ];
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int j = 0; j < FQ; ++j) q[l][j] = qv[j * a.rot_dim + s * 2 + l];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float p0 = pqreg[0][0][t], p1 = pqreg[0][1][t];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float sc[EQ];
+#pragma unroll
+        for (int j = 0; j < EQ; ++j) {
+          const float d0 = q[0][g * EQ + j] - p0;
+          const float d1 = q[1][g * EQ + j] - p1;
+          sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+        }
+        *(typename XL::wr_ptr)(uintptr_t)((uint32_t)(t * 64 + lane) * FL::kRow + s * 16 + g * 8) = acc_t::pack(sc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+  stat_phase(ST_LUT);
+
+  // header of the workgroup's next item (its ticket was drawn at the start of this item)
+  uint4 next_hdr = make_uint4(0u, 0u, 0u, 0xffffffffu);
+  if (threadIdx.x == 0 && next_ticket < share_len) next_hdr = *reinterpret_cast<const uint4*>(share + next_ticket);
+
+  const size_t g0      = (size_t)(base_row >> 6);
+  const uint4* codes16 = reinterpret_cast<const uint4*>(a.codes);
+  const int kr         = (int)a.k - 1;
+  const uint32_t n_tiles = (a.dbg & 16) ? 0u : (len + 63u) / 64u;
+
+  auto key_bound = [&](const uint32_t kk, const bool live) {
+    return !live ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
+  };
+
+  // ---- filter pass: chunk 0 of every row against the FQ bounds; a ticket = a block of 4 tiles (4 loads in flight)
+  {
+    const uint32_t rot      = (a.dbg & 64) ? 0u : (item.first / FQ);
+    const uint32_t n_blocks = (n_tiles + 3u) / 4u;
+    const uint32_t rot_b    = n_blocks ? (rot * kScanWaves) % n_blocks : 0u;
+    uint32_t ticket = 0u;
+    if (lane == 0) ticket = atomicAdd(&ctrl[16], 1u);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    while (ticket < n_blocks) {
+      const uint32_t blk = (ticket + rot_b) % n_blocks;
+      uint32_t next = 0u;
+      if (lane == 0) next = atomicAdd(&ctrl[16], 1u);
+      uint4 c0[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint32_t tile = min(blk * 4 + t, n_tiles - 1);
+        c0[t] = codes16[((g0 + (size_t)tile) * 4) * 64 + lane];
+      }
+      float bf[FQ];
+#pragma unroll
+      for (int j = 0; j < FQ; ++j)
+        bf[j] = key_bound(__builtin_amdgcn_readfirstlane(ctrl[j]), j < (int)item.count);
+      uint32_t flags = 0u;  // bit 2t: row of tile t alive for group A, bit 2t + 1: for group B
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc_t accA, accB;
+        const uint32_t ws[4] = {c0[t].x, c0[t].y, c0[t].z, c0[t].w};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          u32x4_t e[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const uint32_t w   = ws[h];
+            const uint32_t row = b == 0 ? sdwa_byte_times<0>(w, FL::kRow) : b == 1 ? sdwa_byte_times<1>(w, FL::kRow)
+                               : b == 2 ? sdwa_byte_times<2>(w, FL::kRow) : sdwa_byte_times<3>(w, FL::kRow);
+            e[b] = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)(row + (uint32_t)(h * 4 + b) * 16);
+          }
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            accA.add(__builtin_bit_cast(entry_t, u32x2_t{e[b].x, e[b].y}));
+            accB.add(__builtin_bit_cast(entry_t, u32x2_t{e[b].z, e[b].w}));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        bool aliveA = false, aliveB = false;
+#pragma unroll
+        for (int j = 0; j < EQ; ++j) {
+          aliveA = aliveA || (accA.get(j) <= bf[j]);
+          aliveB = aliveB || (accB.get(j) <= bf[EQ + j]);
+        }
+        const bool valid = (blk * 4 + t) * 64 + lane < len;  // also drops the clamped tiles past the end of the list
+        flags |= (aliveA && valid ? 1u : 0u) << (2 * t);
+        flags |= (aliveB && valid ? 1u : 0u) << (2 * t + 1);
+      }
+      // reserve queue space for the block's survivors (one LDS atomic per group) and write them
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        unsigned long long m[4];
+        uint32_t n = 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { m[t] = __ballot((flags >> (2 * t + g)) & 1u); n += (uint32_t)__popcll(m[t]); }
+        if (n == 0u) continue;
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(&ctrl[17 + g], n);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[t], 0u));
+          if (((flags >> (2 * t + g)) & 1u) && pos < (uint32_t)kQCap) queue[g * kQCap + pos] = (blk * 4 + t) * 64 + lane;
+          base += (uint32_t)__popcll(m[t]);
+        }
+      }
+      ticket = __builtin_amdgcn_readfirstlane(next);
+    }
+  }
+  if (stat) { stat_phase(ST_SCAN); if (wave == 0) { stat_add(ST_ROWS, len); stat_add(ST_ITEMS, 1); } }
+  __syncthreads();
+  if (stat && wave == 0) stat_add(ST_QUEUED, ctrl[17] + ctrl[18]);
+
+  // ---- exact passes
+  wave_top<E> top[EQ];
+  auto load_codes = [&](const uint32_t v, uint4 (&cur)[4]) {
+    const uint32_t fr = base_row + v;
+    const uint4* cp   = codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];
+  };
+  for (int g = 0; g < 2; ++g) {
+    if (g * EQ >= (int)item.count) break;  // workgroup-uniform: no queries in this group
+    uint32_t* kthb = ctrl + g * EQ;        // bounds of this group's queries
+    uint32_t* ins  = ctrl + 8 + g * EQ;
+    const int cnt_g = min(EQ, (int)item.count - g * EQ);
+    const uint32_t n_q   = ctrl[17 + g];
+    const bool overflow  = n_q > (uint32_t)kQCap;
+    const uint32_t n_bat = overflow ? n_tiles : (n_q + 63u) / 64u;
+    const uint32_t* qg   = queue + g * kQCap;
+    auto batch_row = [&](const uint32_t b, bool& valid) {
+      uint32_t v;
+      if (overflow) { v = b * 64 + lane; valid = v < len; }
+      else          { valid = b * 64 + lane < n_q; v = qg[valid ? b * 64 + lane : 0]; }
+      return valid ? v : 0u;  // row 0 of the list is always readable
+    };
+    // first batch of this wave: its code loads fly during the LUT build
+    uint4 cur[4];
+    bool valid0 = false;
+    uint32_t v0 = 0u;
+    if ((uint32_t)wave < n_bat) { v0 = batch_row(wave, valid0); load_codes(v0, cur); }
+    if (g > 0) __syncthreads();  // every wave is done with the previous LUT / merge area
+    // ---- exact LUT of the group's EQ queries (same arithmetic and layout as pq_scan_kernel)
+    if (!(a.dbg & 1)) {
+#pragma unroll
+      for (int sg = 0; sg < 4; ++sg) {
+        const uint32_t s = wave + sg * kScanWaves;
+        float q[2][EQ];
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+          for (int j = 0; j < EQ; ++j) q[l][j] = qv[(g * EQ + j) * a.rot_dim + s * 2 + l];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float p0 = pqreg[sg][0][t], p1 = pqreg[sg][1][t];
+          float sc[EQ];
+#pragma unroll
+          for (int j = 0; j < EQ; ++j) {
+            const float d0 = q[0][j] - p0;
+            const float d1 = q[1][j] - p1;
+            sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+          }
+          XL::store(s, t * 64 + lane, acc_t::pack(sc));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < EQ; ++j) top[j].init();
+    __syncthreads();
+    stat_phase(ST_LUT);
+
+    for (uint32_t b = wave; b < n_bat; b += kScanWaves) {
+      bool valid = valid0;
+      uint32_t v = v0;
+      if (b != (uint32_t)wave) { v = batch_row(b, valid); load_codes(v, cur); }
+      float bf[EQ];
+#pragma unroll
+      for (int j = 0; j < EQ; ++j) bf[j] = key_bound(__builtin_amdgcn_readfirstlane(kthb[j]), j < cnt_g);
+      acc_t acc;
+      bool alive = valid;
+      auto still_below = [&]() {
+        bool below = false;
+#pragma unroll
+        for (int j = 0; j < EQ; ++j) below = below || (acc.get(j) <= bf[j]);
+        return below;
+      };
+      if (!(a.dbg & 8)) {
+        if (alive) gather16_cm<acc_t, 0>(acc, cur[0]);
+        alive = alive && still_below();
+        if (alive) gather16_cm<acc_t, 1>(acc, cur[1]);
+        alive = alive && still_below();
+        if (alive) gather16_cm<acc_t, 2>(acc, cur[2]);
+        alive = alive && still_below();
+        if (alive) gather16_cm<acc_t, 3>(acc, cur[3]);
+        alive = alive && still_below();
+      } else {
+        gather16_cm<acc_t, 0>(acc, cur[0]);
+        gather16_cm<acc_t, 1>(acc, cur[1]);
+        gather16_cm<acc_t, 2>(acc, cur[2]);
+        gather16_cm<acc_t, 3>(acc, cur[3]);
+      }
+      if (__ballot(alive) == 0ull) continue;
+      // ---- candidate filter + insertion (pq_scan_kernel's)
+      float dj[EQ];
+      uint32_t djk[EQ];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < EQ; ++j) {
+        dj[j]  = acc.get(j);
+        djk[j] = __float_as_uint(dj[j]) | 0x80000000u;  // L2 scores are >= 0
+        any    = any || (j < cnt_g && djk[j] <= kthb[j]);
+      }
+      if (__ballot(alive && any) == 0ull) continue;
+#pragma unroll
+      for (int j = 0; j < EQ; ++j) {
+        if (j >= cnt_g) break;
+        unsigned long long m = __ballot(alive && djk[j] <= kthb[j]);
+        if (m == 0ull) continue;
+        float kd    = top[j].rank_d(kr);
+        uint32_t ki = top[j].rank_i(kr);
+        bool improved = false;
+        while (m != 0ull) {
+          const int src = (int)__ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[j]), src));
+          const uint32_t ci = __builtin_amdgcn_readlane(v, src);
+          if ((cd < kd) || (cd == kd && ci < ki)) {
+            top[j].insert(cd, ci, lane);
+            kd       = top[j].rank_d(kr);
+            ki       = top[j].rank_i(kr);
+            improved = true;
+          }
+        }
+        if (improved && lane == 0) {
+          ins[j] = 1u;
+          if (kd < INFINITY) atomicMin(&kthb[j], float_to_key(kd));
+        }
+      }
+    }
+    stat_phase(ST_STAGE2);
+    if (a.dbg & 32) continue;  // dbg 32: no merge / output
+    // ---- merge the 16 wave lists of the group's queries (the LUT region is free once every wave is here)
+    __syncthreads();
+    {
+      uint32_t any_ins = 0u;
+#pragma unroll
+      for (int j = 0; j < EQ; ++j) any_ins |= ins[j];
+      if (any_ins == 0u) { stat_phase(ST_MERGE); continue; }  // workgroup-uniform: nothing to merge for this group
+    }
+    float* mg_d    = reinterpret_cast<float*>(smem);
+    uint32_t* mg_i = reinterpret_cast<uint32_t*>(smem + (size_t)EQ * kScanWaves * a.k * 4);
+#pragma unroll
+    for (int j = 0; j < EQ; ++j) {
+      if (ins[j] == 0u) continue;  // workgroup-uniform
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int r = e * 64 + lane;
+        if (r < (int)a.k) {
+          mg_d[((size_t)j * kScanWaves + wave) * a.k + r] = top[j].d[e];
+          mg_i[((size_t)j * kScanWaves + wave) * a.k + r] = top[j].i[e];
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < cnt_g && ins[wave] != 0u) {
+      const int j = wave;
+      wave_top<E> fin;
+      fin.init();
+      float kd    = INFINITY;
+      uint32_t ki = 0xffffffffu;
+      const int n = kScanWaves * (int)a.k;
+      for (int b0 = 0; b0 < n; b0 += 64) {
+        float md    = INFINITY;
+        uint32_t mi = 0xffffffffu;
+        if (b0 + lane < n) { md = mg_d[(size_t)j * n + b0 + lane]; mi = mg_i[(size_t)j * n + b0 + lane]; }
+        unsigned long long m = __ballot(mi != 0xffffffffu && ((md < kd) || (md == kd && mi < ki)));
+        while (m != 0ull) {
+          const int src = (int)__ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(md), src));
+          const uint32_t ci = __builtin_amdgcn_readlane(mi, src);
+          if ((cd < kd) || (cd == kd && ci < ki)) {
+            fin.insert(cd, ci, lane);
+            kd = fin.rank_d(kr);
+            ki = fin.rank_i(kr);
+          }
+        }
+      }
+      const uint32_t pj = pid[g * EQ + j];
+      const size_t o    = (size_t)pj * a.k;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int r = e * 64 + lane;
+        if (r < (int)a.k) {
+          const bool ok  = fin.i[e] != 0xffffffffu;
+          a.out_d[o + r] = ok ? fin.d[e] : FLT_MAX;
+          a.out_i[o + r] = ok ? base_row + fin.i[e] : 0xffffffffu;
+        }
+      }
+      if (lane == 0 && kd < INFINITY) atomicMin(&a.query_kth[pj / a.n_probes], float_to_key(kd));
+    }
+    stat_phase(ST_MERGE);
+  }
+  if (threadIdx.x == 0) *next_slot = next_hdr;
+}
+
+template <typename LutT, typename AccT, int EQ, int E>
+__global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using entry_t = typename lut_acc<LutT, AccT, EQ>::entry_t;
+  const uint32_t item0   = a.item_begin ? *a.item_begin : 0u;
+  const uint32_t n_items = *a.item_end - item0;
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t chunk = (n_items + 7u) / 8u;
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();  // see cm_lut
+  float pqreg[4][2][4];
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          pqreg[sg][l][t] = a.pq_centers[(size_t)((wave + sg * kScanWaves) * 2 + l) * 256 + t * 64 + lane];
+  }
+  const scan2_layout lay(cm_lut<entry_t>::bytes(), 2 * EQ, a.rot_dim);
+  work_item* sh_item       = reinterpret_cast<work_item*>(smem + lay.slots);
+  const uint32_t share0    = min(n_items, xcd * chunk);
+  const uint32_t share_len = min(chunk, n_items - share0);
+  const work_item* share   = a.items + item0 + share0;
+  uint32_t* ticket         = a.xcd_ticket + xcd * 32;
+  if (threadIdx.x == 0) {
+    const uint32_t t = atomicAdd(ticket, 1u);
+    sh_item[0]       = t < share_len ? share[t] : work_item{0u, 0u, 0u, 0xffffffffu};
+  }
+  __syncthreads();
+  for (int buf = 0;; buf ^= 1) {
+    const work_item cur = sh_item[buf];
+    if (cur.pad == 0xffffffffu) break;  // workgroup-uniform
+    uint32_t next_ticket = 0xffffffffu;
+    if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
+    pq_scan2_item<LutT, AccT, EQ, E>(a, cur, smem, pqreg, share, share_len, next_ticket, buf ^ 1);
+    __syncthreads();
+  }
+}
+
+template <typename LutT, typename AccT, int EQ>
+void launch_scan2(resources& res, const scan_args& a, unsigned grid)
+{
+  using entry_t = typename lut_acc<LutT, AccT, EQ>::entry_t;
+  const size_t smem = scan2_layout(cm_lut<entry_t>::bytes(), 2 * EQ, a.rot_dim).total;
+  auto kern = pq_scan2_kernel<LutT, AccT, EQ, 1>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem));
+  profile_begin(res, "pq_scan_kernel");
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kScanThreads), smem, res.stream, a);
+  profile_end(res, "pq_scan_kernel");
+  HIP_TRY(hipGetLastError());
 }
 
 template <typename LutT, typename AccT, int QPB>
@@ -729,10 +1333,8 @@ size_t scan_smem_bytes(const ivf_pq_index& idx, int k)
 {
   using entry_t = typename lut_acc<LutT, AccT, QPB>::entry_t;
   const bool fast4 = idx.pq_bits == 8 && idx.pq_dim == 64;  // code-major LUT: 8 bytes of padding per code row
-  size_t lut = ((fast4 ? cm_lut<entry_t>::bytes() : (size_t)idx.pq_dim * idx.pq_book * sizeof(entry_t)) + 15) & ~size_t(15);
-  size_t mg  = ((size_t)QPB * kScanWaves * k * 8 + 15) & ~size_t(15);
-  return std::max(lut, mg) + ((((size_t)QPB * idx.rot_dim * 4) + 15) & ~size_t(15)) +
-         ((((size_t)idx.rot_dim * 4) + 15) & ~size_t(15)) + 2 * 16 * 4 + 2 * sizeof(work_item);
+  return scan_layout(fast4 ? cm_lut<entry_t>::bytes() : (size_t)idx.pq_dim * idx.pq_book * sizeof(entry_t), QPB,
+                     idx.rot_dim, (uint32_t)k).total;
 }
 
 template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
@@ -893,8 +1495,12 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                          n_pairs, n_probes, head, idx.n_lists, phase_labels.data());
       labels = phase_labels.data();
     }
+    // the tail phase (warm bounds) of the common configuration runs pq_scan2_kernel on items of 2 * qpb pairs
+    // (fp16 LUT only: the fp32-LUT instance of the kernel does not fit 128 VGPRs)
+    bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && lut_half && qpb == 4;
+    if (const char* e = getenv("CUVS_AMD_PQ_SCAN2")) use2 = use2 && atoi(e) != 0;
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
-                     items.data());
+                     items.data(), (int)idx.n_lists, use2 ? 2 * qpb : qpb);
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
     // per-pair candidate rows start out invalid: the scan only writes the rows of pairs that found something
@@ -912,6 +1518,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.is_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
     a.dbg   = getenv("CUVS_AMD_SCAN_DEBUG") ? atoi(getenv("CUVS_AMD_SCAN_DEBUG")) : 0;
     const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);  // persistent: one workgroup per CU
+    dev_buf<unsigned long long> stats(res, (a.dbg & (128 | 512)) ? (size_t)ST_COUNT * grid * kScanWaves : 0);
+    a.stats = stats.data();
+    if (a.dbg & (128 | 512)) HIP_TRY(hipMemsetAsync(stats.data(), 0, stats.bytes(), res.stream));
     auto launch = [&](const scan_args& sa) {
       if (!lut_half) {
         if (qpb == 2) launch_scan_qpb<float, float, 2>(res, sa, smem, grid, bits8, big_k);
@@ -932,11 +1541,27 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       launch(a);  // head phase: the nearest probes, cold bounds
       a.xcd_ticket = tickets.data() + 8 * 32;
       a.item_begin = item_off.data() + idx.n_lists;  a.item_end = item_off.data() + 2 * idx.n_lists;
-      launch(a);  // tail phase: warm bounds
+      if (!use2)          launch(a);  // tail phase: warm bounds
+      else if (!acc_half) launch_scan2<__half, float, 4>(res, a, grid);
+      else                launch_scan2<__half, __half, 4>(res, a, grid);
     } else {
       a.xcd_ticket = tickets.data();
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
       launch(a);
+    }
+    if (a.dbg & (128 | 512)) {
+      std::vector<unsigned long long> hw(stats.n);
+      HIP_TRY(hipMemcpyAsync(hw.data(), stats.data(), stats.bytes(), hipMemcpyDeviceToHost, res.stream));
+      HIP_TRY(hipStreamSynchronize(res.stream));
+      unsigned long long h[ST_COUNT] = {};
+      for (size_t i = 0; i < hw.size(); ++i) h[i % ST_COUNT] += hw[i];
+      const double w = 1.0 / (16.0 * grid);  // wave cycles -> average cycles per wave
+      fprintf(stderr,
+              "[pq_scan stats] items %llu rows %llu queued %llu (%.2f%%) stage2 calls %llu alive after chunk1/2/3 %llu/%llu/%llu"
+              " | cycles per wave: header %.3g lut %.3g scan %.3g (stage2 %.3g) merge+sync %.3g\n",
+              h[ST_ITEMS], h[ST_ROWS], h[ST_QUEUED], 100.0 * h[ST_QUEUED] / (double)std::max<unsigned long long>(1, h[ST_ROWS]),
+              h[ST_S2_CALLS], h[ST_ALIVE1], h[ST_ALIVE2], h[ST_ALIVE3], h[ST_HEADER] * w, h[ST_LUT] * w, h[ST_SCAN] * w,
+              h[ST_STAGE2] * w, (double)(h[ST_MERGE] - h[ST_HEADER] - h[ST_LUT] - h[ST_SCAN]) * w);
     }
     // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
     select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Build the bench.py IVF-PQ index once, then time the search under several scan-kernel settings
 (environment switches read per call: CUVS_AMD_SCAN_DEBUG, CUVS_AMD_PQ_HEAD_PROBES). Prints one line per variant:
-search ms (k*refine candidates), pq_scan_kernel ms per search, and whether the results equal variant 0's.
+search ms (k*refine candidates), pq_scan_kernel ms per search, and whether the results equal those of the first
+variant with the same LUT / accumulator types (LUT=f16|f32|u8, ACC=f16|f32; default f16/f16).
 
-  python scripts/pq_scan_variants.py [--rows N --n-lists L --n-probes P] "DBG=8,HEAD=0" "DBG=0,HEAD=0" "DBG=0,HEAD=1"
+  python scripts/pq_scan_variants.py [--rows N --n-lists L --n-probes P] "DBG=8,HEAD=0" "DBG=0,HEAD=0" "DBG=0,HEAD=1,LUT=f16,ACC=f32"
 """
 import argparse
 import ctypes as C
@@ -41,15 +42,25 @@ def main():
                                             kmeans_trainset_fraction=0.02), data, resources=res)
     res.sync()
     del data
-    sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=np.float16, internal_distance_dtype=np.float16,
-                             max_internal_batch_size=args.batch)
+    dt = {"f16": np.float16, "f32": np.float32, "u8": np.uint8}
     nb = torch.empty((args.batch, args.k), dtype=torch.int64, device=dev)
     ds = torch.empty((args.batch, args.k), dtype=torch.float32, device=dev)
-    first = None
+    firsts = {}
     for v in args.variants:
+        lut, acc = "f16", "f16"
         for kv in v.split(","):
             key, val = kv.split("=")
-            os.environ[{"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES"}[key]] = val
+            if key == "LUT":
+                lut = val
+            elif key == "ACC":
+                acc = val
+            else:
+                os.environ[{"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES", "S2": "CUVS_AMD_PQ_SCAN2"}[key]] = val
+        if lut == "f32":
+            acc = "f32"
+        sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=dt[lut], internal_distance_dtype=dt[acc],
+                                 max_internal_batch_size=args.batch)
+        first = firsts.get((lut, acc))
         for _ in range(2):
             ivf_pq.search(sp, index, queries, args.k, neighbors=nb, distances=ds, resources=res)
         res.sync()
@@ -67,7 +78,7 @@ def main():
         cur = (nb.clone(), ds.clone())
         same = "ref" if first is None else str(bool(torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])))
         if first is None:
-            first = cur
+            firsts[(lut, acc)] = cur
         print(f"{v:24s} search {ms:8.3f} ms  scan {scan.value / args.steps:8.3f} ms ({n // args.steps} launches)  "
               f"same_as_first={same}", flush=True)
 
