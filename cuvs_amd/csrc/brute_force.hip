@@ -50,11 +50,13 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   const bool select_min = metric != M_InnerProduct;
   const int64_t n       = idx.n;
   const T* data         = static_cast<const T*>(idx.data);
-  CUVS_EXPECTS(k >= 1 && k <= 2048, "brute_force::search: k must be in [1, 2048]");
+  CUVS_EXPECTS(k >= 1, "brute_force::search: k must be positive");
+  CUVS_EXPECTS((int64_t)k <= n, "brute_force::search: k (%d) must not exceed the number of indexed rows (%ld)", k, (long)n);
 
-  // row tiles bounded by the workspace; column tiles as wide as the workspace allows
+  // row tiles bounded by the workspace; column tiles as wide as the workspace allows. Large k (beyond the 2048
+  // winners select_k keeps in LDS at full speed) shrinks the row tile so that the per-tile partial results stay small.
   const int64_t ws_floats = (int64_t)(res.workspace_limit / sizeof(float));
-  int64_t m_tile          = std::min<int64_t>(m, 16384);
+  int64_t m_tile          = std::min<int64_t>(m, k > 2048 ? 256 : 16384);
   int64_t n_tile          = std::max<int64_t>(128, (ws_floats / m_tile) / 128 * 128);
   n_tile                  = std::min<int64_t>(n_tile, round_up(n, 128));
   const int64_t n_ct      = (n + n_tile - 1) / n_tile;

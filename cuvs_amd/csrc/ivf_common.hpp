@@ -4,6 +4,10 @@
 #include "ops.hpp"
 #include "device_utils.hpp"
 
+#include <algorithm>
+#include <functional>
+#include <vector>
+
 namespace cuvs_amd {
 namespace {
 
@@ -121,6 +125,37 @@ struct wave_top {
   }
 };
 
+
+// ------------------------------------------------------------------ non-fused path: k beyond the register top lists
+// The reference falls back from its fused top-k to "write every score, then select_k" when k exceeds the warp-sort
+// capacity (is_local_topk_feasible, ivf_pq_compute_similarity_impl.cuh:39-45; ivf_pq_search.cuh:620,
+// ivf_flat_search.cuh:180,283). Same here: the scan kernels store the score of every probed row into a
+// [n_queries, ld] matrix - the rows of probe p of query q at columns seg[q * n_probes + p] .. (calc_chunk_indices,
+// ivf_common.cu:23-51), with the flat row of every column in a second matrix - and select_k picks the k best of every
+// row: which of several equal k-th scores survive is decided by column (probe rank, then in-list position), the
+// winners come out ordered by (score, flat row) - exactly what the fused path's per-pair lists + merge produce.
+// ld = the n_probes largest lists together (the reference's accum_sorted_sizes(n_probes)): no device -> host round trip.
+__global__ void pair_segments_kernel(const uint32_t* __restrict__ probes, const uint32_t* __restrict__ list_sizes,
+                                     int64_t nq, uint32_t n_probes, uint32_t* __restrict__ seg)
+{
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint32_t off = 0;
+  for (uint32_t p = 0; p < n_probes; ++p) {
+    seg[q * n_probes + p] = off;
+    off += list_sizes[probes[q * n_probes + p]];
+  }
+}
+
+inline size_t largest_lists_total(const std::vector<uint32_t>& sizes, uint32_t n_probes)
+{
+  std::vector<uint32_t> s(sizes);
+  const size_t m = std::min<size_t>(n_probes, s.size());
+  std::partial_sort(s.begin(), s.begin() + m, s.end(), std::greater<uint32_t>());
+  size_t t = 0;
+  for (size_t i = 0; i < m; ++i) t += s[i];
+  return t;
+}
 
 // (query, probe) pairs grouped by list and cut into work items of up to `qpb` pairs of ONE list.
 // probes: [n_pairs] list id of pair p (p = query * n_probes + probe rank). Outputs: sorted_pairs[n_pairs],

@@ -131,6 +131,10 @@ struct flat_scan_args {
   const int64_t* indices;       // flat row -> source id (only read when filtering)
   uint32_t n_probes, dim, veclen, n_chunks, k;
   int is_ip;  // 0: L2, 1: inner product, 2: cosine
+  float* all_scores;         // non-fused path (large k, ivf_common.hpp): [n_queries, scores_ld] score of every probed row
+  uint32_t* all_rows;        //   flat row of every column (0xffffffff: nothing there)
+  const uint32_t* pair_seg;  //   first column of each pair in its query's row
+  size_t scores_ld;
 };
 
 // Query tile of every work item, [dim_pad][QPB] fp32 in HBM. The scan kernel reads it with wave-uniform addresses,
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
       bf[j] = (IP || j >= (int)item.count) ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
     }
     for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-      if (!IP && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
+      if (!IP && a.all_scores == nullptr && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
         bool below = false;
 #pragma unroll
         for (int j = 0; j < QPB; ++j) below = below || (accv[j >> 1][j & 1] <= bf[j]);
@@ -274,6 +278,20 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     for (int j = 0; j < QPB; ++j) {
       if (j >= (int)item.count) break;
       const float dj       = IP ? -acc[j] : acc[j];  // smaller is better
+      if (a.all_scores != nullptr) {  // non-fused path: every score goes to the query's row (filtered rows keep the fill)
+        bool keep = valid;
+        if (keep && a.filter_bits != nullptr) {
+          const int64_t sid = a.indices[(size_t)base_row + v];
+          keep              = (a.filter_bits[sid >> 5] >> (sid & 31)) & 1u;
+        }
+        const uint32_t p = pid[j];
+        if (keep) {
+          const size_t o  = (size_t)(p / a.n_probes) * a.scores_ld + a.pair_seg[p] + v;
+          a.all_scores[o] = dj;
+          a.all_rows[o]   = base_row + v;
+        }
+        continue;
+      }
       const uint32_t bound = kthb[j];
       unsigned long long m = __ballot(valid && float_to_key(dj) <= bound);
       if (m == 0ull) continue;
@@ -300,6 +318,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     }
   }
 
+  if (a.all_scores != nullptr) return;  // workgroup-uniform
   // ---- merge the wave lists (the query tile is no longer needed)
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
@@ -573,36 +592,43 @@ std::unique_ptr<ivf_flat_index> ivf_flat_build(resources& res, const cuvsIvfFlat
 void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probes_in, const void* queries, elem_t et,
                      int64_t n_queries, int k, int64_t* neighbors, float* distances, const uint32_t* filter_bits)
 {
-  CUVS_EXPECTS(k > 0 && k <= 256, "ivf_flat::search: k must be in [1, 256]");
+  CUVS_EXPECTS(k > 0, "ivf_flat::search: k must be positive");
+  CUVS_EXPECTS((int64_t)k <= idx.size, "ivf_flat::search: k (%d) must not exceed the number of indexed rows (%ld)", k,
+               (long)idx.size);
   CUVS_EXPECTS(n_probes_in > 0, "n_probes must be positive");
   CUVS_EXPECTS(et == idx.dtype, "queries dtype differs from the index dtype");
   if (n_queries == 0) return;
   const uint32_t n_probes = std::min<uint32_t>(n_probes_in, idx.n_lists);
   const int qpb           = kFlatQPB;
-  const bool big_k        = k > 64;
+  const bool large_k      = k > 256;  // beyond the register top lists: non-fused path (ivf_common.hpp)
+  const bool big_k        = k > 64 && !large_k;
+  const int k_scan        = large_k ? 1 : k;
   const uint32_t dim_pad  = idx.n_chunks * idx.veclen;
-  size_t smem = ((((size_t)qpb * kFlatWaves * k * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;
+  size_t smem = ((((size_t)qpb * kFlatWaves * k_scan * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;
+  const size_t scores_ld  = large_k ? largest_lists_total(idx.h_list_sizes, n_probes) : 0;
 
   int64_t max_batch = 1 << 15;
   {
-    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k * 8 + idx.dim * 4 +
+    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k_scan * 8 + idx.dim * 4 +
                     ((int64_t)n_probes / qpb + 1) * (dim_pad + 1) * qpb * 4;  // + the query tiles of its work items
+    if (large_k) per_q += (int64_t)scores_ld * 8 + (int64_t)k * 12;
     max_batch     = std::min(max_batch, std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q));
   }
   const int64_t bs = std::min<int64_t>(max_batch, n_queries);
   const int64_t np_max = bs * n_probes;
   dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
   // two-phase schedule (ivf_common.hpp): nearest probe of every query first
-  uint32_t head = (n_probes > 8 && metric_is_l2(idx.metric)) ? 1u : 0u;
+  uint32_t head = (n_probes > 8 && metric_is_l2(idx.metric) && !large_k) ? 1u : 0u;
   if (const char* e = getenv("CUVS_AMD_FLAT_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
   const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
   dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, n_labels + 1),
-    item_off(res, n_labels + 1), cand_i(res, (size_t)np_max * k), top_i(res, (size_t)bs * k), query_kth(res, bs);
+    item_off(res, n_labels + 1), cand_i(res, large_k ? (size_t)bs * scores_ld : (size_t)np_max * k), top_i(res, (size_t)bs * k),
+    query_kth(res, bs), pair_seg(res, large_k ? (size_t)np_max : 0);
   dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)np_max : 0);
   const size_t max_items = (size_t)(np_max / qpb + n_labels + 1);
   dev_buf<work_item> items(res, max_items);
   dev_buf<float> qtiles(res, max_items * (dim_pad + 1) * qpb);
-  dev_buf<float> cand_d(res, (size_t)np_max * k), top_d(res, (size_t)bs * k);
+  dev_buf<float> cand_d(res, large_k ? (size_t)bs * scores_ld : (size_t)np_max * k), top_d(res, (size_t)bs * k);
   const size_t esz = elem_size(et);
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -639,7 +665,14 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data());
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
+    if (large_k) {
+      HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)nq * scores_ld, res.stream));
+      HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)nq * scores_ld * sizeof(uint32_t), res.stream));
+      hipLaunchKernelGGL(pair_segments_kernel, dim3(grid_blocks(nq, 256)), dim3(256), 0, res.stream, probes.data(),
+                         idx.list_sizes.data(), nq, n_probes, pair_seg.data());
+    }
     flat_scan_args a;
+    a.all_scores = large_k ? cand_d.data() : nullptr; a.all_rows = cand_i.data(); a.pair_seg = pair_seg.data(); a.scores_ld = scores_ld;
     a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
     {
       const uint32_t* n_all = item_off.data() + n_labels;
@@ -657,7 +690,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     a.list_sizes = idx.list_sizes.data(); a.out_d = cand_d.data(); a.out_i = cand_i.data();
     a.filter_bits = filter_bits; a.indices = idx.indices.data();
     a.query_kth = query_kth.data(); a.n_probes = n_probes; a.dim = idx.dim; a.veclen = idx.veclen;
-    a.n_chunks = idx.n_chunks; a.k = (uint32_t)k; a.is_ip = idx.metric == M_InnerProduct ? 1 : (idx.metric == M_CosineExpanded ? 2 : 0);
+    a.n_chunks = idx.n_chunks; a.k = (uint32_t)k_scan; a.is_ip = idx.metric == M_InnerProduct ? 1 : (idx.metric == M_CosineExpanded ? 2 : 0);
     auto launch = [&](const flat_scan_args& fa, unsigned grid) {
       profile_begin(res, "ivf_flat_scan_kernel");
       switch (et) {
@@ -678,8 +711,13 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
       launch(a, (unsigned)(n_pairs / qpb + idx.n_lists + 1));
     }
-    select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
-                                 k, top_d.data(), top_i.data(), true);
+    if (!large_k) {
+      select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
+                                   k, top_d.data(), top_i.data(), true);
+    } else {
+      select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)scores_ld, (int64_t)scores_ld, k,
+                                   top_d.data(), top_i.data(), true);
+    }
     hipLaunchKernelGGL(flat_postprocess_kernel, dim3(grid_blocks(nq * k, 256)), dim3(256), 0, res.stream, top_i.data(),
                        top_d.data(), nq * k, idx.indices.data(), idx.metric, neighbors + q0 * k, distances + q0 * k);
   }

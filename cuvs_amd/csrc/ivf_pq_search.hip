@@ -54,6 +54,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 
+// fp32 score -> fp16 LUT entry, as the reference stores it (LutT(score): the fp32-rounded score, then round to nearest
+// even). The barrier keeps hipcc from folding fma + convert into v_fma_mixlo_f16, which rounds the exact product-sum
+// ONCE and differs from the reference in the last half bit of some entries.
+__device__ inline _Float16 to_lut_half(float v)
+{
+  asm volatile("" : "+v"(v));
+  return (_Float16)v;
+}
+
 template <>
 struct lut_acc<float, float, 1> {
   using entry_t = float;
@@ -76,7 +85,7 @@ struct lut_acc<__half, float, 1> {
   float a       = 0.f;
   __device__ inline void add(entry_t e) { a += (float)e; }
   __device__ inline float get(int) const { return a; }
-  __device__ static inline entry_t pack(const float (&v)[1]) { return (_Float16)v[0]; }
+  __device__ static inline entry_t pack(const float (&v)[1]) { return to_lut_half(v[0]); }
 };
 template <>
 struct lut_acc<__half, __half, 1> {
@@ -84,7 +93,7 @@ struct lut_acc<__half, __half, 1> {
   _Float16 a    = (_Float16)0.f;
   __device__ inline void add(entry_t e) { a += e; }
   __device__ inline float get(int) const { return (float)a; }
-  __device__ static inline entry_t pack(const float (&v)[1]) { return (_Float16)v[0]; }
+  __device__ static inline entry_t pack(const float (&v)[1]) { return to_lut_half(v[0]); }
 };
 // fp16 LUT entries summed in fp32: v_fma_mix_f32 reads one half of a packed pair, widens it exactly and adds it to the
 // fp32 accumulator in ONE instruction ((float)e + a, a single rounding - the same value as convert-then-add)
@@ -106,7 +115,7 @@ struct lut_acc<__half, float, 2> {
     add_lo_half(a0, ev); add_hi_half(a1, ev);
   }
   __device__ inline float get(int j) const { return j == 0 ? a0 : a1; }
-  __device__ static inline entry_t pack(const float (&v)[2]) { return f16x2_t{(_Float16)v[0], (_Float16)v[1]}; }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return f16x2_t{to_lut_half(v[0]), to_lut_half(v[1])}; }
 };
 template <>
 struct lut_acc<__half, __half, 2> {
@@ -114,7 +123,7 @@ struct lut_acc<__half, __half, 2> {
   f16x2_t a     = {(_Float16)0.f, (_Float16)0.f};
   __device__ inline void add(entry_t e) { a += e; }
   __device__ inline float get(int j) const { return j == 0 ? (float)a.x : (float)a.y; }
-  __device__ static inline entry_t pack(const float (&v)[2]) { return f16x2_t{(_Float16)v[0], (_Float16)v[1]}; }
+  __device__ static inline entry_t pack(const float (&v)[2]) { return f16x2_t{to_lut_half(v[0]), to_lut_half(v[1])}; }
 };
 template <>
 struct lut_acc<__half, float, 4> {
@@ -129,7 +138,7 @@ struct lut_acc<__half, float, 4> {
   __device__ inline float get(int j) const { return j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3; }
   __device__ static inline entry_t pack(const float (&v)[4])
   {
-    return f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    return f16x4_t{to_lut_half(v[0]), to_lut_half(v[1]), to_lut_half(v[2]), to_lut_half(v[3])};
   }
 };
 template <>
@@ -151,9 +160,35 @@ struct lut_acc<__half, __half, 4> {
   }
   __device__ static inline entry_t pack(const float (&v)[4])
   {
-    return f16x4_t{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    return f16x4_t{to_lut_half(v[0]), to_lut_half(v[1]), to_lut_half(v[2]), to_lut_half(v[3])};
   }
 };
+
+// lut_dtype = CUDA_R_8U / CUDA_R_8I: the reference stores LUT entries in its own 8-bit float fp_8bit<5, Signed>
+// (ivf_pq_fp_8bit.cuh:32-100; unsigned for L2, sign in bit 0 for inner product - ivf_pq_search.cuh:711-728): 5 exponent
+// bits (bias 15), 3 value bits, truncation on encode, half an ulp added back on decode. Here the entry is rounded
+// through that type when the LUT is built and stored in the score type (the value every later add sees is the
+// reference's): its float decoder (:75-88) for fp32 scores, its half decoder (:90-102, no implicit one at the
+// smallest exponent, NaN/inf patterns at the largest) for fp16 scores.
+template <typename AccT>
+__device__ inline float fp8_round_trip(float v, bool is_signed)
+{
+  const float av = is_signed ? fabsf(v) : v;
+  uint32_t u;
+  if (av < 1.0f / 32768.0f) u = 0u;
+  else if (av >= 65536.0f * 1.875f) u = 0xffu;
+  else u = ((__float_as_uint(av) + (15u << 23) - 0x3f800000u) >> 20) & 0xffu;
+  const bool neg = is_signed && v < 0.f;
+  if (is_signed) u &= 0xfeu;
+  float r;
+  if constexpr (sizeof(AccT) == 2) {
+    const uint16_t hb = (uint16_t)(((0x3c00u | (0x0200u >> 3)) - (15u << 10)) + (u << 7));
+    r = (float)__builtin_bit_cast(_Float16, hb);
+  } else {
+    r = __uint_as_float(((0x3f800000u | (0x00400000u >> 3)) - (15u << 23)) + (u << 20));
+  }
+  return neg ? -r : r;
+}
 
 // dbg 128 statistics (CUVS_AMD_SCAN_DEBUG=128 prints them per search): wave cycles per phase, rows per stage
 enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QUEUED, ST_S2_CALLS, ST_ALIVE1, ST_ALIVE2,
@@ -177,7 +212,12 @@ struct scan_args {
   uint32_t* out_i;               // [n_pairs, k] flat row
   uint32_t n_probes, rot_dim, pq_dim, pq_len, pq_bits, n_chunks, cpc, k;
   int is_ip;
+  int lut_fp8;  // LUT entries pass through the reference's fp_8bit<5, is_ip> (see fp8_round_trip)
   uint32_t* query_kth;  // [n_queries] order-preserving key of the best known k-th distance (shared by probes)
+  float* all_scores;             // non-fused path (large k): [n_queries, scores_ld] score of every probed row
+  uint32_t* all_rows;            //   flat row of every column (0xffffffff: nothing there)
+  const uint32_t* pair_seg;      //   first column of each pair in its query's row
+  size_t scores_ld;
   unsigned long long* stats;  // dbg 128: per-phase wave cycles and row counters (see scan_stat)
   int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k, 8 no early stop
 };
@@ -444,6 +484,12 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
             }
           }
         }
+        if (a.lut_fp8) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < QPB; ++j) sc[t][j] = fp8_round_trip<AccT>(sc[t][j], a.is_ip != 0);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           if (c0 + t * 64 < book) {
@@ -478,6 +524,10 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
           }
         }
       }
+      if (a.lut_fp8) {
+#pragma unroll
+        for (int j = 0; j < QPB; ++j) sc[j] = fp8_round_trip<AccT>(sc[j], a.is_ip != 0);
+      }
       lut[e] = acc_t::pack(sc);
     }
   }
@@ -500,7 +550,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   const size_t g0       = (size_t)(base_row >> 6);
   const uint4* codes16  = reinterpret_cast<const uint4*>(a.codes);
   const int kr          = (int)a.k - 1;
-  const bool prune      = FAST4 && !a.is_ip && !(a.dbg & 8);  // dbg 8: early stop off (ablation)
+  const bool prune      = FAST4 && !a.is_ip && !(a.dbg & 8) && a.all_scores == nullptr;  // dbg 8: early stop off (ablation)
 
   // k-th bounds of the item's queries as floats (+inf while a query has fewer than k candidates); read once per
   // tile - they only ever decrease, so a row dropped against these is also rejected by the (fresher) filter
@@ -514,6 +564,19 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 
   // candidate filter + insertion for the rows held one per lane (v = in-list row of this lane)
   auto offer = [&](const acc_t& acc, const bool cand, const uint32_t v) {
+    if (a.all_scores != nullptr) {  // non-fused path: every score goes to the query's row, select_k runs afterwards
+#pragma unroll
+      for (int j = 0; j < QPB; ++j) {
+        if (j >= (int)item.count) break;
+        const uint32_t p = pid[j];
+        if (cand) {
+          const size_t o  = (size_t)(p / a.n_probes) * a.scores_ld + a.pair_seg[p] + v;
+          a.all_scores[o] = acc.get(j);
+          a.all_rows[o]   = base_row + v;
+        }
+      }
+      return;
+    }
     if (a.dbg & 4) return;
     if (__ballot(cand) == 0ull) return;  // the usual case once the bounds are warm: nothing in this tile
     // one ballot over "any query passes" first (almost always empty once the bounds are warm), then per query
@@ -728,7 +791,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     if (wave == 0) { stat_add(ST_ROWS, len); stat_add(ST_ITEMS, 1); }
   }
   if (threadIdx.x == 0) *next_slot = next_hdr;
-  if (a.dbg & 32) return;  // dbg 32: no merge / output (workgroup-uniform)
+  if ((a.dbg & 32) || a.all_scores != nullptr) return;  // dbg 32: no merge / output (workgroup-uniform)
   // ---- merge the 16 wave lists of every query (the LUT region is free now)
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
@@ -807,7 +870,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, per = gridDim.x >> 3;
   const uint32_t chunk = (n_items + 7u) / 8u;
   float pqreg[4][2][4];
-  const bool pq_in_regs = FAST4 && a.pq_len == 2 && !a.per_cluster;  // FAST4: pq_dim 64, 8-bit codes
+  const bool pq_in_regs = FAST4 && a.pq_len == 2 && !a.per_cluster && !a.lut_fp8;  // FAST4: pq_dim 64, 8-bit codes
   // the code-major LUT addresses LDS absolutely (see cm_lut): fail loudly if the dynamic LDS does not start at 0
   if (FAST4 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
   {
@@ -1412,34 +1475,37 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                    elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances)
 {
   CUVS_EXPECTS(k > 0, "parameter `k` in top-k must be positive.");
-  CUVS_EXPECTS(k <= 256, "ivf_pq::search: k <= 256 is supported by the fused scan");
   CUVS_EXPECTS((int64_t)k <= idx.size,
                "parameter `k` (%d) in top-k must not be larger that the total size of the index (%ld)", k,
                (long)idx.size);
   CUVS_EXPECTS(p.n_probes > 0, "n_probes (number of clusters to probe in the search) must be positive.");
   CUVS_EXPECTS(p.internal_distance_dtype == 0 || p.internal_distance_dtype == 2,
                "internal_distance_dtype must be either CUDA_R_16F or CUDA_R_32F");
-  CUVS_EXPECTS(p.lut_dtype == 0 || p.lut_dtype == 2 || p.lut_dtype == 8,
-               "lut_dtype must be CUDA_R_16F, CUDA_R_32F or CUDA_R_8U");
+  CUVS_EXPECTS(p.lut_dtype == 0 || p.lut_dtype == 2 || p.lut_dtype == 8 || p.lut_dtype == 3,
+               "lut_dtype must be CUDA_R_16F, CUDA_R_32F, CUDA_R_8U or CUDA_R_8I");
   CUVS_EXPECTS(!idx.dtype_known || et == idx.dtype, "queries dtype differs from the index dtype");
   if (n_queries == 0) return;
   const uint32_t n_probes = std::min<uint32_t>(p.n_probes, idx.n_lists);
-  const bool lut_half     = p.lut_dtype != 0;  // fp8 LUT requests run on the fp16 LUT (superset precision)
-  const bool acc_half     = lut_half && p.internal_distance_dtype == 2;
+  // fp8 LUT (the reference's fp_8bit<5, signed>): entries are rounded through that type and kept in the score type
+  const bool lut_fp8      = p.lut_dtype == 8 || p.lut_dtype == 3;
+  const bool acc_half     = p.lut_dtype != 0 && p.internal_distance_dtype == 2;
+  const bool lut_half     = lut_fp8 ? acc_half : p.lut_dtype != 0;
   const bool bits8        = idx.pq_bits == 8 && idx.pq_dim == 64;  // FAST4 path: 4 full 16-byte chunks
-  const bool big_k        = k > 64;
+  const bool large_k      = k > 256;  // beyond the register top lists: non-fused path (ivf_common.hpp)
+  const bool big_k        = k > 64 && !large_k;
+  const int k_scan        = large_k ? 1 : k;  // top-list length the scan kernel is launched with
   const size_t lds_cap    = 160 * 1024;
 
   // choose the widest interleave (queries per work item) whose LUT fits the 160 KiB LDS
   int qpb = 0;
   size_t smem = 0;
   if (!lut_half) {
-    if ((smem = scan_smem_bytes<float, float, 2>(idx, k)) <= lds_cap) qpb = 2;
-    else if ((smem = scan_smem_bytes<float, float, 1>(idx, k)) <= lds_cap) qpb = 1;
+    if ((smem = scan_smem_bytes<float, float, 2>(idx, k_scan)) <= lds_cap) qpb = 2;
+    else if ((smem = scan_smem_bytes<float, float, 1>(idx, k_scan)) <= lds_cap) qpb = 1;
   } else {
-    if ((smem = scan_smem_bytes<__half, float, 4>(idx, k)) <= lds_cap) qpb = 4;
-    else if ((smem = scan_smem_bytes<__half, float, 2>(idx, k)) <= lds_cap) qpb = 2;
-    else if ((smem = scan_smem_bytes<__half, float, 1>(idx, k)) <= lds_cap) qpb = 1;
+    if ((smem = scan_smem_bytes<__half, float, 4>(idx, k_scan)) <= lds_cap) qpb = 4;
+    else if ((smem = scan_smem_bytes<__half, float, 2>(idx, k_scan)) <= lds_cap) qpb = 2;
+    else if ((smem = scan_smem_bytes<__half, float, 1>(idx, k_scan)) <= lds_cap) qpb = 1;
   }
   CUVS_EXPECTS(qpb > 0, "ivf_pq::search: the PQ look-up table (pq_dim=%u, pq_bits=%u) does not fit 160 KiB of LDS%s",
                idx.pq_dim, idx.pq_bits, lut_half ? "" : "; try lut_dtype=CUDA_R_16F");
@@ -1448,7 +1514,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   int64_t max_batch = std::max<uint32_t>(1, p.max_internal_batch_size);
   {
     // keep the coarse distance matrix and the candidate buffers inside the workspace budget
-    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k * 8 + (int64_t)idx.rot_dim * 4 + idx.dim * 4;
+    int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k_scan * 8 + (int64_t)idx.rot_dim * 4 + idx.dim * 4;
+    if (large_k) per_q += (int64_t)largest_lists_total(idx.h_list_sizes, n_probes) * 8;
     int64_t fit   = std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q);
     max_batch     = std::min(max_batch, fit);
   }
@@ -1463,7 +1530,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   // the order in which pairs are scanned.
   // (measured at 100M x 128, n_probes 128: batch 1000 3.2 vs 4.0 ms with the head phase, batch 100 1.7 vs 1.3 ms without:
   // a second launch and a twice as long label range only pay off once the batch is large)
-  uint32_t head = (n_probes > 8 && n_queries >= 256) ? 1u : 0u;
+  uint32_t head = (n_probes > 8 && n_queries >= 256 && !large_k) ? 1u : 0u;
   if (const char* e = getenv("CUVS_AMD_PQ_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
   if (idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) head = 0;  // signed LUT entries: no early stop
   const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
@@ -1471,8 +1538,10 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)n_pairs_max : 0);
   const int64_t max_items = n_pairs_max / qpb + n_labels + 1;
   dev_buf<work_item> items(res, (size_t)max_items);
-  dev_buf<float> cand_d(res, (size_t)n_pairs_max * k);
-  dev_buf<uint32_t> cand_i(res, (size_t)n_pairs_max * k);
+  const size_t scores_ld = large_k ? largest_lists_total(idx.h_list_sizes, n_probes) : 0;
+  dev_buf<float> cand_d(res, large_k ? (size_t)bs_alloc * scores_ld : (size_t)n_pairs_max * k);
+  dev_buf<uint32_t> cand_i(res, large_k ? (size_t)bs_alloc * scores_ld : (size_t)n_pairs_max * k);
+  dev_buf<uint32_t> pair_seg(res, large_k ? (size_t)n_pairs_max : 0);
   dev_buf<float> top_d(res, (size_t)bs_alloc * k);
   dev_buf<uint32_t> top_i(res, (size_t)bs_alloc * k);
   dev_buf<uint32_t> query_kth(res, (size_t)bs_alloc);
@@ -1497,15 +1566,22 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     }
     // the tail phase (warm bounds) of the common configuration runs pq_scan2_kernel on items of 2 * qpb pairs
     // (fp16 LUT only: the fp32-LUT instance of the kernel does not fit 128 VGPRs)
-    bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && lut_half && qpb == 4;
+    bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && lut_half && qpb == 4 && !lut_fp8;  // (k <= 64 excludes the non-fused path)
     if (const char* e = getenv("CUVS_AMD_PQ_SCAN2")) use2 = use2 && atoi(e) != 0;
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data(), (int)idx.n_lists, use2 ? 2 * qpb : qpb);
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
     // per-pair candidate rows start out invalid: the scan only writes the rows of pairs that found something
-    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)n_pairs * k, res.stream));
-    HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)n_pairs * k * sizeof(uint32_t), res.stream));
+    if (!large_k) {
+      HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)n_pairs * k, res.stream));
+      HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)n_pairs * k * sizeof(uint32_t), res.stream));
+    } else {
+      HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)nq * scores_ld, res.stream));
+      HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)nq * scores_ld * sizeof(uint32_t), res.stream));
+      hipLaunchKernelGGL(pair_segments_kernel, dim3(nblk(nq, 256)), dim3(256), 0, res.stream, probes.data(),
+                         idx.list_sizes.data(), nq, n_probes, pair_seg.data());
+    }
     scan_args a;
     a.query_kth = query_kth.data();
     a.items = items.data(); a.sorted_pairs = sorted_pairs.data(); a.n_lists = idx.n_lists;
@@ -1513,9 +1589,11 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.per_cluster = idx.codebook_kind == 1;
     a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data(); a.list_sizes = idx.list_sizes.data();
     a.out_d = cand_d.data(); a.out_i = cand_i.data();
+    a.all_scores = large_k ? cand_d.data() : nullptr; a.all_rows = cand_i.data(); a.pair_seg = pair_seg.data(); a.scores_ld = scores_ld;
     a.n_probes = n_probes; a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len;
-    a.pq_bits = idx.pq_bits; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.k = (uint32_t)k;
+    a.pq_bits = idx.pq_bits; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.k = (uint32_t)k_scan;
     a.is_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
+    a.lut_fp8 = lut_fp8 ? 1 : 0;
     a.dbg   = getenv("CUVS_AMD_SCAN_DEBUG") ? atoi(getenv("CUVS_AMD_SCAN_DEBUG")) : 0;
     const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);  // persistent: one workgroup per CU
     dev_buf<unsigned long long> stats(res, (a.dbg & (128 | 512)) ? (size_t)ST_COUNT * grid * kScanWaves : 0);
@@ -1564,8 +1642,13 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
               h[ST_STAGE2] * w, (double)(h[ST_MERGE] - h[ST_HEADER] - h[ST_LUT] - h[ST_SCAN]) * w);
     }
     // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
-    select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
-                                 k, top_d.data(), top_i.data(), true);
+    if (!large_k) {
+      select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
+                                   k, top_d.data(), top_i.data(), true);
+    } else {
+      select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)scores_ld, (int64_t)scores_ld, k,
+                                   top_d.data(), top_i.data(), true);
+    }
     const float sc = ivf_pq_index::scale(et);
     hipLaunchKernelGGL(postprocess_kernel, dim3(nblk(nq * k, 256)), dim3(256), 0, res.stream, top_i.data(),
                        top_d.data(), nq * k, idx.indices.data(), idx.metric, sc * sc, neighbors + q0 * k,

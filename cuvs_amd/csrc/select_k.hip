@@ -37,13 +37,17 @@ __global__ __launch_bounds__(kSelThreads) void select_k_radix_kernel(const float
                                                                      bool select_min,
                                                                      int64_t idx_offset,
                                                                      int64_t out_ld,
-                                                                     int64_t out_col_offset)
+                                                                     int64_t out_col_offset,
+                                                                     char* __restrict__ big_k_scratch)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* hist      = reinterpret_cast<int*>(smem_raw);            // kBins
   int* scan      = hist + kBins;                                 // 32
   int* ctrl      = scan + 32;                                    // 8
-  int64_t* s_idx = reinterpret_cast<int64_t*>(ctrl + 8);         // kp2 (8-byte aligned: 8192+160)
+  // the k winners live in LDS up to 8192 of them; beyond that in a per-row slice of a global scratch buffer (the
+  // bitonic sort then runs on global memory - slow, but k in the tens of thousands is not a hot path)
+  char* win      = big_k_scratch ? big_k_scratch + (size_t)blockIdx.x * kp2 * 12 : reinterpret_cast<char*>(ctrl + 8);
+  int64_t* s_idx = reinterpret_cast<int64_t*>(win);              // kp2 (8-byte aligned: 8192+160)
   uint32_t* s_key = reinterpret_cast<uint32_t*>(s_idx + kp2);    // kp2
 
   const int tid       = threadIdx.x;
@@ -186,20 +190,32 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
               int64_t idx_offset, int64_t out_ld, int64_t out_col_offset)
 {
   if (rows == 0 || k == 0) return;
-  CUVS_EXPECTS(k > 0 && k <= 2048, "select_k: k must be in [1, 2048], got %d", k);
+  CUVS_EXPECTS(k > 0 && k <= (1 << 24), "select_k: k must be in [1, 2^24], got %d", k);
   CUVS_EXPECTS(rows < (int64_t(1) << 31), "select_k: too many rows");
   if (out_ld < 0) out_ld = k;
-  int kp2     = next_pow2(k);
-  size_t smem = (kBins + 32 + 8) * sizeof(int) + (size_t)kp2 * (sizeof(int64_t) + sizeof(uint32_t));
-  dim3 grid((unsigned)rows), block(kSelThreads);
-  if (in_idx != nullptr) {
-    hipLaunchKernelGGL((select_k_radix_kernel<InIdxT, OutIdxT, true>), grid, block, smem, res.stream, in,
-                       in_idx, len, in_ld, k, kp2, out_val, out_idx, select_min, idx_offset, out_ld,
-                       out_col_offset);
-  } else {
-    hipLaunchKernelGGL((select_k_radix_kernel<InIdxT, OutIdxT, false>), grid, block, smem, res.stream, in,
-                       in_idx, len, in_ld, k, kp2, out_val, out_idx, select_min, idx_offset, out_ld,
-                       out_col_offset);
+  const int kp2      = next_pow2(k);
+  const bool in_lds  = kp2 <= 8192;
+  const size_t smem  = (kBins + 32 + 8) * sizeof(int) + (in_lds ? (size_t)kp2 * (sizeof(int64_t) + sizeof(uint32_t)) : 0);
+  // rows per launch when the winners live in global scratch: bounded by the workspace budget
+  const int64_t rows_per = in_lds ? rows : std::max<int64_t>(1, (int64_t)(res.workspace_limit / ((size_t)kp2 * 12)));
+  dev_buf<char> scratch(res, in_lds ? 0 : (size_t)std::min(rows, rows_per) * kp2 * 12);
+  for (int64_t r0 = 0; r0 < rows; r0 += rows_per) {
+    dim3 grid((unsigned)std::min(rows_per, rows - r0)), block(kSelThreads);
+    const float* in_r      = in + r0 * in_ld;
+    const InIdxT* in_idx_r = in_idx ? in_idx + r0 * in_ld : nullptr;
+    float* out_val_r       = out_val + r0 * out_ld;
+    OutIdxT* out_idx_r     = out_idx + r0 * out_ld;
+    if (in_idx != nullptr) {
+      auto kern = select_k_radix_kernel<InIdxT, OutIdxT, true>;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(kern, grid, block, smem, res.stream, in_r, in_idx_r, len, in_ld, k, kp2, out_val_r, out_idx_r,
+                         select_min, idx_offset, out_ld, out_col_offset, scratch.data());
+    } else {
+      auto kern = select_k_radix_kernel<InIdxT, OutIdxT, false>;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(kern, grid, block, smem, res.stream, in_r, in_idx_r, len, in_ld, k, kp2, out_val_r, out_idx_r,
+                         select_min, idx_offset, out_ld, out_col_offset, scratch.data());
+    }
   }
   HIP_TRY(hipGetLastError());
 }

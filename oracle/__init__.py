@@ -97,9 +97,13 @@ def recall(found, truth):
     return hits / truth.size
 
 
-def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.0):
-    """Search an index exported with cuvs_amd.neighbors.ivf_pq.export_for_oracle (fp32 LUT / fp32 scores).
-    Returns (distances, neighbors); bit-for-bit twin of cuvsIvfPqSearch at the default dtypes."""
+_LUT_MODES = {"f32": 0, "f16": 1, "fp8": 2}
+
+
+def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.0, lut="f32", acc="f32"):
+    """Search an index exported with cuvs_amd.neighbors.ivf_pq.export_for_oracle. lut: "f32" | "f16" | "fp8" (the
+    reference's fp_8bit<5, signed-for-inner-product>), acc: "f32" | "f16" (search_params.lut_dtype /
+    internal_distance_dtype). Returns (distances, neighbors); bit-for-bit twin of cuvsIvfPqSearch."""
     q = _f32(queries)
     centers = _f32(exported["centers"])
     centers_rot = _f32(exported["centers_rot"])
@@ -118,8 +122,21 @@ def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.
         C.c_int(len(sizes)), C.c_int(rotation.shape[0]), C.c_int(int(exported["pq_dim"])),
         C.c_int(int(exported["pq_len"])), C.c_int(int(exported["pq_bits"])), _p(sizes), _p(start), _p(codes), _p(ids),
         C.c_int(_metric(metric)), C.c_int(n_probes), C.c_int(k), C.c_float(scale), _p(nb), _p(ds),
-        C.c_int(int(bool(exported.get("per_cluster", False)))))
+        C.c_int(int(bool(exported.get("per_cluster", False)))), C.c_int(_LUT_MODES[lut]), C.c_int(_LUT_MODES[acc]))
     return ds, nb
+
+
+def fp8_round_trip(values, signed=False, to_half=False):
+    """decode(encode(v)) of the reference's fp_8bit<5, signed> (ivf_pq_fp_8bit.cuh:32-100), element-wise."""
+    L = lib()
+    L.oracle_fp8_encode.restype = C.c_uint8
+    L.oracle_fp8_decode_f32.restype = C.c_float
+    L.oracle_fp8_decode_f16.restype = C.c_float
+    dec = L.oracle_fp8_decode_f16 if to_half else L.oracle_fp8_decode_f32
+    v = np.asarray(values, np.float32)
+    out = np.array([dec(C.c_uint8(L.oracle_fp8_encode(C.c_float(float(x)), C.c_int(int(signed)))), C.c_int(int(signed)))
+                    for x in v.ravel()], np.float32)
+    return out.reshape(v.shape)
 
 
 def pq_encode(resid, pq_centers, pq_bits):

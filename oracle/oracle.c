@@ -291,6 +291,46 @@ EXPORT int oracle_num_threads(void)
 }
 
 /* ------------------------------------------------------------------ IVF-PQ search on an exported index */
+/* ---- reduced-precision LUT entries and scores of the IVF-PQ search (search_params.lut_dtype / internal_distance_dtype,
+ * ivf_pq.hpp:167-205). fp16: IEEE half, round to nearest even (F16C). fp8: the reference's own 8-bit storage type
+ * fp_8bit<5, Signed> (ivf_pq_fp_8bit.cuh:32-100): 5 exponent bits (bias 15), 3 value bits, truncation on encode, half an
+ * ulp added back on decode; the signed flavour (inner-product metrics, ivf_pq_search.cuh:711-728) keeps the sign in bit
+ * 0. Its decoders to float (:75-88) and to half (:90-102) differ for the smallest exponent (the half has no implicit
+ * one there), and which one runs depends on the score type - both are restated. */
+#include <immintrin.h>
+static inline uint16_t f32_to_f16(float f) { return _cvtss_sh(f, 0); }
+static inline float f16_to_f32(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint8_t fp8_encode_unsigned(float v)
+{
+  const float kMin = 1.0f / 32768.0f, kMax = 65536.0f * (2.0f - 0.125f);
+  if (v < kMin) return 0;
+  if (v >= kMax) return 0xff;
+  uint32_t u; memcpy(&u, &v, 4);
+  return (uint8_t)((u + (15u << 23) - 0x3f800000u) >> 20);
+}
+static inline uint8_t fp8_encode(float v, int is_signed)
+{
+  if (!is_signed) return fp8_encode_unsigned(v);
+  uint8_t u = fp8_encode_unsigned(fabsf(v));
+  return (uint8_t)((u & 0xfeu) | (v < 0.f ? 1u : 0u));
+}
+static inline float fp8_decode_f32(uint8_t b, int is_signed)
+{
+  uint32_t u = is_signed ? (b & ~1u) : b;
+  uint32_t bits = ((0x3f800000u | (0x00400000u >> 3)) - (15u << 23)) + (u << 20);
+  float r; memcpy(&r, &bits, 4);
+  return (is_signed && (b & 1u)) ? -r : r;
+}
+static inline uint16_t fp8_decode_f16(uint8_t b, int is_signed)
+{
+  uint16_t u = is_signed ? (uint16_t)(b & ~1u) : b;
+  uint16_t bits = (uint16_t)(((0x3c00u | (0x0200u >> 3)) - (15u << 10)) + (u << 7));
+  return (is_signed && (b & 1u)) ? (uint16_t)(bits ^ 0x8000u) : bits;
+}
+EXPORT uint8_t oracle_fp8_encode(float v, int is_signed) { return fp8_encode(v, is_signed); }
+EXPORT float oracle_fp8_decode_f32(uint8_t b, int is_signed) { return fp8_decode_f32(b, is_signed); }
+EXPORT float oracle_fp8_decode_f16(uint8_t b, int is_signed) { return f16_to_f32(fp8_decode_f16(b, is_signed)); }
+
 /* Restates ivf_pq_search.cuh:60-168 (select_clusters), :1003-1017 (rotation), create_lut_impl.cuh:17-78 (LUT),
  * compute_distances_impl.cuh:73-91 / compute_score_impl.cuh:20-79 (score = sum of LUT entries in subspace
  * order), ivf_pq_search.cuh:646-674 (merge of n_probes*k candidates, distance/neighbour post-processing),
@@ -311,8 +351,9 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
                                  int n_lists, int rot_dim, int pq_dim, int pq_len, int pq_bits,
                                  const uint32_t* list_sizes, const int64_t* list_start, const uint8_t* codes,
                                  const int64_t* ids, int metric, int n_probes, int k, float scale,
-                                 int64_t* neighbors, float* distances, int per_cluster)
-{  /* per_cluster: pq_centers is [n_lists, pq_len, book] (codebook_gen::PER_CLUSTER), else [pq_dim, pq_len, book] */
+                                 int64_t* neighbors, float* distances, int per_cluster, int lut_mode, int acc_mode)
+{  /* lut_mode 0 fp32 / 1 fp16 / 2 fp8 LUT entries; acc_mode 0 fp32 / 1 fp16 scores (sums in subspace order).
+    * per_cluster: pq_centers is [n_lists, pq_len, book] (codebook_gen::PER_CLUSTER), else [pq_dim, pq_len, book] */
   const int book = 1 << pq_bits;
   const int bpr  = (pq_dim * pq_bits + 7) / 8;
   const int is_cos = metric == M_CosineExpanded;         /* inner product of unit vectors, reported as 1 - cos */
@@ -369,6 +410,11 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
               if (!is_ip) { float diff = qv[dd] - pc; sc = fmaf(diff, diff, sc); }
               else        { sc = fmaf(-qv[dd], cr[dd], sc); sc = fmaf(-qv[dd], pc, sc); }
             }
+            if (lut_mode == 1) sc = f16_to_f32(f32_to_f16(sc));
+            else if (lut_mode == 2) {
+              const uint8_t b = fp8_encode(sc, is_ip);
+              sc = acc_mode == 1 ? f16_to_f32(fp8_decode_f16(b, is_ip)) : fp8_decode_f32(b, is_ip);
+            }
             lut[s * book + c] = sc;
           }
         for (int j = 0; j < k; ++j) { best[j].d = FLT_MAX; best[j].id = INT64_MAX; }
@@ -376,7 +422,11 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
         for (uint32_t v = 0; v < len; ++v) {
           const uint8_t* row = codes + (list_start[L] + v) * bpr;
           float acc = 0.f;
-          for (int s = 0; s < pq_dim; ++s) acc = acc + lut[s * book + code_at(row, s, pq_bits)];
+          if (acc_mode == 1) {  /* half-precision adds: every partial sum rounds to half */
+            for (int s = 0; s < pq_dim; ++s) acc = f16_to_f32(f32_to_f16(acc + lut[s * book + code_at(row, s, pq_bits)]));
+          } else {
+            for (int s = 0; s < pq_dim; ++s) acc = acc + lut[s * book + code_at(row, s, pq_bits)];
+          }
           topk_insert(best, k, acc, pad_off[L] + v);
         }
         for (int j = 0; j < k; ++j) {

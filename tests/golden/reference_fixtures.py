@@ -51,3 +51,43 @@ KMEANS_C_CENTROIDS = np.array([[1.5, 1.5], [10.5, 10.5]], dtype=np.float32)
 KMEANS_C_LABELS = np.array([0, 0, 0, 0, 1, 1, 1, 1], dtype=np.int32)
 KMEANS_C_INERTIA = 4.0
 KMEANS_C_TOL = 1e-4
+
+# java/cuvs-java/src/test/java/com/nvidia/cuvs/BruteForceAndSearchIT.java:36-47 (same 4x2 data as the CAGRA C test),
+# :93-100 — brute force L2Expanded, k = 3: {id: distance} per query (a Java Map: unordered), compared with
+# |d - d_exp| < 1e-4 (CuVSTestCase.java:128).
+BF_JAVA_K3 = [
+    {3: 0.038782537, 2: 0.35904616, 0: 0.83774555},
+    {0: 0.12472606, 2: 0.21700788, 1: 0.3191862},
+    {3: 0.047766685, 2: 0.20332813, 0: 0.48305476},
+    {1: 0.15224183, 0: 0.5906347, 3: 0.5986643},
+]
+# :109-122 — the same search with a bitset prefilter keeping rows {0, 1, 3} (one BitSet per query, all equal)
+BF_JAVA_K3_FILTER_KEEP = [0, 1, 3]
+BF_JAVA_K3_FILTERED = [
+    {0: 0.83774555, 1: 1.0540828, 3: 0.038782537},
+    {0: 0.12472606, 1: 0.3191862, 3: 0.32186073},
+    {0: 0.48305476, 1: 0.7208309, 3: 0.047766685},
+    {0: 0.5906347, 1: 0.15224195, 3: 0.5986643},
+]
+JAVA_TOL = 1e-4
+
+# java/cuvs-java/src/test/java/com/nvidia/cuvs/CagraBuildAndSearchIT.java:104-109 — CAGRA on the same data, k = 3
+CAGRA_JAVA_K3 = [
+    {3: 0.038782578, 2: 0.3590463, 0: 0.83774555},
+    {0: 0.12472608, 2: 0.21700792, 1: 0.31918612},
+    {3: 0.047766715, 2: 0.20332818, 0: 0.48305473},
+    {1: 0.15224178, 0: 0.59063464, 3: 0.5986642},
+]
+
+# Rust binding tests (property KATs on uniform [0,1) data; the queries are the first 4 dataset rows and every query
+# must come back as its own nearest neighbour):
+#   rust/cuvs/src/brute_force.rs:125-177   16 x 8,   k = 4, L2Expanded
+#   rust/cuvs/src/ivf_pq/index.rs:101-151  1024 x 16, n_lists 64 (other params default), k = 10
+#   rust/cuvs/src/ivf_flat/index.rs:110-...  1024 x 16, n_lists 64, k = 10
+#   rust/cuvs/src/cagra/index.rs:302-312   default build params
+RUST_SELF_NEIGHBOR_CASES = {
+    "brute_force": dict(n=16, dim=8, k=4),
+    "ivf_pq": dict(n=1024, dim=16, k=10, n_lists=64),
+    "ivf_flat": dict(n=1024, dim=16, k=10, n_lists=64),
+    "cagra": dict(n=256, dim=16, k=10),
+}

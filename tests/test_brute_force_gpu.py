@@ -141,3 +141,11 @@ def test_fused_and_tiled_paths_agree(metric, monkeypatch):
     monkeypatch.setenv("CUVS_AMD_BF_FUSED", "1")
     fd, fi = _run(x, qq, 33, metric)
     assert (fi == ti).all() and (fd == td).all()
+
+
+def test_large_k():
+    """k beyond 2048 (no bound in the reference): bit-identical to the oracle."""
+    x, qq = _gen(9000, 24, 5, seed=13)
+    gd, gi = _run(x, qq, 3000, "sqeuclidean")
+    od, oi = oracle.brute_force_knn(qq, x, 3000)
+    assert (gi == oi).all() and (gd == od).all()

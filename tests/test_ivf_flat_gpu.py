@@ -141,3 +141,18 @@ def test_cosine_parity_and_recall(dtype, n, d, n_lists, k, n_probes):
     if n_probes == n_lists:
         truth = np.argsort(cosd, axis=1, kind="stable")[:, :k]
         assert oracle.recall(gi, truth) > 0.99
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+def test_large_k_non_fused_path(metric):
+    """k > 256: the reference leaves its fused top-k for "write every score + select_k" (ivf_flat_search.cuh:180,283);
+    so does this library - results identical to the oracle, including the padding when fewer than k rows are probed."""
+    from cuvs_amd.neighbors import ivf_flat
+
+    x, q = _gen(6000, 24, 40, seed=5)
+    index = _build(x, n_lists=16, metric=metric, kmeans_n_iters=10)
+    ex = ivf_flat.export_for_oracle(index, np.float32)
+    for k, n_probes in ((512, 6), (1000, 2), (300, 16)):
+        gd, gi = _search(index, q, k, n_probes)
+        od, oi = oracle.ivf_flat_search(ex, q, k, n_probes, metric=metric)
+        assert (gi == oi).all() and (gd == od).all(), (k, n_probes)

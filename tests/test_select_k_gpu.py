@@ -59,3 +59,14 @@ def test_select_k_with_input_indices():
     gv, gi = _gpu_select(v, 10, True, ids)
     ov, oi = oracle.select_k(v, 10, True, in_idx=ids)
     assert (gi == oi).all() and (gv == ov).all()
+
+
+@pytest.mark.parametrize("rows,ln,k", [(3, 20000, 4096), (2, 30000, 8192), (2, 50000, 20000), (1, 3000, 3000)])
+def test_select_k_large_k(rows, ln, k):
+    """k beyond 2048 (the reference's select_k has no bound): winners in LDS up to 8192, in global scratch beyond."""
+    rng = np.random.default_rng(k)
+    v = rng.standard_normal((rows, ln)).astype(np.float32)
+    v[0, ::7] = 0.25  # ties across the k-th value
+    gv, gi = _gpu_select(v, k, True)
+    ov, oi = oracle.select_k(v, k, True)
+    assert (gi == oi).all() and (gv == ov).all()
