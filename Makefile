@@ -10,7 +10,7 @@ CFLAGS     := -O3 -march=x86-64-v3 -fPIC -fopenmp -ffp-contract=off -Wall -std=c
 
 SRCS := $(wildcard cuvs_amd/csrc/*.hip)
 OBJS := $(patsubst cuvs_amd/csrc/%.hip,build/%.o,$(SRCS))
-HDRS := $(wildcard cuvs_amd/csrc/*.hpp) $(wildcard include/cuvs/*/*.h) include/dlpack/dlpack.h
+HDRS := $(wildcard cuvs_amd/csrc/*.hpp) $(wildcard include/cuvs/*/*.h) $(wildcard include/cuvs_amd/*.h) include/dlpack/dlpack.h
 
 all: cuvs_amd/libcuvs_c.so oracle/liboracle.so
 

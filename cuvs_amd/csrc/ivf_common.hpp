@@ -65,11 +65,17 @@ __global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const u
 // others move to n_lists + list, so that one grouping yields [head items | tail items]. The head phase runs first
 // and leaves a per-query k-th bound that is already close to final - which is what makes the early stop of the
 // tail phase bite. Results do not depend on the order in which pairs are scanned.
+// List-sharded search (shard_world > 1): pairs that probe a list of another rank get the label `skip` - a bucket
+// past the scanned ranges, so that no work item is ever run for them.
 __global__ void phase_labels_kernel(const uint32_t* __restrict__ probes, int64_t n_pairs, uint32_t n_probes,
-                                    uint32_t head, uint32_t n_lists, uint32_t* __restrict__ out)
+                                    uint32_t head, uint32_t n_lists, uint32_t* __restrict__ out,
+                                    uint32_t shard_world = 1, uint32_t shard_rank = 0, uint32_t skip = 0)
 {
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x)
-    out[p] = probes[p] + ((uint32_t)(p % n_probes) < head ? 0u : n_lists);
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t L = probes[p];
+    const bool mine  = shard_world <= 1 || L % shard_world == shard_rank;
+    out[p] = !mine ? skip : L + (((uint32_t)(p % n_probes) < head || head == 0) ? 0u : n_lists);
+  }
 }
 
 // ------------------------------------------------------------------ register-resident sorted top list (one wave)

@@ -42,6 +42,12 @@ struct ivf_pq_index {
   dev_buf<uint32_t> list_offsets; // [n_lists + 1] (rows, multiples of 64)
   std::vector<uint32_t> h_list_sizes, h_list_offsets;
 
+  // List-sharded multi-GPU search (shard_comm.hip): every rank holds the whole model (centres, rotation, codebooks) but
+  // only the lists it owns - list L belongs to rank L % shard_world. extend() drops rows of foreign lists, search()
+  // scans only owned probes; the per-rank top-k lists are all-gathered and merged. shard_world == 1: not sharded.
+  int shard_rank = 0, shard_world = 1;
+  bool owns(uint32_t L) const { return shard_world <= 1 || (int)(L % (uint32_t)shard_world) == shard_rank; }
+
   static float scale(elem_t et)  // kDivisor(T) / kDivisor(float), ann_utils.cuh:134-160
   {
     return et == elem_t::u8 ? 256.0f : (et == elem_t::i8 ? 128.0f : 1.0f);

@@ -524,6 +524,13 @@ std::unique_ptr<ivf_pq_index> ivf_pq_build(resources& res, const ivf_pq_build_pa
   return idx;
 }
 
+__global__ void drop_foreign_labels_kernel(uint32_t* __restrict__ labels, int64_t n, uint32_t n_lists, uint32_t world,
+                                           uint32_t rank)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && labels[i] % world != rank) labels[i] = n_lists;
+}
+
 void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t et, int64_t n_new, bool is_host,
                    const int64_t* new_ids, bool ids_on_host)
 {
@@ -557,10 +564,19 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
                              idx.center_norms.data(), labels.data() + r0, nullptr);
     }
   }
-  // ---- 2. group the new rows by list
-  dev_buf<uint32_t> perm(res, n_new), new_off(res, idx.n_lists + 1);
-  group_by_label(res, labels.data(), n_new, idx.n_lists, perm.data(), new_off.data());
-  std::vector<uint32_t> h_new_off = to_host(res, new_off.data(), idx.n_lists + 1);
+  // ---- 2. group the new rows by list. A list-sharded index (ivf_pq.hpp) keeps only the rows of the lists this rank
+  // owns: the others are relabelled to an extra bucket at the end of the grouping and never encoded.
+  const bool sharded = idx.shard_world > 1;
+  if (sharded)
+    hipLaunchKernelGGL(drop_foreign_labels_kernel, dim3(nblk(n_new, 256)), dim3(256), 0, res.stream, labels.data(), n_new,
+                       idx.n_lists, (uint32_t)idx.shard_world, (uint32_t)idx.shard_rank);
+  const uint32_t n_buckets = idx.n_lists + (sharded ? 1u : 0u);
+  dev_buf<uint32_t> perm(res, n_new), new_off(res, n_buckets + 1);
+  group_by_label(res, labels.data(), n_new, n_buckets, perm.data(), new_off.data());
+  std::vector<uint32_t> h_new_off = to_host(res, new_off.data(), n_buckets + 1);
+  const int64_t n_all = n_new;
+  n_new               = h_new_off[idx.n_lists];  // rows that stay on this rank (all of them when not sharded)
+  (void)n_all;
 
   // ---- 3. new flat layout
   std::vector<uint32_t> sizes(idx.n_lists), offs(idx.n_lists + 1);

@@ -1533,9 +1533,11 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   uint32_t head = (n_probes > 8 && n_queries >= 256 && !large_k) ? 1u : 0u;
   if (const char* e = getenv("CUVS_AMD_PQ_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
   if (idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) head = 0;  // signed LUT entries: no early stop
-  const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
+  const bool sharded      = idx.shard_world > 1;  // list-sharded index: foreign probes go to a bucket that is never scanned
+  const uint32_t n_ranges = head > 0 ? 2 * idx.n_lists : idx.n_lists;
+  const uint32_t n_labels = n_ranges + (sharded ? 1u : 0u);
   dev_buf<uint32_t> sorted_pairs(res, (size_t)n_pairs_max), pair_off(res, n_labels + 1), item_off(res, n_labels + 1);
-  dev_buf<uint32_t> phase_labels(res, head > 0 ? (size_t)n_pairs_max : 0);
+  dev_buf<uint32_t> phase_labels(res, (head > 0 || sharded) ? (size_t)n_pairs_max : 0);
   const int64_t max_items = n_pairs_max / qpb + n_labels + 1;
   dev_buf<work_item> items(res, (size_t)max_items);
   const size_t scores_ld = large_k ? largest_lists_total(idx.h_list_sizes, n_probes) : 0;
@@ -1559,9 +1561,10 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                                     nullptr, nullptr, M_InnerProduct, rot_q.data(), idx.rot_dim);
     // list-major grouping of the (query, probe) pairs
     const uint32_t* labels = probes.data();
-    if (head > 0) {
+    if (head > 0 || sharded) {
       hipLaunchKernelGGL(phase_labels_kernel, dim3(nblk(n_pairs, 256)), dim3(256), 0, res.stream, probes.data(),
-                         n_pairs, n_probes, head, idx.n_lists, phase_labels.data());
+                         n_pairs, n_probes, head, idx.n_lists, phase_labels.data(), (uint32_t)idx.shard_world,
+                         (uint32_t)idx.shard_rank, n_ranges);
       labels = phase_labels.data();
     }
     // the tail phase (warm bounds) of the common configuration runs pq_scan2_kernel on items of 2 * qpb pairs

@@ -1,0 +1,196 @@
+// List-sharded multi-GPU search: communicator (RCCL over xGMI, one process per GPU), the all-gather of per-rank
+// top-k blocks and their merge. Interface and the reference code it stands in for: include/cuvs_amd/shard.h
+// (reference: cpp/src/neighbors/mg/snmg.cuh:248-375 sharded search + :298-340 NCCL send/recv fan-in,
+// cpp/src/neighbors/detail/knn_merge_parts.cuh:27-103).
+//
+// One ncclAllGather per batch instead of the reference's R-1 send/recv pairs into a root: xGMI is point-to-point, a
+// ring all-gather of 12 * Q * k bytes per rank (1.2 MB at Q = 10k, k = 10) keeps every link busy once, and every
+// rank ends up with the merged result (no broadcast afterwards).
+#include "ivf_pq.hpp"
+#include "ops.hpp"
+
+#include <cuvs_amd/shard.h>
+
+#include <rccl/rccl.h>
+
+#include <cfloat>
+#include <dlfcn.h>
+#include <mutex>
+
+struct cuvsAmdShardComm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+namespace cuvs_amd {
+namespace {
+
+// RCCL entry points, resolved once. dlopen by soname: if the process already holds librccl.so.1 (PyTorch loads its
+// own copy), that copy is shared; otherwise the ROCm one is loaded.
+struct rccl_api {
+  decltype(&ncclGetUniqueId) get_unique_id       = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank     = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy        = nullptr;
+  decltype(&ncclAllGather) all_gather            = nullptr;
+  decltype(&ncclGetErrorString) get_error_string = nullptr;
+};
+
+const rccl_api& rccl()
+{
+  static rccl_api api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h != nullptr) break;
+    }
+    if (h == nullptr) return;
+    api.get_unique_id    = reinterpret_cast<decltype(api.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    api.comm_init_rank   = reinterpret_cast<decltype(api.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+    api.comm_destroy     = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    api.all_gather       = reinterpret_cast<decltype(api.all_gather)>(dlsym(h, "ncclAllGather"));
+    api.get_error_string = reinterpret_cast<decltype(api.get_error_string)>(dlsym(h, "ncclGetErrorString"));
+  });
+  CUVS_EXPECTS(api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather && api.get_error_string,
+               "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+  return api;
+}
+
+#define RCCL_TRY(expr)                                                                                   \
+  do {                                                                                                   \
+    ncclResult_t r__ = (expr);                                                                           \
+    if (r__ != ncclSuccess) CUVS_FAIL("RCCL error %d (%s) in %s", (int)r__, rccl().get_error_string(r__), #expr); \
+  } while (0)
+
+// one candidate = 12 bytes on the wire: [n_queries, k] distances (fp32) followed by [n_queries, k] ids (int64)
+__global__ void pack_block_kernel(const float* __restrict__ d, const int64_t* __restrict__ i, int64_t n,
+                                  char* __restrict__ out)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  reinterpret_cast<float*>(out)[t]                = d[t];
+  reinterpret_cast<int64_t*>(out + (size_t)n * 4)[t] = i[t];
+}
+
+// gathered [world][ distances n*4 | ids n*8 ] -> per-query rows [n_queries, world * k] (rank-major inside a row)
+// Slots a rank could not fill (fewer than k rows in its probed lists) carry the id INT64_MAX and the distance FLT_MAX
+// (ivf_common.cuh:31 kOutOfBoundsRecord); for similarity metrics they must lose the merge, so they enter it as -FLT_MAX
+// and leave it as FLT_MAX again (pad_invalid_kernel).
+__global__ void regroup_kernel(const char* __restrict__ gathered, int64_t nq, int k, int world, float* __restrict__ vals,
+                               int64_t* __restrict__ ids, bool select_min)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = nq * k;
+  if (t >= n * world) return;
+  const int64_t r = t / n, rem = t % n, q = rem / k, j = rem % k;
+  const char* blk = gathered + (size_t)r * n * 12;
+  const int64_t o = q * ((int64_t)world * k) + r * k + j;
+  const int64_t id = reinterpret_cast<const int64_t*>(blk + (size_t)n * 4)[rem];
+  const float v    = reinterpret_cast<const float*>(blk)[rem];
+  vals[o]          = id == INT64_MAX ? (select_min ? FLT_MAX : -FLT_MAX) : v;
+  ids[o]           = id;
+}
+
+__global__ void pad_invalid_kernel(float* __restrict__ d, const int64_t* __restrict__ i, int64_t n)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n && i[t] == INT64_MAX) d[t] = FLT_MAX;
+}
+
+}  // namespace
+
+// host/CPU-testable twin of the merge rule lives in cuvs_amd/mg.py (`merge_gathered`); the device path:
+void shard_all_gather_topk(resources& res, cuvsAmdShardComm& c, const float* ld, const int64_t* li, int64_t nq, int k,
+                           bool select_min, float* out_d, int64_t* out_i)
+{
+  CUVS_EXPECTS(nq >= 0 && k > 0, "shard all-gather: bad shape");
+  if (nq == 0) return;
+  const int64_t n = nq * k;
+  dev_buf<char> send(res, (size_t)n * 12), recv(res, (size_t)n * 12 * c.world);
+  hipLaunchKernelGGL(pack_block_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, ld, li, n, send.data());
+  profile_begin(res, "shard_all_gather");
+  RCCL_TRY(rccl().all_gather(send.data(), recv.data(), (size_t)n * 12, ncclUint8, c.comm, res.stream));
+  profile_end(res, "shard_all_gather");
+  dev_buf<float> vals(res, (size_t)n * c.world);
+  dev_buf<int64_t> ids(res, (size_t)n * c.world);
+  hipLaunchKernelGGL(regroup_kernel, dim3(grid_blocks(n * c.world, 256)), dim3(256), 0, res.stream, recv.data(), nq, k,
+                     c.world, vals.data(), ids.data(), select_min);
+  select_k<int64_t, int64_t>(res, vals.data(), ids.data(), nq, (int64_t)c.world * k, (int64_t)c.world * k, k, out_d, out_i,
+                             select_min);
+  hipLaunchKernelGGL(pad_invalid_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, out_d, out_i, n);
+  HIP_TRY(hipGetLastError());
+}
+
+}  // namespace cuvs_amd
+
+using namespace cuvs_amd;
+
+extern "C" {
+
+cuvsError_t cuvsAmdShardCommGetUniqueId(char id[CUVS_AMD_SHARD_ID_BYTES])
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    static_assert(CUVS_AMD_SHARD_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId u;
+    RCCL_TRY(rccl().get_unique_id(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  });
+}
+
+cuvsError_t cuvsAmdShardCommCreate(cuvsResources_t res_h, const char id[CUVS_AMD_SHARD_ID_BYTES], int rank, int world,
+                                   cuvsAmdShardComm_t* comm)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(world >= 1 && rank >= 0 && rank < world, "shard comm: rank %d of %d", rank, world);
+    resources& res = *as_res(res_h);
+    HIP_TRY(hipSetDevice(res.device));
+    auto c = std::make_unique<cuvsAmdShardComm>();
+    c->rank = rank; c->world = world; c->device = res.device;
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    RCCL_TRY(rccl().comm_init_rank(&c->comm, world, u, rank));
+    *comm = c.release();
+  });
+}
+
+cuvsError_t cuvsAmdShardCommDestroy(cuvsAmdShardComm_t comm)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    if (comm == nullptr) return;
+    if (comm->comm != nullptr) RCCL_TRY(rccl().comm_destroy(comm->comm));
+    delete comm;
+  });
+}
+
+cuvsError_t cuvsAmdShardCommRank(cuvsAmdShardComm_t comm, int* rank, int* world)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(comm != nullptr, "null shard communicator");
+    *rank = comm->rank; *world = comm->world;
+  });
+}
+
+cuvsError_t cuvsAmdIvfPqSetListShard(cuvsIvfPqIndex_t index, int rank, int world)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(index != nullptr && index->addr != 0, "IVF-PQ index is not built");
+    CUVS_EXPECTS(world >= 1 && rank >= 0 && rank < world, "list shard: rank %d of %d", rank, world);
+    auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
+    CUVS_EXPECTS(idx.size == 0, "list shard: the index already holds rows (build with add_data_on_build = false)");
+    idx.shard_rank = rank; idx.shard_world = world;
+  });
+}
+
+cuvsError_t cuvsAmdShardAllGatherTopK(cuvsResources_t res_h, cuvsAmdShardComm_t comm, const float* local_distances,
+                                      const int64_t* local_neighbors, int64_t n_queries, int k, int select_min,
+                                      float* distances, int64_t* neighbors)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(comm != nullptr, "null shard communicator");
+    shard_all_gather_topk(*as_res(res_h), *comm, local_distances, local_neighbors, n_queries, k, select_min != 0, distances,
+                          neighbors);
+  });
+}
+
+}  // extern "C"

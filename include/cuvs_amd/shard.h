@@ -1,0 +1,53 @@
+/* List-sharded multi-GPU IVF-PQ search: one process per GPU, RCCL all-gather of the per-rank top-k over xGMI.
+ *
+ * What it replaces in the reference: cuvs::neighbors::mg sharded search - rank-local search, then the partial top-k
+ * lists are exchanged with ncclSend/ncclRecv and merged (cpp/src/neighbors/mg/snmg.cuh:248-375, NCCL call sites
+ * :298-340, merge knn_merge_parts.cuh:27-103). The reference shards by ROW RANGE inside one process
+ * (c/include/cuvs/neighbors/mg_ivf_pq.h:152-190; built here too, mg.hip); this header adds the split the target
+ * asks for - shard by IVF LIST with one global coarse quantizer - for one process per GPU:
+ *   - every rank trains / loads the same model (centres, rotation, codebooks); list L belongs to rank L % world;
+ *   - cuvsIvfPqExtend on a sharded index keeps only the rows that fall into the rank's lists;
+ *   - cuvsIvfPqSearch on a sharded index ranks ALL centres, takes the global n_probes nearest and scans the ones it
+ *     owns: over all ranks exactly the (query, probe) pairs a single GPU would scan, each once;
+ *   - cuvsAmdShardAllGatherTopK: ONE ncclAllGather of the [n_queries, k] (distance, id) blocks (12 B per candidate) and
+ *     an R-way merge on every rank; the result equals the single-GPU search of the whole index.
+ * The communicator wraps an RCCL ncclComm_t. RCCL is loaded at run time (dlopen "librccl.so.1": the copy a host
+ * framework has already loaded is reused), so the library has no link-time dependency on it.
+ */
+#pragma once
+#include <cuvs/core/c_api.h>
+#include <cuvs/core/export.h>
+#include <cuvs/neighbors/ivf_pq.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUVS_AMD_SHARD_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
+
+typedef struct cuvsAmdShardComm* cuvsAmdShardComm_t;
+
+/* rank 0 creates the rendezvous id and hands its 128 bytes to the other ranks by any means (file, MPI, torchrun store) */
+CUVS_EXPORT cuvsError_t cuvsAmdShardCommGetUniqueId(char id[CUVS_AMD_SHARD_ID_BYTES]);
+/* collective: every rank calls it with the same id; binds the communicator to the device of `res` */
+CUVS_EXPORT cuvsError_t cuvsAmdShardCommCreate(cuvsResources_t res, const char id[CUVS_AMD_SHARD_ID_BYTES], int rank, int world,
+                                   cuvsAmdShardComm_t* comm);
+CUVS_EXPORT cuvsError_t cuvsAmdShardCommDestroy(cuvsAmdShardComm_t comm);
+CUVS_EXPORT cuvsError_t cuvsAmdShardCommRank(cuvsAmdShardComm_t comm, int* rank, int* world);
+
+/* Marks a trained, still empty index (add_data_on_build = false, or a deserialized model) as this rank's shard:
+ * list L is owned by rank L % world. Call before cuvsIvfPqExtend. */
+CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetListShard(cuvsIvfPqIndex_t index, int rank, int world);
+
+/* Collective on the stream of `res`. local_distances [n_queries, k] float32 and local_neighbors [n_queries, k] int64
+ * (device; the output of the rank's cuvsIvfPqSearch, invalid slots = FLT_MAX / INT64_MAX as the reference pads them) ->
+ * distances / neighbors [n_queries, k] (device): the k best of the world * k candidates of every query, ordered by
+ * (distance, rank, position); select_min = 0 for similarity metrics (inner product: larger is better). */
+CUVS_EXPORT cuvsError_t cuvsAmdShardAllGatherTopK(cuvsResources_t res, cuvsAmdShardComm_t comm, const float* local_distances,
+                                      const int64_t* local_neighbors, int64_t n_queries, int k, int select_min,
+                                      float* distances, int64_t* neighbors);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,78 @@
+"""GPU: list-sharded IVF-PQ through the C ABI (include/cuvs_amd/shard.h). One GPU per box, so: (a) the native RCCL
+communicator with world size 1 (ncclCommInitRank + ncclAllGather + the merge kernel really run); (b) two list shards
+built and searched one after the other on the same device, their [Q, k] blocks merged by the CPU twin of the merge -
+together they must answer exactly like the unsharded index; (c) extend() on a shard keeps only owned lists."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n=20000, d=32, nq=200, seed=5):
+    rng = np.random.default_rng(seed)
+    return (rng.random((n, d), dtype=np.float32) * 1.9 + 0.1), (rng.random((nq, d), dtype=np.float32) * 1.9 + 0.1)
+
+
+def test_world_size_one_all_gather_is_identity():
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import ivf_pq, ivf_pq_sharded as sh
+
+    res = cuvs_amd.common.Resources()
+    x, q = _data()
+    xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    params = ivf_pq.IndexParams(n_lists=32, pq_dim=16, kmeans_n_iters=10, add_data_on_build=False)
+    comm = sh.ShardComm(0, 1, sh.ShardComm.unique_id(), res)
+    index = sh.build(params, xt, 0, 1, resources=res)
+    sh.extend(index, xt, torch.arange(len(x), dtype=torch.int64, device="cuda"), resources=res)
+    sp = ivf_pq.SearchParams(n_probes=8)
+    d0, i0 = ivf_pq.search(sp, index, qt, 10, resources=res)
+    d1, i1 = sh.search(sp, index, qt, 10, comm, resources=res)
+    res.sync()
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    comm.close()
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+def test_two_list_shards_equal_the_unsharded_index(metric):
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import ivf_pq, ivf_pq_sharded as sh
+
+    res = cuvs_amd.common.Resources()
+    x, q = _data(seed=6)
+    xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    ids = torch.arange(len(x), dtype=torch.int64, device="cuda")
+    k, n_probes, world = 10, 6, 2
+
+    def params():
+        return ivf_pq.IndexParams(n_lists=24, pq_dim=16, kmeans_n_iters=10, metric=metric, add_data_on_build=False)
+
+    full = ivf_pq.build(params(), xt, resources=res)
+    ivf_pq.extend(full, xt, ids, resources=res)
+    sp = ivf_pq.SearchParams(n_probes=n_probes)
+    fd, fi = ivf_pq.search(sp, full, qt, k, resources=res)
+    res.sync()
+    parts_d, parts_i, kept = [], [], 0
+    for rank in range(world):
+        shard = sh.build(params(), xt, rank, world, resources=res)
+        sh.extend(shard, xt[:12000], ids[:12000], resources=res)   # two chunks: extend() with explicit global ids
+        sh.extend(shard, xt[12000:], ids[12000:], resources=res)
+        sizes = shard.list_sizes.cpu().numpy()
+        assert (sizes[np.arange(24) % world != rank] == 0).all()   # foreign lists stay empty
+        assert (sizes == np.where(np.arange(24) % world == rank, full.list_sizes.cpu().numpy(), 0)).all()
+        kept += len(shard)
+        d, i = ivf_pq.search(sp, shard, qt, k, resources=res)
+        res.sync()
+        d, i = d.cpu().numpy(), i.cpu().numpy()
+        if metric == "inner_product":
+            d = np.where(i == np.iinfo(np.int64).max, -np.float32(3.4028235e38), d)
+        parts_d.append(d); parts_i.append(i)
+    assert kept == len(x)
+    md, mi = sh.merge_gathered(parts_d, parts_i, k, metric != "inner_product")
+    fd, fi = fd.cpu().numpy(), fi.cpu().numpy()
+    assert (md == fd).all()
+    for qi in range(len(q)):
+        assert sorted(zip(md[qi].tolist(), mi[qi].tolist())) == sorted(zip(fd[qi].tolist(), fi[qi].tolist()))
