@@ -3,20 +3,36 @@
 
 Default workload (configs[2], the one the metric is quoted on): IVF-PQ over 100M x 128 fp32 synthetic vectors,
 pq_dim=64, pq_bits=8, n_lists=16384, n_probes=128, batch = 10k queries, k = 10, one GPU.
-A "step" is one cuvsIvfPqSearch call over one resident batch of 10k queries. Index build, ground truth and
-the CPU baseline are outside the timed region; queries/outputs are resident in HBM.
+A "step" is one cuvsIvfPqSearch (k * refine_ratio candidates) + cuvsRefine over one resident batch of 10k queries.
+Index build, ground truth and the CPU baseline are outside the timed region; queries/outputs are resident in HBM.
 
-  python bench.py                      # N=1
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   # replicated index, query-parallel
+  python bench.py                      # N=1: headline + the other LUT/score precisions + C1/C2/C4 lines + live PMC passes
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
+                                       # list-sharded index (list L on rank L % N), every step ends in ONE native RCCL
+                                       # all-gather of the per-rank [Q, k] blocks (include/cuvs_amd/shard.h)
 
-Prints ONE JSON line (rank 0). Extra keys: recall@10, roofline (dominant kernel = pq_scan_kernel, timed
-with HIP events on its launch stream), cpu_baseline (reference CPU path restated in oracle/, bounded sample).
+Prints ONE JSON line (rank 0):
+  value / ms_per_step    the headline variant (fp16 LUT, fp16 scores - both reference search_params settings)
+  config.variants        the same step with the reference-default arithmetic (fp32 LUT / fp32 scores), the bench grid's
+                         (fp16 LUT / fp32 scores) and the fp8 LUT, each with ms, recall and scan-kernel time
+  roofline               pq_scan_kernel: the logical scan rate of SURVEY 8d (code bytes / kernel time, HIP events) AND
+                         the physical fractions from rocprofv3 PMC passes of this same workload: hbm_frac,
+                         lds_gather_frac, lds_busy, valu_busy; `bound` names the busiest pipe
+  extra                  C1 (brute force 100k x 128), C2 (IVF-Flat 10M x 128), C4 (CAGRA 10M x 768 fp16) - recall,
+                         ms, kernel time, fraction of the roofline that bounds each
+  cpu_baseline           the reference's CPU exact-search path (refine_host restatement, OpenMP) at the C1 shape
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import signal
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,7 +41,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_TFLOPS = 157.3  # fp32 MFMA peak (spec)
+N_CU, N_SIMD = 256, 1024
 
 
 def log(*a):
@@ -33,22 +51,210 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def gen_rows(n, dim, seed, device, chunk=1 << 22, latent=32, n_modes=65536):
-    """Synthetic corpus with low intrinsic dimension (a 32-d Gaussian mixture embedded in R^dim + small noise):
-    isotropic 128-d clusters would make every neighbour equidistant and recall meaningless."""
+def gen_rows(n, dim, seed, device, chunk=1 << 22, latent=32, n_modes=65536, row0=0, out=None):
+    """Synthetic corpus with low intrinsic dimension (a `latent`-d Gaussian mixture embedded in R^dim + small noise):
+    isotropic dim-d clusters would make every neighbour equidistant and recall meaningless. Rows are
+    generated chunk by chunk from (seed, chunk index), so any row range can be produced on any rank."""
     g = torch.Generator(device=device).manual_seed(1234)  # structure shared by data and queries
     A = torch.randn(latent, dim, generator=g, device=device) / latent ** 0.5
     modes = torch.randn(n_modes, latent, generator=g, device=device)
-    g2 = torch.Generator(device=device).manual_seed(seed)
-    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    assert row0 % chunk == 0
     for r0 in range(0, n, chunk):
         c = min(chunk, n - r0)
+        g2 = torch.Generator(device=device).manual_seed(seed * 1000003 + (row0 + r0) // chunk)
         which = torch.randint(0, n_modes, (c,), generator=g2, device=device)
         z = modes[which] + 0.35 * torch.randn(c, latent, generator=g2, device=device)
-        out[r0:r0 + c] = z @ A + 0.03 * torch.randn(c, dim, generator=g2, device=device)
+        out[r0:r0 + c] = (z @ A + 0.03 * torch.randn(c, dim, generator=g2, device=device)).to(out.dtype)
     return out
 
 
+def recall_of(found, truth):
+    return float(np.mean([len(np.intersect1d(f, t)) for f, t in zip(found, truth)])) / truth.shape[1]
+
+
+LUTS = {"f32": np.float32, "f16": np.float16, "fp8": np.uint8}
+
+
+# ---------------------------------------------------------------------------------------------- PMC passes (rank 0)
+PMC_SETS = [
+    "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE",
+    "FETCH_SIZE",
+    "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
+]
+
+
+def run_pmc_passes(child_args, n_search, timeout_s=240):
+    """rocprofv3 --pmc (counters only, one group per run - MI355X_MICROARCH.md 'rocprofv3 PMC slots') over a child that
+    rebuilds this workload and runs `n_search` searches; returns per-search sums for pq_scan_kernel or None."""
+    if shutil.which("rocprofv3") is None:
+        return None
+    sums = {}
+    for i, counters in enumerate(PMC_SETS):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", *counters.split(), "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", str(n_search), *child_args]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            p = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd="/tmp",
+                                 start_new_session=True)
+            try:
+                p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                log(f"PMC pass {i} timed out")
+                return None
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                log(f"PMC pass {i}: rc={p.returncode}, no counter file")
+                return None
+            n_disp = 0
+            for r in csv.DictReader(open(files[0])):
+                if "pq_scan" in r["Kernel_Name"]:
+                    sums[r["Counter_Name"]] = sums.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    n_disp += 1
+            if n_disp == 0:
+                return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {k: v / n_search for k, v in sums.items()}
+
+
+def pmc_child(args, n_search):
+    """The profiled child: same data, same index, `n_search` searches of the headline variant."""
+    import cuvs_amd
+    from cuvs_amd.neighbors import ivf_pq
+
+    dev = torch.device("cuda", 0)
+    res = cuvs_amd.common.Resources()
+    data = gen_rows(args.rows, args.dim, seed=1234, device=dev)
+    queries = gen_rows(args.batch, args.dim, seed=4321, device=dev)
+    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=args.n_lists, pq_dim=args.pq_dim, pq_bits=8, kmeans_n_iters=20,
+                                            kmeans_trainset_fraction=args.trainset_fraction), data, resources=res)
+    del data
+    sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                             max_internal_batch_size=args.batch)
+    kk = args.k * max(1, args.refine_ratio)
+    nb = torch.empty((args.batch, kk), dtype=torch.int64, device=dev)
+    ds = torch.empty((args.batch, kk), dtype=torch.float32, device=dev)
+    for _ in range(n_search):
+        ivf_pq.search(sp, index, queries, kk, neighbors=nb, distances=ds, resources=res)
+    res.sync()
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------- extra configs (N=1)
+def timeit(fn, steps, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps
+
+
+def profiled(name, fn, steps, warm):
+    from cuvs_amd._lib import lib
+
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    lib().cuvsAmdProfileEnable(1)
+    t = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / steps
+    lib().cuvsAmdProfileEnable(0)
+    ms = C.c_double(0)
+    n = lib().cuvsAmdProfileCollect(name, C.byref(ms))
+    return dt, ms.value / steps, n // max(steps, 1)
+
+
+def extra_c1(res, dev):
+    """C1: brute force L2, 100k x 128 fp32, batch 1k, k = 10 (MFMA fp32 roofline)."""
+    from cuvs_amd.neighbors import brute_force
+
+    x = gen_rows(100_000, 128, 1234, dev)
+    q = gen_rows(1000, 128, 4321, dev)
+    idx = brute_force.build(x, resources=res)
+    dt = timeit(lambda: brute_force.search(idx, q, 10, resources=res), 20, 3)
+    _, i = brute_force.search(idx, q, 10, resources=res)
+    res.sync()
+    d2 = torch.cdist(q.double(), x.double()) ** 2  # fp64 ground truth
+    gt = torch.topk(d2, 10, dim=1, largest=False).indices
+    tf = 2 * 1000 * 100_000 * 128 / dt / 1e12
+    return {"config": "C1 brute_force L2 100000x128 fp32 batch=1000 k=10", "ms": round(dt * 1e3, 3),
+            "qps": round(1000 / dt, 1), "recall_at_10": round(recall_of(i.cpu().numpy(), gt.cpu().numpy()), 4),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / MFMA_F32_TFLOPS, 4)}}, x.cpu().numpy(), q.cpu().numpy()
+
+
+def extra_c2(res, dev):
+    """C2: IVF-Flat 10M x 128 fp32, n_lists 4096, n_probes 64, batch 10k."""
+    from cuvs_amd.neighbors import brute_force, ivf_flat
+
+    n, nq = 10_000_000, 10000
+    x = gen_rows(n, 128, 1234, dev)
+    q = gen_rows(nq, 128, 4321, dev)
+    t0 = time.time()
+    idx = ivf_flat.build(ivf_flat.IndexParams(n_lists=4096, kmeans_trainset_fraction=0.1), x, resources=res)
+    res.sync()
+    build_s = time.time() - t0
+    sp = ivf_flat.SearchParams(n_probes=64)
+    nb = torch.empty((nq, 10), dtype=torch.int64, device=dev)
+    dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    dt, scan_ms, launches = profiled(b"ivf_flat_scan_kernel",
+                                     lambda: ivf_flat.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 5, 2)
+    bf = brute_force.build(x, resources=res)
+    _, gt = brute_force.search(bf, q[:1000], 10, resources=res)
+    res.sync()
+    r = recall_of(nb[:1000].cpu().numpy(), gt.cpu().numpy())
+    logical = 64 * (n / 4096) * 512 * nq  # SURVEY 8d: 80 MB of list bytes per query
+    return {"config": "C2 IVF-Flat 10000000x128 fp32 n_lists=4096 n_probes=64 batch=10000 k=10", "ms": round(dt * 1e3, 3),
+            "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
+            "kernel": "ivf_flat_scan_kernel", "kernel_ms_per_step": round(scan_ms, 3), "launches_per_step": launches,
+            "roofline": {"bound": "valu", "achieved": round(logical / (scan_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(logical / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "unique_list_bytes": n * 512,
+                         "note": "logical list bytes per kernel second (SURVEY 8d); the lists are re-served from L2 ~156x "
+                                 "(unique bytes 5.12 GB), so the kernel is bound by its packed-fp32 VALU work, not by HBM"}}
+
+
+def extra_c4(res, dev, rows, latent):
+    """C4: CAGRA rows x 768 fp16, graph_degree 64 (intermediate 128), itopk 64, batch 10k, k = 10."""
+    from cuvs_amd.neighbors import brute_force, cagra
+
+    nq = 10000
+    x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
+    gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=1, out=x)
+    q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
+    gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=1, out=q)
+    t0 = time.time()
+    idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res)
+    res.sync()
+    build_s = time.time() - t0
+    sp = cagra.SearchParams(itopk_size=64)
+    nb = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+    dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+    dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 5, 2)
+    bf = brute_force.build(x, resources=res)
+    _, gt = brute_force.search(bf, q[:1000], 10, resources=res)
+    res.sync()
+    r = recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt.cpu().numpy())
+    upper = 6.9e6 * nq  # SURVEY 8d upper bound: 6.9 MB of row + graph bytes per query
+    return {"config": f"C4 CAGRA {rows}x768 fp16 graph_degree=64 itopk=64 batch=10000 k=10 (data: {latent}-d latent cloud)",
+            "ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
+            "roofline": {"bound": "hbm", "achieved": round(upper / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(upper / dt / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": "upper bound of the gathered bytes (SURVEY 8d: 128 seeds + <=68 iterations x 64 rows of "
+                                 "1536 B) per wall second; the walk is bound by dependent-gather latency"}}
+
+
+# ---------------------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,17 +265,29 @@ def main():
     ap.add_argument("--n-lists", type=int, default=16384)
     ap.add_argument("--n-probes", type=int, default=128)
     ap.add_argument("--pq-dim", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=10000)
+    ap.add_argument("--batch", type=int, default=10000, help="queries per step and GPU")
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--lut", choices=["f32", "f16"], default="f16",
-                    help="LUT / internal distance dtype (both are reference search_params settings)")
+    ap.add_argument("--lut", choices=list(LUTS), default="f16", help="headline LUT dtype (search_params.lut_dtype)")
+    ap.add_argument("--acc", choices=["f32", "f16"], default="f16", help="headline score dtype (internal_distance_dtype)")
     ap.add_argument("--refine-ratio", type=int, default=2,
                     help="IVF-PQ returns ratio*k candidates that cuvsRefine re-ranks exactly (reference bench grids "
                          "use refine_ratio 1..4, python/cuvs_bench/.../cuvs_ivf_pq.yaml); 1 disables refinement")
     ap.add_argument("--trainset-fraction", type=float, default=0.02)
     ap.add_argument("--gt-queries", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true")
+    ap.add_argument("--c4-rows", type=int, default=10_000_000)
+    ap.add_argument("--c4-latent", type=int, default=24)
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the list-sharded code path (shard build, RCCL all-gather + merge) even with one rank")
     args = ap.parse_args()
+    if args.lut == "f32":
+        args.acc = "f32"
+    if args.pmc_child:
+        return pmc_child(args, args.pmc_child)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,132 +298,230 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)  # control plane: barriers, the max over ranks, the id rendezvous
 
     import cuvs_amd
     from cuvs_amd._lib import lib
-    from cuvs_amd.neighbors import brute_force, ivf_pq, refine
+    from cuvs_amd.neighbors import brute_force, ivf_pq, ivf_pq_sharded, refine
 
     res = cuvs_amd.common.Resources()
+    sharded = world > 1 or args.force_sharded
+    nq_total = args.batch * world  # list-sharded search: every rank sees the whole (world x batch) query batch
+    kk = args.k * max(1, args.refine_ratio)
 
     # ------------------------------------------------------------------ data + index (untimed)
     t0 = time.time()
     data = gen_rows(args.rows, args.dim, seed=1234, device=dev)
-    queries = gen_rows(args.batch, args.dim, seed=4321 + rank, device=dev)
+    queries = torch.cat([gen_rows(args.batch, args.dim, seed=4321 + r, device=dev) for r in range(world)])
     torch.cuda.synchronize()
     log(f"generated {args.rows}x{args.dim} fp32 in {time.time() - t0:.1f}s")
     t0 = time.time()
     ip = ivf_pq.IndexParams(n_lists=args.n_lists, metric="sqeuclidean", pq_dim=args.pq_dim, pq_bits=8,
-                            kmeans_n_iters=20, kmeans_trainset_fraction=args.trainset_fraction)
-    index = ivf_pq.build(ip, data, resources=res)
+                            kmeans_n_iters=20, kmeans_trainset_fraction=args.trainset_fraction,
+                            add_data_on_build=not sharded)
+    comm = None
+    if not sharded:
+        index = ivf_pq.build(ip, data, resources=res)
+    else:
+        # the same model on every rank (same rows, deterministic k-means); each rank then keeps the rows of its lists
+        comm = (ivf_pq_sharded.ShardComm.from_torch(res) if world > 1
+                else ivf_pq_sharded.ShardComm(0, 1, ivf_pq_sharded.ShardComm.unique_id(), res))
+        index = ivf_pq_sharded.build(ip, data, rank, world, resources=res)
+        step_rows = 1 << 24
+        for r0 in range(0, args.rows, step_rows):
+            r1 = min(args.rows, r0 + step_rows)
+            ivf_pq_sharded.extend(index, data[r0:r1], torch.arange(r0, r1, dtype=torch.int64, device=dev), resources=res)
     res.sync()
     build_s = time.time() - t0
-    log(f"built IVF-PQ index in {build_s:.1f}s")
-    lut_np = np.float16 if args.lut == "f16" else np.float32
-    sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=lut_np, internal_distance_dtype=lut_np,
-                             max_internal_batch_size=args.batch)
-    neighbors = torch.empty((args.batch, args.k), dtype=torch.int64, device=dev)
-    distances = torch.empty((args.batch, args.k), dtype=torch.float32, device=dev)
+    log(f"built IVF-PQ index in {build_s:.1f}s ({len(index)} rows on this rank)")
 
-    kk = args.k * max(1, args.refine_ratio)
-    cand_i = torch.empty((args.batch, kk), dtype=torch.int64, device=dev)
-    cand_d = torch.empty((args.batch, kk), dtype=torch.float32, device=dev)
+    neighbors = torch.empty((nq_total, args.k), dtype=torch.int64, device=dev)
+    distances = torch.empty((nq_total, args.k), dtype=torch.float32, device=dev)
+    cand_i = torch.empty((nq_total, kk), dtype=torch.int64, device=dev)
+    cand_d = torch.empty((nq_total, kk), dtype=torch.float32, device=dev)
+    mrg_i, mrg_d = torch.empty_like(cand_i), torch.empty_like(cand_d)
+    q_lo, q_hi = rank * args.batch, (rank + 1) * args.batch  # the slice of the batch this rank refines
 
-    def step():
-        if args.refine_ratio > 1:
-            ivf_pq.search(sp, index, queries, kk, neighbors=cand_i, distances=cand_d, resources=res)
-            refine(data, queries, cand_i, indices=neighbors, distances=distances, metric="sqeuclidean", resources=res)
-        else:
-            ivf_pq.search(sp, index, queries, args.k, neighbors=neighbors, distances=distances, resources=res)
+    def make_step(lut, acc):
+        sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[lut], internal_distance_dtype=LUTS[acc],
+                                 max_internal_batch_size=nq_total)
 
-    # ------------------------------------------------------------------ timed region
-    for _ in range(args.warmup):
-        step()
-    lib().cuvsAmdProfileEnable(1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    lib().cuvsAmdProfileEnable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    scan_ms = C.c_double(0)
-    n_launch = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan_ms))
+        def step():
+            if sharded:
+                ivf_pq.search(sp, index, queries, kk, neighbors=cand_i, distances=cand_d, resources=res)
+                comm.all_gather_topk(cand_d, cand_i, out=(mrg_d, mrg_i), resources=res)  # native RCCL all-gather + merge
+                ci = mrg_i
+            else:
+                ivf_pq.search(sp, index, queries, kk, neighbors=cand_i, distances=cand_d, resources=res)
+                ci = cand_i
+            if args.refine_ratio > 1:
+                refine(data, queries[q_lo:q_hi], ci[q_lo:q_hi], indices=neighbors[q_lo:q_hi], distances=distances[q_lo:q_hi],
+                       metric="sqeuclidean", resources=res)
+            else:
+                neighbors[q_lo:q_hi].copy_(ci[q_lo:q_hi, :args.k])
+        return step
+
+    def timed(step, steps, warmup):
+        for _ in range(warmup):
+            step()
+        lib().cuvsAmdProfileEnable(1)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t_start
+        lib().cuvsAmdProfileEnable(0)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        scan_ms = C.c_double(0)
+        n_launch = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan_ms))
+        ag_ms = C.c_double(0)
+        lib().cuvsAmdProfileCollect(b"shard_all_gather", C.byref(ag_ms))
+        return elapsed, scan_ms.value, n_launch, ag_ms.value
+
+    # ------------------------------------------------------------------ timed region (headline variant)
+    elapsed, scan_ms, n_launch, ag_ms = timed(make_step(args.lut, args.acc), args.steps, args.warmup)
 
     # ------------------------------------------------------------------ recall@10 vs exact search (untimed)
     ng = min(args.gt_queries, args.batch)
     bf = brute_force.build(data, metric="sqeuclidean", resources=res)
-    _, gt = brute_force.search(bf, queries[:ng], args.k, resources=res)
+    _, gt = brute_force.search(bf, queries[q_lo:q_lo + ng], args.k, resources=res)
     res.sync()
-    found, truth = neighbors[:ng].cpu().numpy(), gt.cpu().numpy()
-    recall = float(np.mean([len(np.intersect1d(f, t)) for f, t in zip(found, truth)])) / args.k
+    truth = gt.cpu().numpy()
+    recall = recall_of(neighbors[q_lo:q_lo + ng].cpu().numpy(), truth)
     del bf
 
+    # ------------------------------------------------------------------ the other precisions (same step, untimed region)
+    variants = []
+    early_stop_off_ms = None
+    if rank == 0 and world == 1 and not args.no_variants:
+        for lut, acc in (("f32", "f32"), ("f16", "f32"), ("f16", "f16"), ("fp8", "f16")):
+            if (lut, acc) == (args.lut, args.acc):
+                v_el, v_scan, v_n, v_rec = elapsed / args.steps, scan_ms / args.steps, n_launch // args.steps, recall
+            else:
+                e, s, n, _ = timed(make_step(lut, acc), 5, 1)
+                v_el, v_scan, v_n = e / 5, s / 5, n // 5
+                v_rec = recall_of(neighbors[:ng].cpu().numpy(), truth)
+            variants.append({"lut": lut, "acc": acc, "ms_per_step": round(v_el * 1e3, 3), "qps": round(args.batch / v_el, 1),
+                             "recall_at_10": round(v_rec, 4), "scan_kernel_ms_per_step": round(v_scan, 3),
+                             "scan_launches_per_step": v_n})
+        # data-independent figure: the headline variant with the early stop switched off (CUVS_AMD_SCAN_DEBUG=8)
+        os.environ["CUVS_AMD_SCAN_DEBUG"] = "8"
+        _, s, _, _ = timed(make_step(args.lut, args.acc), 3, 1)
+        early_stop_off_ms = round(s / 3, 3)
+        del os.environ["CUVS_AMD_SCAN_DEBUG"]
+
     # ------------------------------------------------------------------ roofline of the dominant kernel
-    # algorithmic bytes per launch = sum over (query, probe) pairs of list_len * code bytes
+    # algorithmic bytes per step = sum over (query, probe) pairs of list_len * code bytes
     sizes = index.list_sizes.to(torch.int64)
     centers = index.centers
     cn = (centers * centers).sum(1)
+    owned = (torch.arange(args.n_lists, device=dev) % world) == rank
     probe_bytes = 0
-    for q0 in range(0, args.batch, 2048):
+    for q0 in range(0, nq_total, 2048):
         qq = queries[q0:q0 + 2048]
         dmat = cn[None, :] - 2.0 * (qq @ centers.T)
         pr = torch.topk(dmat, min(args.n_probes, args.n_lists), dim=1, largest=False).indices
-        probe_bytes += int(sizes[pr].sum().item()) * (args.pq_dim * 8 // 8)
-    # one search = a small head launch (nearest probe of every query) + the tail launch; both are the same kernel,
-    # so bytes and time are averaged over all its launches (sum of bytes / sum of time)
+        probe_bytes += int((sizes[pr] * owned[pr]).sum().item()) * (args.pq_dim * 8 // 8)
+    # one search = a small head launch (nearest probe of every query) + the tail launch: the same work, bytes and
+    # time are averaged over all launches (sum of bytes / sum of time)
     per_step = max(n_launch, 1) / max(args.steps, 1)
     bytes_per_launch = probe_bytes / per_step
-    avg_ms = scan_ms.value / max(n_launch, 1)
+    avg_ms = scan_ms / max(n_launch, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic = None
-    pmc_busy = {}
-    tfile = os.path.join(ROOT, "profiles", "r01b_pq_scan_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            tj = json.load(open(tfile))
-            # PMC pass (profiles/README.md): HBM bytes of the kernel's launches of one search, averaged per launch
-            traffic = tj.get("hbm_bytes_per_step", tj.get("hbm_bytes_per_launch"))
-            traffic = int(traffic / per_step) if traffic else None
-            pmc_busy = {k: tj[k] for k in ("valu_busy", "lds_busy", "lds_bank_conflict_share", "tcc_hit_rate") if k in tj}
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": "pq_scan_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+    roofline = {"bound": "lds", "kernel": "pq_scan_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 3),
-                "launches": n_launch, "launches_per_step": per_step, "pmc": pmc_busy,
-                "algorithmic_bytes_per_step": probe_bytes, "kernel_ms_per_step": round(avg_ms * per_step, 3),
-                "note": "logical code bytes scanned per launch / HIP-event kernel time. The list-major schedule serves every "
-                        "list byte fetched from HBM ~45 times from L2 (traffic = measured HBM bytes), so the figure exceeds "
-                        "the HBM peak by design; PMC (pmc): neither VALU nor LDS is saturated, the rest is per-item "
-                        "serial phases (DESIGN.md 3.1)"}
+                "launches": n_launch, "launches_per_step": per_step, "algorithmic_bytes_per_step": probe_bytes,
+                "kernel_ms_per_step": round(avg_ms * per_step, 3), "early_stop_off_kernel_ms_per_step": early_stop_off_ms,
+                "note": "achieved/frac = SURVEY 8d's LOGICAL figure: code bytes of every probed list per kernel second. "
+                        "The list-major schedule serves a list byte from L2 many times per HBM fetch, so it exceeds the "
+                        "HBM peak by design and is not a utilisation. The physical fractions are hbm_frac (measured HBM "
+                        "bytes/s / 8 TB/s), lds_busy (LDS array cycles / cycles), lds_gather_frac (LDS wave-instructions "
+                        "x 2 clk / cycles: the conflict-free issue floor), valu_busy; `bound` = the busiest pipe"}
+    if rank == 0 and world == 1 and not args.no_pmc:
+        t0 = time.time()
+        child = ["--rows", str(args.rows), "--dim", str(args.dim), "--n-lists", str(args.n_lists), "--n-probes",
+                 str(args.n_probes), "--pq-dim", str(args.pq_dim), "--batch", str(args.batch), "--k", str(args.k),
+                 "--lut", args.lut, "--acc", args.acc, "--refine-ratio", str(args.refine_ratio), "--trainset-fraction",
+                 str(args.trainset_fraction)]
+        pmc = run_pmc_passes(child, n_search=3)
+        log(f"PMC passes took {time.time() - t0:.1f}s: {'ok' if pmc else 'unavailable'}")
+        if pmc and pmc.get("GRBM_GUI_ACTIVE"):
+            cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+            kernel_s = cycles / 2.4e9               # at the 2.4 GHz peak clock; the profiled clock is lower (DVFS)
+            hbm_bytes = (2.0 * pmc.get("FETCH_SIZE", 0.0) + pmc.get("WRITE_SIZE", 0.0)) * 1024.0  # gfx950: FETCH_SIZE x 2
+            t_ref = avg_ms * per_step * 1e-3        # un-profiled kernel time of one search (HIP events, this run)
+            fr = {"hbm_frac": hbm_bytes / t_ref / 1e9 / HBM_PEAK_GBS,
+                  "lds_busy": pmc.get("SQ_LDS_IDX_ACTIVE", 0.0) / (cycles * N_CU),
+                  "lds_bank_conflict_share": pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(pmc.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0),
+                  "lds_gather_frac": pmc.get("SQ_INSTS_LDS", 0.0) * 2.0 / (cycles * N_CU),
+                  "valu_busy": pmc.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (cycles * N_SIMD),
+                  "tcc_hit_rate": pmc.get("TCC_HIT_sum", 0.0) / max(pmc.get("TCC_HIT_sum", 0.0) + pmc.get("TCC_MISS_sum", 0.0), 1.0)}
+            roofline.update({k: round(v, 4) for k, v in fr.items()})
+            roofline["traffic"] = int(hbm_bytes / per_step)
+            roofline["hbm_bytes_per_step"] = int(hbm_bytes)
+            roofline["pmc_cycles_per_step"] = int(cycles)
+            roofline["pmc_kernel_ms_at_2p4ghz"] = round(kernel_s * 1e3, 3)
+            roofline["bound"] = max((("lds", fr["lds_busy"]), ("valu", fr["valu_busy"]), ("hbm", fr["hbm_frac"])),
+                                    key=lambda t: t[1])[0]
+            roofline["pmc_source"] = "live: rocprofv3 --pmc passes of this workload, spawned by this run"
+    if roofline["traffic"] is None:
+        tfile = os.path.join(ROOT, "profiles", "r02_pq_scan_pmc.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                roofline.update({k: tj[k] for k in ("hbm_frac", "lds_busy", "lds_bank_conflict_share", "lds_gather_frac",
+                                                    "valu_busy", "tcc_hit_rate", "bound") if k in tj})
+                roofline["traffic"] = int(tj["hbm_bytes_per_step"] / per_step) if "hbm_bytes_per_step" in tj else None
+                roofline["pmc_source"] = "profiles/r02_pq_scan_pmc.json (committed PMC passes of the same command)"
+            except Exception:
+                pass
 
-    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1 only)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
+    # ------------------------------------------------------------------ C1 / C2 / C4 lines + CPU baseline (rank 0, N=1)
+    extra, cpu = [], None
+    if rank == 0 and world == 1:
+        del index, data
+        torch.cuda.empty_cache()
+        c1_x = c1_q = None
+        if not args.no_extras:
+            for name, fn in (("C1", lambda: extra_c1(res, dev)), ("C2", lambda: extra_c2(res, dev)),
+                             ("C4", lambda: extra_c4(res, dev, args.c4_rows, args.c4_latent))):
+                t0 = time.time()
+                try:
+                    out = fn()
+                    if name == "C1":
+                        out, c1_x, c1_q = out
+                    extra.append(out)
+                except Exception as e:  # an extra line must not take the headline down
+                    extra.append({"config": name, "error": repr(e)[:300]})
+                torch.cuda.empty_cache()
+                log(f"{name} done in {time.time() - t0:.1f}s")
+        if not args.no_cpu_baseline:
+            import oracle
 
-        sample_rows = min(args.rows, 2_000_000)
-        sample_q = 64
-        xs = data[:sample_rows].cpu().numpy()
-        qs = queries[:sample_q].cpu().numpy()
-        t0 = time.perf_counter()
-        oracle.exact_knn(qs, xs, args.k)
-        dt = time.perf_counter() - t0
-        qps_full = sample_q / dt * (sample_rows / args.rows)
-        cpu = {"value": round(qps_full, 3), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
-               "sample": f"exact kNN (refine_host restatement, OpenMP) of {sample_q} queries over the first "
-                         f"{sample_rows} rows took {dt:.2f}s; scaled linearly to {args.rows} rows"}
+            if c1_x is None:
+                c1_x = gen_rows(100_000, 128, 1234, dev).cpu().numpy()
+                c1_q = gen_rows(1000, 128, 4321, dev).cpu().numpy()
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                oracle.exact_knn(c1_q, c1_x, 10)
+                ts.append(time.perf_counter() - t0)
+            med = float(np.median(ts))
+            cpu = {"value": round(1000 / med, 1), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+                   "gflops": round(2 * 1000 * 100_000 * 128 / med / 1e9, 1),
+                   "sample": f"C1 shape (SURVEY 8d): exact kNN of 1000 queries over 100000x128 fp32, k=10, the reference's "
+                             f"refine_host arithmetic restated in oracle/ (OpenMP), median of 5 runs = {med * 1e3:.1f} ms"}
 
     if rank == 0:
         total_q = args.batch * args.steps * world
@@ -220,17 +536,25 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 codes, " + ("f16" if args.lut == "f16" else "f32") + " LUT/score",
+            "dtype": f"u8 codes, {args.lut} LUT, {args.acc} score",
             "data": "synthetic",
             "config": {"workload": f"IVF-PQ {args.rows}x{args.dim} fp32, pq_dim={args.pq_dim} pq_bits=8 "
                                    f"n_lists={args.n_lists} n_probes={args.n_probes} batch={args.batch} k={args.k}",
-                       "parallelism": "replicated index, queries split across ranks" if world > 1 else "single GPU",
-                       "lut_dtype": args.lut, "refine_ratio": args.refine_ratio, "build_seconds": round(build_s, 1)},
+                       "parallelism": (f"list-sharded index (list L on rank L % {world}), {world} x {args.batch} queries per "
+                                       f"step, one native RCCL all-gather of the [Q,k] blocks per step") if sharded
+                                      else "single GPU",
+                       "lut_dtype": args.lut, "internal_distance_dtype": args.acc, "refine_ratio": args.refine_ratio,
+                       "build_seconds": round(build_s, 1), "variants": variants},
             "recall_at_10": round(recall, 4),
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "extra": extra,
         }
+        if sharded:
+            out["config"]["all_gather_ms_per_step"] = round(ag_ms / max(args.steps, 1), 3)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

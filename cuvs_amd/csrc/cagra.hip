@@ -704,6 +704,121 @@ void launch_search(resources& res, const search_args& a, int64_t nq, size_t smem
 
 }  // namespace
 
+__global__ void popcount_kernel(const uint32_t* __restrict__ bits, int64_t n_bits, unsigned long long* __restrict__ out)
+{
+  const int64_t n_words = (n_bits + 31) / 32;
+  unsigned long long c  = 0;
+  for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t v = bits[w];
+    if (w == n_words - 1 && (n_bits & 31)) v &= (1u << (n_bits & 31)) - 1u;
+    c += (unsigned)__popc(v);
+  }
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+int64_t count_set_bits(resources& res, const uint32_t* bits, int64_t n_bits)
+{
+  dev_buf<unsigned long long> cnt(res, 1);
+  HIP_TRY(hipMemsetAsync(cnt.data(), 0, sizeof(unsigned long long), res.stream));
+  hipLaunchKernelGGL(popcount_kernel, dim3(256), dim3(256), 0, res.stream, bits, n_bits, cnt.data());
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, cnt.data(), sizeof(h), hipMemcpyDeviceToHost, res.stream));
+  HIP_TRY(hipStreamSynchronize(res.stream));
+  return (int64_t)h;
+}
+
+// ------------------------------------------------------------------ search plan (host only)
+// The reference's plan rules restated (search_plan.cuh): algorithm choice of AUTO (:121-131), adjust_search_params
+// (:199-245: max_iterations, the filter-rate dependent itopk of MULTI_CTA, itopk rounded to 32) and calc_hashmap_params
+// (:248-340: small-hash bit length and reset interval of SINGLE_CTA, visited / traversed hash sizes and CTAs per query
+// of MULTI_CTA). `ref_*` fields are what the reference would run with; `run_*` fields are what this library launches
+// (see cagra_search for the two places it deliberately differs: AUTO and the LDS hash sizing).
+struct cagra_plan {
+  uint32_t itopk, max_iterations, search_width;
+  int ref_algo;                                   // SINGLE_CTA / MULTI_CTA / MULTI_KERNEL after AUTO resolution
+  uint32_t ref_small_hash_bitlen, ref_hash_bitlen, ref_small_hash_reset_interval, ref_mc_num_cta_per_query;
+  uint32_t mc_max_iterations;                     // max_iterations if the multi-CTA rule applies (itopk 32 per CTA)
+  int run_algo;
+  uint32_t run_waves_per_query;
+};
+
+inline uint32_t hash_size_of(uint32_t bitlen) { return 1u << bitlen; }  // hashmap.hpp:23
+
+cagra_plan make_cagra_plan(const cuvsCagraSearchParams& p, int64_t n_rows, uint32_t degree, uint32_t topk, int64_t n_queries,
+                           int num_cus, float filtering_rate)
+{
+  cagra_plan pl{};
+  const uint32_t width = (uint32_t)std::max<size_t>(1, p.search_width);
+  pl.search_width      = width;
+  size_t itopk         = std::max<size_t>(p.itopk_size ? p.itopk_size : 64, (size_t)topk);
+  // ---- algorithm: search_plan.cuh:121-131 (persistent mode is not offered by the C search entry point)
+  int algo = (int)p.algo;
+  const size_t max_queries = p.max_queries ? p.max_queries : (size_t)n_queries;  // cagra.cuh: max_queries = min(n_queries, ...)
+  if (algo == (int)AUTO) algo = (itopk <= 512 && max_queries >= (size_t)num_cus * 2) ? (int)SINGLE_CTA : (int)MULTI_CTA;
+  pl.ref_algo = algo;
+  auto reach_iterations = [&](uint32_t it) {
+    int64_t reach = 1;
+    while (reach < n_rows) { reach *= std::max<int64_t>(2, degree / 2); it += 1; }
+    return it;
+  };
+  // ---- adjust_search_params :199-245
+  uint32_t max_it = (uint32_t)p.max_iterations;
+  if (p.max_iterations == 0) max_it = reach_iterations(algo == (int)MULTI_CTA ? 32u / 1u : (uint32_t)(itopk / width));
+  if (max_it < (uint32_t)p.min_iterations) max_it = (uint32_t)p.min_iterations;
+  pl.max_iterations    = std::max<uint32_t>(max_it, (uint32_t)p.max_iterations);
+  pl.mc_max_iterations = p.max_iterations ? std::max<uint32_t>((uint32_t)p.max_iterations, (uint32_t)p.min_iterations)
+                                          : std::max<uint32_t>(reach_iterations(32u), (uint32_t)p.min_iterations);
+  if (algo == (int)MULTI_CTA && filtering_rate > 0.f && filtering_rate < 1.f) {
+    size_t adj = (size_t)((float)topk / (1.0 - filtering_rate) + (float)(itopk - topk) / std::sqrt(1.0 - filtering_rate));
+    if (adj % 32) adj += 32 - adj % 32;
+    if (itopk < adj) itopk = adj;
+  }
+  if (itopk % 32) itopk += 32 - itopk % 32;
+  pl.itopk = (uint32_t)itopk;
+  // ---- calc_hashmap_params :248-340
+  const float fill = p.hashmap_max_fill_rate > 0.f ? p.hashmap_max_fill_rate : 0.5f;
+  const uint32_t min_user = (uint32_t)p.hashmap_min_bitlen;
+  pl.ref_small_hash_reset_interval = 1024 * 1024;
+  if (algo == (int)MULTI_CTA) {
+    pl.ref_mc_num_cta_per_query = (uint32_t)std::max<size_t>(width, (itopk + 31) / 32);
+    const uint32_t max_visited  = 32 + degree * 2;
+    uint32_t sb = 8;
+    while ((float)max_visited > hash_size_of(sb) * fill) ++sb;
+    pl.ref_small_hash_bitlen = sb;
+    const size_t max_trav = (size_t)pl.ref_mc_num_cta_per_query * std::max<size_t>(32, pl.max_iterations);
+    uint32_t hb = std::max<uint32_t>(11, min_user);
+    while ((float)max_trav > hash_size_of(hb) * fill) ++hb;
+    pl.ref_hash_bitlen = hb;
+  } else {
+    uint32_t hb = 0;
+    if (p.hashmap_mode == AUTO_HASH || p.hashmap_mode == SMALL) {
+      const size_t max_visited = itopk + (size_t)width * degree;
+      hb = std::max<uint32_t>(8, min_user);
+      while ((float)max_visited > hash_size_of(hb) * fill) ++hb;
+      if (hb > 13) {
+        CUVS_EXPECTS(p.hashmap_mode == AUTO_HASH, "small-hash cannot be used because the required hash size exceeds the limit (%u)",
+                     hash_size_of(13));
+        hb = 0;
+      } else {
+        pl.ref_small_hash_bitlen = hb;
+        uint32_t interval = 1;
+        while ((float)(itopk + (size_t)width * degree * (interval + 1)) <= hash_size_of(hb) * fill) ++interval;
+        pl.ref_small_hash_reset_interval = interval;
+      }
+    }
+    if (hb == 0) {
+      const size_t max_visited = itopk + (size_t)width * degree * pl.max_iterations;
+      hb = std::max<uint32_t>(11, min_user);
+      while ((float)max_visited > hash_size_of(hb) * fill) ++hb;
+      CUVS_EXPECTS(hb <= 20, "hash_bitlen cannot be largen than 20 (1M). You can decrease itopk_size, search_width or "
+                             "max_iterations to reduce the required hashmap size.");
+    }
+    pl.ref_hash_bitlen = hb;
+  }
+  return pl;
+}
+
 void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchParams& p, const void* queries,
                   int64_t nq, int k, void* out_idx, bool idx64, float* out_dist, const uint32_t* filter_bits)
 {
@@ -715,22 +830,23 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   a.data = idx.data; a.graph = idx.graph.data(); a.queries = queries; a.filter_bits = filter_bits;
   a.out_idx = out_idx; a.out_dist = out_dist; a.n = idx.n; a.dim = idx.dim; a.degree = idx.degree;
   a.width = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, p.search_width));
-  uint32_t itopk = (uint32_t)std::max<size_t>(p.itopk_size ? p.itopk_size : 64, (size_t)k);
-  if (itopk % 32) itopk += 32 - itopk % 32;  // search_plan.cuh:236-244
-  CUVS_EXPECTS(itopk <= 1024, "cagra::search: itopk_size up to 1024 is supported");
-  a.itopk = itopk;
-  // search_plan.cuh:199-215
-  uint32_t max_iter = (uint32_t)p.max_iterations;
-  if (max_iter == 0) {
-    max_iter        = itopk / a.width;
-    int64_t reach   = 1;
-    while (reach < idx.n) { reach *= std::max<int64_t>(2, idx.degree / 2); max_iter += 1; }
+  // share of rows the bitset removes: the reference derives it from the bitset's population count when the caller
+  // does not give one (cagra.cuh:374-381; the C search params have no such field) and widens the multi-CTA itopk
+  float filtering_rate = 0.f;
+  if (filter_bits != nullptr) {
+    const int64_t kept = count_set_bits(res, filter_bits, idx.n);
+    filtering_rate     = std::min(std::max((float)(idx.n - kept) / (float)idx.n, 0.0f), 0.999f);
   }
+  const cagra_plan pl = make_cagra_plan(p, idx.n, idx.degree, (uint32_t)k, nq, res.num_cus, filtering_rate);
+  const uint32_t itopk = pl.itopk;
+  CUVS_EXPECTS(itopk <= 1024, "cagra::search: itopk_size up to 1024 is supported");
+  a.itopk    = itopk;
   a.min_iter = (uint32_t)p.min_iterations;
-  a.max_iter = std::max(max_iter, a.min_iter);
+  a.max_iter = pl.max_iterations;
   a.k        = (uint32_t)k;
   a.np2      = (uint32_t)next_pow2((int)(itopk + a.width * idx.degree));
-  // small hash, reset every few iterations: at most itopk + interval * width * degree keys at <= 50 % fill
+  // LDS hash of the walk: exact (open addressing, no false positives), so its size and reset interval change the
+  // number of re-visited rows but never a result; sized for <= 50 % fill like the reference's small hash (plan above)
   uint32_t bits = 11;
   while ((1u << bits) < 2 * (itopk + 2 * a.width * idx.degree)) ++bits;
   bits = std::max<uint32_t>(bits, (uint32_t)p.hashmap_min_bitlen);
@@ -742,13 +858,16 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   a.norms          = idx.norms.data();
   CUVS_EXPECTS(a.is_ip != 2 || a.norms != nullptr, "cagra::search: cosine index without dataset norms");
   a.idx64          = idx64 ? 1 : 0;
-  // ---- algorithm choice. The reference's AUTO (search_plan.cuh:121-131) keeps one CTA per query once the batch
-  // alone fills the GPU. On MI355X the multi-wave walk measured faster at every batch size from 1 to 10k at equal
-  // recall (1M x 768 fp16, itopk 64, batch 10k: 18.9 vs 26.7 ms; batch 10: 0.68 vs 0.92 ms and recall 0.99 vs
-  // 0.63 because idle CUs run extra walkers), so AUTO takes it whenever its limits allow.
-  int algo = (int)p.algo;
-  if (algo == (int)AUTO)
-    algo = (itopk <= 16 * kMwTopk && idx.degree <= 224 && (size_t)k <= itopk) ? (int)MULTI_CTA : (int)SINGLE_CTA;
+  // ---- algorithm choice: AUTO follows the reference (search_plan.cuh:121-131: one walker per query once the batch
+  // alone fills the GPU, several per query otherwise) so that matched parameters walk the graph the same way.
+  // CUVS_AMD_CAGRA_AUTO=multi makes AUTO take the multi-wave walk at every batch size (on MI355X it measured faster at
+  // equal recall: 1M x 768 fp16, itopk 64, batch 10k: 18.9 vs 26.7 ms).
+  int algo = pl.ref_algo;
+  if ((int)p.algo == (int)AUTO) {
+    const char* e = getenv("CUVS_AMD_CAGRA_AUTO");
+    if (e != nullptr && e[0] == 'm') algo = (int)MULTI_CTA;
+    if (!(itopk <= 16 * kMwTopk && idx.degree <= 224 && (size_t)k <= itopk)) algo = (int)SINGLE_CTA;  // limits of the multi-wave walk
+  }
   // MULTI_KERNEL (search_multi_kernel.cuh) exists in the reference because an itopk list above 512 entries does not
   // fit one CTA's shared memory there, so the walk is split into sample / top-k / pickup / distance kernels with the
   // list in global memory. 160 KB of LDS holds the 1024-entry list, its merge buffer and the hash of one walk, so the
@@ -769,14 +888,7 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
     m.np2_local = (uint32_t)next_pow2((int)(kMwTopk + idx.degree));
     m.vis_bits  = 8;
     while ((1u << m.vis_bits) < 2 * (kMwTopk + idx.degree)) ++m.vis_bits;
-    // search_plan.cuh:199-215 with the multi-CTA list size
-    uint32_t mc_iter = (uint32_t)p.max_iterations;
-    if (mc_iter == 0) {
-      mc_iter       = kMwTopk;
-      int64_t reach = 1;
-      while (reach < idx.n) { reach *= std::max<int64_t>(2, idx.degree / 2); mc_iter += 1; }
-    }
-    m.s.max_iter = std::max(mc_iter, a.min_iter);
+    m.s.max_iter = pl.mc_max_iterations;  // search_plan.cuh:199-215 with the multi-CTA list size
     m.trav_bits  = 11;  // every wave claims <= max_iter parents and inserts <= 32 results; keep the fill <= 50 %
     while ((1u << m.trav_bits) < 2 * W * (m.s.max_iter + kMwTopk)) ++m.trav_bits;
     m.merge_np2 = (uint32_t)next_pow2((int)(W * kMwTopk));
@@ -1373,3 +1485,20 @@ cuvsError_t cuvsCagraMerge(cuvsResources_t res_h, cuvsCagraIndexParams_t params,
 }
 
 }  // extern "C"
+
+
+// Test hook (not part of the reference ABI): the search plan for given parameters, computed on the host without
+// touching a GPU - tests pin it to the reference's rules (search_plan.cuh:121-131,199-340).
+extern "C" __attribute__((visibility("default"))) int cuvsAmdCagraSearchPlan(cuvsCagraSearchParams_t params, int64_t n_rows,
+                                                                              uint32_t graph_degree, uint32_t topk,
+                                                                              int64_t n_queries, int num_cus,
+                                                                              float filtering_rate, uint32_t out[10])
+{
+  return translate_exceptions([=] {
+    const cuvs_amd::cagra_plan pl =
+      cuvs_amd::make_cagra_plan(*params, n_rows, graph_degree, topk, n_queries, num_cus, filtering_rate);
+    out[0] = pl.itopk; out[1] = pl.max_iterations; out[2] = pl.search_width; out[3] = (uint32_t)pl.ref_algo;
+    out[4] = pl.ref_small_hash_bitlen; out[5] = pl.ref_hash_bitlen; out[6] = pl.ref_small_hash_reset_interval;
+    out[7] = pl.ref_mc_num_cta_per_query; out[8] = pl.mc_max_iterations; out[9] = 0;
+  });
+}

@@ -177,7 +177,9 @@ __global__ void flat_query_tiles_kernel(const work_item* __restrict__ items, con
 
 // IP (inner product) is a template argument: tested at run time inside the unrolled element loop it became a
 // scalar branch per element
-template <typename T, int E, int METRIC>  // 0: L2, 1: inner product, 2: cosine (inner product + row norms)
+// ALL: the non-fused path (every score written out, no top lists) - a template argument so that the fused kernels
+// stay exactly as they were
+template <typename T, int E, int METRIC, bool ALL = false>  // METRIC 0: L2, 1: inner product, 2: cosine (+ row norms)
 __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_args a)
 {
   constexpr int QPB = kFlatQPB;
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
       bf[j] = (IP || j >= (int)item.count) ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
     }
     for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-      if (!IP && a.all_scores == nullptr && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
+      if (!IP && !ALL && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
         bool below = false;
 #pragma unroll
         for (int j = 0; j < QPB; ++j) below = below || (accv[j >> 1][j & 1] <= bf[j]);
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     for (int j = 0; j < QPB; ++j) {
       if (j >= (int)item.count) break;
       const float dj       = IP ? -acc[j] : acc[j];  // smaller is better
-      if (a.all_scores != nullptr) {  // non-fused path: every score goes to the query's row (filtered rows keep the fill)
+      if constexpr (ALL) {  // non-fused path: every score goes to the query's row (filtered rows keep the fill)
         bool keep = valid;
         if (keep && a.filter_bits != nullptr) {
           const int64_t sid = a.indices[(size_t)base_row + v];
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
     }
   }
 
-  if (a.all_scores != nullptr) return;  // workgroup-uniform
+  if constexpr (ALL) return;
   // ---- merge the wave lists (the query tile is no longer needed)
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
@@ -402,10 +404,10 @@ __global__ void unpack_flat_list_kernel(const uint8_t* __restrict__ data, uint32
   for (uint32_t b = 0; b < esz; ++b) out[i * esz + b] = data[addr + b];
 }
 
-template <typename T, int E, int METRIC>
+template <typename T, int E, int METRIC, bool ALL = false>
 void launch_flat_scan_kern(resources& res, const flat_scan_args& a, size_t smem, unsigned grid)
 {
-  auto kern = ivf_flat_scan_kernel<T, E, METRIC>;
+  auto kern = ivf_flat_scan_kernel<T, E, METRIC, ALL>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatThreads), smem, res.stream, a);
 }
@@ -413,7 +415,11 @@ void launch_flat_scan_kern(resources& res, const flat_scan_args& a, size_t smem,
 template <typename T>
 void launch_flat_scan(resources& res, const flat_scan_args& a, size_t smem, unsigned grid, bool big_k)
 {
-  if (big_k) {
+  if (a.all_scores != nullptr) {
+    if (a.is_ip == 2)      launch_flat_scan_kern<T, 1, 2, true>(res, a, smem, grid);
+    else if (a.is_ip == 1) launch_flat_scan_kern<T, 1, 1, true>(res, a, smem, grid);
+    else                   launch_flat_scan_kern<T, 1, 0, true>(res, a, smem, grid);
+  } else if (big_k) {
     if (a.is_ip == 2)      launch_flat_scan_kern<T, 4, 2>(res, a, smem, grid);
     else if (a.is_ip == 1) launch_flat_scan_kern<T, 4, 1>(res, a, smem, grid);
     else                   launch_flat_scan_kern<T, 4, 0>(res, a, smem, grid);
@@ -449,9 +455,13 @@ void ivf_flat_extend(resources& res, ivf_flat_index& idx, const void* data, elem
     copy_async(res, ids_dev.data(), new_ids, n_new * sizeof(int64_t));
     new_ids = ids_dev.data();
   }
-  // labels (L2 argmin on mapped floats; ivf_flat_build.cuh:179-200 predicts with the index metric, the coarse
-  // quantizer here is always trained and queried in L2 like ivf_pq's)
+  // labels: predicted with the index metric, like the k-means that trained the centres (ivf_flat_build.cuh:179-200,
+  // :438): L2 argmin; inner product -> the centre with the largest dot product (argmin of |c|^2 - 2 x.c with the |c|^2
+  // term dropped), which is also how the search ranks the probes; cosine -> L2 on unit-length copies
   dev_buf<uint32_t> labels(res, n_new);
+  dev_buf<float> zero_norms(res, idx.metric == M_InnerProduct ? idx.n_lists : 0);
+  if (idx.metric == M_InnerProduct) HIP_TRY(hipMemsetAsync(zero_norms.data(), 0, zero_norms.bytes(), res.stream));
+  const float* label_norms = idx.metric == M_InnerProduct ? zero_norms.data() : idx.center_norms.data();
   const int64_t batch_rows = std::max<int64_t>(1024, std::min<int64_t>(n_new, (int64_t(1) << 28) / dim));
   {
     dev_buf<float> xb(res, (size_t)std::min(batch_rows, n_new) * dim);
@@ -460,7 +470,7 @@ void ivf_flat_extend(resources& res, ivf_flat_index& idx, const void* data, elem
       load_range_as_float(res, data, et, is_host, dim, r0, cnt, xb.data());
       if (idx.metric == M_CosineExpanded)
         normalize_rows(res, xb.data(), cnt, dim);  // cosine: rows are assigned to lists on unit-length copies
-      fused_l2_argmin<float>(res, xb.data(), cnt, dim, idx.centers.data(), idx.n_lists, dim, idx.center_norms.data(),
+      fused_l2_argmin<float>(res, xb.data(), cnt, dim, idx.centers.data(), idx.n_lists, dim, label_norms,
                              labels.data() + r0, nullptr);
     }
   }
@@ -578,7 +588,8 @@ std::unique_ptr<ivf_flat_index> ivf_flat_build(resources& res, const cuvsIvfFlat
   }
   idx->centers      = dev_buf<float>::persistent((size_t)p.n_lists * dim);
   kmeans_params kp;
-  kp.n_iters = (int)p.kmeans_n_iters;
+  kp.n_iters       = (int)p.kmeans_n_iters;
+  kp.inner_product = metric == M_InnerProduct;  // the index metric drives the clustering (ivf_flat_build.cuh:188)
   if (metric == M_CosineExpanded)
     normalize_rows(res, trainset.data(), n_train, dim);
   kmeans_balanced_fit(res, trainset.data(), n_train, dim, (int)p.n_lists, kp, idx->centers.data());

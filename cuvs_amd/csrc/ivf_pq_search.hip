@@ -322,7 +322,7 @@ struct scan_layout {
 };
 
 // FAST4: pq_bits == 8, pq_dim == 64 (4 full chunks): the four chunk loads of a tile are issued back to back. Otherwise the generic path handles any pq_dim / pq_bits.
-template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL>
 __device__ inline void pq_scan_item(const scan_args& a, const work_item item, char* smem,
                                     const float (&pqreg)[4][2][4], const bool pq_in_regs,
                                     const work_item* __restrict__ share, const uint32_t share_len,
@@ -550,7 +550,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   const size_t g0       = (size_t)(base_row >> 6);
   const uint4* codes16  = reinterpret_cast<const uint4*>(a.codes);
   const int kr          = (int)a.k - 1;
-  const bool prune      = FAST4 && !a.is_ip && !(a.dbg & 8) && a.all_scores == nullptr;  // dbg 8: early stop off (ablation)
+  const bool prune      = FAST4 && !ALL && !a.is_ip && !(a.dbg & 8);  // dbg 8: early stop off (ablation)
 
   // k-th bounds of the item's queries as floats (+inf while a query has fewer than k candidates); read once per
   // tile - they only ever decrease, so a row dropped against these is also rejected by the (fresher) filter
@@ -564,7 +564,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 
   // candidate filter + insertion for the rows held one per lane (v = in-list row of this lane)
   auto offer = [&](const acc_t& acc, const bool cand, const uint32_t v) {
-    if (a.all_scores != nullptr) {  // non-fused path: every score goes to the query's row, select_k runs afterwards
+    if constexpr (ALL) {  // non-fused path: every score goes to the query's row, select_k runs afterwards
 #pragma unroll
       for (int j = 0; j < QPB; ++j) {
         if (j >= (int)item.count) break;
@@ -791,7 +791,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     if (wave == 0) { stat_add(ST_ROWS, len); stat_add(ST_ITEMS, 1); }
   }
   if (threadIdx.x == 0) *next_slot = next_hdr;
-  if ((a.dbg & 32) || a.all_scores != nullptr) return;  // dbg 32: no merge / output (workgroup-uniform)
+  if (ALL || (a.dbg & 32)) return;  // dbg 32: no merge / output (workgroup-uniform); ALL: non-fused path
   // ---- merge the 16 wave lists of every query (the LUT region is free now)
   __syncthreads();
   float* mg_d    = reinterpret_cast<float*>(smem);
@@ -861,7 +861,9 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 // observed dispatch places workgroup b on XCD b % 8 (used for speed only): XCD x takes the x-th eighth of the
 // item array and its 32 CUs work on 32 consecutive items, so the ~20 work items of a list run on ONE XCD at
 // about the same time and share its 4 MiB L2 instead of pulling the list into all eight L2s.
-template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
+// ALL: the non-fused path (every score written out, no top lists) - a template argument so that the fused kernels stay
+// exactly as they were
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL = false>
 __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
     uint32_t next_ticket = 0xffffffffu;
     if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
     const unsigned long long t0 = (a.dbg & 128) ? __builtin_readcyclecounter() : 0ull;
-    pq_scan_item<LutT, AccT, QPB, FAST4, E>(a, cur, smem, pqreg, pq_in_regs, share, share_len, next_ticket,
+    pq_scan_item<LutT, AccT, QPB, FAST4, E, ALL>(a, cur, smem, pqreg, pq_in_regs, share, share_len, next_ticket,
                                              buf ^ 1);
     __syncthreads();
     // ST_MERGE accumulates the whole item; the host subtracts the other phases
@@ -1400,10 +1402,10 @@ size_t scan_smem_bytes(const ivf_pq_index& idx, int k)
                      idx.rot_dim, (uint32_t)k).total;
 }
 
-template <typename LutT, typename AccT, int QPB, bool FAST4, int E>
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL = false>
 void launch_scan(resources& res, const scan_args& a, size_t smem, unsigned grid)
 {
-  auto kern = pq_scan_kernel<LutT, AccT, QPB, FAST4, E>;
+  auto kern = pq_scan_kernel<LutT, AccT, QPB, FAST4, E, ALL>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem));
   profile_begin(res, "pq_scan_kernel");
@@ -1415,7 +1417,10 @@ void launch_scan(resources& res, const scan_args& a, size_t smem, unsigned grid)
 template <typename LutT, typename AccT, int QPB>
 void launch_scan_qpb(resources& res, const scan_args& a, size_t smem, unsigned grid, bool bits8, bool big_k)
 {
-  if (bits8) {
+  if (a.all_scores != nullptr) {
+    if (bits8) launch_scan<LutT, AccT, QPB, true, 1, true>(res, a, smem, grid);
+    else       launch_scan<LutT, AccT, QPB, false, 1, true>(res, a, smem, grid);
+  } else if (bits8) {
     if (big_k) launch_scan<LutT, AccT, QPB, true, 4>(res, a, smem, grid);
     else       launch_scan<LutT, AccT, QPB, true, 1>(res, a, smem, grid);
   } else {

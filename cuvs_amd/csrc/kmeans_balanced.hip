@@ -175,10 +175,12 @@ void calc_centers_and_sizes(resources& res, const float* x, int64_t n, int64_t l
 }
 
 void predict_f32(resources& res, const float* x, int64_t n, int64_t ld, int dim, const float* centers,
-                 int n_clusters, uint32_t* labels)
+                 int n_clusters, uint32_t* labels, bool inner_product = false)
 {
   dev_buf<float> cn(res, n_clusters);
-  row_norms<float>(res, centers, n_clusters, dim, dim, cn.data(), false);
+  // argmin_c (|c|^2 - 2 x.c); with |c|^2 := 0 it is argmax_c x.c, the inner-product assignment
+  if (inner_product) HIP_TRY(hipMemsetAsync(cn.data(), 0, cn.bytes(), res.stream));
+  else               row_norms<float>(res, centers, n_clusters, dim, dim, cn.data(), false);
   fused_l2_argmin<float>(res, x, n, ld, centers, n_clusters, dim, cn.data(), labels, nullptr);
 }
 
@@ -208,7 +210,7 @@ bool adjust_centers(resources& res, float* centers, int n_clusters, int dim, con
 
 void balancing_em_iters(resources& res, uint32_t n_iters, int dim, const float* x, int64_t ld, int64_t n_rows,
                         int n_clusters, float* centers, uint32_t* labels, uint32_t* sizes,
-                        uint32_t balancing_pullback, float balancing_threshold, int& i_primes)
+                        uint32_t balancing_pullback, float balancing_threshold, int& i_primes, bool inner_product = false)
 {
   dev_buf<int> flag(res, 1);
   uint32_t balancing_counter = balancing_pullback;
@@ -220,7 +222,8 @@ void balancing_em_iters(resources& res, uint32_t n_iters, int dim, const float* 
         n_iters++;
       }
     }
-    predict_f32(res, x, n_rows, ld, dim, centers, n_clusters, labels);
+    if (inner_product) normalize_rows(res, centers, n_clusters, dim);  // kmeans_balanced.cuh:682-696
+    predict_f32(res, x, n_rows, ld, dim, centers, n_clusters, labels, inner_product);
     calc_centers_and_sizes(res, x, n_rows, ld, dim, n_clusters, labels, centers, sizes);
   }
 }
@@ -229,13 +232,13 @@ void balancing_em_iters(resources& res, uint32_t n_iters, int dim, const float* 
 
 // kmeans_balanced.cuh:724-783
 void kmeans_build_clusters(resources& res, const float* x, int64_t n_rows, int64_t ld, int dim, int n_clusters,
-                           int n_iters, float* centers, uint32_t* labels, uint32_t* sizes)
+                           int n_iters, float* centers, uint32_t* labels, uint32_t* sizes, bool inner_product)
 {
   int i_primes = 0;
   hipLaunchKernelGGL(iota_mod_kernel, dim3(blocks_for(n_rows, 256)), dim3(256), 0, res.stream, labels, n_rows,
                      (uint32_t)n_clusters);
   calc_centers_and_sizes(res, x, n_rows, ld, dim, n_clusters, labels, centers, sizes);
-  balancing_em_iters(res, n_iters, dim, x, ld, n_rows, n_clusters, centers, labels, sizes, 2, 0.25f, i_primes);
+  balancing_em_iters(res, n_iters, dim, x, ld, n_rows, n_clusters, centers, labels, sizes, 2, 0.25f, i_primes, inner_product);
 }
 
 void kmeans_balanced_fit(resources& res, const float* x, int64_t n_rows, int64_t dim64, int n_clusters,
@@ -247,7 +250,7 @@ void kmeans_balanced_fit(resources& res, const float* x, int64_t n_rows, int64_t
   const int n_meso = std::min<int>(n_clusters, (int)(std::sqrt((double)n_clusters) + 0.5));
   if (!p.hierarchical || n_meso <= 1 || n_meso == n_clusters) {
     dev_buf<uint32_t> labels(res, n_rows), sizes(res, n_clusters);
-    kmeans_build_clusters(res, x, n_rows, dim, dim, n_clusters, p.n_iters, centers, labels.data(), sizes.data());
+    kmeans_build_clusters(res, x, n_rows, dim, dim, n_clusters, p.n_iters, centers, labels.data(), sizes.data(), p.inner_product);
     return;
   }
   int i_primes = 0;
@@ -256,7 +259,7 @@ void kmeans_balanced_fit(resources& res, const float* x, int64_t n_rows, int64_t
   {
     dev_buf<float> meso_centers(res, (size_t)n_meso * dim);
     kmeans_build_clusters(res, x, n_rows, dim, dim, n_meso, p.n_iters, meso_centers.data(), meso_labels.data(),
-                          meso_sizes_d.data());
+                          meso_sizes_d.data(), p.inner_product);
   }
   std::vector<uint32_t> meso_sizes = to_host(res, meso_sizes_d.data(), n_meso);
 
@@ -307,7 +310,7 @@ void kmeans_balanced_fit(resources& res, const float* x, int64_t n_rows, int64_t
                          perm.data() + offsets[i], k, mc_train.data());
       if (k >= fine_nums[i]) {
         kmeans_build_clusters(res, mc_train.data(), k, dim, dim, (int)fine_nums[i], p.n_iters, mc_centers.data(),
-                              mc_labels.data(), mc_sizes.data());
+                              mc_labels.data(), mc_sizes.data(), p.inner_product);
       } else {
         // fewer training rows than fine clusters: seed the centres cyclically from the rows
         for (int64_t c = 0; c < fine_nums[i]; ++c)
@@ -320,7 +323,7 @@ void kmeans_balanced_fit(resources& res, const float* x, int64_t n_rows, int64_t
   // ---- final balancing EM over all centres (:1113-1127)
   dev_buf<uint32_t> labels(res, n_rows), sizes(res, n_clusters);
   balancing_em_iters(res, std::max<uint32_t>(p.n_iters / 10, 2), dim, x, dim, n_rows, n_clusters, centers,
-                     labels.data(), sizes.data(), 5, 0.2f, i_primes);
+                     labels.data(), sizes.data(), 5, 0.2f, i_primes, p.inner_product);
 }
 
 template <typename T>

@@ -56,13 +56,17 @@ bool fused_knn(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x,
 struct kmeans_params {
   int n_iters        = 20;
   bool hierarchical  = true;
+  // false: L2 (argmin of |x - c|^2). true: inner product - rows go to the centre with the largest dot product and the
+  // centres are normalised before every E-step so that they do not collapse towards zero
+  // (kmeans_balanced.cuh:123-150 predict_core, :682-696)
+  bool inner_product = false;
 };
 // Balanced k-means fit on float rows (reference: cluster/detail/kmeans_balanced.cuh:986-1148).
 void kmeans_balanced_fit(resources& res, const float* x, int64_t n, int64_t dim, int n_clusters,
                          const kmeans_params& p, float* centers /*[n_clusters, dim]*/);
 // Non-hierarchical balanced EM (kmeans_balanced.cuh:724-783); x has row pitch ld. Used for PQ codebooks.
 void kmeans_build_clusters(resources& res, const float* x, int64_t n_rows, int64_t ld, int dim, int n_clusters,
-                           int n_iters, float* centers, uint32_t* labels, uint32_t* sizes);
+                           int n_iters, float* centers, uint32_t* labels, uint32_t* sizes, bool inner_product = false);
 // Stable grouping of rows by label: perm[n] = row ids ordered by (label, row); offsets[n_clusters + 1].
 void group_by_label(resources& res, const uint32_t* labels, int64_t n, uint32_t n_clusters, uint32_t* perm,
                     uint32_t* offsets);

@@ -156,3 +156,26 @@ def test_large_k_non_fused_path(metric):
         gd, gi = _search(index, q, k, n_probes)
         od, oi = oracle.ivf_flat_search(ex, q, k, n_probes, metric=metric)
         assert (gi == oi).all() and (gd == od).all(), (k, n_probes)
+
+
+def test_inner_product_on_unnormalised_rows():
+    """The lists are trained, filled and probed with the SAME metric (ivf_flat_build.cuh:188,438): with an L2-trained
+    coarse quantizer the inner-product probes were not the lists the rows had been assigned to, and recall at equal
+    n_probes fell on data whose norms vary. Every row must sit in the list whose centre has the largest dot product."""
+    from cuvs_amd.neighbors import ivf_flat
+
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal((20000, 32)) * rng.uniform(0.2, 3.0, size=(20000, 1))).astype(np.float32)  # norms vary 15x
+    q = rng.standard_normal((300, 32)).astype(np.float32)
+    index = _build(x, n_lists=64, metric="inner_product", kmeans_n_iters=20)
+    ex = ivf_flat.export_for_oracle(index, np.float32)
+    centers = ex["centers"]
+    for L in range(0, 64, 7):
+        rows = ex["rows"][L]
+        if len(rows):
+            assert (np.argmax(rows @ centers.T, axis=1) == L).mean() > 0.999
+    gd, gi = _search(index, q, 10, 8)
+    _, ti = oracle.brute_force_knn(q, x, 10, metric="inner_product")
+    assert oracle.recall(gi, ti) >= 0.9, oracle.recall(gi, ti)  # was ~0.6 with L2-trained lists on this data
+    od, oi = oracle.ivf_flat_search(ex, q, 10, 8, metric="inner_product")
+    assert (gi == oi).all() and (gd == od).all()

@@ -64,3 +64,27 @@ def test_cagra_search_walk_matches_oracle(dtype, metric):
         od, oi = oracle.cagra_search(x, graph, q, 10, itopk_size=itopk, search_width=width, metric=metric)
         assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.4f}"
         assert (d.cpu().numpy() == od).all()
+
+
+@pytest.mark.parametrize("dtype,dim", [(np.float16, 768), (np.float32, 600), (np.float16, 1024)])
+def test_cagra_search_walk_matches_oracle_large_dim(dtype, dim):
+    """The BASELINE C4 row shape (768 fp16) and its neighbours: rows longer than one team pass (dim > 512), so the
+    distance loop runs more than once per row. Bit-identical to the oracle walk on the same graph."""
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(dim)
+    lat = rng.standard_normal((2500, 24)).astype(np.float32)
+    A = (rng.standard_normal((24, dim)) / 5).astype(np.float32)
+    x = (lat @ A + 0.02 * rng.standard_normal((2500, dim))).astype(dtype)
+    q = ((rng.standard_normal((80, 24)).astype(np.float32)) @ A).astype(dtype)
+    index = cagra.build(cagra.IndexParams(intermediate_graph_degree=64, graph_degree=32), torch.from_numpy(x).cuda())
+    graph = index.graph.cpu().numpy().view(np.uint32)
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64, algo="single_cta"), index, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    gi = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    od, oi = oracle.cagra_search(x, graph, q, 10, itopk_size=64, search_width=1)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.4f}"
+    assert (d.cpu().numpy() == od).all()
+    _, ti = oracle.exact_knn(q.astype(np.float32), x.astype(np.float32), 10)
+    assert oracle.recall(gi, ti) > 0.95
