@@ -42,6 +42,11 @@ struct ivf_pq_index {
   dev_buf<uint32_t> list_offsets; // [n_lists + 1] (rows, multiples of 64)
   std::vector<uint32_t> h_list_sizes, h_list_offsets;
 
+  // reduced-precision copies for search_params.coarse_search_dtype (ivf_pq_index.cu:640-760), built on first use:
+  // fp16: centres / |c|^2 / rotation rounded to half (kept as floats); int8: trunc(x * 128) saturated, and the
+  // per-centre norm term of the int8 GEMM (the y / z columns of centers_int8, ivf_pq_index.cu:674-732)
+  mutable dev_buf<float> coarse_centers_h, coarse_norms_h, coarse_rot_h, coarse_centers_i8, coarse_normterm_i8, coarse_rot_i8;
+
   // List-sharded multi-GPU search (shard_comm.hip): every rank holds the whole model (centres, rotation, codebooks) but
   // only the lists it owns - list L belongs to rank L % shard_world. extend() drops rows of foreign lists, search()
   // scans only owned probes; the per-rank top-k lists are all-gathered and merged. shard_world == 1: not sharded.
@@ -68,6 +73,7 @@ struct ivf_pq_build_params {
 struct ivf_pq_search_params {
   uint32_t n_probes = 20;
   int lut_dtype = 0, internal_distance_dtype = 0;  // hipDataType values: 0 = f32, 2 = f16, 8 = u8(fp8)
+  int coarse_search_dtype = 0;                     // 0 = f32, 2 = f16, 3 = i8 (ivf_pq_search.cuh:171-340)
   uint32_t max_internal_batch_size = 4096;
 };
 

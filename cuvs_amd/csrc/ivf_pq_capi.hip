@@ -171,6 +171,7 @@ cuvsError_t cuvsIvfPqSearch(cuvsResources_t res_h, cuvsIvfPqSearchParams_t param
     sp.lut_dtype               = (int)params->lut_dtype;
     sp.internal_distance_dtype = (int)params->internal_distance_dtype;
     sp.max_internal_batch_size = params->max_internal_batch_size;
+    sp.coarse_search_dtype     = (int)params->coarse_search_dtype;
     ivf_pq_search(res, sp, idx, dl_data(queries), elem_of(queries.dtype), m, (int)k,
                   static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)));
   });

@@ -1429,13 +1429,96 @@ void launch_scan_qpb(resources& res, const scan_args& a, size_t smem, unsigned g
   }
 }
 
-// n_probes clusters closest to each query (select_clusters, ivf_pq_search.cuh:60-168)
+// ---- reduced-precision coarse search (search_params.coarse_search_dtype; ivf_pq_search.cuh:171-340, :995-1017)
+// The reference converts queries, centres (with their |c|^2 column) and the rotation matrix to half or int8 and runs
+// the coarse GEMM and the rotation GEMM in that type. Here the operands are rounded the same way and kept as
+// floats - products of two halves / two int8 are exact in fp32 - so the fp32 MFMA kernels produce: int8 the exact
+// integer result (bit-identical to any int8 GEMM), fp16 the fp32-accumulated dot product, rounded to half like the
+// reference's half output (cuBLAS's accumulation order is not specified, so fp16 is "the same rounding", not bit-pinned).
+__global__ void round_to_half_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int64_t ld_in,
+                                     int64_t cols)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)(_Float16)in[(i / cols) * ld_in + i % cols];
+}
+__device__ inline float to_int8_value(float v)  // static_cast<int8_t>(clamp(v, -128, 127)): truncation toward zero
+{
+  return truncf(fmaxf(-128.0f, fminf(127.0f, v)));
+}
+__global__ void scale_to_int8_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int64_t ld_in,
+                                     int64_t cols)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = to_int8_value(in[(i / cols) * ld_in + i % cols] * 128.0f);
+}
+// the y / z columns of centers_int8 times the query's constant columns (ivf_pq_index.cu:674-732, ivf_pq_search.cuh:205-215)
+__global__ void int8_norm_term_kernel(const float* __restrict__ norms, int n_lists, int m, bool l2, float* __restrict__ out)
+{
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_lists) return;
+  const float c  = 64.0f / (float)(m - 1);
+  const float y  = fmaxf(-128.0f, fminf(127.0f, norms[j] * c));
+  const float z  = to_int8_value((y - roundf(y)) * 128.0f);
+  const float yr = truncf(roundf(y));
+  // query columns: (1 - m) at `dim`, then (m - 1) times norm_factor (-128 for L2, 0 for inner product / cosine)
+  out[j] = z * (float)(1 - m) + (l2 ? (float)(m - 1) * yr * -128.0f : 0.0f);
+}
+// qc_distances of the reduced-precision GEMM from the exact dot products: half: half(alpha * (dot - 0.5 |c|^2_h));
+// int8: alpha * (dot + norm term), alpha = -2 (L2) / -1 (inner product, cosine)
+__global__ void coarse_finish_kernel(float* __restrict__ d, int64_t nq, int n_lists, const float* __restrict__ term,
+                                     float alpha, bool half_out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq * n_lists) return;
+  float v = d[i];
+  if (term != nullptr) v = v + (half_out ? -0.5f * term[i % n_lists] : term[i % n_lists]);
+  v = alpha * v;
+  d[i] = half_out ? (float)(_Float16)v : v;
+}
+
+// n_probes clusters closest to each query (select_clusters, ivf_pq_search.cuh:60-168 fp32, :171-340 int8 / half).
+// qf: [nq, dim] fp32 queries (normalised for cosine); qc: the copy in the coarse type (== qf for fp32)
 void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, int64_t nq, uint32_t n_probes,
-                     uint32_t* probes)
+                     uint32_t* probes, int coarse_dtype, float* qc)
 {
   dev_buf<float> dist(res, (size_t)nq * idx.n_lists);
   dev_buf<float> pd(res, (size_t)nq * n_probes);
-  if (idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) {  // cosine: unit queries x unit centres
+  const bool ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;  // cosine: unit queries x unit centres
+  if (coarse_dtype != 0) {
+    const bool half_t  = coarse_dtype == 2;
+    const int64_t n_el = (int64_t)idx.n_lists * idx.dim;
+    dev_buf<float>& cc = half_t ? idx.coarse_centers_h : idx.coarse_centers_i8;
+    dev_buf<float>& ct = half_t ? idx.coarse_norms_h : idx.coarse_normterm_i8;
+    if (cc.data() == nullptr) {
+      cc = dev_buf<float>::persistent((size_t)n_el);
+      ct = dev_buf<float>::persistent(idx.n_lists);
+      if (half_t) {
+        hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.centers.data(),
+                           cc.data(), n_el, (int64_t)idx.dim_ext, (int64_t)idx.dim);
+        hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream,
+                           idx.center_norms.data(), ct.data(), (int64_t)idx.n_lists, (int64_t)1, (int64_t)1);
+      } else {
+        hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.centers.data(),
+                           cc.data(), n_el, (int64_t)idx.dim_ext, (int64_t)idx.dim);
+        const int m = (int)(round_up((int64_t)idx.dim + 2, 16) - idx.dim);  // dim_ext_int8 - dim (ivf_pq_index.cu:668)
+        hipLaunchKernelGGL(int8_norm_term_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream,
+                           idx.center_norms.data(), (int)idx.n_lists, m, !ip, ct.data());
+      }
+    }
+    const int64_t nqe = nq * idx.dim;
+    if (half_t) hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(nqe, 256)), dim3(256), 0, res.stream, qf, qc, nqe, (int64_t)idx.dim, (int64_t)idx.dim);
+    else        hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(nqe, 256)), dim3(256), 0, res.stream, qf, qc, nqe, (int64_t)idx.dim, (int64_t)idx.dim);
+    pairwise_distance<float, float>(res, qc, nq, idx.dim, cc.data(), idx.n_lists, idx.dim, idx.dim, nullptr, nullptr,
+                                    M_InnerProduct, dist.data(), idx.n_lists);
+    // half: the norm column only takes part for L2 (norm_factor 0 otherwise); int8: the z column always does
+    const float* term = (half_t && ip) ? nullptr : ct.data();
+    hipLaunchKernelGGL(coarse_finish_kernel, dim3(nblk(nq * idx.n_lists, 256)), dim3(256), 0, res.stream, dist.data(), nq,
+                       (int)idx.n_lists, term, ip ? -1.0f : -2.0f, half_t);
+    select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
+                                 probes, true);
+    return;
+  }
+  if (ip) {
     pairwise_distance<float, float>(res, qf, nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim,
                                     nullptr, nullptr, M_InnerProduct, dist.data(), idx.n_lists);
     select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
@@ -1448,6 +1531,34 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
     select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
                                  probes, true);
   }
+}
+
+// rotation of the queries in the coarse type (ivf_pq_search.cuh:995-1017): R rounded like the queries, fp32 output;
+// int8: alpha = 1 / 128 / 128
+__global__ void scale_kernel(float* __restrict__ x, int64_t n, float a)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= a;
+}
+void rotate_queries(resources& res, const ivf_pq_index& idx, const float* qf, const float* qc, int64_t nq, int coarse_dtype,
+                    float* rot_q)
+{
+  if (coarse_dtype == 0) {
+    pairwise_distance<float, float>(res, qf, nq, idx.dim, idx.rotation.data(), idx.rot_dim, idx.dim, idx.dim, nullptr,
+                                    nullptr, M_InnerProduct, rot_q, idx.rot_dim);
+    return;
+  }
+  const bool half_t  = coarse_dtype == 2;
+  dev_buf<float>& rr = half_t ? idx.coarse_rot_h : idx.coarse_rot_i8;
+  const int64_t n_el = (int64_t)idx.rot_dim * idx.dim;
+  if (rr.data() == nullptr) {
+    rr = dev_buf<float>::persistent((size_t)n_el);
+    if (half_t) hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.rotation.data(), rr.data(), n_el, (int64_t)idx.dim, (int64_t)idx.dim);
+    else        hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.rotation.data(), rr.data(), n_el, (int64_t)idx.dim, (int64_t)idx.dim);
+  }
+  pairwise_distance<float, float>(res, qc, nq, idx.dim, rr.data(), idx.rot_dim, idx.dim, idx.dim, nullptr, nullptr,
+                                  M_InnerProduct, rot_q, idx.rot_dim);
+  if (!half_t) hipLaunchKernelGGL(scale_kernel, dim3(nblk(nq * idx.rot_dim, 256)), dim3(256), 0, res.stream, rot_q, nq * idx.rot_dim, 1.0f / 128.0f / 128.0f);
 }
 
 // flat row -> source id; distance fix-ups (ivf_common.cuh:114-171 postprocess_neighbors, :176-253)
@@ -1488,6 +1599,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                "internal_distance_dtype must be either CUDA_R_16F or CUDA_R_32F");
   CUVS_EXPECTS(p.lut_dtype == 0 || p.lut_dtype == 2 || p.lut_dtype == 8 || p.lut_dtype == 3,
                "lut_dtype must be CUDA_R_16F, CUDA_R_32F, CUDA_R_8U or CUDA_R_8I");
+  CUVS_EXPECTS(p.coarse_search_dtype == 0 || p.coarse_search_dtype == 2 || p.coarse_search_dtype == 3,
+               "Unsupported coarse_search_dtype (only CUDA_R_32F, CUDA_R_16F, and CUDA_R_8I are supported)");
   CUVS_EXPECTS(!idx.dtype_known || et == idx.dtype, "queries dtype differs from the index dtype");
   if (n_queries == 0) return;
   const uint32_t n_probes = std::min<uint32_t>(p.n_probes, idx.n_lists);
@@ -1528,6 +1641,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const int64_t n_pairs_max = bs_alloc * n_probes;
   dev_buf<float> qf(res, (size_t)bs_alloc * idx.dim);
   dev_buf<float> rot_q(res, (size_t)bs_alloc * idx.rot_dim);
+  dev_buf<float> qc(res, p.coarse_search_dtype != 0 ? (size_t)bs_alloc * idx.dim : 0);  // queries in the coarse type
   dev_buf<uint32_t> probes(res, (size_t)n_pairs_max);
   // Two-phase schedule: the `head` nearest probes of every query are scanned first (labels 0..n_lists-1), the
   // rest afterwards (labels n_lists..2 n_lists-1). After the head phase each query's k-th bound (query_kth) is
@@ -1560,10 +1674,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     const int64_t n_pairs = nq * n_probes;
     load_range_as_float(res, queries, et, q_is_host, idx.dim, q0, nq, qf.data());
     if (idx.metric == M_CosineExpanded) normalize_rows(res, qf.data(), nq, idx.dim);
-    select_clusters(res, idx, qf.data(), nq, n_probes, probes.data());
-    // rotation (ivf_pq_search.cuh:1003-1017)
-    pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.rotation.data(), idx.rot_dim, idx.dim, idx.dim,
-                                    nullptr, nullptr, M_InnerProduct, rot_q.data(), idx.rot_dim);
+    select_clusters(res, idx, qf.data(), nq, n_probes, probes.data(), p.coarse_search_dtype, qc.data());
+    rotate_queries(res, idx, qf.data(), qc.data(), nq, p.coarse_search_dtype, rot_q.data());  // ivf_pq_search.cuh:995-1017
+    if (p.coarse_search_dtype != 0 && idx.metric == M_CosineExpanded) normalize_rows(res, rot_q.data(), nq, idx.rot_dim);
     // list-major grouping of the (query, probe) pairs
     const uint32_t* labels = probes.data();
     if (head > 0 || sharded) {

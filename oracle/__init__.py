@@ -100,10 +100,14 @@ def recall(found, truth):
 _LUT_MODES = {"f32": 0, "f16": 1, "fp8": 2}
 
 
-def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.0, lut="f32", acc="f32"):
+_COARSE_MODES = {"f32": 0, "f16": 1, "i8": 2}
+
+
+def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.0, lut="f32", acc="f32", coarse="f32"):
     """Search an index exported with cuvs_amd.neighbors.ivf_pq.export_for_oracle. lut: "f32" | "f16" | "fp8" (the
     reference's fp_8bit<5, signed-for-inner-product>), acc: "f32" | "f16" (search_params.lut_dtype /
-    internal_distance_dtype). Returns (distances, neighbors); bit-for-bit twin of cuvsIvfPqSearch."""
+    internal_distance_dtype), coarse: "f32" | "f16" | "i8" (coarse_search_dtype: coarse search and query rotation in
+    that type). Returns (distances, neighbors); bit-for-bit twin of cuvsIvfPqSearch."""
     q = _f32(queries)
     centers = _f32(exported["centers"])
     centers_rot = _f32(exported["centers_rot"])
@@ -122,7 +126,8 @@ def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.
         C.c_int(len(sizes)), C.c_int(rotation.shape[0]), C.c_int(int(exported["pq_dim"])),
         C.c_int(int(exported["pq_len"])), C.c_int(int(exported["pq_bits"])), _p(sizes), _p(start), _p(codes), _p(ids),
         C.c_int(_metric(metric)), C.c_int(n_probes), C.c_int(k), C.c_float(scale), _p(nb), _p(ds),
-        C.c_int(int(bool(exported.get("per_cluster", False)))), C.c_int(_LUT_MODES[lut]), C.c_int(_LUT_MODES[acc]))
+        C.c_int(int(bool(exported.get("per_cluster", False)))), C.c_int(_LUT_MODES[lut]), C.c_int(_LUT_MODES[acc]),
+        C.c_int(_COARSE_MODES[coarse]))
     return ds, nb
 
 

@@ -327,6 +327,7 @@ static inline uint16_t fp8_decode_f16(uint8_t b, int is_signed)
   uint16_t bits = (uint16_t)(((0x3c00u | (0x0200u >> 3)) - (15u << 10)) + (u << 7));
   return (is_signed && (b & 1u)) ? (uint16_t)(bits ^ 0x8000u) : bits;
 }
+static inline float sat_trunc_i8(float v) { return truncf(fmaxf(-128.0f, fminf(127.0f, v))); }
 EXPORT uint8_t oracle_fp8_encode(float v, int is_signed) { return fp8_encode(v, is_signed); }
 EXPORT float oracle_fp8_decode_f32(uint8_t b, int is_signed) { return fp8_decode_f32(b, is_signed); }
 EXPORT float oracle_fp8_decode_f16(uint8_t b, int is_signed) { return f16_to_f32(fp8_decode_f16(b, is_signed)); }
@@ -351,8 +352,10 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
                                  int n_lists, int rot_dim, int pq_dim, int pq_len, int pq_bits,
                                  const uint32_t* list_sizes, const int64_t* list_start, const uint8_t* codes,
                                  const int64_t* ids, int metric, int n_probes, int k, float scale,
-                                 int64_t* neighbors, float* distances, int per_cluster, int lut_mode, int acc_mode)
-{  /* lut_mode 0 fp32 / 1 fp16 / 2 fp8 LUT entries; acc_mode 0 fp32 / 1 fp16 scores (sums in subspace order).
+                                 int64_t* neighbors, float* distances, int per_cluster, int lut_mode, int acc_mode, int coarse_mode)
+{  /* coarse_mode 0 fp32 / 1 fp16 / 2 int8 coarse search and query rotation (search_params.coarse_search_dtype,
+    * ivf_pq_search.cuh:171-340,:995-1017; centers_half / centers_int8 / rotation_matrix_* ivf_pq_index.cu:640-760).
+    * lut_mode 0 fp32 / 1 fp16 / 2 fp8 LUT entries; acc_mode 0 fp32 / 1 fp16 scores (sums in subspace order).
     * per_cluster: pq_centers is [n_lists, pq_len, book] (codebook_gen::PER_CLUSTER), else [pq_dim, pq_len, book] */
   const int book = 1 << pq_bits;
   const int bpr  = (pq_dim * pq_bits + 7) / 8;
@@ -372,6 +375,8 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
     float* rq     = (float*)malloc(sizeof(float) * (size_t)rot_dim);
     float* qv     = (float*)malloc(sizeof(float) * (size_t)rot_dim);
     float* qh     = (float*)malloc(sizeof(float) * (size_t)dim);
+    float* qcs    = (float*)malloc(sizeof(float) * (size_t)dim);  /* query in the coarse type */
+    float* ccs    = (float*)malloc(sizeof(float) * (size_t)dim);  /* a centre / rotation row in the coarse type */
     float* lut    = (float*)malloc(sizeof(float) * (size_t)pq_dim * book);
     pair_t* best  = (pair_t*)malloc(sizeof(pair_t) * (size_t)k);
     float* buf_d  = (float*)malloc(sizeof(float) * (size_t)n_probes * k);
@@ -387,16 +392,47 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
       }
       /* coarse */
       float qn = canon_sqnorm(q, dim);
+      if (coarse_mode != 0) {
+        for (int d = 0; d < dim; ++d) qcs[d] = coarse_mode == 1 ? f16_to_f32(f32_to_f16(q[d])) : sat_trunc_i8(q[d] * 128.0f);
+      }
+      const int m8 = ((dim + 2 + 15) / 16) * 16 - dim;  /* dim_ext_int8 - dim */
       for (int j = 0; j < n_lists; ++j) {
-        float dot = canon_dot(q, centers + (int64_t)j * dim, dim);
-        cd[j]     = is_ip ? dot : finish_distance(dot, qn, cn[j], M_L2Expanded, 1e-6f);
+        if (coarse_mode == 0) {
+          float dot = canon_dot(q, centers + (int64_t)j * dim, dim);
+          cd[j]     = is_ip ? dot : finish_distance(dot, qn, cn[j], M_L2Expanded, 1e-6f);
+        } else {
+          const float* c = centers + (int64_t)j * dim;
+          for (int d = 0; d < dim; ++d) ccs[d] = coarse_mode == 1 ? f16_to_f32(f32_to_f16(c[d])) : sat_trunc_i8(c[d] * 128.0f);
+          float v = canon_dot(qcs, ccs, dim);
+          if (coarse_mode == 1) {
+            if (!is_ip) v = v + -0.5f * f16_to_f32(f32_to_f16(cn[j]));
+            cd[j] = f16_to_f32(f32_to_f16((is_ip ? -1.0f : -2.0f) * v));
+          } else {
+            const float cc8 = 64.0f / (float)(m8 - 1);
+            const float y   = fmaxf(-128.0f, fminf(127.0f, cn[j] * cc8));
+            const float z   = sat_trunc_i8((y - roundf(y)) * 128.0f);
+            const float yr  = truncf(roundf(y));
+            v     = v + (z * (float)(1 - m8) + (is_ip ? 0.0f : (float)(m8 - 1) * yr * -128.0f));
+            cd[j] = (is_ip ? -1.0f : -2.0f) * v;
+          }
+        }
         uint32_t key = float_to_key(cd[j]);
-        cc[j].key = is_ip ? ~key : key;
+        cc[j].key = (is_ip && coarse_mode == 0) ? ~key : key;  /* the reduced-precision GEMMs already minimise */
         cc[j].pos = j;
         cc[j].idx = j;
       }
       qsort(cc, (size_t)n_lists, sizeof(cand_t), cmp_key_pos);
-      for (int r = 0; r < rot_dim; ++r) rq[r] = canon_dot(q, rotation + (int64_t)r * dim, dim);
+      for (int r = 0; r < rot_dim; ++r) {
+        const float* rr = rotation + (int64_t)r * dim;
+        if (coarse_mode == 0) { rq[r] = canon_dot(q, rr, dim); continue; }
+        for (int d = 0; d < dim; ++d) ccs[d] = coarse_mode == 1 ? f16_to_f32(f32_to_f16(rr[d])) : sat_trunc_i8(rr[d] * 128.0f);
+        rq[r] = canon_dot(qcs, ccs, dim);
+        if (coarse_mode == 2) rq[r] *= 1.0f / 128.0f / 128.0f;
+      }
+      if (coarse_mode != 0 && is_cos) { /* rotated queries are re-normalised (ivf_pq_search.cuh:1018-1023) */
+        const float n2 = canon_sqnorm(rq, rot_dim), inv = n2 > 0.f ? 1.0f / sqrtf(n2) : 0.f;
+        for (int r = 0; r < rot_dim; ++r) rq[r] = rq[r] * inv;
+      }
       for (int p = 0; p < n_probes; ++p) {
         const int L = (int)cc[p].idx;
         const float* cr = centers_rot + (int64_t)L * rot_dim;
@@ -461,6 +497,7 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
         }
       }
     }
+    free(qcs); free(ccs);
     free(cd); free(cc); free(rq); free(qv); free(qh); free(lut); free(best); free(buf_d); free(buf_i); free(mc);
   }
   free(cn);

@@ -377,3 +377,36 @@ def test_large_k_non_fused_path(lut, acc):
             gd, gi = _search(index, q, k, n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
             od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut=lut, acc=acc)
             assert (gi == oi).all() and (gd == od).all(), (n, k, n_probes)
+
+
+_COARSE = {"f16": np.float16, "i8": np.int8}
+
+
+@pytest.mark.parametrize("coarse", ["f16", "i8"])
+@pytest.mark.parametrize("metric,n,d,n_lists,pq_dim", [("sqeuclidean", 4096, 64, 32, 32), ("inner_product", 4096, 64, 32, 32),
+                                                       ("sqeuclidean", 6000, 30, 24, 10), ("cosine", 4096, 64, 32, 32)])
+def test_coarse_search_dtype_parity(coarse, metric, n, d, n_lists, pq_dim):
+    """search_params.coarse_search_dtype (ivf_pq_search.cuh:171-340,:995-1017): queries, centres and the rotation matrix
+    rounded to half / int8 for the coarse GEMM and the rotation GEMM - identical to the oracle's restatement."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal((n, d)).astype(np.float32) * 0.4   # inside the int8 range after the x128 mapping
+    q = rng.standard_normal((64, d)).astype(np.float32) * 0.4
+    index = _build(x, n_lists=n_lists, pq_dim=pq_dim, metric=metric, kmeans_n_iters=10)
+    gd, gi = _search(index, q, 16, n_probes=8, coarse_search_dtype=_COARSE[coarse])
+    od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, 16, 8, metric=metric, coarse=coarse)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+
+
+def test_coarse_search_dtype_recall_thresholds():
+    """ann_ivf_pq.cuh:1036-1046: defaults + coarse_search_dtype = CUDA_R_16F -> min_recall 0.86; CUDA_R_8I -> 0.1
+    ("experimental ... no guarantee of any recall if the data is not normalized")."""
+    n, d, nq, k = 4096, 64, 1024, 32
+    x, q = _gen(n, d, nq, seed=1234)
+    index = _build(x, n_lists=32, kmeans_trainset_fraction=1.0)
+    _, ti = oracle.brute_force_knn(q, x, k)
+    for dt, thr in ((np.float16, 0.86), (np.int8, 0.1)):
+        _, gi = _search(index, q, k, n_probes=20, coarse_search_dtype=dt)
+        assert oracle.recall(gi, ti) >= thr, (dt, oracle.recall(gi, ti))
