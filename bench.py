@@ -414,11 +414,14 @@ def main():
             variants.append({"lut": lut, "acc": acc, "ms_per_step": round(v_el * 1e3, 3), "qps": round(args.batch / v_el, 1),
                              "recall_at_10": round(v_rec, 4), "scan_kernel_ms_per_step": round(v_scan, 3),
                              "scan_launches_per_step": v_n})
-        # data-independent figure: the headline variant with the early stop switched off (CUVS_AMD_SCAN_DEBUG=8)
-        os.environ["CUVS_AMD_SCAN_DEBUG"] = "8"
+        # data-independent figure: the headline variant with every form of pruning off - no early stop
+        # (CUVS_AMD_SCAN_DEBUG=8), no filter stage (CUVS_AMD_PQ_SCAN2=0), no head phase: all 64 gathers of every row
+        prune_off = {"CUVS_AMD_SCAN_DEBUG": "8", "CUVS_AMD_PQ_SCAN2": "0", "CUVS_AMD_PQ_HEAD_PROBES": "0"}
+        os.environ.update(prune_off)
         _, s, _, _ = timed(make_step(args.lut, args.acc), 3, 1)
         early_stop_off_ms = round(s / 3, 3)
-        del os.environ["CUVS_AMD_SCAN_DEBUG"]
+        for key in prune_off:
+            del os.environ[key]
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
     # algorithmic bytes per step = sum over (query, probe) pairs of list_len * code bytes
