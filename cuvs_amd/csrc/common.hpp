@@ -81,6 +81,7 @@ struct resources {
   size_t lds_per_block    = 160 * 1024;
   size_t workspace_limit  = size_t(2) << 30;  // temporary distance tiles etc.
   std::vector<int> mg_devices;                // multi-GPU handle: participating devices
+  hipMemPool_t pool       = nullptr;          // the handle's own stream-ordered pool (scratch buffers stay cached in it)
 };
 
 inline resources* as_res(uintptr_t h)

@@ -19,7 +19,8 @@ std::string& last_error_text()
 void* device_alloc(resources& res, size_t bytes)
 {
   void* p = nullptr;
-  hipError_t e = hipMallocAsync(&p, bytes, res.stream);
+  hipError_t e = res.pool != nullptr ? hipMallocFromPoolAsync(&p, bytes, res.pool, res.stream)
+                                     : hipMallocAsync(&p, bytes, res.stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     // pool exhausted or unsupported: fall back to a synchronous allocation
@@ -128,11 +129,19 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
       long mb = atol(ws);
       if (mb > 0) r->workspace_limit = (size_t)mb << 20;
     }
-    // keep freed blocks in the pool: search allocates the same temporaries every batch
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+    // Scratch buffers come from a pool of the handle's own that keeps freed blocks (search allocates the same
+    // temporaries every batch). The device's default pool is left alone: raising ITS release threshold would keep
+    // gigabytes cached away from every other user of hipMallocAsync in the process. Freed with the handle.
+    hipMemPoolProps props{};
+    props.allocType     = hipMemAllocationTypePinned;
+    props.handleTypes   = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id   = dev;
+    if (hipMemPoolCreate(&r->pool, &props) == hipSuccess) {
       uint64_t thresh = UINT64_MAX;
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thresh);
+      (void)hipMemPoolSetAttribute(r->pool, hipMemPoolAttrReleaseThreshold, &thresh);
+    } else {
+      r->pool = nullptr;  // no private pools on this runtime: plain hipMallocAsync from the default pool
     }
     (void)hipGetLastError();
     *res = reinterpret_cast<uintptr_t>(r);
@@ -143,10 +152,9 @@ cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto* r = as_res(res);
-    if (r->owns_stream && r->stream) {
-      (void)hipStreamSynchronize(r->stream);
-      (void)hipStreamDestroy(r->stream);
-    }
+    (void)hipStreamSynchronize(r->stream);
+    if (r->pool != nullptr) (void)hipMemPoolDestroy(r->pool);
+    if (r->owns_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
   });
 }
@@ -204,7 +212,7 @@ cuvsError_t cuvsMultiGpuResourcesCreateWithDeviceIds(cuvsResources_t* res, DLMan
 {
   cuvsError_t e = cuvsResourcesCreate(res);
   if (e != CUVS_SUCCESS) return e;
-  return (cuvsError_t)translate_exceptions([=] {
+  e = (cuvsError_t)translate_exceptions([=] {
     CUVS_EXPECTS(device_ids != nullptr, "device_ids is null");
     auto& t = device_ids->dl_tensor;
     CUVS_EXPECTS(dtype_is(t.dtype, kDLInt, 32) && t.ndim == 1 && is_host_accessible(t),
@@ -213,6 +221,13 @@ cuvsError_t cuvsMultiGpuResourcesCreateWithDeviceIds(cuvsResources_t* res, DLMan
     auto* ids = static_cast<const int32_t*>(dl_data(t));
     for (int64_t i = 0; i < t.shape[0]; ++i) r->mg_devices.push_back(ids[i]);
   });
+  if (e != CUVS_SUCCESS) {  // do not leak the handle when validation fails (the error text is kept)
+    const std::string msg = last_error_text();
+    (void)cuvsResourcesDestroy(*res);
+    *res = 0;
+    last_error_text() = msg;
+  }
+  return e;
 }
 
 cuvsError_t cuvsMultiGpuResourcesDestroy(cuvsResources_t res) { return cuvsResourcesDestroy(res); }

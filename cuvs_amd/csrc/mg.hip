@@ -413,7 +413,10 @@ void mg_search(mg_index& idx, void* base_params, int search_mode, int64_t n_rows
     });
     return;
   }
-  // SHARDED (snmg.cuh:656-720): every GPU searches every batch, the host merges
+  // SHARDED (snmg.cuh:656-720): every GPU searches every batch, the host merges - straight into the output tensors,
+  // which the multi-GPU API defines as host tensors (mg_ivf_pq.h:152-190)
+  CUVS_EXPECTS(is_host_accessible(nb) && is_host_accessible(ds),
+               "multi-GPU sharded search: neighbors and distances must be host-accessible tensors");
   int64_t batch, n_batches;
   sharded_batches(nq, n_rows_per_batch, &batch, &n_batches);
   std::vector<int64_t> translation(n_ranks, 0);

@@ -69,6 +69,7 @@ inline void merge_on_host(const int64_t* part_i, const float* part_d, int n_rank
       for (int64_t j = 0; j < k; ++j) {
         const int64_t id = part_i[base + j];
         if (id < 0 || id == kNoNeighbor) continue;
+        if (part_d[base + j] != part_d[base + j]) continue;  // NaN: not a strict weak order for partial_sort
         cand.emplace_back(part_d[base + j], id + translation[r]);
       }
     }

@@ -8,7 +8,11 @@
 
 #include <cuvs/neighbors/refine.h>
 
+#include <algorithm>
 #include <cfloat>
+#include <cmath>
+#include <thread>
+#include <vector>
 
 namespace cuvs_amd {
 namespace {
@@ -93,7 +97,88 @@ void refine_typed(resources& res, const void* data, int64_t n, int64_t dim, cons
   HIP_TRY(hipGetLastError());
 }
 
+// ---- host tensors (reference: refine_host.hpp:353-462, dispatched from c/src/neighbors/refine.cpp when the tensors
+// live in host memory): the same arithmetic as refine_kernel - 64 strided fma partial sums per row, summed as a
+// butterfly - so that the host and device paths return identical results; queries are spread over host threads.
+inline float host_value(float v) { return v; }
+inline float host_value(__half v) { return __half2float(v); }
+inline float host_value(int8_t v) { return (float)v; }
+inline float host_value(uint8_t v) { return (float)v; }
+
+template <typename T>
+float host_strided(const T* a, const T* b, int64_t dim, int mode /*0 (a-b)^2, 1 a*b, 2 b*b*/)
+{
+  float p[64];
+  for (int l = 0; l < 64; ++l) p[l] = 0.f;
+  for (int64_t j = 0; j < dim; ++j) {
+    const float x = host_value(a[j]), y = host_value(b[j]);
+    if (mode == 0) { const float t = x - y; p[j & 63] = fmaf(t, t, p[j & 63]); }
+    else if (mode == 1) p[j & 63] = fmaf(x, y, p[j & 63]);
+    else p[j & 63] = fmaf(y, y, p[j & 63]);
+  }
+  for (int off = 32; off > 0; off >>= 1)
+    for (int i = 0; i < off; ++i) p[i] = p[i] + p[i + off];
+  return p[0];
+}
+
+template <typename T>
+void refine_host_typed(const void* data_v, int64_t n, int64_t dim, const void* queries_v, int64_t m, const int64_t* cand,
+                       int n_cand, int k, int metric, int64_t* out_i, float* out_d)
+{
+  const T* data    = static_cast<const T*>(data_v);
+  const T* queries = static_cast<const T*>(queries_v);
+  const bool ip = metric == M_InnerProduct, cosm = metric == M_CosineExpanded;
+  const unsigned n_thr = (unsigned)std::max<int64_t>(1, std::min<int64_t>(m, std::max(1u, std::thread::hardware_concurrency())));
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < n_thr; ++t) {
+    pool.emplace_back([=] {
+      std::vector<std::pair<float, int64_t>> buf((size_t)n_cand);
+      for (int64_t q = t; q < m; q += n_thr) {
+        const T* qv = queries + q * dim;
+        const float qn = cosm ? sqrtf(host_strided(qv, qv, dim, 2)) : 0.f;
+        int cnt = 0;
+        for (int c = 0; c < n_cand; ++c) {
+          const int64_t id = cand[q * n_cand + c];
+          if (id < 0 || id >= n) continue;
+          const T* row = data + id * dim;
+          float v = host_strided(qv, row, dim, (ip || cosm) ? 1 : 0);
+          if (cosm) v = 1.0f - v / (qn * sqrtf(host_strided(qv, row, dim, 2)));
+          buf[cnt++] = {ip ? -v : v, id};  // sort key: smaller is better
+        }
+        std::sort(buf.begin(), buf.begin() + cnt);  // (distance, id) tuples, refine_host.hpp:430-460
+        for (int j = 0; j < k; ++j) {
+          if (j < cnt) {
+            float d = ip ? -buf[j].first : buf[j].first;
+            if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d);
+            out_i[q * k + j] = buf[j].second;
+            out_d[q * k + j] = d;
+          } else {
+            out_i[q * k + j] = INT64_MAX;
+            out_d[q * k + j] = FLT_MAX;
+          }
+        }
+      }
+    });
+  }
+  for (auto& th : pool) th.join();
+}
+
 }  // namespace
+
+void refine_host(const void* data, elem_t et, int64_t n, int64_t dim, const void* queries, int64_t m, const int64_t* cand,
+                 int n_cand, int k, int metric, int64_t* out_i, float* out_d)
+{
+  if (m == 0) return;
+  CUVS_EXPECTS(k <= n_cand, "refine: k (%d) must not exceed the number of candidates (%d)", k, n_cand);
+  CUVS_EXPECTS(metric_is_l2(metric) || metric == M_InnerProduct || metric == M_CosineExpanded,
+               "refine: unsupported metric %d", metric);
+  switch (et) {
+    case elem_t::f32: refine_host_typed<float>(data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+    case elem_t::f16: refine_host_typed<__half>(data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+    case elem_t::i8: refine_host_typed<int8_t>(data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+    case elem_t::u8: refine_host_typed<uint8_t>(data, n, dim, queries, m, cand, n_cand, k, metric, out_i, out_d); break;
+  }
+}
 
 void refine(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, const void* queries, int64_t m,
             const int64_t* cand, int n_cand, int k, int metric, int64_t* out_i, float* out_d)
@@ -128,10 +213,12 @@ extern "C" cuvsError_t cuvsRefine(cuvsResources_t res_h, DLManagedTensor* datase
     auto& cs = candidates_tensor->dl_tensor;
     auto& is = indices_tensor->dl_tensor;
     auto& dd = distances_tensor->dl_tensor;
-    CUVS_EXPECTS(is_device_accessible(ds) && is_device_accessible(qs) && is_device_accessible(cs) &&
-                   is_device_accessible(is) && is_device_accessible(dd),
-                 "cuvsRefine: all tensors must be device accessible in this build (the reference's host path is "
-                 "restated in oracle/ only)");
+    // c/src/neighbors/refine.cpp: all tensors in device memory -> the device path, all in host memory -> refine_host
+    const bool all_dev  = is_device_accessible(ds) && is_device_accessible(qs) && is_device_accessible(cs) &&
+                          is_device_accessible(is) && is_device_accessible(dd);
+    const bool all_host = is_host_accessible(ds) && is_host_accessible(qs) && is_host_accessible(cs) &&
+                          is_host_accessible(is) && is_host_accessible(dd);
+    CUVS_EXPECTS(all_dev || all_host, "cuvsRefine: the tensors must be either all in device memory or all in host memory");
     CUVS_EXPECTS(ds.ndim == 2 && qs.ndim == 2 && cs.ndim == 2 && is.ndim == 2 && dd.ndim == 2, "tensors must be 2-D");
     CUVS_EXPECTS(is_c_contiguous(ds) && is_c_contiguous(qs) && is_c_contiguous(cs) && is_c_contiguous(is) &&
                    is_c_contiguous(dd),
@@ -143,6 +230,12 @@ extern "C" cuvsError_t cuvsRefine(cuvsResources_t res_h, DLManagedTensor* datase
     CUVS_EXPECTS(cs.shape[0] == qs.shape[0] && is.shape[0] == qs.shape[0] && dd.shape[0] == qs.shape[0] &&
                    is.shape[1] == dd.shape[1],
                  "shape mismatch");
+    if (!all_dev) {
+      refine_host(dl_data(ds), elem_of(ds.dtype), ds.shape[0], ds.shape[1], dl_data(qs), qs.shape[0],
+                  static_cast<const int64_t*>(dl_data(cs)), (int)cs.shape[1], (int)is.shape[1], (int)metric,
+                  static_cast<int64_t*>(dl_data(is)), static_cast<float*>(dl_data(dd)));
+      return;
+    }
     refine(res, dl_data(ds), elem_of(ds.dtype), ds.shape[0], ds.shape[1], dl_data(qs), qs.shape[0],
            static_cast<const int64_t*>(dl_data(cs)), (int)cs.shape[1], (int)is.shape[1], (int)metric,
            static_cast<int64_t*>(dl_data(is)), static_cast<float*>(dl_data(dd)));

@@ -20,9 +20,15 @@ struct file_writer {
     CUVS_EXPECTS(name != nullptr, "filename is null");
     f = fopen(name, "wb");
     CUVS_EXPECTS(f != nullptr, "Cannot open file %s", name);
-    raw("CUVSAMD1", 8);
-    scalar<uint32_t>(kind);
-    scalar<uint32_t>(kSerialVersion);
+    try {  // a constructor that throws never runs the destructor: close the file here
+      raw("CUVSAMD1", 8);
+      scalar<uint32_t>(kind);
+      scalar<uint32_t>(kSerialVersion);
+    } catch (...) {
+      fclose(f);
+      f = nullptr;
+      throw;
+    }
   }
   ~file_writer() { if (f) fclose(f); }
   void raw(const void* p, size_t n) { CUVS_EXPECTS(fwrite(p, 1, n, f) == n, "short write"); }
@@ -47,12 +53,18 @@ struct file_reader {
     CUVS_EXPECTS(name != nullptr, "filename is null");
     f = fopen(name, "rb");
     CUVS_EXPECTS(f != nullptr, "Cannot open file %s", name);
-    char magic[8];
-    raw(magic, 8);
-    CUVS_EXPECTS(memcmp(magic, "CUVSAMD1", 8) == 0, "%s is not a cuvs_amd index file", name);
-    uint32_t k = scalar<uint32_t>(), v = scalar<uint32_t>();
-    CUVS_EXPECTS(k == kind, "index kind mismatch in %s (file %u, expected %u)", name, k, kind);
-    CUVS_EXPECTS(v == kSerialVersion, "serialization version mismatch: got %u, expected %u", v, kSerialVersion);
+    try {  // a constructor that throws never runs the destructor: close the file here
+      char magic[8];
+      raw(magic, 8);
+      CUVS_EXPECTS(memcmp(magic, "CUVSAMD1", 8) == 0, "%s is not a cuvs_amd index file", name);
+      uint32_t k = scalar<uint32_t>(), v = scalar<uint32_t>();
+      CUVS_EXPECTS(k == kind, "index kind mismatch in %s (file %u, expected %u)", name, k, kind);
+      CUVS_EXPECTS(v == kSerialVersion, "serialization version mismatch: got %u, expected %u", v, kSerialVersion);
+    } catch (...) {
+      fclose(f);
+      f = nullptr;
+      throw;
+    }
   }
   ~file_reader() { if (f) fclose(f); }
   void raw(void* p, size_t n) { CUVS_EXPECTS(fread(p, 1, n, f) == n, "unexpected end of file"); }

@@ -40,3 +40,48 @@ def test_refine_all_rows_is_exact_search():
     td, ti = oracle.exact_knn(q, x, 10)
     assert oracle.recall(gi.cpu().numpy(), ti) == 1.0
     np.testing.assert_allclose(gd.cpu().numpy(), td, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product", "cosine"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8])
+def test_refine_host_tensors(metric, dtype):
+    """All tensors in host memory -> the reference dispatches to refine_host (c/src/neighbors/refine.cpp,
+    refine_host.hpp:353-462); here the same arithmetic as the device kernel runs on host threads: identical results."""
+    import torch
+    from cuvs_amd.neighbors import refine
+
+    rng = np.random.default_rng(3)
+    if dtype == np.int8:
+        x = rng.integers(-30, 30, size=(1500, 48)).astype(dtype)
+        q = rng.integers(-30, 30, size=(40, 48)).astype(dtype)
+    else:
+        x = rng.standard_normal((1500, 48)).astype(dtype)
+        q = rng.standard_normal((40, 48)).astype(dtype)
+    cand = rng.integers(0, 1500, size=(40, 50)).astype(np.int64)
+    cand[0, 0] = -1
+    hd, hi = refine(x, q, cand, k=10, metric=metric)                      # numpy in, numpy out: host path
+    gd, gi = refine(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(cand).cuda(), k=10, metric=metric)
+    torch.cuda.synchronize()
+    assert isinstance(hi, np.ndarray)
+    assert (hi == gi.cpu().numpy()).all() and (hd == gd.cpu().numpy()).all()
+    od, oi = oracle.refine(x.astype(np.float32), q.astype(np.float32), cand, 10, metric=metric)
+    assert (hi == oi).all() and (hd == od).all()
+
+
+def test_refine_mixed_memory_is_an_error():
+    import ctypes as C
+
+    import torch
+    import cuvs_amd
+    from cuvs_amd._lib import Tensor, lib
+
+    res = cuvs_amd.common.Resources()
+    x = np.zeros((10, 4), np.float32)
+    q = torch.zeros((2, 4), device="cuda")
+    cand = np.zeros((2, 3), np.int64)
+    oi, od = np.zeros((2, 2), np.int64), np.zeros((2, 2), np.float32)
+    ts = [Tensor(t) for t in (x, q, cand, oi, od)]
+    rc = lib().cuvsRefine(res.get_c_obj(), ts[0].ptr, ts[1].ptr, ts[2].ptr, C.c_int(0), ts[3].ptr, ts[4].ptr)
+    assert rc == 0  # CUVS_ERROR
+    lib().cuvsGetLastErrorText.restype = C.c_char_p
+    assert b"all in device memory or all in host memory" in lib().cuvsGetLastErrorText()
