@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <vector>
 
 namespace cuvs_amd {
 
@@ -40,6 +41,62 @@ __global__ void apply_filter_kernel(float* d, int64_t m, int64_t n_tile, int64_t
     bool keep   = (bits[bit >> 5] >> (bit & 31)) & 1u;
     if (!keep) d[r * ldo + c] = worst;
   }
+}
+
+// ---- running-threshold path for datasets wider than one column tile (knn_brute_force.cuh:62-326 selects k per tile
+// and merges; that re-reads every distance tile four times in select_k). After the first tile a row's current k-th
+// value bounds its final k-th value, so a later tile only needs ONE pass: everything strictly better than the
+// threshold is appended - in column order - behind the row's current top-k, and a small select_k over (k + appended)
+// gives the new top-k. An element equal to the threshold cannot enter (ties go to the earlier column), so `<` is
+// exact; appended elements all have larger column ids than the current winners, so position order == column order
+// and the result is identical to the per-tile select + merge.
+constexpr int kBfCap = 1024;  // appended candidates per row and tile; more (adversarial column order) -> select_k on the tile
+
+// one wave per row: 64 columns per step, ordered compaction by ballot
+__global__ __launch_bounds__(256) void bf_filter_append_kernel(const float* __restrict__ tile, int64_t m, int64_t nc,
+                                                               int64_t ldo, int64_t col0, int k, bool select_min,
+                                                               float* __restrict__ buf_v, int64_t* __restrict__ buf_i,
+                                                               int* __restrict__ overflow)
+{
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  const int lane     = threadIdx.x & 63;
+  const int64_t ldb  = k + kBfCap;
+  float* bv          = buf_v + row * ldb;
+  int64_t* bi        = buf_i + row * ldb;
+  const float thr    = bv[k - 1];  // current k-th value (worst value while fewer than k are known)
+  const float* r     = tile + row * ldo;
+  int cnt            = 0;
+  for (int64_t c0 = 0; c0 < nc; c0 += 256) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t c = c0 + u * 64 + lane;
+      v[u] = c < nc ? r[c] : (select_min ? FLT_MAX : -FLT_MAX);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool take = select_min ? v[u] < thr : v[u] > thr;
+      const unsigned long long mk = __ballot(take);
+      if (mk == 0ull) continue;
+      const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+      if (take && pos < kBfCap) { bv[k + pos] = v[u]; bi[k + pos] = col0 + c0 + u * 64 + lane; }
+      cnt += (int)__popcll(mk);
+    }
+  }
+  if (cnt > kBfCap) { if (lane == 0) *overflow = 1; cnt = kBfCap; }
+  // unused slots lose: worst value, invalid id
+  for (int j = cnt + lane; j < kBfCap; j += 64) { bv[k + j] = select_min ? FLT_MAX : -FLT_MAX; bi[k + j] = INT64_MAX; }
+}
+
+__global__ void bf_store_topk_kernel(const float* __restrict__ v, const int64_t* __restrict__ i, int64_t m, int k,
+                                     float* __restrict__ buf_v, int64_t* __restrict__ buf_i)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * k) return;
+  const int64_t row = t / k, j = t % k, ldb = k + kBfCap;
+  buf_v[row * ldb + j] = v[t];
+  buf_i[row * ldb + j] = i[t];
 }
 
 template <typename T>
@@ -81,15 +138,95 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   }
   dev_buf<float> tile(res, (size_t)m_tile * std::min<int64_t>(n_tile, n));
   const int64_t ldo = std::min<int64_t>(n_tile, n);
+  // more than one column tile: the running-threshold path (above) unless switched off or k is too large for it
+  // (a single wide tile - e.g. 1000 queries x 100k rows - is cut into four as well: three of its four quarters then
+  // cost one pass instead of select_k's four, and the GEMM of a quarter overlaps the select of the previous one)
+  const bool running = (n_ct > 1 || n >= 65536) && k <= 1024 && getenv("CUVS_AMD_BF_NO_THRESHOLD") == nullptr;
   dev_buf<float> part_v;
   dev_buf<int64_t> part_i;
-  if (n_ct > 1) {
+  const float worst = select_min ? FLT_MAX : -FLT_MAX;
+
+  // ---- running-threshold path, pipelined: the distance GEMM of tile ct + 1 (compute-bound, the handle's stream) runs
+  // beside the filter + small select of tile ct (memory-bound, a helper stream); two half-width tiles alternate.
+  std::vector<char> redo((size_t)((m + m_tile - 1) / m_tile), running ? 0 : 1);  // row tiles for the per-tile select path
+  if (running) {
+    const int64_t nt2   = std::max<int64_t>(128, std::min<int64_t>((n_tile / 2) / 128 * 128, round_up((n + 3) / 4, 128)));
+    const int64_t n_ct2 = (n + nt2 - 1) / nt2;
+    const int64_t ld2   = std::min<int64_t>(nt2, n);
+    float* tiles[2]     = {tile.data(), tile.data() + (size_t)m_tile * ld2};
+    dev_buf<float> buf_v(res, (size_t)m_tile * (k + kBfCap)), cur_v(res, (size_t)m_tile * k);
+    dev_buf<int64_t> buf_i(res, (size_t)m_tile * (k + kBfCap)), cur_i(res, (size_t)m_tile * k);
+    const size_t n_row_tiles = redo.size();
+    dev_buf<int> ovf(res, n_row_tiles);  // one flag per row tile, read back once at the end
+    HIP_TRY(hipMemsetAsync(ovf.data(), 0, ovf.bytes(), res.stream));
+    if (res.aux_stream == nullptr) {  // the helper stream and its events live with the handle
+      HIP_TRY(hipStreamCreateWithFlags(&res.aux_stream, hipStreamNonBlocking));
+      for (auto& ev : res.aux_events) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    hipStream_t sb = res.aux_stream;
+    hipEvent_t* eg = res.aux_events;
+    hipEvent_t* ed = res.aux_events + 2;
+    hipEvent_t e0  = res.aux_events[4];
+    resources rb = res;
+    rb.stream    = sb;
+    HIP_TRY(hipEventRecord(e0, res.stream));  // the helper stream starts behind everything queued so far (norms, allocations)
+    HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
+    for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
+      const int64_t mr = std::min(m_tile, m - r0);
+      int* ovf_r       = ovf.data() + r0 / m_tile;
+      for (int64_t ct = 0; ct < n_ct2; ++ct) {
+        const int b      = (int)(ct & 1);
+        const int64_t c0 = ct * nt2, nc = std::min(nt2, n - c0);
+        if (ct >= 2) HIP_TRY(hipStreamWaitEvent(res.stream, ed[b], 0));  // the consumer is done with this tile buffer
+        pairwise_distance<T, T>(res, queries + r0 * ldq, mr, ldq, data + c0 * idx.ld, nc, idx.ld, idx.dim,
+                                qn.data() ? qn.data() + r0 : nullptr, idx.norms.data() ? idx.norms.data() + c0 : nullptr,
+                                metric, tiles[b], ld2);
+        if (filter_type != NO_FILTER) {
+          const int64_t total = mr * nc;
+          hipLaunchKernelGGL(apply_filter_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 22)), dim3(256), 0,
+                             res.stream, tiles[b], mr, nc, ld2, c0, r0, n, filter_bits, filter_type == BITMAP, worst);
+        }
+        HIP_TRY(hipEventRecord(eg[b], res.stream));
+        HIP_TRY(hipStreamWaitEvent(sb, eg[b], 0));
+        const bool last = ct == n_ct2 - 1;
+        float* ov       = last ? distances + r0 * k : cur_v.data();
+        int64_t* oi     = last ? neighbors + r0 * k : cur_i.data();
+        if (ct == 0) {  // the first tile's top-k IS the current top-k: straight into the head of every row's buffer
+          select_k<int64_t, int64_t>(rb, tiles[b], nullptr, mr, nc, ld2, k, buf_v.data(), buf_i.data(), select_min, c0,
+                                     k + kBfCap, 0);
+        } else {
+          hipLaunchKernelGGL(bf_filter_append_kernel, dim3((unsigned)((mr + 3) / 4)), dim3(256), 0, sb, tiles[b], mr, nc, ld2,
+                             c0, k, select_min, buf_v.data(), buf_i.data(), ovf_r);
+          select_k<int64_t, int64_t>(rb, buf_v.data(), buf_i.data(), mr, k + kBfCap, k + kBfCap, k, ov, oi, select_min);
+          if (!last)  // the new top-k becomes the head of every row's buffer for the next tile
+            hipLaunchKernelGGL(bf_store_topk_kernel, dim3(grid_blocks(mr * k, 256)), dim3(256), 0, sb, cur_v.data(),
+                               cur_i.data(), mr, k, buf_v.data(), buf_i.data());
+        }
+        HIP_TRY(hipEventRecord(ed[b], sb));
+      }
+      HIP_TRY(hipStreamWaitEvent(res.stream, ed[(n_ct2 - 1) & 1], 0));  // results are ordered on the handle's stream
+      if (r0 + m_tile < m) {  // the next row tile reuses the buffers of the helper stream: let it drain first
+        HIP_TRY(hipEventRecord(e0, sb));
+        HIP_TRY(hipStreamWaitEvent(res.stream, e0, 0));
+      }
+    }
+    // a row with more than kBfCap better elements in one tile (columns arriving in improving order) had its candidates
+    // cut: such row tiles are redone by the per-tile select path below. One host round trip per search, only to read
+    // the flags - the common case leaves the results where they are.
+    std::vector<int> h_ovf(n_row_tiles, 0);
+    HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+    HIP_TRY(hipStreamSynchronize(res.stream));
+    for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
+  }
+  bool any_redo = false;
+  for (char c : redo) any_redo = any_redo || c;
+  if (any_redo && n_ct > 1) {
     part_v = dev_buf<float>(res, (size_t)m_tile * n_ct * k);
     part_i = dev_buf<int64_t>(res, (size_t)m_tile * n_ct * k);
   }
-  const float worst = select_min ? FLT_MAX : -FLT_MAX;
 
   for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
+    if (!redo[(size_t)(r0 / m_tile)]) continue;
     const int64_t mr = std::min(m_tile, m - r0);
     for (int64_t ct = 0; ct < n_ct; ++ct) {
       const int64_t c0 = ct * n_tile;

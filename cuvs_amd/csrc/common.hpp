@@ -82,6 +82,8 @@ struct resources {
   size_t workspace_limit  = size_t(2) << 30;  // temporary distance tiles etc.
   std::vector<int> mg_devices;                // multi-GPU handle: participating devices
   hipMemPool_t pool       = nullptr;          // the handle's own stream-ordered pool (scratch buffers stay cached in it)
+  hipStream_t aux_stream  = nullptr;          // helper stream + events for two-stream pipelines (brute force), made on first use
+  hipEvent_t aux_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 inline resources* as_res(uintptr_t h)

@@ -153,6 +153,11 @@ cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
   return (cuvsError_t)translate_exceptions([=] {
     auto* r = as_res(res);
     (void)hipStreamSynchronize(r->stream);
+    if (r->aux_stream != nullptr) {
+      (void)hipStreamSynchronize(r->aux_stream);
+      (void)hipStreamDestroy(r->aux_stream);
+      for (auto& e : r->aux_events) if (e != nullptr) (void)hipEventDestroy(e);
+    }
     if (r->pool != nullptr) (void)hipMemPoolDestroy(r->pool);
     if (r->owns_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;

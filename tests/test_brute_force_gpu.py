@@ -149,3 +149,33 @@ def test_large_k():
     gd, gi = _run(x, qq, 3000, "sqeuclidean")
     od, oi = oracle.brute_force_knn(qq, x, 3000)
     assert (gi == oi).all() and (gd == od).all()
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+@pytest.mark.parametrize("adversarial", [False, True])
+def test_running_threshold_path(monkeypatch, metric, adversarial):
+    """Datasets wider than one column tile: after the first tile only elements better than a row's current k-th value
+    are kept (one pass per tile instead of select_k's four). Identical to the oracle - also when the columns arrive
+    in improving order, so that every tile overflows the candidate buffer and falls back to select_k on the tile -
+    and identical to the per-tile select + merge it replaces."""
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import brute_force
+
+    monkeypatch.setenv("CUVS_AMD_WORKSPACE_MB", "1")  # 40 rows x 6400-column tiles
+    res = cuvs_amd.common.Resources()
+    x, qq = _gen(40000, 16, 40, seed=23)
+    if adversarial:  # rows sorted by decreasing distance to the first query: every later tile is better than all before
+        key = ((x - qq[0]) ** 2).sum(1) if metric == "sqeuclidean" else -(x @ qq[0])
+        x = np.ascontiguousarray(x[np.argsort(-key)])
+    x[100] = x[30000]  # exact ties across tiles: the earlier column must win
+    tx, tq = torch.from_numpy(x).cuda(), torch.from_numpy(qq).cuda()
+    idx = brute_force.build(tx, metric=metric, resources=res)
+    d, i = brute_force.search(idx, tq, 12, resources=res)
+    res.sync()
+    od, oi = oracle.brute_force_knn(qq, x, 12, metric=metric)
+    assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
+    monkeypatch.setenv("CUVS_AMD_BF_NO_THRESHOLD", "1")
+    d2, i2 = brute_force.search(idx, tq, 12, resources=res)
+    res.sync()
+    assert torch.equal(i, i2) and torch.equal(d, d2)
