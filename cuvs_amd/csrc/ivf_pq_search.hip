@@ -1042,6 +1042,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
           const float d0 = q[0][g * EQ + j] - p0;
           const float d1 = q[1][g * EQ + j] - p1;
           sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+          if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], false);  // L2 only here: the unsigned fp_8bit<5, false>
         }
         *(typename XL::wr_ptr)(uintptr_t)((uint32_t)(t * 64 + lane) * FL::kRow + s * 16 + g * 8) = acc_t::pack(sc);
       }
@@ -1191,6 +1192,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
             const float d0 = q[0][j] - p0;
             const float d1 = q[1][j] - p1;
             sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+            if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
           }
           XL::store(s, t * 64 + lane, acc_t::pack(sc));
           __builtin_amdgcn_sched_barrier(0);
@@ -1687,7 +1689,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     }
     // the tail phase (warm bounds) of the common configuration runs pq_scan2_kernel on items of 2 * qpb pairs
     // (fp16 LUT only: the fp32-LUT instance of the kernel does not fit 128 VGPRs)
-    bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && lut_half && qpb == 4 && !lut_fp8;  // (k <= 64 excludes the non-fused path)
+    bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && lut_half && qpb == 4;  // (k <= 64 excludes the non-fused path)
     if (const char* e = getenv("CUVS_AMD_PQ_SCAN2")) use2 = use2 && atoi(e) != 0;
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data(), (int)idx.n_lists, use2 ? 2 * qpb : qpb);
