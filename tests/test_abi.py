@@ -98,3 +98,10 @@ def test_headers_are_valid_c99_and_cxx17(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
     subprocess.check_call(["g++", "-std=c++17", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+
+
+def test_cpp_surface_header_compiles(tmp_path):
+    """include/cuvs_amd/neighbors.hpp (cuvs::neighbors::* over the C ABI) is valid C++17 without HIP or RAFT headers."""
+    src = tmp_path / "n.cpp"
+    src.write_text("#include <cuvs_amd/neighbors.hpp>\nint main() { cuvs::neighbors::ivf_pq::search_params p; return p.n_probes == 20 ? 0 : 1; }\n")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
