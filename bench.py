@@ -202,6 +202,8 @@ def extra_c2(res, dev):
     q = gen_rows(nq, 128, 4321, dev)
     t0 = time.time()
     idx = ivf_flat.build(ivf_flat.IndexParams(n_lists=4096, kmeans_trainset_fraction=0.1), x, resources=res)
+    if sharded:
+        ivf_pq_sharded.attach_comm(index, comm)  # head-phase bounds are all-reduced (min) before the tail phase
     res.sync()
     build_s = time.time() - t0
     sp = ivf_flat.SearchParams(n_probes=64)
@@ -235,6 +237,8 @@ def extra_c4(res, dev, rows, latent):
     gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=1, out=q)
     t0 = time.time()
     idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res)
+    if sharded:
+        ivf_pq_sharded.attach_comm(index, comm)  # head-phase bounds are all-reduced (min) before the tail phase
     res.sync()
     build_s = time.time() - t0
     sp = cagra.SearchParams(itopk_size=64)
@@ -331,6 +335,8 @@ def main():
         for r0 in range(0, args.rows, step_rows):
             r1 = min(args.rows, r0 + step_rows)
             ivf_pq_sharded.extend(index, data[r0:r1], torch.arange(r0, r1, dtype=torch.int64, device=dev), resources=res)
+    if sharded:
+        ivf_pq_sharded.attach_comm(index, comm)  # head-phase bounds are all-reduced (min) before the tail phase
     res.sync()
     build_s = time.time() - t0
     log(f"built IVF-PQ index in {build_s:.1f}s ({len(index)} rows on this rank)")

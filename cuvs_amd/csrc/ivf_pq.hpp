@@ -51,6 +51,7 @@ struct ivf_pq_index {
   // only the lists it owns - list L belongs to rank L % shard_world. extend() drops rows of foreign lists, search()
   // scans only owned probes; the per-rank top-k lists are all-gathered and merged. shard_world == 1: not sharded.
   int shard_rank = 0, shard_world = 1;
+  void* shard_comm = nullptr;  // cuvsAmdShardComm* (not owned): all-reduce of the k-th bounds between the scan phases
   bool owns(uint32_t L) const { return shard_world <= 1 || (int)(L % (uint32_t)shard_world) == shard_rank; }
 
   static float scale(elem_t et)  // kDivisor(T) / kDivisor(float), ann_utils.cuh:134-160
@@ -88,6 +89,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
 void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data, elem_t et, int64_t n, uint32_t* out_labels,
                       uint8_t* out_codes);
 // [n_take, ceil(pq_dim*pq_bits/8)] contiguous bit-packed codes of list `label` starting at `offset`
+// shard_comm.hip: in-place min over all ranks of `count` order-preserving bound keys, on the stream of `res`
+void shard_allreduce_min_u32(resources& res, void* comm, uint32_t* keys, size_t count);
+
 void ivf_pq_unpack_list(resources& res, const ivf_pq_index& idx, uint32_t label, uint32_t offset,
                         uint32_t n_take, uint8_t* out);
 

@@ -1740,6 +1740,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       a.xcd_ticket = tickets.data();
       a.item_begin = nullptr;                        a.item_end = item_off.data() + idx.n_lists;
       launch(a);  // head phase: the nearest probes, cold bounds
+      // list-sharded index with a communicator: every rank continues with the bound of the query's globally nearest
+      // probe (one all-reduce of nq keys), not only the rank that owns that probe
+      if (idx.shard_comm != nullptr) shard_allreduce_min_u32(res, idx.shard_comm, query_kth.data(), (size_t)nq);
       a.xcd_ticket = tickets.data() + 8 * 32;
       a.item_begin = item_off.data() + idx.n_lists;  a.item_end = item_off.data() + 2 * idx.n_lists;
       if (!use2)          launch(a);  // tail phase: warm bounds

@@ -32,6 +32,7 @@ struct rccl_api {
   decltype(&ncclCommInitRank) comm_init_rank     = nullptr;
   decltype(&ncclCommDestroy) comm_destroy        = nullptr;
   decltype(&ncclAllGather) all_gather            = nullptr;
+  decltype(&ncclAllReduce) all_reduce            = nullptr;
   decltype(&ncclGetErrorString) get_error_string = nullptr;
 };
 
@@ -50,9 +51,11 @@ const rccl_api& rccl()
     api.comm_init_rank   = reinterpret_cast<decltype(api.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
     api.comm_destroy     = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
     api.all_gather       = reinterpret_cast<decltype(api.all_gather)>(dlsym(h, "ncclAllGather"));
+    api.all_reduce       = reinterpret_cast<decltype(api.all_reduce)>(dlsym(h, "ncclAllReduce"));
     api.get_error_string = reinterpret_cast<decltype(api.get_error_string)>(dlsym(h, "ncclGetErrorString"));
   });
-  CUVS_EXPECTS(api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather && api.get_error_string,
+  CUVS_EXPECTS(api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather && api.all_reduce &&
+                 api.get_error_string,
                "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
   return api;
 }
@@ -122,6 +125,15 @@ void shard_all_gather_topk(resources& res, cuvsAmdShardComm& c, const float* ld,
   HIP_TRY(hipGetLastError());
 }
 
+void shard_allreduce_min_u32(resources& res, void* comm, uint32_t* keys, size_t count)
+{
+  auto* c = static_cast<cuvsAmdShardComm*>(comm);
+  if (c == nullptr || count == 0) return;  // (a one-rank communicator still makes the call: that is what the tests run)
+  profile_begin(res, "shard_all_reduce");
+  RCCL_TRY(rccl().all_reduce(keys, keys, count, ncclUint32, ncclMin, c->comm, res.stream));
+  profile_end(res, "shard_all_reduce");
+}
+
 }  // namespace cuvs_amd
 
 using namespace cuvs_amd;
@@ -179,6 +191,18 @@ cuvsError_t cuvsAmdIvfPqSetListShard(cuvsIvfPqIndex_t index, int rank, int world
     auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
     CUVS_EXPECTS(idx.size == 0, "list shard: the index already holds rows (build with add_data_on_build = false)");
     idx.shard_rank = rank; idx.shard_world = world;
+  });
+}
+
+cuvsError_t cuvsAmdIvfPqSetShardComm(cuvsIvfPqIndex_t index, cuvsAmdShardComm_t comm)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(index != nullptr && index->addr != 0, "IVF-PQ index is not built");
+    auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
+    CUVS_EXPECTS(comm == nullptr || (comm->world == idx.shard_world && comm->rank == idx.shard_rank),
+                 "shard communicator (rank %d of %d) does not match the index's list shard (rank %d of %d)",
+                 comm ? comm->rank : 0, comm ? comm->world : 0, idx.shard_rank, idx.shard_world);
+    idx.shard_comm = comm;
   });
 }
 

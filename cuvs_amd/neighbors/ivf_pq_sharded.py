@@ -78,6 +78,13 @@ def build(index_params, trainset, rank, world, resources=None):
     return index
 
 
+def attach_comm(index, comm):
+    """Lets the shard's searches all-reduce the per-query bounds between their two scan phases (collective: every rank
+    must then run the same searches). Results do not change, per-rank pruning does."""
+    check(lib().cuvsAmdIvfPqSetShardComm(index._p, comm._c if comm is not None else None))
+    index._shard_comm = comm  # keep it alive
+
+
 def extend(index, rows, ids, resources=None):
     """Adds the rows that fall into this rank's lists (the others are dropped); ids = global row ids."""
     return ivf_pq.extend(index, rows, ids, resources=resources)

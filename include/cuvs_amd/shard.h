@@ -40,6 +40,13 @@ CUVS_EXPORT cuvsError_t cuvsAmdShardCommRank(cuvsAmdShardComm_t comm, int* rank,
  * list L is owned by rank L % world. Call before cuvsIvfPqExtend. */
 CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetListShard(cuvsIvfPqIndex_t index, int rank, int world);
 
+/* Optional: gives the shard's searches access to the communicator. cuvsIvfPqSearch then all-reduces (min) the per-query
+ * k-th bounds between its two scan phases - one ncclAllReduce of n_queries uint32 per batch - so that every rank prunes
+ * with the bound of the query's globally nearest probe, whoever owns it. Results do not depend on it (bounds only
+ * prune); without it a rank that owns none of a query's near lists scans its probes with a cold bound. Collective:
+ * every rank must make the same searches. comm = NULL detaches. */
+CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetShardComm(cuvsIvfPqIndex_t index, cuvsAmdShardComm_t comm);
+
 /* Collective on the stream of `res`. local_distances [n_queries, k] float32 and local_neighbors [n_queries, k] int64
  * (device; the output of the rank's cuvsIvfPqSearch, invalid slots = FLT_MAX / INT64_MAX as the reference pads them) ->
  * distances / neighbors [n_queries, k] (device): the k best of the world * k candidates of every query, ordered by

@@ -32,6 +32,15 @@ def test_world_size_one_all_gather_is_identity():
     d1, i1 = sh.search(sp, index, qt, 10, comm, resources=res)
     res.sync()
     assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    # with the communicator attached, a batch large enough for the two-phase schedule all-reduces its bounds in between
+    sh.attach_comm(index, comm)
+    qb = torch.from_numpy(np.tile(q, (2, 1))).cuda()  # 400 queries: head phase + ncclAllReduce + tail phase
+    sp2 = ivf_pq.SearchParams(n_probes=12)
+    d2, i2 = sh.search(sp2, index, qb, 10, comm, resources=res)
+    sh.attach_comm(index, None)
+    d3, i3 = ivf_pq.search(sp2, index, qb, 10, resources=res)
+    res.sync()
+    assert torch.equal(i2, i3) and torch.equal(d2, d3)
     comm.close()
 
 
