@@ -99,6 +99,59 @@ __global__ void bf_store_topk_kernel(const float* __restrict__ v, const int64_t*
   buf_i[row * ldb + j] = i[t];
 }
 
+// ---- fused threshold path (round 2): beyond the first column tile the distance tile is never written. The MFMA kernel
+// compares every element with the row's current k-th value in its epilogue and appends the few that beat it
+// (pairwise_threshold_append); this kernel then sorts a row's k + appended entries by (value, source id) - the order
+// of the tiled path: ties go to the smaller id - and keeps the first k. Column tiles grow geometrically: after `seen`
+// columns a further `seen * cap / (4 k)` are expected to append cap / 4 per row.
+__global__ __launch_bounds__(256) void bf_merge_appended_kernel(float* __restrict__ buf_v, int64_t* __restrict__ buf_i,
+                                                                const int* __restrict__ cnt, int k, bool select_min,
+                                                                int* __restrict__ overflow)
+{
+  __shared__ float sv[2 * kBfCap];
+  __shared__ int64_t si[2 * kBfCap];
+  const int64_t row = blockIdx.x;
+  int c             = cnt[row];
+  if (c == 0) return;  // workgroup-uniform
+  if (c > kBfCap) { if (threadIdx.x == 0) *overflow = 1; c = kBfCap; }
+  const int total   = k + c;
+  int P             = 1;
+  while (P < total) P <<= 1;
+  const int64_t ldb = k + kBfCap;
+  const float worst = select_min ? FLT_MAX : -FLT_MAX;
+  for (int t = threadIdx.x; t < P; t += 256) {
+    sv[t] = t < total ? buf_v[row * ldb + t] : worst;
+    si[t] = t < total ? buf_i[row * ldb + t] : INT64_MAX;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < P / 2; t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = (lo & size) == 0;  // ascending block: the better entry goes first
+        const float va = sv[lo], vb = sv[hi];
+        const int64_t ia = si[lo], ib = si[hi];
+        const bool b_first = select_min ? (vb < va || (vb == va && ib < ia)) : (vb > va || (vb == va && ib < ia));
+        const bool a_first = select_min ? (va < vb || (va == vb && ia < ib)) : (va > vb || (va == vb && ia < ib));
+        if (up ? b_first : a_first) { sv[lo] = vb; sv[hi] = va; si[lo] = ib; si[hi] = ia; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < k; t += 256) { buf_v[row * ldb + t] = sv[t]; buf_i[row * ldb + t] = si[t]; }
+}
+
+__global__ void bf_emit_topk_kernel(const float* __restrict__ buf_v, const int64_t* __restrict__ buf_i, int64_t m, int k,
+                                    float* __restrict__ out_v, int64_t* __restrict__ out_i)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * k) return;
+  const int64_t row = t / k, j = t % k, ldb = k + kBfCap;
+  out_v[t] = buf_v[row * ldb + j];
+  out_i[t] = buf_i[row * ldb + j];
+}
+
 template <typename T>
 void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int64_t m, int64_t ldq, int k,
                      int64_t* neighbors, float* distances, const uint32_t* filter_bits, int filter_type)
@@ -149,7 +202,53 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   // ---- running-threshold path, pipelined: the distance GEMM of tile ct + 1 (compute-bound, the handle's stream) runs
   // beside the filter + small select of tile ct (memory-bound, a helper stream); two half-width tiles alternate.
   std::vector<char> redo((size_t)((m + m_tile - 1) / m_tile), running ? 0 : 1);  // row tiles for the per-tile select path
-  if (running) {
+  const bool fused_filter = running && getenv("CUVS_AMD_BF_NO_FUSED_FILTER") == nullptr;
+  if (fused_filter) {
+    const int64_t n0 = std::min<int64_t>(std::min<int64_t>(n_tile, round_up(n, 128)), round_up(std::max<int64_t>(32768, 32 * (int64_t)k), 128));
+    const int64_t ld0 = std::min<int64_t>(n0, n);
+    dev_buf<float> buf_v(res, (size_t)m_tile * (k + kBfCap));
+    dev_buf<int64_t> buf_i(res, (size_t)m_tile * (k + kBfCap));
+    dev_buf<int> cnt(res, (size_t)m_tile);
+    const size_t n_row_tiles = redo.size();
+    dev_buf<int> ovf(res, n_row_tiles);
+    HIP_TRY(hipMemsetAsync(ovf.data(), 0, ovf.bytes(), res.stream));
+    for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
+      const int64_t mr = std::min(m_tile, m - r0);
+      const T* qr      = queries + r0 * ldq;
+      const float* qnr = qn.data() ? qn.data() + r0 : nullptr;
+      // first tile: distances + select_k straight into the head of every row's buffer
+      const int64_t nc0 = std::min(n0, n);
+      pairwise_distance<T, T>(res, qr, mr, ldq, data, nc0, idx.ld, idx.dim, qnr, idx.norms.data(), metric, tile.data(), ld0);
+      if (filter_type != NO_FILTER) {
+        const int64_t total = mr * nc0;
+        hipLaunchKernelGGL(apply_filter_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 22)), dim3(256), 0,
+                           res.stream, tile.data(), mr, nc0, ld0, (int64_t)0, r0, n, filter_bits, filter_type == BITMAP, worst);
+      }
+      select_k<int64_t, int64_t>(res, tile.data(), nullptr, mr, nc0, ld0, k, buf_v.data(), buf_i.data(), select_min, 0,
+                                 k + kBfCap, 0);
+      for (int64_t seen = nc0; seen < n;) {
+        int64_t nc = (int64_t)((double)seen * kBfCap / (4.0 * k));
+        nc         = std::min<int64_t>(n - seen, std::max<int64_t>(16384, nc / 128 * 128));
+        HIP_TRY(hipMemsetAsync(cnt.data(), 0, (size_t)mr * sizeof(int), res.stream));
+        pairwise_threshold_append<T, T>(res, qr, mr, ldq, data + seen * idx.ld, nc, idx.ld, idx.dim, qnr,
+                                        idx.norms.data() ? idx.norms.data() + seen : nullptr, metric, buf_v.data(),
+                                        buf_i.data(), cnt.data(), k, kBfCap, seen, r0, n, filter_bits,
+                                        filter_type == NO_FILTER ? 0 : (filter_type == BITMAP ? 2 : 1));
+        hipLaunchKernelGGL(bf_merge_appended_kernel, dim3((unsigned)mr), dim3(256), 0, res.stream, buf_v.data(), buf_i.data(),
+                           cnt.data(), k, select_min, ovf.data() + r0 / m_tile);
+        seen += nc;
+      }
+      hipLaunchKernelGGL(bf_emit_topk_kernel, dim3(grid_blocks(mr * k, 256)), dim3(256), 0, res.stream, buf_v.data(),
+                         buf_i.data(), mr, k, distances + r0 * k, neighbors + r0 * k);
+    }
+    // a row with more than kBfCap better elements in one tile (columns arriving in improving order, or a pre-filter
+    // that leaves fewer than k of the first tile) had its candidates cut: such row tiles are redone by the per-tile
+    // select path below. One host round trip per search, only to read the flags.
+    std::vector<int> h_ovf(n_row_tiles, 0);
+    HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+    HIP_TRY(hipStreamSynchronize(res.stream));
+    for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
+  } else if (running) {
     const int64_t nt2   = std::max<int64_t>(128, std::min<int64_t>((n_tile / 2) / 128 * 128, round_up((n + 3) / 4, 128)));
     const int64_t n_ct2 = (n + nt2 - 1) / nt2;
     const int64_t ld2   = std::min<int64_t>(nt2, n);

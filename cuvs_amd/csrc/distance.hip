@@ -14,6 +14,8 @@
 #include "distance_tile.hpp"
 
 #include <cfloat>
+#include <cstdlib>
+#include <type_traits>
 
 namespace cuvs_amd {
 
@@ -56,14 +58,35 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__
   }
 }
 
-// MODE 0: write D tile.  MODE 1: running argmin over all column tiles (grid.x = 1).
+// MODE 2 (brute force beyond the first column tile): the distance tile never leaves the registers - every element that
+// beats its row's current k-th value is appended behind the row's top-k (see brute_force.hip).
+struct append_args {
+  float* buf_v       = nullptr;  // [m, ldb]: the row's sorted top-k, then the appended candidates
+  int64_t* buf_i     = nullptr;
+  int* cnt           = nullptr;  // [m] appended so far (may exceed cap: the caller checks)
+  int64_t ldb        = 0;
+  int k              = 0;
+  int cap            = 0;
+  int64_t col_off    = 0;        // source id of column 0 of x
+  int64_t row_off    = 0;        // query row of row 0 of q (bitmap filters)
+  int64_t n_total    = 0;        // indexed rows (bitmap row pitch)
+  const uint32_t* bits = nullptr;
+  int filter_type    = 0;        // 0 none, 1 bitset, 2 bitmap
+  int select_min     = 1;
+  int srt = 1, sct = 1;          // supertile: srt row tiles x sct column tiles per 256 consecutive blocks of an XCD
+  int64_t n_rt = 0, n_ct = 0;
+  unsigned long long* stats = nullptr;  // dbg & 4: cycles of [prologue, main loop, epilogue] summed over workgroups, + count
+  int dbg = 0;  // timing experiments only (results are wrong): 1 no staging in the main loop, 2 no LDS reads either
+};
+
+// MODE 0: write D tile.  MODE 1: running argmin over all column tiles (grid.x = 1).  MODE 2: threshold + append.
 template <typename TQ, typename TX, int MODE, bool VEC>
 __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q, int64_t m, int64_t ldq,
                                                         const TX* __restrict__ x, int64_t n, int64_t ldx,
                                                         int64_t dim, epilogue_args ep,
                                                         float* __restrict__ out, int64_t ldo,
                                                         uint32_t* __restrict__ labels,
-                                                        float* __restrict__ min_val)
+                                                        float* __restrict__ min_val, append_args ap)
 {
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
@@ -76,7 +99,21 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q
   const int l15  = lane & 15;
   const int lg   = lane >> 4;
 
-  const int64_t row0 = (int64_t)blockIdx.y * BM;
+  int64_t row0 = (int64_t)blockIdx.y * BM;
+  int64_t col0_m2 = 0;
+  if constexpr (MODE == 2) {
+    // XCD x (blocks x, x + 8, ...) owns every 8th supertile; the srt row tiles and sct column tiles of a supertile
+    // (~2 MiB of operands) stay in its L2 while its srt * sct blocks run
+    const int64_t j  = (int64_t)(blockIdx.x >> 3);
+    const int64_t g  = (j / (ap.srt * ap.sct)) * 8 + (blockIdx.x & 7u);
+    const int w      = (int)(j % (ap.srt * ap.sct));
+    const int64_t sr = (ap.n_rt + ap.srt - 1) / ap.srt;
+    const int64_t rt = (g % sr) * ap.srt + (w % ap.srt);
+    const int64_t ct = (g / sr) * ap.sct + (w / ap.srt);
+    if (rt >= ap.n_rt || ct >= ap.n_ct) return;  // workgroup-uniform
+    row0    = rt * BM;
+    col0_m2 = ct * BN;
+  }
   const int nkt      = (int)((dim + BK - 1) / BK);
 
   // staging assignment: two (row, chunk) pairs per thread and per operand
@@ -92,7 +129,7 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q
 
   const int64_t n_col_tiles = (MODE == 1) ? (n + BN - 1) / BN : 1;
   for (int64_t ct = 0; ct < n_col_tiles; ++ct) {
-    const int64_t col0 = (MODE == 1) ? ct * BN : (int64_t)blockIdx.x * BN;
+    const int64_t col0 = (MODE == 1) ? ct * BN : (MODE == 2) ? col0_m2 : (int64_t)blockIdx.x * BN;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -169,6 +206,40 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q
           }
         }
       }
+    } else if constexpr (MODE == 2) {
+      float xnv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t col = col0 + wn * 64 + j * 16 + l15;
+        xnv[j]      = (ep.xn != nullptr && col < n) ? ep.xn[col] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
+          if (row >= m) continue;
+          const float qnv = ep.qn != nullptr ? ep.qn[row] : 0.f;
+          const float thr = ap.buf_v[row * ap.ldb + ap.k - 1];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t col = col0 + wn * 64 + j * 16 + l15;
+            const float d     = finish_distance(acc[i][j][e], qnv, xnv[j], ep.metric, ep.clamp_eps);
+            bool take         = col < n && (ap.select_min ? d < thr : d > thr);
+            if (take && ap.filter_type != 0) {
+              const int64_t bit = ap.filter_type == 2 ? (ap.row_off + row) * ap.n_total + (ap.col_off + col) : ap.col_off + col;
+              take              = (ap.bits[bit >> 5] >> (bit & 31)) & 1u;
+            }
+            if (take) {
+              const int pos = atomicAdd(&ap.cnt[row], 1);
+              if (pos < ap.cap) {
+                ap.buf_v[row * ap.ldb + ap.k + pos] = d;
+                ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col;
+              }
+            }
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -223,6 +294,233 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dist_tile_kernel: the same 128 x 128 x 16 tile, accumulation order and epilogue as dist_mfma_kernel (bit-identical
+// results) for the common shape - 16-byte aligned rows, dim a multiple of 16 - without the edge handling in the main
+// loop: rows past the end are CLAMPED to the last row (their results are dropped by the epilogue) instead of being
+// branched around, so a k-tile is 4 unconditional 16-byte loads, 64 MFMAs, 16 ds_read2 with immediate offsets (the XOR
+// swizzle c << 3 is folded into "fragment i ^ (c >> 1) at one of two base addresses"), 8 ds_write2 and one barrier.
+// MODE 0 writes the tile; MODE 2 keeps it in registers: one straight-line pass compares every element with its row's
+// k-th value, and only a lane that found something (rare once the thresholds are warm) enters the append loop.
+template <typename T>
+__device__ inline void load4v(const T* __restrict__ p, float (&v)[4])
+{
+  if constexpr (sizeof(T) == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    const uint2 t   = *reinterpret_cast<const uint2*>(p);
+    const __half* h = reinterpret_cast<const __half*>(&t);
+    v[0] = __half2float(h[0]); v[1] = __half2float(h[1]); v[2] = __half2float(h[2]); v[3] = __half2float(h[3]);
+  }
+}
+
+constexpr int kTileOcc = 3;  // waves per SIMD the register budget is set for
+
+template <typename TQ, typename TX, int MODE, int OCC, int METRIC>
+__global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restrict__ q, int64_t m, int64_t ldq,
+                                                             const TX* __restrict__ x, int64_t n, int64_t ldx, int64_t dim,
+                                                             epilogue_args ep, float* __restrict__ out, int64_t ldo,
+                                                             append_args ap)
+{
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+
+  const int tid  = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm   = wave >> 1;
+  const int wn   = wave & 1;
+  const int l15  = lane & 15;
+  const int lg   = lane >> 4;
+
+  int64_t row0, col0;
+  if constexpr (MODE == 2) {
+    const int64_t j  = (int64_t)(blockIdx.x >> 3);
+    const int64_t g  = (j / (ap.srt * ap.sct)) * 8 + (blockIdx.x & 7u);
+    const int w      = (int)(j % (ap.srt * ap.sct));
+    const int64_t sr = (ap.n_rt + ap.srt - 1) / ap.srt;
+    const int64_t rt = (g % sr) * ap.srt + (w % ap.srt);
+    const int64_t ct = (g / sr) * ap.sct + (w / ap.srt);
+    if (rt >= ap.n_rt || ct >= ap.n_ct) return;  // workgroup-uniform
+    row0 = rt * BM;
+    col0 = ct * BN;
+  } else {
+    row0 = (int64_t)blockIdx.y * BM;
+    col0 = (int64_t)blockIdx.x * BN;
+  }
+  const int nkt = (int)(dim / BK);
+  // the tile's row / column norms and (MODE 2) row thresholds, staged once: visible after the first barrier
+  __shared__ __attribute__((aligned(16))) float s_qn[BM], s_xn[BN], s_thr[BM];
+  if (tid < BM) {
+    const int64_t row = row0 + tid;
+    s_qn[tid]         = ep.qn != nullptr ? ep.qn[min(row, m - 1)] : 0.f;
+    if constexpr (MODE == 2)  // rows past the end never pass
+      s_thr[tid] = row < m ? ap.buf_v[row * ap.ldb + ap.k - 1] : (ap.select_min ? -INFINITY : INFINITY);
+  } else {
+    s_xn[tid - BM] = ep.xn != nullptr ? ep.xn[min(col0 + tid - BM, n - 1)] : 0.f;
+  }
+  const bool stat = MODE == 2 && (ap.dbg & 4);
+  const unsigned long long t_start = stat ? __builtin_readcyclecounter() : 0ull;
+
+  // staging: thread t moves rows t / 4 and 64 + t / 4, k-chunk t % 4 of both operands
+  const int sr0 = tid >> 2, sc = tid & 3;
+  const TQ* pa0 = q + min(row0 + sr0, m - 1) * ldq + sc * 4;
+  const TQ* pa1 = q + min(row0 + sr0 + 64, m - 1) * ldq + sc * 4;
+  const TX* pb0 = x + min(col0 + sr0, n - 1) * ldx + sc * 4;
+  const TX* pb1 = x + min(col0 + sr0 + 64, n - 1) * ldx + sc * 4;
+  const int st0 = (4 * sc) * LDT + (sr0 ^ (sc << 3));         // stage_store's address, e = 0
+  const int st1 = (4 * sc) * LDT + ((sr0 + 64) ^ (sc << 3));
+
+  // fragment reads: A[(4c + lg) * LDT + ((wm * 64 + i * 16 + l15) ^ (c << 3))]; bit 3 of the swizzle flips bit 3 of
+  // l15 (two base addresses), bit 4 turns fragment i into fragment i ^ 1 (an immediate)
+  const int ra_[2] = {lg * LDT + wm * 64 + l15, lg * LDT + wm * 64 + (l15 ^ 8)};
+  const int rb_[2] = {lg * LDT + wn * 64 + l15, lg * LDT + wn * 64 + (l15 ^ 8)};
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float ga0[4], ga1[4], gb0[4], gb1[4];
+  load4v(pa0, ga0); load4v(pa1, ga1); load4v(pb0, gb0); load4v(pb1, gb1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    As[0][st0 + e * LDT] = ga0[e]; As[0][st1 + e * LDT] = ga1[e];
+    Bs[0][st0 + e * LDT] = gb0[e]; Bs[0][st1 + e * LDT] = gb1[e];
+  }
+  __syncthreads();
+  const unsigned long long t_loop = stat ? __builtin_readcyclecounter() : 0ull;
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt && !(ap.dbg & 1)) {
+      const int k0 = (kt + 1) * BK;
+      load4v(pa0 + k0, ga0); load4v(pa1 + k0, ga1); load4v(pb0 + k0, gb0); load4v(pb1 + k0, gb1);
+    }
+    const float* A = As[buf];
+    const float* B = Bs[buf];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float a[4], b[4];
+      if (ap.dbg & 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = ga0[i] + c; b[i] = gb0[i] + c; }
+      } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = A[ra_[c & 1] + (4 * c) * LDT + ((i ^ (c >> 1)) * 16)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = B[rb_[c & 1] + (4 * c) * LDT + ((j ^ (c >> 1)) * 16)];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (ap.dbg & 1) continue;
+    if (kt + 1 < nkt) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        As[buf ^ 1][st0 + e * LDT] = ga0[e]; As[buf ^ 1][st1 + e * LDT] = ga1[e];
+        Bs[buf ^ 1][st0 + e * LDT] = gb0[e]; Bs[buf ^ 1][st1 + e * LDT] = gb1[e];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C layout col = lane & 15, row = (lane >> 4) * 4 + e
+  const unsigned long long t_epi = stat ? __builtin_readcyclecounter() : 0ull;
+  float xnv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xnv[j] = s_xn[wn * 64 + j * 16 + l15];
+  float qnv[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(&s_qn[wm * 64 + i * 16 + lg * 4]);
+    qnv[i * 4 + 0] = t[0]; qnv[i * 4 + 1] = t[1]; qnv[i * 4 + 2] = t[2]; qnv[i * 4 + 3] = t[3];
+  }
+  if constexpr (MODE == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
+        if (row >= m) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t col = col0 + wn * 64 + j * 16 + l15;
+          if (col < n) out[row * ldo + col] = finish_distance(acc[i][j][e], qnv[i * 4 + e], xnv[j], METRIC, ep.clamp_eps);
+        }
+      }
+    }
+  } else {
+    float thr[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(&s_thr[wm * 64 + i * 16 + lg * 4]);
+      thr[i * 4 + 0] = t[0]; thr[i * 4 + 1] = t[1]; thr[i * 4 + 2] = t[2]; thr[i * 4 + 3] = t[3];
+    }
+    // one straight-line pass: does this lane hold anything that beats its row's k-th value?
+    uint32_t any = 0u;
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = finish_distance(acc[t >> 2][j][t & 3], qnv[t], xnv[j], METRIC, ep.clamp_eps);
+        any |= (uint32_t)(METRIC != M_InnerProduct ? d < thr[t] : d > thr[t]);
+      }
+    if (any != 0u) {  // rare once the thresholds are warm
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int64_t row = row0 + wm * 64 + (t >> 2) * 16 + lg * 4 + (t & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t col = col0 + wn * 64 + j * 16 + l15;
+          const float d = finish_distance(acc[t >> 2][j][t & 3], qnv[t], xnv[j], METRIC, ep.clamp_eps);
+          bool take     = col < n && (METRIC != M_InnerProduct ? d < thr[t] : d > thr[t]);
+          if (take && ap.filter_type != 0) {
+            const int64_t bit = ap.filter_type == 2 ? (ap.row_off + row) * ap.n_total + (ap.col_off + col) : ap.col_off + col;
+            take              = (ap.bits[bit >> 5] >> (bit & 31)) & 1u;
+          }
+          if (take) {
+            const int pos = atomicAdd(&ap.cnt[row], 1);
+            if (pos < ap.cap) {
+              ap.buf_v[row * ap.ldb + ap.k + pos] = d;
+              ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col;
+            }
+          }
+        }
+      }
+    }
+    if (stat && tid == 0) {
+      const unsigned long long t_end = __builtin_readcyclecounter();
+      atomicAdd(&ap.stats[0], t_loop - t_start);
+      atomicAdd(&ap.stats[1], t_epi - t_loop);
+      atomicAdd(&ap.stats[2], t_end - t_epi);
+      atomicAdd(&ap.stats[3], 1ull);
+    }
+  }
+}
+
+template <typename TQ, typename TX, int MODE>
+void launch_tile(int metric, dim3 grid, hipStream_t stream, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n,
+                 int64_t ldx, int64_t dim, epilogue_args ep, float* out, int64_t ldo, append_args ap)
+{
+#define TILE_CASE(M)                                                                                                     \
+  case M:                                                                                                                \
+    hipLaunchKernelGGL((dist_tile_kernel<TQ, TX, MODE, kTileOcc, M>), grid, dim3(256), 0, stream, q, m, ldq, x, n, ldx, dim, \
+                       ep, out, ldo, ap);                                                                                \
+    break;
+  switch (metric) {
+    TILE_CASE(M_L2Expanded) TILE_CASE(M_L2SqrtExpanded) TILE_CASE(M_CosineExpanded) TILE_CASE(M_L2Unexpanded)
+    TILE_CASE(M_L2SqrtUnexpanded) TILE_CASE(M_InnerProduct)
+    default: CUVS_FAIL("unsupported metric %d", metric);
+  }
+#undef TILE_CASE
+}
+
 }  // namespace
 
 template <typename T>
@@ -255,12 +553,69 @@ void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, cons
   dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((m + BM - 1) / BM));
   CUVS_EXPECTS((m + BM - 1) / BM <= 65535, "pairwise_distance: too many query rows per call");
   bool vec = vec_ok(q, ldq, dim) && vec_ok(x, ldx, dim);
+  if constexpr (std::is_same_v<TQ, TX> && (sizeof(TQ) == 4 || sizeof(TQ) == 2)) {
+    if (vec && dim % BK == 0 && getenv("CUVS_AMD_DIST_OLD") == nullptr) {
+      launch_tile<TQ, TX, 0>(metric, grid, res.stream, q, m, ldq, x, n, ldx, dim, ep, out, ldo, append_args{});
+      HIP_TRY(hipGetLastError());
+      return;
+    }
+  }
   if (vec) {
     hipLaunchKernelGGL((dist_mfma_kernel<TQ, TX, 0, true>), grid, dim3(256), 0, res.stream, q, m, ldq, x, n,
-                       ldx, dim, ep, out, ldo, (uint32_t*)nullptr, (float*)nullptr);
+                       ldx, dim, ep, out, ldo, (uint32_t*)nullptr, (float*)nullptr, append_args{});
   } else {
     hipLaunchKernelGGL((dist_mfma_kernel<TQ, TX, 0, false>), grid, dim3(256), 0, res.stream, q, m, ldq, x, n,
-                       ldx, dim, ep, out, ldo, (uint32_t*)nullptr, (float*)nullptr);
+                       ldx, dim, ep, out, ldo, (uint32_t*)nullptr, (float*)nullptr, append_args{});
+  }
+  HIP_TRY(hipGetLastError());
+}
+
+template <typename TQ, typename TX>
+void pairwise_threshold_append(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n, int64_t ldx,
+                               int64_t dim, const float* qn, const float* xn, int metric, float* buf_v, int64_t* buf_i,
+                               int* cnt, int k, int cap, int64_t col_off, int64_t row_off, int64_t n_total,
+                               const uint32_t* bits, int filter_type)
+{
+  if (m == 0 || n == 0) return;
+  CUVS_EXPECTS(metric_supported(metric), "pairwise_threshold_append: unsupported metric %d", metric);
+  epilogue_args ep{qn, xn, metric, (sizeof(TX) == 2 ? 1e-3f : 1e-6f)};
+  append_args ap;
+  ap.buf_v = buf_v; ap.buf_i = buf_i; ap.cnt = cnt; ap.ldb = k + cap; ap.k = k; ap.cap = cap;
+  ap.col_off = col_off; ap.row_off = row_off; ap.n_total = n_total; ap.bits = bits; ap.filter_type = filter_type;
+  ap.select_min = metric != M_InnerProduct;
+  ap.n_rt = (m + BM - 1) / BM;
+  ap.n_ct = (n + BN - 1) / BN;
+  ap.srt  = (int)std::min<int64_t>(16, ap.n_rt);
+  ap.sct  = 256 / ap.srt;
+  if (const char* e = getenv("CUVS_AMD_TILE_DBG")) ap.dbg = atoi(e);
+  const int64_t supertiles = ((ap.n_rt + ap.srt - 1) / ap.srt) * ((ap.n_ct + ap.sct - 1) / ap.sct);
+  const int64_t blocks     = (supertiles + 7) / 8 * 8 * (int64_t)(ap.srt * ap.sct);
+  CUVS_EXPECTS(blocks < (int64_t(1) << 31), "pairwise_threshold_append: grid too large");
+  const bool vec = vec_ok(q, ldq, dim) && vec_ok(x, ldx, dim);
+  if (vec && dim % BK == 0 && getenv("CUVS_AMD_DIST_OLD") == nullptr) {
+    dev_buf<unsigned long long> stats;
+    if (ap.dbg & 4) {
+      stats = dev_buf<unsigned long long>(res, 4);
+      HIP_TRY(hipMemsetAsync(stats.data(), 0, stats.bytes(), res.stream));
+      ap.stats = stats.data();
+    }
+    launch_tile<TQ, TX, 2>(metric, dim3((unsigned)blocks), res.stream, q, m, ldq, x, n, ldx, dim, ep, (float*)nullptr, (int64_t)0, ap);
+    HIP_TRY(hipGetLastError());
+    if (ap.dbg & 4) {
+      unsigned long long h[4];
+      HIP_TRY(hipMemcpyAsync(h, stats.data(), sizeof(h), hipMemcpyDeviceToHost, res.stream));
+      HIP_TRY(hipStreamSynchronize(res.stream));
+      fprintf(stderr, "[dist_tile stats] tiles %llu, cycles per tile (wave 0): prologue %.0f main loop %.0f epilogue %.0f\n", h[3],
+              (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3]);
+    }
+    return;
+  }
+  if (vec) {
+    hipLaunchKernelGGL((dist_mfma_kernel<TQ, TX, 2, true>), dim3((unsigned)blocks), dim3(256), 0, res.stream, q, m, ldq, x, n,
+                       ldx, dim, ep, (float*)nullptr, (int64_t)0, (uint32_t*)nullptr, (float*)nullptr, ap);
+  } else {
+    hipLaunchKernelGGL((dist_mfma_kernel<TQ, TX, 2, false>), dim3((unsigned)blocks), dim3(256), 0, res.stream, q, m, ldq, x, n,
+                       ldx, dim, ep, (float*)nullptr, (int64_t)0, (uint32_t*)nullptr, (float*)nullptr, ap);
   }
   HIP_TRY(hipGetLastError());
 }
@@ -284,10 +639,10 @@ void fused_l2_argmin(resources& res, const TQ* q, int64_t m, int64_t ldq, const 
     float* mv      = min_val ? min_val + r0 : nullptr;
     if (vec) {
       hipLaunchKernelGGL((dist_mfma_kernel<TQ, float, 1, true>), grid, dim3(256), 0, res.stream, qq, mr, ldq,
-                         centers, n, dim, dim, ep, (float*)nullptr, (int64_t)0, lab, mv);
+                         centers, n, dim, dim, ep, (float*)nullptr, (int64_t)0, lab, mv, append_args{});
     } else {
       hipLaunchKernelGGL((dist_mfma_kernel<TQ, float, 1, false>), grid, dim3(256), 0, res.stream, qq, mr, ldq,
-                         centers, n, dim, dim, ep, (float*)nullptr, (int64_t)0, lab, mv);
+                         centers, n, dim, dim, ep, (float*)nullptr, (int64_t)0, lab, mv, append_args{});
     }
   }
   HIP_TRY(hipGetLastError());
@@ -302,6 +657,13 @@ INST_N(float) INST_N(__half) INST_N(int8_t) INST_N(uint8_t)
                                           int64_t, int64_t, const float*, const float*, int, float*, int64_t);
 INST_P(float, float) INST_P(__half, __half) INST_P(__half, float) INST_P(int8_t, float) INST_P(uint8_t, float)
 #undef INST_P
+
+#define INST_T(TQ, TX)                                                                                              \
+  template void pairwise_threshold_append<TQ, TX>(resources&, const TQ*, int64_t, int64_t, const TX*, int64_t, int64_t, \
+                                                  int64_t, const float*, const float*, int, float*, int64_t*, int*, int, int, \
+                                                  int64_t, int64_t, int64_t, const uint32_t*, int);
+INST_T(float, float) INST_T(__half, __half)
+#undef INST_T
 
 #define INST_A(TQ)                                                                                        \
   template void fused_l2_argmin<TQ>(resources&, const TQ*, int64_t, int64_t, const float*, int64_t,       \
@@ -338,6 +700,45 @@ extern "C" __attribute__((visibility("default"))) int cuvsAmdFusedArgmin(uintptr
     dev_buf<float> cn(r, n);
     row_norms<float>(r, centers, n, dim, dim, cn.data(), false);
     fused_l2_argmin<float>(r, q, m, dim, centers, n, dim, cn.data(), labels, nullptr);
+  });
+}
+
+// Timing hook for the threshold-append tile kernel alone: thresholds that nothing beats, `reps` launches between two
+// events. dbg != 0 switches parts of the main loop off (results are wrong; only the duration means anything).
+extern "C" __attribute__((visibility("default"))) int cuvsAmdTileBench(uintptr_t res, int64_t m, int64_t n, int64_t dim,
+                                                                         int dbg, int reps, float* ms_out)
+{
+  using namespace cuvs_amd;
+  return translate_exceptions([=] {
+    auto& r = *as_res(res);
+    const int k = 10, cap = 16;
+    dev_buf<float> q(r, (size_t)m * dim), x(r, (size_t)n * dim), qn(r, m), xn(r, n), bv(r, (size_t)m * (k + cap));
+    dev_buf<int64_t> bi(r, (size_t)m * (k + cap));
+    dev_buf<int> cnt(r, m);
+    HIP_TRY(hipMemsetAsync(q.data(), 0, q.bytes(), r.stream));
+    HIP_TRY(hipMemsetAsync(x.data(), 0, x.bytes(), r.stream));
+    HIP_TRY(hipMemsetAsync(qn.data(), 0, qn.bytes(), r.stream));
+    HIP_TRY(hipMemsetAsync(xn.data(), 0, xn.bytes(), r.stream));
+    HIP_TRY(hipMemsetAsync(bv.data(), 0xff, bv.bytes(), r.stream));  // NaN thresholds: no comparison passes
+    HIP_TRY(hipMemsetAsync(cnt.data(), 0, cnt.bytes(), r.stream));
+    char buf[16];
+    snprintf(buf, sizeof(buf), "%d", dbg);
+    setenv("CUVS_AMD_TILE_DBG", buf, 1);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int it = 0; it < reps + 1; ++it) {
+      if (it == 1) HIP_TRY(hipEventRecord(e0, r.stream));
+      pairwise_threshold_append<float, float>(r, q.data(), m, dim, x.data(), n, dim, dim, qn.data(), xn.data(), M_L2Expanded,
+                                              bv.data(), bi.data(), cnt.data(), k, cap, 0, 0, n, nullptr, 0);
+    }
+    HIP_TRY(hipEventRecord(e1, r.stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms_out, e0, e1));
+    *ms_out /= reps;
+    unsetenv("CUVS_AMD_TILE_DBG");
+    HIP_TRY(hipEventDestroy(e0));
+    HIP_TRY(hipEventDestroy(e1));
   });
 }
 

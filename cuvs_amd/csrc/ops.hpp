@@ -38,6 +38,15 @@ void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, cons
                        int64_t ldx, int64_t dim, const float* qn, const float* xn, int metric,
                        float* out, int64_t ldo);
 
+// The same distance tile, kept in registers: every element (i, j) that beats row i's current k-th value
+// buf_v[i * (k + cap) + k - 1] (strictly) and passes the pre-filter is appended - value and source id col_off + j -
+// at buf[i * (k + cap) + k + cnt[i]++] (atomic: the order within a row is arbitrary; cnt may run past cap).
+template <typename TQ, typename TX>
+void pairwise_threshold_append(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n, int64_t ldx,
+                               int64_t dim, const float* qn, const float* xn, int metric, float* buf_v, int64_t* buf_i,
+                               int* cnt, int k, int cap, int64_t col_off, int64_t row_off, int64_t n_total,
+                               const uint32_t* bits, int filter_type);
+
 // labels[i] = argmin_j ( xn_j - 2 dot(Q_i, X_j) ) (ties -> smallest j); optional min value out
 // (= squared L2 distance minus |q|^2). The k-means E-step and IVF list assignment.
 template <typename TQ>

@@ -175,7 +175,41 @@ def test_running_threshold_path(monkeypatch, metric, adversarial):
     res.sync()
     od, oi = oracle.brute_force_knn(qq, x, 12, metric=metric)
     assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
+    monkeypatch.setenv("CUVS_AMD_BF_NO_FUSED_FILTER", "1")  # round 2's first form: distance tiles + a filter pass
+    d1, i1 = brute_force.search(idx, tq, 12, resources=res)
+    res.sync()
+    assert torch.equal(i, i1) and torch.equal(d, d1)
     monkeypatch.setenv("CUVS_AMD_BF_NO_THRESHOLD", "1")
     d2, i2 = brute_force.search(idx, tq, 12, resources=res)
     res.sync()
     assert torch.equal(i, i2) and torch.equal(d, d2)
+
+
+@pytest.mark.parametrize("metric,dtype", [("sqeuclidean", "float32"), ("inner_product", "float32"),
+                                          ("cosine", "float16"), ("euclidean", "float32")])
+@pytest.mark.parametrize("filt", ["none", "bitset", "bitmap"])
+def test_fused_threshold_epilogue(metric, dtype, filt):
+    """n >= 65536: beyond the first 32768 columns no distance tile is written - the MFMA epilogue appends what beats a
+    row's k-th value (pre-filter applied to those only) and a per-row sort by (value, id) keeps k. Identical to the
+    oracle, ties included, with every kind of pre-filter."""
+    import torch
+    from cuvs_amd._lib import BITMAP, BITSET
+
+    n, q, k = 90000, 70, 10
+    x, qq = _gen(n, 24, q, seed=31)
+    x[200] = x[60000]; x[70001] = x[40]  # exact ties between the first tile and the fused part, both directions
+    if dtype == "float16":
+        x, qq = x.astype(np.float16).astype(np.float32), qq.astype(np.float16).astype(np.float32)
+    rng = np.random.default_rng(5)
+    pre, kw = None, {}
+    if filt == "bitset":
+        keep = rng.random(n) < 0.4
+        words = np.packbits(np.concatenate([keep, np.zeros((-n) % 32, bool)]), bitorder="little").view(np.uint32)
+        pre, kw = (torch.from_numpy(words.view(np.int32)).cuda(), BITSET), {"keep_bits": words}
+    elif filt == "bitmap":
+        keep = (rng.random((q, n)) < 0.5).reshape(-1)
+        words = np.packbits(np.concatenate([keep, np.zeros((-keep.size) % 32, bool)]), bitorder="little").view(np.uint32)
+        pre, kw = (torch.from_numpy(words.view(np.int32)).cuda(), BITMAP), {"keep_bits": words, "bitmap": True}
+    gd, gi = _run(x, qq, k, metric, prefilter=pre, dtype=dtype)
+    od, oi = oracle.brute_force_knn(qq, x, k, metric=metric, **kw)
+    assert (gi == oi).all() and (gd == od).all()
