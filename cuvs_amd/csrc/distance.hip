@@ -435,15 +435,10 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
   float xnv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) xnv[j] = s_xn[wn * 64 + j * 16 + l15];
-  float qnv[16];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(&s_qn[wm * 64 + i * 16 + lg * 4]);
-    qnv[i * 4 + 0] = t[0]; qnv[i * 4 + 1] = t[1]; qnv[i * 4 + 2] = t[2]; qnv[i * 4 + 3] = t[3];
-  }
   if constexpr (MODE == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const f32x4 qn4 = *reinterpret_cast<const f32x4*>(&s_qn[wm * 64 + i * 16 + lg * 4]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
@@ -451,44 +446,49 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int64_t col = col0 + wn * 64 + j * 16 + l15;
-          if (col < n) out[row * ldo + col] = finish_distance(acc[i][j][e], qnv[i * 4 + e], xnv[j], METRIC, ep.clamp_eps);
+          if (col < n) out[row * ldo + col] = finish_distance(acc[i][j][e], qn4[e], xnv[j], METRIC, ep.clamp_eps);
         }
       }
     }
   } else {
-    float thr[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(&s_thr[wm * 64 + i * 16 + lg * 4]);
-      thr[i * 4 + 0] = t[0]; thr[i * 4 + 1] = t[1]; thr[i * 4 + 2] = t[2]; thr[i * 4 + 3] = t[3];
-    }
-    // one straight-line pass: does this lane hold anything that beats its row's k-th value?
+    // one straight-line pass: does this lane hold anything that beats its row's k-th value? (norms and thresholds come
+    // from LDS four rows at a time: 8 live registers instead of 32)
     uint32_t any = 0u;
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 qn4 = *reinterpret_cast<const f32x4*>(&s_qn[wm * 64 + i * 16 + lg * 4]);
+      const f32x4 th4 = *reinterpret_cast<const f32x4*>(&s_thr[wm * 64 + i * 16 + lg * 4]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d = finish_distance(acc[t >> 2][j][t & 3], qnv[t], xnv[j], METRIC, ep.clamp_eps);
-        any |= (uint32_t)(METRIC != M_InnerProduct ? d < thr[t] : d > thr[t]);
-      }
-    if (any != 0u) {  // rare once the thresholds are warm
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int64_t row = row0 + wm * 64 + (t >> 2) * 16 + lg * 4 + (t & 3);
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int64_t col = col0 + wn * 64 + j * 16 + l15;
-          const float d = finish_distance(acc[t >> 2][j][t & 3], qnv[t], xnv[j], METRIC, ep.clamp_eps);
-          bool take     = col < n && (METRIC != M_InnerProduct ? d < thr[t] : d > thr[t]);
-          if (take && ap.filter_type != 0) {
-            const int64_t bit = ap.filter_type == 2 ? (ap.row_off + row) * ap.n_total + (ap.col_off + col) : ap.col_off + col;
-            take              = (ap.bits[bit >> 5] >> (bit & 31)) & 1u;
-          }
-          if (take) {
-            const int pos = atomicAdd(&ap.cnt[row], 1);
-            if (pos < ap.cap) {
-              ap.buf_v[row * ap.ldb + ap.k + pos] = d;
-              ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col;
+          const float d = finish_distance(acc[i][j][e], qn4[e], xnv[j], METRIC, ep.clamp_eps);
+          any |= (uint32_t)(METRIC != M_InnerProduct ? d < th4[e] : d > th4[e]);
+        }
+    }
+    if (any != 0u) {  // rare once the thresholds are warm
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 qn4 = *reinterpret_cast<const f32x4*>(&s_qn[wm * 64 + i * 16 + lg * 4]);
+        const f32x4 th4 = *reinterpret_cast<const f32x4*>(&s_thr[wm * 64 + i * 16 + lg * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int64_t col = col0 + wn * 64 + j * 16 + l15;
+            const float d = finish_distance(acc[i][j][e], qn4[e], xnv[j], METRIC, ep.clamp_eps);
+            bool take     = col < n && (METRIC != M_InnerProduct ? d < th4[e] : d > th4[e]);
+            if (take && ap.filter_type != 0) {
+              const int64_t bit = ap.filter_type == 2 ? (ap.row_off + row) * ap.n_total + (ap.col_off + col) : ap.col_off + col;
+              take              = (ap.bits[bit >> 5] >> (bit & 31)) & 1u;
+            }
+            if (take) {
+              const int pos = atomicAdd(&ap.cnt[row], 1);
+              if (pos < ap.cap) {
+                ap.buf_v[row * ap.ldb + ap.k + pos] = d;
+                ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col;
+              }
             }
           }
         }
