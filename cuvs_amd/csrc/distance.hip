@@ -402,22 +402,26 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
     }
     const float* A = As[buf];
     const float* B = Bs[buf];
+    // fragment reads of step c + 1 are issued before the MFMAs of step c (two register sets): one exposed LDS latency
+    // per k-tile instead of four
+    float a[2][4], b[2][4];
+    auto read_frags = [&](const int c, float (&fa)[4], float (&fb)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = A[ra_[c & 1] + (4 * c) * LDT + ((i ^ (c >> 1)) * 16)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = B[rb_[c & 1] + (4 * c) * LDT + ((j ^ (c >> 1)) * 16)];
+    };
+    read_frags(0, a[0], b[0]);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float a[4], b[4];
-      if (ap.dbg & 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { a[i] = ga0[i] + c; b[i] = gb0[i] + c; }
-      } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = A[ra_[c & 1] + (4 * c) * LDT + ((i ^ (c >> 1)) * 16)];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = B[rb_[c & 1] + (4 * c) * LDT + ((j ^ (c >> 1)) * 16)];
-      }
+      if (c < 3) read_frags(c + 1, a[(c + 1) & 1], b[(c + 1) & 1]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the 8 ds_read2 first ...
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c & 1][i], b[c & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // ... then the 16 MFMAs of this step
     }
     if (ap.dbg & 1) continue;
     if (kt + 1 < nkt) {
