@@ -20,6 +20,7 @@
 #include <cuvs/neighbors/ivf_flat.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cfloat>
 
 namespace cuvs_amd {
@@ -175,6 +176,51 @@ __global__ void flat_query_tiles_kernel(const work_item* __restrict__ items, con
   }
 }
 
+// int8 / uint8 (L2, inner product): the tile holds the RAW query bytes, four per dword - [chunk][query][4 dwords] - and,
+// behind them, the running sum of q^2 after every chunk - [chunk][query] - for v_dot4 (the reference's dp4a path,
+// metric_impl.cuh:12-49: integer accumulators, exact).
+template <typename T>
+__global__ void flat_query_tiles_int_kernel(const work_item* __restrict__ items, const uint32_t* __restrict__ n_items,
+                                            const uint32_t* __restrict__ sorted_pairs, const T* __restrict__ queries,
+                                            uint32_t n_probes, uint32_t dim, uint32_t n_chunks, size_t tile_floats,
+                                            float* __restrict__ tiles)
+{
+  constexpr int QPB = kFlatQPB;
+  const uint32_t w = blockIdx.x;
+  if (w >= *n_items) return;
+  const work_item item = items[w];
+  __shared__ uint32_t qid[QPB];
+  if (threadIdx.x < QPB)
+    qid[threadIdx.x] = threadIdx.x < item.count ? sorted_pairs[item.first + threadIdx.x] / n_probes : 0xffffffffu;
+  __syncthreads();
+  uint32_t* words = reinterpret_cast<uint32_t*>(tiles + (size_t)w * tile_floats);
+  uint32_t* q2    = words + (size_t)n_chunks * QPB * 4;
+  for (uint32_t t = threadIdx.x; t < n_chunks * QPB * 4; t += blockDim.x) {
+    const uint32_t ch = t / (QPB * 4), j = (t / 4) % QPB, u = t % 4;
+    uint32_t wv = 0u;
+    if (qid[j] != 0xffffffffu) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t d = ch * 16 + u * 4 + b;
+        if (d < dim) wv |= (uint32_t)(uint8_t)queries[(size_t)qid[j] * dim + d] << (8 * b);
+      }
+    }
+    words[t] = wv;
+  }
+  if (threadIdx.x < QPB) {
+    const uint32_t j = threadIdx.x;
+    uint32_t acc = 0u;  // sum of squares: the same bits for int32 and uint32 accumulators
+    for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+      if (qid[j] != 0xffffffffu)
+        for (uint32_t d = ch * 16; d < ch * 16 + 16 && d < dim; ++d) {
+          const int v = (int)queries[(size_t)qid[j] * dim + d];
+          acc += (uint32_t)(v * v);
+        }
+      q2[ch * QPB + j] = acc;
+    }
+  }
+}
+
 // IP (inner product) is a template argument: tested at run time inside the unrolled element loop it became a
 // scalar branch per element
 // ALL: the non-fused path (every score written out, no top lists) - a template argument so that the fused kernels
@@ -185,6 +231,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
   constexpr int QPB = kFlatQPB;
   constexpr int VL  = 16 / sizeof(T);
   constexpr bool IP = METRIC != 0;  // scores that are dot products: no early stop, negated as sort keys
+  constexpr bool INT = (std::is_same_v<T, int8_t> || std::is_same_v<T, uint8_t>) && METRIC != 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t item0 = a.item_begin ? *a.item_begin : 0u;
   const uint32_t w     = item0 + blockIdx.x;
@@ -240,6 +287,46 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
       const uint32_t kk = __builtin_amdgcn_readfirstlane(kthb[j]);
       bf[j] = (IP || j >= (int)item.count) ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
     }
+    float acc[QPB];
+    if constexpr (INT) {
+      // integer path: sum (x - q)^2 = sum x^2 + sum q^2 - 2 sum x q, every term exact in 32-bit integers (v_dot4: four
+      // elements per instruction; 36 instructions per 16-byte chunk and 8 queries instead of 144)
+      using iacc_t = std::conditional_t<std::is_same_v<T, int8_t>, int32_t, uint32_t>;
+      const uint32_t* qw = reinterpret_cast<const uint32_t*>(qt);  // wave-uniform: scalar loads
+      const uint32_t* q2 = qw + (size_t)a.n_chunks * QPB * 4;
+      iacc_t dot[QPB];
+#pragma unroll
+      for (int j = 0; j < QPB; ++j) dot[j] = 0;
+      iacc_t sx2 = 0;
+      auto dot4 = [](const uint32_t x, const uint32_t y, const iacc_t c) -> iacc_t {
+        if constexpr (std::is_same_v<T, int8_t>) return __builtin_amdgcn_sdot4((int)x, (int)y, c, false);
+        else return __builtin_amdgcn_udot4(x, y, c, false);
+      };
+      uint32_t done = 0;
+      for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
+        if (!IP && !ALL && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
+          bool below = false;
+#pragma unroll
+          for (int j = 0; j < QPB; ++j)
+            below = below || ((float)(iacc_t)(sx2 + (iacc_t)q2[(ch - 1) * QPB + j] - 2 * dot[j]) <= bf[j]);
+          if (__ballot(valid && below) == 0ull) break;  // wave-uniform
+        }
+        const uint4 cw       = cp[(size_t)ch * 64];
+        const uint32_t xw[4] = {cw.x, cw.y, cw.z, cw.w};
+        const uint32_t* qr   = qw + (size_t)ch * QPB * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!IP) sx2 = dot4(xw[u], xw[u], sx2);
+#pragma unroll
+          for (int j = 0; j < QPB; ++j) dot[j] = dot4(xw[u], qr[j * 4 + u], dot[j]);
+        }
+        done = ch + 1;
+      }
+      // after an early stop the partial sums (all above every bound) stand in for the scores: rejected below
+#pragma unroll
+      for (int j = 0; j < QPB; ++j)
+        acc[j] = IP ? (float)dot[j] : (float)(iacc_t)(sx2 + (iacc_t)q2[(done - 1) * QPB + j] - 2 * dot[j]);
+    } else {
     for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
       if (!IP && !ALL && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
         bool below = false;
@@ -267,9 +354,9 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
         }
       }
     }
-    float acc[QPB];
 #pragma unroll
     for (int j = 0; j < QPB; ++j) acc[j] = accv[j >> 1][j & 1];
+    }
     if (METRIC == 2) {
       // cos = dot / (|q| * |x|); reported later as 1 - cos (post_process_compose)
       const float xn = sqrtf(xn2);
@@ -692,8 +779,14 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       switch (et) {
         case elem_t::f32: hipLaunchKernelGGL(flat_query_tiles_kernel<float>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const float*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
         case elem_t::f16: hipLaunchKernelGGL(flat_query_tiles_kernel<__half>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const __half*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
-        case elem_t::i8: hipLaunchKernelGGL(flat_query_tiles_kernel<int8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const int8_t*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
-        case elem_t::u8: hipLaunchKernelGGL(flat_query_tiles_kernel<uint8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const uint8_t*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data()); break;
+        case elem_t::i8:
+          if (!with_norms) hipLaunchKernelGGL(flat_query_tiles_int_kernel<int8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const int8_t*>(qptr), n_probes, idx.dim, idx.n_chunks, (size_t)(dim_pad + 1) * qpb, qtiles.data());
+          else hipLaunchKernelGGL(flat_query_tiles_kernel<int8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const int8_t*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data());
+          break;
+        case elem_t::u8:
+          if (!with_norms) hipLaunchKernelGGL(flat_query_tiles_int_kernel<uint8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const uint8_t*>(qptr), n_probes, idx.dim, idx.n_chunks, (size_t)(dim_pad + 1) * qpb, qtiles.data());
+          else hipLaunchKernelGGL(flat_query_tiles_kernel<uint8_t>, dim3(g), dim3(256), 0, res.stream, items.data(), n_all, sorted_pairs.data(), reinterpret_cast<const uint8_t*>(qptr), n_probes, idx.dim, dim_pad, with_norms, qtiles.data());
+          break;
       }
       a.qtiles = qtiles.data();
     }

@@ -168,6 +168,7 @@ def refine(dataset, queries, candidates, k, metric="sqeuclidean"):
 def ivf_flat_search(exported, queries, k, n_probes, metric="sqeuclidean", coarse_scale=1.0):
     """Search an index exported with cuvs_amd.neighbors.ivf_flat.export_for_oracle. `queries` in the index dtype;
     coarse_scale = 1/128 (int8) or 1/256 (uint8): the coarse quantizer sees mapped floats (ann_utils.cuh:134-196)."""
+    int_mode = int(np.asarray(queries).dtype in (np.int8, np.uint8) and metric != "cosine")
     q_raw = _f32(np.asarray(queries).astype(np.float32))
     q_coarse = _f32(q_raw * np.float32(coarse_scale))
     centers = _f32(exported["centers"])
@@ -181,7 +182,7 @@ def ivf_flat_search(exported, queries, k, n_probes, metric="sqeuclidean", coarse
     ds = np.empty((nq, k), np.float32)
     lib().oracle_ivf_flat_search(_p(q_coarse), _p(q_raw), C.c_int64(nq), C.c_int(q_raw.shape[1]), _p(centers),
                                  C.c_int(len(sizes)), _p(sizes), _p(start), _p(rows), _p(ids), C.c_int(_metric(metric)),
-                                 C.c_int(n_probes), C.c_int(k), _p(nb), _p(ds))
+                                 C.c_int(n_probes), C.c_int(k), C.c_int(int_mode), _p(nb), _p(ds))
     return ds, nb
 
 

@@ -2,7 +2,8 @@
  * oracle_ivf_flat.c — CPU twin of cuvsIvfFlatSearch on an exported index (TEST INFRASTRUCTURE ONLY).
  * Restates ivf_flat_search.cuh:104-187 (coarse search), interleaved_scan_impl.cuh:127-204 +
  * load_and_compute_dist_impl.cuh:690-738 + metric_impl.cuh:12-49 (per-row distance accumulated in
- * dimension order with fma; unexpanded L2 for both L2 variants; inner product), the n_probes*k merge
+ * dimension order with fma; unexpanded L2 for both L2 variants; inner product; int8 / uint8 rows accumulate in
+ * integers - metric_impl.cuh:12-49, dp4a - and the exact sum is converted to float once), the n_probes*k merge
  * (ivf_flat_search.cuh:273-295) and post-processing (post_process_impl.cuh:12-30).
  * Tie rules: per (query, probe) candidates ordered by (distance, flat row); merge by (distance, buffer
  * position) then ordered by (distance, flat row); flat row = 64-padded list offset + in-list position.
@@ -57,7 +58,7 @@ static void ins(fpair_t* best, int k, float d, int64_t id)
 EXPORT void oracle_ivf_flat_search(const float* queries_coarse, const float* queries_raw, int64_t nq, int dim,
                                    const float* centers, int n_lists, const uint32_t* list_sizes,
                                    const int64_t* list_start, const float* rows, const int64_t* ids, int metric,
-                                   int n_probes, int k, int64_t* neighbors, float* distances)
+                                   int n_probes, int k, int int_mode, int64_t* neighbors, float* distances)
 {
   const int is_ip = metric == 6, is_cos = metric == 2;
   if (n_probes > n_lists) n_probes = n_lists;
@@ -107,6 +108,11 @@ EXPORT void oracle_ivf_flat_search(const float* queries_coarse, const float* que
             float xn2 = 0.f;
             for (int d = 0; d < dim; ++d) { xn2 = fmaf(x[d], x[d], xn2); acc = fmaf(x[d], qr[d], acc); }
             acc = acc / (qn_fine * sqrtf(xn2));
+          } else if (int_mode) {  /* int8 / uint8: integer accumulator (exact), one conversion at the end */
+            int64_t ia = 0;
+            if (!is_ip) for (int d = 0; d < dim; ++d) { int64_t t = (int64_t)x[d] - (int64_t)qr[d]; ia += t * t; }
+            else        for (int d = 0; d < dim; ++d) ia += (int64_t)x[d] * (int64_t)qr[d];
+            acc = (float)ia;
           } else if (!is_ip) for (int d = 0; d < dim; ++d) { float t = x[d] - qr[d]; acc = fmaf(t, t, acc); }
           else               for (int d = 0; d < dim; ++d) acc = fmaf(x[d], qr[d], acc);
           ins(best, k, (is_ip || is_cos) ? -acc : acc, pad_off[L] + v);

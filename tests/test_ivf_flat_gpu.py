@@ -65,6 +65,30 @@ def test_other_dtypes_parity(dtype, scale):
     assert (gi == oi).all() and (gd == od).all()
 
 
+@pytest.mark.parametrize("dtype,scale", [(np.int8, 1 / 128), (np.uint8, 1 / 256)])
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
+@pytest.mark.parametrize("dim", [2500, 37])
+def test_int8_integer_accumulation(dtype, scale, metric, dim):
+    """int8 / uint8 rows: the reference accumulates in 32-bit integers (dp4a, metric_impl.cuh:12-49) and converts the
+    exact sum once. Full-range values at dim 2500 give sums far beyond 2^24, where an fp32 chain would round at every
+    step: ids and distances equal the integer oracle. dim 37: a partial last chunk."""
+    from cuvs_amd.neighbors import ivf_flat
+
+    rng = np.random.default_rng(dim)
+    lo, hi = (-128, 128) if dtype == np.int8 else (0, 256)
+    x = rng.integers(lo, hi, size=(3000, dim)).astype(dtype)
+    q = rng.integers(lo, hi, size=(60, dim)).astype(dtype)
+    x[10] = x[2000]  # ties
+    index = _build(x, n_lists=12, metric=metric, kmeans_n_iters=10)
+    gd, gi = _search(index, q, 10, 5)
+    ex = ivf_flat.export_for_oracle(index, dtype)
+    od, oi = oracle.ivf_flat_search(ex, q, 10, 5, metric=metric, coarse_scale=scale)
+    assert (gi == oi).all() and (gd == od).all()
+    if metric == "sqeuclidean" and dim == 2500:
+        exact = ((x[gi[:, 0]].astype(np.int64) - q.astype(np.int64)) ** 2).sum(1)
+        assert exact.max() > 2 ** 24 and (gd[:, 0] == exact.astype(np.float32)).all()
+
+
 def test_recall_threshold_and_structure():
     from cuvs_amd.neighbors import ivf_flat
 
