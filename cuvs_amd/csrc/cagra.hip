@@ -59,13 +59,13 @@ constexpr uint32_t kParentFlag  = 0x80000000u;
 // ------------------------------------------------------------------ graph optimisation
 // kern_fused_prune restated: one wave per node.
 __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__ knn, int64_t n, uint32_t K,
-                                                    uint32_t out_degree, uint32_t* __restrict__ out)
+                                                    uint32_t out_degree, uint32_t* __restrict__ out, int64_t nid0)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* s_idx = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 2 * K;
   uint32_t* s_det = s_idx + K;
-  const int64_t nid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nid = nid0 + (int64_t)blockIdx.x * 4 + wave;
   if (nid >= n) return;
   for (uint32_t k = lane; k < K; k += 64) {
     uint32_t v = knn[nid * K + k];
@@ -112,35 +112,49 @@ __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__
   }
 }
 
-// edge list in (rank-major, source-ascending) order: dest[e], e = k * n + src
-__global__ void edge_dest_kernel(const uint32_t* __restrict__ g, int64_t n, uint32_t degree, uint32_t* dest)
+// edge list of ranks [r0, r0 + nr) in (rank-major, source-ascending) order: dest[e], e = (k - r0) * n + src
+__global__ void edge_dest_kernel(const uint32_t* __restrict__ g, int64_t n, uint32_t degree, uint32_t r0, uint32_t nr,
+                                 uint32_t* dest)
 {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n * degree) return;
-  int64_t k = e / n, src = e % n;
+  if (e >= n * (int64_t)nr) return;
+  int64_t k = r0 + e / n, src = e % n;
   uint32_t d = g[src * degree + k];
   dest[e]    = d < n ? d : (uint32_t)(n);  // invalid edges go to the extra bucket n
 }
 
+// the first `degree` reverse edges of every node in (rank, source) order, collected rank chunk by rank chunk (a chunk
+// holds fewer than 2^32 edges, so n * degree itself is not bounded)
+__global__ void append_reverse_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ off, int64_t n,
+                                      uint32_t degree, uint32_t* __restrict__ rev, uint32_t* __restrict__ rev_cnt)
+{
+  const int64_t nid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (nid >= n) return;
+  const uint32_t b = off[nid], e = off[nid + 1];
+  const uint32_t c = rev_cnt[nid];
+  const uint32_t take = min(e - b, degree - c);
+  for (uint32_t t = 0; t < take; ++t) rev[(size_t)nid * degree + c + t] = perm[b + t] % (uint32_t)n;  // source node
+  rev_cnt[nid] = c + take;
+}
+
 // kern_merge_graph restated (no MST): keep the first degree/2 forward edges, insert reverse edges behind them.
 __global__ __launch_bounds__(256) void merge_graph_kernel(uint32_t* __restrict__ g, int64_t n, uint32_t degree,
-                                                          const uint32_t* __restrict__ rev_perm,
-                                                          const uint32_t* __restrict__ rev_off)
+                                                          const uint32_t* __restrict__ rev,
+                                                          const uint32_t* __restrict__ rev_cnt, int64_t nid0)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* row  = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * degree;
-  const int64_t nid = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nid = nid0 + (int64_t)blockIdx.x * 4 + wave;
   if (nid >= n) return;
   for (uint32_t i = lane; i < degree; i += 64) row[i] = g[nid * degree + i];
   __builtin_amdgcn_wave_barrier();
   const uint32_t prot = degree / 2;
   if (prot < degree) {
-    const uint32_t b = rev_off[nid], e = rev_off[nid + 1];
-    uint32_t kr = min(e - b, degree);
+    uint32_t kr = min(rev_cnt[nid], degree);
     while (kr) {
       kr -= 1;
-      const uint32_t rv = rev_perm[b + kr] % (uint32_t)n;  // source node of the kr-th reverse edge
+      const uint32_t rv = rev[(size_t)nid * degree + kr];  // source node of the kr-th reverse edge
       // position of rv in the row (degree if absent)
       uint32_t pos = degree;
       for (uint32_t i = lane; i < degree; i += 64)
@@ -251,17 +265,30 @@ void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, 
 {
   CUVS_EXPECTS(degree <= K, "graph_degree (%u) must not exceed intermediate_graph_degree (%u)", degree, K);
   CUVS_EXPECTS(degree <= 256 && K <= 1024, "cagra: degree <= 256 and intermediate degree <= 1024 supported");
-  CUVS_EXPECTS(n * (int64_t)degree < (int64_t(1) << 32), "cagra: n * degree must be below 2^32");
+  CUVS_EXPECTS(n < (int64_t(1) << 32) - 1, "cagra: at most 2^32 - 2 rows (uint32 graph)");
   size_t smem = (size_t)4 * 2 * K * sizeof(uint32_t);
-  hipLaunchKernelGGL(prune_kernel, dim3(grid_blocks(n, 4)), dim3(256), smem, res.stream, knn, n, K, degree, graph);
-  // reverse edges grouped by destination, ordered by (rank, source)
-  const int64_t n_edges = n * degree;
-  dev_buf<uint32_t> dest(res, n_edges), perm(res, n_edges), off(res, n + 2);
-  hipLaunchKernelGGL(edge_dest_kernel, dim3(grid_blocks(n_edges, 256)), dim3(256), 0, res.stream, graph, n, degree,
-                     dest.data());
-  group_by_label(res, dest.data(), n_edges, (uint32_t)(n + 1), perm.data(), off.data());
-  hipLaunchKernelGGL(merge_graph_kernel, dim3(grid_blocks(n, 4)), dim3(256), (size_t)4 * degree * sizeof(uint32_t),
-                     res.stream, graph, n, degree, perm.data(), off.data());
+  const int64_t slab = int64_t(1) << 25;  // rows per launch of the wave-per-row kernels (2^23 workgroups)
+  for (int64_t r0 = 0; r0 < n; r0 += slab)
+    hipLaunchKernelGGL(prune_kernel, dim3(grid_blocks(std::min(slab, n - r0), 4)), dim3(256), smem, res.stream, knn, n, K, degree,
+                       graph, r0);
+  // reverse edges grouped by destination, ordered by (rank, source): the edge list is sorted a chunk of ranks at a
+  // time (a chunk stays below 2^32 edges; 100M rows x degree 64 takes two)
+  uint32_t ranks = (uint32_t)std::min<int64_t>(degree, std::max<int64_t>(1, ((int64_t(1) << 32) - 1024) / n));
+  if (const char* e = getenv("CUVS_AMD_CAGRA_RANK_CHUNK")) ranks = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)degree));
+  const int64_t chunk_edges = n * (int64_t)ranks;
+  dev_buf<uint32_t> dest(res, chunk_edges), perm(res, chunk_edges), off(res, n + 2), rev(res, (size_t)n * degree), rev_cnt(res, n);
+  HIP_TRY(hipMemsetAsync(rev_cnt.data(), 0, rev_cnt.bytes(), res.stream));
+  for (uint32_t r0 = 0; r0 < degree; r0 += ranks) {
+    const uint32_t nr = std::min(ranks, degree - r0);
+    hipLaunchKernelGGL(edge_dest_kernel, dim3(grid_blocks(n * (int64_t)nr, 256)), dim3(256), 0, res.stream, graph, n, degree,
+                       r0, nr, dest.data());
+    group_by_label(res, dest.data(), n * (int64_t)nr, (uint32_t)(n + 1), perm.data(), off.data());
+    hipLaunchKernelGGL(append_reverse_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, perm.data(), off.data(), n,
+                       degree, rev.data(), rev_cnt.data());
+  }
+  for (int64_t r0 = 0; r0 < n; r0 += slab)
+    hipLaunchKernelGGL(merge_graph_kernel, dim3(grid_blocks(std::min(slab, n - r0), 4)), dim3(256),
+                       (size_t)4 * degree * sizeof(uint32_t), res.stream, graph, n, degree, rev.data(), rev_cnt.data(), r0);
   HIP_TRY(hipGetLastError());
 }
 
@@ -939,7 +966,7 @@ void cagra_extend(resources& res, cagra_index& idx, const void* new_rows, bool n
 {
   if (m == 0) return;
   CUVS_EXPECTS(idx.data != nullptr && idx.graph.data() != nullptr, "cagra::extend: index has no graph/dataset");
-  CUVS_EXPECTS((idx.n + m) * (int64_t)idx.degree < (int64_t(1) << 32), "cagra: n * degree must be below 2^32");
+  CUVS_EXPECTS(idx.n + m < (int64_t(1) << 32) - 1, "cagra: at most 2^32 - 2 rows (uint32 graph)");
   const size_t esz = elem_size(idx.dtype), row_bytes = (size_t)idx.dim * esz;
   const int64_t n0 = idx.n, n1 = idx.n + m;
   auto data  = dev_buf<char>::persistent((size_t)n1 * row_bytes);

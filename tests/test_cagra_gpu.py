@@ -103,6 +103,18 @@ def test_graph_invariants_and_int64_neighbors():
     assert ((i2.cpu().numpy().astype(np.int64) & 0xFFFFFFFF) == i.cpu().numpy()).all()
 
 
+def test_reverse_edges_in_rank_chunks(monkeypatch):
+    """The reverse-edge lists are collected a chunk of ranks at a time (so that n * degree may exceed 2^32): any chunk
+    size gives the graph of the one-pass sort."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((4000, 24)).astype(np.float32)
+    g0 = _build(x, intermediate_graph_degree=32, graph_degree=16).graph.cpu().numpy()
+    for chunk in ("1", "5"):
+        monkeypatch.setenv("CUVS_AMD_CAGRA_RANK_CHUNK", chunk)
+        g1 = _build(x, intermediate_graph_degree=32, graph_degree=16).graph.cpu().numpy()
+        assert (g0 == g1).all()
+
+
 @pytest.mark.parametrize("algo", ["multi_cta", "auto"])
 @pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
 def test_multi_wave_search_small_batch(algo, metric):
