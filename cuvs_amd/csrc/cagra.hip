@@ -350,7 +350,33 @@ __device__ inline void team_distances(const T* __restrict__ data, int64_t dim, c
     float acc           = 0.f;
     if (ok) {
       const T* row = data + (int64_t)node * dim;
-      for (int64_t d0 = (int64_t)tl * VL; d0 < dim; d0 += 8 * VL) {
+      int64_t d0   = (int64_t)tl * VL;
+      auto accumulate = [&](const uint4& w, const int64_t dd) {
+        const T* el = reinterpret_cast<const T*>(&w);
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+          const float x = to_float(el[e]), q = qf[dd + e];
+          if (is_ip) {
+            acc = __fmaf_rn(x, q, acc);
+          } else {
+            float t = x - q;
+            acc     = __fmaf_rn(t, t, acc);
+          }
+        }
+      };
+      if (vec) {
+        // four 16-byte pieces in flight per lane (the walk is bound by the latency of these dependent row gathers);
+        // the pieces are accumulated in the same order as one at a time
+        constexpr int64_t S = 8 * VL;
+        for (; d0 + 3 * S < dim; d0 += 4 * S) {
+          const uint4 w0 = *reinterpret_cast<const uint4*>(row + d0);
+          const uint4 w1 = *reinterpret_cast<const uint4*>(row + d0 + S);
+          const uint4 w2 = *reinterpret_cast<const uint4*>(row + d0 + 2 * S);
+          const uint4 w3 = *reinterpret_cast<const uint4*>(row + d0 + 3 * S);
+          accumulate(w0, d0); accumulate(w1, d0 + S); accumulate(w2, d0 + 2 * S); accumulate(w3, d0 + 3 * S);
+        }
+      }
+      for (; d0 < dim; d0 += 8 * VL) {
         T el[VL];
         if (vec) {
           *reinterpret_cast<uint4*>(el) = *reinterpret_cast<const uint4*>(row + d0);
