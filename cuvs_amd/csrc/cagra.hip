@@ -237,14 +237,17 @@ void knn_graph_ivf_pq(resources& res, const void* data, elem_t et, int64_t n, in
   bp.kmeans_trainset_fraction = std::min(1.0, std::max(0.02, 2.0e6 / (double)n));
   bp.pq_bits                  = 8;
   bp.pq_dim                   = (uint32_t)std::max<int64_t>(8, std::min<int64_t>(64, round_up(dim / 2, 8)));
+  if (const char* e = getenv("CUVS_AMD_CAGRA_PQ_LISTS")) bp.n_lists = (uint32_t)std::max(1, atoi(e));
   auto pq = ivf_pq_build(res, bp, data, et, n, dim, false);
   ivf_pq_search_params sp;
   sp.n_probes                = std::max<uint32_t>(8, bp.n_lists / 50);
+  if (const char* e = getenv("CUVS_AMD_CAGRA_PQ_PROBES")) sp.n_probes = (uint32_t)std::max(1, atoi(e));
   sp.lut_dtype               = 2;
   sp.internal_distance_dtype = 2;
   sp.max_internal_batch_size = 16384;
   const int kp1   = (int)K + 1;
-  const int k_pq  = std::min(256, 2 * kp1);
+  int k_pq        = std::min(256, 2 * kp1);
+  if (const char* e = getenv("CUVS_AMD_CAGRA_KPQ")) k_pq = std::max(kp1, std::min(256, atoi(e)));
   const int64_t b = 16384;
   dev_buf<int64_t> cand(res, (size_t)b * k_pq), ri(res, (size_t)b * kp1);
   dev_buf<float> cd(res, (size_t)b * k_pq), rd(res, (size_t)b * kp1);
