@@ -91,6 +91,8 @@ void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data,
 // [n_take, ceil(pq_dim*pq_bits/8)] contiguous bit-packed codes of list `label` starting at `offset`
 // shard_comm.hip: in-place min over all ranks of `count` order-preserving bound keys, on the stream of `res`
 void shard_allreduce_min_u32(resources& res, void* comm, uint32_t* keys, size_t count);
+// in-place all-gather: rank r's `count` words already sit at buf + r * count; afterwards every rank holds all blocks
+void shard_allgather_inplace_u32(resources& res, void* comm, uint32_t* buf, size_t count);
 
 void ivf_pq_unpack_list(resources& res, const ivf_pq_index& idx, uint32_t label, uint32_t offset,
                         uint32_t n_take, uint8_t* out);

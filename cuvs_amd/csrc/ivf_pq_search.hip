@@ -1644,7 +1644,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<float> qf(res, (size_t)bs_alloc * idx.dim);
   dev_buf<float> rot_q(res, (size_t)bs_alloc * idx.rot_dim);
   dev_buf<float> qc(res, p.coarse_search_dtype != 0 ? (size_t)bs_alloc * idx.dim : 0);  // queries in the coarse type
-  dev_buf<uint32_t> probes(res, (size_t)n_pairs_max);
+  dev_buf<uint32_t> probes(res, (size_t)n_pairs_max + (size_t)std::max(1, idx.shard_world) * n_probes);  // + slice padding
   // Two-phase schedule: the `head` nearest probes of every query are scanned first (labels 0..n_lists-1), the
   // rest afterwards (labels n_lists..2 n_lists-1). After the head phase each query's k-th bound (query_kth) is
   // already close to final, which is what makes the early stop in the scan loop bite. Results do not depend on
@@ -1676,7 +1676,22 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     const int64_t n_pairs = nq * n_probes;
     load_range_as_float(res, queries, et, q_is_host, idx.dim, q0, nq, qf.data());
     if (idx.metric == M_CosineExpanded) normalize_rows(res, qf.data(), nq, idx.dim);
-    select_clusters(res, idx, qf.data(), nq, n_probes, probes.data(), p.coarse_search_dtype, qc.data());
+    // list-sharded index with a communicator: the coarse search is sharded by QUERY - this rank ranks the lists for its
+    // slice of the batch and one all-gather of the probe lists (n_probes x 4 B per query) replaces world - 1 replicas of
+    // the coarse GEMM + select_k (the same deterministic kernels on the same inputs: identical probes)
+    const bool shard_coarse = idx.shard_comm != nullptr && p.coarse_search_dtype == 0 &&  // (one rank: the same calls)
+                              getenv("CUVS_AMD_SHARD_COARSE_REPLICATED") == nullptr;
+    if (shard_coarse) {
+      const int64_t slice = (nq + idx.shard_world - 1) / idx.shard_world;
+      const int64_t s0    = std::min<int64_t>(nq, (int64_t)idx.shard_rank * slice);
+      const int64_t s1    = std::min<int64_t>(nq, s0 + slice);
+      if (s1 > s0)
+        select_clusters(res, idx, qf.data() + s0 * idx.dim, s1 - s0, n_probes,
+                        probes.data() + (size_t)idx.shard_rank * slice * n_probes, 0, qc.data());
+      shard_allgather_inplace_u32(res, idx.shard_comm, probes.data(), (size_t)slice * n_probes);
+    } else {
+      select_clusters(res, idx, qf.data(), nq, n_probes, probes.data(), p.coarse_search_dtype, qc.data());
+    }
     rotate_queries(res, idx, qf.data(), qc.data(), nq, p.coarse_search_dtype, rot_q.data());  // ivf_pq_search.cuh:995-1017
     if (p.coarse_search_dtype != 0 && idx.metric == M_CosineExpanded) normalize_rows(res, rot_q.data(), nq, idx.rot_dim);
     // list-major grouping of the (query, probe) pairs

@@ -134,6 +134,15 @@ void shard_allreduce_min_u32(resources& res, void* comm, uint32_t* keys, size_t 
   profile_end(res, "shard_all_reduce");
 }
 
+void shard_allgather_inplace_u32(resources& res, void* comm, uint32_t* buf, size_t count)
+{
+  auto* c = static_cast<cuvsAmdShardComm*>(comm);
+  if (c == nullptr || count == 0) return;
+  profile_begin(res, "shard_all_gather_probes");
+  RCCL_TRY(rccl().all_gather(buf + (size_t)c->rank * count, buf, count, ncclUint32, c->comm, res.stream));
+  profile_end(res, "shard_all_gather_probes");
+}
+
 }  // namespace cuvs_amd
 
 using namespace cuvs_amd;
