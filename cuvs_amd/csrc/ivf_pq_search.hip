@@ -349,7 +349,9 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
   const bool statc = (a.dbg & 512) != 0;  // row counters: atomics per tile (slow; counts only)
   // every wave owns a row of counters (no contention); the host sums the rows
   auto stat_add = [&](int which, unsigned long long v) {
-    if (lane == 0) a.stats[((size_t)blockIdx.x * kScanWaves + wave) * ST_COUNT + which] += v;
+    // fire-and-forget atomic on the wave's private slot: a plain += would wait (vmcnt) for every load in flight - e.g. the
+    // prefetched code loads - and book their latency to the phase being closed
+    if (lane == 0) atomicAdd(&a.stats[((size_t)blockIdx.x * kScanWaves + wave) * ST_COUNT + which], v);
   };
   unsigned long long t_prev = stat ? __builtin_readcyclecounter() : 0ull, t_s2 = 0ull;
   auto stat_phase = [&](int which) {
@@ -991,7 +993,9 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
 
   const bool stat = (a.dbg & 128) != 0;
   auto stat_add = [&](int which, unsigned long long v) {
-    if (lane == 0) a.stats[((size_t)blockIdx.x * kScanWaves + wave) * ST_COUNT + which] += v;
+    // fire-and-forget atomic on the wave's private slot: a plain += would wait (vmcnt) for every load in flight - e.g. the
+    // prefetched code loads - and book their latency to the phase being closed
+    if (lane == 0) atomicAdd(&a.stats[((size_t)blockIdx.x * kScanWaves + wave) * ST_COUNT + which], v);
   };
   unsigned long long t_prev = stat ? __builtin_readcyclecounter() : 0ull;
   auto stat_phase = [&](int which) {
@@ -1049,8 +1053,9 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
   stat_phase(ST_LUT);
+  __syncthreads();
+  stat_phase(ST_ALIVE1);  // (pq_scan2: barrier wait after the filter LUT build)
 
   // header of the workgroup's next item (its ticket was drawn at the start of this item)
   uint4 next_hdr = make_uint4(0u, 0u, 0u, 0xffffffffu);
@@ -1142,6 +1147,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   }
   if (stat) { stat_phase(ST_SCAN); if (wave == 0) { stat_add(ST_ROWS, len); stat_add(ST_ITEMS, 1); } }
   __syncthreads();
+  stat_phase(ST_ALIVE2);  // (pq_scan2: barrier wait after the filter pass)
   if (stat && wave == 0) stat_add(ST_QUEUED, ctrl[17] + ctrl[18]);
 
   // ---- exact passes
@@ -1172,7 +1178,9 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     bool valid0 = false;
     uint32_t v0 = 0u;
     if ((uint32_t)wave < n_bat) { v0 = batch_row(wave, valid0); load_codes(v0, cur); }
+    stat_phase(ST_MERGE);
     if (g > 0) __syncthreads();  // every wave is done with the previous LUT / merge area
+    stat_phase(ST_S2_CALLS);  // (pq_scan2: barrier wait before the second exact LUT build)
     // ---- exact LUT of the group's EQ queries (same arithmetic and layout as pq_scan_kernel)
     if (!(a.dbg & 1)) {
 #pragma unroll
@@ -1201,8 +1209,9 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     }
 #pragma unroll
     for (int j = 0; j < EQ; ++j) top[j].init();
-    __syncthreads();
     stat_phase(ST_LUT);
+    __syncthreads();
+    stat_phase(ST_ALIVE3);  // (pq_scan2: barrier wait after an exact LUT build)
 
     for (uint32_t b = wave; b < n_bat; b += kScanWaves) {
       bool valid = valid0;
@@ -1273,9 +1282,10 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
       }
     }
     stat_phase(ST_STAGE2);
-    if (a.dbg & 32) continue;  // dbg 32: no merge / output
+    if (a.dbg & (32 | 2048)) continue;  // dbg 32: no merge / output; 2048: in this kernel only (the head phase still warms the bounds)
     // ---- merge the 16 wave lists of the group's queries (the LUT region is free once every wave is here)
     __syncthreads();
+    stat_phase(ST_CAND);  // (pq_scan2: barrier wait after an exact pass)
     {
       uint32_t any_ins = 0u;
 #pragma unroll
@@ -1781,6 +1791,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
               h[ST_ITEMS], h[ST_ROWS], h[ST_QUEUED], 100.0 * h[ST_QUEUED] / (double)std::max<unsigned long long>(1, h[ST_ROWS]),
               h[ST_S2_CALLS], h[ST_ALIVE1], h[ST_ALIVE2], h[ST_ALIVE3], h[ST_HEADER] * w, h[ST_LUT] * w, h[ST_SCAN] * w,
               h[ST_STAGE2] * w, (double)(h[ST_MERGE] - h[ST_HEADER] - h[ST_LUT] - h[ST_SCAN]) * w);
+      fprintf(stderr, "[pq_scan2 waits, cycles per wave] after filter LUT %.3g, after filter pass %.3g, before LUT B %.3g, after exact LUT "
+              "%.3g, after exact pass %.3g, merge %.3g\n", h[ST_ALIVE1] * w, h[ST_ALIVE2] * w, h[ST_S2_CALLS] * w, h[ST_ALIVE3] * w,
+              h[ST_CAND] * w, h[ST_MERGE] * w);
     }
     // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
     if (!large_k) {
