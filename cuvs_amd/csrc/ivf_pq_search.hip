@@ -405,22 +405,12 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         for (int t = 0; t < 4; ++t) {
           const float p0 = pqreg[sg][0][t], p1 = pqreg[sg][1][t];
           float sc[QPB];
-          if constexpr (false && QPB % 2 == 0) {  // packed fp32 pairs cost ~50 spilled VGPRs here
-            // two queries per packed fp32 instruction: lane by lane the same IEEE operations as the scalar form
+          // (packed fp32 pairs - v_pk_add_f32 / v_pk_fma_f32 - were measured here: ~50 spilled VGPRs, slower)
 #pragma unroll
-            for (int j = 0; j < QPB; j += 2) {
-              const f32x2_t d0 = f32x2_t{q[0][j], q[0][j + 1]} - p0;
-              const f32x2_t d1 = f32x2_t{q[1][j], q[1][j + 1]} - p1;
-              const f32x2_t r  = __builtin_elementwise_fma(d1, d1, d0 * d0);
-              sc[j] = r.x; sc[j + 1] = r.y;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < QPB; ++j) {
-              float d0 = q[0][j] - p0;
-              float d1 = q[1][j] - p1;
-              sc[j]    = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-            }
+          for (int j = 0; j < QPB; ++j) {
+            float d0 = q[0][j] - p0;
+            float d1 = q[1][j] - p1;
+            sc[j]    = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
           }
           cm_lut<entry_t>::store(s, t * 64 + lane, acc_t::pack(sc));  // pq_in_regs implies FAST4
           __builtin_amdgcn_sched_barrier(0);
