@@ -191,6 +191,41 @@ __device__ inline float fp8_round_trip(float v, bool is_signed)
 }
 
 // dbg 128 statistics (CUVS_AMD_SCAN_DEBUG=128 prints them per search): wave cycles per phase, rows per stage
+// Top-kp2 of n_l sorted lists (n_l a power of two) by the whole workgroup, in place in LDS: lists l and l + w merge
+// into l - C[r] = min(A[r], B[kp2 - 1 - r]) is bitonic and holds the kp2 best of the pair, log2(kp2) compare-exchange
+// stages sort it - for w = 1, 2, 4, ... Order: (distance, id) ascending, invalid entries (id 0xffffffff, +inf) last, the
+// order of the wave lists. Serial insertion of 16 x 256 candidates by one wave took 300 k cycles per work item in the
+// kNN-graph searches of the CAGRA build (k = 256); this takes a few thousand. All threads of the workgroup call it.
+template <int NT>
+__device__ inline void merge_sorted_lists(float* __restrict__ d, uint32_t* __restrict__ id, const int n_l, const int kp2,
+                                          const int tid)
+{
+  auto less = [](const float da, const uint32_t ia, const float db, const uint32_t ib) {
+    return da < db || (da == db && ia < ib);
+  };
+  for (int w = 1; w < n_l; w <<= 1) {
+    const int pairs = n_l / (2 * w);
+    for (int t = tid; t < pairs * kp2; t += NT) {
+      const int pr = t / kp2, r = t % kp2;
+      const int ia = pr * 2 * w * kp2 + r, ib = (pr * 2 * w + w) * kp2 + (kp2 - 1 - r);
+      const float da = d[ia], db = d[ib];
+      const uint32_t xa = id[ia], xb = id[ib];
+      if (less(db, xb, da, xa)) { d[ia] = db; id[ia] = xb; }
+    }
+    __syncthreads();
+    for (int stride = kp2 >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < pairs * (kp2 >> 1); t += NT) {
+        const int pr = t / (kp2 >> 1), x = t % (kp2 >> 1);
+        const int lo = pr * 2 * w * kp2 + 2 * x - (x & (stride - 1)), hi = lo + stride;
+        const float da = d[lo], db = d[hi];
+        const uint32_t xa = id[lo], xb = id[hi];
+        if (less(db, xb, da, xa)) { d[lo] = db; id[lo] = xb; d[hi] = da; id[hi] = xa; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QUEUED, ST_S2_CALLS, ST_ALIVE1, ST_ALIVE2,
                  ST_ALIVE3, ST_CAND, ST_ITEMS, ST_COUNT };
 
@@ -452,26 +487,37 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int j = 0; j < QPB; ++j) sc[t][j] = 0.f;
-        for (uint32_t l = 0; l < a.pq_len; ++l) {
-          const uint32_t dd = s * a.pq_len + l;
-          float q[QPB];
+        // the codebook values of FOUR components are loaded before any is used (the build of a pq_len = 12 LUT was a chain
+        // of 12 dependent L2 latencies per subspace); components are accumulated in the same order
+        for (uint32_t l0 = 0; l0 < a.pq_len; l0 += 4) {
+          float p[4][4];
 #pragma unroll
-          for (int j = 0; j < QPB; ++j) q[j] = qv[j * a.rot_dim + dd];
-          const float cc   = cv[dd];
-          const float* pqr = a.pq_centers + (size_t)(a.per_cluster ? L * a.pq_len + l : dd) * book + c0 + lane;
-          float p[4];
+          for (int li = 0; li < 4; ++li) {
+            const uint32_t l  = min(l0 + li, a.pq_len - 1);
+            const uint32_t dd = s * a.pq_len + l;
+            const float* pqr  = a.pq_centers + (size_t)(a.per_cluster ? L * a.pq_len + l : dd) * book + c0 + lane;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) p[t] = (c0 + t * 64 < book) ? pqr[t * 64] : 0.f;
+            for (int t = 0; t < 4; ++t) p[li][t] = (c0 + t * 64 < book) ? pqr[t * 64] : 0.f;
+          }
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int li = 0; li < 4; ++li) {
+            if (l0 + li >= a.pq_len) break;  // wave-uniform
+            const uint32_t dd = s * a.pq_len + l0 + li;
+            float q[QPB];
 #pragma unroll
-            for (int j = 0; j < QPB; ++j) {
-              if (!a.is_ip) {
-                float diff = q[j] - p[t];
-                sc[t][j]   = __fmaf_rn(diff, diff, sc[t][j]);
-              } else {
-                sc[t][j] = __fmaf_rn(-q[j], cc, sc[t][j]);
-                sc[t][j] = __fmaf_rn(-q[j], p[t], sc[t][j]);
+            for (int j = 0; j < QPB; ++j) q[j] = qv[j * a.rot_dim + dd];
+            const float cc = cv[dd];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+              for (int j = 0; j < QPB; ++j) {
+                if (!a.is_ip) {
+                  float diff = q[j] - p[li][t];
+                  sc[t][j]   = __fmaf_rn(diff, diff, sc[t][j]);
+                } else {
+                  sc[t][j] = __fmaf_rn(-q[j], cc, sc[t][j]);
+                  sc[t][j] = __fmaf_rn(-q[j], p[li][t], sc[t][j]);
+                }
               }
             }
           }
@@ -795,6 +841,34 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 #pragma unroll
     for (int j = 0; j < QPB; ++j) any_ins |= kthb[8 + j];
     if (any_ins == 0u) return;  // workgroup-uniform: nothing to merge for this item
+  }
+  if constexpr (E > 1) {
+    // k > 64: the wave lists (sorted, rank e * 64 + lane) are merged by the whole workgroup, one query after the other
+    constexpr int KP2 = E == 2 ? 128 : 256;  // E = 2: k <= 128, E = 4: k <= 256
+    float* sd    = reinterpret_cast<float*>(smem);
+    uint32_t* si = reinterpret_cast<uint32_t*>(smem + (size_t)kScanWaves * KP2 * 4);
+    for (int j = 0; j < QPB; ++j) {
+      if (j >= (int)item.count || kthb[8 + j] == 0u) continue;  // workgroup-uniform
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int r = e * 64 + lane;
+        const bool in = r < (int)a.k;
+        sd[wave * KP2 + r] = in ? top[j].d[e] : INFINITY;
+        si[wave * KP2 + r] = in ? top[j].i[e] : 0xffffffffu;
+      }
+      __syncthreads();
+      merge_sorted_lists<kScanThreads>(sd, si, kScanWaves, KP2, tid);
+      const size_t o = (size_t)pid[j] * a.k;
+      for (int r = tid; r < (int)a.k; r += kScanThreads) {
+        const bool ok  = si[r] != 0xffffffffu;
+        a.out_d[o + r] = ok ? sd[r] : FLT_MAX;
+        a.out_i[o + r] = ok ? base_row + si[r] : 0xffffffffu;
+      }
+      if (tid == 0 && si[a.k - 1] != 0xffffffffu && sd[a.k - 1] < INFINITY)
+        atomicMin(&a.query_kth[pid[j] / a.n_probes], float_to_key(sd[a.k - 1]));
+      __syncthreads();  // the next query reuses the area
+    }
+    return;
   }
 #pragma unroll
   for (int j = 0; j < QPB; ++j) {

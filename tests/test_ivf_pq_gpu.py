@@ -58,7 +58,8 @@ def _min_recall(n_probes, n_lists, dim, pq_dim, pq_bits, elem_bytes=4):
     (3000, 30, 20, 10, 8, 10, 20),     # pq_len 3, rot_dim == dim
     (5000, 33, 16, 8, 8, 7, 5),        # rot_dim 40 != dim 33 -> random rotation
     (4096, 64, 32, 64, 5, 16, 6),      # 5-bit codes (generic bit path), pq_len 1
-    (2048, 128, 8, 64, 8, 100, 8),     # k > 64 (4 ranks per lane)
+    (2048, 128, 8, 64, 8, 100, 8),     # k > 64 (2 ranks per lane, workgroup merge of the wave lists)
+    (3000, 64, 8, 16, 8, 200, 8),      # k > 128 (4 ranks per lane)
 ])
 def test_search_parity_with_oracle_on_same_index(metric, n, d, n_lists, pq_dim, pq_bits, k, n_probes):
     from cuvs_amd.neighbors import ivf_pq
