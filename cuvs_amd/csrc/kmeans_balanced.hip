@@ -53,9 +53,12 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* co
   if (threadIdx.x == 0) offsets[n] = (uint32_t)carry;
 }
 
-// One workgroup per cluster: mean of the rows perm[offsets[c] .. offsets[c+1]) in a fixed order
-// (4 waves stride over the rows; partial sums combined wave 0..3). Empty cluster -> zeros
-// (reference: div_checkzero_op).
+// One workgroup per cluster: mean of the rows perm[offsets[c] .. offsets[c+1]) in a fixed order. Row j of the cluster
+// goes to slot (j - b) % S; a slot adds its rows in ascending order and the S partial sums are combined
+// (((p0 + p1) + p2) + ...) - oracle_kmeans.c restates exactly this. S = 4 waves x R rows per wave step, R = 64 / dp for
+// dim <= 32 (dp = dim rounded up to a power of two): the 12-dimensional rows of PQ codebook training used 12 of 64
+// lanes per step. Four row loads are in flight per lane (gathers of short rows are latency-bound).
+// Empty cluster -> zeros (reference: div_checkzero_op).
 __global__ __launch_bounds__(256) void cluster_means_kernel(const float* __restrict__ x, int64_t ld, int dim,
                                                             const uint32_t* __restrict__ perm,
                                                             const uint32_t* __restrict__ offsets,
@@ -69,16 +72,32 @@ __global__ __launch_bounds__(256) void cluster_means_kernel(const float* __restr
   const uint32_t b = offsets[c], e = offsets[c + 1];
   const uint32_t cnt = e - b;
   if (threadIdx.x == 0) sizes[c] = cnt;
-  for (int d0 = 0; d0 < dim; d0 += 64) {
-    const int d = d0 + lane;
+  int dp = 64, R = 1;
+  if (dim <= 32) {
+    dp = 1;
+    while (dp < dim) dp <<= 1;
+    R = 64 / dp;
+  }
+  const uint32_t S = 4u * (uint32_t)R;
+  const int r = lane / dp, dl = lane % dp;
+  for (int d0 = 0; d0 < dim; d0 += dp) {
+    const int d = d0 + dl;
     float acc   = 0.f;
     if (d < dim) {
-      for (uint32_t j = b + wave; j < e; j += 4) acc += x[(int64_t)perm[j] * ld + d];
+      uint32_t j = b + (uint32_t)(wave * R + r);
+      for (; j + 3 * S < e; j += 4 * S) {
+        const uint32_t p0 = perm[j], p1 = perm[j + S], p2 = perm[j + 2 * S], p3 = perm[j + 3 * S];
+        const float v0 = x[(int64_t)p0 * ld + d], v1 = x[(int64_t)p1 * ld + d], v2 = x[(int64_t)p2 * ld + d],
+                    v3 = x[(int64_t)p3 * ld + d];
+        acc += v0; acc += v1; acc += v2; acc += v3;
+      }
+      for (; j < e; j += S) acc += x[(int64_t)perm[j] * ld + d];
     }
     part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && d < dim) {
-      float s = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (wave == 0 && r == 0 && d < dim) {
+      float s = part[0][dl];
+      for (uint32_t slot = 1; slot < S; ++slot) s = s + part[slot / R][(slot % R) * dp + dl];
       centers[(int64_t)c * dim + d] = cnt ? s / (float)cnt : 0.f;
     }
     __syncthreads();

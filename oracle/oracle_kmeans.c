@@ -6,7 +6,7 @@
  * :253-315 (mean per cluster, empty -> 0), arrange_fine_clusters :786-848, build_hierarchical :986-1148.
  * Two deliberate differences from the reference, shared with the HIP code so that results are reproducible:
  * the row that re-seeds a small cluster is chosen from a per-cluster sequence instead of a racing atomic
- * counter, and means are summed in a fixed order (4 strided partial sums per cluster and dimension).
+ * counter, and means are summed in a fixed order (S strided partial sums per cluster and dimension).
  */
 #include <math.h>
 #include <stdint.h>
@@ -48,7 +48,8 @@ static void predict(const float* x, int64_t n, int64_t ld, int dim, const float*
   free(cn);
 }
 
-/* M-step: rows of a cluster in ascending id; 4 strided partial sums combined ((p0+p1)+p2)+p3 */
+/* M-step: rows of a cluster in ascending id; S strided partial sums combined ((p0+p1)+p2)+... with S = 4 for
+ * dim > 32 and 4 * 64 / pow2ceil(dim) below (kmeans_balanced.hip cluster_means_kernel: rows per wave step) */
 static void calc_centers_and_sizes(const float* x, int64_t n, int64_t ld, int dim, int k, const uint32_t* labels,
                                    float* centers, uint32_t* sizes)
 {
@@ -63,11 +64,17 @@ static void calc_centers_and_sizes(const float* x, int64_t n, int64_t ld, int di
   for (int c = 0; c < k; ++c) {
     int64_t b = off[c], e = off[c + 1];
     sizes[c]  = (uint32_t)(e - b);
+    int dp = 64, R = 1;
+    if (dim <= 32) { dp = 1; while (dp < dim) dp <<= 1; R = 64 / dp; }
+    const int S = 4 * R;
     for (int d = 0; d < dim; ++d) {
-      float p[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int w = 0; w < 4; ++w)
-        for (int64_t j = b + w; j < e; j += 4) p[w] += x[perm[j] * ld + d];
-      float s = ((p[0] + p[1]) + p[2]) + p[3];
+      float p[256];
+      for (int w = 0; w < S; ++w) {
+        p[w] = 0.f;
+        for (int64_t j = b + w; j < e; j += S) p[w] += x[perm[j] * ld + d];
+      }
+      float s = p[0];
+      for (int w = 1; w < S; ++w) s = s + p[w];
       centers[(int64_t)c * dim + d] = (e > b) ? s / (float)(e - b) : 0.f;
     }
   }
