@@ -255,6 +255,10 @@ struct scan_args {
   size_t scores_ld;
   unsigned long long* stats;  // dbg 128: per-phase wave cycles and row counters (see scan_stat)
   int dbg;  // ablation switches (CUVS_AMD_SCAN_DEBUG): 1 no LUT build, 2 no gathers, 4 no top-k, 8 no early stop
+  // LUT that does not fit the LDS (e.g. pq_dim 384 x 8 bit, the default for 768-d data): a per-workgroup LUT in global
+  // memory, served from L2 - the reference's non-shared-memory LUT mode (ivf_pq_compute_similarity_impl.cuh:449-465)
+  char* global_lut = nullptr;
+  size_t global_lut_stride = 0;
 };
 
 // gathers of one 16-byte chunk of 8-bit codes, issued 8 at a time (8 independent ds_reads in flight;
@@ -344,7 +348,8 @@ struct scan_layout {
   __host__ __device__ scan_layout(size_t lut_bytes, int qpb, uint32_t rot_dim, uint32_t k)
   {
     size_t off = (lut_bytes + 15) & ~size_t(15);
-    const size_t mg = (size_t)qpb * kScanWaves * k * 8;  // merge area reuses the LUT region after the scan
+    size_t mg = (size_t)qpb * kScanWaves * k * 8;  // merge area reuses the LUT region after the scan
+    if (k > 64) mg = std::max<size_t>(mg, (size_t)kScanWaves * 256 * 8);  // workgroup merge: 16 lists padded to 256 entries
     if (mg > off) off = (mg + 15) & ~size_t(15);
     qv = off;    off += (((size_t)qpb * rot_dim * 4) + 15) & ~size_t(15);
     cv = off;    off += (((size_t)rot_dim * 4) + 15) & ~size_t(15);
@@ -357,7 +362,7 @@ struct scan_layout {
 };
 
 // FAST4: pq_bits == 8, pq_dim == 64 (4 full chunks): the four chunk loads of a tile are issued back to back. Otherwise the generic path handles any pq_dim / pq_bits.
-template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL>
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL, bool GLUT = false>
 __device__ inline void pq_scan_item(const scan_args& a, const work_item item, char* smem,
                                     const float (&pqreg)[4][2][4], const bool pq_in_regs,
                                     const work_item* __restrict__ share, const uint32_t share_len,
@@ -368,8 +373,11 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 
   const uint32_t book      = 1u << a.pq_bits;
   const uint32_t lut_elems = a.pq_dim * book;
-  const scan_layout lay(FAST4 ? cm_lut<entry_t>::bytes() : (size_t)lut_elems * sizeof(entry_t), QPB, a.rot_dim, a.k);
-  entry_t* lut     = reinterpret_cast<entry_t*>(smem);
+  static_assert(!(GLUT && FAST4), "the code-major LUT lives in LDS");
+  const scan_layout lay(GLUT ? (size_t)0 : (FAST4 ? cm_lut<entry_t>::bytes() : (size_t)lut_elems * sizeof(entry_t)), QPB,
+                        a.rot_dim, a.k);
+  entry_t* lut     = GLUT ? reinterpret_cast<entry_t*>(a.global_lut + (size_t)blockIdx.x * a.global_lut_stride)
+                          : reinterpret_cast<entry_t*>(smem);
   float* qv        = reinterpret_cast<float*>(smem + lay.qv);
   float* cv        = reinterpret_cast<float*>(smem + lay.cv);
   uint32_t* kthb   = reinterpret_cast<uint32_t*>(smem + lay.kthb);
@@ -569,6 +577,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
       lut[e] = acc_t::pack(sc);
     }
   }
+  if constexpr (GLUT) __threadfence_block();  // the LUT went to global memory: visible to the workgroup's other waves
   __syncthreads();
   stat_phase(ST_LUT);
 
@@ -929,7 +938,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
 // about the same time and share its 4 MiB L2 instead of pulling the list into all eight L2s.
 // ALL: the non-fused path (every score written out, no top lists) - a template argument so that the fused kernels stay
 // exactly as they were
-template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL = false>
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL = false, bool GLUT = false>
 __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -959,8 +968,8 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   using entry_t = typename lut_acc<LutT, AccT, QPB>::entry_t;
   work_item* sh_item;
   {
-    const scan_layout lay(FAST4 ? cm_lut<entry_t>::bytes() : (size_t)a.pq_dim * (1u << a.pq_bits) * sizeof(entry_t), QPB,
-                          a.rot_dim, a.k);
+    const scan_layout lay(GLUT ? (size_t)0 : (FAST4 ? cm_lut<entry_t>::bytes() : (size_t)a.pq_dim * (1u << a.pq_bits) * sizeof(entry_t)),
+                          QPB, a.rot_dim, a.k);
     sh_item = reinterpret_cast<work_item*>(smem + lay.slots);
   }
   const uint32_t share0     = min(n_items, xcd * chunk);
@@ -979,7 +988,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
     uint32_t next_ticket = 0xffffffffu;
     if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
     const unsigned long long t0 = (a.dbg & 128) ? __builtin_readcyclecounter() : 0ull;
-    pq_scan_item<LutT, AccT, QPB, FAST4, E, ALL>(a, cur, smem, pqreg, pq_in_regs, share, share_len, next_ticket,
+    pq_scan_item<LutT, AccT, QPB, FAST4, E, ALL, GLUT>(a, cur, smem, pqreg, pq_in_regs, share, share_len, next_ticket,
                                              buf ^ 1);
     __syncthreads();
     // ST_MERGE accumulates the whole item; the host subtracts the other phases
@@ -1478,10 +1487,10 @@ size_t scan_smem_bytes(const ivf_pq_index& idx, int k)
                      idx.rot_dim, (uint32_t)k).total;
 }
 
-template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL = false>
+template <typename LutT, typename AccT, int QPB, bool FAST4, int E, bool ALL = false, bool GLUT = false>
 void launch_scan(resources& res, const scan_args& a, size_t smem, unsigned grid)
 {
-  auto kern = pq_scan_kernel<LutT, AccT, QPB, FAST4, E, ALL>;
+  auto kern = pq_scan_kernel<LutT, AccT, QPB, FAST4, E, ALL, GLUT>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem));
   profile_begin(res, "pq_scan_kernel");
@@ -1503,6 +1512,15 @@ void launch_scan_qpb(resources& res, const scan_args& a, size_t smem, unsigned g
     if (big_k) launch_scan<LutT, AccT, QPB, false, 4>(res, a, smem, grid);
     else       launch_scan<LutT, AccT, QPB, false, 1>(res, a, smem, grid);
   }
+}
+
+// LUT in global memory (one query per work item)
+template <typename LutT, typename AccT>
+void launch_scan_glut(resources& res, const scan_args& a, size_t smem, unsigned grid, bool big_k)
+{
+  if (a.all_scores != nullptr) launch_scan<LutT, AccT, 1, false, 1, true, true>(res, a, smem, grid);
+  else if (big_k)              launch_scan<LutT, AccT, 1, false, 4, false, true>(res, a, smem, grid);
+  else                         launch_scan<LutT, AccT, 1, false, 1, false, true>(res, a, smem, grid);
 }
 
 // ---- reduced-precision coarse search (search_params.coarse_search_dtype; ivf_pq_search.cuh:171-340, :995-1017)
@@ -1701,8 +1719,13 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     else if ((smem = scan_smem_bytes<__half, float, 2>(idx, k_scan)) <= lds_cap) qpb = 2;
     else if ((smem = scan_smem_bytes<__half, float, 1>(idx, k_scan)) <= lds_cap) qpb = 1;
   }
-  CUVS_EXPECTS(qpb > 0, "ivf_pq::search: the PQ look-up table (pq_dim=%u, pq_bits=%u) does not fit 160 KiB of LDS%s",
-               idx.pq_dim, idx.pq_bits, lut_half ? "" : "; try lut_dtype=CUDA_R_16F");
+  // no fit: one query per item and the LUT in global memory (L2), as the reference does when its LUT exceeds shared memory
+  const bool glut = qpb == 0;
+  if (glut) {
+    qpb  = 1;
+    smem = scan_layout(0, 1, idx.rot_dim, (uint32_t)k_scan).total;
+    CUVS_EXPECTS(smem <= lds_cap, "ivf_pq::search: rot_dim %u / k %d do not fit 160 KiB of LDS", idx.rot_dim, k_scan);
+  }
 
   // batch of queries per pass (reference: max_internal_batch_size bounds the coarse batch, :814-857)
   int64_t max_batch = std::max<uint32_t>(1, p.max_internal_batch_size);
@@ -1811,7 +1834,20 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     dev_buf<unsigned long long> stats(res, (a.dbg & (128 | 512)) ? (size_t)ST_COUNT * grid * kScanWaves : 0);
     a.stats = stats.data();
     if (a.dbg & (128 | 512)) HIP_TRY(hipMemsetAsync(stats.data(), 0, stats.bytes(), res.stream));
+    dev_buf<char> glut_buf;
+    if (glut) {
+      const size_t entry = lut_half ? 2 : 4;  // one query per item
+      a.global_lut_stride = ((size_t)idx.pq_dim * idx.pq_book * entry + 255) & ~size_t(255);
+      glut_buf     = dev_buf<char>(res, a.global_lut_stride * grid);
+      a.global_lut = glut_buf.data();
+    }
     auto launch = [&](const scan_args& sa) {
+      if (glut) {
+        if (!lut_half)      launch_scan_glut<float, float>(res, sa, smem, grid, big_k);
+        else if (!acc_half) launch_scan_glut<__half, float>(res, sa, smem, grid, big_k);
+        else                launch_scan_glut<__half, __half>(res, sa, smem, grid, big_k);
+        return;
+      }
       if (!lut_half) {
         if (qpb == 2) launch_scan_qpb<float, float, 2>(res, sa, smem, grid, bits8, big_k);
         else          launch_scan_qpb<float, float, 1>(res, sa, smem, grid, bits8, big_k);

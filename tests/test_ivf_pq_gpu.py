@@ -52,6 +52,22 @@ def _min_recall(n_probes, n_lists, dim, pq_dim, pq_bits, elem_bytes=4):
     return min(math.erfc(0.05 * compression / max(p, 0.5)), p)
 
 
+@pytest.mark.parametrize("lut,acc,k", [("f32", "f32", 10), ("f16", "f16", 10), ("f16", "f32", 100)])
+def test_lut_larger_than_lds(lut, acc, k):
+    """768-d data with the reference's default pq_dim (dim / 2 = 384, 8 bits): a 384 x 256 LUT does not fit 160 KiB of
+    LDS even for one query (ivf_pq_compute_similarity_impl.cuh:449-465 falls back to a LUT outside shared memory). The
+    scan keeps a per-workgroup LUT in global memory: ids and distances identical to the oracle."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(3000, 768, 60, seed=77)
+    index = _build(x, n_lists=8, pq_dim=0, pq_bits=8, kmeans_n_iters=10)
+    assert index.pq_dim == 384
+    gd, gi = _search(index, q, k, n_probes=4, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    ex = ivf_pq.export_for_oracle(index)
+    od, oi = oracle.ivf_pq_search(ex, q, k, 4, metric="sqeuclidean", lut=lut, acc=acc)
+    assert (gi == oi).all() and (gd == od).all()
+
+
 @pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "inner_product"])
 @pytest.mark.parametrize("n,d,n_lists,pq_dim,pq_bits,k,n_probes", [
     (4096, 64, 32, 32, 8, 32, 8),      # reference defaults
