@@ -202,12 +202,13 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   // ---- running-threshold path, pipelined: the distance GEMM of tile ct + 1 (compute-bound, the handle's stream) runs
   // beside the filter + small select of tile ct (memory-bound, a helper stream); two half-width tiles alternate.
   std::vector<char> redo((size_t)((m + m_tile - 1) / m_tile), running ? 0 : 1);  // row tiles for the per-tile select path
-  const bool fused_filter = running && getenv("CUVS_AMD_BF_NO_FUSED_FILTER") == nullptr;
+  // first tile: n / 16 columns (4096 .. 32768, at least 32 k) - select_k reads it four times, and the thresholds it
+  // gives let the next tile be 25 times wider at k = 10
+  const int64_t n0_want = std::max<int64_t>(std::min<int64_t>(32768, std::max<int64_t>(4096, n / 16)), 32 * (int64_t)k);
+  const int64_t n0      = std::min<int64_t>(std::min<int64_t>(n_tile, round_up(n, 128)), round_up(n0_want, 128));
+  // (a workspace too small for a first tile of k columns: the tile path below)
+  const bool fused_filter = running && std::min<int64_t>(n0, n) >= k && getenv("CUVS_AMD_BF_NO_FUSED_FILTER") == nullptr;
   if (fused_filter) {
-    // first tile: n / 16 columns (4096 .. 32768, at least 32 k) - select_k reads it four times, and the thresholds it
-    // gives let the next tile be 25 times wider at k = 10
-    const int64_t n0_want = std::max<int64_t>(std::min<int64_t>(32768, std::max<int64_t>(4096, n / 16)), 32 * (int64_t)k);
-    const int64_t n0      = std::min<int64_t>(std::min<int64_t>(n_tile, round_up(n, 128)), round_up(n0_want, 128));
     const int64_t ld0 = std::min<int64_t>(n0, n);
     dev_buf<float> buf_v(res, (size_t)m_tile * (k + kBfCap));
     dev_buf<int64_t> buf_i(res, (size_t)m_tile * (k + kBfCap));
