@@ -1514,13 +1514,13 @@ void launch_scan_qpb(resources& res, const scan_args& a, size_t smem, unsigned g
   }
 }
 
-// LUT in global memory (one query per work item)
-template <typename LutT, typename AccT>
+// LUT in global memory: the interleave is not bounded by the LDS any more, so one 8-byte load serves QPB queries
+template <typename LutT, typename AccT, int QPB>
 void launch_scan_glut(resources& res, const scan_args& a, size_t smem, unsigned grid, bool big_k)
 {
-  if (a.all_scores != nullptr) launch_scan<LutT, AccT, 1, false, 1, true, true>(res, a, smem, grid);
-  else if (big_k)              launch_scan<LutT, AccT, 1, false, 4, false, true>(res, a, smem, grid);
-  else                         launch_scan<LutT, AccT, 1, false, 1, false, true>(res, a, smem, grid);
+  if (a.all_scores != nullptr) launch_scan<LutT, AccT, QPB, false, 1, true, true>(res, a, smem, grid);
+  else if (big_k)              launch_scan<LutT, AccT, QPB, false, 4, false, true>(res, a, smem, grid);
+  else                         launch_scan<LutT, AccT, QPB, false, 1, false, true>(res, a, smem, grid);
 }
 
 // ---- reduced-precision coarse search (search_params.coarse_search_dtype; ivf_pq_search.cuh:171-340, :995-1017)
@@ -1719,11 +1719,11 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     else if ((smem = scan_smem_bytes<__half, float, 2>(idx, k_scan)) <= lds_cap) qpb = 2;
     else if ((smem = scan_smem_bytes<__half, float, 1>(idx, k_scan)) <= lds_cap) qpb = 1;
   }
-  // no fit: one query per item and the LUT in global memory (L2), as the reference does when its LUT exceeds shared memory
+  // no fit: the LUT goes to global memory (L2), as the reference does when its LUT exceeds shared memory
   const bool glut = qpb == 0;
   if (glut) {
-    qpb  = 1;
-    smem = scan_layout(0, 1, idx.rot_dim, (uint32_t)k_scan).total;
+    qpb  = lut_half ? 4 : 2;  // 8-byte entries
+    smem = scan_layout(0, qpb, idx.rot_dim, (uint32_t)k_scan).total;
     CUVS_EXPECTS(smem <= lds_cap, "ivf_pq::search: rot_dim %u / k %d do not fit 160 KiB of LDS", idx.rot_dim, k_scan);
   }
 
@@ -1836,16 +1836,16 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (a.dbg & (128 | 512)) HIP_TRY(hipMemsetAsync(stats.data(), 0, stats.bytes(), res.stream));
     dev_buf<char> glut_buf;
     if (glut) {
-      const size_t entry = lut_half ? 2 : 4;  // one query per item
+      const size_t entry = 8;  // 4 x fp16 or 2 x fp32
       a.global_lut_stride = ((size_t)idx.pq_dim * idx.pq_book * entry + 255) & ~size_t(255);
       glut_buf     = dev_buf<char>(res, a.global_lut_stride * grid);
       a.global_lut = glut_buf.data();
     }
     auto launch = [&](const scan_args& sa) {
       if (glut) {
-        if (!lut_half)      launch_scan_glut<float, float>(res, sa, smem, grid, big_k);
-        else if (!acc_half) launch_scan_glut<__half, float>(res, sa, smem, grid, big_k);
-        else                launch_scan_glut<__half, __half>(res, sa, smem, grid, big_k);
+        if (!lut_half)      launch_scan_glut<float, float, 2>(res, sa, smem, grid, big_k);
+        else if (!acc_half) launch_scan_glut<__half, float, 4>(res, sa, smem, grid, big_k);
+        else                launch_scan_glut<__half, __half, 4>(res, sa, smem, grid, big_k);
         return;
       }
       if (!lut_half) {
