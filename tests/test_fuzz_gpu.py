@@ -1,0 +1,98 @@
+"""GPU: randomized differential tests against the CPU oracle. A fixed seed draws parameter combinations that the
+hand-picked cases do not cover (odd dims, every pq_bits, k on both sides of 64 / 128 / 256, LUT / score types, metrics,
+ragged lists); every result must be bit-identical to the oracle searching the same exported index."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+_LUTS = {"f32": np.float32, "f16": np.float16, "fp8": np.uint8}
+
+
+def _draw_pq(rng):
+    d = int(rng.choice([8, 17, 32, 48, 64, 96, 100, 128, 200]))
+    pq_dim = int(rng.choice([p for p in (4, 8, 16, 24, 32, 48, 64, 96) if p <= max(4, d)]))
+    return dict(n=int(rng.integers(1500, 5000)), d=d, n_lists=int(rng.choice([4, 9, 16, 33])), pq_dim=pq_dim,
+                pq_bits=int(rng.choice([4, 5, 6, 7, 8])), k=int(rng.choice([1, 5, 10, 32, 64, 65, 100, 129, 200, 256, 300])),
+                n_probes=int(rng.integers(1, 9)), metric=str(rng.choice(["sqeuclidean", "euclidean", "inner_product", "cosine"])),
+                lut=str(rng.choice(["f32", "f16", "fp8"])), nq=int(rng.choice([3, 50, 300])),
+                codebook=str(rng.choice(["subspace", "subspace", "cluster"])))
+
+
+@pytest.mark.parametrize("case", range(64))
+def test_ivf_pq_random_configuration(case):
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    rng = np.random.default_rng(1000 + case)
+    c = _draw_pq(rng)
+    acc = "f32" if c["lut"] == "f32" else str(rng.choice(["f32", "f16"]))
+    x = (rng.random((c["n"], c["d"]), dtype=np.float32) * 1.9 + 0.1)
+    x[: c["n"] // 3] += 3.0  # uneven lists
+    q = (rng.random((c["nq"], c["d"]), dtype=np.float32) * 1.9 + 0.1)
+    q[::2] += 3.0
+    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=c["n_lists"], metric=c["metric"], pq_dim=c["pq_dim"], pq_bits=c["pq_bits"],
+                                            kmeans_n_iters=5, codebook_kind=c["codebook"]), torch.from_numpy(x).cuda())
+    k = min(c["k"], c["n"])
+    sp = ivf_pq.SearchParams(n_probes=c["n_probes"], lut_dtype=_LUTS[c["lut"]], internal_distance_dtype=_LUTS[acc])
+    gd, gi = ivf_pq.search(sp, index, torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    ex = ivf_pq.export_for_oracle(index, per_cluster=c["codebook"] == "cluster")
+    od, oi = oracle.ivf_pq_search(ex, q, k, c["n_probes"], metric=c["metric"], lut=c["lut"], acc=acc)
+    gd, gi = gd.cpu().numpy(), gi.cpu().numpy()
+    assert (gi == oi).all(), f"{c} acc={acc}: id mismatch rate {(gi != oi).mean():.4f}"
+    assert (gd == od).all(), f"{c} acc={acc}: max |d| diff {np.nanmax(np.abs(gd - od))}"
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_ivf_flat_random_configuration(case):
+    import torch
+    from cuvs_amd.neighbors import ivf_flat
+
+    rng = np.random.default_rng(2000 + case)
+    d = int(rng.choice([1, 7, 16, 33, 64, 100, 257]))
+    n, nq = int(rng.integers(1000, 4000)), int(rng.choice([2, 40, 200]))
+    dtype = [np.float32, np.float16, np.int8, np.uint8][int(rng.integers(0, 4))]
+    metric = str(rng.choice(["sqeuclidean", "euclidean", "inner_product", "cosine"]))
+    k = int(rng.choice([1, 10, 64, 65, 128, 200, 300]))
+    n_lists, n_probes = int(rng.choice([3, 8, 20])), int(rng.integers(1, 6))
+    if dtype in (np.int8, np.uint8):
+        lo, hi = (-100, 100) if dtype == np.int8 else (0, 200)
+        x, q = rng.integers(lo, hi, size=(n, d)).astype(dtype), rng.integers(lo, hi, size=(nq, d)).astype(dtype)
+        scale = 1 / 128 if dtype == np.int8 else 1 / 256
+    else:
+        x = (rng.random((n, d), dtype=np.float32) * 1.9 + 0.1).astype(dtype)
+        q = (rng.random((nq, d), dtype=np.float32) * 1.9 + 0.1).astype(dtype)
+        scale = 1.0
+    index = ivf_flat.build(ivf_flat.IndexParams(n_lists=n_lists, metric=metric, kmeans_n_iters=5), torch.from_numpy(x).cuda())
+    k = min(k, n)
+    gd, gi = ivf_flat.search(ivf_flat.SearchParams(n_probes=n_probes), index, torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    ex = ivf_flat.export_for_oracle(index, dtype)
+    od, oi = oracle.ivf_flat_search(ex, q, k, n_probes, metric=metric, coarse_scale=scale)
+    gd, gi = gd.cpu().numpy(), gi.cpu().numpy()
+    tag = f"d={d} n={n} nq={nq} {np.dtype(dtype).name} {metric} k={k} lists={n_lists} probes={n_probes}"
+    assert (gi == oi).all(), f"{tag}: id mismatch rate {(gi != oi).mean():.4f}"
+    assert (gd == od).all(), f"{tag}: max |d| diff {np.nanmax(np.abs(gd - od))}"
+
+
+@pytest.mark.parametrize("case", range(20))
+def test_brute_force_random_configuration(case):
+    import torch
+    from cuvs_amd.neighbors import brute_force
+
+    rng = np.random.default_rng(3000 + case)
+    d = int(rng.choice([3, 16, 40, 64, 100, 128]))
+    n, nq = int(rng.choice([500, 7000, 70000, 140000])), int(rng.choice([1, 33, 130]))
+    k = int(rng.choice([1, 10, 100, 1000]))
+    metric = str(rng.choice(["sqeuclidean", "euclidean", "cosine", "inner_product"]))
+    x = (rng.random((n, d), dtype=np.float32) * 1.9 + 0.1)
+    q = (rng.random((nq, d), dtype=np.float32) * 1.9 + 0.1)
+    k = min(k, n)
+    idx = brute_force.build(torch.from_numpy(x).cuda(), metric=metric)
+    gd, gi = brute_force.search(idx, torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    od, oi = oracle.brute_force_knn(q, x, k, metric=metric)
+    assert (gi.cpu().numpy() == oi).all() and (gd.cpu().numpy() == od).all(), f"d={d} n={n} nq={nq} k={k} {metric}"
