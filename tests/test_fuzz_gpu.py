@@ -96,3 +96,35 @@ def test_brute_force_random_configuration(case):
     torch.cuda.synchronize()
     od, oi = oracle.brute_force_knn(q, x, k, metric=metric)
     assert (gi.cpu().numpy() == oi).all() and (gd.cpu().numpy() == od).all(), f"d={d} n={n} nq={nq} k={k} {metric}"
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_cagra_walk_random_configuration(case):
+    """The single-wave walk on a built graph: dims on both sides of the 8-lane team pass and of the 4-piece load groups,
+    every dtype, itopk / search_width / k drawn at random - ids and distances identical to the oracle walk."""
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(4000 + case)
+    dim = int(rng.choice([4, 24, 33, 96, 128, 200, 256, 520, 768]))
+    dtype = [np.float32, np.float16, np.int8, np.uint8][int(rng.integers(0, 4))]
+    metric = str(rng.choice(["sqeuclidean", "inner_product", "cosine"]))
+    n, nq = int(rng.integers(1200, 3000)), int(rng.choice([5, 60]))
+    if dtype in (np.int8, np.uint8):
+        lo, hi = (-20, 20) if dtype == np.int8 else (0, 40)
+        x, q = rng.integers(lo, hi, size=(n, dim)).astype(dtype), rng.integers(lo, hi, size=(nq, dim)).astype(dtype)
+    else:
+        x, q = rng.standard_normal((n, dim)).astype(dtype), rng.standard_normal((nq, dim)).astype(dtype)
+    degree = int(rng.choice([16, 24, 32]))
+    index = cagra.build(cagra.IndexParams(metric=metric, intermediate_graph_degree=2 * degree, graph_degree=degree),
+                        torch.from_numpy(x).cuda())
+    graph = index.graph.cpu().numpy().view(np.uint32)
+    itopk, width, k = int(rng.choice([32, 64, 128])), int(rng.choice([1, 2, 4])), int(rng.choice([1, 10, 32]))
+    d, i = cagra.search(cagra.SearchParams(itopk_size=itopk, search_width=width, algo="single_cta"), index,
+                        torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    gi = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    od, oi = oracle.cagra_search(x, graph, q, k, itopk_size=itopk, search_width=width, metric=metric)
+    tag = f"dim={dim} {np.dtype(dtype).name} {metric} n={n} degree={degree} itopk={itopk} width={width} k={k}"
+    assert (gi == oi).all(), f"{tag}: id mismatch rate {(gi != oi).mean():.4f}"
+    assert (d.cpu().numpy() == od).all(), tag
