@@ -128,3 +128,62 @@ def test_cagra_walk_random_configuration(case):
     tag = f"dim={dim} {np.dtype(dtype).name} {metric} n={n} degree={degree} itopk={itopk} width={width} k={k}"
     assert (gi == oi).all(), f"{tag}: id mismatch rate {(gi != oi).mean():.4f}"
     assert (d.cpu().numpy() == od).all(), tag
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_select_k_random_configuration(case):
+    """Row lengths and k across the kernel's internal switch points (64 / 2048 / 8192 winners), heavy ties (values drawn
+    from a handful of levels, +-inf, signed zeros), min and max selection: values, positions and tie order equal the
+    oracle's."""
+    import ctypes as C
+    import torch
+    import cuvs_amd
+    from cuvs_amd._lib import check, lib
+
+    rng = np.random.default_rng(5000 + case)
+    rows = int(rng.choice([1, 3, 40]))
+    ln = int(rng.choice([1, 7, 64, 65, 1000, 4097, 20000, 70000]))
+    k = int(min(ln, rng.choice([1, 2, 10, 64, 65, 300, 2048, 2049, 9000])))
+    select_min = bool(rng.integers(0, 2))
+    mode = int(rng.integers(0, 3))
+    if mode == 0:
+        v = rng.standard_normal((rows, ln)).astype(np.float32)
+    elif mode == 1:  # few distinct levels: ties everywhere
+        v = rng.integers(-3, 4, size=(rows, ln)).astype(np.float32)
+    else:
+        v = rng.standard_normal((rows, ln)).astype(np.float32)
+        v[rng.random((rows, ln)) < 0.1] = np.inf
+        v[rng.random((rows, ln)) < 0.1] = -np.inf
+        v[rng.random((rows, ln)) < 0.1] = -0.0
+    res = cuvs_amd.common.Resources()
+    tv = torch.from_numpy(v).cuda()
+    ov = torch.empty((rows, k), dtype=torch.float32, device="cuda")
+    oi = torch.empty((rows, k), dtype=torch.int64, device="cuda")
+    fn = lib().cuvsAmdSelectK
+    fn.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    check(fn(res.get_c_obj(), tv.data_ptr(), None, rows, ln, k, ov.data_ptr(), oi.data_ptr(), int(select_min)))
+    res.sync()
+    ev, ei = oracle.select_k(v, k, select_min)
+    tag = f"rows={rows} len={ln} k={k} min={select_min} mode={mode}"
+    assert (oi.cpu().numpy() == ei).all(), tag
+    assert np.array_equal(ov.cpu().numpy(), ev), tag
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_refine_random_configuration(case):
+    import torch
+    from cuvs_amd.neighbors import refine
+
+    rng = np.random.default_rng(6000 + case)
+    n, d = int(rng.integers(200, 3000)), int(rng.choice([1, 5, 32, 100, 257]))
+    m, n_cand = int(rng.choice([1, 17, 200])), int(rng.choice([4, 33, 128]))
+    k = int(min(n_cand, rng.choice([1, 4, 10, 64])))
+    metric = str(rng.choice(["sqeuclidean", "euclidean", "inner_product", "cosine"]))
+    x = (rng.random((n, d), dtype=np.float32) * 1.9 + 0.1)
+    q = (rng.random((m, d), dtype=np.float32) * 1.9 + 0.1)
+    cand = rng.integers(0, n, size=(m, n_cand)).astype(np.int64)  # duplicates allowed
+    gd, gi = refine(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(cand).cuda(), k=k, metric=metric)
+    torch.cuda.synchronize()
+    od, oi = oracle.refine(x, q, cand, k, metric=metric)
+    tag = f"n={n} d={d} m={m} n_cand={n_cand} k={k} {metric}"
+    assert (gi.cpu().numpy() == oi).all() and (gd.cpu().numpy() == od).all(), tag
