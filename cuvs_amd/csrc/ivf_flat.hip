@@ -410,6 +410,34 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
   if constexpr (ALL) return;
   // ---- merge the wave lists (the query tile is no longer needed)
   __syncthreads();
+  if constexpr (E > 1) {
+    // k > 64: the sorted wave lists are merged by the whole workgroup, one query after the other (ivf_common.hpp)
+    constexpr int KP2 = E == 2 ? 128 : 256;
+    float* sd    = reinterpret_cast<float*>(smem);
+    uint32_t* si = reinterpret_cast<uint32_t*>(smem + (size_t)kFlatWaves * KP2 * 4);
+    for (int j = 0; j < QPB; ++j) {
+      if (j >= (int)item.count) break;  // workgroup-uniform
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int r = e * 64 + lane;
+        const bool in = r < (int)a.k;
+        sd[wave * KP2 + r] = in ? top[j].d[e] : INFINITY;
+        si[wave * KP2 + r] = in ? top[j].i[e] : 0xffffffffu;
+      }
+      __syncthreads();
+      merge_sorted_lists<kFlatThreads>(sd, si, kFlatWaves, KP2, tid);
+      const size_t o = (size_t)pid[j] * a.k;
+      for (int r = tid; r < (int)a.k; r += kFlatThreads) {
+        const bool ok  = si[r] != 0xffffffffu;
+        a.out_d[o + r] = ok ? sd[r] : FLT_MAX;
+        a.out_i[o + r] = ok ? base_row + si[r] : 0xffffffffu;
+      }
+      if (tid == 0 && si[a.k - 1] != 0xffffffffu && sd[a.k - 1] < INFINITY)
+        atomicMin(&a.query_kth[pid[j] / a.n_probes], float_to_key(sd[a.k - 1]));
+      __syncthreads();  // the next query reuses the area
+    }
+    return;
+  }
   float* mg_d    = reinterpret_cast<float*>(smem);
   uint32_t* mg_i = reinterpret_cast<uint32_t*>(smem + (size_t)QPB * kFlatWaves * a.k * 4);
 #pragma unroll
@@ -702,7 +730,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   const bool big_k        = k > 64 && !large_k;
   const int k_scan        = large_k ? 1 : k;
   const uint32_t dim_pad  = idx.n_chunks * idx.veclen;
-  size_t smem = ((((size_t)qpb * kFlatWaves * k_scan * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;
+  size_t smem = ((((size_t)qpb * kFlatWaves * k_scan * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;  // (>= 16 KiB at k > 64: the workgroup merge's 8 x 256 entries)
   const size_t scores_ld  = large_k ? largest_lists_total(idx.h_list_sizes, n_probes) : 0;
 
   int64_t max_batch = 1 << 15;

@@ -191,41 +191,6 @@ __device__ inline float fp8_round_trip(float v, bool is_signed)
 }
 
 // dbg 128 statistics (CUVS_AMD_SCAN_DEBUG=128 prints them per search): wave cycles per phase, rows per stage
-// Top-kp2 of n_l sorted lists (n_l a power of two) by the whole workgroup, in place in LDS: lists l and l + w merge
-// into l - C[r] = min(A[r], B[kp2 - 1 - r]) is bitonic and holds the kp2 best of the pair, log2(kp2) compare-exchange
-// stages sort it - for w = 1, 2, 4, ... Order: (distance, id) ascending, invalid entries (id 0xffffffff, +inf) last, the
-// order of the wave lists. Serial insertion of 16 x 256 candidates by one wave took 300 k cycles per work item in the
-// kNN-graph searches of the CAGRA build (k = 256); this takes a few thousand. All threads of the workgroup call it.
-template <int NT>
-__device__ inline void merge_sorted_lists(float* __restrict__ d, uint32_t* __restrict__ id, const int n_l, const int kp2,
-                                          const int tid)
-{
-  auto less = [](const float da, const uint32_t ia, const float db, const uint32_t ib) {
-    return da < db || (da == db && ia < ib);
-  };
-  for (int w = 1; w < n_l; w <<= 1) {
-    const int pairs = n_l / (2 * w);
-    for (int t = tid; t < pairs * kp2; t += NT) {
-      const int pr = t / kp2, r = t % kp2;
-      const int ia = pr * 2 * w * kp2 + r, ib = (pr * 2 * w + w) * kp2 + (kp2 - 1 - r);
-      const float da = d[ia], db = d[ib];
-      const uint32_t xa = id[ia], xb = id[ib];
-      if (less(db, xb, da, xa)) { d[ia] = db; id[ia] = xb; }
-    }
-    __syncthreads();
-    for (int stride = kp2 >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < pairs * (kp2 >> 1); t += NT) {
-        const int pr = t / (kp2 >> 1), x = t % (kp2 >> 1);
-        const int lo = pr * 2 * w * kp2 + 2 * x - (x & (stride - 1)), hi = lo + stride;
-        const float da = d[lo], db = d[hi];
-        const uint32_t xa = id[lo], xb = id[hi];
-        if (less(db, xb, da, xa)) { d[lo] = db; id[lo] = xb; d[hi] = da; id[hi] = xa; }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QUEUED, ST_S2_CALLS, ST_ALIVE1, ST_ALIVE2,
                  ST_ALIVE3, ST_CAND, ST_ITEMS, ST_COUNT };
 
