@@ -213,3 +213,12 @@ def test_fused_threshold_epilogue(metric, dtype, filt):
     gd, gi = _run(x, qq, k, metric, prefilter=pre, dtype=dtype)
     od, oi = oracle.brute_force_knn(qq, x, k, metric=metric, **kw)
     assert (gi == oi).all() and (gd == od).all()
+
+
+def test_fused_threshold_epilogue_more_than_one_row_tile():
+    """More queries than one row tile (16384): the per-row buffers, counters and overflow flags are reused by the second
+    row tile. Identical to the oracle."""
+    x, qq = _gen(66000, 4, 17000, seed=41)
+    gd, gi = _run(x, qq, 5, "sqeuclidean")
+    od, oi = oracle.brute_force_knn(qq, x, 5)
+    assert (gi == oi).all() and (gd == od).all()
