@@ -22,6 +22,7 @@
 #include <cuvs/neighbors/cagra.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cfloat>
 #include <cmath>
 
@@ -57,14 +58,23 @@ constexpr uint32_t kInvalidNode = 0xffffffffu;
 constexpr uint32_t kParentFlag  = 0x80000000u;
 
 // ------------------------------------------------------------------ graph optimisation
-// kern_fused_prune restated: one wave per node.
+// kern_fused_prune restated: one wave per node. For every neighbour D (rank kAD) of the node and every neighbour B of D,
+// the FIRST rank kAB > kAD at which the node lists B gets a detour count. The node's list is looked up through a small
+// open-addressing table (id -> lowest rank) instead of a linear scan of up to K LDS words per candidate; a hit at a
+// rank <= kAD (duplicate ids in the list) falls back to the scan, so the counts are exactly those of the scan. The row
+// of the next neighbour is loaded while the current one is processed (the 127 row gathers of a node were serial).
+template <int PER>  // ids per lane and neighbour row: K <= 64 * PER; 16 / PER rows are in flight
 __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__ knn, int64_t n, uint32_t K,
-                                                    uint32_t out_degree, uint32_t* __restrict__ out, int64_t nid0)
+                                                    uint32_t out_degree, uint32_t* __restrict__ out, int64_t nid0, int dbg)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t* s_idx = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * 2 * K;
+  uint32_t tsize = 64;
+  while (tsize < 2 * K) tsize <<= 1;  // <= 50 % load
+  uint32_t* s_idx = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * (2 * K + 2 * tsize);
   uint32_t* s_det = s_idx + K;
+  uint32_t* t_key = s_det + K;
+  uint32_t* t_pos = t_key + tsize;
   const int64_t nid = nid0 + (int64_t)blockIdx.x * 4 + wave;
   if (nid >= n) return;
   for (uint32_t k = lane; k < K; k += 64) {
@@ -72,16 +82,72 @@ __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__
     s_idx[k]   = v;
     s_det[k]   = (v == (uint32_t)nid) ? K : 0;
   }
+  for (uint32_t t = lane; t < tsize; t += 64) { t_key[t] = kInvalidNode; t_pos[t] = 0xffffffffu; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t kAD = 0; kAD + 1 < K; ++kAD) {
-    const uint32_t iD = s_idx[kAD];
-    if (iD >= n) continue;
-    for (uint32_t kDB = lane; kDB < K; kDB += 64) {
-      const uint32_t cand = knn[(int64_t)iD * K + kDB];
-      for (uint32_t kAB = kAD + 1; kAB < K; ++kAB) {
-        if (s_idx[kAB] == cand) {
-          atomicAdd(&s_det[kAB], 1u);
-          break;
+  // table: id -> lowest rank holding it (invalid ids are not entered)
+  for (uint32_t k = lane; k < K; k += 64) {
+    const uint32_t v = s_idx[k];
+    if (v >= n) continue;
+    uint32_t pos = (v * 2654435761u) & (tsize - 1);
+    for (;;) {
+      const uint32_t old = atomicCAS(&t_key[pos], kInvalidNode, v);
+      if (old == kInvalidNode || old == v) { atomicMin(&t_pos[pos], k); break; }
+      pos = (pos + 1) & (tsize - 1);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  constexpr int D = 16 / PER;  // neighbour rows loaded ahead as a block
+  uint32_t nxt[D][PER];
+  auto load_block = [&](const uint32_t kAD0, uint32_t (&blk)[D][PER]) {
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      const uint32_t kAD = kAD0 + dd;
+      const uint32_t iD  = kAD + 1 < K ? s_idx[kAD] : kInvalidNode;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t kDB = lane + 64 * u;
+        blk[dd][u] = (kDB < K && iD < n) ? knn[(int64_t)iD * K + kDB] : kInvalidNode;
+      }
+    }
+  };
+  load_block(0, nxt);
+  for (uint32_t kAD0 = 0; kAD0 + 1 < ((dbg & 1) ? 0u : K); kAD0 += D) {
+    uint32_t cur[D][PER];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd)
+#pragma unroll
+      for (int u = 0; u < PER; ++u) cur[dd][u] = nxt[dd][u];
+    load_block(kAD0 + D, nxt);
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      const uint32_t kAD = kAD0 + dd;
+      if (kAD + 1 >= K) break;  // wave-uniform
+      const uint32_t iD = s_idx[kAD];
+      if (iD >= n) continue;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const uint32_t cand = cur[dd][u];
+        if (lane + 64 * u >= K) continue;
+        if (cand >= n) {  // invalid candidate: the scan matches the first invalid entry of the node's list, if any
+          for (uint32_t kAB = kAD + 1; kAB < K; ++kAB)
+            if (s_idx[kAB] == cand) { atomicAdd(&s_det[kAB], 1u); break; }
+          continue;
+        }
+        uint32_t pos = (cand * 2654435761u) & (tsize - 1), hit = 0xffffffffu;
+        for (;;) {
+          const uint32_t key = t_key[pos];
+          if (key == cand) { hit = t_pos[pos]; break; }
+          if (key == kInvalidNode) break;
+          pos = (pos + 1) & (tsize - 1);
+        }
+        if (hit == 0xffffffffu) continue;  // the node does not list cand
+        if (hit > kAD) {
+          atomicAdd(&s_det[hit], 1u);
+        } else {  // lowest rank is not behind kAD: a duplicate further down would still count
+          for (uint32_t kAB = kAD + 1; kAB < K; ++kAB)
+            if (s_idx[kAB] == cand) { atomicAdd(&s_det[kAB], 1u); break; }
         }
       }
     }
@@ -93,7 +159,7 @@ __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__
     s_det[k] = d;
   }
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = 0; i < out_degree; ++i) {
+  for (uint32_t i = 0; i < ((dbg & 2) ? 0u : out_degree); ++i) {
     uint32_t best = 0xffffffffu;
     for (uint32_t k = lane; k < K; k += 64) {
       uint32_t tag = (s_det[k] << 16) | k;
@@ -269,11 +335,25 @@ void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, 
   CUVS_EXPECTS(degree <= K, "graph_degree (%u) must not exceed intermediate_graph_degree (%u)", degree, K);
   CUVS_EXPECTS(degree <= 256 && K <= 1024, "cagra: degree <= 256 and intermediate degree <= 1024 supported");
   CUVS_EXPECTS(n < (int64_t(1) << 32) - 1, "cagra: at most 2^32 - 2 rows (uint32 graph)");
-  size_t smem = (size_t)4 * 2 * K * sizeof(uint32_t);
+  uint32_t tsize = 64;
+  while (tsize < 2 * K) tsize <<= 1;
+  size_t smem = (size_t)4 * (2 * K + 2 * tsize) * sizeof(uint32_t);
+  auto launch_prune = [&](auto per_tag, int64_t r0, int64_t rows) {
+    constexpr int PER = decltype(per_tag)::value;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(prune_kernel<PER>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem));
+    hipLaunchKernelGGL(prune_kernel<PER>, dim3(grid_blocks(rows, 4)), dim3(256), smem, res.stream, knn, n, K, degree, graph, r0,
+                       getenv("CUVS_AMD_PRUNE_DBG") ? atoi(getenv("CUVS_AMD_PRUNE_DBG")) : 0);
+  };
   const int64_t slab = int64_t(1) << 25;  // rows per launch of the wave-per-row kernels (2^23 workgroups)
-  for (int64_t r0 = 0; r0 < n; r0 += slab)
-    hipLaunchKernelGGL(prune_kernel, dim3(grid_blocks(std::min(slab, n - r0), 4)), dim3(256), smem, res.stream, knn, n, K, degree,
-                       graph, r0);
+  for (int64_t r0 = 0; r0 < n; r0 += slab) {
+    const int64_t rows = std::min(slab, n - r0);
+    if (K <= 64)       launch_prune(std::integral_constant<int, 1>{}, r0, rows);
+    else if (K <= 128) launch_prune(std::integral_constant<int, 2>{}, r0, rows);
+    else if (K <= 256) launch_prune(std::integral_constant<int, 4>{}, r0, rows);
+    else if (K <= 512) launch_prune(std::integral_constant<int, 8>{}, r0, rows);
+    else               launch_prune(std::integral_constant<int, 16>{}, r0, rows);
+  }
   // reverse edges grouped by destination, ordered by (rank, source): the edge list is sorted a chunk of ranks at a
   // time (a chunk stays below 2^32 edges; 100M rows x degree 64 takes two)
   uint32_t ranks = (uint32_t)std::min<int64_t>(degree, std::max<int64_t>(1, ((int64_t(1) << 32) - 1024) / n));
