@@ -85,17 +85,22 @@ __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__
   for (uint32_t t = lane; t < tsize; t += 64) { t_key[t] = kInvalidNode; t_pos[t] = 0xffffffffu; }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // table: id -> lowest rank holding it (invalid ids are not entered)
+  // table: id -> lowest rank holding it (invalid ids are not entered). A list with duplicate or invalid ids (not what a
+  // kNN graph holds, but legal input) keeps the scan as the fallback; a wave whose list has neither never scans - one
+  // scanning lane would hold up the other 63
+  bool odd = false;
   for (uint32_t k = lane; k < K; k += 64) {
     const uint32_t v = s_idx[k];
-    if (v >= n) continue;
+    if (v >= n) { odd = true; continue; }
     uint32_t pos = (v * 2654435761u) & (tsize - 1);
     for (;;) {
       const uint32_t old = atomicCAS(&t_key[pos], kInvalidNode, v);
+      if (old == v) odd = true;  // a second rank with this id
       if (old == kInvalidNode || old == v) { atomicMin(&t_pos[pos], k); break; }
       pos = (pos + 1) & (tsize - 1);
     }
   }
+  const bool has_odd = __ballot(odd) != 0ull;  // wave-uniform
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   constexpr int D = 16 / PER;  // neighbour rows loaded ahead as a block
@@ -131,8 +136,9 @@ __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__
         const uint32_t cand = cur[dd][u];
         if (lane + 64 * u >= K) continue;
         if (cand >= n) {  // invalid candidate: the scan matches the first invalid entry of the node's list, if any
-          for (uint32_t kAB = kAD + 1; kAB < K; ++kAB)
-            if (s_idx[kAB] == cand) { atomicAdd(&s_det[kAB], 1u); break; }
+          if (has_odd)
+            for (uint32_t kAB = kAD + 1; kAB < K; ++kAB)
+              if (s_idx[kAB] == cand) { atomicAdd(&s_det[kAB], 1u); break; }
           continue;
         }
         uint32_t pos = (cand * 2654435761u) & (tsize - 1), hit = 0xffffffffu;
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(256) void prune_kernel(const uint32_t* __restrict__
         if (hit == 0xffffffffu) continue;  // the node does not list cand
         if (hit > kAD) {
           atomicAdd(&s_det[hit], 1u);
-        } else {  // lowest rank is not behind kAD: a duplicate further down would still count
+        } else if (has_odd) {  // lowest rank is not behind kAD: a duplicate further down would still count
           for (uint32_t kAB = kAD + 1; kAB < K; ++kAB)
             if (s_idx[kAB] == cand) { atomicAdd(&s_det[kAB], 1u); break; }
         }
