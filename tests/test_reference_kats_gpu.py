@@ -83,3 +83,33 @@ def test_rust_self_neighbor_cagra():
     index = cagra.build(cagra.IndexParams(), xt)
     _, i = cagra.search(cagra.SearchParams(), index, xt[:4], c["k"])
     assert ((i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF)[:, 0] == np.arange(4)).all()
+
+
+def test_go_cagra_filtering():
+    """go/cagra/cagra_test.go:160-362 (TestCagraFiltering): 1024 x 16 uniform rows, default index / search parameters,
+    k = 4. Without a filter the first four rows find themselves; with an allow-list of rows 512..1023 no result is below
+    512 for those queries, and rows 512..515 find themselves at distance < 1e-3."""
+    import torch
+    from cuvs_amd._lib import BITSET
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(160)
+    x = rng.random((1024, 16), dtype=np.float32)
+    xt = torch.from_numpy(x).cuda()
+    index = cagra.build(cagra.IndexParams(), xt)
+    nb = torch.empty((4, 4), dtype=torch.int32, device="cuda")
+    d, i = cagra.search(cagra.SearchParams(), index, xt[:4], 4, neighbors=nb)
+    torch.cuda.synchronize()
+    got = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert (got[:, 0] == np.arange(4)).all() and (np.abs(d.cpu().numpy()[:, 0]) < 1e-3).all()
+    keep = np.zeros(1024, bool)
+    keep[512:] = True
+    words = torch.from_numpy(np.packbits(keep, bitorder="little").view(np.int32).copy()).cuda()
+    d, i = cagra.search(cagra.SearchParams(), index, xt[:4], 4, neighbors=nb, filter=(words, BITSET))
+    torch.cuda.synchronize()
+    got = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert (got >= 512).all()
+    d, i = cagra.search(cagra.SearchParams(), index, xt[512:516], 4, neighbors=nb, filter=(words, BITSET))
+    torch.cuda.synchronize()
+    got = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert (got[:, 0] == np.arange(512, 516)).all() and (np.abs(d.cpu().numpy()[:, 0]) < 1e-3).all()
