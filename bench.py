@@ -12,9 +12,9 @@ Index build, ground truth and the CPU baseline are outside the timed region; que
                                        # all-gather of the per-rank [Q, k] blocks (include/cuvs_amd/shard.h)
 
 Prints ONE JSON line (rank 0):
-  value / ms_per_step    the headline variant (fp16 LUT, fp16 scores - both reference search_params settings)
-  config.variants        the same step with the reference-default arithmetic (fp32 LUT / fp32 scores), the bench grid's
-                         (fp16 LUT / fp32 scores) and the fp8 LUT, each with ms, recall and scan-kernel time
+  value / ms_per_step    the headline variant: fp16 LUT / fp32 scores, the arithmetic of the reference's own bench grid
+  config.variants        the same step with the reference-default arithmetic (fp32 LUT / fp32 scores), fp16 / fp16 and
+                         the fp8 LUT, each with ms, recall and scan-kernel time
   roofline               pq_scan_kernel: the logical scan rate of SURVEY 8d (code bytes / kernel time, HIP events) AND
                          the physical fractions from rocprofv3 PMC passes of this same workload: hbm_frac,
                          lds_gather_frac, lds_busy, valu_busy; `bound` names the busiest pipe
@@ -301,7 +301,9 @@ def main():
     ap.add_argument("--batch", type=int, default=10000, help="queries per step and GPU")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--lut", choices=list(LUTS), default="f16", help="headline LUT dtype (search_params.lut_dtype)")
-    ap.add_argument("--acc", choices=["f32", "f16"], default="f16", help="headline score dtype (internal_distance_dtype)")
+    ap.add_argument("--acc", choices=["f32", "f16"], default="f32",
+                    help="headline score dtype (internal_distance_dtype); fp16 LUT / fp32 score is what the reference's own "
+                         "bench grid runs (cuvs_ivf_pq.yaml: smemLutDtype half, internalDistanceDtype float)")
     ap.add_argument("--refine-ratio", type=int, default=2,
                     help="IVF-PQ returns ratio*k candidates that cuvsRefine re-ranks exactly (reference bench grids "
                          "use refine_ratio 1..4, python/cuvs_bench/.../cuvs_ivf_pq.yaml); 1 disables refinement")
@@ -377,7 +379,7 @@ def main():
     mrg_i, mrg_d = torch.empty_like(cand_i), torch.empty_like(cand_d)
     q_lo, q_hi = rank * args.batch, (rank + 1) * args.batch  # the slice of the batch this rank refines
 
-    def make_step(lut, acc):
+    def make_step(lut, acc, res=res):
         sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[lut], internal_distance_dtype=LUTS[acc],
                                  max_internal_batch_size=nq_total)
 
@@ -449,10 +451,12 @@ def main():
         # (CUVS_AMD_SCAN_DEBUG=8), no filter stage (CUVS_AMD_PQ_SCAN2=0), no head phase: all 64 gathers of every row
         prune_off = {"CUVS_AMD_SCAN_DEBUG": "8", "CUVS_AMD_PQ_SCAN2": "0", "CUVS_AMD_PQ_HEAD_PROBES": "0"}
         os.environ.update(prune_off)
-        _, s, _, _ = timed(make_step(args.lut, args.acc), 3, 1)
-        early_stop_off_ms = round(s / 3, 3)
+        res_off = cuvs_amd.common.Resources()  # the switches are read once, when a handle is created
         for key in prune_off:
             del os.environ[key]
+        _, s, _, _ = timed(make_step(args.lut, args.acc, res_off), 3, 1)
+        early_stop_off_ms = round(s / 3, 3)
+        del res_off
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
     # algorithmic bytes per step = sum over (query, probe) pairs of list_len * code bytes

@@ -179,7 +179,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   // fused distance + top-k (the reference's fusedL2Knn path, knn_brute_force.cuh:452): k <= 64, no pre-filter.
   // Same results as the tiled path; in round 1 it is still slower than GEMM + select_k (244 VGPRs, cold-tile
   // cost), so it is opt-in: CUVS_AMD_BF_FUSED=1.
-  if (k <= 64 && filter_type == NO_FILTER && getenv("CUVS_AMD_BF_FUSED") != nullptr) {
+  if (k <= 64 && filter_type == NO_FILTER && res.tune.bf_fused) {
     bool done = true;
     for (int64_t r0 = 0; r0 < m && done; r0 += int64_t(65535) * 128) {
       const int64_t mr = std::min<int64_t>(int64_t(65535) * 128, m - r0);
@@ -194,7 +194,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   // more than one column tile: the running-threshold path (above) unless switched off or k is too large for it
   // (a single wide tile - e.g. 1000 queries x 100k rows - is cut into four as well: three of its four quarters then
   // cost one pass instead of select_k's four, and the GEMM of a quarter overlaps the select of the previous one)
-  const bool running = (n_ct > 1 || n >= 65536) && k <= 1024 && getenv("CUVS_AMD_BF_NO_THRESHOLD") == nullptr;
+  const bool running = (n_ct > 1 || n >= 65536) && k <= 1024 && !res.tune.bf_no_threshold;
   dev_buf<float> part_v;
   dev_buf<int64_t> part_i;
   const float worst = select_min ? FLT_MAX : -FLT_MAX;
@@ -207,7 +207,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   const int64_t n0_want = std::max<int64_t>(std::min<int64_t>(32768, std::max<int64_t>(4096, n / 16)), 32 * (int64_t)k);
   const int64_t n0      = std::min<int64_t>(std::min<int64_t>(n_tile, round_up(n, 128)), round_up(n0_want, 128));
   // (a workspace too small for a first tile of k columns: the tile path below)
-  const bool fused_filter = running && std::min<int64_t>(n0, n) >= k && getenv("CUVS_AMD_BF_NO_FUSED_FILTER") == nullptr;
+  const bool fused_filter = running && std::min<int64_t>(n0, n) >= k && !res.tune.bf_no_fused_filter;
   if (fused_filter) {
     const int64_t ld0 = std::min<int64_t>(n0, n);
     dev_buf<float> buf_v(res, (size_t)m_tile * (k + kBfCap));
@@ -500,7 +500,7 @@ cuvsError_t cuvsBruteForceSerialize(cuvsResources_t res_h, const char* filename,
     auto& res = *as_res(res_h);
     CUVS_EXPECTS(index_c_ptr && index_c_ptr->addr, "index is not built");
     auto& idx = *reinterpret_cast<bf_index*>(index_c_ptr->addr);
-    if (write_native_container()) {
+    if (write_native_container(res)) {
       file_writer w(filename, KIND_BRUTE_FORCE);
       w.scalar<int32_t>(idx.metric); w.scalar<float>(idx.metric_arg); w.scalar<int32_t>((int)idx.dtype);
       w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);

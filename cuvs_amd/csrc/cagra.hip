@@ -309,17 +309,17 @@ void knn_graph_ivf_pq(resources& res, const void* data, elem_t et, int64_t n, in
   bp.kmeans_trainset_fraction = std::min(1.0, std::max(0.02, 2.0e6 / (double)n));
   bp.pq_bits                  = 8;
   bp.pq_dim                   = (uint32_t)std::max<int64_t>(8, std::min<int64_t>(64, round_up(dim / 2, 8)));
-  if (const char* e = getenv("CUVS_AMD_CAGRA_PQ_LISTS")) bp.n_lists = (uint32_t)std::max(1, atoi(e));
+  if (res.tune.cagra_pq_lists > 0) bp.n_lists = (uint32_t)res.tune.cagra_pq_lists;
   auto pq = ivf_pq_build(res, bp, data, et, n, dim, false);
   ivf_pq_search_params sp;
   sp.n_probes                = std::max<uint32_t>(8, bp.n_lists / 50);
-  if (const char* e = getenv("CUVS_AMD_CAGRA_PQ_PROBES")) sp.n_probes = (uint32_t)std::max(1, atoi(e));
+  if (res.tune.cagra_pq_probes > 0) sp.n_probes = (uint32_t)res.tune.cagra_pq_probes;
   sp.lut_dtype               = 2;
   sp.internal_distance_dtype = 2;
   sp.max_internal_batch_size = 16384;
   const int kp1   = (int)K + 1;
   int k_pq        = std::min(256, 2 * kp1);
-  if (const char* e = getenv("CUVS_AMD_CAGRA_KPQ")) k_pq = std::max(kp1, std::min(256, atoi(e)));
+  if (res.tune.cagra_kpq > 0) k_pq = std::max(kp1, std::min(256, res.tune.cagra_kpq));
   const int64_t b = 16384;
   dev_buf<int64_t> cand(res, (size_t)b * k_pq), ri(res, (size_t)b * kp1);
   dev_buf<float> cd(res, (size_t)b * k_pq), rd(res, (size_t)b * kp1);
@@ -349,7 +349,7 @@ void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, 
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(prune_kernel<PER>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     hipLaunchKernelGGL(prune_kernel<PER>, dim3(grid_blocks(rows, 4)), dim3(256), smem, res.stream, knn, n, K, degree, graph, r0,
-                       getenv("CUVS_AMD_PRUNE_DBG") ? atoi(getenv("CUVS_AMD_PRUNE_DBG")) : 0);
+                       res.tune.prune_dbg);
   };
   const int64_t slab = int64_t(1) << 25;  // rows per launch of the wave-per-row kernels (2^23 workgroups)
   for (int64_t r0 = 0; r0 < n; r0 += slab) {
@@ -363,7 +363,7 @@ void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, 
   // reverse edges grouped by destination, ordered by (rank, source): the edge list is sorted a chunk of ranks at a
   // time (a chunk stays below 2^32 edges; 100M rows x degree 64 takes two)
   uint32_t ranks = (uint32_t)std::min<int64_t>(degree, std::max<int64_t>(1, ((int64_t(1) << 32) - 1024) / n));
-  if (const char* e = getenv("CUVS_AMD_CAGRA_RANK_CHUNK")) ranks = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)degree));
+  if (res.tune.cagra_rank_chunk > 0) ranks = (uint32_t)std::min<int>(res.tune.cagra_rank_chunk, (int)degree);
   const int64_t chunk_edges = n * (int64_t)ranks;
   dev_buf<uint32_t> dest(res, chunk_edges), perm(res, chunk_edges), off(res, n + 2), rev(res, (size_t)n * degree), rev_cnt(res, n);
   HIP_TRY(hipMemsetAsync(rev_cnt.data(), 0, rev_cnt.bytes(), res.stream));
@@ -1006,8 +1006,7 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   // equal recall: 1M x 768 fp16, itopk 64, batch 10k: 18.9 vs 26.7 ms).
   int algo = pl.ref_algo;
   if ((int)p.algo == (int)AUTO) {
-    const char* e = getenv("CUVS_AMD_CAGRA_AUTO");
-    if (e != nullptr && e[0] == 'm') algo = (int)MULTI_CTA;
+    if (res.tune.cagra_auto_multi) algo = (int)MULTI_CTA;
     if (!(itopk <= 16 * kMwTopk && idx.degree <= 224 && (size_t)k <= itopk)) algo = (int)SINGLE_CTA;  // limits of the multi-wave walk
   }
   // MULTI_KERNEL (search_multi_kernel.cuh) exists in the reference because an itopk list above 512 entries does not
@@ -1424,7 +1423,7 @@ cuvsError_t cuvsCagraSerialize(cuvsResources_t res_h, const char* filename, cuvs
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     auto& idx = get_cagra(index);
-    if (write_native_container()) {
+    if (write_native_container(res)) {
       file_writer w(filename, KIND_CAGRA);
       w.scalar<int32_t>(idx.metric); w.scalar<int32_t>((int)idx.dtype); w.scalar<int64_t>(idx.n); w.scalar<int64_t>(idx.dim);
       w.scalar<uint32_t>(idx.degree); w.scalar<uint8_t>(index->dtype.code); w.scalar<uint8_t>(index->dtype.bits);

@@ -73,7 +73,27 @@ int translate_exceptions(Fn&& fn)
 }
 
 // ---------------------------------------------------------------- resources
+// Test / ablation switches (CUVS_AMD_* environment variables). They are read ONCE, when the handle is created
+// (cuvsResourcesCreate -> load_tuning_from_env), never inside a search: a drop-in library must not call getenv on its
+// hot path (not thread-safe against setenv) nor change behaviour under a running caller.
+struct tuning {
+  int pq_head_probes    = -1;  // CUVS_AMD_PQ_HEAD_PROBES: probes per query in the cold-bounds phase (-1: default rule)
+  int pq_scan2          = 1;   // CUVS_AMD_PQ_SCAN2=0: tail phase through pq_scan_kernel (comparator in the tests)
+  int pq_qcap           = 0;   // CUVS_AMD_PQ_QCAP: survivor-queue rows of pq_scan2_kernel (test hook: forces the overflow path)
+  int scan_debug        = 0;   // CUVS_AMD_SCAN_DEBUG: ablation / statistics bits of the PQ scan
+  bool shard_coarse_replicated = false;  // CUVS_AMD_SHARD_COARSE_REPLICATED
+  bool bf_fused = false, bf_no_threshold = false, bf_no_fused_filter = false;  // CUVS_AMD_BF_*
+  bool dist_old         = false;  // CUVS_AMD_DIST_OLD
+  int tile_dbg          = 0;      // CUVS_AMD_TILE_DBG
+  int flat_head_probes  = -1;     // CUVS_AMD_FLAT_HEAD_PROBES
+  int cagra_pq_lists = 0, cagra_pq_probes = 0, cagra_kpq = 0, cagra_rank_chunk = 0, prune_dbg = 0;  // CUVS_AMD_CAGRA_*, CUVS_AMD_PRUNE_DBG
+  bool cagra_auto_multi = false;  // CUVS_AMD_CAGRA_AUTO=multi
+  bool native_format    = false;  // CUVS_AMD_NATIVE_FORMAT=1: *Serialize writes this library's own container
+};
+tuning load_tuning_from_env();
+
 struct resources {
+  tuning tune;
   int device              = 0;
   hipStream_t stream      = nullptr;  // nullptr == the legacy default stream
   bool owns_stream        = false;

@@ -89,6 +89,32 @@ void profile_end(resources& res, const char* name)
     if (it->name == name) { HIP_TRY(hipEventRecord(it->stop, res.stream)); return; }
 }
 
+tuning load_tuning_from_env()
+{
+  tuning t;
+  auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+  auto set  = [](const char* name) { return getenv(name) != nullptr; };
+  t.pq_head_probes   = geti("CUVS_AMD_PQ_HEAD_PROBES", -1);
+  t.pq_scan2         = geti("CUVS_AMD_PQ_SCAN2", 1);
+  t.pq_qcap          = geti("CUVS_AMD_PQ_QCAP", 0);
+  t.scan_debug       = geti("CUVS_AMD_SCAN_DEBUG", 0);
+  t.shard_coarse_replicated = set("CUVS_AMD_SHARD_COARSE_REPLICATED");
+  t.bf_fused           = set("CUVS_AMD_BF_FUSED");
+  t.bf_no_threshold    = set("CUVS_AMD_BF_NO_THRESHOLD");
+  t.bf_no_fused_filter = set("CUVS_AMD_BF_NO_FUSED_FILTER");
+  t.dist_old           = set("CUVS_AMD_DIST_OLD");
+  t.tile_dbg           = geti("CUVS_AMD_TILE_DBG", 0);
+  t.flat_head_probes   = geti("CUVS_AMD_FLAT_HEAD_PROBES", -1);
+  t.cagra_pq_lists     = geti("CUVS_AMD_CAGRA_PQ_LISTS", 0);
+  t.cagra_pq_probes    = geti("CUVS_AMD_CAGRA_PQ_PROBES", 0);
+  t.cagra_kpq          = geti("CUVS_AMD_CAGRA_KPQ", 0);
+  t.cagra_rank_chunk   = geti("CUVS_AMD_CAGRA_RANK_CHUNK", 0);
+  t.prune_dbg          = geti("CUVS_AMD_PRUNE_DBG", 0);
+  if (const char* e = getenv("CUVS_AMD_CAGRA_AUTO")) t.cagra_auto_multi = e[0] == 'm';
+  if (const char* e = getenv("CUVS_AMD_NATIVE_FORMAT")) t.native_format = e[0] == '1';
+  return t;
+}
+
 }  // namespace cuvs_amd
 
 using namespace cuvs_amd;
@@ -123,6 +149,7 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
     // ordered after the work queued here. A non-blocking stream would let such callers read results too early.
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamDefault));
     r->owns_stream = true;
+    r->tune = load_tuning_from_env();
     // test hook: shrink the temporary-tile budget so tiling/merge logic runs on small inputs
     // (the reference has max_row_tile_size/max_col_tile_size hooks, knn_brute_force.cuh:90-93)
     if (const char* ws = getenv("CUVS_AMD_WORKSPACE_MB")) {

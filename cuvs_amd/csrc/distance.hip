@@ -573,7 +573,7 @@ void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, cons
   CUVS_EXPECTS((m + BM - 1) / BM <= 65535, "pairwise_distance: too many query rows per call");
   bool vec = vec_ok(q, ldq, dim) && vec_ok(x, ldx, dim);
   if constexpr (std::is_same_v<TQ, TX> && (sizeof(TQ) == 4 || sizeof(TQ) == 2)) {
-    if (vec && dim % BK == 0 && getenv("CUVS_AMD_DIST_OLD") == nullptr) {
+    if (vec && dim % BK == 0 && !res.tune.dist_old) {
       launch_tile<TQ, TX, 0>(metric, grid, res.stream, q, m, ldq, x, n, ldx, dim, ep, out, ldo, append_args{});
       HIP_TRY(hipGetLastError());
       return;
@@ -606,12 +606,12 @@ void pairwise_threshold_append(resources& res, const TQ* q, int64_t m, int64_t l
   ap.n_ct = (n + BN - 1) / BN;
   ap.srt  = (int)std::min<int64_t>(16, ap.n_rt);
   ap.sct  = 256 / ap.srt;
-  if (const char* e = getenv("CUVS_AMD_TILE_DBG")) ap.dbg = atoi(e);
+  ap.dbg = res.tune.tile_dbg;
   const int64_t supertiles = ((ap.n_rt + ap.srt - 1) / ap.srt) * ((ap.n_ct + ap.sct - 1) / ap.sct);
   const int64_t blocks     = (supertiles + 7) / 8 * 8 * (int64_t)(ap.srt * ap.sct);
   CUVS_EXPECTS(blocks < (int64_t(1) << 31), "pairwise_threshold_append: grid too large");
   const bool vec = vec_ok(q, ldq, dim) && vec_ok(x, ldx, dim);
-  if (vec && dim % BK == 0 && getenv("CUVS_AMD_DIST_OLD") == nullptr) {
+  if (vec && dim % BK == 0 && !res.tune.dist_old) {
     dev_buf<unsigned long long> stats;
     if (ap.dbg & 4) {
       stats = dev_buf<unsigned long long>(res, 4);

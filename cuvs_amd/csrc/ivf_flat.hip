@@ -745,7 +745,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
   // two-phase schedule (ivf_common.hpp): nearest probe of every query first
   uint32_t head = (n_probes > 8 && metric_is_l2(idx.metric) && !large_k) ? 1u : 0u;
-  if (const char* e = getenv("CUVS_AMD_FLAT_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
+  if (res.tune.flat_head_probes >= 0) head = std::min<uint32_t>((uint32_t)res.tune.flat_head_probes, n_probes);
   const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
   dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, n_labels + 1),
     item_off(res, n_labels + 1), cand_i(res, large_k ? (size_t)bs * scores_ld : (size_t)np_max * k), top_i(res, (size_t)bs * k),
@@ -1189,7 +1189,7 @@ cuvsError_t cuvsIvfFlatSerialize(cuvsResources_t res_h, const char* filename, cu
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     auto& idx = get_flat(index);
-    if (write_native_container()) flat_write_native(res, filename, idx, index->dtype);
+    if (write_native_container(res)) flat_write_native(res, filename, idx, index->dtype);
     else flat_write_ref(res, filename, idx);
   });
 }

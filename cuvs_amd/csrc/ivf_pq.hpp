@@ -83,8 +83,10 @@ std::unique_ptr<ivf_pq_index> ivf_pq_build(resources& res, const ivf_pq_build_pa
                                            elem_t et, int64_t n, int64_t dim, bool is_host);
 void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t et, int64_t n, bool is_host,
                    const int64_t* new_ids, bool ids_on_host);
+// filter_bits: optional bitset over source ids (1 keeps the row; sample_filter.cuh bitset_filter semantics), device memory
 void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_index& idx, const void* queries,
-                   elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances);
+                   elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances,
+                   const uint32_t* filter_bits = nullptr);
 // labels [n] (uint32) and contiguous bit-packed codes [n, ceil(pq_dim*pq_bits/8)] of device rows (cuvsIvfPqTransform)
 void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data, elem_t et, int64_t n, uint32_t* out_labels,
                       uint8_t* out_codes);

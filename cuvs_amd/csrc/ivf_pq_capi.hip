@@ -492,7 +492,7 @@ cuvsError_t cuvsIvfPqSerialize(cuvsResources_t res_h, const char* filename, cuvs
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     auto& idx = get_index(index);
-    if (write_native_container()) pq_write_native(res, filename, idx, index->dtype);
+    if (write_native_container(res)) pq_write_native(res, filename, idx, index->dtype);
     else pq_write_ref(res, filename, idx);
   });
 }

@@ -224,6 +224,10 @@ struct scan_args {
   // memory, served from L2 - the reference's non-shared-memory LUT mode (ivf_pq_compute_similarity_impl.cuh:449-465)
   char* global_lut = nullptr;
   size_t global_lut_stride = 0;
+  // pre-filter (compute_distances_impl.cuh:78-80, ivf_pq_search.cuh:1111-1134): bitset over SOURCE ids, 1 keeps the row
+  const uint32_t* filter_bits = nullptr;
+  const int64_t* indices      = nullptr;  // flat row -> source id (only read when filtering)
+  uint32_t qcap = 0;  // pq_scan2_kernel: rows per survivor queue (0: the compile-time capacity; smaller: test hook)
 };
 
 // gathers of one 16-byte chunk of 8-bit codes, issued 8 at a time (8 independent ds_reads in flight;
@@ -303,6 +307,32 @@ __device__ inline void gather16_cm(acc_t& acc, const uint4 cw)
     for (int b = 0; b < 8; ++b) acc.add(e[b]);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// pre-filter test of a flat row (wave-uniform or per lane): bit `source id` of the bitset, 1 keeps the row
+__device__ inline bool row_passes(const scan_args& a, const uint32_t flat_row)
+{
+  if (a.filter_bits == nullptr) return true;
+  const int64_t sid = a.indices[flat_row];
+  return (a.filter_bits[sid >> 5] >> (sid & 31)) & 1u;
+}
+
+// The register-resident codebook (pq_dim 64 x pq_len 2 x 256 codes = 32 values per thread of a 1024-thread workgroup):
+// thread (wave w, lane l) owns subspaces (l & 15) + 16 sg, sg = 0..3, and the codes pq_code0(w, l) .. + 3. A 16-lane
+// LDS store group then writes 16 DIFFERENT subspaces of one code: contiguous in the code-major exact LUT, and one bank
+// quad each in the unpadded filter LUT of pq_scan2_kernel (whose reads rely on "bank = subspace").
+__device__ inline uint32_t pq_code0(const int wave, const int lane) { return (uint32_t)wave * 16u + ((uint32_t)lane >> 4) * 4u; }
+__device__ inline void pq_regs_load(float (&pqreg)[4][2][4], const float* __restrict__ pq_centers, const bool on)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        pqreg[sg][l][t] = on ? pq_centers[(size_t)((sl + sg * 16) * 2 + l) * 256 + cb + t] : 0.f;
 }
 
 // LDS carve of the scan kernel (all offsets multiples of 16). The FAST4 LUT must sit at LDS address 0, so the kernel
@@ -400,10 +430,13 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     // The metric test sits OUTSIDE the unrolled loops (inside, it became scalar branches around every entry),
     // and a scheduling fence after every entry keeps the compiler from overlapping entries: that overlap costs
     // ~45 spilled VGPRs at the 128-register budget, i.e. the codebook registers end up in scratch.
+    // A thread owns subspaces (lane & 15) + 16 sg and the four codes pq_code0(..) .. + 3 (see pq_regs_load): the 16
+    // lanes of an LDS store group write 16 neighbouring subspaces of ONE code - 128 contiguous bytes.
+    const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);
     if (!a.is_ip) {
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
-        const uint32_t s = wave + sg * kScanWaves;
+        const uint32_t s = sl + sg * 16;
         float q[2][QPB];
 #pragma unroll
         for (int l = 0; l < 2; ++l)
@@ -419,15 +452,16 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
             float d0 = q[0][j] - p0;
             float d1 = q[1][j] - p1;
             sc[j]    = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+            if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
           }
-          cm_lut<entry_t>::store(s, t * 64 + lane, acc_t::pack(sc));  // pq_in_regs implies FAST4
+          cm_lut<entry_t>::store(s, cb + t, acc_t::pack(sc));  // pq_in_regs implies FAST4
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     } else {
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
-        const uint32_t s = wave + sg * kScanWaves;
+        const uint32_t s = sl + sg * 16;
         float q[2][QPB];
 #pragma unroll
         for (int l = 0; l < 2; ++l)
@@ -443,8 +477,9 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
             v       = __fmaf_rn(-q[0][j], pqreg[sg][0][t], v);
             v       = __fmaf_rn(-q[1][j], cc1, v);
             sc[j]   = __fmaf_rn(-q[1][j], pqreg[sg][1][t], v);
+            if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], true);
           }
-          cm_lut<entry_t>::store(s, t * 64 + lane, acc_t::pack(sc));
+          cm_lut<entry_t>::store(s, cb + t, acc_t::pack(sc));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -581,7 +616,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
       for (int j = 0; j < QPB; ++j) {
         if (j >= (int)item.count) break;
         const uint32_t p = pid[j];
-        if (cand) {
+        if (cand && row_passes(a, base_row + v)) {  // filtered rows keep the "invalid" fill
           const size_t o  = (size_t)(p / a.n_probes) * a.scores_ld + a.pair_seg[p] + v;
           a.all_scores[o] = acc.get(j);
           a.all_rows[o]   = base_row + v;
@@ -616,6 +651,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
         m &= m - 1ull;
         const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[j]), src));
         const uint32_t ci = __builtin_amdgcn_readlane(v, src);
+        if (!row_passes(a, base_row + ci)) continue;  // pre-filter: masked rows never enter a top list
         if ((cd < kd) || (cd == kd && ci < ki)) {
           top[j].insert(cd, ci, lane);
           kd       = top[j].rank_d(kr);
@@ -912,19 +948,10 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
   const uint32_t xcd = blockIdx.x & 7u, lb = blockIdx.x >> 3, per = gridDim.x >> 3;
   const uint32_t chunk = (n_items + 7u) / 8u;
   float pqreg[4][2][4];
-  const bool pq_in_regs = FAST4 && a.pq_len == 2 && !a.per_cluster && !a.lut_fp8;  // FAST4: pq_dim 64, 8-bit codes
+  const bool pq_in_regs = FAST4 && a.pq_len == 2 && !a.per_cluster;  // FAST4: pq_dim 64, 8-bit codes
   // the code-major LUT addresses LDS absolutely (see cm_lut): fail loudly if the dynamic LDS does not start at 0
   if (FAST4 && (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
-  {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int sg = 0; sg < 4; ++sg)
-#pragma unroll
-      for (int l = 0; l < 2; ++l)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          pqreg[sg][l][t] = pq_in_regs ? a.pq_centers[(size_t)((wave + sg * kScanWaves) * 2 + l) * 256 + t * 64 + lane] : 0.f;
-  }
+  pq_regs_load(pqreg, a.pq_centers, pq_in_regs);
   // Work distribution: XCD x owns the x-th eighth of the (list-sorted) item array and its workgroups draw
   // items from it through one ticket counter, so at any moment the XCD's 32 CUs work on ~32 CONSECUTIVE items
   // (~1.6 lists) and every list is pulled into that XCD's L2 once. A static stride let the CUs drift apart by
@@ -967,19 +994,35 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan_kernel(scan_args a)
 //
 // Once every query has a k-th bound (after the head phase), ~96 % of the (row, query) pairs of a probed list are out
 // after the first 16 of the 64 subspaces, but a wave only saves work when all 64 of its rows are out for all queries
-// of the item. So the work item is cut differently here - (list, FQ = 2 x EQ queries) - and runs in three steps:
-//   filter  a LUT of the first 16 subspaces only, 16-byte entries holding FQ partial distances side by side (one
-//           ds_read_b128 serves FQ queries), and ONE pass over chunk 0 of the list's rows (1 KiB per 64 rows, four
-//           tiles in flight per wave). Rows still below the bound of a query of group A (B) go to queue A (B) in LDS;
-//   exact   for group A, then B: the exact 64-subspace LUT of pq_scan_kernel (8-byte entries, EQ queries) replaces
-//           the filter LUT, and the queued rows are scored 64 at a time, one row per lane - a full wave of useful
-//           gathers - over all 64 subspaces in the order every other path uses (bit-identical sums). The code loads of
-//           a wave's first batch are issued BEFORE the LUT build, which hides their latency;
+// of the item. So the work item is cut differently here - (list, 8 queries in NG groups of EQ) - and runs in three steps:
+//   filter  a LUT of the first 16 subspaces only, 16-byte entries = the 8 queries' partial distances as fp16 side by
+//           side, and ONE pass over chunk 0 of the list's rows (1 KiB per 64 rows, four tiles in flight per wave). A
+//           random gather of `ds_read_b128` (16 lanes per LDS cycle, 4 banks each) costs ~3 cycles per lane group in
+//           bank conflicts when all lanes look up the same subspace at random codes (round 2: 54 % of the LDS cycles
+//           of this kernel were conflict cycles). Round 3: the LUT is laid out WITHOUT padding - entry (s, code) at
+//           byte code * 256 + s * 16, i.e. in bank quad s whatever the code - and at step t lane l looks up subspace
+//           (l + t) mod 16: the 16 lanes of a group hit 16 different bank quads by construction. The code bytes of a
+//           row are rotated by (l mod 16) once per tile (v_alignbyte), the gather address is one v_perm_b32.
+//           Every lane therefore sums its 16 entries in its own order, and in fp16 whatever the score type; the filter
+//           stays SAFE because it only drops a row when that sum exceeds the bound by more than 1/32: the two sums of
+//           the same 16 non-negative numbers differ by at most a factor (1 + 2^-11)^15 / (1 - 2^-11)^15 < 1.016 (fp16,
+//           any order), the canonical partial sum only grows over the remaining 48 subspaces, so such a row is above
+//           the bound in the exact order too. Bounds at or beyond the fp16 range keep every row. For an fp32 LUT the
+//           filter entries are the exact entries rounded toward zero to fp16 (a lower bound), the argument is the same.
+//           Rows still below the bound of some query of group g go to queue g in LDS;
+//   exact   for every group: the exact 64-subspace LUT of pq_scan_kernel (8-byte entries, EQ queries: 4 x fp16 or
+//           2 x fp32) replaces the filter LUT, and the queued rows are scored 64 at a time, one row per lane, over all
+//           64 subspaces in the order every other path uses (bit-identical sums). The code loads of a wave's first
+//           batch are issued BEFORE the LUT build, which hides their latency;
 //   merge   per group, as in pq_scan_kernel.
-// The partial sums of the filter are the exact partial sums (same LUT entries, same order), and fp addition of
-// non-negative terms is monotone, so a dropped row can never have reached a top list: results are identical to
-// pq_scan_kernel's. A queue that overflows (cold bounds) makes the item fall back to scoring every row.
-constexpr int kQCap = 3072;  // rows per survivor queue (two queues per workgroup)
+// Results are identical to pq_scan_kernel's: a dropped row can never have reached a top list. A queue that overflows
+// (cold bounds) makes the group fall back to scoring every row.
+constexpr int kQueueBytes = 24 * 1024;  // survivor queues of a workgroup (NG queues of kQueueBytes / 4 / NG rows)
+
+struct filter_lut {  // code-major, 16 subspaces x 16 bytes per code row, no padding: bank quad == subspace
+  static constexpr uint32_t kRow = 256;
+  static constexpr size_t bytes() { return (size_t)256 * kRow; }
+};
 
 struct scan2_layout {
   size_t qv, cv, ctrl, pid, slots, queue, total;
@@ -988,42 +1031,59 @@ struct scan2_layout {
     size_t off = (lut_bytes + 15) & ~size_t(15);
     qv = off;    off += (((size_t)fq * rot_dim * 4) + 15) & ~size_t(15);
     cv = off;    off += (((size_t)rot_dim * 4) + 15) & ~size_t(15);
-    ctrl = off;  off += 32 * 4;  // [0..7] k-th bound keys, [8..15] "inserted" flags, [16] block ticket, [17..18] queue
-                                 // lengths, [19] spare
+    ctrl = off;  off += 32 * 4;  // [0..7] k-th bound keys, [8..15] "inserted" flags, [16] block ticket, [17..20] queue
+                                 // lengths
     pid = off;   off += 8 * 4;
     slots = off; off += 2 * 16;
-    queue = off; off += (size_t)2 * kQCap * 4;
+    queue = off; off += (size_t)kQueueBytes;
     total = off;
   }
 };
 
-template <typename entry_t>
-struct filter_lut {  // code-major, 16 subspaces x 16 bytes + 16 bytes of padding per code row
-  static constexpr uint32_t kRow = 16 * 16 + 16;
-  static constexpr size_t bytes() { return (size_t)256 * kRow; }
-};
-
-template <typename LutT, typename AccT, int EQ, int E>
-__device__ inline void pq_scan2_item(const scan_args& a, const work_item item, char* smem, const float (&pqreg)[4][2][4],
-                                     const work_item* __restrict__ share, const uint32_t share_len,
-                                     const uint32_t next_ticket, const int next_slot_id)
+// two floats -> packed fp16, rounded toward zero (a lower bound of non-negative entries)
+__device__ inline uint32_t pack_half_rtz(float a, float b)
 {
-  constexpr int FQ = 2 * EQ;
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// smallest fp16 >= v for 0 <= v < 60000 (bits)
+__device__ inline uint32_t half_bits_round_up(float v)
+{
+  if (v < 6.2e-5f) return 0x0400u;  // below the normal range: the smallest normal number bounds it
+  uint32_t h = pack_half_rtz(v, v) & 0xffffu;
+  if ((float)__builtin_bit_cast(_Float16, (uint16_t)h) < v) h += 1u;
+  return h;
+}
+__device__ inline uint32_t pk_sub_f16(uint32_t a, uint32_t b)  // a - b, two halves
+{
+  uint32_t r;
+  asm volatile("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// X: the kernel-wide per-lane constants of the rotated filter gathers - byte b of xoff[w] = ((lane + 4 w + b) & 15) << 4,
+// the byte offset of the subspace this lane looks up at step 4 w + b inside a 256-byte code row
+template <typename LutT, typename AccT, int EQ, int NG, int E>
+__device__ inline void pq_scan2_item(const scan_args& a, const work_item item, char* smem, const float (&pqreg)[4][2][4],
+                                     const uint32_t (&xoff)[4], const work_item* __restrict__ share,
+                                     const uint32_t share_len, const uint32_t next_ticket, const int next_slot_id)
+{
+  constexpr int FQ = EQ * NG;
+  static_assert(FQ == 8 && (NG == 2 || NG == 4), "the filter entry holds 8 fp16 partial distances");
+  constexpr uint32_t kCap = kQueueBytes / 4 / NG;
   using acc_t   = lut_acc<LutT, AccT, EQ>;
   using entry_t = typename acc_t::entry_t;
   using XL      = cm_lut<entry_t>;
-  using FL      = filter_lut<entry_t>;
+  using FL      = filter_lut;
   typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-  typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-  static_assert(sizeof(entry_t) == 8, "the filter entry is two exact entries side by side");
+  static_assert(sizeof(entry_t) == 8, "exact LUT entries are 8 bytes (4 x fp16 or 2 x fp32)");
 
   const scan2_layout lay(XL::bytes(), FQ, a.rot_dim);
-  entry_t* lut     = reinterpret_cast<entry_t*>(smem);
   float* qv        = reinterpret_cast<float*>(smem + lay.qv);
   uint32_t* ctrl   = reinterpret_cast<uint32_t*>(smem + lay.ctrl);
   uint32_t* pid    = reinterpret_cast<uint32_t*>(smem + lay.pid);
   uint4* next_slot = reinterpret_cast<uint4*>(smem + lay.slots) + next_slot_id;
   uint32_t* queue  = reinterpret_cast<uint32_t*>(smem + lay.queue);
+  const uint32_t qcap = a.qcap != 0u ? min(a.qcap, kCap) : kCap;
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -1050,7 +1110,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     ctrl[tid]        = p != 0xffffffffu ? a.query_kth[p / a.n_probes] : 0u;
     ctrl[8 + tid]    = 0u;
   }
-  if (tid >= 16 && tid < 20) ctrl[tid] = 0u;
+  if (tid >= 16 && tid < 24) ctrl[tid] = 0u;
   // query residuals (L2 only here); every thread resolves its pair id itself: no barrier after the header loads
   for (uint32_t t = tid; t < FQ * a.rot_dim; t += kScanThreads) {
     const uint32_t j = t / a.rot_dim, dd = t % a.rot_dim;
@@ -1064,30 +1124,34 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   __syncthreads();
   stat_phase(ST_HEADER);
 
-  // ---- filter LUT: wave w owns subspace w (its codebook values are pqreg[0][.][.]); entry (s, code) at byte
-  // code * 272 + s * 16 holds group A's EQ partial scores, then group B's
+  const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);  // this thread's subspaces / codes (pq_regs_load)
+
+  // ---- filter LUT: subspaces 0..15 (this thread: subspace sl, codes cb .. cb + 3), the 8 queries' entries as fp16
   if (!(a.dbg & 1)) {
-    const uint32_t s = wave;
     float q[2][FQ];
 #pragma unroll
     for (int l = 0; l < 2; ++l)
 #pragma unroll
-      for (int j = 0; j < FQ; ++j) q[l][j] = qv[j * a.rot_dim + s * 2 + l];
+      for (int j = 0; j < FQ; ++j) q[l][j] = qv[j * a.rot_dim + sl * 2 + l];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const float p0 = pqreg[0][0][t], p1 = pqreg[0][1][t];
+      u32x4_t ev;
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        float sc[EQ];
+      for (int jj = 0; jj < 4; ++jj) {
+        float sc[2];
 #pragma unroll
-        for (int j = 0; j < EQ; ++j) {
-          const float d0 = q[0][g * EQ + j] - p0;
-          const float d1 = q[1][g * EQ + j] - p1;
-          sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-          if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], false);  // L2 only here: the unsigned fp_8bit<5, false>
+        for (int h = 0; h < 2; ++h) {
+          const float d0 = q[0][jj * 2 + h] - p0;
+          const float d1 = q[1][jj * 2 + h] - p1;
+          sc[h]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+          if (a.lut_fp8) sc[h] = fp8_round_trip<AccT>(sc[h], false);  // L2 only here: the unsigned fp_8bit<5, false>
         }
-        *(typename XL::wr_ptr)(uintptr_t)((uint32_t)(t * 64 + lane) * FL::kRow + s * 16 + g * 8) = acc_t::pack(sc);
+        // fp16 LUT: the exact entry itself (round to nearest, as the exact LUT stores it); fp32 LUT: rounded toward zero
+        if constexpr (sizeof(LutT) == 2) ev[jj] = __builtin_bit_cast(uint32_t, f16x2_t{to_lut_half(sc[0]), to_lut_half(sc[1])});
+        else                             ev[jj] = pack_half_rtz(sc[0], sc[1]);
       }
+      *(__attribute__((address_space(3))) u32x4_t*)(uintptr_t)((cb + t) * FL::kRow + sl * 16) = ev;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1108,11 +1172,13 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     return !live ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
   };
 
-  // ---- filter pass: chunk 0 of every row against the FQ bounds; a ticket = a block of 4 tiles (4 loads in flight)
+  // ---- filter pass: chunk 0 of every row against the 8 bounds; a ticket = a block of 4 tiles (4 loads in flight)
   {
     const uint32_t rot      = (a.dbg & 64) ? 0u : (item.first / FQ);
     const uint32_t n_blocks = (n_tiles + 3u) / 4u;
     const uint32_t rot_b    = n_blocks ? (rot * kScanWaves) % n_blocks : 0u;
+    const uint32_t rr       = (uint32_t)lane & 15u;  // byte rotation of this lane's code words
+    const uint32_t rb       = rr & 3u;               //   = rb bytes after (rr >> 2) dwords
     uint32_t ticket = 0u;
     if (lane == 0) ticket = atomicAdd(&ctrl[16], 1u);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
@@ -1126,58 +1192,92 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
         const uint32_t tile = min(blk * 4 + t, n_tiles - 1);
         c0[t] = codes16[((g0 + (size_t)tile) * 4) * 64 + lane];
       }
-      float bf[FQ];
+      // the 8 bounds as fp16, widened by 1/32 and rounded up (lane j < 8 converts query j's); a query without a bound
+      // yet, or with one beyond the fp16 range, keeps every row of its group alive (`force`)
+      uint32_t bfh[4];
+      uint32_t force = 0u;  // bit g: group g keeps every row
+      {
+        const int j       = lane & 7;
+        const uint32_t kk = ctrl[j];
+        uint32_t hb       = 0xfc00u;  // -inf: no such query in this item
+        bool fo           = false;
+        if (j < (int)item.count) {
+          const float bw = (kk >= 0xff800000u ? INFINITY : key_to_float(kk)) * 1.03125f;
+          if (!(bw < 60000.0f) || (a.dbg & 8)) { fo = true; hb = 0x7bffu; }  // dbg 8: early stop off (ablation)
+          else hb = half_bits_round_up(bw);
+        }
+        const uint32_t fm = (uint32_t)__ballot(fo) & 0xffu;
+        uint32_t hj[8];
 #pragma unroll
-      for (int j = 0; j < FQ; ++j)
-        bf[j] = key_bound(__builtin_amdgcn_readfirstlane(ctrl[j]), j < (int)item.count);
-      uint32_t flags = 0u;  // bit 2t: row of tile t alive for group A, bit 2t + 1: for group B
+        for (int q = 0; q < 8; ++q) hj[q] = __builtin_amdgcn_readlane(hb, q);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) bfh[d] = hj[2 * d] | (hj[2 * d + 1] << 16);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) force |= ((fm >> (g * EQ)) & ((1u << EQ) - 1u)) ? (1u << g) : 0u;
+      }
+      unsigned long long mk[NG][4];  // lanes whose row of tile t is still alive for group g
+      uint32_t flags = 0u;           // this lane's bits of mk: bit NG * t + g
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        acc_t accA, accB;
-        const uint32_t ws[4] = {c0[t].x, c0[t].y, c0[t].z, c0[t].w};
+        // rotate the 16 code bytes right by rr: byte i of R = code of subspace (i + rr) & 15
+        uint32_t w0 = c0[t].x, w1 = c0[t].y, w2 = c0[t].z, w3 = c0[t].w;
+        if (rr & 4u) { const uint32_t x = w0; w0 = w1; w1 = w2; w2 = w3; w3 = x; }
+        if (rr & 8u) { uint32_t x = w0; w0 = w2; w2 = x; x = w1; w1 = w3; w3 = x; }
+        uint32_t R[4];
+        R[0] = __builtin_amdgcn_alignbyte(w1, w0, rb);
+        R[1] = __builtin_amdgcn_alignbyte(w2, w1, rb);
+        R[2] = __builtin_amdgcn_alignbyte(w3, w2, rb);
+        R[3] = __builtin_amdgcn_alignbyte(w0, w3, rb);
+        uint32_t acc[4] = {0u, 0u, 0u, 0u};  // 8 fp16 partial sums
+        if (!(a.dbg & 2)) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          u32x4_t e[4];
+          for (int h = 0; h < 4; ++h) {
+            u32x4_t e[4];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const uint32_t w   = ws[h];
-            const uint32_t row = b == 0 ? sdwa_byte_times<0>(w, FL::kRow) : b == 1 ? sdwa_byte_times<1>(w, FL::kRow)
-                               : b == 2 ? sdwa_byte_times<2>(w, FL::kRow) : sdwa_byte_times<3>(w, FL::kRow);
-            e[b] = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)(row + (uint32_t)(h * 4 + b) * 16);
+            for (int b = 0; b < 4; ++b) {
+              // address = code << 8 | subspace offset: byte 0 from xoff[h] byte b, byte 1 from R[h] byte b
+              const uint32_t ad = __builtin_amdgcn_perm(R[h], xoff[h], 0x0c0c0400u + 0x0101u * (uint32_t)b);
+              e[b] = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)ad;
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              asm volatile("v_pk_add_f16 %0, %0, %4\n\tv_pk_add_f16 %1, %1, %5\n\tv_pk_add_f16 %2, %2, %6\n\tv_pk_add_f16 %3, %3, %7"
+                           : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                           : "v"(e[b].x), "v"(e[b].y), "v"(e[b].z), "v"(e[b].w));
+            __builtin_amdgcn_sched_barrier(0);
           }
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            accA.add(__builtin_bit_cast(entry_t, u32x2_t{e[b].x, e[b].y}));
-            accB.add(__builtin_bit_cast(entry_t, u32x2_t{e[b].z, e[b].w}));
-          }
-          __builtin_amdgcn_sched_barrier(0);
         }
-        bool aliveA = false, aliveB = false;
+        // bound - sum per half: a set sign bit = that query is out (no inf - inf here: a +inf bound is `force`)
+        uint32_t dv[4];
 #pragma unroll
-        for (int j = 0; j < EQ; ++j) {
-          aliveA = aliveA || (accA.get(j) <= bf[j]);
-          aliveB = aliveB || (accB.get(j) <= bf[EQ + j]);
-        }
+        for (int d = 0; d < 4; ++d) dv[d] = pk_sub_f16(bfh[d], acc[d]);
         const bool valid = (blk * 4 + t) * 64 + lane < len;  // also drops the clamped tiles past the end of the list
-        flags |= (aliveA && valid ? 1u : 0u) << (2 * t);
-        flags |= (aliveB && valid ? 1u : 0u) << (2 * t + 1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          bool dead;
+          if constexpr (NG == 2) dead = ((dv[2 * g] & dv[2 * g + 1]) & 0x80008000u) == 0x80008000u;
+          else                   dead = (dv[g] & 0x80008000u) == 0x80008000u;
+          const bool alive = valid && (!dead || ((force >> g) & 1u));
+          mk[g][t] = __ballot(alive);
+          flags |= (alive ? 1u : 0u) << (NG * t + g);
+        }
       }
       // reserve queue space for the block's survivors (one LDS atomic per group) and write them
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        unsigned long long m[4];
+      for (int g = 0; g < NG; ++g) {
         uint32_t n = 0u;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { m[t] = __ballot((flags >> (2 * t + g)) & 1u); n += (uint32_t)__popcll(m[t]); }
+        for (int t = 0; t < 4; ++t) n += (uint32_t)__popcll(mk[g][t]);
         if (n == 0u) continue;
         uint32_t base = 0u;
         if (lane == 0) base = atomicAdd(&ctrl[17 + g], n);
         base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[t], 0u));
-          if (((flags >> (2 * t + g)) & 1u) && pos < (uint32_t)kQCap) queue[g * kQCap + pos] = (blk * 4 + t) * 64 + lane;
-          base += (uint32_t)__popcll(m[t]);
+          const unsigned long long m = mk[g][t];
+          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          if (((flags >> (NG * t + g)) & 1u) && pos < qcap) queue[g * kCap + pos] = (blk * 4 + t) * 64 + lane;
+          base += (uint32_t)__popcll(m);
         }
       }
       ticket = __builtin_amdgcn_readfirstlane(next);
@@ -1186,7 +1286,12 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   if (stat) { stat_phase(ST_SCAN); if (wave == 0) { stat_add(ST_ROWS, len); stat_add(ST_ITEMS, 1); } }
   __syncthreads();
   stat_phase(ST_ALIVE2);  // (pq_scan2: barrier wait after the filter pass)
-  if (stat && wave == 0) stat_add(ST_QUEUED, ctrl[17] + ctrl[18]);
+  if (stat && wave == 0) {
+    uint32_t nq = 0u;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) nq += ctrl[17 + g];
+    stat_add(ST_QUEUED, nq);
+  }
 
   // ---- exact passes
   wave_top<E> top[EQ];
@@ -1196,15 +1301,15 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];
   };
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     if (g * EQ >= (int)item.count) break;  // workgroup-uniform: no queries in this group
     uint32_t* kthb = ctrl + g * EQ;        // bounds of this group's queries
     uint32_t* ins  = ctrl + 8 + g * EQ;
     const int cnt_g = min(EQ, (int)item.count - g * EQ);
     const uint32_t n_q   = ctrl[17 + g];
-    const bool overflow  = n_q > (uint32_t)kQCap;
+    const bool overflow  = n_q > qcap;
     const uint32_t n_bat = overflow ? n_tiles : (n_q + 63u) / 64u;
-    const uint32_t* qg   = queue + g * kQCap;
+    const uint32_t* qg   = queue + g * kCap;
     auto batch_row = [&](const uint32_t b, bool& valid) {
       uint32_t v;
       if (overflow) { v = b * 64 + lane; valid = v < len; }
@@ -1218,12 +1323,12 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     if ((uint32_t)wave < n_bat) { v0 = batch_row(wave, valid0); load_codes(v0, cur); }
     stat_phase(ST_MERGE);
     if (g > 0) __syncthreads();  // every wave is done with the previous LUT / merge area
-    stat_phase(ST_S2_CALLS);  // (pq_scan2: barrier wait before the second exact LUT build)
+    stat_phase(ST_S2_CALLS);  // (pq_scan2: barrier wait before the next exact LUT build)
     // ---- exact LUT of the group's EQ queries (same arithmetic and layout as pq_scan_kernel)
     if (!(a.dbg & 1)) {
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
-        const uint32_t s = wave + sg * kScanWaves;
+        const uint32_t s = sl + sg * 16;
         float q[2][EQ];
 #pragma unroll
         for (int l = 0; l < 2; ++l)
@@ -1240,7 +1345,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
             sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
             if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
           }
-          XL::store(s, t * 64 + lane, acc_t::pack(sc));
+          XL::store(s, cb + t, acc_t::pack(sc));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1306,6 +1411,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
           m &= m - 1ull;
           const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dj[j]), src));
           const uint32_t ci = __builtin_amdgcn_readlane(v, src);
+          if (!row_passes(a, base_row + ci)) continue;  // pre-filter: masked rows never enter a top list
           if ((cd < kd) || (cd == kd && ci < ki)) {
             top[j].insert(cd, ci, lane);
             kd       = top[j].rank_d(kr);
@@ -1387,7 +1493,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   if (threadIdx.x == 0) *next_slot = next_hdr;
 }
 
-template <typename LutT, typename AccT, int EQ, int E>
+template <typename LutT, typename AccT, int EQ, int NG, int E>
 __global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1398,17 +1504,18 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
   const uint32_t chunk = (n_items + 7u) / 8u;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();  // see cm_lut
   float pqreg[4][2][4];
+  pq_regs_load(pqreg, a.pq_centers, true);
+  uint32_t xoff[4];
   {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
-    for (int sg = 0; sg < 4; ++sg)
+    for (int w = 0; w < 4; ++w) {
+      xoff[w] = 0u;
 #pragma unroll
-      for (int l = 0; l < 2; ++l)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          pqreg[sg][l][t] = a.pq_centers[(size_t)((wave + sg * kScanWaves) * 2 + l) * 256 + t * 64 + lane];
+      for (int b = 0; b < 4; ++b) xoff[w] |= (((lane + 4u * w + b) & 15u) << 4) << (8 * b);
+    }
   }
-  const scan2_layout lay(cm_lut<entry_t>::bytes(), 2 * EQ, a.rot_dim);
+  const scan2_layout lay(cm_lut<entry_t>::bytes(), EQ * NG, a.rot_dim);
   work_item* sh_item       = reinterpret_cast<work_item*>(smem + lay.slots);
   const uint32_t share0    = min(n_items, xcd * chunk);
   const uint32_t share_len = min(chunk, n_items - share0);
@@ -1424,17 +1531,18 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
     if (cur.pad == 0xffffffffu) break;  // workgroup-uniform
     uint32_t next_ticket = 0xffffffffu;
     if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
-    pq_scan2_item<LutT, AccT, EQ, E>(a, cur, smem, pqreg, share, share_len, next_ticket, buf ^ 1);
+    pq_scan2_item<LutT, AccT, EQ, NG, E>(a, cur, smem, pqreg, xoff, share, share_len, next_ticket, buf ^ 1);
     __syncthreads();
   }
 }
 
-template <typename LutT, typename AccT, int EQ>
+template <typename LutT, typename AccT, int EQ, int NG>
 void launch_scan2(resources& res, const scan_args& a, unsigned grid)
 {
   using entry_t = typename lut_acc<LutT, AccT, EQ>::entry_t;
-  const size_t smem = scan2_layout(cm_lut<entry_t>::bytes(), 2 * EQ, a.rot_dim).total;
-  auto kern = pq_scan2_kernel<LutT, AccT, EQ, 1>;
+  const size_t smem = scan2_layout(cm_lut<entry_t>::bytes(), EQ * NG, a.rot_dim).total;
+  CUVS_EXPECTS(smem <= res.lds_per_block, "pq_scan2_kernel: %zu bytes of LDS", smem);
+  auto kern = pq_scan2_kernel<LutT, AccT, EQ, NG, 1>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem));
   profile_begin(res, "pq_scan_kernel");
@@ -1647,7 +1755,7 @@ __global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float
 }  // namespace
 
 void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_index& idx, const void* queries,
-                   elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances)
+                   elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances, const uint32_t* filter_bits)
 {
   CUVS_EXPECTS(k > 0, "parameter `k` in top-k must be positive.");
   CUVS_EXPECTS((int64_t)k <= idx.size,
@@ -1714,7 +1822,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   // (measured at 100M x 128, n_probes 128: batch 1000 3.2 vs 4.0 ms with the head phase, batch 100 1.7 vs 1.3 ms without:
   // a second launch and a twice as long label range only pay off once the batch is large)
   uint32_t head = (n_probes > 8 && n_queries >= 256 && !large_k) ? 1u : 0u;
-  if (const char* e = getenv("CUVS_AMD_PQ_HEAD_PROBES")) head = std::min<uint32_t>((uint32_t)atoi(e), n_probes);
+  if (res.tune.pq_head_probes >= 0) head = std::min<uint32_t>((uint32_t)res.tune.pq_head_probes, n_probes);
   if (idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) head = 0;  // signed LUT entries: no early stop
   const bool sharded      = idx.shard_world > 1;  // list-sharded index: foreign probes go to a bucket that is never scanned
   const uint32_t n_ranges = head > 0 ? 2 * idx.n_lists : idx.n_lists;
@@ -1742,7 +1850,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     // slice of the batch and one all-gather of the probe lists (n_probes x 4 B per query) replaces world - 1 replicas of
     // the coarse GEMM + select_k (the same deterministic kernels on the same inputs: identical probes)
     const bool shard_coarse = idx.shard_comm != nullptr && p.coarse_search_dtype == 0 &&  // (one rank: the same calls)
-                              getenv("CUVS_AMD_SHARD_COARSE_REPLICATED") == nullptr;
+                              !res.tune.shard_coarse_replicated;
     if (shard_coarse) {
       const int64_t slice = (nq + idx.shard_world - 1) / idx.shard_world;
       const int64_t s0    = std::min<int64_t>(nq, (int64_t)idx.shard_rank * slice);
@@ -1765,11 +1873,12 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       labels = phase_labels.data();
     }
     // the tail phase (warm bounds) of the common configuration runs pq_scan2_kernel on items of 2 * qpb pairs
-    // (fp16 LUT only: the fp32-LUT instance of the kernel does not fit 128 VGPRs)
-    bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && lut_half && qpb == 4;  // (k <= 64 excludes the non-fused path)
-    if (const char* e = getenv("CUVS_AMD_PQ_SCAN2")) use2 = use2 && atoi(e) != 0;
+    // (8 pairs whatever the LUT type: two groups of four with an fp16 LUT, four groups of two with an fp32 LUT)
+    bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 &&  // (k <= 64 excludes the non-fused path)
+                ((lut_half && qpb == 4) || (!lut_half && qpb == 2));
+    use2 = use2 && res.tune.pq_scan2 != 0;
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
-                     items.data(), (int)idx.n_lists, use2 ? 2 * qpb : qpb);
+                     items.data(), (int)idx.n_lists, use2 ? 8 : qpb);
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
     // per-pair candidate rows start out invalid: the scan only writes the rows of pairs that found something
@@ -1794,7 +1903,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     a.pq_bits = idx.pq_bits; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.k = (uint32_t)k_scan;
     a.is_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
     a.lut_fp8 = lut_fp8 ? 1 : 0;
-    a.dbg   = getenv("CUVS_AMD_SCAN_DEBUG") ? atoi(getenv("CUVS_AMD_SCAN_DEBUG")) : 0;
+    a.dbg   = res.tune.scan_debug;
+    a.qcap  = (uint32_t)std::max(0, res.tune.pq_qcap);
+    a.filter_bits = filter_bits; a.indices = idx.indices.data();
     const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);  // persistent: one workgroup per CU
     dev_buf<unsigned long long> stats(res, (a.dbg & (128 | 512)) ? (size_t)ST_COUNT * grid * kScanWaves : 0);
     a.stats = stats.data();
@@ -1836,8 +1947,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       a.xcd_ticket = tickets.data() + 8 * 32;
       a.item_begin = item_off.data() + idx.n_lists;  a.item_end = item_off.data() + 2 * idx.n_lists;
       if (!use2)          launch(a);  // tail phase: warm bounds
-      else if (!acc_half) launch_scan2<__half, float, 4>(res, a, grid);
-      else                launch_scan2<__half, __half, 4>(res, a, grid);
+      else if (!lut_half) launch_scan2<float, float, 2, 4>(res, a, grid);
+      else if (!acc_half) launch_scan2<__half, float, 4, 2>(res, a, grid);
+      else                launch_scan2<__half, __half, 4, 2>(res, a, grid);
     } else {
       a.xcd_ticket = tickets.data();
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;

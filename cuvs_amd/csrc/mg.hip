@@ -456,7 +456,9 @@ void mg_search(mg_index& idx, void* base_params, int search_mode, int64_t n_rows
 void mg_serialize(mg_index& idx, DLDataType dtype, const char* filename)
 {
   CUVS_EXPECTS(filename != nullptr, "filename is null");
-  CUVS_EXPECTS(!write_native_container(), "multi-GPU index files use the reference container: unset CUVS_AMD_NATIVE_FORMAT");
+  for (auto& sh : idx.shards)
+    CUVS_EXPECTS(sh.res == 0 || !write_native_container(*as_res(sh.res)),
+                 "multi-GPU index files use the reference container: unset CUVS_AMD_NATIVE_FORMAT");
   {
     npy_writer w(filename);
     char prefix[4];

@@ -349,10 +349,6 @@ inline bool is_native_container(const char* name)
   return n == 8 && memcmp(m, "CUVSAMD1", 8) == 0;
 }
 // CUVS_AMD_NATIVE_FORMAT=1 makes *Serialize write this library's own container instead of the reference's
-inline bool write_native_container()
-{
-  const char* e = getenv("CUVS_AMD_NATIVE_FORMAT");
-  return e != nullptr && e[0] == '1';
-}
+inline bool write_native_container(const resources& res) { return res.tune.native_format; }
 
 }  // namespace cuvs_amd

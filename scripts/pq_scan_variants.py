@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Build the bench.py IVF-PQ index once, then time the search under several scan-kernel settings
-(environment switches read per call: CUVS_AMD_SCAN_DEBUG, CUVS_AMD_PQ_HEAD_PROBES). Prints one line per variant:
+(environment switches CUVS_AMD_SCAN_DEBUG, CUVS_AMD_PQ_HEAD_PROBES, CUVS_AMD_PQ_SCAN2, CUVS_AMD_PQ_QCAP: read when a handle
+is created, so every variant gets its own handle). Prints one line per variant:
 search ms (k*refine candidates), pq_scan_kernel ms per search, and whether the results equal those of the first
 variant with the same LUT / accumulator types (LUT=f16|f32|u8, ACC=f16|f32; default f16/f16).
 
@@ -46,8 +47,11 @@ def main():
     nb = torch.empty((args.batch, args.k), dtype=torch.int64, device=dev)
     ds = torch.empty((args.batch, args.k), dtype=torch.float32, device=dev)
     firsts = {}
+    keys = {"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES", "S2": "CUVS_AMD_PQ_SCAN2", "QCAP": "CUVS_AMD_PQ_QCAP"}
     for v in args.variants:
         lut, acc = "f16", "f16"
+        for name in keys.values():
+            os.environ.pop(name, None)
         for kv in v.split(","):
             key, val = kv.split("=")
             if key == "LUT":
@@ -55,9 +59,10 @@ def main():
             elif key == "ACC":
                 acc = val
             else:
-                os.environ[{"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES", "S2": "CUVS_AMD_PQ_SCAN2"}[key]] = val
+                os.environ[keys[key]] = val
         if lut == "f32":
             acc = "f32"
+        res = cuvs_amd.common.Resources()  # reads the switches
         sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=dt[lut], internal_distance_dtype=dt[acc],
                                  max_internal_batch_size=args.batch)
         first = firsts.get((lut, acc))

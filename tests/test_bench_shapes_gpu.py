@@ -1,0 +1,172 @@
+"""GPU: fixed parity cases at the shapes bench.py times ("next round" item 1).
+
+* C3 shape - IVF-PQ with lists of thousands of rows (pq_dim 64 / 8 bit / pq_len 2: pq_scan_kernel head phase +
+  pq_scan2_kernel tail phase with its multi-block filter tickets and survivor queues), every LUT / score type the bench
+  runs, against the oracle, against the same search with the tail phase on pq_scan_kernel (CUVS_AMD_PQ_SCAN2=0) and with
+  the survivor queues shrunk until they overflow (CUVS_AMD_PQ_QCAP: the "score every row" fallback);
+* C4 shape - CAGRA 768-d fp16, graph degree 64, itopk 64: single_cta bit-exact against oracle.cagra_search, multi_cta
+  and auto by recall against exact kNN;
+* C5 shape - IVF-PQ on 96-d int8 rows (pq_dim 64 -> rot_dim 128, the kDivisor scaling of ann_utils.cuh:134-160) with
+  the reference's int8 generator (uniformInt[1, 20), ann_ivf_pq.cuh:150-168): parity + the reference's recall bound.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+_LUTS = {"f32": np.float32, "f16": np.float16, "fp8": np.uint8}
+
+
+def _mixture(n, d, q, seed, modes=64, latent=16, sigma=0.35):
+    """Gaussian mixture in a latent subspace embedded in R^d (what bench.py draws): neighbours are much closer than the
+    bulk of a probed list, so the k-th bounds prune as they do at the bench shape."""
+    rng = np.random.default_rng(seed)
+    basis = rng.standard_normal((latent, d)).astype(np.float32) / math.sqrt(latent)
+    centres = rng.standard_normal((modes, latent)).astype(np.float32) * 2.0
+
+    def draw(m):
+        z = centres[rng.integers(0, modes, size=m)] + sigma * rng.standard_normal((m, latent)).astype(np.float32)
+        return (z @ basis + 0.02 * rng.standard_normal((m, d)).astype(np.float32)).astype(np.float32)
+
+    return draw(n), draw(q)
+
+
+def _pq_build(x, **kw):
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    return ivf_pq.build(ivf_pq.IndexParams(**kw), torch.from_numpy(x).cuda())
+
+
+def _pq_search(index, q, k, **kw):
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    d, i = ivf_pq.search(ivf_pq.SearchParams(**kw), index, torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def big_lists():
+    """200k x 128, 16 lists of ~12.5k rows (the bench's lists hold ~6.1k), 512 queries: two-phase schedule, 8-pair items,
+    several 4-tile filter blocks per wave."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(200_000, 128, 512, seed=2024)
+    index = _pq_build(x, n_lists=16, pq_dim=64, pq_bits=8, kmeans_n_iters=10, kmeans_trainset_fraction=0.2)
+    return x, q, index, ivf_pq.export_for_oracle(index)
+
+
+@pytest.mark.parametrize("lut,acc", [("f16", "f16"), ("f16", "f32"), ("fp8", "f16"), ("f32", "f32")])
+def test_c3_shape_lists_of_thousands_of_rows(big_lists, lut, acc, monkeypatch):
+    x, q, index, ex = big_lists
+    k, n_probes = 20, 8
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    # the same search with the tail phase on pq_scan_kernel (no filter stage)
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN2", "0")
+    pd, pi = _pq_search(index, q, k, **kw)
+    assert (gi == pi).all() and (gd == pd).all()
+    monkeypatch.delenv("CUVS_AMD_PQ_SCAN2")
+    # survivor queues of 64 rows: every group overflows and scores every row of the list
+    monkeypatch.setenv("CUVS_AMD_PQ_QCAP", "64")
+    qd, qi = _pq_search(index, q, k, **kw)
+    assert (gi == qi).all() and (gd == qd).all()
+
+
+def test_c3_shape_cold_bounds_overflow_the_default_queues(big_lists, monkeypatch):
+    """Uniform queries far from every mode: bounds stay loose, most rows survive the filter and the default queues
+    (3072 rows per group for 12.5k-row lists) overflow without any test hook."""
+    x, _, index, ex = big_lists
+    rng = np.random.default_rng(5)
+    q = (rng.random((300, 128), dtype=np.float32) * 4.0 - 2.0).astype(np.float32)
+    gd, gi = _pq_search(index, q, 64, n_probes=6, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+    od, oi = oracle.ivf_pq_search(ex, q, 64, 6, lut="f16", acc="f32")
+    assert (gi == oi).all() and (gd == od).all()
+
+
+def test_c3_shape_recall_with_refine(big_lists):
+    """bench.py's step: search(2k) + refine(k) at fp16 LUT / fp32 score reaches the headline's recall bar on the mixture."""
+    import torch
+    from cuvs_amd.neighbors import refine
+
+    x, q, index, _ = big_lists
+    k = 10
+    _, gi = _pq_search(index, q, 2 * k, n_probes=8, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+    _, ri = refine.refine(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(gi).cuda(), k)
+    torch.cuda.synchronize()
+    _, ti = oracle.exact_knn(q, x, k)
+    assert oracle.recall(ri.cpu().numpy(), ti) >= 0.9
+
+
+# ---------------------------------------------------------------------------------------------------------- C4 shape
+@pytest.fixture(scope="module")
+def cagra_768():
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(768)
+    z = rng.standard_normal((20_000, 24)).astype(np.float32)
+    basis = rng.standard_normal((24, 768)).astype(np.float32) / math.sqrt(24)
+    x = (z @ basis + 0.02 * rng.standard_normal((20_000, 768)).astype(np.float32)).astype(np.float16)
+    zq = rng.standard_normal((256, 24)).astype(np.float32)
+    q = (zq @ basis + 0.02 * rng.standard_normal((256, 768)).astype(np.float32)).astype(np.float16)
+    index = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), torch.from_numpy(x).cuda())
+    return x, q, index
+
+
+def test_c4_shape_single_cta_walk_is_the_oracle_walk(cagra_768):
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    x, q, index = cagra_768
+    assert index.graph_degree == 64
+    graph = index.graph.cpu().numpy().view(np.uint32)
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64, algo="single_cta"), index, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    gi = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    od, oi = oracle.cagra_search(x, graph, q, 10, itopk_size=64)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (d.cpu().numpy() == od).all()
+
+
+@pytest.mark.parametrize("algo", ["multi_cta", "auto"])
+def test_c4_shape_recall(cagra_768, algo):
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    x, q, index = cagra_768
+    _, i = cagra.search(cagra.SearchParams(itopk_size=64, algo=algo), index, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    _, ti = oracle.exact_knn(q.astype(np.float32), x.astype(np.float32), 10)
+    assert oracle.recall(i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, ti) >= 0.95
+
+
+# ---------------------------------------------------------------------------------------------------------- C5 shape
+@pytest.mark.parametrize("lut,acc", [("f16", "f32"), ("f16", "f16"), ("f32", "f32")])
+def test_c5_shape_int8_rows(lut, acc):
+    from cuvs_amd.neighbors import ivf_pq
+
+    rng = np.random.default_rng(96)
+    n, d, nq, k, n_lists, n_probes = 60_000, 96, 400, 10, 32, 16
+    x = rng.integers(1, 20, size=(n, d)).astype(np.int8)   # the reference's int8 generator
+    q = rng.integers(1, 20, size=(nq, d)).astype(np.int8)
+    index = _pq_build(x, n_lists=n_lists, pq_dim=64, pq_bits=8, kmeans_n_iters=10)
+    assert index.pq_dim == 64 and index.pq_len == 2   # rot_dim 128: the bench kernels
+    gd, gi = _pq_search(index, q, k, n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    ex = ivf_pq.export_for_oracle(index)
+    od, oi = oracle.ivf_pq_search(ex, q.astype(np.float32) / 128.0, k, n_probes, scale=128.0, lut=lut, acc=acc)  # mapping<float>(int8)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    _, ti = oracle.exact_knn(q.astype(np.float32), x.astype(np.float32), k)
+    p = n_probes / n_lists
+    compression = d * 8 * 1 / (64 * 8)
+    assert oracle.recall(gi, ti) >= min(math.erfc(0.05 * compression / max(p, 0.5)), p) * 0.9  # ann_ivf_pq.cuh:639-655
