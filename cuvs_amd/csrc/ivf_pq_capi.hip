@@ -5,6 +5,7 @@
 #include "npy_io.hpp"
 
 #include <cuvs/neighbors/ivf_pq.h>
+#include <cuvs_amd/extensions.h>
 
 namespace cuvs_amd {
 std::unique_ptr<ivf_pq_index> ivf_pq_make_empty(resources& res, const ivf_pq_build_params& p, elem_t et, int64_t dim);
@@ -139,9 +140,9 @@ cuvsError_t cuvsIvfPqBuildPrecomputed(cuvsResources_t res_h, cuvsIvfPqIndexParam
   });
 }
 
-cuvsError_t cuvsIvfPqSearch(cuvsResources_t res_h, cuvsIvfPqSearchParams_t params, cuvsIvfPqIndex_t index_c,
-                            DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
-                            DLManagedTensor* distances_tensor)
+static cuvsError_t pq_search_entry(cuvsResources_t res_h, cuvsIvfPqSearchParams_t params, cuvsIvfPqIndex_t index_c,
+                                   DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
+                                   DLManagedTensor* distances_tensor, cuvsFilter filter)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
@@ -166,6 +167,16 @@ cuvsError_t cuvsIvfPqSearch(cuvsResources_t res_h, cuvsIvfPqSearchParams_t param
     int64_t m = queries.shape[0], k = neighbors.shape[1];
     CUVS_EXPECTS(neighbors.shape[0] == m && distances.shape[0] == m && distances.shape[1] == k,
                  "neighbors/distances shape mismatch");
+    const uint32_t* filter_bits = nullptr;
+    if (filter.type != NO_FILTER) {  // same contract as cuvsIvfFlatSearch's prefilter (c/src/neighbors/ivf_flat.cpp)
+      CUVS_EXPECTS(filter.type == BITSET && filter.addr != 0, "ivf_pq search: only BITSET filters are supported");
+      auto& ft = reinterpret_cast<DLManagedTensor*>(filter.addr)->dl_tensor;
+      CUVS_EXPECTS(dtype_is(ft.dtype, kDLUInt, 32) && is_device_accessible(ft), "filter must be a device uint32 tensor");
+      int64_t words = 1;
+      for (int i = 0; i < ft.ndim; ++i) words *= ft.shape[i];
+      CUVS_EXPECTS(words * 32 >= idx.size, "bitset filter holds %ld bits, the index %ld rows", (long)(words * 32), (long)idx.size);
+      filter_bits = static_cast<const uint32_t*>(dl_data(ft));
+    }
     ivf_pq_search_params sp;
     sp.n_probes                = params->n_probes;
     sp.lut_dtype               = (int)params->lut_dtype;
@@ -173,8 +184,25 @@ cuvsError_t cuvsIvfPqSearch(cuvsResources_t res_h, cuvsIvfPqSearchParams_t param
     sp.max_internal_batch_size = params->max_internal_batch_size;
     sp.coarse_search_dtype     = (int)params->coarse_search_dtype;
     ivf_pq_search(res, sp, idx, dl_data(queries), elem_of(queries.dtype), m, (int)k,
-                  static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)));
+                  static_cast<int64_t*>(dl_data(neighbors)), static_cast<float*>(dl_data(distances)), filter_bits);
   });
+}
+
+cuvsError_t cuvsIvfPqSearch(cuvsResources_t res_h, cuvsIvfPqSearchParams_t params, cuvsIvfPqIndex_t index_c,
+                            DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
+                            DLManagedTensor* distances_tensor)
+{
+  return pq_search_entry(res_h, params, index_c, queries_tensor, neighbors_tensor, distances_tensor, cuvsFilter{0, NO_FILTER});
+}
+
+// The C++ search overload with a sample filter (cpp/include/cuvs/neighbors/ivf_pq.hpp:1818-1828: bitset_filter over
+// source ids) has no C entry point in the reference (c/include/cuvs/neighbors/ivf_pq.h:536-541 takes no filter); this is
+// that overload with the argument convention of cuvsIvfFlatSearch (include/cuvs_amd/extensions.h).
+cuvsError_t cuvsAmdIvfPqSearchFiltered(cuvsResources_t res_h, cuvsIvfPqSearchParams_t params, cuvsIvfPqIndex_t index_c,
+                                       DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
+                                       DLManagedTensor* distances_tensor, cuvsFilter filter)
+{
+  return pq_search_entry(res_h, params, index_c, queries_tensor, neighbors_tensor, distances_tensor, filter);
 }
 
 cuvsError_t cuvsIvfPqExtend(cuvsResources_t res_h, DLManagedTensor* new_vectors, DLManagedTensor* new_indices,

@@ -30,6 +30,7 @@
 
 #include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 
 namespace cuvs_amd {
 
@@ -192,7 +193,7 @@ __device__ inline float fp8_round_trip(float v, bool is_signed)
 
 // dbg 128 statistics (CUVS_AMD_SCAN_DEBUG=128 prints them per search): wave cycles per phase, rows per stage
 enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QUEUED, ST_S2_CALLS, ST_ALIVE1, ST_ALIVE2,
-                 ST_ALIVE3, ST_CAND, ST_ITEMS, ST_COUNT };
+                 ST_ALIVE3, ST_CAND, ST_ITEMS, ST_F_LOAD, ST_F_GATHER, ST_F_FLUSH, ST_COUNT };
 
 struct scan_args {
   const work_item* items;
@@ -433,6 +434,10 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
     // A thread owns subspaces (lane & 15) + 16 sg and the four codes pq_code0(..) .. + 3 (see pq_regs_load): the 16
     // lanes of an LDS store group write 16 neighbouring subspaces of ONE code - 128 contiguous bytes.
     const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);
+    // (the fp8 test is a compile-time argument of the loop body: as a run-time test inside it hipcc emitted one scalar
+    // branch per LUT value - 64 per thread and LUT)
+    auto build_regs = [&](auto fp8_tag) {
+    constexpr bool FP8 = decltype(fp8_tag)::value;
     if (!a.is_ip) {
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
@@ -452,7 +457,7 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
             float d0 = q[0][j] - p0;
             float d1 = q[1][j] - p1;
             sc[j]    = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-            if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
+            if constexpr (FP8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
           }
           cm_lut<entry_t>::store(s, cb + t, acc_t::pack(sc));  // pq_in_regs implies FAST4
           __builtin_amdgcn_sched_barrier(0);
@@ -477,13 +482,15 @@ __device__ inline void pq_scan_item(const scan_args& a, const work_item item, ch
             v       = __fmaf_rn(-q[0][j], pqreg[sg][0][t], v);
             v       = __fmaf_rn(-q[1][j], cc1, v);
             sc[j]   = __fmaf_rn(-q[1][j], pqreg[sg][1][t], v);
-            if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], true);
+            if constexpr (FP8) sc[j] = fp8_round_trip<AccT>(sc[j], true);
           }
           cm_lut<entry_t>::store(s, cb + t, acc_t::pack(sc));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
+    };
+    if (a.lut_fp8) build_regs(std::true_type{}); else build_regs(std::false_type{});
   } else if (book >= 64 && !(a.dbg & 1)) {
     // wave-per-subspace: the QPB query residuals of subspace s are read from LDS once per wave (they are the
     // same for all 64 lanes) and reused for the book/64 code blocks; the codebook loads of a subspace are
@@ -1040,6 +1047,18 @@ struct scan2_layout {
   }
 };
 
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS)
+__device__ inline uint32_t wave_inclusive_scan_dpp(uint32_t v)
+{
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // two floats -> packed fp16, rounded toward zero (a lower bound of non-negative entries)
 __device__ inline uint32_t pack_half_rtz(float a, float b)
 {
@@ -1064,7 +1083,7 @@ __device__ inline uint32_t pk_sub_f16(uint32_t a, uint32_t b)  // a - b, two hal
 // the byte offset of the subspace this lane looks up at step 4 w + b inside a 256-byte code row
 template <typename LutT, typename AccT, int EQ, int NG, int E>
 __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, char* smem, const float (&pqreg)[4][2][4],
-                                     const uint32_t (&xoff)[4], const work_item* __restrict__ share,
+                                     const work_item* __restrict__ share,
                                      const uint32_t share_len, const uint32_t next_ticket, const int next_slot_id)
 {
   constexpr int FQ = EQ * NG;
@@ -1085,9 +1104,25 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   uint32_t* queue  = reinterpret_cast<uint32_t*>(smem + lay.queue);
   const uint32_t qcap = a.qcap != 0u ? min(a.qcap, kCap) : kCap;
 
-  const int tid  = threadIdx.x;
+  // Everything derived from the thread id is recomputed per item: the empty asm hides the value from hipcc's
+  // loop-invariant code motion, which otherwise keeps dozens of per-thread addresses (LUT slots, query residual slots,
+  // codebook pointers) alive across the persistent item loop - at the 128-register budget of a 1024-thread workgroup
+  // they end up in scratch, and every use waits for a scratch load.
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = tid >> 6;
+
+  // per-lane constants of the rotated filter gathers: byte b of xoff[w] = ((lane + 4 w + b) & 15) << 4, the byte offset
+  // of the subspace this lane looks up at step 4 w + b inside a 256-byte code row
+  (void)0;
+  uint32_t xoff[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    xoff[w] = 0u;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xoff[w] |= ((((uint32_t)lane + 4u * w + b) & 15u) << 4) << (8 * b);
+  }
 
   const bool stat = (a.dbg & 128) != 0;
   auto stat_add = [&](int which, unsigned long long v) {
@@ -1104,6 +1139,20 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   const uint32_t base_row = a.list_offsets[L];
   const uint32_t len      = a.list_sizes[L];
 
+  // The codebook is NOT kept in registers across the item (round 2 pinned 32 registers per thread for it; the filter pass
+  // and the exact passes then had to fit their gathers into what was left): every LUT build fetches this thread's
+  // slice - (pq_len = 2) x 4 codes of subspace sl + 16 sg: one 16-byte load per component from the 128 KiB codebook,
+  // L2-resident - and the loads are issued BEFORE the barrier that precedes the build, so their latency falls into
+  // the barrier wait.
+  const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);  // this thread's subspaces / codes
+  auto load_pq = [&](const int sg, float4 (&dst)[2]) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+      dst[l] = (a.dbg & 32768) ? make_float4(0.f, 0.f, 0.f, 0.f)  // dbg 32768: no codebook loads (ablation)
+                               : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.pq_centers) +
+                                                                  (uint32_t)((((sl + sg * 16) * 2 + l) * 256 + cb) * 4u));
+  };
+
   if (tid < FQ) {
     const uint32_t p = tid < (int)item.count ? a.sorted_pairs[item.first + tid] : 0xffffffffu;
     pid[tid]         = p;
@@ -1115,7 +1164,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   for (uint32_t t = tid; t < FQ * a.rot_dim; t += kScanThreads) {
     const uint32_t j = t / a.rot_dim, dd = t % a.rot_dim;
     float v = 0.f;
-    if (j < item.count) {
+    if (j < item.count && !(a.dbg & 65536)) {  // dbg 65536: no residual loads (ablation)
       const uint32_t q = a.sorted_pairs[item.first + j] / a.n_probes;
       v = a.rot_queries[(size_t)q * a.rot_dim + dd] - a.centers_rot[(size_t)L * a.rot_dim + dd];
     }
@@ -1124,10 +1173,9 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   __syncthreads();
   stat_phase(ST_HEADER);
 
-  const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);  // this thread's subspaces / codes (pq_regs_load)
-
   // ---- filter LUT: subspaces 0..15 (this thread: subspace sl, codes cb .. cb + 3), the 8 queries' entries as fp16
-  if (!(a.dbg & 1)) {
+  auto build_filter_lut = [&](auto fp8_tag) {
+    constexpr bool FP8 = decltype(fp8_tag)::value;  // compile-time: see pq_scan_item
     float q[2][FQ];
 #pragma unroll
     for (int l = 0; l < 2; ++l)
@@ -1145,7 +1193,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
           const float d0 = q[0][jj * 2 + h] - p0;
           const float d1 = q[1][jj * 2 + h] - p1;
           sc[h]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-          if (a.lut_fp8) sc[h] = fp8_round_trip<AccT>(sc[h], false);  // L2 only here: the unsigned fp_8bit<5, false>
+          if constexpr (FP8) sc[h] = fp8_round_trip<AccT>(sc[h], false);  // L2 only here: the unsigned fp_8bit<5, false>
         }
         // fp16 LUT: the exact entry itself (round to nearest, as the exact LUT stores it); fp32 LUT: rounded toward zero
         if constexpr (sizeof(LutT) == 2) ev[jj] = __builtin_bit_cast(uint32_t, f16x2_t{to_lut_half(sc[0]), to_lut_half(sc[1])});
@@ -1154,7 +1202,8 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
       *(__attribute__((address_space(3))) u32x4_t*)(uintptr_t)((cb + t) * FL::kRow + sl * 16) = ev;
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
+  };
+  if (!(a.dbg & 1)) { if (a.lut_fp8) build_filter_lut(std::true_type{}); else build_filter_lut(std::false_type{}); }
   stat_phase(ST_LUT);
   __syncthreads();
   stat_phase(ST_ALIVE1);  // (pq_scan2: barrier wait after the filter LUT build)
@@ -1172,116 +1221,264 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     return !live ? -INFINITY : (kk >= 0xff800000u ? INFINITY : key_to_float(kk));
   };
 
-  // ---- filter pass: chunk 0 of every row against the 8 bounds; a ticket = a block of 4 tiles (4 loads in flight)
+  // ---- filter pass: chunk 0 of every row against the 8 bounds. Tiles (64 rows, 1 KiB of chunk-0 codes) are dealt to
+  // the waves statically - wave w takes tiles w, w + 16, ... (a rotated start per item) - because every tile costs the
+  // same here: a ticket per block of 4 tiles left 12 waves with two blocks and 4 with one (28 blocks for 16 waves), and
+  // every block began with an exposed load. The codes of the next two tiles of a wave are in flight while it works.
   {
-    const uint32_t rot      = (a.dbg & 64) ? 0u : (item.first / FQ);
-    const uint32_t n_blocks = (n_tiles + 3u) / 4u;
-    const uint32_t rot_b    = n_blocks ? (rot * kScanWaves) % n_blocks : 0u;
-    const uint32_t rr       = (uint32_t)lane & 15u;  // byte rotation of this lane's code words
-    const uint32_t rb       = rr & 3u;               //   = rb bytes after (rr >> 2) dwords
-    uint32_t ticket = 0u;
-    if (lane == 0) ticket = atomicAdd(&ctrl[16], 1u);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    while (ticket < n_blocks) {
-      const uint32_t blk = (ticket + rot_b) % n_blocks;
-      uint32_t next = 0u;
-      if (lane == 0) next = atomicAdd(&ctrl[16], 1u);
-      uint4 c0[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const uint32_t tile = min(blk * 4 + t, n_tiles - 1);
-        c0[t] = codes16[((g0 + (size_t)tile) * 4) * 64 + lane];
+    const uint32_t rot   = (a.dbg & 64) ? 0u : (item.first / FQ);
+    const uint32_t rot_t = n_tiles ? (rot * kScanWaves) % n_tiles : 0u;
+    const uint32_t rr    = (uint32_t)lane & 15u;  // byte rotation of this lane's code words
+    const uint32_t rb    = rr & 3u;               //   = rb bytes after (rr >> 2) dwords
+    auto tile_of = [&](const uint32_t i) {  // the i-th tile of this wave (i * 16 + wave < n_tiles)
+      uint32_t t = i * kScanWaves + (uint32_t)wave + rot_t;
+      return t >= n_tiles ? t - n_tiles : t;
+    };
+    auto load_tile = [&](const uint32_t i) {
+      const uint32_t t = min(tile_of(min(i, 0x00ffffffu)), n_tiles ? n_tiles - 1 : 0u);
+      return codes16[((g0 + (size_t)t) * 4) * 64 + lane];
+    };
+    const uint32_t my_tiles = n_tiles > (uint32_t)wave ? (n_tiles - (uint32_t)wave + kScanWaves - 1) / kScanWaves : 0u;
+    uint4 cb0 = make_uint4(0u, 0u, 0u, 0u), cb1 = cb0, cb2 = cb0;
+    if (my_tiles > 0u) cb0 = load_tile(0);
+    if (my_tiles > 1u) cb1 = load_tile(1);
+    // the 8 bounds as fp16, widened by 1/32 and rounded up (lane j < 8 converts query j's), once per item; a query
+    // without a bound yet, or with one beyond the fp16 range, keeps every row of its group alive (`force`)
+    uint32_t bfh[4];
+    uint32_t force = 0u;  // bit g: group g keeps every row
+    {
+      const int j       = lane & 7;
+      const uint32_t kk = ctrl[j];
+      uint32_t hb       = 0xfc00u;  // -inf: no such query in this item
+      bool fo           = false;
+      if (j < (int)item.count) {
+        const float bw = (kk >= 0xff800000u ? INFINITY : key_to_float(kk)) * 1.03125f;
+        if (!(bw < 60000.0f) || (a.dbg & 8)) { fo = true; hb = 0x7bffu; }  // dbg 8: early stop off (ablation)
+        else hb = half_bits_round_up(bw);
       }
-      // the 8 bounds as fp16, widened by 1/32 and rounded up (lane j < 8 converts query j's); a query without a bound
-      // yet, or with one beyond the fp16 range, keeps every row of its group alive (`force`)
-      uint32_t bfh[4];
-      uint32_t force = 0u;  // bit g: group g keeps every row
-      {
-        const int j       = lane & 7;
-        const uint32_t kk = ctrl[j];
-        uint32_t hb       = 0xfc00u;  // -inf: no such query in this item
-        bool fo           = false;
-        if (j < (int)item.count) {
-          const float bw = (kk >= 0xff800000u ? INFINITY : key_to_float(kk)) * 1.03125f;
-          if (!(bw < 60000.0f) || (a.dbg & 8)) { fo = true; hb = 0x7bffu; }  // dbg 8: early stop off (ablation)
-          else hb = half_bits_round_up(bw);
-        }
-        const uint32_t fm = (uint32_t)__ballot(fo) & 0xffu;
-        uint32_t hj[8];
+      const uint32_t fm = (uint32_t)__ballot(fo) & 0xffu;
+      uint32_t hj[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) hj[q] = __builtin_amdgcn_readlane(hb, q);
+      for (int q = 0; q < 8; ++q) hj[q] = __builtin_amdgcn_readlane(hb, q);
 #pragma unroll
-        for (int d = 0; d < 4; ++d) bfh[d] = hj[2 * d] | (hj[2 * d + 1] << 16);
+      for (int d = 0; d < 4; ++d) bfh[d] = hj[2 * d] | (hj[2 * d + 1] << 16);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) force |= ((fm >> (g * EQ)) & ((1u << EQ) - 1u)) ? (1u << g) : 0u;
-      }
-      unsigned long long mk[NG][4];  // lanes whose row of tile t is still alive for group g
-      uint32_t flags = 0u;           // this lane's bits of mk: bit NG * t + g
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        // rotate the 16 code bytes right by rr: byte i of R = code of subspace (i + rr) & 15
-        uint32_t w0 = c0[t].x, w1 = c0[t].y, w2 = c0[t].z, w3 = c0[t].w;
-        if (rr & 4u) { const uint32_t x = w0; w0 = w1; w1 = w2; w2 = w3; w3 = x; }
-        if (rr & 8u) { uint32_t x = w0; w0 = w2; w2 = x; x = w1; w1 = w3; w3 = x; }
-        uint32_t R[4];
-        R[0] = __builtin_amdgcn_alignbyte(w1, w0, rb);
-        R[1] = __builtin_amdgcn_alignbyte(w2, w1, rb);
-        R[2] = __builtin_amdgcn_alignbyte(w3, w2, rb);
-        R[3] = __builtin_amdgcn_alignbyte(w0, w3, rb);
-        uint32_t acc[4] = {0u, 0u, 0u, 0u};  // 8 fp16 partial sums
-        if (!(a.dbg & 2)) {
-#pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            u32x4_t e[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              // address = code << 8 | subspace offset: byte 0 from xoff[h] byte b, byte 1 from R[h] byte b
-              const uint32_t ad = __builtin_amdgcn_perm(R[h], xoff[h], 0x0c0c0400u + 0x0101u * (uint32_t)b);
-              e[b] = *(__attribute__((address_space(3))) const u32x4_t*)(uintptr_t)ad;
-            }
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              asm volatile("v_pk_add_f16 %0, %0, %4\n\tv_pk_add_f16 %1, %1, %5\n\tv_pk_add_f16 %2, %2, %6\n\tv_pk_add_f16 %3, %3, %7"
-                           : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
-                           : "v"(e[b].x), "v"(e[b].y), "v"(e[b].z), "v"(e[b].w));
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        // bound - sum per half: a set sign bit = that query is out (no inf - inf here: a +inf bound is `force`)
-        uint32_t dv[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dv[d] = pk_sub_f16(bfh[d], acc[d]);
-        const bool valid = (blk * 4 + t) * 64 + lane < len;  // also drops the clamped tiles past the end of the list
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-          bool dead;
-          if constexpr (NG == 2) dead = ((dv[2 * g] & dv[2 * g + 1]) & 0x80008000u) == 0x80008000u;
-          else                   dead = (dv[g] & 0x80008000u) == 0x80008000u;
-          const bool alive = valid && (!dead || ((force >> g) & 1u));
-          mk[g][t] = __ballot(alive);
-          flags |= (alive ? 1u : 0u) << (NG * t + g);
-        }
-      }
-      // reserve queue space for the block's survivors (one LDS atomic per group) and write them
+      for (int g = 0; g < NG; ++g) force |= ((fm >> (g * EQ)) & ((1u << EQ) - 1u)) ? (1u << g) : 0u;
+    }
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    // survivors are collected in a bit field per lane (bit NG * slot + g: this lane's row of the wave's tile `slot` of
+    // the current chunk of 8 tiles is alive for group g) and appended to the queues once per chunk: one LDS atomic per
+    // group and 8 tiles
+    uint32_t flags = 0u;
+    auto flush = [&](const uint32_t i0) {  // tiles i0 .. of this wave (the set bits of `flags`)
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-        uint32_t n = 0u;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) n += (uint32_t)__popcll(mk[g][t]);
+        uint32_t gm = flags & (NG == 2 ? 0x5555u << g : 0x11111111u << g);
+        const uint32_t cnt = (uint32_t)__popc(gm);            // this lane's surviving rows of the chunk for group g
+        const uint32_t incl = wave_inclusive_scan_dpp(cnt);   // six DPP adds
+        const uint32_t n = __builtin_amdgcn_readlane(incl, 63);
         if (n == 0u) continue;
         uint32_t base = 0u;
         if (lane == 0) base = atomicAdd(&ctrl[17 + g], n);
-        base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const unsigned long long m = mk[g][t];
-          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          if (((flags >> (NG * t + g)) & 1u) && pos < qcap) queue[g * kCap + pos] = (blk * 4 + t) * 64 + lane;
-          base += (uint32_t)__popcll(m);
+        uint32_t pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+        while (gm != 0u) {  // at most 8 rounds, usually one or two: 11 % of the rows survive
+          const uint32_t sl2 = ((uint32_t)__ffs((int)gm) - 1u) / NG;
+          gm &= gm - 1u;
+          if (pos < qcap) queue[g * kCap + pos] = tile_of(i0 + sl2) * 64 + lane;
+          ++pos;
         }
       }
-      ticket = __builtin_amdgcn_readfirstlane(next);
+      flags = 0u;
+    };
+    unsigned long long tf_load = 0ull, tf_gather = 0ull, tf_flush = 0ull;  // dbg 128: where the pass spends its cycles
+    auto process = [&](const uint32_t i, const uint4& c0) {
+      const uint32_t slot = i & 7u;
+      if (stat) {  // wait for this tile's codes (and only them)
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        asm volatile("" ::"v"(c0.x), "v"(c0.y), "v"(c0.z), "v"(c0.w));
+        tf_load += __builtin_readcyclecounter() - t0;
+      }
+      // rotate the 16 code bytes right by rr: byte k of R = code of subspace (k + rr) & 15
+      uint32_t w0 = c0.x, w1 = c0.y, w2 = c0.z, w3 = c0.w;
+      {
+        const bool r1 = (rr & 4u) != 0u, r2 = (rr & 8u) != 0u;
+        const uint32_t a0 = r1 ? w1 : w0, a1 = r1 ? w2 : w1, a2 = r1 ? w3 : w2, a3 = r1 ? w0 : w3;
+        w0 = r2 ? a2 : a0; w1 = r2 ? a3 : a1; w2 = r2 ? a0 : a2; w3 = r2 ? a1 : a3;
+      }
+      uint32_t R[4];
+      R[0] = __builtin_amdgcn_alignbyte(w1, w0, rb);
+      R[1] = __builtin_amdgcn_alignbyte(w2, w1, rb);
+      R[2] = __builtin_amdgcn_alignbyte(w3, w2, rb);
+      R[3] = __builtin_amdgcn_alignbyte(w0, w3, rb);
+      h2_t acc[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) acc[d] = h2_t{(_Float16)0.f, (_Float16)0.f};
+      if (!(a.dbg & 2)) {
+        // The 16 gathers and 64 packed adds of a tile as ONE hand-scheduled block: eight ds_read_b128 in flight, gather
+        // s + 8 is issued right behind the adds of gather s (registers v96..v127 are the eight 16-byte slots). The
+        // waves of the workgroup leave the barrier together and run this loop in lockstep, so LDS time and VALU time
+        // only overlap when they overlap inside each wave; hipcc's own schedule - all 16 gathers, one wait, 64 adds -
+        // gave 3.3 k cycles per round of tiles against ~1.7 k of VALU work and ~1.0 k of LDS time. lgkmcnt counts this
+        // block's own reads only: it starts by draining what the compiler may have in flight and ends drained.
+        uint32_t a0 = 0u, a1 = 0u, a2 = 0u, a3 = 0u, ta;
+        const unsigned long long tg0 = stat ? __builtin_readcyclecounter() : 0ull;
+        asm volatile(
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_perm_b32 %[t], %[R0], %[X0], %[s0]\n\t"
+          "ds_read_b128 v[96:99], %[t]\n\t"
+          "v_perm_b32 %[t], %[R0], %[X0], %[s1]\n\t"
+          "ds_read_b128 v[100:103], %[t]\n\t"
+          "v_perm_b32 %[t], %[R0], %[X0], %[s2]\n\t"
+          "ds_read_b128 v[104:107], %[t]\n\t"
+          "v_perm_b32 %[t], %[R0], %[X0], %[s3]\n\t"
+          "ds_read_b128 v[108:111], %[t]\n\t"
+          "v_perm_b32 %[t], %[R1], %[X1], %[s0]\n\t"
+          "ds_read_b128 v[112:115], %[t]\n\t"
+          "v_perm_b32 %[t], %[R1], %[X1], %[s1]\n\t"
+          "ds_read_b128 v[116:119], %[t]\n\t"
+          "v_perm_b32 %[t], %[R1], %[X1], %[s2]\n\t"
+          "ds_read_b128 v[120:123], %[t]\n\t"
+          "v_perm_b32 %[t], %[R1], %[X1], %[s3]\n\t"
+          "ds_read_b128 v[124:127], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v96\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v97\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v98\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v99\n\t"
+          "v_perm_b32 %[t], %[R2], %[X2], %[s0]\n\t"
+          "ds_read_b128 v[96:99], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v100\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v101\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v102\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v103\n\t"
+          "v_perm_b32 %[t], %[R2], %[X2], %[s1]\n\t"
+          "ds_read_b128 v[100:103], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v104\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v105\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v106\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v107\n\t"
+          "v_perm_b32 %[t], %[R2], %[X2], %[s2]\n\t"
+          "ds_read_b128 v[104:107], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v108\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v109\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v110\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v111\n\t"
+          "v_perm_b32 %[t], %[R2], %[X2], %[s3]\n\t"
+          "ds_read_b128 v[108:111], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v112\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v113\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v114\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v115\n\t"
+          "v_perm_b32 %[t], %[R3], %[X3], %[s0]\n\t"
+          "ds_read_b128 v[112:115], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v116\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v117\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v118\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v119\n\t"
+          "v_perm_b32 %[t], %[R3], %[X3], %[s1]\n\t"
+          "ds_read_b128 v[116:119], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v120\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v121\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v122\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v123\n\t"
+          "v_perm_b32 %[t], %[R3], %[X3], %[s2]\n\t"
+          "ds_read_b128 v[120:123], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v124\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v125\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v126\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v127\n\t"
+          "v_perm_b32 %[t], %[R3], %[X3], %[s3]\n\t"
+          "ds_read_b128 v[124:127], %[t]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v96\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v97\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v98\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v99\n\t"
+          "s_waitcnt lgkmcnt(6)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v100\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v101\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v102\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v103\n\t"
+          "s_waitcnt lgkmcnt(5)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v104\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v105\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v106\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v107\n\t"
+          "s_waitcnt lgkmcnt(4)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v108\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v109\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v110\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v111\n\t"
+          "s_waitcnt lgkmcnt(3)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v112\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v113\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v114\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v115\n\t"
+          "s_waitcnt lgkmcnt(2)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v116\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v117\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v118\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v119\n\t"
+          "s_waitcnt lgkmcnt(1)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v120\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v121\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v122\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v123\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_pk_add_f16 %[a0], %[a0], v124\n\t"
+          "v_pk_add_f16 %[a1], %[a1], v125\n\t"
+          "v_pk_add_f16 %[a2], %[a2], v126\n\t"
+          "v_pk_add_f16 %[a3], %[a3], v127\n\t"
+          : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3), [t] "=&v"(ta)
+          : [R0] "v"(R[0]), [R1] "v"(R[1]), [R2] "v"(R[2]), [R3] "v"(R[3]), [X0] "v"(xoff[0]), [X1] "v"(xoff[1]),
+            [X2] "v"(xoff[2]), [X3] "v"(xoff[3]), [s0] "s"(0x0c0c0400u), [s1] "s"(0x0c0c0501u), [s2] "s"(0x0c0c0602u),
+            [s3] "s"(0x0c0c0703u)
+          : "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+            "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+            "v124", "v125", "v126", "v127", "memory");
+        if (stat) tf_gather += __builtin_readcyclecounter() - tg0;
+        acc[0] = __builtin_bit_cast(h2_t, a0); acc[1] = __builtin_bit_cast(h2_t, a1);
+        acc[2] = __builtin_bit_cast(h2_t, a2); acc[3] = __builtin_bit_cast(h2_t, a3);
+      }
+      // bound - sum per half: a set sign bit = that query is out (no inf - inf here: a +inf bound is `force`)
+      uint32_t dv[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dv[d] = pk_sub_f16(bfh[d], __builtin_bit_cast(uint32_t, acc[d]));
+      const bool valid = tile_of(i) * 64 + lane < len;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        bool dead;
+        if constexpr (NG == 2) dead = ((dv[2 * g] & dv[2 * g + 1]) & 0x80008000u) == 0x80008000u;
+        else                   dead = (dv[g] & 0x80008000u) == 0x80008000u;
+        const bool alive = valid && (!dead || ((force >> g) & 1u));
+        flags |= (alive ? 1u : 0u) << (NG * slot + g);
+      }
+      if ((slot == 7u || i + 1 == my_tiles) && !(a.dbg & 8192)) {  // dbg 8192: survivors dropped (ablation)
+        const unsigned long long t0 = stat ? __builtin_readcyclecounter() : 0ull;
+        flush(i - slot);
+        if (stat) tf_flush += __builtin_readcyclecounter() - t0;
+      }
+    };
+    // three code buffers in rotation, the loop unrolled by three: the loads of the next TWO tiles stay in flight while
+    // a tile is worked on (with two buffers and a copy hipcc waited for the newest load - vmcnt(0) - at every tile)
+    for (uint32_t i = 0; i < my_tiles; i += 3) {
+      if (i + 2 < my_tiles) cb2 = load_tile(i + 2);
+      process(i, cb0);
+      if (i + 1 >= my_tiles) break;
+      if (i + 3 < my_tiles) cb0 = load_tile(i + 3);
+      process(i + 1, cb1);
+      if (i + 2 >= my_tiles) break;
+      if (i + 4 < my_tiles) cb1 = load_tile(i + 4);
+      process(i + 2, cb2);
     }
+    if (stat) { stat_add(ST_F_LOAD, tf_load); stat_add(ST_F_GATHER, tf_gather); stat_add(ST_F_FLUSH, tf_flush); }
   }
   if (stat) { stat_phase(ST_SCAN); if (wave == 0) { stat_add(ST_ROWS, len); stat_add(ST_ITEMS, 1); } }
   __syncthreads();
@@ -1301,14 +1498,28 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) cur[ch] = cp[ch * 64];
   };
+  const int tid_item = tid;
   for (int g = 0; g < NG; ++g) {
     if (g * EQ >= (int)item.count) break;  // workgroup-uniform: no queries in this group
+    // (per-group copy of the thread id behind an empty asm: keeps the per-thread LDS addresses of this loop body from
+    // being hoisted out of the loop and spilled - see the top of the function)
+    int tid_g = tid_item;
+    asm volatile("" : "+v"(tid_g));
+    const int lane = tid_g & 63, wave = tid_g >> 6;
+    const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);
+    auto load_pq = [&](const int sg, float4 (&dst)[2]) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+        dst[l] = (a.dbg & 32768) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                 : *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.pq_centers) +
+                                                                    (uint32_t)((((sl + sg * 16) * 2 + l) * 256 + cb) * 4u));
+    };
     uint32_t* kthb = ctrl + g * EQ;        // bounds of this group's queries
     uint32_t* ins  = ctrl + 8 + g * EQ;
     const int cnt_g = min(EQ, (int)item.count - g * EQ);
     const uint32_t n_q   = ctrl[17 + g];
     const bool overflow  = n_q > qcap;
-    const uint32_t n_bat = overflow ? n_tiles : (n_q + 63u) / 64u;
+    const uint32_t n_bat = (a.dbg & 16384) ? 0u : (overflow ? n_tiles : (n_q + 63u) / 64u);  // dbg 16384: no exact batches
     const uint32_t* qg   = queue + g * kCap;
     auto batch_row = [&](const uint32_t b, bool& valid) {
       uint32_t v;
@@ -1325,7 +1536,8 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     if (g > 0) __syncthreads();  // every wave is done with the previous LUT / merge area
     stat_phase(ST_S2_CALLS);  // (pq_scan2: barrier wait before the next exact LUT build)
     // ---- exact LUT of the group's EQ queries (same arithmetic and layout as pq_scan_kernel)
-    if (!(a.dbg & 1)) {
+    auto build_exact_lut = [&](auto fp8_tag) {
+      constexpr bool FP8 = decltype(fp8_tag)::value;
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
         const uint32_t s = sl + sg * 16;
@@ -1343,13 +1555,13 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
             const float d0 = q[0][j] - p0;
             const float d1 = q[1][j] - p1;
             sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-            if (a.lut_fp8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
+            if constexpr (FP8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
           }
           XL::store(s, cb + t, acc_t::pack(sc));
-          __builtin_amdgcn_sched_barrier(0);
         }
       }
-    }
+    };
+    if (!(a.dbg & 1)) { if (a.lut_fp8) build_exact_lut(std::true_type{}); else build_exact_lut(std::false_type{}); }
 #pragma unroll
     for (int j = 0; j < EQ; ++j) top[j].init();
     stat_phase(ST_LUT);
@@ -1420,7 +1632,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
           }
         }
         if (improved && lane == 0) {
-          ins[j] = 1u;
+          atomicOr(&ins[j], 1u << wave);  // which waves hold candidates of query j: only their lists are merged
           if (kd < INFINITY) atomicMin(&kthb[j], float_to_key(kd));
         }
       }
@@ -1440,7 +1652,7 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
     uint32_t* mg_i = reinterpret_cast<uint32_t*>(smem + (size_t)EQ * kScanWaves * a.k * 4);
 #pragma unroll
     for (int j = 0; j < EQ; ++j) {
-      if (ins[j] == 0u) continue;  // workgroup-uniform
+      if (!((ins[j] >> wave) & 1u)) continue;  // wave-uniform: this wave holds nothing for query j
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int r = e * 64 + lane;
@@ -1458,10 +1670,12 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
       float kd    = INFINITY;
       uint32_t ki = 0xffffffffu;
       const int n = kScanWaves * (int)a.k;
-      for (int b0 = 0; b0 < n; b0 += 64) {
+      static_assert(E == 1, "k <= 64: one chunk of lanes per wave list");
+      for (uint32_t wm = ins[j]; wm != 0u; wm &= wm - 1u) {  // the lists of the waves that inserted, ascending wave
+        const int b0 = (__ffs((int)wm) - 1) * (int)a.k;
         float md    = INFINITY;
         uint32_t mi = 0xffffffffu;
-        if (b0 + lane < n) { md = mg_d[(size_t)j * n + b0 + lane]; mi = mg_i[(size_t)j * n + b0 + lane]; }
+        if (lane < (int)a.k) { md = mg_d[(size_t)j * n + b0 + lane]; mi = mg_i[(size_t)j * n + b0 + lane]; }
         unsigned long long m = __ballot(mi != 0xffffffffu && ((md < kd) || (md == kd && mi < ki)));
         while (m != 0ull) {
           const int src = (int)__ffsll((long long)m) - 1;
@@ -1503,18 +1717,8 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
   const uint32_t xcd = blockIdx.x & 7u;
   const uint32_t chunk = (n_items + 7u) / 8u;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();  // see cm_lut
-  float pqreg[4][2][4];
+  float pqreg[4][2][4];  // this thread's slice of the codebook, in registers for the whole launch (pq_regs_load)
   pq_regs_load(pqreg, a.pq_centers, true);
-  uint32_t xoff[4];
-  {
-    const uint32_t lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      xoff[w] = 0u;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) xoff[w] |= (((lane + 4u * w + b) & 15u) << 4) << (8 * b);
-    }
-  }
   const scan2_layout lay(cm_lut<entry_t>::bytes(), EQ * NG, a.rot_dim);
   work_item* sh_item       = reinterpret_cast<work_item*>(smem + lay.slots);
   const uint32_t share0    = min(n_items, xcd * chunk);
@@ -1531,7 +1735,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
     if (cur.pad == 0xffffffffu) break;  // workgroup-uniform
     uint32_t next_ticket = 0xffffffffu;
     if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
-    pq_scan2_item<LutT, AccT, EQ, NG, E>(a, cur, smem, pqreg, xoff, share, share_len, next_ticket, buf ^ 1);
+    pq_scan2_item<LutT, AccT, EQ, NG, E>(a, cur, smem, pqreg, share, share_len, next_ticket, buf ^ 1);
     __syncthreads();
   }
 }
@@ -1962,6 +2166,17 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       unsigned long long h[ST_COUNT] = {};
       for (size_t i = 0; i < hw.size(); ++i) h[i % ST_COUNT] += hw[i];
       const double w = 1.0 / (16.0 * grid);  // wave cycles -> average cycles per wave
+      if (a.dbg & 4096) {  // per-wave view of the filter pass (which wave of a workgroup runs late?)
+        for (int which : {(int)ST_SCAN, (int)ST_ALIVE2, (int)ST_F_GATHER, (int)ST_F_FLUSH, (int)ST_STAGE2, (int)ST_CAND, (int)ST_S2_CALLS}) {
+          fprintf(stderr, "[pq_scan per-wave stat %d, Mcycles]", which);
+          for (int wv = 0; wv < kScanWaves; ++wv) {
+            unsigned long long t = 0;
+            for (unsigned b = 0; b < grid; ++b) t += hw[((size_t)b * kScanWaves + wv) * ST_COUNT + which];
+            fprintf(stderr, " %.2f", (double)t / grid * 1e-6);
+          }
+          fprintf(stderr, "\n");
+        }
+      }
       fprintf(stderr,
               "[pq_scan stats] items %llu rows %llu queued %llu (%.2f%%) stage2 calls %llu alive after chunk1/2/3 %llu/%llu/%llu"
               " | cycles per wave: header %.3g lut %.3g scan %.3g (stage2 %.3g) merge+sync %.3g\n",
@@ -1969,8 +2184,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
               h[ST_S2_CALLS], h[ST_ALIVE1], h[ST_ALIVE2], h[ST_ALIVE3], h[ST_HEADER] * w, h[ST_LUT] * w, h[ST_SCAN] * w,
               h[ST_STAGE2] * w, (double)(h[ST_MERGE] - h[ST_HEADER] - h[ST_LUT] - h[ST_SCAN]) * w);
       fprintf(stderr, "[pq_scan2 waits, cycles per wave] after filter LUT %.3g, after filter pass %.3g, before LUT B %.3g, after exact LUT "
-              "%.3g, after exact pass %.3g, merge %.3g\n", h[ST_ALIVE1] * w, h[ST_ALIVE2] * w, h[ST_S2_CALLS] * w, h[ST_ALIVE3] * w,
-              h[ST_CAND] * w, h[ST_MERGE] * w);
+              "%.3g, after exact pass %.3g, merge %.3g | filter pass: code-load wait %.3g, gather block %.3g, flush %.3g\n",
+              h[ST_ALIVE1] * w, h[ST_ALIVE2] * w, h[ST_S2_CALLS] * w, h[ST_ALIVE3] * w, h[ST_CAND] * w, h[ST_MERGE] * w,
+              h[ST_F_LOAD] * w, h[ST_F_GATHER] * w, h[ST_F_FLUSH] * w);
     }
     // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
     if (!large_k) {

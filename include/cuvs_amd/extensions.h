@@ -1,0 +1,28 @@
+/* Entry points of libcuvs_c.so that the reference's C headers do not declare. Everything a binding needs for the
+ * reference's API lives in <cuvs/...>; these are additions in the same conventions (cuvsError_t, DLPack tensors).
+ */
+#pragma once
+#include <cuvs/core/c_api.h>
+#include <cuvs/core/export.h>
+#include <cuvs/neighbors/common.h>
+#include <cuvs/neighbors/ivf_pq.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* IVF-PQ search with a pre-filter. The reference has this only in C++ - cuvs::neighbors::ivf_pq::search(..., const
+ * filtering::base_filter& sample_filter), cpp/include/cuvs/neighbors/ivf_pq.hpp:1818-1828; kernel side
+ * cpp/src/neighbors/ivf_pq/detail/jit_lto_kernels/compute_distances_impl.cuh:78-80 - its C entry point
+ * cuvsIvfPqSearch (c/include/cuvs/neighbors/ivf_pq.h:536-541) takes no filter. Same argument convention as
+ * cuvsIvfFlatSearch: filter.type NO_FILTER or BITSET, filter.addr = DLManagedTensor* of uint32 words on the device,
+ * bit i = 1 keeps source id i. */
+CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSearchFiltered(cuvsResources_t res, cuvsIvfPqSearchParams_t search_params,
+                                                   cuvsIvfPqIndex_t index, DLManagedTensor* queries,
+                                                   DLManagedTensor* neighbors, DLManagedTensor* distances,
+                                                   cuvsFilter filter);
+
+#ifdef __cplusplus
+}
+#endif

@@ -103,11 +103,13 @@ _LUT_MODES = {"f32": 0, "f16": 1, "fp8": 2}
 _COARSE_MODES = {"f32": 0, "f16": 1, "i8": 2}
 
 
-def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.0, lut="f32", acc="f32", coarse="f32"):
+def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.0, lut="f32", acc="f32", coarse="f32",
+                  keep_bits=None):
     """Search an index exported with cuvs_amd.neighbors.ivf_pq.export_for_oracle. lut: "f32" | "f16" | "fp8" (the
     reference's fp_8bit<5, signed-for-inner-product>), acc: "f32" | "f16" (search_params.lut_dtype /
     internal_distance_dtype), coarse: "f32" | "f16" | "i8" (coarse_search_dtype: coarse search and query rotation in
-    that type). Returns (distances, neighbors); bit-for-bit twin of cuvsIvfPqSearch."""
+    that type), keep_bits: optional uint32 words of a bitset over source ids (1 keeps the row).
+    Returns (distances, neighbors); bit-for-bit twin of cuvsIvfPqSearch."""
     q = _f32(queries)
     centers = _f32(exported["centers"])
     centers_rot = _f32(exported["centers_rot"])
@@ -121,13 +123,15 @@ def ivf_pq_search(exported, queries, k, n_probes, metric="sqeuclidean", scale=1.
     nq = q.shape[0]
     nb = np.empty((nq, k), np.int64)
     ds = np.empty((nq, k), np.float32)
+    kb = None if keep_bits is None else np.ascontiguousarray(keep_bits, dtype=np.uint32)
     lib().oracle_ivf_pq_search(
         _p(q), C.c_int64(nq), C.c_int(q.shape[1]), _p(centers), _p(centers_rot), _p(rotation), _p(pqc),
         C.c_int(len(sizes)), C.c_int(rotation.shape[0]), C.c_int(int(exported["pq_dim"])),
         C.c_int(int(exported["pq_len"])), C.c_int(int(exported["pq_bits"])), _p(sizes), _p(start), _p(codes), _p(ids),
         C.c_int(_metric(metric)), C.c_int(n_probes), C.c_int(k), C.c_float(scale), _p(nb), _p(ds),
         C.c_int(int(bool(exported.get("per_cluster", False)))), C.c_int(_LUT_MODES[lut]), C.c_int(_LUT_MODES[acc]),
-        C.c_int(_COARSE_MODES[coarse]))
+        C.c_int(_COARSE_MODES[coarse]),
+        _p(kb) if kb is not None else None)
     return ds, nb
 
 

@@ -352,8 +352,10 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
                                  int n_lists, int rot_dim, int pq_dim, int pq_len, int pq_bits,
                                  const uint32_t* list_sizes, const int64_t* list_start, const uint8_t* codes,
                                  const int64_t* ids, int metric, int n_probes, int k, float scale,
-                                 int64_t* neighbors, float* distances, int per_cluster, int lut_mode, int acc_mode, int coarse_mode)
-{  /* coarse_mode 0 fp32 / 1 fp16 / 2 int8 coarse search and query rotation (search_params.coarse_search_dtype,
+                                 int64_t* neighbors, float* distances, int per_cluster, int lut_mode, int acc_mode, int coarse_mode,
+                                 const uint32_t* keep_bits)
+{ /* keep_bits: optional bitset over source ids, 1 keeps the row (sample_filter.cuh bitset_filter through
+   * ivf_to_sample_filter, applied per scanned row: compute_distances_impl.cuh:78-80) */  /* coarse_mode 0 fp32 / 1 fp16 / 2 int8 coarse search and query rotation (search_params.coarse_search_dtype,
     * ivf_pq_search.cuh:171-340,:995-1017; centers_half / centers_int8 / rotation_matrix_* ivf_pq_index.cu:640-760).
     * lut_mode 0 fp32 / 1 fp16 / 2 fp8 LUT entries; acc_mode 0 fp32 / 1 fp16 scores (sums in subspace order).
     * per_cluster: pq_centers is [n_lists, pq_len, book] (codebook_gen::PER_CLUSTER), else [pq_dim, pq_len, book] */
@@ -457,6 +459,10 @@ EXPORT void oracle_ivf_pq_search(const float* queries, int64_t nq, int dim, cons
         const uint32_t len = list_sizes[L];
         for (uint32_t v = 0; v < len; ++v) {
           const uint8_t* row = codes + (list_start[L] + v) * bpr;
+          if (keep_bits != NULL) {
+            const int64_t sid = ids[list_start[L] + v];
+            if (!((keep_bits[sid >> 5] >> (sid & 31)) & 1u)) continue;
+          }
           float acc = 0.f;
           if (acc_mode == 1) {  /* half-precision adds: every partial sum rounds to half */
             for (int s = 0; s < pq_dim; ++s) acc = f16_to_f32(f32_to_f16(acc + lut[s * book + code_at(row, s, pq_bits)]));

@@ -101,7 +101,7 @@ def test_c3_shape_recall_with_refine(big_lists):
     x, q, index, _ = big_lists
     k = 10
     _, gi = _pq_search(index, q, 2 * k, n_probes=8, lut_dtype=np.float16, internal_distance_dtype=np.float32)
-    _, ri = refine.refine(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(gi).cuda(), k)
+    _, ri = refine(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(gi).cuda(), k)
     torch.cuda.synchronize()
     _, ti = oracle.exact_knn(q, x, k)
     assert oracle.recall(ri.cpu().numpy(), ti) >= 0.9
