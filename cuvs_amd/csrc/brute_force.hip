@@ -161,7 +161,8 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   const int64_t n       = idx.n;
   const T* data         = static_cast<const T*>(idx.data);
   CUVS_EXPECTS(k >= 1, "brute_force::search: k must be positive");
-  CUVS_EXPECTS((int64_t)k <= n, "brute_force::search: k (%d) must not exceed the number of indexed rows (%ld)", k, (long)n);
+  // (k > n is served, as in the reference - knn_brute_force.cuh has no such check: the per-tile select path pads the
+  // missing slots with the worst value and an invalid id)
 
   // row tiles bounded by the workspace; column tiles as wide as the workspace allows. Large k (beyond the 2048
   // winners select_k keeps in LDS at full speed) shrinks the row tile so that the per-tile partial results stay small.

@@ -907,10 +907,13 @@ cagra_plan make_cagra_plan(const cuvsCagraSearchParams& p, int64_t n_rows, uint3
   // ---- adjust_search_params :199-245
   uint32_t max_it = (uint32_t)p.max_iterations;
   if (p.max_iterations == 0) max_it = reach_iterations(algo == (int)MULTI_CTA ? 32u / 1u : (uint32_t)(itopk / width));
-  if (max_it < (uint32_t)p.min_iterations) max_it = (uint32_t)p.min_iterations;
+  // the reference tests the ORIGINAL field (search_plan.cuh:216): with max_iterations = 0 and min_iterations > 0 the walk
+  // runs exactly min_iterations, not the reach-based count
+  if ((uint32_t)p.max_iterations < (uint32_t)p.min_iterations) max_it = (uint32_t)p.min_iterations;
   pl.max_iterations    = std::max<uint32_t>(max_it, (uint32_t)p.max_iterations);
-  pl.mc_max_iterations = p.max_iterations ? std::max<uint32_t>((uint32_t)p.max_iterations, (uint32_t)p.min_iterations)
-                                          : std::max<uint32_t>(reach_iterations(32u), (uint32_t)p.min_iterations);
+  pl.mc_max_iterations = (uint32_t)p.max_iterations < (uint32_t)p.min_iterations
+                           ? (uint32_t)p.min_iterations
+                           : (p.max_iterations ? (uint32_t)p.max_iterations : reach_iterations(32u));
   if (algo == (int)MULTI_CTA && filtering_rate > 0.f && filtering_rate < 1.f) {
     size_t adj = (size_t)((float)topk / (1.0 - filtering_rate) + (float)(itopk - topk) / std::sqrt(1.0 - filtering_rate));
     if (adj % 32) adj += 32 - adj % 32;

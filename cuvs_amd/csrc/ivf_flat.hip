@@ -719,8 +719,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
                      int64_t n_queries, int k, int64_t* neighbors, float* distances, const uint32_t* filter_bits)
 {
   CUVS_EXPECTS(k > 0, "ivf_flat::search: k must be positive");
-  CUVS_EXPECTS((int64_t)k <= idx.size, "ivf_flat::search: k (%d) must not exceed the number of indexed rows (%ld)", k,
-               (long)idx.size);
+  // (k beyond the index size is served with padded slots, as in the reference: ivf_flat_search.cuh has no such check)
   CUVS_EXPECTS(n_probes_in > 0, "n_probes must be positive");
   CUVS_EXPECTS(et == idx.dtype, "queries dtype differs from the index dtype");
   if (n_queries == 0) return;

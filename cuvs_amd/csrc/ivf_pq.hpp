@@ -52,7 +52,14 @@ struct ivf_pq_index {
   // scans only owned probes; the per-rank top-k lists are all-gathered and merged. shard_world == 1: not sharded.
   int shard_rank = 0, shard_world = 1;
   void* shard_comm = nullptr;  // cuvsAmdShardComm* (not owned): all-reduce of the k-th bounds between the scan phases
-  bool owns(uint32_t L) const { return shard_world <= 1 || (int)(L % (uint32_t)shard_world) == shard_rank; }
+  // optional owner of every list (cuvsAmdIvfPqSetListOwners: lists dealt by size, cuvsAmdShardDealLists); empty: L % world
+  std::vector<int32_t> h_list_owner;
+  dev_buf<int32_t> list_owner;
+  bool owns(uint32_t L) const
+  {
+    if (shard_world <= 1) return true;
+    return h_list_owner.empty() ? (int)(L % (uint32_t)shard_world) == shard_rank : h_list_owner[L] == shard_rank;
+  }
 
   static float scale(elem_t et)  // kDivisor(T) / kDivisor(float), ann_utils.cuh:134-160
   {

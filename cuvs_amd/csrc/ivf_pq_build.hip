@@ -525,10 +525,12 @@ std::unique_ptr<ivf_pq_index> ivf_pq_build(resources& res, const ivf_pq_build_pa
 }
 
 __global__ void drop_foreign_labels_kernel(uint32_t* __restrict__ labels, int64_t n, uint32_t n_lists, uint32_t world,
-                                           uint32_t rank)
+                                           uint32_t rank, const int32_t* __restrict__ owner)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && labels[i] % world != rank) labels[i] = n_lists;
+  if (i >= n) return;
+  const uint32_t L = labels[i];
+  if ((owner != nullptr ? (uint32_t)owner[L] : L % world) != rank) labels[i] = n_lists;
 }
 
 void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t et, int64_t n_new, bool is_host,
@@ -569,7 +571,7 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
   const bool sharded = idx.shard_world > 1;
   if (sharded)
     hipLaunchKernelGGL(drop_foreign_labels_kernel, dim3(nblk(n_new, 256)), dim3(256), 0, res.stream, labels.data(), n_new,
-                       idx.n_lists, (uint32_t)idx.shard_world, (uint32_t)idx.shard_rank);
+                       idx.n_lists, (uint32_t)idx.shard_world, (uint32_t)idx.shard_rank, idx.list_owner.data());
   const uint32_t n_buckets = idx.n_lists + (sharded ? 1u : 0u);
   dev_buf<uint32_t> perm(res, n_new), new_off(res, n_buckets + 1);
   group_by_label(res, labels.data(), n_new, n_buckets, perm.data(), new_off.data());
@@ -678,6 +680,7 @@ void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data,
     if (idx.metric == M_CosineExpanded) normalize_rows(res, xb.data(), cnt, dim);
     fused_l2_argmin<float>(res, xb.data(), cnt, dim, centers_flat.data(), idx.n_lists, dim, idx.center_norms.data(),
                            out_labels + r0, nullptr);
+    if (out_codes == nullptr) continue;  // labels only (cuvsAmdIvfPqListHistogram)
     pairwise_distance<float, float>(res, xb.data(), cnt, dim, idx.rotation.data(), idx.rot_dim, dim, dim, nullptr, nullptr,
                                     M_InnerProduct, rx.data(), idx.rot_dim);
     HIP_TRY(hipMemsetAsync(tmp_codes.data(), 0, tmp_codes.bytes(), res.stream));

@@ -1047,6 +1047,31 @@ struct scan2_layout {
   }
 };
 
+// L2 LUT entries of TWO queries at once with packed fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: the
+// cost of one plain fp32 instruction each, measured): (q0 - p0)^2 + (q1 - p1)^2 per component, with exactly the
+// roundings of fma(d1, d1, fma(d0, d0, 0)) - a product plus zero rounds like the product alone.
+// p = {p0, p1}, the two components of one codebook entry in a register pair: op_sel broadcasts one half of the pair to
+// both lanes of the packed subtract, so the codebook stays in 32 registers (hipcc materialises {p0, p0} pairs otherwise)
+__device__ inline f32x2_t pq_l2_entry2(const f32x2_t q0, const f32x2_t q1, const f32x2_t p)
+{
+  f32x2_t d0, d1;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d0) : "v"(q0), "v"(p));               // q0 - p.x
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d1) : "v"(q1), "v"(p));  // q1 - p.y
+  return __builtin_elementwise_fma(d1, d1, d0 * d0);
+}
+// the codebook slice of pq_regs_load as (component 0, component 1) pairs
+__device__ inline void pq_regs_load2(f32x2_t (&pq2)[4][4], const float* __restrict__ pq_centers)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t sl = (uint32_t)lane & 15u, cb = pq_code0(wave, lane);
+#pragma unroll
+  for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      pq2[sg][t] = f32x2_t{pq_centers[(size_t)((sl + sg * 16) * 2 + 0) * 256 + cb + t],
+                           pq_centers[(size_t)((sl + sg * 16) * 2 + 1) * 256 + cb + t]};
+}
+
 // inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS)
 __device__ inline uint32_t wave_inclusive_scan_dpp(uint32_t v)
 {
@@ -1082,7 +1107,7 @@ __device__ inline uint32_t pk_sub_f16(uint32_t a, uint32_t b)  // a - b, two hal
 // X: the kernel-wide per-lane constants of the rotated filter gathers - byte b of xoff[w] = ((lane + 4 w + b) & 15) << 4,
 // the byte offset of the subspace this lane looks up at step 4 w + b inside a 256-byte code row
 template <typename LutT, typename AccT, int EQ, int NG, int E>
-__device__ inline void pq_scan2_item(const scan_args& a, const work_item item, char* smem, const float (&pqreg)[4][2][4],
+__device__ inline void pq_scan2_item(const scan_args& a, const work_item item, char* smem, const f32x2_t (&pq2)[4][4],
                                      const work_item* __restrict__ share,
                                      const uint32_t share_len, const uint32_t next_ticket, const int next_slot_id)
 {
@@ -1176,25 +1201,19 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
   // ---- filter LUT: subspaces 0..15 (this thread: subspace sl, codes cb .. cb + 3), the 8 queries' entries as fp16
   auto build_filter_lut = [&](auto fp8_tag) {
     constexpr bool FP8 = decltype(fp8_tag)::value;  // compile-time: see pq_scan_item
-    float q[2][FQ];
+    f32x2_t q[2][FQ / 2];  // query pairs (j, j + 1)
 #pragma unroll
     for (int l = 0; l < 2; ++l)
 #pragma unroll
-      for (int j = 0; j < FQ; ++j) q[l][j] = qv[j * a.rot_dim + sl * 2 + l];
+      for (int j = 0; j < FQ; ++j) q[l][j >> 1][j & 1] = qv[j * a.rot_dim + sl * 2 + l];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const float p0 = pqreg[0][0][t], p1 = pqreg[0][1][t];
       u32x4_t ev;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        float sc[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float d0 = q[0][jj * 2 + h] - p0;
-          const float d1 = q[1][jj * 2 + h] - p1;
-          sc[h]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-          if constexpr (FP8) sc[h] = fp8_round_trip<AccT>(sc[h], false);  // L2 only here: the unsigned fp_8bit<5, false>
-        }
+        const f32x2_t e2 = pq_l2_entry2(q[0][jj], q[1][jj], pq2[0][t]);
+        float sc[2] = {e2.x, e2.y};
+        if constexpr (FP8) { sc[0] = fp8_round_trip<AccT>(sc[0], false); sc[1] = fp8_round_trip<AccT>(sc[1], false); }  // L2 only here: fp_8bit<5, false>
         // fp16 LUT: the exact entry itself (round to nearest, as the exact LUT stores it); fp32 LUT: rounded toward zero
         if constexpr (sizeof(LutT) == 2) ev[jj] = __builtin_bit_cast(uint32_t, f16x2_t{to_lut_half(sc[0]), to_lut_half(sc[1])});
         else                             ev[jj] = pack_half_rtz(sc[0], sc[1]);
@@ -1541,21 +1560,19 @@ __device__ inline void pq_scan2_item(const scan_args& a, const work_item item, c
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
         const uint32_t s = sl + sg * 16;
-        float q[2][EQ];
+        f32x2_t q[2][EQ / 2];  // query pairs (j, j + 1)
 #pragma unroll
         for (int l = 0; l < 2; ++l)
 #pragma unroll
-          for (int j = 0; j < EQ; ++j) q[l][j] = qv[(g * EQ + j) * a.rot_dim + s * 2 + l];
+          for (int j = 0; j < EQ; ++j) q[l][j >> 1][j & 1] = qv[(g * EQ + j) * a.rot_dim + s * 2 + l];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float p0 = pqreg[sg][0][t], p1 = pqreg[sg][1][t];
           float sc[EQ];
 #pragma unroll
-          for (int j = 0; j < EQ; ++j) {
-            const float d0 = q[0][j] - p0;
-            const float d1 = q[1][j] - p1;
-            sc[j]          = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-            if constexpr (FP8) sc[j] = fp8_round_trip<AccT>(sc[j], false);
+          for (int jj = 0; jj < EQ / 2; ++jj) {
+            const f32x2_t e2 = pq_l2_entry2(q[0][jj], q[1][jj], pq2[sg][t]);
+            sc[2 * jj] = e2.x; sc[2 * jj + 1] = e2.y;
+            if constexpr (FP8) { sc[2 * jj] = fp8_round_trip<AccT>(sc[2 * jj], false); sc[2 * jj + 1] = fp8_round_trip<AccT>(sc[2 * jj + 1], false); }
           }
           XL::store(s, cb + t, acc_t::pack(sc));
         }
@@ -1717,8 +1734,8 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
   const uint32_t xcd = blockIdx.x & 7u;
   const uint32_t chunk = (n_items + 7u) / 8u;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();  // see cm_lut
-  float pqreg[4][2][4];  // this thread's slice of the codebook, in registers for the whole launch (pq_regs_load)
-  pq_regs_load(pqreg, a.pq_centers, true);
+  f32x2_t pq2[4][4];  // this thread's slice of the codebook, in registers for the whole launch (pq_regs_load2)
+  pq_regs_load2(pq2, a.pq_centers);
   const scan2_layout lay(cm_lut<entry_t>::bytes(), EQ * NG, a.rot_dim);
   work_item* sh_item       = reinterpret_cast<work_item*>(smem + lay.slots);
   const uint32_t share0    = min(n_items, xcd * chunk);
@@ -1735,7 +1752,7 @@ __global__ __launch_bounds__(kScanThreads) void pq_scan2_kernel(scan_args a)
     if (cur.pad == 0xffffffffu) break;  // workgroup-uniform
     uint32_t next_ticket = 0xffffffffu;
     if (threadIdx.x == 0) next_ticket = atomicAdd(ticket, 1u);
-    pq_scan2_item<LutT, AccT, EQ, NG, E>(a, cur, smem, pqreg, share, share_len, next_ticket, buf ^ 1);
+    pq_scan2_item<LutT, AccT, EQ, NG, E>(a, cur, smem, pq2, share, share_len, next_ticket, buf ^ 1);
     __syncthreads();
   }
 }
@@ -1962,7 +1979,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                    elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances, const uint32_t* filter_bits)
 {
   CUVS_EXPECTS(k > 0, "parameter `k` in top-k must be positive.");
-  CUVS_EXPECTS((int64_t)k <= idx.size,
+  // (a list shard may hold fewer than k rows - its peers pad: every rank must reach the collectives of this call)
+  CUVS_EXPECTS((int64_t)k <= idx.size || idx.shard_world > 1,
                "parameter `k` (%d) in top-k must not be larger that the total size of the index (%ld)", k,
                (long)idx.size);
   CUVS_EXPECTS(p.n_probes > 0, "n_probes (number of clusters to probe in the search) must be positive.");
@@ -2004,12 +2022,24 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     CUVS_EXPECTS(smem <= lds_cap, "ivf_pq::search: rot_dim %u / k %d do not fit 160 KiB of LDS", idx.rot_dim, k_scan);
   }
 
+  // rows of the n_probes largest lists: the width of the score matrix of the non-fused path. With a shard communicator
+  // attached the batch size derived from it must be the same on every rank (the ranks issue one probe all-gather and
+  // one bound all-reduce per batch: different batch counts would hang the collectives), so the maximum over the
+  // ranks is used (one 4-byte all-reduce, only on this rarely taken path).
+  size_t largest_total = large_k ? largest_lists_total(idx.h_list_sizes, n_probes) : 0;
+  if (large_k && idx.shard_comm != nullptr) {
+    dev_buf<uint32_t> key(res, 1);
+    const uint32_t mine = ~(uint32_t)std::min<size_t>(largest_total, 0xfffffffeu);  // min over ~x = max over x
+    copy_async(res, key.data(), &mine, sizeof(mine));
+    shard_allreduce_min_u32(res, idx.shard_comm, key.data(), 1);
+    largest_total = (size_t)~to_host(res, key.data(), 1)[0];
+  }
   // batch of queries per pass (reference: max_internal_batch_size bounds the coarse batch, :814-857)
   int64_t max_batch = std::max<uint32_t>(1, p.max_internal_batch_size);
   {
     // keep the coarse distance matrix and the candidate buffers inside the workspace budget
     int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k_scan * 8 + (int64_t)idx.rot_dim * 4 + idx.dim * 4;
-    if (large_k) per_q += (int64_t)largest_lists_total(idx.h_list_sizes, n_probes) * 8;
+    if (large_k) per_q += (int64_t)largest_total * 8;
     int64_t fit   = std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q);
     max_batch     = std::min(max_batch, fit);
   }
@@ -2035,7 +2065,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<uint32_t> phase_labels(res, (head > 0 || sharded) ? (size_t)n_pairs_max : 0);
   const int64_t max_items = n_pairs_max / qpb + n_labels + 1;
   dev_buf<work_item> items(res, (size_t)max_items);
-  const size_t scores_ld = large_k ? largest_lists_total(idx.h_list_sizes, n_probes) : 0;
+  const size_t scores_ld = largest_total;
   dev_buf<float> cand_d(res, large_k ? (size_t)bs_alloc * scores_ld : (size_t)n_pairs_max * k);
   dev_buf<uint32_t> cand_i(res, large_k ? (size_t)bs_alloc * scores_ld : (size_t)n_pairs_max * k);
   dev_buf<uint32_t> pair_seg(res, large_k ? (size_t)n_pairs_max : 0);
@@ -2073,7 +2103,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (head > 0 || sharded) {
       hipLaunchKernelGGL(phase_labels_kernel, dim3(nblk(n_pairs, 256)), dim3(256), 0, res.stream, probes.data(),
                          n_pairs, n_probes, head, idx.n_lists, phase_labels.data(), (uint32_t)idx.shard_world,
-                         (uint32_t)idx.shard_rank, n_ranges);
+                         (uint32_t)idx.shard_rank, n_ranges, idx.list_owner.data());
       labels = phase_labels.data();
     }
     // the tail phase (warm bounds) of the common configuration runs pq_scan2_kernel on items of 2 * qpb pairs

@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <dlfcn.h>
 #include <mutex>
+#include <string>
 
 struct cuvsAmdShardComm {
   ncclComm_t comm = nullptr;
@@ -39,12 +40,14 @@ struct rccl_api {
 const rccl_api& rccl()
 {
   static rccl_api api;
+  static std::string load_error = "missing symbols";  // dlerror() text of the failed dlopen, captured once
   static std::once_flag once;
   std::call_once(once, [] {
     void* h = nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (h != nullptr) break;
+      if (const char* err = dlerror()) load_error = err;  // (dlerror() clears the state: read it once)
     }
     if (h == nullptr) return;
     api.get_unique_id    = reinterpret_cast<decltype(api.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
@@ -56,7 +59,7 @@ const rccl_api& rccl()
   });
   CUVS_EXPECTS(api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather && api.all_reduce &&
                  api.get_error_string,
-               "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+               "RCCL (librccl.so.1) could not be loaded: %s", load_error.c_str());
   return api;
 }
 
@@ -66,17 +69,19 @@ const rccl_api& rccl()
     if (r__ != ncclSuccess) CUVS_FAIL("RCCL error %d (%s) in %s", (int)r__, rccl().get_error_string(r__), #expr); \
   } while (0)
 
-// one candidate = 12 bytes on the wire: [n_queries, k] distances (fp32) followed by [n_queries, k] ids (int64)
+// one candidate = 12 bytes on the wire: a rank's block is [n_queries, k] ids (int64) followed by [n_queries, k] distances
+// (fp32), padded to a multiple of 16 bytes so that the ids of every block are 8-byte aligned whatever n_queries * k is
+__host__ __device__ inline size_t wire_block_bytes(int64_t n) { return ((size_t)n * 12 + 15) & ~size_t(15); }
 __global__ void pack_block_kernel(const float* __restrict__ d, const int64_t* __restrict__ i, int64_t n,
                                   char* __restrict__ out)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  reinterpret_cast<float*>(out)[t]                = d[t];
-  reinterpret_cast<int64_t*>(out + (size_t)n * 4)[t] = i[t];
+  reinterpret_cast<int64_t*>(out)[t]               = i[t];
+  reinterpret_cast<float*>(out + (size_t)n * 8)[t] = d[t];
 }
 
-// gathered [world][ distances n*4 | ids n*8 ] -> per-query rows [n_queries, world * k] (rank-major inside a row)
+// gathered [world][ ids n*8 | distances n*4 | pad ] -> per-query rows [n_queries, world * k] (rank-major inside a row)
 // Slots a rank could not fill (fewer than k rows in its probed lists) carry the id INT64_MAX and the distance FLT_MAX
 // (ivf_common.cuh:31 kOutOfBoundsRecord); for similarity metrics they must lose the merge, so they enter it as -FLT_MAX
 // and leave it as FLT_MAX again (pad_invalid_kernel).
@@ -87,10 +92,10 @@ __global__ void regroup_kernel(const char* __restrict__ gathered, int64_t nq, in
   const int64_t n = nq * k;
   if (t >= n * world) return;
   const int64_t r = t / n, rem = t % n, q = rem / k, j = rem % k;
-  const char* blk = gathered + (size_t)r * n * 12;
+  const char* blk = gathered + (size_t)r * wire_block_bytes(n);
   const int64_t o = q * ((int64_t)world * k) + r * k + j;
-  const int64_t id = reinterpret_cast<const int64_t*>(blk + (size_t)n * 4)[rem];
-  const float v    = reinterpret_cast<const float*>(blk)[rem];
+  const int64_t id = reinterpret_cast<const int64_t*>(blk)[rem];
+  const float v    = reinterpret_cast<const float*>(blk + (size_t)n * 8)[rem];
   vals[o]          = id == INT64_MAX ? (select_min ? FLT_MAX : -FLT_MAX) : v;
   ids[o]           = id;
 }
@@ -110,10 +115,11 @@ void shard_all_gather_topk(resources& res, cuvsAmdShardComm& c, const float* ld,
   CUVS_EXPECTS(nq >= 0 && k > 0, "shard all-gather: bad shape");
   if (nq == 0) return;
   const int64_t n = nq * k;
-  dev_buf<char> send(res, (size_t)n * 12), recv(res, (size_t)n * 12 * c.world);
+  const size_t blk = wire_block_bytes(n);
+  dev_buf<char> send(res, blk), recv(res, blk * c.world);
   hipLaunchKernelGGL(pack_block_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, ld, li, n, send.data());
   profile_begin(res, "shard_all_gather");
-  RCCL_TRY(rccl().all_gather(send.data(), recv.data(), (size_t)n * 12, ncclUint8, c.comm, res.stream));
+  RCCL_TRY(rccl().all_gather(send.data(), recv.data(), blk, ncclUint8, c.comm, res.stream));
   profile_end(res, "shard_all_gather");
   dev_buf<float> vals(res, (size_t)n * c.world);
   dev_buf<int64_t> ids(res, (size_t)n * c.world);
@@ -200,6 +206,59 @@ cuvsError_t cuvsAmdIvfPqSetListShard(cuvsIvfPqIndex_t index, int rank, int world
     auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
     CUVS_EXPECTS(idx.size == 0, "list shard: the index already holds rows (build with add_data_on_build = false)");
     idx.shard_rank = rank; idx.shard_world = world;
+  });
+}
+
+// Greedy longest-processing-time dealing: lists by descending weight (ties: lower id first), each to the rank with the
+// smallest load so far (ties: lower rank). Deterministic, so every rank computes the same table from the same weights.
+cuvsError_t cuvsAmdShardDealLists(const uint64_t* weights, uint32_t n_lists, int world, int32_t* owners)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(weights != nullptr && owners != nullptr && world >= 1, "deal lists: bad arguments");
+    std::vector<uint32_t> order(n_lists);
+    for (uint32_t i = 0; i < n_lists; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return weights[a] > weights[b]; });
+    std::vector<uint64_t> load((size_t)world, 0);
+    for (uint32_t L : order) {
+      int best = 0;
+      for (int r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+      owners[L] = best;
+      load[best] += weights[L];
+    }
+  });
+}
+
+cuvsError_t cuvsAmdIvfPqSetListOwners(cuvsIvfPqIndex_t index, const int32_t* owners, uint32_t n_lists, int rank, int world)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(index != nullptr && index->addr != 0, "IVF-PQ index is not built");
+    CUVS_EXPECTS(world >= 1 && rank >= 0 && rank < world, "list shard: rank %d of %d", rank, world);
+    auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
+    CUVS_EXPECTS(idx.size == 0, "list shard: the index already holds rows (build with add_data_on_build = false)");
+    CUVS_EXPECTS(owners != nullptr && n_lists == idx.n_lists, "list owners: %u entries for %u lists", n_lists, idx.n_lists);
+    for (uint32_t L = 0; L < n_lists; ++L)
+      CUVS_EXPECTS(owners[L] >= 0 && owners[L] < world, "list owners: list %u -> rank %d of %d", L, owners[L], world);
+    idx.shard_rank = rank; idx.shard_world = world;
+    idx.h_list_owner.assign(owners, owners + n_lists);
+    idx.list_owner = dev_buf<int32_t>::persistent(n_lists);
+    HIP_TRY(hipMemcpy(idx.list_owner.data(), owners, (size_t)n_lists * sizeof(int32_t), hipMemcpyHostToDevice));
+  });
+}
+
+cuvsError_t cuvsAmdIvfPqListHistogram(cuvsResources_t res_h, cuvsIvfPqIndex_t index, DLManagedTensor* rows, uint64_t* counts)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index != nullptr && index->addr != 0 && rows != nullptr && counts != nullptr, "list histogram: null argument");
+    auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
+    auto& t   = rows->dl_tensor;
+    CUVS_EXPECTS(t.ndim == 2 && is_c_contiguous(t) && t.shape[1] == idx.dim && is_device_accessible(t),
+                 "list histogram: rows must be a device [n, dim] row-major matrix");
+    const int64_t n = t.shape[0];
+    dev_buf<uint32_t> labels(res, (size_t)std::max<int64_t>(n, 1));
+    ivf_pq_transform(res, idx, dl_data(t), elem_of(t.dtype), n, labels.data(), nullptr);
+    auto h = to_host(res, labels.data(), (size_t)n);
+    for (int64_t i = 0; i < n; ++i) counts[h[i]] += 1;
   });
 }
 

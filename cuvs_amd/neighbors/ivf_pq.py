@@ -8,7 +8,7 @@ import torch
 from .._lib import DLDataType, DLManagedTensor, Tensor, check, lib, view_to_torch
 from ..common import auto_sync_resources
 from ..distance import DISTANCE_TYPES
-from ._util import as_device, out_buffers
+from ._util import as_device, make_filter, out_buffers
 
 _HIP_DT = {np.dtype("float32"): 0, np.dtype("float16"): 2, np.dtype("int8"): 3, np.dtype("uint8"): 8}
 
@@ -195,14 +195,21 @@ def extend(index, new_vectors, new_indices, resources=None):
 
 
 @auto_sync_resources
-def search(search_params, index, queries, k, neighbors=None, distances=None, resources=None):
-    """Returns (distances [m,k] float32, neighbors [m,k] int64)."""
+def search(search_params, index, queries, k, neighbors=None, distances=None, resources=None, filter=None):
+    """Returns (distances [m,k] float32, neighbors [m,k] int64). filter: None or (uint32 words on the device, BITSET) - a
+    bitset over source ids, 1 keeps the row (the C++ overload with a sample filter, ivf_pq.hpp:1818-1828; the reference's
+    C / Python layers do not expose it: include/cuvs_amd/extensions.h)."""
     if not index.trained:
         raise ValueError("Index needs to be built before calling search.")
     q = as_device(queries)
     neighbors, distances = out_buffers(q.shape[0], k, neighbors, distances)
     tq, tn, td = Tensor(q), Tensor(neighbors), Tensor(distances)
-    check(lib().cuvsIvfPqSearch(resources.get_c_obj(), search_params._p, index._p, tq.ptr, tn.ptr, td.ptr))
+    if filter is None:
+        check(lib().cuvsIvfPqSearch(resources.get_c_obj(), search_params._p, index._p, tq.ptr, tn.ptr, td.ptr))
+    else:
+        flt, keep = make_filter(filter)
+        check(lib().cuvsAmdIvfPqSearchFiltered(resources.get_c_obj(), search_params._p, index._p, tq.ptr, tn.ptr, td.ptr, flt))
+        del keep
     return distances, neighbors
 
 

@@ -1,7 +1,8 @@
 """List-sharded multi-GPU IVF-PQ: one process per GPU, the per-rank top-k blocks all-gathered by RCCL inside the
 library (include/cuvs_amd/shard.h, cuvs_amd/csrc/shard_comm.hip). Reference: the sharded search of
 cpp/src/neighbors/mg/snmg.cuh:248-375 (row-range shards, NCCL send/recv fan-in) - here the split by IVF list with one
-global coarse quantizer: list L lives on rank L % world, every rank ranks all centres and scans the probes it owns.
+global coarse quantizer: list L lives on rank L % world - or, dealt by size, on owners[L] (deal_lists: greedy LPT over the
+rows per list) - every rank ranks all centres and scans the probes it owns.
 
 Only the rendezvous (128 bytes of id from rank 0 to the others) needs an out-of-band channel - `ShardComm.from_torch`
 uses the torch.distributed store the launcher already provides; the data path never touches torch.distributed."""
@@ -17,8 +18,36 @@ from . import ivf_pq
 ID_BYTES = 128
 
 
-def owner(list_id, world):
-    return list_id % world
+def owner(list_id, world, owners=None):
+    return list_id % world if owners is None else int(owners[list_id])
+
+
+def deal_lists(weights, world):
+    """Greedy longest-processing-time dealing of the lists (rows per list) to `world` ranks - cuvsAmdShardDealLists, the same
+    table on every rank for the same weights. Returns int32 [n_lists]."""
+    w = np.ascontiguousarray(weights, dtype=np.uint64)
+    owners = np.empty(len(w), np.int32)
+    check(lib().cuvsAmdShardDealLists(w.ctypes.data_as(C.c_void_p), C.c_uint32(len(w)), C.c_int(world),
+                                      owners.ctypes.data_as(C.c_void_p)))
+    return owners
+
+
+@auto_sync_resources
+def list_histogram(index, rows, counts=None, resources=None):
+    """Adds the number of `rows` (device tensor [n, dim]) falling into every list to `counts` (uint64 [n_lists])."""
+    from .._lib import Tensor
+
+    if counts is None:
+        counts = np.zeros(index.n_lists, np.uint64)
+    t = Tensor(rows.contiguous())
+    check(lib().cuvsAmdIvfPqListHistogram(resources.get_c_obj(), index._p, t.ptr, counts.ctypes.data_as(C.c_void_p)))
+    return counts
+
+
+def set_list_owners(index, owners, rank, world):
+    """Marks the (still empty) index as the shard of `rank` with an explicit owner per list (same table on every rank)."""
+    o = np.ascontiguousarray(owners, dtype=np.int32)
+    check(lib().cuvsAmdIvfPqSetListOwners(index._p, o.ctypes.data_as(C.c_void_p), C.c_uint32(len(o)), C.c_int(rank), C.c_int(world)))
 
 
 class ShardComm:
@@ -69,12 +98,16 @@ class ShardComm:
 
 
 @auto_sync_resources
-def build(index_params, trainset, rank, world, resources=None):
+def build(index_params, trainset, rank, world, owners=None, resources=None):
     """Train the model (identical on every rank: same trainset, deterministic k-means) and mark the empty index as the
-    shard of `rank`. index_params must have add_data_on_build=False."""
+    shard of `rank`: list L on rank L % world, or on owners[L] (deal_lists). index_params must have
+    add_data_on_build=False."""
     assert not index_params.add_data_on_build, "list-sharded build trains first and adds rows with extend()"
     index = ivf_pq.build(index_params, trainset, resources=resources)
-    check(lib().cuvsAmdIvfPqSetListShard(index._p, C.c_int(rank), C.c_int(world)))
+    if owners is None:
+        check(lib().cuvsAmdIvfPqSetListShard(index._p, C.c_int(rank), C.c_int(world)))
+    else:
+        set_list_owners(index, owners, rank, world)
     return index
 
 

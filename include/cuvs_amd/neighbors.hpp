@@ -7,6 +7,7 @@
 // cuvsGetLastErrorText(), like the reference's raft::exception.
 #pragma once
 #include <cuvs/core/all.h>
+#include <cuvs_amd/extensions.h>
 
 #include <cstdint>
 #include <memory>
@@ -95,6 +96,15 @@ struct c_params {
 }  // namespace detail
 
 namespace neighbors {
+
+namespace filtering {
+// cuvs::neighbors::filtering::bitset_filter (cpp/include/cuvs/neighbors/common.hpp): bit i of the device words = 1 keeps
+// source row i
+struct bitset_filter {
+  const uint32_t* words = nullptr;  // device memory
+  int64_t n_bits        = 0;
+};
+}  // namespace filtering
 
 namespace brute_force {
 template <typename T = float>
@@ -256,6 +266,24 @@ void search(const resources& res, const search_params& p, const index& idx, devi
   detail::tensor<int64_t> n(neighbors);
   detail::tensor<float> d(distances);
   check(cuvsIvfPqSearch(res.get(), cp.p, idx.get(), q.get(), n.get(), d.get()), "cuvsIvfPqSearch");
+}
+// search with a sample filter (ivf_pq.hpp:1818-1828); the C entry point is this library's (cuvs_amd/extensions.h)
+template <typename T>
+void search(const resources& res, const search_params& p, const index& idx, device_matrix_view<const T> queries,
+            device_matrix_view<int64_t> neighbors, device_matrix_view<float> distances,
+            const filtering::bitset_filter& sample_filter)
+{
+  detail::c_params<cuvsIvfPqSearchParams_t, cuvsIvfPqSearchParamsCreate, cuvsIvfPqSearchParamsDestroy> cp;
+  cp.p->n_probes = p.n_probes; cp.p->lut_dtype = p.lut_dtype; cp.p->internal_distance_dtype = p.internal_distance_dtype;
+  cp.p->coarse_search_dtype = p.coarse_search_dtype; cp.p->max_internal_batch_size = p.max_internal_batch_size;
+  cp.p->preferred_shmem_carveout = p.preferred_shmem_carveout;
+  detail::tensor<const T> q(queries);
+  detail::tensor<int64_t> n(neighbors);
+  detail::tensor<float> d(distances);
+  detail::tensor<const uint32_t> f(device_matrix_view<const uint32_t>{sample_filter.words, 1, (sample_filter.n_bits + 31) / 32, false});
+  f.m.dl_tensor.ndim = 1; f.shape[0] = (sample_filter.n_bits + 31) / 32;
+  cuvsFilter flt{reinterpret_cast<uintptr_t>(f.get()), BITSET};
+  check(cuvsAmdIvfPqSearchFiltered(res.get(), cp.p, idx.get(), q.get(), n.get(), d.get(), flt), "cuvsAmdIvfPqSearchFiltered");
 }
 }  // namespace ivf_pq
 

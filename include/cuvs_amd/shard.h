@@ -40,6 +40,18 @@ CUVS_EXPORT cuvsError_t cuvsAmdShardCommRank(cuvsAmdShardComm_t comm, int* rank,
  * list L is owned by rank L % world. Call before cuvsIvfPqExtend. */
 CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetListShard(cuvsIvfPqIndex_t index, int rank, int world);
 
+/* Lists dealt by size instead of L % world. cuvsAmdShardDealLists: greedy longest-processing-time dealing of n_lists
+ * weights (rows per list) to `world` ranks - deterministic, so every rank derives the same table from the same weights.
+ * cuvsAmdIvfPqListHistogram: adds, for every row of `rows` (device, [n, dim], the index dtype), one to counts[list of
+ * the row] (host array of n_lists entries) - a rank calls it on ITS slice of the corpus, the launcher sums the arrays
+ * over the ranks. cuvsAmdIvfPqSetListOwners: like cuvsAmdIvfPqSetListShard with an explicit owner per list (host
+ * array); every rank must pass the same table. */
+CUVS_EXPORT cuvsError_t cuvsAmdShardDealLists(const uint64_t* weights, uint32_t n_lists, int world, int32_t* owners);
+CUVS_EXPORT cuvsError_t cuvsAmdIvfPqListHistogram(cuvsResources_t res, cuvsIvfPqIndex_t index, DLManagedTensor* rows,
+                                                  uint64_t* counts);
+CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetListOwners(cuvsIvfPqIndex_t index, const int32_t* owners, uint32_t n_lists, int rank,
+                                                  int world);
+
 /* Optional: gives the shard's searches access to the communicator. cuvsIvfPqSearch then all-reduces (min) the per-query
  * k-th bounds between its two scan phases - one ncclAllReduce of n_queries uint32 per batch - so that every rank prunes
  * with the bound of the query's globally nearest probe, whoever owns it. Results do not depend on it (bounds only

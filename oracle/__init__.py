@@ -210,7 +210,8 @@ def cagra_search(dataset, graph, queries, k, itopk_size=64, search_width=1, max_
         while reach < n:
             reach *= max(2, degree // 2)
             max_iter += 1
-    max_iter = max(max_iter, int(min_iterations))
+    if int(max_iterations) < int(min_iterations):  # the reference tests the original field (search_plan.cuh:216)
+        max_iter = int(min_iterations)
     bits = 11
     while (1 << bits) < 2 * (itopk + 2 * width * degree):
         bits += 1

@@ -3,8 +3,8 @@
 # scripts/pq_scan_variants.py at the bench.py workload; writes gpurun_out/pmc/<tag>_pmcN.txt summaries.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; TAG=${1:-cur}; VAR="${2:-DBG=0,HEAD=1}"; mkdir -p gpurun_out/pmc
 W=/tmp/pmc_work; rm -rf $W; mkdir -p $W
-P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM"
-P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"
+P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM"
 P3="FETCH_SIZE"
 P4="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 i=1

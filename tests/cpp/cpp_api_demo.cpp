@@ -68,6 +68,18 @@ int main()
       HIPCHECK(hipMemcpy(got.data(), dn, nq * k * 8, hipMemcpyDeviceToHost));
       std::printf("ivf_pq recall %.4f\n", recall(got));
       if (recall(got) < 0.85) return 1;
+      // the overload with a sample filter: only even source ids may come back
+      std::vector<uint32_t> words((n + 31) / 32, 0x55555555u);
+      uint32_t* dw;
+      HIPCHECK(hipMalloc((void**)&dw, words.size() * 4));
+      HIPCHECK(hipMemcpy(dw, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+      nb::ivf_pq::search<float>(res, sp, idx, queries, nbr, dst, nb::filtering::bitset_filter{dw, n});
+      res.sync_stream();
+      HIPCHECK(hipMemcpy(got.data(), dn, nq * k * 8, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < nq * k; ++i)
+        if (got[i] < 0 || got[i] >= n || (got[i] & 1)) { std::printf("ivf_pq filtered: id %ld\n", (long)got[i]); return 1; }
+      std::printf("ivf_pq filtered OK\n");
+      HIPCHECK(hipFree(dw));
     }
     {
       nb::cagra::index_params ip; ip.intermediate_graph_degree = 64; ip.graph_degree = 32;

@@ -222,3 +222,25 @@ def test_fused_threshold_epilogue_more_than_one_row_tile():
     gd, gi = _run(x, qq, 5, "sqeuclidean")
     od, oi = oracle.brute_force_knn(qq, x, 5)
     assert (gi == oi).all() and (gd == od).all()
+
+
+def test_k_beyond_the_number_of_rows_is_padded():
+    """The reference accepts k > n (knn_brute_force.cuh / ivf_flat_search.cuh have no such check): the first n slots are the
+    exact ranking, the rest are padding (worst distance, an id that is no row)."""
+    import torch
+    from cuvs_amd.neighbors import brute_force, ivf_flat
+
+    x, q = _gen(40, 16, 7, seed=9)
+    idx = brute_force.build(torch.from_numpy(x).cuda())
+    d, i = brute_force.search(idx, torch.from_numpy(q).cuda(), 64)
+    torch.cuda.synchronize()
+    d, i = d.cpu().numpy(), i.cpu().numpy()
+    od, oi = oracle.brute_force_knn(q, x, 40)
+    assert (i[:, :40] == oi).all() and (d[:, :40] == od).all()
+    assert ((i[:, 40:] < 0) | (i[:, 40:] >= 40)).all()
+    fidx = ivf_flat.build(ivf_flat.IndexParams(n_lists=4, kmeans_n_iters=5), torch.from_numpy(x).cuda())
+    d2, i2 = ivf_flat.search(ivf_flat.SearchParams(n_probes=4), fidx, torch.from_numpy(q).cuda(), 64)
+    torch.cuda.synchronize()
+    i2 = i2.cpu().numpy()
+    assert (np.sort(i2[:, :40], axis=1) == np.arange(40)[None, :]).all()   # every row once (all lists probed)
+    assert ((i2[:, 40:] < 0) | (i2[:, 40:] >= 40)).all()

@@ -113,6 +113,8 @@ def test_c4_shape_pins():
     (5000, 16, 16, 1000, dict(itopk_size=512, search_width=4)),
     (200_000, 128, 10, 5000, dict(itopk_size=256, search_width=8)),        # small hash does not fit -> normal hash
     (3_000_000, 64, 10, 10, dict(itopk_size=64, max_iterations=20, min_iterations=30)),
+    (3_000_000, 64, 10, 10000, dict(itopk_size=64, min_iterations=10)),   # max_iterations 0: the walk runs min_iterations
+    (3_000_000, 64, 10, 10, dict(algo="multi_cta", min_iterations=12)),
     (1_000_000, 64, 10, 100, dict(algo="multi_cta", itopk_size=128, hashmap_min_bitlen=13)),
     (50_000, 32, 8, 10000, dict(algo="single_cta", hashmap_mode="hash")),
 ])

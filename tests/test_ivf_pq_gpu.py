@@ -427,3 +427,62 @@ def test_coarse_search_dtype_recall_thresholds():
     for dt, thr in ((np.float16, 0.86), (np.int8, 0.1)):
         _, gi = _search(index, q, k, n_probes=20, coarse_search_dtype=dt)
         assert oracle.recall(gi, ti) >= thr, (dt, oracle.recall(gi, ti))
+
+
+def _bitset(keep):
+    words = np.zeros((len(keep) + 31) // 32, np.uint32)
+    idx = np.nonzero(keep)[0]
+    np.bitwise_or.at(words, idx >> 5, (np.uint32(1) << (idx & 31).astype(np.uint32)))
+    return words
+
+
+@pytest.mark.parametrize("lut,acc,k,nq,n,pq_dim,n_lists", [
+    ("f32", "f32", 10, 64, 6000, 16, 16),     # generic kernel, small batch (single phase)
+    ("f16", "f32", 20, 400, 30000, 64, 64),   # FAST4 head phase + pq_scan2 tail phase
+    ("f16", "f16", 100, 300, 20000, 64, 32),  # k > 64: workgroup merge of the wave lists
+    ("f32", "f32", 300, 40, 8000, 64, 16),    # k > 256: non-fused path (every score written, select_k)
+])
+def test_bitset_prefilter_parity(lut, acc, k, nq, n, pq_dim, n_lists):
+    """Pre-filtered search (cpp/include/cuvs/neighbors/ivf_pq.hpp:1818-1828 with a bitset_filter; applied per scanned row,
+    compute_distances_impl.cuh:78-80, ivf_pq_search.cuh:1111-1134): ids and distances identical to the oracle with the same
+    bitset, and no masked id ever comes back."""
+    import torch
+    from cuvs_amd._lib import BITSET
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _gen(n, 128 if pq_dim == 64 else 32, nq, seed=61)
+    rng = np.random.default_rng(8)
+    keep = rng.random(n) < 0.6
+    words = _bitset(keep)
+    index = _build(x, n_lists=n_lists, pq_dim=pq_dim, pq_bits=8, kmeans_n_iters=10)
+    sp = ivf_pq.SearchParams(n_probes=8, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    tw = torch.from_numpy(words.view(np.int32)).cuda()
+    d, i = ivf_pq.search(sp, index, torch.from_numpy(q).cuda(), k, filter=(tw, BITSET))
+    torch.cuda.synchronize()
+    gd, gi = d.cpu().numpy(), i.cpu().numpy()
+    od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, k, 8, lut=lut, acc=acc, keep_bits=words)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    valid = gi != np.iinfo(np.int64).max
+    assert keep[gi[valid]].all()
+
+
+def test_bitset_prefilter_recall():
+    """python/cuvs/cuvs/tests/ann_utils.py:131 style: recall of the filtered search against the exact kNN of the kept rows
+    (all lists probed: only the PQ error remains)."""
+    import torch
+    from cuvs_amd._lib import BITSET
+    from cuvs_amd.neighbors import ivf_pq
+
+    n, d, nq, k = 8000, 32, 200, 10
+    x, q = _gen(n, d, nq, seed=62)
+    keep = np.arange(n) % 3 != 0
+    index = _build(x, n_lists=16, pq_dim=32, pq_bits=8)
+    tw = torch.from_numpy(_bitset(keep).view(np.int32)).cuda()
+    _, i = ivf_pq.search(ivf_pq.SearchParams(n_probes=16), index, torch.from_numpy(q).cuda(), k, filter=(tw, BITSET))
+    torch.cuda.synchronize()
+    gi = i.cpu().numpy()
+    kept_ids = np.nonzero(keep)[0]
+    _, ti = oracle.exact_knn(q, x[keep], k)
+    assert oracle.recall(gi, kept_ids[ti]) > 0.7
+    assert keep[gi].all()

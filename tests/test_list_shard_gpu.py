@@ -85,3 +85,55 @@ def test_two_list_shards_equal_the_unsharded_index(metric):
     assert (md == fd).all()
     for qi in range(len(q)):
         assert sorted(zip(md[qi].tolist(), mi[qi].tolist())) == sorted(zip(fd[qi].tolist(), fi[qi].tolist()))
+
+
+def test_lists_dealt_by_size_equal_the_unsharded_index():
+    """Lists dealt to the ranks by size (cuvsAmdIvfPqListHistogram per row slice, summed; cuvsAmdShardDealLists = greedy
+    LPT; cuvsAmdIvfPqSetListOwners) instead of L % world: the rows per rank are balanced and the merged shards answer
+    like the unsharded index."""
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import ivf_pq, ivf_pq_sharded as sh
+
+    res = cuvs_amd.common.Resources()
+    rng = np.random.default_rng(11)
+    # very uneven lists: a third of the rows in one tight cluster
+    x = (rng.random((24000, 32), dtype=np.float32) * 1.9 + 0.1)
+    x[:8000] = 1.0 + 0.02 * rng.standard_normal((8000, 32)).astype(np.float32)
+    q = (rng.random((150, 32), dtype=np.float32) * 1.9 + 0.1)
+    xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    ids = torch.arange(len(x), dtype=torch.int64, device="cuda")
+    k, n_probes, world, n_lists = 10, 8, 3, 30
+
+    def params():
+        return ivf_pq.IndexParams(n_lists=n_lists, pq_dim=16, kmeans_n_iters=10, add_data_on_build=False)
+
+    full = ivf_pq.build(params(), xt, resources=res)
+    # every "rank" counts the lists of its slice of the rows; the launcher sums the histograms
+    counts = np.zeros(n_lists, np.uint64)
+    for r in range(world):
+        counts += sh.list_histogram(full, xt[r * 8000:(r + 1) * 8000], resources=res)
+    ivf_pq.extend(full, xt, ids, resources=res)
+    assert (counts == full.list_sizes.cpu().numpy().astype(np.uint64)).all()
+    owners = sh.deal_lists(counts, world)
+    loads = np.array([counts[owners == r].sum() for r in range(world)], dtype=np.float64)
+    modulo = np.array([counts[np.arange(n_lists) % world == r].sum() for r in range(world)], dtype=np.float64)
+    assert loads.max() <= modulo.max()            # never worse than L % world ...
+    assert loads.max() <= max(counts.max(), 1.34 * loads.mean())   # ... and within the LPT bound (4/3 - 1/(3 world))
+    sp = ivf_pq.SearchParams(n_probes=n_probes)
+    fd, fi = ivf_pq.search(sp, full, qt, k, resources=res)
+    res.sync()
+    parts_d, parts_i = [], []
+    for rank in range(world):
+        shard = sh.build(params(), xt, rank, world, owners=owners, resources=res)
+        sh.extend(shard, xt, ids, resources=res)
+        sizes = shard.list_sizes.cpu().numpy()
+        assert (sizes == np.where(owners == rank, counts, 0)).all()
+        d, i = ivf_pq.search(sp, shard, qt, k, resources=res)
+        res.sync()
+        parts_d.append(d.cpu().numpy()); parts_i.append(i.cpu().numpy())
+    md, mi = sh.merge_gathered(parts_d, parts_i, k, True)
+    fd, fi = fd.cpu().numpy(), fi.cpu().numpy()
+    assert (md == fd).all()
+    for qi in range(len(q)):
+        assert sorted(zip(md[qi].tolist(), mi[qi].tolist())) == sorted(zip(fd[qi].tolist(), fi[qi].tolist()))

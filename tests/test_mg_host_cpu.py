@@ -87,3 +87,26 @@ def test_merge_matches_a_numpy_restatement(host, select_min):
         assert [int(v) for v in oi[q]] == [c[1] for c in want], q
         assert [float(v) for v in od[q]] == [c[0] for c in want], q
     assert (oi[0] == big).all() and (oi[1, 3:] == big).all() and (oi[1, :3] < 1000).all()
+
+
+def test_deal_lists_is_lpt_and_deterministic():
+    """cuvsAmdShardDealLists (no GPU needed): greedy longest-processing-time dealing - every list exactly one owner, the
+    heaviest rank within the LPT bound of the mean, the same table for the same weights."""
+    from cuvs_amd.neighbors import ivf_pq_sharded as sh
+
+    rng = np.random.default_rng(3)
+    w = (rng.pareto(1.5, size=4096) * 1000 + 10).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        o1, o2 = sh.deal_lists(w, world), sh.deal_lists(w, world)
+        assert (o1 == o2).all() and o1.min() >= 0 and o1.max() < world
+        loads = np.array([w[o1 == r].sum() for r in range(world)], dtype=np.float64)
+        assert loads.max() <= max(float(w.max()), loads.mean() * (4 / 3))
+        # reference python restatement of the rule
+        order = np.argsort(-w.astype(np.int64), kind="stable")
+        ld = np.zeros(world)
+        want = np.empty(len(w), np.int32)
+        for L in order:
+            r = int(np.argmin(ld))
+            want[L] = r
+            ld[r] += float(w[L])
+        assert (want == o1).all()
