@@ -95,7 +95,7 @@ LUTS = {"f32": np.float32, "f16": np.float16, "fp8": np.uint8}
 
 # ---------------------------------------------------------------------------------------------- PMC passes (rank 0)
 PMC_SETS = [
-    "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES GRBM_GUI_ACTIVE",
+    "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE",
     "FETCH_SIZE",
     "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
 ]
@@ -233,6 +233,8 @@ def extra_c2(res, dev):
     bf_dt = timeit(lambda: brute_force.search(bf, q, 10, resources=res), 2, 1)
     bf_tf = 2 * nq * n * 128 / bf_dt / 1e12
     logical = 64 * (n / 4096) * 512 * nq  # 80 MB of list bytes per query
+    # VALU floor of the scan: every (row, query) pair costs 32 pieces x 8 packed instructions / 8 queries = 32 instructions
+    valu_floor_ms = (logical / 16.0) * 8.0 / 8.0 / 64.0 * 2.79 / (N_SIMD * 2.4e9) * 1e3
     return {"brute_force_same_data": {"config": "brute_force L2 10000000x128 fp32 batch=10000 k=10", "ms": round(bf_dt * 1e3, 1),
                                       "qps": round(nq / bf_dt, 1),
                                       "roofline": {"bound": "mfma", "achieved": round(bf_tf, 1), "peak": MFMA_F32_TFLOPS,
@@ -240,22 +242,26 @@ def extra_c2(res, dev):
             "config": "C2 IVF-Flat 10000000x128 fp32 n_lists=4096 n_probes=64 batch=10000 k=10", "ms": round(dt * 1e3, 3),
             "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
             "kernel": "ivf_flat_scan_kernel", "kernel_ms_per_step": round(scan_ms, 3), "launches_per_step": launches,
-            "roofline": {"bound": "valu", "achieved": round(logical / (scan_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(logical / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "unique_list_bytes": n * 512,
-                         "note": "logical list bytes per kernel second (SURVEY 8d); the lists are re-served from L2 ~156x "
-                                 "(unique bytes 5.12 GB), so the kernel is bound by its packed-fp32 VALU work, not by HBM"}}
+            "roofline": {"bound": "valu", "logical_scan_gbs": round(logical / (scan_ms * 1e-3) / 1e9, 1),
+                         "achieved": round(valu_floor_ms, 3), "peak": round(scan_ms, 3), "unit": "ms (VALU floor / kernel)",
+                         "frac": round(valu_floor_ms / max(scan_ms, 1e-9), 4), "unique_list_bytes": n * 512,
+                         "note": "frac = VALU floor / kernel time: 8 packed-fp32 instructions (4 v_pk_add_f32 + 4 v_pk_fma_f32, "
+                                 "2.79 cycles each, profiles/r03_valu_rate_bench.json) per 16-byte row piece and 8 queries, "
+                                 "over all probed rows, on 1024 SIMDs at 2.4 GHz; the early stop skips part of that work, so "
+                                 "the floor is an upper bound of the useful work. logical_scan_gbs = list bytes per kernel "
+                                 "second (SURVEY 8d): the lists are re-served from L2 ~156x (unique bytes 5.12 GB); "
+                                 "PMC summary of this kernel: profiles/r03_c2_ivf_flat_pmc.txt"}}
 
 
-def extra_c4(res, dev, rows, latent):
+def extra_c4(res, dev, rows, latent, modes=1):
     """C4: CAGRA rows x 768 fp16, graph_degree 64 (intermediate 128), itopk 64, batch 10k, k = 10."""
     from cuvs_amd.neighbors import brute_force, cagra
 
     nq = 10000
     x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
-    gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=1, out=x)
+    gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=modes, out=x)
     q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
-    gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=1, out=q)
+    gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=modes, out=q)
     t0 = time.time()
     idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res)
     res.sync()
@@ -266,6 +272,16 @@ def extra_c4(res, dev, rows, latent):
     _, gt = brute_force.search(bf, q[:1000], 10, resources=res)
     res.sync()
     gt = gt.cpu().numpy()
+    from cuvs_amd._lib import check, lib
+
+    def measured_work(sp):
+        """rows scored / graph rows read / walkers of ONE search of the batch (cuvsAmdCagraWorkCounters)."""
+        out = (C.c_uint64 * 3)()
+        check(lib().cuvsAmdCagraWorkCounters(res.get_c_obj(), 1, out))
+        cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res)
+        check(lib().cuvsAmdCagraWorkCounters(res.get_c_obj(), 0, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     algos = {}
     # the search algorithm is a search parameter (the reference's bench grids sweep it): multi_cta = one workgroup of W
     # waves per query, single_cta = one wave per query; AUTO follows the reference's rule (single_cta at this batch size)
@@ -273,18 +289,24 @@ def extra_c4(res, dev, rows, latent):
         sp = cagra.SearchParams(itopk_size=64, algo=algo)
         t = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 5, 2)
         res.sync()
+        n_dist, n_rows, n_walk = measured_work(sp)
+        bytes_q = (n_dist * 768 * 2 + n_rows * 64 * 4) / nq  # n_dist * dim * sizeof(T) + n_iter * degree * 4
         algos[algo] = {"ms": round(t * 1e3, 3), "qps": round(nq / t, 1),
-                       "recall_at_10": round(recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt), 4)}
+                       "recall_at_10": round(recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt), 4),
+                       "rows_scored_per_query": round(n_dist / nq, 1), "graph_rows_read_per_query": round(n_rows / nq, 1),
+                       "walkers_per_query": round(n_walk / nq, 2), "measured_bytes_per_query": int(bytes_q),
+                       "gathered_gbs": round(bytes_q * nq / t / 1e9, 1)}
     best = max(algos, key=lambda a: algos[a]["qps"] if algos[a]["recall_at_10"] >= 0.9 else 0.0)
     dt, r = algos[best]["ms"] * 1e-3, algos[best]["recall_at_10"]
-    upper = 6.9e6 * nq  # SURVEY 8d upper bound: 6.9 MB of row + graph bytes per query
-    return {"config": f"C4 CAGRA {rows}x768 fp16 graph_degree=64 itopk=64 batch=10000 k=10 algo={best} (data: {latent}-d latent cloud)",
+    gbs = algos[best]["gathered_gbs"]
+    return {"config": f"C4 CAGRA {rows}x768 fp16 graph_degree=64 itopk=64 batch=10000 k=10 algo={best} (data: {latent}-d latent, {modes} modes)",
             "ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
             "algos": algos,
-            "roofline": {"bound": "hbm", "achieved": round(upper / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(upper / dt / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": "upper bound of the gathered bytes (SURVEY 8d: 128 seeds + <=68 iterations x 64 rows of "
-                                 "1536 B) per wall second; the walk is bound by dependent-gather latency"}}
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "note": "MEASURED gathered bytes (rows scored x 1536 B + graph rows read x 256 B, counted in the "
+                                 "kernel: cuvsAmdCagraWorkCounters) per wall second; children already in the visited hash "
+                                 "are not scored, so this is below SURVEY 8d's 6.9 MB/query upper bound"}}
 
 
 # ---------------------------------------------------------------------------------------------------------- main
@@ -475,17 +497,22 @@ def main():
     per_step = max(n_launch, 1) / max(args.steps, 1)
     bytes_per_launch = probe_bytes / per_step
     avg_ms = scan_ms / max(n_launch, 1)
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"bound": "lds", "kernel": "pq_scan_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+    logical = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # `frac` is a real fraction: the busiest pipe's floor (its busy cycles without bank conflicts) over the kernel's
+    # cycles, from the PMC passes below; achieved / peak are that pipe's busy and available cycles per second. The
+    # logical scan rate of SURVEY 8d (code bytes of every probed list per kernel second) is kept as `logical_scan_gbs`:
+    # the list-major schedule serves a list byte from L2 many times per HBM fetch, so that figure exceeds the HBM peak
+    # by design and is no utilisation.
+    roofline = {"bound": None, "kernel": "pq_scan_kernel + pq_scan2_kernel", "achieved": None, "peak": None,
+                "unit": "Gcycles/s", "frac": None, "traffic": None, "logical_scan_gbs": round(logical, 1),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 3),
                 "launches": n_launch, "launches_per_step": per_step, "algorithmic_bytes_per_step": probe_bytes,
                 "kernel_ms_per_step": round(avg_ms * per_step, 3), "early_stop_off_kernel_ms_per_step": early_stop_off_ms,
-                "note": "achieved/frac = SURVEY 8d's LOGICAL figure: code bytes of every probed list per kernel second. "
-                        "The list-major schedule serves a list byte from L2 many times per HBM fetch, so it exceeds the "
-                        "HBM peak by design and is not a utilisation. The physical fractions are hbm_frac (measured HBM "
-                        "bytes/s / 8 TB/s), lds_busy (LDS array cycles / cycles), lds_gather_frac (LDS wave-instructions "
-                        "x 2 clk / cycles: the conflict-free issue floor), valu_busy; `bound` = the busiest pipe"}
+                "note": "frac = floor / kernel: busy cycles of the busiest pipe (VALU issue cycles, or LDS array cycles minus "
+                        "bank-conflict cycles, or HBM bytes / 8 TB/s) over the kernel's cycles, all from rocprofv3 PMC passes "
+                        "of this workload (GRBM_GUI_ACTIVE, SQ_ACTIVE_INST_VALU, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, "
+                        "FETCH_SIZE x 2 + WRITE_SIZE). The per-instruction ceilings behind the floors are microbenchmarked "
+                        "in profiles/r03_lds_gather_bench.json and profiles/r03_valu_rate_bench.json"}
     if rank == 0 and world == 1 and not args.no_pmc:
         t0 = time.time()
         child = ["--rows", str(args.rows), "--dim", str(args.dim), "--n-lists", str(args.n_lists), "--n-probes",
@@ -505,23 +532,31 @@ def main():
                   "lds_gather_frac": pmc.get("SQ_INSTS_LDS", 0.0) * 2.0 / (cycles * N_CU),
                   "valu_busy": pmc.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (cycles * N_SIMD),
                   "tcc_hit_rate": pmc.get("TCC_HIT_sum", 0.0) / max(pmc.get("TCC_HIT_sum", 0.0) + pmc.get("TCC_MISS_sum", 0.0), 1.0)}
+            fr["lds_floor"] = fr["lds_busy"] * (1.0 - fr["lds_bank_conflict_share"])  # conflict-free LDS array cycles
+            fr["valu_insts_per_step"] = pmc.get("SQ_INSTS_VALU", 0.0)
+            fr["lds_insts_per_step"] = pmc.get("SQ_INSTS_LDS", 0.0)
             roofline.update({k: round(v, 4) for k, v in fr.items()})
             roofline["traffic"] = int(hbm_bytes / per_step)
             roofline["hbm_bytes_per_step"] = int(hbm_bytes)
             roofline["pmc_cycles_per_step"] = int(cycles)
             roofline["pmc_kernel_ms_at_2p4ghz"] = round(kernel_s * 1e3, 3)
-            roofline["bound"] = max((("lds", fr["lds_busy"]), ("valu", fr["valu_busy"]), ("hbm", fr["hbm_frac"])),
-                                    key=lambda t: t[1])[0]
+            bound, frac = max((("lds", fr["lds_floor"]), ("valu", fr["valu_busy"]), ("hbm", fr["hbm_frac"])), key=lambda t: t[1])
+            roofline["bound"], roofline["frac"] = bound, round(frac, 4)
+            clock_ghz = cycles / max(t_ref, 1e-9) / 1e9  # effective clock of the profiled cycles over the un-profiled time
+            pipes = {"valu": N_SIMD, "lds": N_CU, "hbm": 1}[bound]
+            roofline["peak"] = round(pipes * clock_ghz, 1) if bound != "hbm" else HBM_PEAK_GBS
+            roofline["achieved"] = round(frac * roofline["peak"], 1)
+            roofline["unit"] = "Gcycles/s" if bound != "hbm" else "GB/s"
             roofline["pmc_source"] = "live: rocprofv3 --pmc passes of this workload, spawned by this run"
     if roofline["traffic"] is None:
-        tfile = os.path.join(ROOT, "profiles", "r02_pq_scan_pmc.json")
+        tfile = os.path.join(ROOT, "profiles", "r03_pq_scan_pmc.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                roofline.update({k: tj[k] for k in ("hbm_frac", "lds_busy", "lds_bank_conflict_share", "lds_gather_frac",
-                                                    "valu_busy", "tcc_hit_rate", "bound") if k in tj})
+                roofline.update({k: tj[k] for k in ("hbm_frac", "lds_busy", "lds_bank_conflict_share", "lds_gather_frac", "lds_floor",
+                                                    "valu_busy", "tcc_hit_rate", "bound", "frac", "achieved", "peak", "unit") if k in tj})
                 roofline["traffic"] = int(tj["hbm_bytes_per_step"] / per_step) if "hbm_bytes_per_step" in tj else None
-                roofline["pmc_source"] = "profiles/r02_pq_scan_pmc.json (committed PMC passes of the same command)"
+                roofline["pmc_source"] = "profiles/r03_pq_scan_pmc.json (committed PMC passes of the same command)"
             except Exception:
                 pass
 

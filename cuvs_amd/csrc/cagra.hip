@@ -394,6 +394,10 @@ struct search_args {
   uint64_t rand_xor_mask;
   int is_ip, idx64;    // is_ip: 0 L2, 1 inner product, 2 cosine (1 - q.x / (|q| |x|), |x| from `norms`)
   const float* norms;  // [n] canonical |x| (cosine)
+  // optional work counters (cuvsAmdCagraWorkCounters; SURVEY 8d: bytes(q) = n_dist * dim * sizeof(T) + n_iter * degree * 4
+  // with n_dist, n_iter MEASURED): [0] rows scored, [1] walk iterations (graph rows read), [2] walkers (waves). One atomic
+  // per wave and counter at the end of the walk; nullptr: not counted.
+  unsigned long long* work = nullptr;
 };
 
 __device__ inline uint32_t hash_slot(uint32_t key, uint32_t bits) { return (key ^ (key >> bits)) & ((1u << bits) - 1u); }
@@ -424,7 +428,7 @@ __device__ inline uint64_t xorshift64(uint64_t u)
 // Arithmetic (oracle twin: oracle_cagra.c): team lane t accumulates the elements of its 16-byte pieces in
 // order with fmaf, then the 8 partial sums are combined by the xor butterfly (1, 2, 4).
 template <typename T>
-__device__ inline void team_distances(const T* __restrict__ data, int64_t dim, const float* __restrict__ qf,
+__device__ inline uint32_t team_distances(const T* __restrict__ data, int64_t dim, const float* __restrict__ qf,
                                       uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, uint32_t first,
                                       uint32_t count, int is_ip, int lane, const float* __restrict__ norms = nullptr,
                                       float qn = 1.f)
@@ -432,10 +436,12 @@ __device__ inline void team_distances(const T* __restrict__ data, int64_t dim, c
   constexpr int VL = 16 / sizeof(T);
   const int team = lane >> 3, tl = lane & 7;
   const bool vec = (dim % VL == 0) && ((reinterpret_cast<uintptr_t>(data) & 15) == 0);
+  uint32_t n_scored = 0u;  // rows whose distance was computed (children already in the hash are skipped)
   for (uint32_t c0 = 0; c0 < count; c0 += 8) {
     const uint32_t c    = c0 + team;
     const uint32_t node = c < count ? (idx[first + c] & ~kParentFlag) : kInvalidNode;
     const bool ok       = c < count && idx[first + c] != kInvalidNode;
+    n_scored += (uint32_t)__popcll(__ballot(ok && tl == 0));
     float acc           = 0.f;
     if (ok) {
       const T* row = data + (int64_t)node * dim;
@@ -493,6 +499,7 @@ __device__ inline void team_distances(const T* __restrict__ data, int64_t dim, c
     if (is_ip == 2 && ok) acc = 1.0f - acc / (qn * norms[node]);  // the brute-force cosine epilogue
     if (tl == 0 && c < count) keys[first + c] = ok ? float_to_key(is_ip == 1 ? -acc : acc) : 0xffffffffu;
   }
+  return n_scored;
 }
 
 __device__ inline float wave_query_norm(const float* qf, int64_t dim, int lane)
@@ -534,7 +541,8 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  team_distances<T>(data, a.dim, qf, keys, idx, 0, a.itopk, a.is_ip, lane, a.norms, qn);
+  uint32_t n_dist = team_distances<T>(data, a.dim, qf, keys, idx, 0, a.itopk, a.is_ip, lane, a.norms, qn);
+  uint32_t n_rows_read = 0u;  // graph rows read (parents expanded)
 
   const uint32_t n_cand = a.width * a.degree;
   uint32_t iter         = 0;
@@ -582,8 +590,14 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    team_distances<T>(data, a.dim, qf, keys, idx, a.itopk, n_cand, a.is_ip, lane, a.norms, qn);
+    n_dist += team_distances<T>(data, a.dim, qf, keys, idx, a.itopk, n_cand, a.is_ip, lane, a.norms, qn);
+    n_rows_read += n_parents;
     ++iter;
+  }
+  if (a.work != nullptr && lane == 0) {
+    atomicAdd(&a.work[0], (unsigned long long)n_dist);
+    atomicAdd(&a.work[1], (unsigned long long)n_rows_read);
+    atomicAdd(&a.work[2], 1ull);
   }
 
   // ---- results: first k entries of the sorted list that pass the filter
@@ -701,7 +715,8 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  team_distances<T>(data, a.dim, qf, keys, idx, 0, kMwTopk, a.is_ip, lane, a.norms, qn);
+  uint32_t n_dist = team_distances<T>(data, a.dim, qf, keys, idx, 0, kMwTopk, a.is_ip, lane, a.norms, qn);
+  uint32_t n_rows_read = 0u;
 
   uint32_t iter = 0;
   while (true) {
@@ -776,7 +791,8 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    team_distances<T>(data, a.dim, qf, keys, idx, kMwTopk, a.degree, a.is_ip, lane, a.norms, qn);
+    n_dist += team_distances<T>(data, a.dim, qf, keys, idx, kMwTopk, a.degree, a.is_ip, lane, a.norms, qn);
+    n_rows_read += parent != kInvalidNode ? 1u : 0u;
     // ---- drop what another wave has expanded meanwhile; a parent that fails the filter leaves the list
     for (uint32_t i = lane; i < np2; i += 64) {
       const uint32_t e = idx[i];
@@ -794,6 +810,11 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
     ++iter;
   }
 
+  if (a.work != nullptr && lane == 0) {
+    atomicAdd(&a.work[0], (unsigned long long)n_dist);
+    atomicAdd(&a.work[1], (unsigned long long)n_rows_read);
+    atomicAdd(&a.work[2], 1ull);
+  }
   // ---- this wave's 32 results: parents are unique by construction, the others must win the traversed table
   // (duplicates across waves lose); filtered-out nodes are dropped
   {
@@ -1001,6 +1022,7 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   a.rand_xor_mask  = p.rand_xor_mask;
   a.is_ip          = idx.metric == M_InnerProduct ? 1 : (idx.metric == M_CosineExpanded ? 2 : 0);
   a.norms          = idx.norms.data();
+  a.work           = res.cagra_work;
   CUVS_EXPECTS(a.is_ip != 2 || a.norms != nullptr, "cagra::search: cosine index without dataset norms");
   a.idx64          = idx64 ? 1 : 0;
   // ---- algorithm choice: AUTO follows the reference (search_plan.cuh:121-131: one walker per query once the batch
@@ -1630,6 +1652,30 @@ cuvsError_t cuvsCagraMerge(cuvsResources_t res_h, cuvsCagraIndexParams_t params,
 
 }  // extern "C"
 
+
+// Measured work of the graph walks run on this handle (CAGRA bytes(q) = n_dist * dim * sizeof(T) + n_iter *
+// degree * 4 with n_dist and n_iter measured; the reference has its per-phase _CLK_BREAKDOWN counters,
+// search_single_cta_jit.cuh:91-103,425-451). enable != 0: zero the counters and count from now on; enable == 0: stop and
+// return {rows scored, graph rows read, walkers} of the searches since (include/cuvs_amd/extensions.h).
+extern "C" __attribute__((visibility("default"))) cuvsError_t cuvsAmdCagraWorkCounters(cuvsResources_t res_h, int enable,
+                                                                                       uint64_t out[3])
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *cuvs_amd::as_res(res_h);
+    if (enable) {
+      if (res.cagra_work == nullptr) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&res.cagra_work), 3 * sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(res.cagra_work, 0, 3 * sizeof(unsigned long long), res.stream));
+      return;
+    }
+    CUVS_EXPECTS(res.cagra_work != nullptr && out != nullptr, "cagra work counters were not enabled on this handle");
+    unsigned long long h[3];
+    HIP_TRY(hipMemcpyAsync(h, res.cagra_work, sizeof(h), hipMemcpyDeviceToHost, res.stream));
+    HIP_TRY(hipStreamSynchronize(res.stream));
+    for (int i = 0; i < 3; ++i) out[i] = h[i];
+    (void)hipFree(res.cagra_work);
+    res.cagra_work = nullptr;
+  });
+}
 
 // Test hook (not part of the reference ABI): the search plan for given parameters, computed on the host without
 // touching a GPU - tests pin it to the reference's rules (search_plan.cuh:121-131,199-340).

@@ -185,6 +185,7 @@ cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
       (void)hipStreamDestroy(r->aux_stream);
       for (auto& e : r->aux_events) if (e != nullptr) (void)hipEventDestroy(e);
     }
+    if (r->cagra_work != nullptr) (void)hipFree(r->cagra_work);
     if (r->pool != nullptr) (void)hipMemPoolDestroy(r->pool);
     if (r->owns_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;

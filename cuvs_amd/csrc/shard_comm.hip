@@ -100,6 +100,20 @@ __global__ void regroup_kernel(const char* __restrict__ gathered, int64_t nq, in
   ids[o]           = id;
 }
 
+// local row ids of a row-range shard -> global ids (snmg.cuh:420-429); slots without a neighbour (0xffffffff from the
+// CAGRA walk, negative or INT64_MAX elsewhere) become INT64_MAX, the id the merge treats as "no candidate"
+template <typename IdT>
+__global__ void translate_ids_kernel(const IdT* __restrict__ in, int64_t n, int64_t row_offset, int64_t* __restrict__ out)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const IdT v = in[t];
+  bool invalid;
+  if constexpr (sizeof(IdT) == 4) invalid = v == (IdT)0xffffffffu;
+  else                            invalid = v < 0 || v == INT64_MAX;
+  out[t] = invalid ? INT64_MAX : (int64_t)v + row_offset;
+}
+
 __global__ void pad_invalid_kernel(float* __restrict__ d, const int64_t* __restrict__ i, int64_t n)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,6 +285,24 @@ cuvsError_t cuvsAmdIvfPqSetShardComm(cuvsIvfPqIndex_t index, cuvsAmdShardComm_t 
                  "shard communicator (rank %d of %d) does not match the index's list shard (rank %d of %d)",
                  comm ? comm->rank : 0, comm ? comm->world : 0, idx.shard_rank, idx.shard_world);
     idx.shard_comm = comm;
+  });
+}
+
+cuvsError_t cuvsAmdShardTranslateIds(cuvsResources_t res_h, const void* local_ids, int id_bits, int64_t n, int64_t row_offset,
+                                     int64_t* global_ids)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(id_bits == 32 || id_bits == 64, "translate ids: id_bits must be 32 (uint32) or 64 (int64)");
+    if (n == 0) return;
+    CUVS_EXPECTS(local_ids != nullptr && global_ids != nullptr, "translate ids: null argument");
+    if (id_bits == 32)
+      hipLaunchKernelGGL(translate_ids_kernel<uint32_t>, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream,
+                         static_cast<const uint32_t*>(local_ids), n, row_offset, global_ids);
+    else
+      hipLaunchKernelGGL(translate_ids_kernel<int64_t>, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream,
+                         static_cast<const int64_t*>(local_ids), n, row_offset, global_ids);
+    HIP_TRY(hipGetLastError());
   });
 }
 

@@ -23,6 +23,12 @@ CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSearchFiltered(cuvsResources_t res, cuvsIvfP
                                                    DLManagedTensor* neighbors, DLManagedTensor* distances,
                                                    cuvsFilter filter);
 
+/* Measured work of the CAGRA graph walks run on `res` (the hot path's algorithmic bytes per query are n_dist * dim *
+ * sizeof(T) + n_iter * graph_degree * 4 with n_dist, n_iter measured; the reference keeps per-phase clock counters,
+ * cpp/src/neighbors/detail/cagra/search_single_cta_jit.cuh:91-103,425-451). enable != 0 zeroes the counters and starts
+ * counting; enable == 0 stops and fills out = {rows whose distance was computed, graph rows read, walkers (waves)}. */
+CUVS_EXPORT cuvsError_t cuvsAmdCagraWorkCounters(cuvsResources_t res, int enable, uint64_t out[3]);
+
 #ifdef __cplusplus
 }
 #endif

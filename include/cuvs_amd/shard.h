@@ -59,6 +59,15 @@ CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetListOwners(cuvsIvfPqIndex_t index, const 
  * every rank must make the same searches. comm = NULL detaches. */
 CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetShardComm(cuvsIvfPqIndex_t index, cuvsAmdShardComm_t comm);
 
+/* Row-range shards (the reference's SHARDED mode, cpp/src/neighbors/mg/snmg.cuh:128-166 build, :248-375 search, any
+ * index type: IVF-Flat, IVF-PQ, CAGRA, brute force): every rank builds a complete index over its rows, searches all
+ * queries, translates its local row ids to global ones ON THE DEVICE - cuvsAmdShardTranslateIds: local_ids [n] uint32
+ * (id_bits 32, the CAGRA output) or int64 (id_bits 64) -> global_ids [n] int64 = id + row_offset, empty slots ->
+ * INT64_MAX (snmg.cuh:420-429) - and the [n_queries, k] blocks go through cuvsAmdShardAllGatherTopK: one ncclAllGather
+ * instead of the reference's ncclSend/ncclRecv fan-in (:298-340) or merge tree (:439-475). */
+CUVS_EXPORT cuvsError_t cuvsAmdShardTranslateIds(cuvsResources_t res, const void* local_ids, int id_bits, int64_t n,
+                                                 int64_t row_offset, int64_t* global_ids);
+
 /* Collective on the stream of `res`. local_distances [n_queries, k] float32 and local_neighbors [n_queries, k] int64
  * (device; the output of the rank's cuvsIvfPqSearch, invalid slots = FLT_MAX / INT64_MAX as the reference pads them) ->
  * distances / neighbors [n_queries, k] (device): the k best of the world * k candidates of every query, ordered by
