@@ -209,19 +209,43 @@ __global__ void append_reverse_kernel(const uint32_t* __restrict__ perm, const u
   rev_cnt[nid] = c + take;
 }
 
-// kern_merge_graph restated (no MST): keep the first degree/2 forward edges, insert reverse edges behind them.
+// kern_merge_graph restated: the protected head of a row is its spanning-forest edges (guarantee_connectivity; mst ==
+// nullptr otherwise) followed by the pruned edges not among them, at least degree/2 entries; reverse edges are inserted
+// behind the protected head.
 __global__ __launch_bounds__(256) void merge_graph_kernel(uint32_t* __restrict__ g, int64_t n, uint32_t degree,
                                                           const uint32_t* __restrict__ rev,
-                                                          const uint32_t* __restrict__ rev_cnt, int64_t nid0)
+                                                          const uint32_t* __restrict__ rev_cnt, int64_t nid0,
+                                                          const uint32_t* __restrict__ mst,
+                                                          const uint32_t* __restrict__ mst_cnt)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* row  = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * degree;
   const int64_t nid = nid0 + (int64_t)blockIdx.x * 4 + wave;
   if (nid >= n) return;
-  for (uint32_t i = lane; i < degree; i += 64) row[i] = g[nid * degree + i];
-  __builtin_amdgcn_wave_barrier();
-  const uint32_t prot = degree / 2;
+  uint32_t n_mst = 0;
+  if (mst != nullptr) {
+    n_mst = min(mst_cnt[nid], degree);
+    for (uint32_t i = lane; i < n_mst; i += 64) row[i] = mst[nid * degree + i];
+    __builtin_amdgcn_wave_barrier();
+    uint32_t out = n_mst;
+    for (uint32_t pj = 0; pj < degree && out < degree; ++pj) {
+      const uint32_t v = g[nid * degree + pj];
+      bool dup = false;
+      for (uint32_t m = lane; m < out; m += 64) dup |= row[m] == v;
+      if (__ballot(dup) == 0) {
+        if (lane == 0) row[out] = v;
+        ++out;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    for (uint32_t i = out + lane; i < degree; i += 64) row[i] = kInvalidNode;
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    for (uint32_t i = lane; i < degree; i += 64) row[i] = g[nid * degree + i];
+    __builtin_amdgcn_wave_barrier();
+  }
+  const uint32_t prot = max(n_mst, degree / 2);
   if (prot < degree) {
     uint32_t kr = min(rev_cnt[nid], degree);
     while (kr) {
@@ -335,8 +359,9 @@ void knn_graph_ivf_pq(resources& res, const void* data, elem_t et, int64_t n, in
   sync(res);
 }
 
-// graph::optimize (graph_core.cuh:1706-1809) without the MST step
-void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, uint32_t degree, uint32_t* graph)
+// graph::optimize (graph_core.cuh:1706-1809); guarantee_connectivity adds the spanning-forest pass of cagra_mst.hip
+void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, uint32_t degree, uint32_t* graph,
+                    bool guarantee_connectivity)
 {
   CUVS_EXPECTS(degree <= K, "graph_degree (%u) must not exceed intermediate_graph_degree (%u)", degree, K);
   CUVS_EXPECTS(degree <= 256 && K <= 1024, "cagra: degree <= 256 and intermediate degree <= 1024 supported");
@@ -365,6 +390,14 @@ void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, 
   uint32_t ranks = (uint32_t)std::min<int64_t>(degree, std::max<int64_t>(1, ((int64_t(1) << 32) - 1024) / n));
   if (res.tune.cagra_rank_chunk > 0) ranks = (uint32_t)std::min<int>(res.tune.cagra_rank_chunk, (int)degree);
   const int64_t chunk_edges = n * (int64_t)ranks;
+  dev_buf<uint32_t> mst, mst_cnt;
+  if (guarantee_connectivity) {
+    mst     = dev_buf<uint32_t>(res, (size_t)n * degree);
+    mst_cnt = dev_buf<uint32_t>(res, n);
+    const int64_t left = cagra_mst_optimize(res, knn, n, K, degree, mst.data(), mst_cnt.data());
+    if (left > 1)
+      fprintf(stderr, "[cuvs_amd] cagra: guarantee_connectivity left %lld components (rows out of protected slots)\n", (long long)left);
+  }
   dev_buf<uint32_t> dest(res, chunk_edges), perm(res, chunk_edges), off(res, n + 2), rev(res, (size_t)n * degree), rev_cnt(res, n);
   HIP_TRY(hipMemsetAsync(rev_cnt.data(), 0, rev_cnt.bytes(), res.stream));
   for (uint32_t r0 = 0; r0 < degree; r0 += ranks) {
@@ -377,7 +410,8 @@ void optimize_graph(resources& res, const uint32_t* knn, int64_t n, uint32_t K, 
   }
   for (int64_t r0 = 0; r0 < n; r0 += slab)
     hipLaunchKernelGGL(merge_graph_kernel, dim3(grid_blocks(std::min(slab, n - r0), 4)), dim3(256),
-                       (size_t)4 * degree * sizeof(uint32_t), res.stream, graph, n, degree, rev.data(), rev_cnt.data(), r0);
+                       (size_t)4 * degree * sizeof(uint32_t), res.stream, graph, n, degree, rev.data(), rev_cnt.data(), r0,
+                       (const uint32_t*)mst.data(), (const uint32_t*)mst_cnt.data());
   HIP_TRY(hipGetLastError());
 }
 
@@ -1197,7 +1231,7 @@ std::unique_ptr<cagra_index> cagra_build(resources& res, const cuvsCagraIndexPar
     knn_graph_ivf_pq(res, idx->data, et, n, dim, K, metric, knn.data());
   }
   idx->graph = dev_buf<uint32_t>::persistent((size_t)n * degree);
-  optimize_graph(res, knn.data(), n, K, degree, idx->graph.data());
+  optimize_graph(res, knn.data(), n, K, degree, idx->graph.data(), res.cagra_guarantee_connectivity);
   cagra_set_norms(res, *idx);
   sync(res);
   return idx;
@@ -1674,6 +1708,51 @@ extern "C" __attribute__((visibility("default"))) cuvsError_t cuvsAmdCagraWorkCo
     for (int i = 0; i < 3; ++i) out[i] = h[i];
     (void)hipFree(res.cagra_work);
     res.cagra_work = nullptr;
+  });
+}
+
+// cagra::index_params::guarantee_connectivity (cpp/include/cuvs/neighbors/cagra.hpp:193) has no field in the C struct
+// cuvsCagraIndexParams (c/include/cuvs/neighbors/cagra.h): the switch lives on the handle and applies to the
+// cuvsCagraBuild / cuvsCagraExtend calls made with it (include/cuvs_amd/extensions.h).
+extern "C" __attribute__((visibility("default"))) cuvsError_t cuvsAmdCagraSetGuaranteeConnectivity(cuvsResources_t res_h, int on)
+{
+  return (cuvsError_t)translate_exceptions([=] { cuvs_amd::as_res(res_h)->cagra_guarantee_connectivity = on != 0; });
+}
+
+// cagra::helpers::optimize (cpp/include/cuvs/neighbors/cagra_optimize.hpp; graph_core.cuh:1706-1809): kNN graph
+// [n, K] uint32 (host or device) -> search graph [n, degree] uint32 (host or device); components_left (optional):
+// connected components of the spanning forest (1 when guarantee_connectivity succeeded, 0 when it was not asked for).
+extern "C" __attribute__((visibility("default"))) cuvsError_t cuvsAmdCagraOptimize(cuvsResources_t res_h,
+                                                                                   DLManagedTensor* knn_tensor,
+                                                                                   DLManagedTensor* graph_tensor,
+                                                                                   int guarantee_connectivity)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    using namespace cuvs_amd;
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(knn_tensor && graph_tensor, "null argument");
+    auto& kg = knn_tensor->dl_tensor;
+    auto& g  = graph_tensor->dl_tensor;
+    CUVS_EXPECTS(dtype_is(kg.dtype, kDLUInt, 32) && kg.ndim == 2 && is_c_contiguous(kg), "knn_graph must be uint32 [n, K]");
+    CUVS_EXPECTS(dtype_is(g.dtype, kDLUInt, 32) && g.ndim == 2 && is_c_contiguous(g) && g.shape[0] == kg.shape[0],
+                 "graph must be uint32 [n, degree]");
+    const int64_t n = kg.shape[0];
+    const uint32_t K = (uint32_t)kg.shape[1], degree = (uint32_t)g.shape[1];
+    dev_buf<uint32_t> knn_d, g_d;
+    const uint32_t* knn = static_cast<const uint32_t*>(dl_data(kg));
+    if (!is_device_accessible(kg)) {
+      knn_d = dev_buf<uint32_t>(res, (size_t)n * K);
+      copy_async(res, knn_d.data(), knn, knn_d.bytes());
+      knn = knn_d.data();
+    }
+    uint32_t* out = static_cast<uint32_t*>(dl_data(g));
+    if (!is_device_accessible(g)) {
+      g_d = dev_buf<uint32_t>(res, (size_t)n * degree);
+      out = g_d.data();
+    }
+    optimize_graph(res, knn, n, K, degree, out, guarantee_connectivity != 0);
+    if (!is_device_accessible(g)) copy_async(res, dl_data(g), out, (size_t)n * degree * sizeof(uint32_t));
+    sync(res);
   });
 }
 

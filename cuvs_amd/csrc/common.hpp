@@ -104,6 +104,7 @@ struct resources {
   hipMemPool_t pool       = nullptr;          // the handle's own stream-ordered pool (scratch buffers stay cached in it)
   hipStream_t aux_stream  = nullptr;          // helper stream + events for two-stream pipelines (brute force), made on first use
   hipEvent_t aux_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool cagra_guarantee_connectivity = false;  // cuvsAmdCagraSetGuaranteeConnectivity (cagra.hpp:193 has no C field)
   unsigned long long* cagra_work = nullptr;   // device [3]: rows scored / graph rows read / walkers (cuvsAmdCagraWorkCounters)
 };
 

@@ -93,6 +93,12 @@ void knn_graph_nn_descent(resources& res, const void* data, elem_t et, int64_t n
                           const float* norms, int n_iters, uint32_t* knn, uint32_t* keys_out = nullptr,
                           float termination_threshold = 1e-4f);
 
+// ---------------------------------------------------------------- cagra_mst.hip
+// graph::optimize's guarantee_connectivity pass: protected spanning-forest edges per node (front-packed rows of `mst`
+// [n, degree], counts in mst_cnt [n]); returns the number of connected components left (1 on success).
+int64_t cagra_mst_optimize(resources& res, const uint32_t* knn, int64_t n, uint32_t K, uint32_t degree, uint32_t* mst,
+                           uint32_t* mst_cnt);
+
 // ---------------------------------------------------------------- refine.hip
 // exact re-ranking of candidate ids; out sorted by (distance, id). All pointers device.
 void refine(resources& res, const void* data, elem_t et, int64_t n, int64_t dim, const void* queries, int64_t m,

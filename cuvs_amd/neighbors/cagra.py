@@ -52,7 +52,10 @@ _BUILD_ALGOS = {"auto": 0, "ivf_pq": 1, "nn_descent": 2, "iterative_cagra_search
 
 class IndexParams:
     def __init__(self, *, metric="sqeuclidean", intermediate_graph_degree=128, graph_degree=64, build_algo="ivf_pq",
-                 nn_descent_niter=20):
+                 nn_descent_niter=20, guarantee_connectivity=False):
+        # guarantee_connectivity: cagra::index_params::guarantee_connectivity (cagra.hpp:193; C++-only in the reference,
+        # here a switch on the handle: cuvsAmdCagraSetGuaranteeConnectivity)
+        self.guarantee_connectivity = bool(guarantee_connectivity)
         self._p = C.POINTER(_CIndexParams)()
         check(lib().cuvsCagraIndexParamsCreate(C.byref(self._p)))
         p = self._p.contents
@@ -135,7 +138,11 @@ def build(index_params, dataset, resources=None):
     idx = Index()
     t = Tensor(ds)
     index_params._p.contents.build_algo = max(index_params._algo, 1) if index_params._algo != 3 else 3
-    check(lib().cuvsCagraBuild(resources.get_c_obj(), index_params._p, t.ptr, idx._p))
+    check(lib().cuvsAmdCagraSetGuaranteeConnectivity(resources.get_c_obj(), C.c_int(int(index_params.guarantee_connectivity))))
+    try:
+        check(lib().cuvsCagraBuild(resources.get_c_obj(), index_params._p, t.ptr, idx._p))
+    finally:
+        lib().cuvsAmdCagraSetGuaranteeConnectivity(resources.get_c_obj(), C.c_int(0))
     index_params._p.contents.build_algo = 1  # keep Destroy's graph_build_params bookkeeping valid
     idx._keep = ds  # the index views a device dataset
     idx.trained = True
@@ -161,6 +168,20 @@ def extend(index, additional_dataset, max_chunk_size=0, resources=None):
         lib().cuvsCagraExtendParamsDestroy(p)
     index._keep = None
     return index
+
+
+@auto_sync_resources
+def optimize(knn_graph, graph_degree, guarantee_connectivity=False, resources=None):
+    """cuvs::neighbors::cagra::helpers::optimize (cagra_optimize.hpp): kNN graph [n, K] uint32 -> search graph
+    [n, graph_degree] uint32 on the device (cuvsAmdCagraOptimize)."""
+    g = knn_graph if isinstance(knn_graph, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(knn_graph).astype(np.uint32).view(np.int32))
+    g = g.contiguous().to(torch.int32)
+    out = torch.empty((g.shape[0], graph_degree), dtype=torch.int32, device="cuda")
+    tk, to = Tensor(g), Tensor(out)
+    tk.m.dl_tensor.dtype.code = 1  # uint32
+    to.m.dl_tensor.dtype.code = 1
+    check(lib().cuvsAmdCagraOptimize(resources.get_c_obj(), tk.ptr, to.ptr, C.c_int(int(guarantee_connectivity))))
+    return out
 
 
 @auto_sync_resources

@@ -29,6 +29,18 @@ CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSearchFiltered(cuvsResources_t res, cuvsIvfP
  * counting; enable == 0 stops and fills out = {rows whose distance was computed, graph rows read, walkers (waves)}. */
 CUVS_EXPORT cuvsError_t cuvsAmdCagraWorkCounters(cuvsResources_t res, int enable, uint64_t out[3]);
 
+/* cagra::index_params::guarantee_connectivity (cpp/include/cuvs/neighbors/cagra.hpp:193; the spanning-forest pass of
+ * graph::optimize, cpp/src/neighbors/detail/cagra/graph_core.cuh:1186-1581,1747-1760) is C++-only in the reference: the C
+ * struct cuvsCagraIndexParams has no such field. The switch is kept on the handle and applies to every cuvsCagraBuild
+ * made with it. */
+CUVS_EXPORT cuvsError_t cuvsAmdCagraSetGuaranteeConnectivity(cuvsResources_t res, int on);
+
+/* cuvs::neighbors::cagra::helpers::optimize (cpp/include/cuvs/neighbors/cagra_optimize.hpp): kNN graph [n, K] uint32 ->
+ * search graph [n, degree] uint32 (prune by 2-hop detours, reverse edges, optional connectivity guarantee). Either
+ * tensor may live on the host or on the device. */
+CUVS_EXPORT cuvsError_t cuvsAmdCagraOptimize(cuvsResources_t res, DLManagedTensor* knn_graph, DLManagedTensor* graph,
+                                             int guarantee_connectivity);
+
 #ifdef __cplusplus
 }
 #endif

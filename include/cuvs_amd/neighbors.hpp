@@ -294,6 +294,7 @@ struct index_params {  // cagra.hpp:84-200
   size_t graph_degree              = 64;
   cuvsCagraGraphBuildAlgo build_algo = IVF_PQ;
   size_t nn_descent_niter          = 20;
+  bool guarantee_connectivity      = false;  // cagra.hpp:193 (handle switch here: cuvsAmdCagraSetGuaranteeConnectivity)
 };
 enum class search_algo { SINGLE_CTA = 0, MULTI_CTA = 1, MULTI_KERNEL = 2, AUTO = 100 };
 struct search_params {  // cagra.hpp:203-360
@@ -337,7 +338,10 @@ index<T> build(const resources& res, const index_params& p, device_matrix_view<c
   cp.p->graph_degree = p.graph_degree; cp.p->build_algo = p.build_algo; cp.p->nn_descent_niter = p.nn_descent_niter;
   index<T> idx;
   detail::tensor<const T> d(dataset);
-  check(cuvsCagraBuild(res.get(), cp.p, d.get(), idx.get()), "cuvsCagraBuild");
+  check(cuvsAmdCagraSetGuaranteeConnectivity(res.get(), p.guarantee_connectivity ? 1 : 0), "cuvsAmdCagraSetGuaranteeConnectivity");
+  const cuvsError_t rc = cuvsCagraBuild(res.get(), cp.p, d.get(), idx.get());
+  cuvsAmdCagraSetGuaranteeConnectivity(res.get(), 0);
+  check(rc, "cuvsCagraBuild");
   return idx;
 }
 // neighbors: uint32_t (the reference's index type) or int64_t

@@ -228,6 +228,30 @@ def cagra_search(dataset, graph, queries, k, itopk_size=64, search_width=1, max_
     return od, oi
 
 
+def cagra_optimize(knn_graph, graph_degree, guarantee_connectivity=False):
+    """CPU twin of graph::optimize (oracle_cagra_optimize.c). Returns (graph [n, degree] uint32, components left by the
+    connectivity pass - 0 when it was not asked for)."""
+    g = np.ascontiguousarray(knn_graph, dtype=np.uint32)
+    n, K = g.shape
+    out = np.empty((n, graph_degree), np.uint32)
+    fn = lib().oracle_cagra_optimize
+    fn.restype = C.c_int64
+    left = fn(_p(g), C.c_int64(n), C.c_uint32(K), C.c_uint32(graph_degree), C.c_int(int(guarantee_connectivity)), _p(out))
+    return out, int(left)
+
+
+def cagra_mst(knn_graph, graph_degree):
+    """The spanning forest alone: (rows [n, degree] front-packed with 0xffffffff fillers, counts [n], components left)."""
+    g = np.ascontiguousarray(knn_graph, dtype=np.uint32)
+    n, K = g.shape
+    mst = np.empty((n, graph_degree), np.uint32)
+    cnt = np.empty(n, np.uint32)
+    fn = lib().oracle_cagra_mst
+    fn.restype = C.c_int64
+    left = fn(_p(g), C.c_int64(n), C.c_uint32(K), C.c_uint32(graph_degree), _p(mst), _p(cnt))
+    return mst, cnt, int(left)
+
+
 def kmeans_balanced_fit(x, n_clusters, n_iters=20, hierarchical=True):
     """CPU twin of the balanced k-means (cuvs_amd/csrc/kmeans_balanced.hip). Returns (centers, labels)."""
     x = _f32(x)
