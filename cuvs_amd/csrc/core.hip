@@ -96,6 +96,8 @@ tuning load_tuning_from_env()
   auto set  = [](const char* name) { return getenv(name) != nullptr; };
   t.pq_head_probes   = geti("CUVS_AMD_PQ_HEAD_PROBES", -1);
   t.pq_scan2         = geti("CUVS_AMD_PQ_SCAN2", 1);
+  t.pq_scan3         = geti("CUVS_AMD_PQ_SCAN3", 1);
+  t.pq3_surv_cap     = geti("CUVS_AMD_PQ3_SURV_CAP", 0);
   t.pq_qcap          = geti("CUVS_AMD_PQ_QCAP", 0);
   t.scan_debug       = geti("CUVS_AMD_SCAN_DEBUG", 0);
   t.shard_coarse_replicated = set("CUVS_AMD_SHARD_COARSE_REPLICATED");

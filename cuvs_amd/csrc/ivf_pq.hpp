@@ -47,6 +47,17 @@ struct ivf_pq_index {
   // per-centre norm term of the int8 GEMM (the y / z columns of centers_int8, ivf_pq_index.cu:674-732)
   mutable dev_buf<float> coarse_centers_h, coarse_norms_h, coarse_rot_h, coarse_centers_i8, coarse_normterm_i8, coarse_rot_i8;
 
+  // decode tables of the matrix-core filter (ivf_pq_scan3.hip), built on first use and rebuilt when the lists change
+  struct scan3_cache {
+    dev_buf<uint32_t> cb16;
+    dev_buf<float> row_term;
+    float sc = 1.f, cbmax = 0.f;
+    const void* codes_ptr = nullptr;
+    const void* pq_ptr    = nullptr;
+    int64_t rows = -1, size = -1;
+  };
+  mutable scan3_cache scan3;
+
   // List-sharded multi-GPU search (shard_comm.hip): every rank holds the whole model (centres, rotation, codebooks) but
   // only the lists it owns - list L belongs to rank L % shard_world. extend() drops rows of foreign lists, search()
   // scans only owned probes; the per-rank top-k lists are all-gathered and merged. shard_world == 1: not sharded.

@@ -1,0 +1,636 @@
+// IVF-PQ search, warm-bounds phase on the matrix cores: "decode + MFMA filter, exact re-score of the survivors".
+//
+// Reference semantics: the score of (query, probed row) is the sum over the pq_dim subspaces of the query's LUT entry
+// of the row's code (compute_score_impl.cuh:52-79, create_lut_impl.cuh:17-78), the k smallest win
+// (ivf_pq_search.cuh:421-669). Once a query has a k-th bound (after the head phase, ivf_pq_search.hip) all but ~1e-4
+// of the (row, query) pairs of the remaining probes are above it. The LUT scan still gathers one LDS entry per code
+// byte and pair to find that out; here the bulk of the pairs never touch a LUT:
+//
+//   filter    For L2 the real-valued score is |r - d|^2 = |r|^2 - 2 r.d + |d|^2 (r: rotated query minus rotated list
+//             centre, d: the row's decoded residual); for inner product it is -(q.c + q.d). r.d over (32 rows x 64
+//             queries) is a GEMM tile: a wave DECODES 32 rows straight into MFMA A operands (lane = (row, half of the
+//             K slice): 4 ds_read_b32 gathers of fp16x2 codebook entries per v_mfma_f32_32x32x16_f16, 32 per row for
+//             all 64 subspaces - per row and 64 queries, not per row and query) against the queries' residuals held as
+//             fp16 B operands in registers. A pair is DROPPED only when a lower bound of its exact score - the fp16
+//             GEMM value minus rigorous rounding margins, see filter_threshold() - is above the query's bound; every
+//             other pair is appended to a survivor list (pair id, flat row).
+//   re-score  one lane per survivor computes the reference's score with the reference's arithmetic for the requested
+//             LUT / score types (pq_lut_math.hpp: the same entry roundings, the same summation order as the LUT scan:
+//             bit-identical scores) and, if it is still within the bound and passes the pre-filter, appends it to the
+//             query's candidate pool (the tail of the query's per-pair candidate rows);
+//   merge     one wave per query selects the k best of head lists + pool by (score, probe rank, row) - the order the
+//             per-pair lists + select_k of the LUT path produce - and writes them sorted by (score, row).
+// The bound is the head phase's and does not move during the filter, so the survivor set - and with it every result -
+// is independent of scheduling. Queries the scheme cannot serve (no finite bound yet, residuals beyond the fp16
+// range, a full pool) are flagged and re-done by the LUT scan kernel, pair by pair (ivf_pq_search.hip).
+//
+// Roofline: the decode is bound by the random LDS gathers (5.2 cycles per wave-level ds_read_b32 and CU, measured:
+// profiles/r03_lds_gather_bench.json): 32 gathers per 32 rows and 64 queries = 0.081 cycles per pair, against 16
+// MFMAs x 8 cycles per CU = 0.0625 cycles per pair on the matrix cores.
+#include "ivf_pq.hpp"
+#include "ops.hpp"
+#include "device_utils.hpp"
+#include "ivf_common.hpp"
+#include "pq_lut_math.hpp"
+#include "ivf_pq_scan3.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <mutex>
+
+namespace cuvs_amd {
+
+namespace {
+
+constexpr int kFThreads = 512;  // 8 waves: two per SIMD, up to 256 registers each (64 of them the B operands)
+constexpr int kFWaves   = kFThreads / 64;
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ per-index tables
+__global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, float sc, uint32_t* __restrict__ cb16)
+{
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // s * 256 + code
+  if (e >= pq_dim * 256u) return;
+  const uint32_t s = e >> 8, code = e & 255u;
+  const _Float16 h0 = (_Float16)(sc * pq_centers[(size_t)(s * 2 + 0) * 256 + code]);
+  const _Float16 h1 = (_Float16)(sc * pq_centers[(size_t)(s * 2 + 1) * 256 + code]);
+  cb16[e] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+}
+
+// |d|^2 of every row's decoded residual, shrunk by the relative margin (see filter_threshold): one thread per row
+__global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows,
+                                float* __restrict__ term)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const uint4* cp = reinterpret_cast<const uint4*>(codes) + ((size_t)(r >> 6) * 4) * 64 + (r & 63);
+  float dn = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint4 cw       = cp[c * 64];
+    const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+      const uint32_t s    = c * 16 + b;
+      const float p0 = pq_centers[(size_t)(s * 2 + 0) * 256 + code], p1 = pq_centers[(size_t)(s * 2 + 1) * 256 + code];
+      dn = __fmaf_rn(p0, p0, dn);
+      dn = __fmaf_rn(p1, p1, dn);
+    }
+  }
+  term[r] = dn * (1.0f - 1.0f / 512.0f);
+}
+
+// ------------------------------------------------------------------ work units: (list, <= 64 pairs, row chunk)
+struct filter_unit {
+  uint32_t list, first, count, row0;
+};
+
+__global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
+                                                           const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
+                                                           uint32_t* __restrict__ unit_off)
+{
+  __shared__ int smem[17];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_lists; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    int v = 0;
+    if (i < n_lists) {
+      const uint32_t np = pair_off[n_lists + i + 1] - pair_off[n_lists + i];  // tail labels: n_lists + list
+      const uint32_t len = list_sizes[i];
+      v = (int)(((np + 63u) / 64u) * ((len + unit_rows - 1u) / unit_rows));
+    }
+    int total;
+    const int excl = block_exclusive_scan(v, smem, &total);
+    if (i < n_lists) unit_off[i] = (uint32_t)(carry + excl);
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) unit_off[n_lists] = (uint32_t)carry;
+}
+
+__global__ void fill_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
+                                  const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
+                                  const uint32_t* __restrict__ unit_off, filter_unit* __restrict__ units)
+{
+  const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= n_lists) return;
+  const uint32_t b = pair_off[n_lists + L], e = pair_off[n_lists + L + 1], len = list_sizes[L];
+  uint32_t w = unit_off[L];
+  if (b == e) return;
+  // row chunk major: the query groups of one chunk run next to each other and share its rows in L2
+  for (uint32_t r0 = 0; r0 < len; r0 += unit_rows)
+    for (uint32_t p = b; p < e; p += 64u) units[w++] = filter_unit{L, p, min(64u, e - p), r0};
+}
+
+// ------------------------------------------------------------------ the filter
+struct filter_params {
+  const filter_unit* units;
+  const uint32_t* n_units;  // device scalar
+  uint32_t* xcd_ticket;     // 8 counters, 32 words apart
+  const uint32_t* sorted_pairs;
+  const float* rot_queries;
+  const float* centers_rot;
+  const uint32_t* cb16;
+  const uint8_t* codes;
+  const uint32_t* list_offsets;
+  const uint32_t* list_sizes;
+  const float* row_term;
+  const uint32_t* query_kth;
+  uint32_t* qflag;
+  uint2* surv;
+  uint32_t* surv_cnt;
+  uint32_t surv_cap;
+  uint32_t n_probes, rot_dim, unit_rows;
+  float sc;        // power of two applied to both GEMM operands before the fp16 rounding
+  float c1;        // -2 / sc^2 (L2) or -1 / sc^2 (inner product)
+  float eps, alpha;  // exact score >= real score * (1 - eps) - alpha for the requested LUT / score types
+  float cbmax;
+  float bound_max;   // bounds beyond this are not served here (fp8 LUT saturation)
+  int is_ip;
+  unsigned long long* stats;  // optional [4]: pairs tested, survivors, subtiles, subtiles that took the slow path
+};
+
+// Largest value B with: exact score > bound  whenever  (row term - 2 dot16 / sc^2) > B   (L2; see the file header).
+// With T the real-valued score, S the score in the reference's arithmetic and A the filter's value
+//   S >= T (1 - eps) - alpha                          entry roundings of the LUT type, summation in the score type
+//   T >= A - 2^-9 (rn + dn) - mabs                    fp16 rounding of both GEMM operands: |x^ y^ - x y| <= 2^-10 |x y| +
+//                                                     2^-25 (|x| + |y|) per element (normal + subnormal range), fp32
+//                                                     accumulation; 2 |r.d| <= rn + dn
+// so S > bound is implied by  dn (1 - 2^-9) - 2 dot > (bound + alpha) / (1 - eps) + mabs - rn (1 - 2^-9). The right side
+// is evaluated in double and rounded up.
+__device__ inline float filter_threshold(const float bound, const float rn, const filter_params& a)
+{
+  const double mabs = 1.1920929e-07 /* 2^-23 */ / (double)a.sc *
+                      (sqrt((double)a.rot_dim * (double)rn) + (double)a.rot_dim * (double)a.cbmax);
+  const double b = ((double)bound + (double)a.alpha) * (1.0 + 2.0 * (double)a.eps) + mabs - (double)rn * (1.0 - 1.0 / 512.0);
+  float f = (float)b;
+  f += fabsf(f) * 2.4e-7f + 1e-37f;
+  return f;
+}
+
+__global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_params a)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* cb = reinterpret_cast<uint32_t*>(smem);  // [64 subspaces][256 codes] fp16x2, 64 KiB
+  for (uint32_t i = threadIdx.x; i < 64u * 256u / 4u; i += kFThreads)
+    reinterpret_cast<uint4*>(cb)[i] = reinterpret_cast<const uint4*>(a.cb16)[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const uint32_t ql = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
+  const uint32_t* cbh = cb + h * (8u * 256u);  // this lane's half of every 16-subspace chunk
+
+  // XCD x owns the x-th eighth of the (list-sorted) unit array; its waves draw units through one ticket counter
+  const uint32_t n_units = *a.n_units;
+  const uint32_t xcd = blockIdx.x & 7u, chunk = (n_units + 7u) / 8u;
+  const uint32_t share0 = min(n_units, xcd * chunk), share_len = min(chunk, n_units - share0);
+  const filter_unit* share = a.units + share0;
+  uint32_t* ticket = a.xcd_ticket + xcd * 32;
+  const uint4* codes16 = reinterpret_cast<const uint4*>(a.codes);
+
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= share_len) break;
+    const uint4 uu = *reinterpret_cast<const uint4*>(share + t);
+    const uint32_t L = __builtin_amdgcn_readfirstlane(uu.x), first = __builtin_amdgcn_readfirstlane(uu.y),
+                   count = __builtin_amdgcn_readfirstlane(uu.z), row0 = __builtin_amdgcn_readfirstlane(uu.w);
+    const uint32_t base_row = a.list_offsets[L], len = a.list_sizes[L];
+    const bool two = count > 32u;  // wave-uniform: the second group of 32 queries
+
+    // ---- B operands: the item's query residuals as fp16, lane = (query ql of group g, K half h)
+    f16x8_t bop[2][8];
+    float thr[2];
+    uint32_t pairid[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const uint32_t jj = g * 32u + ql;
+      const bool valid  = jj < count;
+      const uint32_t p  = valid ? a.sorted_pairs[first + jj] : 0u;
+      const uint32_t q  = p / a.n_probes;
+      pairid[g]         = p;
+      const float* rq   = a.rot_queries + (size_t)q * a.rot_dim;
+      const float* ct   = a.centers_rot + (size_t)L * a.rot_dim;
+      float rn = 0.f, big = 0.f;
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const uint32_t s0 = 16u * (st >> 1) + 8u * h + 4u * (st & 1);
+        const float4 q0 = *reinterpret_cast<const float4*>(rq + 2 * s0), q1 = *reinterpret_cast<const float4*>(rq + 2 * s0 + 4);
+        float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        if (!a.is_ip) {
+          const float4 c0 = *reinterpret_cast<const float4*>(ct + 2 * s0), c1 = *reinterpret_cast<const float4*>(ct + 2 * s0 + 4);
+          const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] -= c[e];
+        }
+        f16x8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          rn   = __fmaf_rn(r[e], r[e], rn);
+          const float x = a.sc * r[e];
+          big  = fmaxf(big, fabsf(x));
+          v[e] = (_Float16)x;
+        }
+        bop[g][st] = v;
+      }
+      rn  += __shfl_xor(rn, 32);
+      big  = fmaxf(big, __shfl_xor(big, 32));
+      const uint32_t kk = valid ? a.query_kth[q] : 0u;
+      const float bound = key_to_float(kk);
+      // no finite bound yet, an operand beyond the fp16 range, a bound the LUT type cannot represent, or a query that
+      // is re-done by the LUT scan anyway: nothing of this query survives here
+      const bool served = valid && kk < 0xff800000u && big < 60000.f && bound <= a.bound_max && a.qflag[q] == 0u;
+      if (valid && !served) a.qflag[q] = 1u;
+      thr[g] = served ? filter_threshold(bound, rn, a) : -INFINITY;
+    }
+
+    // ---- rows of the unit, 32 at a time; the code words of the next subtile are in flight during the current one
+    const uint32_t r_end = min(len, row0 + a.unit_rows);
+    const uint32_t u0 = row0 >> 5, u1 = (r_end + 31u) >> 5;
+    auto load_codes = [&](const uint32_t u, uint2 (&cw)[4]) {
+      const uint32_t fr = base_row + (u << 5) + ql;  // this lane's row (padded rows of a group are readable)
+      const char* p = reinterpret_cast<const char*>(codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u)) + 8u * h;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const uint2*>(p + (size_t)c * 64 * 16);
+    };
+    uint2 nxt[4];
+    load_codes(u0, nxt);
+    for (uint32_t u = u0; u < u1; ++u) {
+      uint2 cw[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) cw[c] = nxt[c];
+      if (u + 1 < u1) load_codes(u + 1, nxt);
+      f32x16_t acc0 = {}, acc1 = {};
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const uint32_t w = (st & 1) ? cw[st >> 1].y : cw[st >> 1].x;
+        u32x4_t av;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          av[e] = cbh[((16u * (st >> 1) + 4u * (st & 1) + e) << 8) + ((w >> (8 * e)) & 0xffu)];
+        const f16x8_t aop = __builtin_bit_cast(f16x8_t, av);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[0][st], acc0, 0, 0, 0);
+        if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[1][st], acc1, 0, 0, 0);
+      }
+      // ---- screen: accumulator register i of this lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile
+      float tv[16];
+      if (a.row_term != nullptr) {
+        const float* tp = a.row_term + base_row + (u << 5) + 4u * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(tp + 8 * j);
+          tv[4 * j] = v.x; tv[4 * j + 1] = v.y; tv[4 * j + 2] = v.z; tv[4 * j + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tv[i] = 0.f;
+      }
+      float m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        m0 = fminf(m0, __fmaf_rn(acc0[i], a.c1, tv[i]));
+        m1 = fminf(m1, __fmaf_rn(acc1[i], a.c1, tv[i]));
+      }
+      const bool any = (m0 <= thr[0]) || (two && m1 <= thr[1]);
+      if (a.stats != nullptr && lane == 0) {
+        atomicAdd(&a.stats[0], (unsigned long long)(32u * count));
+        atomicAdd(&a.stats[2], 1ull);
+      }
+      if (__ballot(any) == 0ull) continue;  // the usual case
+      // ---- slow path: append the surviving (pair, row) pairs
+      if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[3], 1ull);
+      unsigned long long masks[2][16];
+      uint32_t total = 0u;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const uint32_t v  = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+          const float x     = __fmaf_rn(g == 0 ? acc0[i] : acc1[i], a.c1, tv[i]);
+          const bool keep   = (g == 0 || two) && x <= thr[g] && v < len;
+          masks[g][i]       = __ballot(keep);
+          total += (uint32_t)__popcll(masks[g][i]);
+        }
+      if (total == 0u) continue;
+      uint32_t base = 0u;
+      if (lane == 0) base = atomicAdd(a.surv_cnt, total);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[1], (unsigned long long)total);
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const unsigned long long m = masks[g][i];
+          if (m == 0ull) continue;
+          if ((m >> lane) & 1ull) {
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t v   = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+            if (pos < a.surv_cap) a.surv[pos] = make_uint2(pairid[g], base_row + v);
+            else a.qflag[pairid[g] / a.n_probes] = 1u;  // survivor list full: the query is re-done by the LUT scan
+          }
+          base += (uint32_t)__popcll(m);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ re-score
+struct rescore_params {
+  const uint2* surv;
+  const uint32_t* surv_cnt;
+  uint32_t surv_cap;
+  const uint32_t* probes;  // [n_pairs] list of every pair
+  const float* rot_queries;
+  const float* centers_rot;
+  const float* pq_centers;
+  const uint8_t* codes;
+  const uint32_t* query_kth;
+  uint32_t* qflag;
+  uint32_t* qcnt;
+  float* cand_d;
+  uint32_t* cand_i;
+  uint32_t* cand_r;
+  uint32_t n_probes, rot_dim, k, head;
+  int is_ip;
+  const uint32_t* filter_bits;
+  const int64_t* indices;
+};
+
+template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
+__global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
+{
+  const uint32_t n = min(*a.surv_cnt, a.surv_cap);
+  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
+    const uint2 sv = a.surv[s];
+    const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
+    if (a.qflag[q] != 0u) continue;  // re-done by the LUT scan
+    if (a.filter_bits != nullptr) {
+      const int64_t sid = a.indices[row];
+      if (((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) == 0u) continue;
+    }
+    const uint32_t L = a.probes[pair];
+    const float* rq  = a.rot_queries + (size_t)q * a.rot_dim;
+    const float* ct  = a.centers_rot + (size_t)L * a.rot_dim;
+    const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * 4) * 64 + (row & 63u);
+    float af       = 0.f;
+    _Float16 ah    = (_Float16)0.f;
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      const uint4 cw       = cp[c * 64];
+      const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+        const uint32_t sb   = c * 16 + b;
+        const float p0 = a.pq_centers[(size_t)(sb * 2 + 0) * 256 + code], p1 = a.pq_centers[(size_t)(sb * 2 + 1) * 256 + code];
+        const float q0 = rq[sb * 2], q1 = rq[sb * 2 + 1], c0 = ct[sb * 2], c1 = ct[sb * 2 + 1];
+        float v;
+        if (!a.is_ip) {
+          const float d0 = (q0 - c0) - p0, d1 = (q1 - c1) - p1;
+          v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+        } else {
+          v = __fmaf_rn(-q0, c0, 0.f);
+          v = __fmaf_rn(-q0, p0, v);
+          v = __fmaf_rn(-q1, c1, v);
+          v = __fmaf_rn(-q1, p1, v);
+        }
+        if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
+        if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
+          af += v;  // fp32 entries
+        } else {
+          const _Float16 e = to_lut_half(v);
+          if constexpr (ACC_HALF) ah += e; else af += (float)e;
+        }
+      }
+    }
+    const float score = ACC_HALF ? (float)ah : af;
+    if (float_to_key(score) > a.query_kth[q]) continue;
+    const uint32_t cap = (a.n_probes - a.head) * a.k;
+    const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
+    if (pos >= cap) { a.qflag[q] = 1u; continue; }
+    const size_t o = (size_t)q * a.n_probes * a.k + (size_t)a.head * a.k + pos;
+    a.cand_d[o] = score;
+    a.cand_i[o] = row;
+    a.cand_r[o] = pair % a.n_probes;
+  }
+}
+
+// ------------------------------------------------------------------ flagged queries: back to the LUT scan, pair by pair
+__global__ void reset_flagged_kernel(const uint32_t* __restrict__ qflag, int64_t nq, uint32_t n_probes, uint32_t k, uint32_t head,
+                                     float* __restrict__ cand_d, uint32_t* __restrict__ cand_i)
+{
+  const int64_t q = blockIdx.x;
+  if (q >= nq || qflag[q] == 0u) return;
+  const size_t o = (size_t)q * n_probes * k;
+  for (uint32_t s = head * k + threadIdx.x; s < n_probes * k; s += blockDim.x) {
+    cand_d[o + s] = FLT_MAX;
+    cand_i[o + s] = 0xffffffffu;
+  }
+}
+
+__global__ void fallback_items_kernel(const uint32_t* __restrict__ sorted_pairs, const uint32_t* __restrict__ pair_off,
+                                      uint32_t n_lists, const uint32_t* __restrict__ probes, uint32_t n_probes,
+                                      const uint32_t* __restrict__ qflag, work_item* __restrict__ items,
+                                      uint32_t* __restrict__ n_items)
+{
+  const uint32_t b = pair_off[n_lists], e = pair_off[2 * n_lists];
+  for (uint32_t s = b + blockIdx.x * blockDim.x + threadIdx.x; s < e; s += gridDim.x * blockDim.x) {
+    const uint32_t p = sorted_pairs[s];
+    if (qflag[p / n_probes] == 0u) continue;
+    const uint32_t w = atomicAdd(n_items, 1u);
+    items[w] = work_item{n_lists + probes[p], s, 1u, 0u};
+  }
+}
+
+// ------------------------------------------------------------------ merge: one wave per query
+struct top3 {  // sorted ascending by (d, rank, row), rank r in lane r
+  float d;
+  uint32_t rk, row;
+  __device__ inline void init() { d = INFINITY; rk = 0xffffffffu; row = 0xffffffffu; }
+  __device__ static inline bool before(float da, uint32_t ra, uint32_t wa, float db, uint32_t rb, uint32_t wb)
+  {
+    return da < db || (da == db && (ra < rb || (ra == rb && wa < wb)));
+  }
+  __device__ inline void insert(float cd, uint32_t cr, uint32_t cw, int lane)
+  {
+    const int pos = __popcll(__ballot(!before(cd, cr, cw, d, rk, row)));  // entries at or before the candidate
+    const uint32_t du = __float_as_uint(d);
+    const uint32_t ud = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)du, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    const uint32_t ur = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rk, 0x138, 0xf, 0xf, false);
+    const uint32_t uw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)row, 0x138, 0xf, 0xf, false);
+    if (lane > pos) { d = __uint_as_float(ud); rk = ur; row = uw; }
+    else if (lane == pos) { d = cd; rk = cr; row = cw; }
+  }
+};
+
+__global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict__ cand_d, const uint32_t* __restrict__ cand_i,
+                                                         const uint32_t* __restrict__ cand_r, const uint32_t* __restrict__ qcnt,
+                                                         const uint32_t* __restrict__ qflag, int64_t nq, uint32_t n_probes,
+                                                         uint32_t k, uint32_t head, float* __restrict__ top_d,
+                                                         uint32_t* __restrict__ top_i)
+{
+  const int lane  = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const size_t o      = (size_t)q * n_probes * k;
+  const bool flagged  = qflag[q] != 0u;
+  const uint32_t pool = min(qcnt[q], (n_probes - head) * k);
+  const uint32_t n    = flagged ? n_probes * k : head * k + pool;
+  const int kr        = (int)k - 1;
+  top3 best;
+  best.init();
+  float kd = INFINITY;
+  uint32_t krk = 0xffffffffu, krow = 0xffffffffu;
+  for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+    const uint32_t s = s0 + lane;
+    float d = INFINITY;
+    uint32_t rk = 0xffffffffu, row = 0xffffffffu;
+    if (s < n) {
+      d   = cand_d[o + s];
+      row = cand_i[o + s];
+      rk  = (flagged || s < head * k) ? s / k : cand_r[o + s];
+    }
+    unsigned long long m = __ballot(row != 0xffffffffu && top3::before(d, rk, row, kd, krk, krow));
+    while (m != 0ull) {
+      const int src = (int)__ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), src));
+      const uint32_t cr = __builtin_amdgcn_readlane(rk, src), cw = __builtin_amdgcn_readlane(row, src);
+      if (top3::before(cd, cr, cw, kd, krk, krow)) {
+        best.insert(cd, cr, cw, lane);
+        kd   = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best.d), kr));
+        krk  = __builtin_amdgcn_readlane(best.rk, kr);
+        krow = __builtin_amdgcn_readlane(best.row, kr);
+      }
+    }
+  }
+  // the winners, ordered by (score, row) as select_k orders them
+  wave_top<1> out;
+  out.init();
+  for (int r = 0; r < (int)k; ++r) {
+    const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best.d), r));
+    const uint32_t cw = __builtin_amdgcn_readlane(best.row, r);
+    if (cw == 0xffffffffu) break;
+    out.insert(cd, cw, lane);
+  }
+  if (lane < (int)k) {
+    const bool ok = out.i[0] != 0xffffffffu;
+    top_d[q * k + lane] = ok ? out.d[0] : FLT_MAX;
+    top_i[q * k + lane] = ok ? out.i[0] : 0xffffffffu;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+bool pq3_supported(const ivf_pq_index& idx, int k)
+{
+  return idx.pq_bits == 8 && idx.pq_dim == 64 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && idx.rot_dim == 128;
+}
+
+pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
+{
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  auto& c = idx.scan3;
+  if (c.codes_ptr != idx.codes.data() || c.rows != idx.padded_rows || c.size != idx.size || c.pq_ptr != idx.pq_centers.data()) {
+    std::vector<float> h = to_host(res, idx.pq_centers.data(), idx.pq_centers.size());
+    float mx = 0.f;
+    for (float v : h) mx = std::max(mx, std::fabs(v));
+    // both GEMM operands are scaled by a power of two so that the largest codebook value lands in (8, 16]: query
+    // residuals up to 4096 times larger still fit the fp16 range, values 2^17 times smaller are still normal numbers
+    c.sc    = mx > 0.f ? std::exp2(std::floor(std::log2(16.0f / mx))) : 1.0f;
+    c.cbmax = mx;
+    c.cb16  = dev_buf<uint32_t>::persistent((size_t)idx.pq_dim * 256);
+    hipLaunchKernelGGL(cb16_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream,
+                       idx.pq_centers.data(), idx.pq_dim, c.sc, c.cb16.data());
+    c.row_term = dev_buf<float>::persistent((size_t)std::max<int64_t>(idx.padded_rows, 1));
+    if (idx.padded_rows > 0)
+      hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, idx.codes.data(),
+                         idx.pq_centers.data(), idx.padded_rows, c.row_term.data());
+    sync(res);
+    c.codes_ptr = idx.codes.data(); c.rows = idx.padded_rows; c.size = idx.size; c.pq_ptr = idx.pq_centers.data();
+  }
+  return pq3_tables{c.cb16.data(), c.row_term.data(), c.sc, c.cbmax};
+}
+
+size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows)
+{
+  uint32_t max_len = 0;
+  for (uint32_t v : idx.h_list_sizes) max_len = std::max(max_len, v);
+  const uint32_t ur = std::max<uint32_t>(2048u, (uint32_t)round_up((int64_t)(max_len + 15) / 16, 64));  // <= 16 chunks per list
+  *unit_rows = ur;
+  return (size_t)16 * ((size_t)n_pairs / 64 + idx.n_lists + 1);
+}
+
+void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
+{
+  const pq3_tables tb = pq3_prepare(res, idx);
+  profile_begin(res, "pq_scan_kernel");  // bench.py sums the scan phases under this name
+  auto* units = static_cast<filter_unit*>(r.units);
+  hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
+                     r.unit_rows, r.unit_off);
+  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
+                     idx.list_sizes.data(), r.unit_rows, r.unit_off, units);
+  filter_params f{};
+  f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket;
+  f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = idx.centers_rot.data();
+  f.cb16 = tb.cb16; f.codes = idx.codes.data(); f.list_offsets = idx.list_offsets.data(); f.list_sizes = idx.list_sizes.data();
+  f.row_term = r.is_ip ? nullptr : tb.row_term; f.query_kth = r.query_kth; f.qflag = r.qflag;
+  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.counters; f.surv_cap = r.surv_cap;
+  f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.unit_rows = r.unit_rows;
+  f.sc = tb.sc; f.c1 = (r.is_ip ? -1.0f : -2.0f) / (tb.sc * tb.sc);
+  f.cbmax = tb.cbmax; f.is_ip = r.is_ip; f.stats = r.stats;
+  // exact score >= real score * (1 - eps) - alpha (L2: all entries are >= 0)
+  //   fp32 LUT / fp32 score: 2 roundings per entry + 64 adds
+  //   fp16 LUT: + 2^-11 per entry (2^-24 absolute below the normal range); fp16 score: + 2^-11 of the partial sum per add
+  //   fp8 LUT (5 exponent bits, 3 value bits, truncation, half an ulp added back): 2^-4 per entry, 2^-15 absolute below its
+  //   range; it saturates at 1.875 * 2^16, so bounds near that are not served
+  f.bound_max = FLT_MAX;
+  if (r.lut_mode == 0)      { f.eps = 1.0f / 65536.0f; f.alpha = 0.f; }
+  else if (r.lut_mode == 1) { f.eps = r.acc_half ? 0.04f : 1.0f / 1024.0f; f.alpha = 64.0f / 16777216.0f; f.bound_max = 60000.f; }
+  else                      { f.eps = r.acc_half ? 0.11f : 0.07f; f.alpha = 64.0f / 32768.0f; f.bound_max = 30000.f; }
+  const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  profile_begin(res, "pq_filter_kernel");
+  hipLaunchKernelGGL(pq_filter_kernel, dim3(grid), dim3(kFThreads), 64 * 1024, res.stream, f);
+  profile_end(res, "pq_filter_kernel");
+
+  rescore_params s{};
+  s.surv = f.surv; s.surv_cnt = r.counters; s.surv_cap = r.surv_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
+  s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = idx.codes.data();
+  s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
+  s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip;
+  s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
+  const dim3 rg(grid * 8), rb(256);
+  profile_begin(res, "pq_rescore_kernel");
+  if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_kernel<0, false>), rg, rb, 0, res.stream, s);
+  else if (r.lut_mode == 1) { if (r.acc_half) hipLaunchKernelGGL((pq_rescore_kernel<1, true>), rg, rb, 0, res.stream, s);
+                              else            hipLaunchKernelGGL((pq_rescore_kernel<1, false>), rg, rb, 0, res.stream, s); }
+  else                      { if (r.acc_half) hipLaunchKernelGGL((pq_rescore_kernel<2, true>), rg, rb, 0, res.stream, s);
+                              else            hipLaunchKernelGGL((pq_rescore_kernel<2, false>), rg, rb, 0, res.stream, s); }
+  profile_end(res, "pq_rescore_kernel");
+  // flagged queries: their candidate rows go back to "per-pair segments, nothing found yet", their tail pairs become
+  // single-pair work items of the LUT scan kernel (launched by the caller)
+  hipLaunchKernelGGL(reset_flagged_kernel, dim3((unsigned)r.nq), dim3(256), 0, res.stream, r.qflag, r.nq, r.n_probes, r.k, r.head,
+                     r.cand_d, r.cand_i);
+  hipLaunchKernelGGL(fallback_items_kernel, dim3(grid * 4), dim3(256), 0, res.stream, r.sorted_pairs, r.pair_off, idx.n_lists,
+                     r.probes, r.n_probes, r.qflag, static_cast<work_item*>(r.fb_items), r.counters + 1);
+  profile_end(res, "pq_scan_kernel");
+}
+
+void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)
+{
+  hipLaunchKernelGGL(pool_merge_kernel, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
+                     r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i);
+}
+
+}  // namespace cuvs_amd

@@ -1,0 +1,46 @@
+// Interface of the warm-bounds IVF-PQ phase on the matrix cores (ivf_pq_scan3.hip), driven by ivf_pq_search.hip.
+#pragma once
+#include "ivf_pq.hpp"
+
+namespace cuvs_amd {
+
+struct pq3_tables {
+  const uint32_t* cb16;   // [pq_dim][256] codebook entries as scaled fp16 pairs (decode table of the filter)
+  const float* row_term;  // [padded_rows] |decoded residual|^2 * (1 - 2^-9)
+  float sc, cbmax;
+};
+
+// one batch of the tail phase; all pointers device memory owned by the caller (ivf_pq_search)
+struct pq3_run {
+  int64_t nq;
+  uint32_t n_probes, k, head;
+  int is_ip, lut_mode /* 0 fp32, 1 fp16, 2 fp8 */, acc_half;
+  const uint32_t* sorted_pairs;  // pair ids grouped by phase label
+  const uint32_t* pair_off;      // [2 n_lists + 1] label offsets into sorted_pairs (head labels, then tail labels)
+  const uint32_t* probes;        // [n_pairs] list of every pair
+  const float* rot_queries;
+  const uint32_t* query_kth;     // bound keys after the head phase
+  float* cand_d;                 // [nq, n_probes * k]: head segments first, the rest is the query's pool
+  uint32_t* cand_i;
+  uint32_t* cand_r;              // probe rank of the pool entries
+  uint32_t* qflag;               // [nq] zeroed: queries handed back to the LUT scan
+  uint32_t* qcnt;                // [nq] zeroed: pool fill
+  uint32_t* counters;            // [2] zeroed: survivors, fallback work items
+  void* surv;                    // [surv_cap] (pair, flat row)
+  uint32_t surv_cap;
+  void* units;                   // work units of the filter, pq3_max_units() entries
+  uint32_t* unit_off;            // [n_lists + 1]
+  uint32_t unit_rows;
+  uint32_t* xcd_ticket;          // 8 x 32 zeroed words
+  void* fb_items;                // work_item[n tail pairs]: single-pair items of the flagged queries
+  const uint32_t* filter_bits;
+  unsigned long long* stats;     // optional device [4]
+};
+
+bool pq3_supported(const ivf_pq_index& idx, int k);
+size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows);
+// filter + re-score + fallback work items of the flagged queries (the caller launches the LUT scan on them)
+void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r);
+void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i);
+
+}  // namespace cuvs_amd

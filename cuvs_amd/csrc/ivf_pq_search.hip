@@ -27,6 +27,8 @@
 #include "ops.hpp"
 #include "device_utils.hpp"
 #include "ivf_common.hpp"
+#include "pq_lut_math.hpp"
+#include "ivf_pq_scan3.hpp"
 
 #include <cfloat>
 #include <cstdlib>
@@ -54,15 +56,6 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
-
-// fp32 score -> fp16 LUT entry, as the reference stores it (LutT(score): the fp32-rounded score, then round to nearest
-// even). The barrier keeps hipcc from folding fma + convert into v_fma_mixlo_f16, which rounds the exact product-sum
-// ONCE and differs from the reference in the last half bit of some entries.
-__device__ inline _Float16 to_lut_half(float v)
-{
-  asm volatile("" : "+v"(v));
-  return (_Float16)v;
-}
 
 template <>
 struct lut_acc<float, float, 1> {
@@ -164,32 +157,6 @@ struct lut_acc<__half, __half, 4> {
     return f16x4_t{to_lut_half(v[0]), to_lut_half(v[1]), to_lut_half(v[2]), to_lut_half(v[3])};
   }
 };
-
-// lut_dtype = CUDA_R_8U / CUDA_R_8I: the reference stores LUT entries in its own 8-bit float fp_8bit<5, Signed>
-// (ivf_pq_fp_8bit.cuh:32-100; unsigned for L2, sign in bit 0 for inner product - ivf_pq_search.cuh:711-728): 5 exponent
-// bits (bias 15), 3 value bits, truncation on encode, half an ulp added back on decode. Here the entry is rounded
-// through that type when the LUT is built and stored in the score type (the value every later add sees is the
-// reference's): its float decoder (:75-88) for fp32 scores, its half decoder (:90-102, no implicit one at the
-// smallest exponent, NaN/inf patterns at the largest) for fp16 scores.
-template <typename AccT>
-__device__ inline float fp8_round_trip(float v, bool is_signed)
-{
-  const float av = is_signed ? fabsf(v) : v;
-  uint32_t u;
-  if (av < 1.0f / 32768.0f) u = 0u;
-  else if (av >= 65536.0f * 1.875f) u = 0xffu;
-  else u = ((__float_as_uint(av) + (15u << 23) - 0x3f800000u) >> 20) & 0xffu;
-  const bool neg = is_signed && v < 0.f;
-  if (is_signed) u &= 0xfeu;
-  float r;
-  if constexpr (sizeof(AccT) == 2) {
-    const uint16_t hb = (uint16_t)(((0x3c00u | (0x0200u >> 3)) - (15u << 10)) + (u << 7));
-    r = (float)__builtin_bit_cast(_Float16, hb);
-  } else {
-    r = __uint_as_float(((0x3f800000u | (0x00400000u >> 3)) - (15u << 23)) + (u << 20));
-  }
-  return neg ? -r : r;
-}
 
 // dbg 128 statistics (CUVS_AMD_SCAN_DEBUG=128 prints them per search): wave cycles per phase, rows per stage
 enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QUEUED, ST_S2_CALLS, ST_ALIVE1, ST_ALIVE2,
@@ -2072,7 +2039,19 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<float> top_d(res, (size_t)bs_alloc * k);
   dev_buf<uint32_t> top_i(res, (size_t)bs_alloc * k);
   dev_buf<uint32_t> query_kth(res, (size_t)bs_alloc);
-  dev_buf<uint32_t> tickets(res, 2 * 8 * 32);
+  dev_buf<uint32_t> tickets(res, 4 * 8 * 32);
+  // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): decode + MFMA filter, exact re-score of the survivors
+  const bool metric_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
+  const bool use3 = head > 0 && !sharded && !metric_ip && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0;
+  uint32_t unit_rows = 0;
+  const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows) : 0;
+  uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 4, 1 << 20), 1 << 28) : 0u;
+  if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
+  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)2 * bs_alloc + 2 : 0);
+  dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0);
+  dev_buf<uint2> surv(res, surv_cap);
+  dev_buf<uint4> units3(res, max_units);
+  dev_buf<work_item> fb_items(res, use3 ? (size_t)n_pairs_max : 0);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -2110,7 +2089,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     // (8 pairs whatever the LUT type: two groups of four with an fp16 LUT, four groups of two with an fp32 LUT)
     bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 &&  // (k <= 64 excludes the non-fused path)
                 ((lut_half && qpb == 4) || (!lut_half && qpb == 2));
-    use2 = use2 && res.tune.pq_scan2 != 0;
+    use2 = use2 && res.tune.pq_scan2 != 0 && !use3;
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data(), (int)idx.n_lists, use2 ? 8 : qpb);
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
@@ -2180,7 +2159,35 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       if (idx.shard_comm != nullptr) shard_allreduce_min_u32(res, idx.shard_comm, query_kth.data(), (size_t)nq);
       a.xcd_ticket = tickets.data() + 8 * 32;
       a.item_begin = item_off.data() + idx.n_lists;  a.item_end = item_off.data() + 2 * idx.n_lists;
-      if (!use2)          launch(a);  // tail phase: warm bounds
+      if (use3) {
+        HIP_TRY(hipMemsetAsync(qstate.data(), 0, qstate.bytes(), res.stream));
+        pq3_run r{};
+        r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = a.is_ip;
+        r.lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0); r.acc_half = acc_half ? 1 : 0;
+        r.sorted_pairs = sorted_pairs.data(); r.pair_off = pair_off.data(); r.probes = probes.data();
+        r.rot_queries = rot_q.data(); r.query_kth = query_kth.data();
+        r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
+        r.qflag = qstate.data(); r.qcnt = qstate.data() + bs_alloc; r.counters = qstate.data() + 2 * bs_alloc;
+        r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
+        r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
+        r.filter_bits = filter_bits;
+        dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 4 : 0);
+        if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
+        r.stats = st3.data();
+        pq3_tail(res, idx, r);
+        // queries the filter could not serve (no finite bound, operands beyond fp16, full pool): LUT scan of their pairs
+        a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters + 1;
+        a.xcd_ticket = tickets.data() + 3 * 8 * 32;
+        launch(a);
+        pq3_merge(res, r, top_d.data(), top_i.data());
+        if (a.dbg & 1024) {
+          auto hs = to_host(res, st3.data(), 4);
+          auto hc = to_host(res, r.counters, 2);
+          fprintf(stderr, "[pq_scan3] pairs screened %llu, survivors %llu (%.4f%%), subtiles %llu (slow path %llu), fallback pairs %u\n",
+                  hs[0], hs[1], 100.0 * hs[1] / (double)std::max<unsigned long long>(1, hs[0]), hs[2], hs[3], hc[1]);
+        }
+      }
+      else if (!use2)     launch(a);  // tail phase: warm bounds
       else if (!lut_half) launch_scan2<float, float, 2, 4>(res, a, grid);
       else if (!acc_half) launch_scan2<__half, float, 4, 2>(res, a, grid);
       else                launch_scan2<__half, __half, 4, 2>(res, a, grid);
@@ -2219,7 +2226,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
               h[ST_F_LOAD] * w, h[ST_F_GATHER] * w, h[ST_F_FLUSH] * w);
     }
     // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
-    if (!large_k) {
+    if (use3) {
+      // merged already (pq3_merge: head lists + pool)
+    } else if (!large_k) {
       select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
                                    k, top_d.data(), top_i.data(), true);
     } else {

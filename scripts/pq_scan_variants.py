@@ -47,7 +47,8 @@ def main():
     nb = torch.empty((args.batch, args.k), dtype=torch.int64, device=dev)
     ds = torch.empty((args.batch, args.k), dtype=torch.float32, device=dev)
     firsts = {}
-    keys = {"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES", "S2": "CUVS_AMD_PQ_SCAN2", "QCAP": "CUVS_AMD_PQ_QCAP"}
+    keys = {"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES", "S2": "CUVS_AMD_PQ_SCAN2", "QCAP": "CUVS_AMD_PQ_QCAP",
+            "S3": "CUVS_AMD_PQ_SCAN3", "SCAP": "CUVS_AMD_PQ3_SURV_CAP"}
     for v in args.variants:
         lut, acc = "f16", "f16"
         for name in keys.values():
@@ -80,12 +81,15 @@ def main():
         lib().cuvsAmdProfileEnable(0)
         scan = C.c_double(0)
         n = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan))
+        flt, rsc = C.c_double(0), C.c_double(0)
+        lib().cuvsAmdProfileCollect(b"pq_filter_kernel", C.byref(flt))
+        lib().cuvsAmdProfileCollect(b"pq_rescore_kernel", C.byref(rsc))
         cur = (nb.clone(), ds.clone())
         same = "ref" if first is None else str(bool(torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])))
         if first is None:
             firsts[(lut, acc)] = cur
         print(f"{v:24s} search {ms:8.3f} ms  scan {scan.value / args.steps:8.3f} ms ({n // args.steps} launches)  "
-              f"same_as_first={same}", flush=True)
+              f"filter {flt.value / args.steps:7.3f} rescore {rsc.value / args.steps:7.3f}  same_as_first={same}", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,9 +1,11 @@
 """GPU: fixed parity cases at the shapes bench.py times ("next round" item 1).
 
-* C3 shape - IVF-PQ with lists of thousands of rows (pq_dim 64 / 8 bit / pq_len 2: pq_scan_kernel head phase +
-  pq_scan2_kernel tail phase with its multi-block filter tickets and survivor queues), every LUT / score type the bench
-  runs, against the oracle, against the same search with the tail phase on pq_scan_kernel (CUVS_AMD_PQ_SCAN2=0) and with
-  the survivor queues shrunk until they overflow (CUVS_AMD_PQ_QCAP: the "score every row" fallback);
+* C3 shape - IVF-PQ with lists of thousands of rows (pq_dim 64 / 8 bit / pq_len 2: pq_scan_kernel head phase + the
+  matrix-core filter / re-score / pool merge of ivf_pq_scan3.hip in the tail phase), every LUT / score type the bench
+  runs, against the oracle; against the same search with the tail phase on pq_scan2_kernel (CUVS_AMD_PQ_SCAN3=0: LDS
+  filter LUT, multi-block tickets, survivor queues) and on pq_scan_kernel (+ CUVS_AMD_PQ_SCAN2=0); with pq_scan2's
+  survivor queues shrunk until they overflow (CUVS_AMD_PQ_QCAP) and with the matrix-core filter's survivor list shrunk
+  until queries are handed back to the LUT scan (CUVS_AMD_PQ3_SURV_CAP);
 * C4 shape - CAGRA 768-d fp16, graph degree 64, itopk 64: single_cta bit-exact against oracle.cagra_search, multi_cta
   and auto by recall against exact kNN;
 * C5 shape - IVF-PQ on 96-d int8 rows (pq_dim 64 -> rot_dim 128, the kDivisor scaling of ann_utils.cuh:134-160) with
@@ -65,21 +67,30 @@ def big_lists():
 @pytest.mark.parametrize("lut,acc", [("f16", "f16"), ("f16", "f32"), ("fp8", "f16"), ("f32", "f32")])
 def test_c3_shape_lists_of_thousands_of_rows(big_lists, lut, acc, monkeypatch):
     x, q, index, ex = big_lists
-    k, n_probes = 20, 8
+    k, n_probes = 20, 12  # more than 8 probes and 256+ queries: two-phase schedule
     kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
-    gd, gi = _pq_search(index, q, k, **kw)
+    gd, gi = _pq_search(index, q, k, **kw)  # tail phase: matrix-core filter + re-score
     od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut=lut, acc=acc)
     assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
     assert (gd == od).all()
-    # the same search with the tail phase on pq_scan_kernel (no filter stage)
-    monkeypatch.setenv("CUVS_AMD_PQ_SCAN2", "0")
-    pd, pi = _pq_search(index, q, k, **kw)
-    assert (gi == pi).all() and (gd == pd).all()
-    monkeypatch.delenv("CUVS_AMD_PQ_SCAN2")
+    # a survivor list of 1000 entries: most queries are handed back to the LUT scan, pair by pair
+    monkeypatch.setenv("CUVS_AMD_PQ3_SURV_CAP", "1000")
+    hd, hi = _pq_search(index, q, k, **kw)
+    assert (gi == hi).all() and (gd == hd).all()
+    monkeypatch.delenv("CUVS_AMD_PQ3_SURV_CAP")
+    # the tail phase on pq_scan2_kernel (filter LUT in LDS)
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (gi == si).all() and (gd == sd).all()
     # survivor queues of 64 rows: every group overflows and scores every row of the list
     monkeypatch.setenv("CUVS_AMD_PQ_QCAP", "64")
     qd, qi = _pq_search(index, q, k, **kw)
     assert (gi == qi).all() and (gd == qd).all()
+    monkeypatch.delenv("CUVS_AMD_PQ_QCAP")
+    # the tail phase on pq_scan_kernel (no filter stage at all)
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN2", "0")
+    pd, pi = _pq_search(index, q, k, **kw)
+    assert (gi == pi).all() and (gd == pd).all()
 
 
 def test_c3_shape_cold_bounds_overflow_the_default_queues(big_lists, monkeypatch):
@@ -88,9 +99,11 @@ def test_c3_shape_cold_bounds_overflow_the_default_queues(big_lists, monkeypatch
     x, _, index, ex = big_lists
     rng = np.random.default_rng(5)
     q = (rng.random((300, 128), dtype=np.float32) * 4.0 - 2.0).astype(np.float32)
-    gd, gi = _pq_search(index, q, 64, n_probes=6, lut_dtype=np.float16, internal_distance_dtype=np.float32)
-    od, oi = oracle.ivf_pq_search(ex, q, 64, 6, lut="f16", acc="f32")
-    assert (gi == oi).all() and (gd == od).all()
+    od, oi = oracle.ivf_pq_search(ex, q, 64, 12, lut="f16", acc="f32")
+    for scan3 in ("1", "0"):  # matrix-core filter (pools fill up: queries handed back) / pq_scan2 (queues overflow)
+        monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", scan3)
+        gd, gi = _pq_search(index, q, 64, n_probes=12, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+        assert (gi == oi).all() and (gd == od).all()
 
 
 def test_c3_shape_recall_with_refine(big_lists):
