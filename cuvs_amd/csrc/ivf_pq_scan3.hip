@@ -37,6 +37,7 @@
 #include <cfloat>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 
 namespace cuvs_amd {
 
@@ -144,9 +145,9 @@ struct filter_params {
   const float* row_term;
   const uint32_t* query_kth;
   uint32_t* qflag;
-  uint2* surv;
-  uint32_t* surv_cnt;
-  uint32_t surv_cap;
+  uint2* surv;         // one region of surv_cap entries per workgroup (a single global counter for all survivors made
+  uint32_t* surv_cnt;  // ~500 k same-address atomics per search the bottleneck of the kernel: 6.6 of them per us)
+  uint32_t surv_cap;   // entries per region; surv_cnt[b]: fill of workgroup b's region, written once at kernel end
   uint32_t n_probes, rot_dim, unit_rows;
   float sc;        // power of two applied to both GEMM operands before the fp16 rounding
   float c1;        // -2 / sc^2 (L2) or -1 / sc^2 (inner product)
@@ -179,6 +180,9 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* cb = reinterpret_cast<uint32_t*>(smem);  // [64 subspaces][256 codes] fp16x2, 64 KiB
+  uint32_t* wg_fill = reinterpret_cast<uint32_t*>(smem + 64 * 1024);  // survivors of this workgroup so far
+  uint2* my_surv    = a.surv + (size_t)blockIdx.x * a.surv_cap;
+  if (threadIdx.x == 0) *wg_fill = 0u;
   for (uint32_t i = threadIdx.x; i < 64u * 256u / 4u; i += kFThreads)
     reinterpret_cast<uint4*>(cb)[i] = reinterpret_cast<const uint4*>(a.cb16)[i];
   __syncthreads();
@@ -252,100 +256,120 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
       thr[g] = served ? filter_threshold(bound, rn, a) : -INFINITY;
     }
 
-    // ---- rows of the unit, 32 at a time; the code words of the next subtile are in flight during the current one
+    // ---- rows of the unit, 32 at a time. Software pipeline of a wave: the code words are loaded two subtiles ahead;
+    // the 32 gathers that decode subtile u + 1 are issued right after the MFMAs of subtile u and land while its
+    // accumulators are screened; the other wave of the SIMD fills the matrix pipe meanwhile.
     const uint32_t r_end = min(len, row0 + a.unit_rows);
     const uint32_t u0 = row0 >> 5, u1 = (r_end + 31u) >> 5;
     auto load_codes = [&](const uint32_t u, uint2 (&cw)[4]) {
-      const uint32_t fr = base_row + (u << 5) + ql;  // this lane's row (padded rows of a group are readable)
+      const uint32_t fr = base_row + (min(u, u1 - 1u) << 5) + ql;  // this lane's row (padded rows of a group are readable)
       const char* p = reinterpret_cast<const char*>(codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u)) + 8u * h;
 #pragma unroll
       for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const uint2*>(p + (size_t)c * 64 * 16);
     };
-    uint2 nxt[4];
-    load_codes(u0, nxt);
-    for (uint32_t u = u0; u < u1; ++u) {
-      uint2 cw[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) cw[c] = nxt[c];
-      if (u + 1 < u1) load_codes(u + 1, nxt);
-      f32x16_t acc0 = {}, acc1 = {};
+    auto decode = [&](const uint2 (&cw)[4], u32x4_t (&av)[8]) {
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         const uint32_t w = (st & 1) ? cw[st >> 1].y : cw[st >> 1].x;
-        u32x4_t av;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          av[e] = cbh[((16u * (st >> 1) + 4u * (st & 1) + e) << 8) + ((w >> (8 * e)) & 0xffu)];
-        const f16x8_t aop = __builtin_bit_cast(f16x8_t, av);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[0][st], acc0, 0, 0, 0);
-        if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[1][st], acc1, 0, 0, 0);
+          av[st][e] = cbh[((16u * (st >> 1) + 4u * (st & 1) + e) << 8) + ((w >> (8 * e)) & 0xffu)];
       }
-      // ---- screen: accumulator register i of this lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile
-      float tv[16];
-      if (a.row_term != nullptr) {
-        const float* tp = a.row_term + base_row + (u << 5) + 4u * h;
+    };
+    auto run = [&](auto two_tag) {
+      constexpr bool TWO = decltype(two_tag)::value;
+      uint2 cw1[4], cw2[4];
+      u32x4_t av[8];
+      load_codes(u0, cw1);
+      load_codes(u0 + 1, cw2);
+      decode(cw1, av);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 v = *reinterpret_cast<const float4*>(tp + 8 * j);
-          tv[4 * j] = v.x; tv[4 * j + 1] = v.y; tv[4 * j + 2] = v.z; tv[4 * j + 3] = v.w;
-        }
-      } else {
+      for (int c = 0; c < 4; ++c) cw1[c] = cw2[c];
+      load_codes(u0 + 2, cw2);
+      for (uint32_t u = u0; u < u1; ++u) {
+        // the rows' terms first: their L2 latency passes under the MFMAs
+        float tv[16];
+        if (a.row_term != nullptr) {
+          const float* tp = a.row_term + base_row + (u << 5) + 4u * h;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tv[i] = 0.f;
-      }
-      float m0 = INFINITY, m1 = INFINITY;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        m0 = fminf(m0, __fmaf_rn(acc0[i], a.c1, tv[i]));
-        m1 = fminf(m1, __fmaf_rn(acc1[i], a.c1, tv[i]));
-      }
-      const bool any = (m0 <= thr[0]) || (two && m1 <= thr[1]);
-      if (a.stats != nullptr && lane == 0) {
-        atomicAdd(&a.stats[0], (unsigned long long)(32u * count));
-        atomicAdd(&a.stats[2], 1ull);
-      }
-      if (__ballot(any) == 0ull) continue;  // the usual case
-      // ---- slow path: append the surviving (pair, row) pairs
-      if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[3], 1ull);
-      unsigned long long masks[2][16];
-      uint32_t total = 0u;
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const uint32_t v  = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
-          const float x     = __fmaf_rn(g == 0 ? acc0[i] : acc1[i], a.c1, tv[i]);
-          const bool keep   = (g == 0 || two) && x <= thr[g] && v < len;
-          masks[g][i]       = __ballot(keep);
-          total += (uint32_t)__popcll(masks[g][i]);
-        }
-      if (total == 0u) continue;
-      uint32_t base = 0u;
-      if (lane == 0) base = atomicAdd(a.surv_cnt, total);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[1], (unsigned long long)total);
-#pragma unroll
-      for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const unsigned long long m = masks[g][i];
-          if (m == 0ull) continue;
-          if ((m >> lane) & 1ull) {
-            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            const uint32_t v   = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
-            if (pos < a.surv_cap) a.surv[pos] = make_uint2(pairid[g], base_row + v);
-            else a.qflag[pairid[g] / a.n_probes] = 1u;  // survivor list full: the query is re-done by the LUT scan
+          for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(tp + 8 * j);
+            tv[4 * j] = v.x; tv[4 * j + 1] = v.y; tv[4 * j + 2] = v.z; tv[4 * j + 3] = v.w;
           }
-          base += (uint32_t)__popcll(m);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) tv[i] = 0.f;
         }
+        f32x16_t acc0 = {}, acc1 = {};
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const f16x8_t aop = __builtin_bit_cast(f16x8_t, av[st]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[0][st], acc0, 0, 0, 0);
+          if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[1][st], acc1, 0, 0, 0);
+        }
+        // decode of the next subtile (clamped to the last one: harmless repeat), code words of the one after
+        decode(cw1, av);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cw1[c] = cw2[c];
+        load_codes(u + 3, cw2);
+        // ---- screen: accumulator register i of this lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile
+        float m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          m0 = fminf(m0, __fmaf_rn(acc0[i], a.c1, tv[i]));
+          if constexpr (TWO) m1 = fminf(m1, __fmaf_rn(acc1[i], a.c1, tv[i]));
+        }
+        const bool any = (m0 <= thr[0]) || (TWO && m1 <= thr[1]);
+        if (a.stats != nullptr && lane == 0) {
+          atomicAdd(&a.stats[0], (unsigned long long)(32u * count));
+          atomicAdd(&a.stats[2], 1ull);
+        }
+        if (__ballot(any) == 0ull) continue;  // the usual case
+        // ---- slow path: append the surviving (pair, row) pairs (two passes over the 32 tests: count, then write)
+        if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[3], 1ull);
+        auto keep_mask = [&](const int g, const int i) {
+          const uint32_t v = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+          const float x    = __fmaf_rn(g == 0 ? acc0[i] : acc1[i], a.c1, tv[i]);
+          return __ballot(x <= thr[g] && v < len);
+        };
+        uint32_t total = 0u;
+#pragma unroll
+        for (int g = 0; g < (TWO ? 2 : 1); ++g)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) total += (uint32_t)__popcll(keep_mask(g, i));
+        if (total == 0u) continue;
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(wg_fill, total);  // LDS
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[1], (unsigned long long)total);
+#pragma unroll
+        for (int g = 0; g < (TWO ? 2 : 1); ++g)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const unsigned long long m = keep_mask(g, i);
+            if (m == 0ull) continue;
+            if ((m >> lane) & 1ull) {
+              const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+              const uint32_t v   = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+              if (pos < a.surv_cap) my_surv[pos] = make_uint2(pairid[g], base_row + v);
+              else a.qflag[pairid[g] / a.n_probes] = 1u;  // survivor list full: the query is re-done by the LUT scan
+            }
+            base += (uint32_t)__popcll(m);
+          }
+      }
+    };
+    if (u0 < u1) {
+      if (two) run(std::true_type{}); else run(std::false_type{});
     }
   }
+  __syncthreads();
+  if (threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(*wg_fill, a.surv_cap);
 }
 
 // ------------------------------------------------------------------ re-score
 struct rescore_params {
-  const uint2* surv;
-  const uint32_t* surv_cnt;
+  const uint2* surv;         // regions of surv_cap entries, one per workgroup of the filter
+  const uint32_t* surv_cnt;  // [gridDim.x] fill of every region
   uint32_t surv_cap;
   const uint32_t* probes;  // [n_pairs] list of every pair
   const float* rot_queries;
@@ -367,9 +391,10 @@ struct rescore_params {
 template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
 __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
 {
-  const uint32_t n = min(*a.surv_cnt, a.surv_cap);
-  for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x) {
-    const uint2 sv = a.surv[s];
+  const uint32_t n = a.surv_cnt[blockIdx.x];
+  const uint2* region = a.surv + (size_t)blockIdx.x * a.surv_cap;
+  for (uint32_t s = blockIdx.y * blockDim.x + threadIdx.x; s < n; s += gridDim.y * blockDim.x) {
+    const uint2 sv = region[s];
     const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
     if (a.qflag[q] != 0u) continue;  // re-done by the LUT scan
     if (a.filter_bits != nullptr) {
@@ -531,6 +556,8 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
 }  // namespace
 
 // ------------------------------------------------------------------ host side
+unsigned pq3_grid(const resources& res) { return (unsigned)std::max(8, res.num_cus / 8 * 8); }
+
 bool pq3_supported(const ivf_pq_index& idx, int k)
 {
   return idx.pq_bits == 8 && idx.pq_dim == 64 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && idx.rot_dim == 128;
@@ -585,7 +612,8 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = idx.centers_rot.data();
   f.cb16 = tb.cb16; f.codes = idx.codes.data(); f.list_offsets = idx.list_offsets.data(); f.list_sizes = idx.list_sizes.data();
   f.row_term = r.is_ip ? nullptr : tb.row_term; f.query_kth = r.query_kth; f.qflag = r.qflag;
-  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.counters; f.surv_cap = r.surv_cap;
+  const unsigned grid = pq3_grid(res);
+  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = r.surv_cap / grid;
   f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.unit_rows = r.unit_rows;
   f.sc = tb.sc; f.c1 = (r.is_ip ? -1.0f : -2.0f) / (tb.sc * tb.sc);
   f.cbmax = tb.cbmax; f.is_ip = r.is_ip; f.stats = r.stats;
@@ -598,19 +626,18 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   if (r.lut_mode == 0)      { f.eps = 1.0f / 65536.0f; f.alpha = 0.f; }
   else if (r.lut_mode == 1) { f.eps = r.acc_half ? 0.04f : 1.0f / 1024.0f; f.alpha = 64.0f / 16777216.0f; f.bound_max = 60000.f; }
   else                      { f.eps = r.acc_half ? 0.11f : 0.07f; f.alpha = 64.0f / 32768.0f; f.bound_max = 30000.f; }
-  const unsigned grid = (unsigned)std::max(8, res.num_cus / 8 * 8);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 16));
   profile_begin(res, "pq_filter_kernel");
-  hipLaunchKernelGGL(pq_filter_kernel, dim3(grid), dim3(kFThreads), 64 * 1024, res.stream, f);
+  hipLaunchKernelGGL(pq_filter_kernel, dim3(grid), dim3(kFThreads), 64 * 1024 + 16, res.stream, f);
   profile_end(res, "pq_filter_kernel");
 
   rescore_params s{};
-  s.surv = f.surv; s.surv_cnt = r.counters; s.surv_cap = r.surv_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
+  s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
   s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = idx.codes.data();
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
-  const dim3 rg(grid * 8), rb(256);
+  const dim3 rg(grid, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
   if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_kernel<0, false>), rg, rb, 0, res.stream, s);
   else if (r.lut_mode == 1) { if (r.acc_half) hipLaunchKernelGGL((pq_rescore_kernel<1, true>), rg, rb, 0, res.stream, s);
@@ -623,7 +650,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   hipLaunchKernelGGL(reset_flagged_kernel, dim3((unsigned)r.nq), dim3(256), 0, res.stream, r.qflag, r.nq, r.n_probes, r.k, r.head,
                      r.cand_d, r.cand_i);
   hipLaunchKernelGGL(fallback_items_kernel, dim3(grid * 4), dim3(256), 0, res.stream, r.sorted_pairs, r.pair_off, idx.n_lists,
-                     r.probes, r.n_probes, r.qflag, static_cast<work_item*>(r.fb_items), r.counters + 1);
+                     r.probes, r.n_probes, r.qflag, static_cast<work_item*>(r.fb_items), r.counters);
   profile_end(res, "pq_scan_kernel");
 }
 

@@ -25,8 +25,9 @@ struct pq3_run {
   uint32_t* cand_r;              // probe rank of the pool entries
   uint32_t* qflag;               // [nq] zeroed: queries handed back to the LUT scan
   uint32_t* qcnt;                // [nq] zeroed: pool fill
-  uint32_t* counters;            // [2] zeroed: survivors, fallback work items
-  void* surv;                    // [surv_cap] (pair, flat row)
+  uint32_t* counters;            // [1] zeroed: fallback work items
+  uint32_t* surv_cnt;            // [pq3_grid()] fill of every workgroup's survivor region (written by the filter)
+  void* surv;                    // [surv_cap] (pair, flat row), cut into one region per workgroup of the filter
   uint32_t surv_cap;
   void* units;                   // work units of the filter, pq3_max_units() entries
   uint32_t* unit_off;            // [n_lists + 1]
@@ -37,6 +38,7 @@ struct pq3_run {
   unsigned long long* stats;     // optional device [4]
 };
 
+unsigned pq3_grid(const resources& res);  // workgroups of the filter = survivor regions
 bool pq3_supported(const ivf_pq_index& idx, int k);
 size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows);
 // filter + re-score + fallback work items of the flagged queries (the caller launches the LUT scan on them)

@@ -2047,7 +2047,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows) : 0;
   uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 4, 1 << 20), 1 << 28) : 0u;
   if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
-  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)2 * bs_alloc + 2 : 0);
+  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)2 * bs_alloc + 2 + pq3_grid(res) : 0);
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0);
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, max_units);
@@ -2168,6 +2168,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.rot_queries = rot_q.data(); r.query_kth = query_kth.data();
         r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
         r.qflag = qstate.data(); r.qcnt = qstate.data() + bs_alloc; r.counters = qstate.data() + 2 * bs_alloc;
+        r.surv_cnt = qstate.data() + 2 * bs_alloc + 2;
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
         r.filter_bits = filter_bits;
@@ -2176,13 +2177,14 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.stats = st3.data();
         pq3_tail(res, idx, r);
         // queries the filter could not serve (no finite bound, operands beyond fp16, full pool): LUT scan of their pairs
-        a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters + 1;
+        a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters;
         a.xcd_ticket = tickets.data() + 3 * 8 * 32;
         launch(a);
         pq3_merge(res, r, top_d.data(), top_i.data());
         if (a.dbg & 1024) {
           auto hs = to_host(res, st3.data(), 4);
           auto hc = to_host(res, r.counters, 2);
+          hc[1] = hc[0];
           fprintf(stderr, "[pq_scan3] pairs screened %llu, survivors %llu (%.4f%%), subtiles %llu (slow path %llu), fallback pairs %u\n",
                   hs[0], hs[1], 100.0 * hs[1] / (double)std::max<unsigned long long>(1, hs[0]), hs[2], hs[3], hc[1]);
         }
