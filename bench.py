@@ -96,7 +96,7 @@ LUTS = {"f32": np.float32, "f16": np.float16, "fp8": np.uint8}
 # ---------------------------------------------------------------------------------------------- PMC passes (rank 0)
 PMC_SETS = [
     "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE",
-    "FETCH_SIZE",
+    "FETCH_SIZE SQ_VALU_MFMA_BUSY_CYCLES",
     "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum",
 ]
 
@@ -127,7 +127,7 @@ def run_pmc_passes(child_args, n_search, timeout_s=240):
                 return None
             n_disp = 0
             for r in csv.DictReader(open(files[0])):
-                if "pq_scan" in r["Kernel_Name"]:
+                if any(t in r["Kernel_Name"] for t in ("pq_scan", "pq_filter", "pq_rescore", "pool_merge")):
                     sums[r["Counter_Name"]] = sums.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                     n_disp += 1
             if n_disp == 0:
@@ -420,6 +420,8 @@ def main():
                 neighbors[q_lo:q_hi].copy_(ci[q_lo:q_hi, :args.k])
         return step
 
+    phase_ms = {}  # per-search HIP-event time of the tail-phase kernels of the last timed() call
+
     def timed(step, steps, warmup):
         for _ in range(warmup):
             step()
@@ -443,12 +445,17 @@ def main():
             elapsed = float(t.item())
         scan_ms = C.c_double(0)
         n_launch = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan_ms))
+        for nm in (b"pq_filter_kernel", b"pq_rescore_kernel"):
+            v = C.c_double(0)
+            lib().cuvsAmdProfileCollect(nm, C.byref(v))
+            phase_ms[nm.decode()] = v.value / max(steps, 1)
         ag_ms = C.c_double(0)
         lib().cuvsAmdProfileCollect(b"shard_all_gather", C.byref(ag_ms))
         return elapsed, scan_ms.value, n_launch, ag_ms.value
 
     # ------------------------------------------------------------------ timed region (headline variant)
     elapsed, scan_ms, n_launch, ag_ms = timed(make_step(args.lut, args.acc), args.steps, args.warmup)
+    headline_phase_ms = {k: round(v, 3) for k, v in phase_ms.items()}
 
     # ------------------------------------------------------------------ recall@10 vs exact search (untimed)
     ng = min(args.gt_queries, args.batch)
@@ -471,7 +478,7 @@ def main():
                              "scan_launches_per_step": v_n})
         # data-independent figure: the headline variant with every form of pruning off - no early stop
         # (CUVS_AMD_SCAN_DEBUG=8), no filter stage (CUVS_AMD_PQ_SCAN2=0), no head phase: all 64 gathers of every row
-        prune_off = {"CUVS_AMD_SCAN_DEBUG": "8", "CUVS_AMD_PQ_SCAN2": "0", "CUVS_AMD_PQ_HEAD_PROBES": "0"}
+        prune_off = {"CUVS_AMD_SCAN_DEBUG": "8", "CUVS_AMD_PQ_SCAN2": "0", "CUVS_AMD_PQ_SCAN3": "0", "CUVS_AMD_PQ_HEAD_PROBES": "0"}
         os.environ.update(prune_off)
         res_off = cuvs_amd.common.Resources()  # the switches are read once, when a handle is created
         for key in prune_off:
@@ -503,13 +510,14 @@ def main():
     # logical scan rate of SURVEY 8d (code bytes of every probed list per kernel second) is kept as `logical_scan_gbs`:
     # the list-major schedule serves a list byte from L2 many times per HBM fetch, so that figure exceeds the HBM peak
     # by design and is no utilisation.
-    roofline = {"bound": None, "kernel": "pq_scan_kernel + pq_scan2_kernel", "achieved": None, "peak": None,
+    roofline = {"bound": None, "kernel": "pq_scan_kernel (head phase) + pq_filter_kernel + pq_rescore_kernel (tail phase)", "achieved": None, "peak": None,
                 "unit": "Gcycles/s", "frac": None, "traffic": None, "logical_scan_gbs": round(logical, 1),
                 "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 3),
                 "launches": n_launch, "launches_per_step": per_step, "algorithmic_bytes_per_step": probe_bytes,
                 "kernel_ms_per_step": round(avg_ms * per_step, 3), "early_stop_off_kernel_ms_per_step": early_stop_off_ms,
-                "note": "frac = floor / kernel: busy cycles of the busiest pipe (VALU issue cycles, or LDS array cycles minus "
-                        "bank-conflict cycles, or HBM bytes / 8 TB/s) over the kernel's cycles, all from rocprofv3 PMC passes "
+                "tail_phase_ms_per_step": headline_phase_ms,
+                "note": "frac = floor / kernel: busy cycles of the busiest pipe (VALU issue cycles, matrix-core busy cycles, LDS array "
+                        "cycles minus bank-conflict cycles, or HBM bytes / 8 TB/s) over the cycles of the scan kernels of one search, all from rocprofv3 PMC passes "
                         "of this workload (GRBM_GUI_ACTIVE, SQ_ACTIVE_INST_VALU, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, "
                         "FETCH_SIZE x 2 + WRITE_SIZE). The per-instruction ceilings behind the floors are microbenchmarked "
                         "in profiles/r03_lds_gather_bench.json and profiles/r03_valu_rate_bench.json"}
@@ -531,6 +539,7 @@ def main():
                   "lds_bank_conflict_share": pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(pmc.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0),
                   "lds_gather_frac": pmc.get("SQ_INSTS_LDS", 0.0) * 2.0 / (cycles * N_CU),
                   "valu_busy": pmc.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (cycles * N_SIMD),
+                  "mfma_busy": pmc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cycles * N_SIMD),
                   "tcc_hit_rate": pmc.get("TCC_HIT_sum", 0.0) / max(pmc.get("TCC_HIT_sum", 0.0) + pmc.get("TCC_MISS_sum", 0.0), 1.0)}
             fr["lds_floor"] = fr["lds_busy"] * (1.0 - fr["lds_bank_conflict_share"])  # conflict-free LDS array cycles
             fr["valu_insts_per_step"] = pmc.get("SQ_INSTS_VALU", 0.0)
@@ -540,10 +549,11 @@ def main():
             roofline["hbm_bytes_per_step"] = int(hbm_bytes)
             roofline["pmc_cycles_per_step"] = int(cycles)
             roofline["pmc_kernel_ms_at_2p4ghz"] = round(kernel_s * 1e3, 3)
-            bound, frac = max((("lds", fr["lds_floor"]), ("valu", fr["valu_busy"]), ("hbm", fr["hbm_frac"])), key=lambda t: t[1])
+            bound, frac = max((("lds", fr["lds_floor"]), ("valu", fr["valu_busy"]), ("mfma", fr["mfma_busy"]), ("hbm", fr["hbm_frac"])),
+                              key=lambda t: t[1])
             roofline["bound"], roofline["frac"] = bound, round(frac, 4)
             clock_ghz = cycles / max(t_ref, 1e-9) / 1e9  # effective clock of the profiled cycles over the un-profiled time
-            pipes = {"valu": N_SIMD, "lds": N_CU, "hbm": 1}[bound]
+            pipes = {"valu": N_SIMD, "mfma": N_SIMD, "lds": N_CU, "hbm": 1}[bound]
             roofline["peak"] = round(pipes * clock_ghz, 1) if bound != "hbm" else HBM_PEAK_GBS
             roofline["achieved"] = round(frac * roofline["peak"], 1)
             roofline["unit"] = "Gcycles/s" if bound != "hbm" else "GB/s"
@@ -554,7 +564,7 @@ def main():
             try:
                 tj = json.load(open(tfile))
                 roofline.update({k: tj[k] for k in ("hbm_frac", "lds_busy", "lds_bank_conflict_share", "lds_gather_frac", "lds_floor",
-                                                    "valu_busy", "tcc_hit_rate", "bound", "frac", "achieved", "peak", "unit") if k in tj})
+                                                    "valu_busy", "mfma_busy", "tcc_hit_rate", "bound", "frac", "achieved", "peak", "unit") if k in tj})
                 roofline["traffic"] = int(tj["hbm_bytes_per_step"] / per_step) if "hbm_bytes_per_step" in tj else None
                 roofline["pmc_source"] = "profiles/r03_pq_scan_pmc.json (committed PMC passes of the same command)"
             except Exception:

@@ -191,24 +191,33 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
   const uint32_t ql = (uint32_t)lane & 31u, h = (uint32_t)lane >> 5;
   const uint32_t* cbh = cb + h * (8u * 256u);  // this lane's half of every 16-subspace chunk
 
-  // XCD x owns the x-th eighth of the (list-sorted) unit array; its waves draw units through one ticket counter
+  // XCD x owns the x-th eighth of the (list-sorted) unit array; its waves draw units through one ticket counter (the
+  // units of a list run on one XCD at about the same time and share its L2). A wave whose XCD has run dry moves on to
+  // the next XCD's share: the shares are equal in units, not in work.
   const uint32_t n_units = *a.n_units;
-  const uint32_t xcd = blockIdx.x & 7u, chunk = (n_units + 7u) / 8u;
-  const uint32_t share0 = min(n_units, xcd * chunk), share_len = min(chunk, n_units - share0);
-  const filter_unit* share = a.units + share0;
-  uint32_t* ticket = a.xcd_ticket + xcd * 32;
+  const uint32_t chunk = (n_units + 7u) / 8u;
+  uint32_t xcd = blockIdx.x & 7u, hops = 0u;
   const uint4* codes16 = reinterpret_cast<const uint4*>(a.codes);
 
+  unsigned long long st_pairs = 0, st_surv = 0, st_sub = 0, st_slow = 0, st_units = 0, st_t[3] = {0, 0, 0};
   for (;;) {
+    const uint32_t share0 = min(n_units, xcd * chunk), share_len = min(chunk, n_units - share0);
+    const filter_unit* share = a.units + share0;
     uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(ticket, 1u);
+    if (lane == 0) t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
     t = __builtin_amdgcn_readfirstlane(t);
-    if (t >= share_len) break;
+    if (t >= share_len) {
+      if (++hops == 8u) break;
+      xcd = (xcd + 1u) & 7u;
+      continue;
+    }
     const uint4 uu = *reinterpret_cast<const uint4*>(share + t);
     const uint32_t L = __builtin_amdgcn_readfirstlane(uu.x), first = __builtin_amdgcn_readfirstlane(uu.y),
                    count = __builtin_amdgcn_readfirstlane(uu.z), row0 = __builtin_amdgcn_readfirstlane(uu.w);
     const uint32_t base_row = a.list_offsets[L], len = a.list_sizes[L];
     const bool two = count > 32u;  // wave-uniform: the second group of 32 queries
+    const unsigned long long t_unit = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_slow = 0ull;
 
     // ---- B operands: the item's query residuals as fp16, lane = (query ql of group g, K half h)
     f16x8_t bop[2][8];
@@ -320,47 +329,47 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
           if constexpr (TWO) m1 = fminf(m1, __fmaf_rn(acc1[i], a.c1, tv[i]));
         }
         const bool any = (m0 <= thr[0]) || (TWO && m1 <= thr[1]);
-        if (a.stats != nullptr && lane == 0) {
-          atomicAdd(&a.stats[0], (unsigned long long)(32u * count));
-          atomicAdd(&a.stats[2], 1ull);
-        }
+        if (a.stats != nullptr) { st_pairs += 32u * count; st_sub += 1u; }
         if (__ballot(any) == 0ull) continue;  // the usual case
-        // ---- slow path: append the surviving (pair, row) pairs (two passes over the 32 tests: count, then write)
-        if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[3], 1ull);
-        auto keep_mask = [&](const int g, const int i) {
-          const uint32_t v = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
-          const float x    = __fmaf_rn(g == 0 ? acc0[i] : acc1[i], a.c1, tv[i]);
-          return __ballot(x <= thr[g] && v < len);
-        };
-        uint32_t total = 0u;
+        // ---- slow path (9 % of the subtiles, one or two survivors each): the few lanes that hold a survivor go through
+        // their own 16 (32) values and append them one by one through the workgroup's LDS counter
+        if (a.stats != nullptr) st_slow += 1u;
+        const unsigned long long t_s0 = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
+        if (any) {
 #pragma unroll
-        for (int g = 0; g < (TWO ? 2 : 1); ++g)
+          for (int g = 0; g < (TWO ? 2 : 1); ++g)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) total += (uint32_t)__popcll(keep_mask(g, i));
-        if (total == 0u) continue;
-        uint32_t base = 0u;
-        if (lane == 0) base = atomicAdd(wg_fill, total);  // LDS
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (a.stats != nullptr && lane == 0) atomicAdd(&a.stats[1], (unsigned long long)total);
-#pragma unroll
-        for (int g = 0; g < (TWO ? 2 : 1); ++g)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const unsigned long long m = keep_mask(g, i);
-            if (m == 0ull) continue;
-            if ((m >> lane) & 1ull) {
-              const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-              const uint32_t v   = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
-              if (pos < a.surv_cap) my_surv[pos] = make_uint2(pairid[g], base_row + v);
-              else a.qflag[pairid[g] / a.n_probes] = 1u;  // survivor list full: the query is re-done by the LUT scan
+            for (int i = 0; i < 16; ++i) {
+              const uint32_t v = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+              const float x    = __fmaf_rn(g == 0 ? acc0[i] : acc1[i], a.c1, tv[i]);
+              if (x <= thr[g] && v < len) {
+                const uint32_t pos = atomicAdd(wg_fill, 1u);  // LDS
+                if (pos < a.surv_cap) my_surv[pos] = make_uint2(pairid[g], base_row + v);
+                else a.qflag[pairid[g] / a.n_probes] = 1u;  // survivor region full: the query is re-done by the LUT scan
+                if (a.stats != nullptr) st_surv += 1u;
+              }
             }
-            base += (uint32_t)__popcll(m);
-          }
+        }
+        if (a.stats != nullptr) t_slow += __builtin_readcyclecounter() - t_s0;
       }
     };
+    const unsigned long long t_loop = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
     if (u0 < u1) {
       if (two) run(std::true_type{}); else run(std::false_type{});
     }
+    if (a.stats != nullptr) {
+      const unsigned long long t_end = __builtin_readcyclecounter();
+      st_t[0] += t_loop - t_unit;  // unit prologue (B operands, thresholds)
+      st_t[1] += t_end - t_loop;   // subtile loop
+      st_t[2] += t_slow;           // of which slow path
+      st_units += 1u;
+    }
+  }
+  if (a.stats != nullptr) atomicAdd(&a.stats[1], st_surv);  // counted per lane
+  if (a.stats != nullptr && lane == 0) {  // one flush per wave (atomics inside the loop cost more than the loop)
+    atomicAdd(&a.stats[0], st_pairs); atomicAdd(&a.stats[2], st_sub);
+    atomicAdd(&a.stats[3], st_slow);  atomicAdd(&a.stats[4], st_t[0]); atomicAdd(&a.stats[5], st_t[1]);
+    atomicAdd(&a.stats[6], st_t[2]);  atomicAdd(&a.stats[7], st_units);
   }
   __syncthreads();
   if (threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(*wg_fill, a.surv_cap);
@@ -593,7 +602,9 @@ size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_ro
 {
   uint32_t max_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_len = std::max(max_len, v);
-  const uint32_t ur = std::max<uint32_t>(2048u, (uint32_t)round_up((int64_t)(max_len + 15) / 16, 64));  // <= 16 chunks per list
+  // a unit is a chunk of 4096 rows of a list for one group of queries (the B operands and thresholds are built once per
+  // unit: ~23 k cycles against ~250 k for the rows); a list is cut into at most 16 row chunks
+  const uint32_t ur = std::max<uint32_t>(4096u, (uint32_t)round_up((int64_t)(max_len + 15) / 16, 64));
   *unit_rows = ur;
   return (size_t)16 * ((size_t)n_pairs / 64 + idx.n_lists + 1);
 }

@@ -2042,7 +2042,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<uint32_t> tickets(res, 4 * 8 * 32);
   // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): decode + MFMA filter, exact re-score of the survivors
   const bool metric_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
-  const bool use3 = head > 0 && !sharded && !metric_ip && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0;
+  const bool use3 = head > 0 && !metric_ip && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0;
   uint32_t unit_rows = 0;
   const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows) : 0;
   uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 4, 1 << 20), 1 << 28) : 0u;
@@ -2172,7 +2172,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
         r.filter_bits = filter_bits;
-        dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 4 : 0);
+        dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 8 : 0);
         if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
         r.stats = st3.data();
         pq3_tail(res, idx, r);
@@ -2182,7 +2182,10 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         launch(a);
         pq3_merge(res, r, top_d.data(), top_i.data());
         if (a.dbg & 1024) {
-          auto hs = to_host(res, st3.data(), 4);
+          auto hs = to_host(res, st3.data(), 8);
+          fprintf(stderr, "[pq_scan3] units %llu; wave cycles per unit: prologue %.0f, loop %.0f (slow path %.0f); per subtile %.0f\n", hs[7],
+                  (double)hs[4] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[7]),
+                  (double)hs[6] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[2]));
           auto hc = to_host(res, r.counters, 2);
           hc[1] = hc[0];
           fprintf(stderr, "[pq_scan3] pairs screened %llu, survivors %llu (%.4f%%), subtiles %llu (slow path %llu), fallback pairs %u\n",

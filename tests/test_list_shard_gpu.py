@@ -44,20 +44,23 @@ def test_world_size_one_all_gather_is_identity():
     comm.close()
 
 
-@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product"])
-def test_two_list_shards_equal_the_unsharded_index(metric):
+@pytest.mark.parametrize("metric,shape", [("sqeuclidean", "small"), ("inner_product", "small"), ("sqeuclidean", "c3")])
+def test_two_list_shards_equal_the_unsharded_index(metric, shape):
     import torch
     import cuvs_amd
     from cuvs_amd.neighbors import ivf_pq, ivf_pq_sharded as sh
 
     res = cuvs_amd.common.Resources()
-    x, q = _data(seed=6)
+    # "c3": the bench kernels' shape (128-d, pq_dim 64, two-phase schedule: head scan, matrix-core filter, pool merge;
+    # a shard searched alone has no bound for queries whose nearest probe is foreign: handed back to the LUT scan)
+    x, q = _data(seed=6) if shape == "small" else _data(n=40000, d=128, nq=300, seed=7)
     xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
     ids = torch.arange(len(x), dtype=torch.int64, device="cuda")
-    k, n_probes, world = 10, 6, 2
+    k, n_probes, world = (10, 6, 2) if shape == "small" else (10, 12, 2)
+    pq_dim = 16 if shape == "small" else 64
 
     def params():
-        return ivf_pq.IndexParams(n_lists=24, pq_dim=16, kmeans_n_iters=10, metric=metric, add_data_on_build=False)
+        return ivf_pq.IndexParams(n_lists=24, pq_dim=pq_dim, kmeans_n_iters=10, metric=metric, add_data_on_build=False)
 
     full = ivf_pq.build(params(), xt, resources=res)
     ivf_pq.extend(full, xt, ids, resources=res)
