@@ -457,6 +457,260 @@ __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
   }
 }
 
+// ------------------------------------------------------------------ single-query list scan (head phase, handed-back pairs)
+// One (query, list) pair per work item with no bound to prune against: the LUT scan kernel of ivf_pq_search.hip spends
+// such an item on top-list bookkeeping (16 wave lists with serial insertions while the bounds are cold, then their
+// merge: ~130 k cycles for 6 k rows). Here the workgroup builds the query's LUT, writes the score KEY of every row of
+// the list to LDS and selects the k smallest by (score, row) with three histogram passes - select_k's scheme
+// (select_k.hip) on data that never leaves the LDS. Scores are the reference's (same entries, same summation order).
+struct head_params {
+  const work_item* items;
+  const uint32_t* item_begin;  // device scalars (item_begin == nullptr: from 0)
+  const uint32_t* item_end;
+  uint32_t n_lists;
+  uint32_t* xcd_ticket;
+  const uint32_t* sorted_pairs;
+  const float* rot_queries;
+  const float* centers_rot;
+  const float* pq_centers;
+  const uint8_t* codes;
+  const uint32_t* list_offsets;
+  const uint32_t* list_sizes;
+  float* out_d;
+  uint32_t* out_i;
+  uint32_t* query_kth;
+  uint32_t n_probes, rot_dim, k, cap_rows;
+  int is_ip;
+  const uint32_t* filter_bits;
+  const int64_t* indices;
+  unsigned long long* stats;  // optional [8]: workgroup cycles in header / LUT / scores / select / output, items
+};
+
+constexpr int kHCand = 256;  // candidates of a list chunk at or below its threshold (about k of them)
+
+template <int LUT, bool ACC_HALF, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void pq_head_kernel(const head_params a)
+{
+  constexpr bool LUT32 = LUT == 0 || (LUT == 2 && !ACC_HALF);
+  using lut_t = std::conditional_t<LUT32, float, _Float16>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  lut_t* lut      = reinterpret_cast<lut_t*>(smem);                              // [64][256]
+  float* rv       = reinterpret_cast<float*>(smem + 64 * 256 * sizeof(lut_t));   // [128] residual (L2) / query (IP)
+  float* cv       = rv + 128;                                                    // [128] list centre
+  unsigned long long* min64 = reinterpret_cast<unsigned long long*>(cv + 128);   // [2]
+  int* ctrl       = reinterpret_cast<int*>(min64 + 2);                           // [8]
+  uint32_t* tk    = reinterpret_cast<uint32_t*>(ctrl + 8);                       // [NT] smallest key of every thread
+  uint32_t* ckey  = tk + NT;                                                     // [2][kHCand] candidates (two buffers)
+  uint32_t* crow  = ckey + 2 * kHCand;                                           // [2][kHCand]
+  uint32_t* keys  = crow + 2 * kHCand;                                           // [cap_rows] score keys of the current chunk
+  __shared__ work_item cur;
+
+  const int tid = threadIdx.x;
+  const uint32_t item0   = a.item_begin ? *a.item_begin : 0u;
+  const uint32_t n_items = *a.item_end - item0;
+  const uint32_t xcd = blockIdx.x & 7u, chunk = (n_items + 7u) / 8u;
+  const uint32_t share0 = min(n_items, xcd * chunk), share_len = min(chunk, n_items - share0);
+  const work_item* share = a.items + item0 + share0;
+  const uint4* codes16   = reinterpret_cast<const uint4*>(a.codes);
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
+      cur = t < share_len ? share[t] : work_item{0u, 0u, 0u, 0xffffffffu};
+    }
+    __syncthreads();
+    const work_item item = cur;
+    if (item.pad == 0xffffffffu) break;  // workgroup-uniform
+    unsigned long long t_prev = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
+    auto phase = [&](int which) {
+      if (a.stats != nullptr && tid == 0) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        atomicAdd(&a.stats[which], t - t_prev);
+        t_prev = t;
+      }
+    };
+    const uint32_t L        = item.list >= a.n_lists ? item.list - a.n_lists : item.list;
+    const uint32_t base_row = a.list_offsets[L], len = a.list_sizes[L];
+    const uint32_t pair     = a.sorted_pairs[item.first];
+    const uint32_t q        = pair / a.n_probes;
+    if (tid < (int)a.rot_dim) {
+      const float c = a.centers_rot[(size_t)L * a.rot_dim + tid];
+      float v       = a.rot_queries[(size_t)q * a.rot_dim + tid];
+      if (!a.is_ip) v -= c;
+      rv[tid] = v;
+      cv[tid] = c;
+    }
+    __syncthreads();
+    phase(0);
+    // ---- LUT (create_lut_impl.cuh:17-78), entry (s, code) at s * 256 + code; the codebook values of 8 entries are
+    // loaded before any is used (one L2 round trip per batch instead of one per entry)
+#pragma unroll 1
+    for (uint32_t e0 = tid; e0 < 64u * 256u; e0 += 8u * NT) {
+      float p0[8], p1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t e = e0 + (uint32_t)j * NT, sb = e >> 8, code = e & 255u;
+        p0[j] = a.pq_centers[(size_t)(sb * 2 + 0) * 256 + code];
+        p1[j] = a.pq_centers[(size_t)(sb * 2 + 1) * 256 + code];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t e = e0 + (uint32_t)j * NT, sb = e >> 8;
+        const float q0 = rv[sb * 2], q1 = rv[sb * 2 + 1];
+        float v;
+        if (!a.is_ip) {
+          const float d0 = q0 - p0[j], d1 = q1 - p1[j];
+          v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+        } else {
+          v = __fmaf_rn(-q0, cv[sb * 2], 0.f);
+          v = __fmaf_rn(-q0, p0[j], v);
+          v = __fmaf_rn(-q1, cv[sb * 2 + 1], v);
+          v = __fmaf_rn(-q1, p1[j], v);
+        }
+        if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
+        if constexpr (LUT32) lut[e] = v; else lut[e] = to_lut_half(v);
+      }
+    }
+    if (tid == 0) ctrl[0] = 0;  // candidates kept so far (buffer 0)
+    __syncthreads();
+    phase(1);
+    const int k = (int)a.k;
+    int buf = 0;  // candidate buffer holding the kept candidates
+    // ---- the list in chunks of cap_rows rows (one chunk for all but very long lists)
+    for (uint32_t c0 = 0; c0 < len; c0 += a.cap_rows) {
+      const uint32_t clen = min(a.cap_rows, len - c0);
+      // score keys of the chunk's rows (filtered rows: invalid)
+      uint32_t my_min = 0xffffffffu;
+      for (uint32_t v = tid; v < clen; v += NT) {
+        const uint32_t fr = base_row + c0 + v;
+        const uint4* cp   = codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u);
+        uint4 cw[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cw[c] = cp[c * 64];
+        float af    = 0.f;
+        _Float16 ah = (_Float16)0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t ws[4] = {cw[c].x, cw[c].y, cw[c].z, cw[c].w};
+#pragma unroll
+          for (int b = 0; b < 16; ++b) {
+            const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+            const lut_t e       = lut[((c * 16 + b) << 8) + code];
+            if constexpr (LUT32) af += e;
+            else if constexpr (ACC_HALF) ah += e;
+            else af += (float)e;
+          }
+        }
+        const float score = ACC_HALF ? (float)ah : af;
+        bool keep = true;
+        if (a.filter_bits != nullptr) {
+          const int64_t sid = a.indices[fr];
+          keep = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
+        }
+        const uint32_t key = keep ? float_to_key(score) : 0xffffffffu;  // (a NaN score has a key beyond every finite one as well)
+        keys[v] = key;
+        my_min  = min(my_min, key);
+      }
+      // minima of groups of four threads (DPP): NT / 4 >= 128 groups, each a set of rows of its own
+      my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0xb1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+      my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0x4e, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+      if ((tid & 3) == 0) tk[tid >> 2] = my_min;
+      __syncthreads();
+      phase(2);
+      // ---- candidates of the chunk. The scores of a list share their leading bits: a histogram select serializes on a
+      // few LDS counters (33 k cycles measured), a bitonic sort is a chain of barriers. Instead: the k-th smallest of the
+      // group minima bounds the chunk's k-th smallest key from above (k groups hold k different rows at or below it),
+      // found by counting ranks over broadcast reads; the keys at or below it - about k - join the candidates.
+      constexpr int NG = NT / 4;
+      const int k_c   = (int)min((uint32_t)k, clen);
+      const int kept  = ctrl[0];
+      if (tid < NG) {
+        const uint32_t mine = tk[tid];
+        const uint4* tk4    = reinterpret_cast<const uint4*>(tk);
+        int r = 0;
+#pragma unroll 4
+        for (int j = 0; j < NG / 4; ++j) {  // 16-byte broadcast reads, four in flight
+          const uint4 o = tk4[j];
+          r += (o.x < mine || (o.x == mine && 4 * j + 0 < tid)) ? 1 : 0;
+          r += (o.y < mine || (o.y == mine && 4 * j + 1 < tid)) ? 1 : 0;
+          r += (o.z < mine || (o.z == mine && 4 * j + 2 < tid)) ? 1 : 0;
+          r += (o.w < mine || (o.w == mine && 4 * j + 3 < tid)) ? 1 : 0;
+        }
+        if (r == k_c - 1) ctrl[1] = (int)mine;
+        if (tid == 0) ctrl[2] = kept;  // append position
+      }
+      __syncthreads();
+      const uint32_t tau = (uint32_t)ctrl[1];
+      uint32_t* bk = ckey + buf * kHCand;
+      uint32_t* br = crow + buf * kHCand;
+      for (uint32_t i = tid; i < clen; i += NT) {
+        const uint32_t key = keys[i];
+        if (key <= tau && key != 0xffffffffu) {
+          const int pos = atomicAdd(&ctrl[2], 1);
+          if (pos < kHCand) { bk[pos] = key; br[pos] = c0 + i; }
+        }
+      }
+      __syncthreads();
+      int cnt = ctrl[2];
+      if (cnt > kHCand) {
+        // masses of equal scores at the threshold: the chunk's k smallest (key, row) one after the other instead
+        unsigned long long last = 0ull;
+        bool first = true;
+        cnt = kept;
+        for (int r = 0; r < k_c; ++r) {
+          if (tid == 0) min64[0] = ~0ull;
+          __syncthreads();
+          unsigned long long best = ~0ull;
+          for (uint32_t i = tid; i < clen; i += NT) {
+            const unsigned long long v = ((unsigned long long)keys[i] << 32) | (unsigned long long)(c0 + i);
+            if ((first || v > last) && keys[i] != 0xffffffffu && v < best) best = v;
+          }
+          if (best != ~0ull) atomicMin(&min64[0], best);
+          __syncthreads();
+          last  = min64[0];
+          first = false;
+          if (last == ~0ull) break;  // workgroup-uniform
+          if (tid == 0) { bk[cnt] = (uint32_t)(last >> 32); br[cnt] = (uint32_t)last; }
+          ++cnt;
+          __syncthreads();
+        }
+      }
+      // ---- keep the k best of the candidates, in (key, row) order, in the other buffer
+      uint32_t* nk = ckey + (buf ^ 1) * kHCand;
+      uint32_t* nr = crow + (buf ^ 1) * kHCand;
+      for (int t = tid; t < cnt; t += NT) {
+        const uint32_t key = bk[t], row = br[t];
+        int r = 0;
+        for (int j = 0; j < cnt; ++j) {
+          const uint32_t ok = bk[j], orow = br[j];
+          r += (ok < key || (ok == key && orow < row)) ? 1 : 0;
+        }
+        if (r < k) { nk[r] = key; nr[r] = row; }
+      }
+      if (tid == 0) ctrl[0] = min(cnt, k);
+      buf ^= 1;
+      __syncthreads();
+      phase(3);
+    }
+    // ---- the pair's candidate row, ordered by (score, row) (the caller pre-filled it "invalid")
+    {
+      const int cnt = ctrl[0];
+      const uint32_t* bk = ckey + buf * kHCand;
+      const uint32_t* br = crow + buf * kHCand;
+      if (tid < cnt) {
+        const uint32_t key = bk[tid];
+        const size_t o     = (size_t)pair * a.k + tid;
+        a.out_d[o]         = key_to_float(key);
+        a.out_i[o]         = base_row + br[tid];
+        if (tid == k - 1 && key < 0xff800000u) atomicMin(&a.query_kth[q], key);
+      }
+    }
+    phase(4);
+    if (a.stats != nullptr && tid == 0) atomicAdd(&a.stats[5], 1ull);
+  }
+}
+
 // ------------------------------------------------------------------ flagged queries: back to the LUT scan, pair by pair
 __global__ void reset_flagged_kernel(const uint32_t* __restrict__ qflag, int64_t nq, uint32_t n_probes, uint32_t k, uint32_t head,
                                      float* __restrict__ cand_d, uint32_t* __restrict__ cand_i)
@@ -663,6 +917,42 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   hipLaunchKernelGGL(fallback_items_kernel, dim3(grid * 4), dim3(256), 0, res.stream, r.sorted_pairs, r.pair_off, idx.n_lists,
                      r.probes, r.n_probes, r.qflag, static_cast<work_item*>(r.fb_items), r.counters);
   profile_end(res, "pq_scan_kernel");
+}
+
+static size_t head_smem(int lut_mode, bool acc_half, int nt, uint32_t cap_rows)
+{
+  const bool lut32 = lut_mode == 0 || (lut_mode == 2 && !acc_half);
+  return (size_t)64 * 256 * (lut32 ? 4 : 2) + 2 * 128 * 4 + 16 + 32 + (size_t)nt * 4 + 4 * kHCand * 4 + (size_t)cap_rows * 4;
+}
+
+void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
+{
+  head_params a{};
+  a.items = static_cast<const work_item*>(h.items); a.item_begin = h.item_begin; a.item_end = h.item_end; a.n_lists = idx.n_lists;
+  a.xcd_ticket = h.xcd_ticket; a.sorted_pairs = h.sorted_pairs; a.rot_queries = h.rot_queries; a.centers_rot = idx.centers_rot.data();
+  a.pq_centers = idx.pq_centers.data(); a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data();
+  a.list_sizes = idx.list_sizes.data(); a.out_d = h.cand_d; a.out_i = h.cand_i; a.query_kth = h.query_kth;
+  a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip;
+  a.filter_bits = h.filter_bits; a.indices = idx.indices.data(); a.stats = h.stats;
+  // fp16 LUT (32 KiB): two 512-thread workgroups per CU with 8192 score keys each - one streams its list while the
+  // other selects; fp32 LUT (64 KiB): one 1024-thread workgroup with 16384 keys. Longer lists are scanned in chunks.
+  const bool lut32 = h.lut_mode == 0 || (h.lut_mode == 2 && !h.acc_half);
+  const int nt = lut32 ? 1024 : 512;
+  a.cap_rows   = lut32 ? 16384u : 8192u;
+  if (h.max_list_len > 0) a.cap_rows = std::min<uint32_t>(a.cap_rows, (uint32_t)round_up(h.max_list_len, 64));
+  const size_t smem   = head_smem(h.lut_mode, h.acc_half != 0, nt, a.cap_rows);
+  const unsigned grid = pq3_grid(res) * (lut32 ? 1u : 2u);
+  auto go = [&](auto kern) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    profile_begin(res, "pq_scan_kernel");
+    profile_begin(res, "pq_head_kernel");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nt), smem, res.stream, a);
+    profile_end(res, "pq_head_kernel");
+    profile_end(res, "pq_scan_kernel");
+  };
+  if (h.lut_mode == 0)      go(pq_head_kernel<0, false, 1024>);
+  else if (h.lut_mode == 1) { if (h.acc_half) go(pq_head_kernel<1, true, 512>); else go(pq_head_kernel<1, false, 512>); }
+  else                      { if (h.acc_half) go(pq_head_kernel<2, true, 512>); else go(pq_head_kernel<2, false, 1024>); }
 }
 
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)

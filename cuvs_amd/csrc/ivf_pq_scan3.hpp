@@ -38,6 +38,24 @@ struct pq3_run {
   unsigned long long* stats;     // optional device [4]
 };
 
+// single-query list scan with the k smallest selected in LDS (head phase, pairs of handed-back queries)
+struct pq3_head {
+  const void* items;             // work_item[]: single-pair items
+  const uint32_t* item_begin;    // device scalars (nullptr: from 0)
+  const uint32_t* item_end;
+  uint32_t* xcd_ticket;          // 8 x 32 zeroed words
+  const uint32_t* sorted_pairs;
+  const float* rot_queries;
+  float* cand_d;
+  uint32_t* cand_i;
+  uint32_t* query_kth;
+  uint32_t n_probes, k, max_list_len;
+  int is_ip, lut_mode, acc_half;
+  const uint32_t* filter_bits;
+  unsigned long long* stats;     // optional device [8] (CUVS_AMD_SCAN_DEBUG=2048)
+};
+void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h);
+
 unsigned pq3_grid(const resources& res);  // workgroups of the filter = survivor regions
 bool pq3_supported(const ivf_pq_index& idx, int k);
 size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows);

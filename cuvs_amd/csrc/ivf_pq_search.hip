@@ -2052,6 +2052,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, max_units);
   dev_buf<work_item> fb_items(res, use3 ? (size_t)n_pairs_max : 0);
+  uint32_t max_list_len = 0;
+  for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -2090,7 +2092,12 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 &&  // (k <= 64 excludes the non-fused path)
                 ((lut_half && qpb == 4) || (!lut_half && qpb == 2));
     use2 = use2 && res.tune.pq_scan2 != 0 && !use3;
-    build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
+    // with the matrix-core tail phase the LUT scan only sees the head pairs - nearly always one query per list at the
+    // bench shape (10k queries, 16384 lists) - and the pairs of handed-back queries: single-query items and a
+    // single-query LUT (a quarter of the LUT build and of the accumulate work of the 4-query interleave)
+    const int lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0);
+    const bool head1 = use3 && !glut;
+    build_work_items(res, labels, n_pairs, n_labels, head1 ? 1 : qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data(), (int)idx.n_lists, use2 ? 8 : qpb);
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
@@ -2150,10 +2157,27 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         else               launch_scan_qpb<__half, __half, 1>(res, sa, smem, grid, bits8, big_k);
       }
     };
+    auto launch1 = [&](const scan_args& sa) {  // single-pair work items: scores of the whole list in LDS, k smallest selected there
+      pq3_head h{};
+      h.items = sa.items; h.item_begin = sa.item_begin; h.item_end = sa.item_end; h.xcd_ticket = sa.xcd_ticket;
+      h.sorted_pairs = sa.sorted_pairs; h.rot_queries = sa.rot_queries; h.cand_d = sa.out_d; h.cand_i = sa.out_i;
+      h.query_kth = sa.query_kth; h.n_probes = n_probes; h.k = (uint32_t)k; h.max_list_len = max_list_len; h.is_ip = sa.is_ip;
+      h.lut_mode = lut_mode; h.acc_half = acc_half ? 1 : 0; h.filter_bits = filter_bits;
+      dev_buf<unsigned long long> hst(res, (sa.dbg & 2048) ? 8 : 0);
+      if (sa.dbg & 2048) HIP_TRY(hipMemsetAsync(hst.data(), 0, hst.bytes(), res.stream));
+      h.stats = hst.data();
+      pq3_head_scan(res, idx, h);
+      if (sa.dbg & 2048) {
+        auto hs = to_host(res, hst.data(), 8);
+        const double n = (double)std::max<unsigned long long>(1, hs[5]);
+        fprintf(stderr, "[pq_head] items %llu; workgroup cycles per item: header %.0f, LUT %.0f, scores %.0f, select %.0f, output %.0f\n", hs[5],
+                hs[0] / n, hs[1] / n, hs[2] / n, hs[3] / n, hs[4] / n);
+      }
+    };
     if (head > 0) {
       a.xcd_ticket = tickets.data();
       a.item_begin = nullptr;                        a.item_end = item_off.data() + idx.n_lists;
-      launch(a);  // head phase: the nearest probes, cold bounds
+      if (head1) launch1(a); else launch(a);  // head phase: the nearest probes, cold bounds
       // list-sharded index with a communicator: every rank continues with the bound of the query's globally nearest
       // probe (one all-reduce of nq keys), not only the rank that owns that probe
       if (idx.shard_comm != nullptr) shard_allreduce_min_u32(res, idx.shard_comm, query_kth.data(), (size_t)nq);
@@ -2179,7 +2203,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         // queries the filter could not serve (no finite bound, operands beyond fp16, full pool): LUT scan of their pairs
         a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters;
         a.xcd_ticket = tickets.data() + 3 * 8 * 32;
-        launch(a);
+        if (head1) launch1(a); else launch(a);
         pq3_merge(res, r, top_d.data(), top_i.data());
         if (a.dbg & 1024) {
           auto hs = to_host(res, st3.data(), 8);

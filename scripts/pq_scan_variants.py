@@ -84,12 +84,14 @@ def main():
         flt, rsc = C.c_double(0), C.c_double(0)
         lib().cuvsAmdProfileCollect(b"pq_filter_kernel", C.byref(flt))
         lib().cuvsAmdProfileCollect(b"pq_rescore_kernel", C.byref(rsc))
+        hd = C.c_double(0)
+        lib().cuvsAmdProfileCollect(b"pq_head_kernel", C.byref(hd))
         cur = (nb.clone(), ds.clone())
         same = "ref" if first is None else str(bool(torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])))
         if first is None:
             firsts[(lut, acc)] = cur
         print(f"{v:24s} search {ms:8.3f} ms  scan {scan.value / args.steps:8.3f} ms ({n // args.steps} launches)  "
-              f"filter {flt.value / args.steps:7.3f} rescore {rsc.value / args.steps:7.3f}  same_as_first={same}", flush=True)
+              f"filter {flt.value / args.steps:7.3f} rescore {rsc.value / args.steps:7.3f} head+handback {hd.value / args.steps:7.3f}  same_as_first={same}", flush=True)
 
 
 if __name__ == "__main__":
