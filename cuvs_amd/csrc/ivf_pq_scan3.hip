@@ -395,6 +395,9 @@ struct rescore_params {
   int is_ip;
   const uint32_t* filter_bits;
   const int64_t* indices;
+  uint4* overflow;        // candidates of queries whose pool is full: (query, score bits, probe rank, row)
+  uint32_t* overflow_cnt;
+  uint32_t overflow_cap;
 };
 
 template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
@@ -449,7 +452,14 @@ __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
     if (float_to_key(score) > a.query_kth[q]) continue;
     const uint32_t cap = (a.n_probes - a.head) * a.k;
     const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
-    if (pos >= cap) { a.qflag[q] = 1u; continue; }
+    if (pos >= cap) {
+      // a loose head bound: the query's further candidates go to a list shared by all such queries (the merge reads it
+      // for the queries whose pool count went past the capacity); only when that is full too is the query handed back
+      const uint32_t ov = atomicAdd(a.overflow_cnt, 1u);
+      if (ov < a.overflow_cap) a.overflow[ov] = make_uint4(q, __float_as_uint(score), pair % a.n_probes, row);
+      else a.qflag[q] = 1u;
+      continue;
+    }
     const size_t o = (size_t)q * a.n_probes * a.k + (size_t)a.head * a.k + pos;
     a.cand_d[o] = score;
     a.cand_i[o] = row;
@@ -763,7 +773,8 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ cand_r, const uint32_t* __restrict__ qcnt,
                                                          const uint32_t* __restrict__ qflag, int64_t nq, uint32_t n_probes,
                                                          uint32_t k, uint32_t head, float* __restrict__ top_d,
-                                                         uint32_t* __restrict__ top_i)
+                                                         uint32_t* __restrict__ top_i, const uint4* __restrict__ overflow,
+                                                         const uint32_t* __restrict__ overflow_cnt, uint32_t overflow_cap)
 {
   const int lane  = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -777,7 +788,9 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
   best.init();
   float kd = INFINITY;
   uint32_t krk = 0xffffffffu, krow = 0xffffffffu;
-  for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+  // a query whose pool ran over also has candidates in the shared overflow list
+  const uint32_t n_ov = (!flagged && qcnt[q] > (n_probes - head) * k) ? min(*overflow_cnt, overflow_cap) : 0u;
+  for (uint32_t s0 = 0; s0 < n + n_ov; s0 += 64) {
     const uint32_t s = s0 + lane;
     float d = INFINITY;
     uint32_t rk = 0xffffffffu, row = 0xffffffffu;
@@ -785,6 +798,9 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
       d   = cand_d[o + s];
       row = cand_i[o + s];
       rk  = (flagged || s < head * k) ? s / k : cand_r[o + s];
+    } else if (s < n + n_ov) {
+      const uint4 e = overflow[s - n];
+      if (e.x == (uint32_t)q) { d = __uint_as_float(e.y); rk = e.z; row = e.w; }
     }
     unsigned long long m = __ballot(row != 0xffffffffu && top3::before(d, rk, row, kd, krk, krow));
     while (m != 0ull) {
@@ -902,6 +918,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
+  s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap;
   const dim3 rg(grid, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
   if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_kernel<0, false>), rg, rb, 0, res.stream, s);
@@ -958,7 +975,8 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)
 {
   hipLaunchKernelGGL(pool_merge_kernel, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
-                     r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i);
+                     r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, static_cast<const uint4*>(r.overflow), r.counters + 1,
+                     r.overflow_cap);
 }
 
 }  // namespace cuvs_amd

@@ -2051,6 +2051,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0);
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, max_units);
+  const uint32_t overflow_cap = use3 ? (res.tune.pq3_surv_cap > 0 ? (uint32_t)res.tune.pq3_surv_cap : (1u << 22)) : 0u;
+  dev_buf<uint4> overflow3(res, overflow_cap);
   dev_buf<work_item> fb_items(res, use3 ? (size_t)n_pairs_max : 0);
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
@@ -2195,7 +2197,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.surv_cnt = qstate.data() + 2 * bs_alloc + 2;
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
-        r.filter_bits = filter_bits;
+        r.filter_bits = filter_bits; r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
         dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 8 : 0);
         if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
         r.stats = st3.data();
@@ -2211,6 +2213,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                   (double)hs[4] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[7]),
                   (double)hs[6] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[2]));
           auto hc = to_host(res, r.counters, 2);
+          fprintf(stderr, "[pq_scan3] overflow entries %u\n", hc[1]);
           hc[1] = hc[0];
           fprintf(stderr, "[pq_scan3] pairs screened %llu, survivors %llu (%.4f%%), subtiles %llu (slow path %llu), fallback pairs %u\n",
                   hs[0], hs[1], 100.0 * hs[1] / (double)std::max<unsigned long long>(1, hs[0]), hs[2], hs[3], hc[1]);
