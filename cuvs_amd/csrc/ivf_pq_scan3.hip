@@ -748,6 +748,42 @@ __global__ void fallback_items_kernel(const uint32_t* __restrict__ sorted_pairs,
   }
 }
 
+// ------------------------------------------------------------------ overflow list binned by query (count, scan, fill)
+__global__ void ov_count_kernel(const uint4* __restrict__ ov, const uint32_t* __restrict__ n_ov, uint32_t cap, uint32_t* __restrict__ cnt)
+{
+  const uint32_t n = min(*n_ov, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&cnt[ov[i].x], 1u);
+}
+
+__global__ __launch_bounds__(1024) void ov_scan_kernel(uint32_t* __restrict__ cnt, int64_t nq, uint32_t* __restrict__ off)
+{
+  __shared__ int smem[17];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nq; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int v = i < nq ? (int)cnt[i] : 0;
+    int total;
+    const int excl = block_exclusive_scan(v, smem, &total);
+    if (i < nq) { off[i] = (uint32_t)(carry + excl); cnt[i] = 0u; }  // cnt becomes the fill cursor
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) off[nq] = (uint32_t)carry;
+}
+
+__global__ void ov_fill_kernel(const uint4* __restrict__ ov, const uint32_t* __restrict__ n_ov, uint32_t cap,
+                               const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor, uint4* __restrict__ sorted)
+{
+  const uint32_t n = min(*n_ov, cap);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint4 e = ov[i];
+    sorted[off[e.x] + atomicAdd(&cursor[e.x], 1u)] = e;
+  }
+}
+
 // ------------------------------------------------------------------ merge: one wave per query
 struct top3 {  // sorted ascending by (d, rank, row), rank r in lane r
   float d;
@@ -774,7 +810,7 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
                                                          const uint32_t* __restrict__ qflag, int64_t nq, uint32_t n_probes,
                                                          uint32_t k, uint32_t head, float* __restrict__ top_d,
                                                          uint32_t* __restrict__ top_i, const uint4* __restrict__ overflow,
-                                                         const uint32_t* __restrict__ overflow_cnt, uint32_t overflow_cap)
+                                                         const uint32_t* __restrict__ ov_off)
 {
   const int lane  = threadIdx.x & 63;
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -788,8 +824,9 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
   best.init();
   float kd = INFINITY;
   uint32_t krk = 0xffffffffu, krow = 0xffffffffu;
-  // a query whose pool ran over also has candidates in the shared overflow list
-  const uint32_t n_ov = (!flagged && qcnt[q] > (n_probes - head) * k) ? min(*overflow_cnt, overflow_cap) : 0u;
+  // a query whose pool ran over also has candidates in the overflow list (binned by query)
+  const uint32_t ov0  = ov_off[q];
+  const uint32_t n_ov = flagged ? 0u : ov_off[q + 1] - ov0;
   for (uint32_t s0 = 0; s0 < n + n_ov; s0 += 64) {
     const uint32_t s = s0 + lane;
     float d = INFINITY;
@@ -799,8 +836,8 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
       row = cand_i[o + s];
       rk  = (flagged || s < head * k) ? s / k : cand_r[o + s];
     } else if (s < n + n_ov) {
-      const uint4 e = overflow[s - n];
-      if (e.x == (uint32_t)q) { d = __uint_as_float(e.y); rk = e.z; row = e.w; }
+      const uint4 e = overflow[ov0 + s - n];
+      d = __uint_as_float(e.y); rk = e.z; row = e.w;
     }
     unsigned long long m = __ballot(row != 0xffffffffu && top3::before(d, rk, row, kd, krk, krow));
     while (m != 0ull) {
@@ -974,9 +1011,13 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
 
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)
 {
+  auto* ov = static_cast<uint4*>(r.overflow);
+  hipLaunchKernelGGL(ov_count_kernel, dim3(256), dim3(256), 0, res.stream, ov, r.counters + 1, r.overflow_cap, r.ov_cnt);
+  hipLaunchKernelGGL(ov_scan_kernel, dim3(1), dim3(1024), 0, res.stream, r.ov_cnt, r.nq, r.ov_off);
+  hipLaunchKernelGGL(ov_fill_kernel, dim3(256), dim3(256), 0, res.stream, ov, r.counters + 1, r.overflow_cap, r.ov_off, r.ov_cnt,
+                     ov + r.overflow_cap);
   hipLaunchKernelGGL(pool_merge_kernel, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
-                     r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, static_cast<const uint4*>(r.overflow), r.counters + 1,
-                     r.overflow_cap);
+                     r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, ov + r.overflow_cap, r.ov_off);
 }
 
 }  // namespace cuvs_amd

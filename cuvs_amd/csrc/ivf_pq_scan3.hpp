@@ -26,8 +26,10 @@ struct pq3_run {
   uint32_t* qflag;               // [nq] zeroed: queries handed back to the LUT scan
   uint32_t* qcnt;                // [nq] zeroed: pool fill
   uint32_t* counters;            // [2] zeroed: fallback work items, overflow entries
-  void* overflow;                // [overflow_cap] x 16 bytes: candidates of queries whose pool ran over
-  uint32_t overflow_cap;
+  void* overflow;                // [2 * overflow_cap] x 16 bytes: candidates of queries whose pool ran over, then the same
+  uint32_t overflow_cap;         //   binned by query
+  uint32_t* ov_cnt;              // [nq] zeroed
+  uint32_t* ov_off;              // [nq + 1]
   uint32_t* surv_cnt;            // [pq3_grid()] fill of every workgroup's survivor region (written by the filter)
   void* surv;                    // [surv_cap] (pair, flat row), cut into one region per workgroup of the filter
   uint32_t surv_cap;
