@@ -50,7 +50,7 @@ struct ivf_pq_index {
   // decode tables of the matrix-core filter (ivf_pq_scan3.hip), built on first use and rebuilt when the lists change
   struct scan3_cache {
     dev_buf<uint32_t> cb16;
-    dev_buf<float> row_term;
+    dev_buf<uint32_t> row_term;
     float sc = 1.f, cbmax = 0.f;
     const void* codes_ptr = nullptr;
     const void* pq_ptr    = nullptr;

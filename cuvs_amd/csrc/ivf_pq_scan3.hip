@@ -61,9 +61,11 @@ __global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_di
   cb16[e] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
 }
 
-// |d|^2 of every row's decoded residual, shrunk by the relative margin (see filter_threshold): one thread per row
-__global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows,
-                                float* __restrict__ term)
+// |d|^2 of every row's decoded residual, shrunk by the relative margin (see filter_threshold), as an extra K element of
+// the GEMM: x = -|d|^2 (1 - 2^-9) sc^2 / 2 split into two fp16 values (hi + lo = x to 2^-22; |x| <= 16384 by the choice
+// of sc), so that the accumulator of a (row, query) pair ends up holding sc^2 (r.d - |d|^2 (1 - 2^-9) / 2). One thread per row
+__global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows, float sc,
+                                uint32_t* __restrict__ term)
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
@@ -82,7 +84,10 @@ __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* 
       dn = __fmaf_rn(p1, p1, dn);
     }
   }
-  term[r] = dn * (1.0f - 1.0f / 512.0f);
+  const float x     = -0.5f * sc * sc * (dn * (1.0f - 1.0f / 512.0f));
+  const _Float16 hi = (_Float16)x;
+  const _Float16 lo = (_Float16)(x - (float)hi);
+  term[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
 }
 
 // ------------------------------------------------------------------ work units: (list, <= 64 pairs, row chunk)
@@ -142,7 +147,7 @@ struct filter_params {
   const uint8_t* codes;
   const uint32_t* list_offsets;
   const uint32_t* list_sizes;
-  const float* row_term;
+  const uint32_t* row_term;  // packed fp16 (hi, lo) of the row's K-extension term (L2), nullptr for inner product
   const uint32_t* query_kth;
   uint32_t* qflag;
   uint2* surv;         // one region of surv_cap entries per workgroup (a single global counter for all survivors made
@@ -262,8 +267,11 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
       // is re-done by the LUT scan anyway: nothing of this query survives here
       const bool served = valid && kk < 0xff800000u && big < 60000.f && bound <= a.bound_max && a.qflag[q] == 0u;
       if (valid && !served) a.qflag[q] = 1u;
-      thr[g] = served ? filter_threshold(bound, rn, a) : -INFINITY;
+      thr[g] = served ? filter_threshold(bound, rn, a) / a.c1 : INFINITY;  // in accumulator units (c1 < 0: the test flips)
     }
+    // B operand of the K-extension step: the row term's two halves times one
+    const u32x4_t oq   = {h == 0u ? 0x3c003c00u : 0u, 0u, 0u, 0u};
+    const f16x8_t ones = __builtin_bit_cast(f16x8_t, oq);
 
     // ---- rows of the unit, 32 at a time. Software pipeline of a wave: the code words are loaded two subtiles ahead;
     // the 32 gathers that decode subtile u + 1 are issued right after the MFMAs of subtile u and land while its
@@ -288,49 +296,46 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
     auto run = [&](auto two_tag) {
       constexpr bool TWO = decltype(two_tag)::value;
       uint2 cw1[4], cw2[4];
-      u32x4_t av[8];
+      u32x4_t avA[8], avB[8];  // decoded rows of the current / the next subtile (roles alternate)
       load_codes(u0, cw1);
       load_codes(u0 + 1, cw2);
-      decode(cw1, av);
+      decode(cw1, avA);
 #pragma unroll
       for (int c = 0; c < 4; ++c) cw1[c] = cw2[c];
       load_codes(u0 + 2, cw2);
-      for (uint32_t u = u0; u < u1; ++u) {
-        // the rows' terms first: their L2 latency passes under the MFMAs
-        float tv[16];
-        if (a.row_term != nullptr) {
-          const float* tp = a.row_term + base_row + (u << 5) + 4u * h;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(tp + 8 * j);
-            tv[4 * j] = v.x; tv[4 * j + 1] = v.y; tv[4 * j + 2] = v.z; tv[4 * j + 3] = v.w;
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) tv[i] = 0.f;
-        }
-        f32x16_t acc0 = {}, acc1 = {};
-#pragma unroll
-        for (int st = 0; st < 8; ++st) {
-          const f16x8_t aop = __builtin_bit_cast(f16x8_t, av[st]);
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[0][st], acc0, 0, 0, 0);
-          if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[1][st], acc1, 0, 0, 0);
-        }
-        // decode of the next subtile (clamped to the last one: harmless repeat), code words of the one after
-        decode(cw1, av);
+      // one subtile: the gathers that decode subtile u + 1 are issued BEFORE the MFMAs of subtile u, so their trip
+      // through the LDS queue (shared with seven other waves) overlaps this wave's own matrix work
+      auto step = [&](const uint32_t u, const u32x4_t (&cur)[8], u32x4_t (&nxt)[8]) {
+        uint32_t term = 0u;  // the rows' K-extension term (one dword per row, lanes of half 0)
+        if (a.row_term != nullptr && h == 0u) term = a.row_term[base_row + (u << 5) + ql];
+        decode(cw1, nxt);  // (clamped to the last subtile: a harmless repeat at the end)
 #pragma unroll
         for (int c = 0; c < 4; ++c) cw1[c] = cw2[c];
         load_codes(u + 3, cw2);
-        // ---- screen: accumulator register i of this lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile
-        float m0 = INFINITY, m1 = INFINITY;
+        f32x16_t acc0 = {}, acc1 = {};
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          const f16x8_t aop = __builtin_bit_cast(f16x8_t, cur[st]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[0][st], acc0, 0, 0, 0);
+          if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[1][st], acc1, 0, 0, 0);
+        }
+        if (a.row_term != nullptr) {  // wave-uniform: the extra K step adds -|d|^2 (1 - 2^-9) sc^2 / 2 to every pair of the row
+          const u32x4_t tq  = {term, 0u, 0u, 0u};
+          const f16x8_t top = __builtin_bit_cast(f16x8_t, tq);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(top, ones, acc0, 0, 0, 0);
+          if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(top, ones, acc1, 0, 0, 0);
+        }
+        // ---- screen: accumulator register i of this lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile; a pair
+        // survives when c1 * acc <= thr, i.e. acc >= thr / c1 (c1 < 0, a power of two)
+        float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          m0 = fminf(m0, __fmaf_rn(acc0[i], a.c1, tv[i]));
-          if constexpr (TWO) m1 = fminf(m1, __fmaf_rn(acc1[i], a.c1, tv[i]));
+          m0 = fmaxf(m0, acc0[i]);
+          if constexpr (TWO) m1 = fmaxf(m1, acc1[i]);
         }
-        const bool any = (m0 <= thr[0]) || (TWO && m1 <= thr[1]);
+        const bool any = (m0 >= thr[0]) || (TWO && m1 >= thr[1]);
         if (a.stats != nullptr) { st_pairs += 32u * count; st_sub += 1u; }
-        if (__ballot(any) == 0ull) continue;  // the usual case
+        if (__ballot(any) == 0ull) return;  // the usual case
         // ---- slow path (9 % of the subtiles, one or two survivors each): the few lanes that hold a survivor go through
         // their own 16 (32) values and append them one by one through the workgroup's LDS counter
         if (a.stats != nullptr) st_slow += 1u;
@@ -341,8 +346,8 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
               const uint32_t v = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
-              const float x    = __fmaf_rn(g == 0 ? acc0[i] : acc1[i], a.c1, tv[i]);
-              if (x <= thr[g] && v < len) {
+              const float x    = g == 0 ? acc0[i] : acc1[i];
+              if (x >= thr[g] && v < len) {
                 const uint32_t pos = atomicAdd(wg_fill, 1u);  // LDS
                 if (pos < a.surv_cap) my_surv[pos] = make_uint2(pairid[g], base_row + v);
                 else a.qflag[pairid[g] / a.n_probes] = 1u;  // survivor region full: the query is re-done by the LUT scan
@@ -351,6 +356,10 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
             }
         }
         if (a.stats != nullptr) t_slow += __builtin_readcyclecounter() - t_s0;
+      };
+      for (uint32_t u = u0; u < u1; u += 2) {
+        step(u, avA, avB);
+        if (u + 1 < u1) step(u + 1, avB, avA);
       }
     };
     const unsigned long long t_loop = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
@@ -895,10 +904,10 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
     c.cb16  = dev_buf<uint32_t>::persistent((size_t)idx.pq_dim * 256);
     hipLaunchKernelGGL(cb16_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream,
                        idx.pq_centers.data(), idx.pq_dim, c.sc, c.cb16.data());
-    c.row_term = dev_buf<float>::persistent((size_t)std::max<int64_t>(idx.padded_rows, 1));
+    c.row_term = dev_buf<uint32_t>::persistent((size_t)std::max<int64_t>(idx.padded_rows, 1));
     if (idx.padded_rows > 0)
       hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, idx.codes.data(),
-                         idx.pq_centers.data(), idx.padded_rows, c.row_term.data());
+                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data());
     sync(res);
     c.codes_ptr = idx.codes.data(); c.rows = idx.padded_rows; c.size = idx.size; c.pq_ptr = idx.pq_centers.data();
   }

@@ -6,7 +6,7 @@ namespace cuvs_amd {
 
 struct pq3_tables {
   const uint32_t* cb16;   // [pq_dim][256] codebook entries as scaled fp16 pairs (decode table of the filter)
-  const float* row_term;  // [padded_rows] |decoded residual|^2 * (1 - 2^-9)
+  const uint32_t* row_term;  // [padded_rows] fp16 (hi, lo) of -|decoded residual|^2 (1 - 2^-9) sc^2 / 2: an extra K element of the GEMM
   float sc, cbmax;
 };
 
