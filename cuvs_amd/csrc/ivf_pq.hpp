@@ -51,7 +51,7 @@ struct ivf_pq_index {
   struct scan3_cache {
     dev_buf<uint32_t> cb16;
     dev_buf<uint32_t> row_term;
-    float sc = 1.f, cbmax = 0.f;
+    float sc = 1.f, cbmax = 0.f, dmax = 0.f;
     const void* codes_ptr = nullptr;
     const void* pq_ptr    = nullptr;
     int64_t rows = -1, size = -1;

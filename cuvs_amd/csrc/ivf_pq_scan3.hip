@@ -36,6 +36,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 
@@ -61,14 +62,21 @@ __global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_di
   cb16[e] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
 }
 
+__device__ inline float wave_reduce_max_f32(float v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
 // |d|^2 of every row's decoded residual, shrunk by the relative margin (see filter_threshold), as an extra K element of
 // the GEMM: x = -|d|^2 (1 - 2^-9) sc^2 / 2 split into two fp16 values (hi + lo = x to 2^-22; |x| <= 16384 by the choice
 // of sc), so that the accumulator of a (row, query) pair ends up holding sc^2 (r.d - |d|^2 (1 - 2^-9) / 2). One thread per row
 __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows, float sc,
-                                uint32_t* __restrict__ term)
+                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits)
 {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
+  const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r  = min(r0, rows - 1);  // (no early exit: the wave reduction below needs every lane)
   const uint4* cp = reinterpret_cast<const uint4*>(codes) + ((size_t)(r >> 6) * 4) * 64 + (r & 63);
   float dn = 0.f;
 #pragma unroll
@@ -84,10 +92,13 @@ __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* 
       dn = __fmaf_rn(p1, p1, dn);
     }
   }
+  // the largest |d|^2 of the index (bits of a non-negative float order like unsigned integers)
+  const float wmax = wave_reduce_max_f32(dn);
+  if ((threadIdx.x & 63) == 0) atomicMax(dn_max_bits, __float_as_uint(wmax));
   const float x     = -0.5f * sc * sc * (dn * (1.0f - 1.0f / 512.0f));
   const _Float16 hi = (_Float16)x;
   const _Float16 lo = (_Float16)(x - (float)hi);
-  term[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+  if (r0 < rows) term[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
 }
 
 // ------------------------------------------------------------------ work units: (list, <= 64 pairs, row chunk)
@@ -157,10 +168,11 @@ struct filter_params {
   float sc;        // power of two applied to both GEMM operands before the fp16 rounding
   float c1;        // -2 / sc^2 (L2) or -1 / sc^2 (inner product)
   float eps, alpha;  // exact score >= real score * (1 - eps) - alpha for the requested LUT / score types
-  float cbmax;
+  float cbmax, dmax; // largest codebook value, largest decoded residual norm
   float bound_max;   // bounds beyond this are not served here (fp8 LUT saturation)
   int is_ip;
-  unsigned long long* stats;  // optional [4]: pairs tested, survivors, subtiles, subtiles that took the slow path
+  unsigned long long* stats;  // optional [8]: pairs tested, survivors, subtiles, slow-path subtiles, cycles (see the kernel), units
+  int dbg;                    // ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs
 };
 
 // Largest value B with: exact score > bound  whenever  (row term - 2 dot16 / sc^2) > B   (L2; see the file header).
@@ -181,6 +193,23 @@ __device__ inline float filter_threshold(const float bound, const float rn, cons
   return f;
 }
 
+// Inner product / cosine: T = -(q.c + q.d) (q the rotated query, c the list centre, d the row's decoded residual); the LUT
+// entries have both signs, so the roundings of S scale with sum |entry| <= |q| (|c| + |d|) instead of with T:
+//   S >= T - eps |q| (|c| + |d|) - alpha,   T >= A - 2^-17 |q| |c| - 2^-9.9 |q| |d| - mabs,   A = -(qc + dot16 / sc^2)
+// with qc = q.c in fp32 and |d| <= dmax (the largest decoded norm of the index). S > bound is implied by
+//   -dot16 / sc^2 > bound + qc + |q| ((eps + 2^-17) |c| + (eps + 2^-9) dmax) + mabs + alpha.
+__device__ inline float filter_threshold_ip(const float bound, const float qn, const float cn, const float qc, const filter_params& a)
+{
+  const double nq = sqrt((double)qn), nc = sqrt((double)cn);
+  const double mabs = 1.1920929e-07 /* 2^-23 */ / (double)a.sc * (sqrt((double)a.rot_dim) * nq + (double)a.rot_dim * (double)a.cbmax);
+  const double m = nq * (((double)a.eps + 7.63e-6) * nc + ((double)a.eps + 1.0 / 512.0) * (double)a.dmax);
+  const double b = (double)bound + (double)qc + (fabs((double)qc) + fabs((double)bound)) * 1e-6 + m + mabs + (double)a.alpha;
+  float f = (float)b;
+  f += fabsf(f) * 2.4e-7f + 1e-37f;
+  return f;
+}
+
+template <int DBG>  // ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs, 8 no code loads
 __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_params a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -237,17 +266,20 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
       pairid[g]         = p;
       const float* rq   = a.rot_queries + (size_t)q * a.rot_dim;
       const float* ct   = a.centers_rot + (size_t)L * a.rot_dim;
-      float rn = 0.f, big = 0.f;
+      float rn = 0.f, big = 0.f, qc = 0.f, cn = 0.f;
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         const uint32_t s0 = 16u * (st >> 1) + 8u * h + 4u * (st & 1);
         const float4 q0 = *reinterpret_cast<const float4*>(rq + 2 * s0), q1 = *reinterpret_cast<const float4*>(rq + 2 * s0 + 4);
         float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const float4 c0 = *reinterpret_cast<const float4*>(ct + 2 * s0), c1 = *reinterpret_cast<const float4*>(ct + 2 * s0 + 4);
+        const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         if (!a.is_ip) {
-          const float4 c0 = *reinterpret_cast<const float4*>(ct + 2 * s0), c1 = *reinterpret_cast<const float4*>(ct + 2 * s0 + 4);
-          const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
           for (int e = 0; e < 8; ++e) r[e] -= c[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { qc = __fmaf_rn(r[e], c[e], qc); cn = __fmaf_rn(c[e], c[e], cn); }
         }
         f16x8_t v;
 #pragma unroll
@@ -260,14 +292,17 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
         bop[g][st] = v;
       }
       rn  += __shfl_xor(rn, 32);
+      qc  += __shfl_xor(qc, 32);
+      cn  += __shfl_xor(cn, 32);
       big  = fmaxf(big, __shfl_xor(big, 32));
       const uint32_t kk = valid ? a.query_kth[q] : 0u;
       const float bound = key_to_float(kk);
       // no finite bound yet, an operand beyond the fp16 range, a bound the LUT type cannot represent, or a query that
       // is re-done by the LUT scan anyway: nothing of this query survives here
-      const bool served = valid && kk < 0xff800000u && big < 60000.f && bound <= a.bound_max && a.qflag[q] == 0u;
+      const bool served = valid && kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max && a.qflag[q] == 0u;
       if (valid && !served) a.qflag[q] = 1u;
-      thr[g] = served ? filter_threshold(bound, rn, a) / a.c1 : INFINITY;  // in accumulator units (c1 < 0: the test flips)
+      const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
+      thr[g] = served ? t / a.c1 : INFINITY;  // in accumulator units (c1 < 0: the test flips)
     }
     // B operand of the K-extension step: the row term's two halves times one
     const u32x4_t oq   = {h == 0u ? 0x3c003c00u : 0u, 0u, 0u, 0u};
@@ -282,15 +317,21 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
       const uint32_t fr = base_row + (min(u, u1 - 1u) << 5) + ql;  // this lane's row (padded rows of a group are readable)
       const char* p = reinterpret_cast<const char*>(codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u)) + 8u * h;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const uint2*>(p + (size_t)c * 64 * 16);
+      for (int c = 0; c < 4; ++c) {
+        if constexpr ((DBG & 8) != 0) cw[c] = make_uint2(u * 2654435761u + c, fr);  // ablation: no code loads
+        else cw[c] = *reinterpret_cast<const uint2*>(p + (size_t)c * 64 * 16);
+      }
     };
     auto decode = [&](const uint2 (&cw)[4], u32x4_t (&av)[8]) {
 #pragma unroll
       for (int st = 0; st < 8; ++st) {
         const uint32_t w = (st & 1) ? cw[st >> 1].y : cw[st >> 1].x;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          av[st][e] = cbh[((16u * (st >> 1) + 4u * (st & 1) + e) << 8) + ((w >> (8 * e)) & 0xffu)];
+        for (int e = 0; e < 4; ++e) {
+          uint32_t code = (w >> (8 * e)) & 0xffu;
+          if constexpr ((DBG & 1) != 0) code = ql;  // ablation: every lane of a half in its own bank
+          av[st][e] = (DBG & 2) ? code : cbh[((16u * (st >> 1) + 4u * (st & 1) + e) << 8) + code];
+        }
       }
     };
     auto run = [&](auto two_tag) {
@@ -316,6 +357,7 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
           const f16x8_t aop = __builtin_bit_cast(f16x8_t, cur[st]);
+          if constexpr ((DBG & 4) != 0) { acc0[st] += (float)aop[0]; continue; }  // ablation: no MFMAs
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[0][st], acc0, 0, 0, 0);
           if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[1][st], acc1, 0, 0, 0);
         }
@@ -905,13 +947,18 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
     hipLaunchKernelGGL(cb16_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream,
                        idx.pq_centers.data(), idx.pq_dim, c.sc, c.cb16.data());
     c.row_term = dev_buf<uint32_t>::persistent((size_t)std::max<int64_t>(idx.padded_rows, 1));
+    dev_buf<uint32_t> mxd(res, 1);
+    HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
     if (idx.padded_rows > 0)
       hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, idx.codes.data(),
-                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data());
-    sync(res);
+                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data());
+    const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
+    float dn_max;
+    memcpy(&dn_max, &mbits, 4);
+    c.dmax = std::sqrt(dn_max) * 1.0001f;
     c.codes_ptr = idx.codes.data(); c.rows = idx.padded_rows; c.size = idx.size; c.pq_ptr = idx.pq_centers.data();
   }
-  return pq3_tables{c.cb16.data(), c.row_term.data(), c.sc, c.cbmax};
+  return pq3_tables{c.cb16.data(), c.row_term.data(), c.sc, c.cbmax, c.dmax};
 }
 
 size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows)
@@ -943,7 +990,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = r.surv_cap / grid;
   f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.unit_rows = r.unit_rows;
   f.sc = tb.sc; f.c1 = (r.is_ip ? -1.0f : -2.0f) / (tb.sc * tb.sc);
-  f.cbmax = tb.cbmax; f.is_ip = r.is_ip; f.stats = r.stats;
+  f.cbmax = tb.cbmax; f.dmax = tb.dmax; f.is_ip = r.is_ip; f.stats = r.stats; f.dbg = r.filter_dbg;
   // exact score >= real score * (1 - eps) - alpha (L2: all entries are >= 0)
   //   fp32 LUT / fp32 score: 2 roundings per entry + 64 adds
   //   fp16 LUT: + 2^-11 per entry (2^-24 absolute below the normal range); fp16 score: + 2^-11 of the partial sum per add
@@ -953,10 +1000,22 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   if (r.lut_mode == 0)      { f.eps = 1.0f / 65536.0f; f.alpha = 0.f; }
   else if (r.lut_mode == 1) { f.eps = r.acc_half ? 0.04f : 1.0f / 1024.0f; f.alpha = 64.0f / 16777216.0f; f.bound_max = 60000.f; }
   else                      { f.eps = r.acc_half ? 0.11f : 0.07f; f.alpha = 64.0f / 32768.0f; f.bound_max = 30000.f; }
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pq_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 16));
-  profile_begin(res, "pq_filter_kernel");
-  hipLaunchKernelGGL(pq_filter_kernel, dim3(grid), dim3(kFThreads), 64 * 1024 + 16, res.stream, f);
-  profile_end(res, "pq_filter_kernel");
+  if (r.is_ip && r.lut_mode == 2) f.eps = r.acc_half ? 0.18f : 0.14f;  // signed fp8: one value bit less (2^-3 per entry)
+  auto launch_filter = [&](auto kern) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 16));
+    profile_begin(res, "pq_filter_kernel");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFThreads), 64 * 1024 + 16, res.stream, f);
+    profile_end(res, "pq_filter_kernel");
+  };
+  switch (r.filter_dbg) {  // CUVS_AMD_SCAN_DEBUG bits 16..19: ablation builds of the kernel
+    case 1:  launch_filter(pq_filter_kernel<1>); break;
+    case 2:  launch_filter(pq_filter_kernel<2>); break;
+    case 4:  launch_filter(pq_filter_kernel<4>); break;
+    case 6:  launch_filter(pq_filter_kernel<6>); break;
+    case 8:  launch_filter(pq_filter_kernel<8>); break;
+    case 14: launch_filter(pq_filter_kernel<14>); break;
+    default: launch_filter(pq_filter_kernel<0>); break;
+  }
 
   rescore_params s{};
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;

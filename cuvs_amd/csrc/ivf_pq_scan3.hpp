@@ -7,7 +7,7 @@ namespace cuvs_amd {
 struct pq3_tables {
   const uint32_t* cb16;   // [pq_dim][256] codebook entries as scaled fp16 pairs (decode table of the filter)
   const uint32_t* row_term;  // [padded_rows] fp16 (hi, lo) of -|decoded residual|^2 (1 - 2^-9) sc^2 / 2: an extra K element of the GEMM
-  float sc, cbmax;
+  float sc, cbmax, dmax;
 };
 
 // one batch of the tail phase; all pointers device memory owned by the caller (ivf_pq_search)
@@ -39,7 +39,8 @@ struct pq3_run {
   uint32_t* xcd_ticket;          // 8 x 32 zeroed words
   void* fb_items;                // work_item[n tail pairs]: single-pair items of the flagged queries
   const uint32_t* filter_bits;
-  unsigned long long* stats;     // optional device [4]
+  int filter_dbg;                // ablation bits of the filter kernel (timing only)
+  unsigned long long* stats;     // optional device [8]
 };
 
 // single-query list scan with the k smallest selected in LDS (head phase, pairs of handed-back queries)

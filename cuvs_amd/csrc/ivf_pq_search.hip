@@ -2024,7 +2024,10 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   // a second launch and a twice as long label range only pay off once the batch is large)
   uint32_t head = (n_probes > 8 && n_queries >= 256 && !large_k) ? 1u : 0u;
   if (res.tune.pq_head_probes >= 0) head = std::min<uint32_t>((uint32_t)res.tune.pq_head_probes, n_probes);
-  if (idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) head = 0;  // signed LUT entries: no early stop
+  // signed LUT entries: no early stop in the LUT scan kernels - unless the tail phase runs on the matrix-core filter,
+  // which needs no non-negativity (a full-score bound): then the head phase supplies its bounds as for L2
+  const bool pq3_ok = !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0 && res.tune.pq_head_probes != 0;
+  if ((idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) && !pq3_ok) head = 0;
   const bool sharded      = idx.shard_world > 1;  // list-sharded index: foreign probes go to a bucket that is never scanned
   const uint32_t n_ranges = head > 0 ? 2 * idx.n_lists : idx.n_lists;
   const uint32_t n_labels = n_ranges + (sharded ? 1u : 0u);
@@ -2042,7 +2045,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<uint32_t> tickets(res, 4 * 8 * 32);
   // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): decode + MFMA filter, exact re-score of the survivors
   const bool metric_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
-  const bool use3 = head > 0 && !metric_ip && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0;
+  const bool use3 = head > 0 && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0;
   uint32_t unit_rows = 0;
   const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows) : 0;
   uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 4, 1 << 20), 1 << 28) : 0u;
@@ -2201,7 +2204,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.filter_bits = filter_bits; r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
         dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 8 : 0);
         if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
-        r.stats = st3.data();
+        r.stats = st3.data(); r.filter_dbg = (a.dbg >> 16) & 15;  // CUVS_AMD_SCAN_DEBUG bits 16..19
         pq3_tail(res, idx, r);
         // queries the filter could not serve (no finite bound, operands beyond fp16, full pool): LUT scan of their pairs
         a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters;

@@ -120,6 +120,29 @@ def test_c3_shape_recall_with_refine(big_lists):
     assert oracle.recall(ri.cpu().numpy(), ti) >= 0.9
 
 
+@pytest.mark.parametrize("metric", ["inner_product", "cosine"])
+@pytest.mark.parametrize("lut,acc", [("f16", "f32"), ("f16", "f16"), ("fp8", "f16"), ("f32", "f32")])
+def test_c3_shape_inner_product_and_cosine(metric, lut, acc, monkeypatch):
+    """Signed LUT entries have no early stop in the LUT scan; the matrix-core filter works on full-score bounds, so the
+    two-phase schedule (head scan -> bounds -> filter / re-score / pool merge) serves inner product and cosine too."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(80_000, 128, 384, seed=77)
+    x += 0.5  # off-centre: inner products of both signs and a wide spread of norms
+    q += 0.5
+    index = _pq_build(x, n_lists=16, pq_dim=64, pq_bits=8, kmeans_n_iters=10, kmeans_trainset_fraction=0.3, metric=metric)
+    ex = ivf_pq.export_for_oracle(index)
+    k, n_probes = 20, 12
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")  # single-phase LUT scan
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (gi == si).all() and (gd == sd).all()
+
+
 # ---------------------------------------------------------------------------------------------------------- C4 shape
 @pytest.fixture(scope="module")
 def cagra_768():
