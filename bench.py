@@ -10,14 +10,19 @@ Index build, ground truth and the CPU baseline are outside the timed region; que
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
                                        # list-sharded index (list L on rank L % N), every step ends in ONE native RCCL
                                        # all-gather of the per-rank [Q, k] blocks (include/cuvs_amd/shard.h)
+  [torchrun ...] bench.py --config c5 [--rows R]
+                                       # BASELINE configs[4]: IVF-PQ rows x 96 int8 (default 1B), list shards dealt by
+                                       # size over the ranks, rows generated chunk by chunk (no rank holds the corpus)
 
 Prints ONE JSON line (rank 0):
   value / ms_per_step    the headline variant: fp16 LUT / fp32 scores, the arithmetic of the reference's own bench grid
   config.variants        the same step with the reference-default arithmetic (fp32 LUT / fp32 scores), fp16 / fp16 and
                          the fp8 LUT, each with ms, recall and scan-kernel time
-  roofline               pq_scan_kernel: the logical scan rate of SURVEY 8d (code bytes / kernel time, HIP events) AND
-                         the physical fractions from rocprofv3 PMC passes of this same workload: hbm_frac,
-                         lds_gather_frac, lds_busy, valu_busy; `bound` names the busiest pipe
+  config.metric_variants the same search on an inner-product and a cosine index of the same rows
+  roofline               the scan kernels of one search (head-phase list scan, matrix-core filter, re-score): HIP-event
+                         times per kernel, the logical scan rate of SURVEY 8d (code bytes / kernel time) AND the
+                         physical fractions from rocprofv3 PMC passes of this same workload: hbm_frac, lds_busy,
+                         valu_busy, mfma_busy; `bound` names the busiest pipe, `frac` its busy fraction
   extra                  C1 (brute force 100k x 128), C2 (IVF-Flat 10M x 128), C4 (CAGRA 10M x 768 fp16) - recall,
                          ms, kernel time, fraction of the roofline that bounds each
   cpu_baseline           the reference's CPU exact-search path (refine_host restatement, OpenMP) at the C1 shape
@@ -158,6 +163,145 @@ def pmc_child(args, n_search):
         ivf_pq.search(sp, index, queries, kk, neighbors=nb, distances=ds, resources=res)
     res.sync()
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------------------- C5: 1B x 96 int8, list shards
+def gen_int8_rows(n, dim, seed, device, row0=0, out=None):
+    """int8 rows of the same latent mixture as gen_rows (scaled to the int8 range), generated chunk by chunk from
+    (seed, chunk index): any row range can be produced on any rank, nothing but the chunk is ever resident."""
+    x = gen_rows(n, dim, seed, device, row0=row0)
+    x.mul_(40.0).round_().clamp_(-127, 127)
+    y = x.to(torch.int8) if out is None else out.copy_(x)
+    del x
+    return y
+
+
+def run_c5(args):
+    """BASELINE configs[4]: IVF-PQ over `rows` x 96 int8 vectors, the index sharded by IVF list over the ranks (one process
+    per GPU), per-rank top-k all-gathered by RCCL and merged (mg_ivf_pq.h:152-190, snmg.cuh:128-166,248-375). No rank
+    ever holds the corpus: rows are generated 2^24 at a time, every rank encodes the chunk's rows that fall into its own
+    lists and drops the rest; the lists are dealt to the ranks by size (greedy LPT over the list histogram). Recall is
+    measured against an exact search that regenerates the chunks. Search without refinement (the corpus is not kept)."""
+    import cuvs_amd
+    from cuvs_amd._lib import lib
+    from cuvs_amd.neighbors import ivf_pq, ivf_pq_sharded as sh
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    res = cuvs_amd.common.Resources()
+    rows = args.rows if args.rows != 100_000_000 else 1_000_000_000
+    dim, chunk = 96, 1 << 24
+    n_lists = args.n_lists if args.n_lists != 16384 else 32768
+    nq_total = args.batch * world
+    t0 = time.time()
+    # model: trained on a sample of the first chunk (the same rows, hence the same model, on every rank)
+    first = gen_int8_rows(min(chunk, rows), dim, 1234, dev)
+    train = first[:: max(1, first.shape[0] // 2_000_000)].contiguous()
+    ip = ivf_pq.IndexParams(n_lists=n_lists, metric="sqeuclidean", pq_dim=args.pq_dim, pq_bits=8, kmeans_n_iters=20,
+                            kmeans_trainset_fraction=1.0, add_data_on_build=False)
+    comm = (sh.ShardComm.from_torch(res) if world > 1 else sh.ShardComm(0, 1, sh.ShardComm.unique_id(), res))
+    index = ivf_pq.build(ip, train, resources=res)
+    # pass 1: list histogram (every rank counts its share of the chunks, the counts are summed), lists dealt by size
+    counts = np.zeros(n_lists, np.uint64)
+    n_chunks = (rows + chunk - 1) // chunk
+    for c in range(rank, n_chunks, world):
+        x = first if c == 0 else gen_int8_rows(min(chunk, rows - c * chunk), dim, 1234, dev, row0=c * chunk)
+        counts += sh.list_histogram(index, x, resources=res)
+        del x
+    if world > 1:
+        t = torch.from_numpy(counts.astype(np.int64)).to(dev)
+        dist.all_reduce(t)
+        counts = t.cpu().numpy().astype(np.uint64)
+    owners = sh.deal_lists(counts, world)
+    sh.set_list_owners(index, owners, rank, world)
+    # pass 2: every rank sees every chunk and keeps the rows of its own lists
+    for c in range(n_chunks):
+        r0 = c * chunk
+        x = first if c == 0 else gen_int8_rows(min(chunk, rows - r0), dim, 1234, dev, row0=r0)
+        sh.extend(index, x, torch.arange(r0, r0 + x.shape[0], dtype=torch.int64, device=dev), resources=res)
+        del x
+    del first, train
+    sh.attach_comm(index, comm)
+    res.sync()
+    build_s = time.time() - t0
+    mine = int(counts[owners == rank].sum())
+    log(f"C5: built {rows} x {dim} int8 in {build_s:.1f}s; this rank holds {len(index)} rows ({mine} by the histogram)")
+    queries = torch.cat([gen_int8_rows(args.batch, dim, 4321 + r, dev) for r in range(world)])
+    k = args.k
+    sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                             max_internal_batch_size=nq_total)
+    cand_i = torch.empty((nq_total, k), dtype=torch.int64, device=dev)
+    cand_d = torch.empty((nq_total, k), dtype=torch.float32, device=dev)
+    out_i, out_d = torch.empty_like(cand_i), torch.empty_like(cand_d)
+
+    def step():
+        ivf_pq.search(sp, index, queries, k, neighbors=cand_i, distances=cand_d, resources=res)
+        comm.all_gather_topk(cand_d, cand_i, out=(out_d, out_i), resources=res)
+
+    for _ in range(args.warmup):
+        step()
+    lib().cuvsAmdProfileEnable(1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    lib().cuvsAmdProfileEnable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    scan_ms, ag_ms = C.c_double(0), C.c_double(0)
+    n_launch = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan_ms))
+    lib().cuvsAmdProfileCollect(b"shard_all_gather", C.byref(ag_ms))
+    # recall@k of rank 0's slice against an exact search over regenerated chunks (fp32 arithmetic is exact on int8 values)
+    ng = min(args.gt_queries, 200, args.batch)
+    recall = None
+    if rank == 0:
+        qf = queries[:ng].float()
+        best_d = torch.full((ng, k), float("inf"), device=dev)
+        best_i = torch.zeros((ng, k), dtype=torch.int64, device=dev)
+        for c in range(n_chunks):
+            x = gen_int8_rows(min(chunk, rows - c * chunk), dim, 1234, dev, row0=c * chunk).float()
+            d2 = (x * x).sum(1)[None, :] - 2.0 * (qf @ x.T)
+            v, ii = torch.topk(d2, k, dim=1, largest=False)
+            cd, ci = torch.cat([best_d, v], 1), torch.cat([best_i, ii + c * chunk], 1)
+            o = torch.argsort(cd, dim=1)[:, :k]
+            best_d, best_i = torch.gather(cd, 1, o), torch.gather(ci, 1, o)
+            del x, d2
+        recall = recall_of(out_i[:ng].cpu().numpy(), best_i.cpu().numpy())
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        print(json.dumps({
+            "metric": f"QPS, IVF-PQ {rows}x96 int8 list-sharded, batch={args.batch} per GPU", "value": round(nq_total / (ms * 1e-3), 1),
+            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": f"u8 codes, {args.lut} LUT, {args.acc} score", "data": "synthetic",
+            "config": {"workload": f"C5 IVF-PQ {rows}x96 int8, pq_dim={args.pq_dim} pq_bits=8 n_lists={n_lists} n_probes={args.n_probes} "
+                                   f"batch={args.batch} per GPU k={k}, no refinement",
+                       "parallelism": f"list shards x{world} dealt by size (LPT), RCCL all-gather of the per-rank top-k",
+                       "rows_on_rank0": len(index), "build_seconds": round(build_s, 1)},
+            f"recall_at_{k}": None if recall is None else round(recall, 4),
+            "scan_kernel_ms_per_step": round(scan_ms.value / max(args.steps, 1), 3), "scan_launches_per_step": n_launch // max(args.steps, 1),
+            "all_gather_merge_ms_per_step": round(ag_ms.value / max(args.steps, 1), 3)}), flush=True)
+    comm.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------- extra configs (N=1)
@@ -338,6 +482,9 @@ def main():
     ap.add_argument("--c4-rows", type=int, default=10_000_000)
     ap.add_argument("--c4-latent", type=int, default=24)
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--config", choices=["c3", "c5"], default="c3",
+                    help="c3: the headline (IVF-PQ 100M x 128 fp32); c5: IVF-PQ rows x 96 int8 list-sharded over the ranks "
+                         "(BASELINE configs[4]: 1B rows over 8 GPUs; --rows scales it down), rows generated chunk by chunk")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the list-sharded code path (shard build, RCCL all-gather + merge) even with one rank")
     args = ap.parse_args()
@@ -345,6 +492,8 @@ def main():
         args.acc = "f32"
     if args.pmc_child:
         return pmc_child(args, args.pmc_child)
+    if args.config == "c5":
+        return run_c5(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -445,7 +594,7 @@ def main():
             elapsed = float(t.item())
         scan_ms = C.c_double(0)
         n_launch = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan_ms))
-        for nm in (b"pq_filter_kernel", b"pq_rescore_kernel"):
+        for nm in (b"pq_head_kernel", b"pq_filter_kernel", b"pq_rescore_kernel"):
             v = C.c_double(0)
             lib().cuvsAmdProfileCollect(nm, C.byref(v))
             phase_ms[nm.decode()] = v.value / max(steps, 1)
@@ -570,6 +719,44 @@ def main():
             except Exception:
                 pass
 
+    # ------------------------------------------------------------------ the same workload with inner product / cosine
+    # (signed LUT entries: no early stop in a LUT scan; the matrix-core filter works on full-score bounds)
+    metric_variants = []
+    if rank == 0 and world == 1 and not args.no_variants and not sharded:
+        gq = queries[:min(200, args.batch)]
+        for metric in ("inner_product", "cosine"):
+            try:
+                t0 = time.time()
+                mi = ivf_pq.build(ivf_pq.IndexParams(n_lists=args.n_lists, metric=metric, pq_dim=args.pq_dim, pq_bits=8, kmeans_n_iters=20,
+                                                     kmeans_trainset_fraction=args.trainset_fraction), data, resources=res)
+                res.sync()
+                b_s = time.time() - t0
+                sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                                         max_internal_batch_size=nq_total)
+                m_dt = timeit(lambda: ivf_pq.search(sp, mi, queries, kk, neighbors=cand_i, distances=cand_d, resources=res), 5, 2)
+                # ground truth in fp64: inner products (cosine: of the normalised vectors)
+                qd = gq.double()
+                if metric == "cosine":
+                    qd = qd / qd.norm(dim=1, keepdim=True)
+                best_v = torch.full((gq.shape[0], kk), -float("inf"), dtype=torch.float64, device=dev)
+                best_i = torch.zeros((gq.shape[0], kk), dtype=torch.int64, device=dev)
+                for r0 in range(0, args.rows, 500_000):
+                    xc = data[r0:r0 + 500_000].double()
+                    if metric == "cosine":
+                        xc = xc / xc.norm(dim=1, keepdim=True)
+                    v, ii = torch.topk(qd @ xc.T, kk, dim=1)
+                    cv, ci = torch.cat([best_v, v], 1), torch.cat([best_i, ii + r0], 1)
+                    o = torch.argsort(cv, dim=1, descending=True)[:, :kk]
+                    best_v, best_i = torch.gather(cv, 1, o), torch.gather(ci, 1, o)
+                    del xc
+                rec = recall_of(cand_i[:gq.shape[0]].cpu().numpy(), best_i.cpu().numpy())
+                metric_variants.append({"metric": metric, "ms_per_search": round(m_dt * 1e3, 3), "qps": round(args.batch / m_dt, 1),
+                                        f"recall_at_{kk}_without_refine": round(rec, 4), "build_seconds": round(b_s, 1)})
+                del mi
+            except Exception as e:
+                metric_variants.append({"metric": metric, "error": repr(e)[:300]})
+            torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ C1 / C2 / C4 lines + CPU baseline (rank 0, N=1)
     extra, cpu = [], None
     if rank == 0 and world == 1:
@@ -627,7 +814,7 @@ def main():
                                        f"step, one native RCCL all-gather of the [Q,k] blocks per step") if sharded
                                       else "single GPU",
                        "lut_dtype": args.lut, "internal_distance_dtype": args.acc, "refine_ratio": args.refine_ratio,
-                       "build_seconds": round(build_s, 1), "variants": variants},
+                       "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants},
             "recall_at_10": round(recall, 4),
             "roofline": roofline,
             "cpu_baseline": cpu,
