@@ -164,6 +164,7 @@ struct filter_params {
   uint2* surv;         // one region of surv_cap entries per workgroup (a single global counter for all survivors made
   uint32_t* surv_cnt;  // ~500 k same-address atomics per search the bottleneck of the kernel: 6.6 of them per us)
   uint32_t surv_cap;   // entries per region; surv_cnt[b]: fill of workgroup b's region, written once at kernel end
+  uint32_t spill_cap;  // entries of the shared spill region behind the workgroups' regions (counter: surv_cnt[gridDim.x])
   uint32_t n_probes, rot_dim, unit_rows;
   float sc;        // power of two applied to both GEMM operands before the fp16 rounding
   float c1;        // -2 / sc^2 (L2) or -1 / sc^2 (inner product)
@@ -391,8 +392,15 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
               const float x    = g == 0 ? acc0[i] : acc1[i];
               if (x >= thr[g] && v < len) {
                 const uint32_t pos = atomicAdd(wg_fill, 1u);  // LDS
-                if (pos < a.surv_cap) my_surv[pos] = make_uint2(pairid[g], base_row + v);
-                else a.qflag[pairid[g] / a.n_probes] = 1u;  // survivor region full: the query is re-done by the LUT scan
+                if (pos < a.surv_cap) {
+                  my_surv[pos] = make_uint2(pairid[g], base_row + v);
+                } else {
+                  // this workgroup's region is full: the spill region shared by all (one global counter, rarely touched);
+                  // only when that is full too is the query handed back to the LUT scan
+                  const uint32_t sp = atomicAdd(a.surv_cnt + gridDim.x, 1u);
+                  if (sp < a.spill_cap) a.surv[(size_t)gridDim.x * a.surv_cap + sp] = make_uint2(pairid[g], base_row + v);
+                  else a.qflag[pairid[g] / a.n_probes] = 1u;
+                }
                 if (a.stats != nullptr) st_surv += 1u;
               }
             }
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
 struct rescore_params {
   const uint2* surv;         // regions of surv_cap entries, one per workgroup of the filter
   const uint32_t* surv_cnt;  // [gridDim.x] fill of every region
-  uint32_t surv_cap;
+  uint32_t surv_cap, spill_cap;
   const uint32_t* probes;  // [n_pairs] list of every pair
   const float* rot_queries;
   const float* centers_rot;
@@ -454,7 +462,9 @@ struct rescore_params {
 template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
 __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
 {
-  const uint32_t n = a.surv_cnt[blockIdx.x];
+  // region blockIdx.x of the filter's workgroups; the last one is the shared spill region
+  const bool spill = blockIdx.x + 1 == gridDim.x;
+  const uint32_t n = spill ? min(a.surv_cnt[blockIdx.x], a.spill_cap) : a.surv_cnt[blockIdx.x];
   const uint2* region = a.surv + (size_t)blockIdx.x * a.surv_cap;
   for (uint32_t s = blockIdx.y * blockDim.x + threadIdx.x; s < n; s += gridDim.y * blockDim.x) {
     const uint2 sv = region[s];
@@ -987,7 +997,9 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   f.cb16 = tb.cb16; f.codes = idx.codes.data(); f.list_offsets = idx.list_offsets.data(); f.list_sizes = idx.list_sizes.data();
   f.row_term = r.is_ip ? nullptr : tb.row_term; f.query_kth = r.query_kth; f.qflag = r.qflag;
   const unsigned grid = pq3_grid(res);
-  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = r.surv_cap / grid;
+  // three quarters of the survivor buffer are cut into one region per workgroup, the rest is the shared spill region
+  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / grid);
+  f.spill_cap = r.surv_cap - f.surv_cap * grid;
   f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.unit_rows = r.unit_rows;
   f.sc = tb.sc; f.c1 = (r.is_ip ? -1.0f : -2.0f) / (tb.sc * tb.sc);
   f.cbmax = tb.cbmax; f.dmax = tb.dmax; f.is_ip = r.is_ip; f.stats = r.stats; f.dbg = r.filter_dbg;
@@ -1018,13 +1030,13 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   }
 
   rescore_params s{};
-  s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
+  s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
   s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = idx.codes.data();
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap;
-  const dim3 rg(grid, 8), rb(256);
+  const dim3 rg(grid + 1, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
   if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_kernel<0, false>), rg, rb, 0, res.stream, s);
   else if (r.lut_mode == 1) { if (r.acc_half) hipLaunchKernelGGL((pq_rescore_kernel<1, true>), rg, rb, 0, res.stream, s);

@@ -30,7 +30,7 @@ struct pq3_run {
   uint32_t overflow_cap;         //   binned by query
   uint32_t* ov_cnt;              // [nq] zeroed
   uint32_t* ov_off;              // [nq + 1]
-  uint32_t* surv_cnt;            // [pq3_grid()] fill of every workgroup's survivor region (written by the filter)
+  uint32_t* surv_cnt;            // [pq3_grid() + 1] zeroed: fill of every workgroup's survivor region, of the spill region
   void* surv;                    // [surv_cap] (pair, flat row), cut into one region per workgroup of the filter
   uint32_t surv_cap;
   void* units;                   // work units of the filter, pq3_max_units() entries

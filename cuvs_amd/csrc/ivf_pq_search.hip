@@ -2048,9 +2048,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const bool use3 = head > 0 && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0;
   uint32_t unit_rows = 0;
   const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows) : 0;
-  uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 4, 1 << 20), 1 << 28) : 0u;
+  uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 16, 1 << 22), 1 << 28) : 0u;
   if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
-  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)4 * bs_alloc + 4 + pq3_grid(res) : 0);
+  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)4 * bs_alloc + 8 + pq3_grid(res) : 0);
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0);
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, max_units);
@@ -2198,7 +2198,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
         r.qflag = qstate.data(); r.qcnt = qstate.data() + bs_alloc; r.counters = qstate.data() + 2 * bs_alloc;
         r.surv_cnt = qstate.data() + 2 * bs_alloc + 2;
-        r.ov_cnt = qstate.data() + 2 * bs_alloc + 2 + pq3_grid(res); r.ov_off = r.ov_cnt + bs_alloc;
+        r.ov_cnt = qstate.data() + 2 * bs_alloc + 4 + pq3_grid(res); r.ov_off = r.ov_cnt + bs_alloc;
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
         r.filter_bits = filter_bits; r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
