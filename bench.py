@@ -397,6 +397,38 @@ def extra_c2(res, dev):
                                  "PMC summary of this kernel: profiles/r03_c2_ivf_flat_pmc.txt"}}
 
 
+def extra_c4_clustered(res, dev, rows=2_000_000, latent=24, modes=4096):
+    """CAGRA on the clustered generator family of C2 / C3 (many tight modes: the kNN graph falls apart into components),
+    with and without index_params.guarantee_connectivity (cagra.hpp:193; graph_core.cuh:1186-1581), itopk 64 and 256."""
+    from cuvs_amd.neighbors import brute_force, cagra
+
+    nq = 10000
+    x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
+    gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=modes, out=x)
+    q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
+    gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=modes, out=q)
+    _, gt = brute_force.search(brute_force.build(x, resources=res), q[:1000], 10, resources=res)
+    res.sync()
+    gt = gt.cpu().numpy()
+    out = {"config": f"C4-clustered CAGRA {rows}x768 fp16, {modes} modes in a {latent}-d latent space, graph_degree=64, batch=10000 k=10"}
+    for guarantee in (False, True):
+        t0 = time.time()
+        idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64, guarantee_connectivity=guarantee), x,
+                          resources=res)
+        res.sync()
+        line = {"build_seconds": round(time.time() - t0, 1)}
+        for itopk in (64, 256):
+            sp = cagra.SearchParams(itopk_size=itopk, algo="auto")
+            nb = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+            dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+            dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 3, 1)
+            rec = recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt)
+            line[f"itopk_{itopk}"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(rec, 4)}
+        out["guarantee_connectivity" if guarantee else "plain"] = line
+        del idx
+    return out
+
+
 def extra_c4(res, dev, rows, latent, modes=1):
     """C4: CAGRA rows x 768 fp16, graph_degree 64 (intermediate 128), itopk 64, batch 10k, k = 10."""
     from cuvs_amd.neighbors import brute_force, cagra
@@ -757,6 +789,48 @@ def main():
                 metric_variants.append({"metric": metric, "error": repr(e)[:300]})
             torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ the sharded code path with one rank (every round
+    # times shard build, head-bound all-reduce, RCCL all-gather of the [Q, k] blocks and the merge, even without a node)
+    sharded_line = None
+    if rank == 0 and world == 1 and not args.no_variants and not sharded:
+        try:
+            t0 = time.time()
+            scomm = ivf_pq_sharded.ShardComm(0, 1, ivf_pq_sharded.ShardComm.unique_id(), res)
+            sip = ivf_pq.IndexParams(n_lists=args.n_lists, metric="sqeuclidean", pq_dim=args.pq_dim, pq_bits=8, kmeans_n_iters=20,
+                                     kmeans_trainset_fraction=args.trainset_fraction, add_data_on_build=False)
+            sidx = ivf_pq_sharded.build(sip, data, 0, 1, resources=res)
+            for r0 in range(0, args.rows, 1 << 24):
+                r1 = min(args.rows, r0 + (1 << 24))
+                ivf_pq_sharded.extend(sidx, data[r0:r1], torch.arange(r0, r1, dtype=torch.int64, device=dev), resources=res)
+            ivf_pq_sharded.attach_comm(sidx, scomm)
+            res.sync()
+            sb = time.time() - t0
+            ssp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                                      max_internal_batch_size=nq_total)
+
+            def sstep():
+                ivf_pq.search(ssp, sidx, queries, kk, neighbors=cand_i, distances=cand_d, resources=res)
+                scomm.all_gather_topk(cand_d, cand_i, out=(mrg_d, mrg_i), resources=res)
+
+            sstep()
+            lib().cuvsAmdProfileEnable(1)
+            s_dt = timeit(sstep, 5, 1)
+            lib().cuvsAmdProfileEnable(0)
+            agv = C.c_double(0)
+            n_ag = lib().cuvsAmdProfileCollect(b"shard_all_gather", C.byref(agv))
+            for nm in (b"pq_scan_kernel", b"pq_head_kernel", b"pq_filter_kernel", b"pq_rescore_kernel", b"shard_all_reduce"):
+                lib().cuvsAmdProfileCollect(nm, None)
+            same = bool(torch.equal(mrg_i, cand_i))
+            sharded_line = {"config": "the headline search through the list-sharded path, one rank (native RCCL communicator)",
+                            "ms_per_search_incl_all_gather_merge": round(s_dt * 1e3, 3), "all_gather_merge_ms": round(agv.value / max(n_ag, 1), 3),
+                            "build_seconds": round(sb, 1), "merged_equals_local": same}
+            ivf_pq_sharded.attach_comm(sidx, None)
+            del sidx
+            scomm.close()
+        except Exception as e:
+            sharded_line = {"config": "sharded one-rank", "error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ C1 / C2 / C4 lines + CPU baseline (rank 0, N=1)
     extra, cpu = [], None
     if rank == 0 and world == 1:
@@ -765,7 +839,8 @@ def main():
         c1_x = c1_q = None
         if not args.no_extras:
             for name, fn in (("C1", lambda: extra_c1(res, dev)), ("C2", lambda: extra_c2(res, dev)),
-                             ("C4", lambda: extra_c4(res, dev, args.c4_rows, args.c4_latent))):
+                             ("C4", lambda: extra_c4(res, dev, args.c4_rows, args.c4_latent)),
+                             ("C4-clustered", lambda: extra_c4_clustered(res, dev))):
                 t0 = time.time()
                 try:
                     out = fn()
@@ -814,7 +889,8 @@ def main():
                                        f"step, one native RCCL all-gather of the [Q,k] blocks per step") if sharded
                                       else "single GPU",
                        "lut_dtype": args.lut, "internal_distance_dtype": args.acc, "refine_ratio": args.refine_ratio,
-                       "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants},
+                       "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants,
+                       "sharded_one_rank": sharded_line},
             "recall_at_10": round(recall, 4),
             "roofline": roofline,
             "cpu_baseline": cpu,
