@@ -73,14 +73,13 @@ __device__ inline float wave_reduce_max_f32(float v)
 // the GEMM: x = -|d|^2 (1 - 2^-9) sc^2 / 2 split into two fp16 values (hi + lo = x to 2^-22; |x| <= 16384 by the choice
 // of sc), so that the accumulator of a (row, query) pair ends up holding sc^2 (r.d - |d|^2 (1 - 2^-9) / 2). One thread per row
 __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows, float sc,
-                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits)
+                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks)
 {
   const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r  = min(r0, rows - 1);  // (no early exit: the wave reduction below needs every lane)
-  const uint4* cp = reinterpret_cast<const uint4*>(codes) + ((size_t)(r >> 6) * 4) * 64 + (r & 63);
+  const uint4* cp = reinterpret_cast<const uint4*>(codes) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
   float dn = 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < n_chunks; ++c) {
     const uint4 cw       = cp[c * 64];
     const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
@@ -108,7 +107,7 @@ struct filter_unit {
 
 __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
                                                            const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
-                                                           uint32_t* __restrict__ unit_off)
+                                                           uint32_t* __restrict__ unit_off, uint32_t group)
 {
   __shared__ int smem[17];
   __shared__ int carry;
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __res
     if (i < n_lists) {
       const uint32_t np = pair_off[n_lists + i + 1] - pair_off[n_lists + i];  // tail labels: n_lists + list
       const uint32_t len = list_sizes[i];
-      v = (int)(((np + 63u) / 64u) * ((len + unit_rows - 1u) / unit_rows));
+      v = (int)(((np + group - 1u) / group) * ((len + unit_rows - 1u) / unit_rows));
     }
     int total;
     const int excl = block_exclusive_scan(v, smem, &total);
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __res
 
 __global__ void fill_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
                                   const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
-                                  const uint32_t* __restrict__ unit_off, filter_unit* __restrict__ units)
+                                  const uint32_t* __restrict__ unit_off, filter_unit* __restrict__ units, uint32_t group)
 {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= n_lists) return;
@@ -143,7 +142,7 @@ __global__ void fill_units_kernel(const uint32_t* __restrict__ pair_off, uint32_
   if (b == e) return;
   // row chunk major: the query groups of one chunk run next to each other and share its rows in L2
   for (uint32_t r0 = 0; r0 < len; r0 += unit_rows)
-    for (uint32_t p = b; p < e; p += 64u) units[w++] = filter_unit{L, p, min(64u, e - p), r0};
+    for (uint32_t p = b; p < e; p += group) units[w++] = filter_unit{L, p, min(group, e - p), r0};
 }
 
 // ------------------------------------------------------------------ the filter
@@ -210,15 +209,21 @@ __device__ inline float filter_threshold_ip(const float bound, const float qn, c
   return f;
 }
 
-template <int DBG>  // ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs, 8 no code loads
+// NCH: 16-byte code chunks per row = pq_dim / 16 (pq_len 2: rot_dim = 32 NCH, 2 NCH MFMA K steps). Up to 4 chunks a
+// work unit holds two groups of 32 queries (B operands: 16 NCH registers) and the decoded rows are double-buffered;
+// beyond (pq_dim 80 .. 128) one group and one buffer.
+// DBG: ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs, 8 no code loads
+template <int NCH, int DBG>
 __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_params a)
 {
+  constexpr int NST = 2 * NCH;            // MFMA K steps
+  constexpr int NG  = NCH <= 4 ? 2 : 1;   // groups of 32 queries per work unit
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* cb = reinterpret_cast<uint32_t*>(smem);  // [64 subspaces][256 codes] fp16x2, 64 KiB
-  uint32_t* wg_fill = reinterpret_cast<uint32_t*>(smem + 64 * 1024);  // survivors of this workgroup so far
+  uint32_t* cb = reinterpret_cast<uint32_t*>(smem);  // [pq_dim subspaces][256 codes] fp16x2 (64 KiB at pq_dim 64)
+  uint32_t* wg_fill = reinterpret_cast<uint32_t*>(smem + NCH * 16 * 1024);  // survivors of this workgroup so far
   uint2* my_surv    = a.surv + (size_t)blockIdx.x * a.surv_cap;
   if (threadIdx.x == 0) *wg_fill = 0u;
-  for (uint32_t i = threadIdx.x; i < 64u * 256u / 4u; i += kFThreads)
+  for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * 256u / 4u; i += kFThreads)
     reinterpret_cast<uint4*>(cb)[i] = reinterpret_cast<const uint4*>(a.cb16)[i];
   __syncthreads();
 
@@ -250,16 +255,16 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
     const uint32_t L = __builtin_amdgcn_readfirstlane(uu.x), first = __builtin_amdgcn_readfirstlane(uu.y),
                    count = __builtin_amdgcn_readfirstlane(uu.z), row0 = __builtin_amdgcn_readfirstlane(uu.w);
     const uint32_t base_row = a.list_offsets[L], len = a.list_sizes[L];
-    const bool two = count > 32u;  // wave-uniform: the second group of 32 queries
+    const bool two = NG == 2 && count > 32u;  // wave-uniform: the second group of 32 queries
     const unsigned long long t_unit = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
     unsigned long long t_slow = 0ull;
 
     // ---- B operands: the item's query residuals as fp16, lane = (query ql of group g, K half h)
-    f16x8_t bop[2][8];
-    float thr[2];
-    uint32_t pairid[2];
+    f16x8_t bop[NG][NST];
+    float thr[2] = {INFINITY, INFINITY};
+    uint32_t pairid[2] = {0u, 0u};
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
       const uint32_t jj = g * 32u + ql;
       const bool valid  = jj < count;
       const uint32_t p  = valid ? a.sorted_pairs[first + jj] : 0u;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
       const float* ct   = a.centers_rot + (size_t)L * a.rot_dim;
       float rn = 0.f, big = 0.f, qc = 0.f, cn = 0.f;
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {
+      for (int st = 0; st < NST; ++st) {
         const uint32_t s0 = 16u * (st >> 1) + 8u * h + 4u * (st & 1);
         const float4 q0 = *reinterpret_cast<const float4*>(rq + 2 * s0), q1 = *reinterpret_cast<const float4*>(rq + 2 * s0 + 4);
         float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -314,18 +319,18 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
     // accumulators are screened; the other wave of the SIMD fills the matrix pipe meanwhile.
     const uint32_t r_end = min(len, row0 + a.unit_rows);
     const uint32_t u0 = row0 >> 5, u1 = (r_end + 31u) >> 5;
-    auto load_codes = [&](const uint32_t u, uint2 (&cw)[4]) {
+    auto load_codes = [&](const uint32_t u, uint2 (&cw)[NCH]) {
       const uint32_t fr = base_row + (min(u, u1 - 1u) << 5) + ql;  // this lane's row (padded rows of a group are readable)
-      const char* p = reinterpret_cast<const char*>(codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u)) + 8u * h;
+      const char* p = reinterpret_cast<const char*>(codes16 + ((size_t)(fr >> 6) * NCH) * 64 + (fr & 63u)) + 8u * h;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NCH; ++c) {
         if constexpr ((DBG & 8) != 0) cw[c] = make_uint2(u * 2654435761u + c, fr);  // ablation: no code loads
         else cw[c] = *reinterpret_cast<const uint2*>(p + (size_t)c * 64 * 16);
       }
     };
-    auto decode = [&](const uint2 (&cw)[4], u32x4_t (&av)[8]) {
+    auto decode = [&](const uint2 (&cw)[NCH], u32x4_t (&av)[NST]) {
 #pragma unroll
-      for (int st = 0; st < 8; ++st) {
+      for (int st = 0; st < NST; ++st) {
         const uint32_t w = (st & 1) ? cw[st >> 1].y : cw[st >> 1].x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -337,30 +342,39 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
     };
     auto run = [&](auto two_tag) {
       constexpr bool TWO = decltype(two_tag)::value;
-      uint2 cw1[4], cw2[4];
-      u32x4_t avA[8], avB[8];  // decoded rows of the current / the next subtile (roles alternate)
+      constexpr bool DOUBLE = NCH <= 4;  // decoded rows of the current / the next subtile in two buffers (roles alternate)
+      uint2 cw1[NCH], cw2[NCH];
+      u32x4_t avA[NST], avB[DOUBLE ? NST : 1];
       load_codes(u0, cw1);
       load_codes(u0 + 1, cw2);
       decode(cw1, avA);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) cw1[c] = cw2[c];
+      for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
       load_codes(u0 + 2, cw2);
       // one subtile: the gathers that decode subtile u + 1 are issued BEFORE the MFMAs of subtile u, so their trip
       // through the LDS queue (shared with seven other waves) overlaps this wave's own matrix work
-      auto step = [&](const uint32_t u, const u32x4_t (&cur)[8], u32x4_t (&nxt)[8]) {
+      auto step = [&](const uint32_t u, u32x4_t (&cur)[NST], auto& nxt) {
         uint32_t term = 0u;  // the rows' K-extension term (one dword per row, lanes of half 0)
         if (a.row_term != nullptr && h == 0u) term = a.row_term[base_row + (u << 5) + ql];
-        decode(cw1, nxt);  // (clamped to the last subtile: a harmless repeat at the end)
+        if constexpr (DOUBLE) {
+          decode(cw1, nxt);  // (clamped to the last subtile: a harmless repeat at the end)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) cw1[c] = cw2[c];
-        load_codes(u + 3, cw2);
+          for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
+          load_codes(u + 3, cw2);
+        }
         f32x16_t acc0 = {}, acc1 = {};
 #pragma unroll
-        for (int st = 0; st < 8; ++st) {
+        for (int st = 0; st < NST; ++st) {
           const f16x8_t aop = __builtin_bit_cast(f16x8_t, cur[st]);
           if constexpr ((DBG & 4) != 0) { acc0[st] += (float)aop[0]; continue; }  // ablation: no MFMAs
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[0][st], acc0, 0, 0, 0);
-          if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[1][st], acc1, 0, 0, 0);
+          if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[NG - 1][st], acc1, 0, 0, 0);
+        }
+        if constexpr (!DOUBLE) {  // one buffer: the next subtile is decoded once this one's MFMAs are issued
+          decode(cw1, cur);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
+          load_codes(u + 3, cw2);
         }
         if (a.row_term != nullptr) {  // wave-uniform: the extra K step adds -|d|^2 (1 - 2^-9) sc^2 / 2 to every pair of the row
           const u32x4_t tq  = {term, 0u, 0u, 0u};
@@ -407,9 +421,13 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
         }
         if (a.stats != nullptr) t_slow += __builtin_readcyclecounter() - t_s0;
       };
-      for (uint32_t u = u0; u < u1; u += 2) {
-        step(u, avA, avB);
-        if (u + 1 < u1) step(u + 1, avB, avA);
+      if constexpr (DOUBLE) {
+        for (uint32_t u = u0; u < u1; u += 2) {
+          step(u, avA, avB);
+          if (u + 1 < u1) step(u + 1, avB, avA);
+        }
+      } else {
+        for (uint32_t u = u0; u < u1; ++u) step(u, avA, avA);
       }
     };
     const unsigned long long t_loop = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
@@ -450,7 +468,7 @@ struct rescore_params {
   float* cand_d;
   uint32_t* cand_i;
   uint32_t* cand_r;
-  uint32_t n_probes, rot_dim, k, head;
+  uint32_t n_probes, rot_dim, k, head, n_chunks;
   int is_ip;
   const uint32_t* filter_bits;
   const int64_t* indices;
@@ -477,11 +495,11 @@ __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
     const uint32_t L = a.probes[pair];
     const float* rq  = a.rot_queries + (size_t)q * a.rot_dim;
     const float* ct  = a.centers_rot + (size_t)L * a.rot_dim;
-    const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * 4) * 64 + (row & 63u);
+    const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
     float af       = 0.f;
     _Float16 ah    = (_Float16)0.f;
 #pragma unroll 1
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < (int)a.n_chunks; ++c) {
       const uint4 cw       = cp[c * 64];
       const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
@@ -550,7 +568,7 @@ struct head_params {
   float* out_d;
   uint32_t* out_i;
   uint32_t* query_kth;
-  uint32_t n_probes, rot_dim, k, cap_rows;
+  uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks;
   int is_ip;
   const uint32_t* filter_bits;
   const int64_t* indices;
@@ -565,10 +583,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   constexpr bool LUT32 = LUT == 0 || (LUT == 2 && !ACC_HALF);
   using lut_t = std::conditional_t<LUT32, float, _Float16>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  lut_t* lut      = reinterpret_cast<lut_t*>(smem);                              // [64][256]
-  float* rv       = reinterpret_cast<float*>(smem + 64 * 256 * sizeof(lut_t));   // [128] residual (L2) / query (IP)
-  float* cv       = rv + 128;                                                    // [128] list centre
-  unsigned long long* min64 = reinterpret_cast<unsigned long long*>(cv + 128);   // [2]
+  lut_t* lut      = reinterpret_cast<lut_t*>(smem);                                      // [pq_dim][256]
+  float* rv       = reinterpret_cast<float*>(smem + (size_t)a.pq_dim * 256 * sizeof(lut_t));  // [256] residual (L2) / query (IP)
+  float* cv       = rv + 256;                                                            // [256] list centre
+  unsigned long long* min64 = reinterpret_cast<unsigned long long*>(cv + 256);           // [2]
   int* ctrl       = reinterpret_cast<int*>(min64 + 2);                           // [8]
   uint32_t* tk    = reinterpret_cast<uint32_t*>(ctrl + 8);                       // [NT] smallest key of every thread
   uint32_t* ckey  = tk + NT;                                                     // [2][kHCand] candidates (two buffers)
@@ -617,17 +635,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ---- LUT (create_lut_impl.cuh:17-78), entry (s, code) at s * 256 + code; the codebook values of 8 entries are
     // loaded before any is used (one L2 round trip per batch instead of one per entry)
 #pragma unroll 1
-    for (uint32_t e0 = tid; e0 < 64u * 256u; e0 += 8u * NT) {
+    for (uint32_t e0 = tid; e0 < a.pq_dim * 256u; e0 += 8u * NT) {
       float p0[8], p1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const uint32_t e = e0 + (uint32_t)j * NT, sb = e >> 8, code = e & 255u;
+        const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = e & 255u;
         p0[j] = a.pq_centers[(size_t)(sb * 2 + 0) * 256 + code];
         p1[j] = a.pq_centers[(size_t)(sb * 2 + 1) * 256 + code];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t e = e0 + (uint32_t)j * NT, sb = e >> 8;
+        if (e >= a.pq_dim * 256u) break;
         const float q0 = rv[sb * 2], q1 = rv[sb * 2 + 1];
         float v;
         if (!a.is_ip) {
@@ -655,22 +674,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       uint32_t my_min = 0xffffffffu;
       for (uint32_t v = tid; v < clen; v += NT) {
         const uint32_t fr = base_row + c0 + v;
-        const uint4* cp   = codes16 + ((size_t)(fr >> 6) * 4) * 64 + (fr & 63u);
-        uint4 cw[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) cw[c] = cp[c * 64];
+        const uint4* cp   = codes16 + ((size_t)(fr >> 6) * a.n_chunks) * 64 + (fr & 63u);
         float af    = 0.f;
         _Float16 ah = (_Float16)0.f;
+        for (int c0c = 0; c0c < (int)a.n_chunks; c0c += 4) {  // four chunk loads in flight
+          uint4 cw[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint32_t ws[4] = {cw[c].x, cw[c].y, cw[c].z, cw[c].w};
+          for (int c = 0; c < 4; ++c) cw[c] = cp[(size_t)min(c0c + c, (int)a.n_chunks - 1) * 64];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int c = c0c + cc;
+            if (c >= (int)a.n_chunks) break;
+            const uint32_t ws[4] = {cw[cc].x, cw[cc].y, cw[cc].z, cw[cc].w};
 #pragma unroll
           for (int b = 0; b < 16; ++b) {
             const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-            const lut_t e       = lut[((c * 16 + b) << 8) + code];
-            if constexpr (LUT32) af += e;
-            else if constexpr (ACC_HALF) ah += e;
-            else af += (float)e;
+              const lut_t e       = lut[((c * 16 + b) << 8) + code];
+              if constexpr (LUT32) af += e;
+              else if constexpr (ACC_HALF) ah += e;
+              else af += (float)e;
+            }
           }
         }
         const float score = ACC_HALF ? (float)ah : af;
@@ -937,7 +960,10 @@ unsigned pq3_grid(const resources& res) { return (unsigned)std::max(8, res.num_c
 
 bool pq3_supported(const ivf_pq_index& idx, int k)
 {
-  return idx.pq_bits == 8 && idx.pq_dim == 64 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 && idx.rot_dim == 128;
+  // pq_len 2 (a lane's 8 K elements of an MFMA step = 4 subspaces = 4 code bytes), whole 16-byte code chunks, a decode
+  // table of at most 128 KiB
+  return idx.pq_bits == 8 && idx.pq_len == 2 && idx.pq_dim % 16 == 0 && idx.pq_dim >= 16 && idx.pq_dim <= 128 &&
+         idx.rot_dim == 2 * idx.pq_dim && idx.codebook_kind == 0 && k <= 64;
 }
 
 pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
@@ -961,7 +987,7 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
     HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
     if (idx.padded_rows > 0)
       hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, idx.codes.data(),
-                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data());
+                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)idx.n_chunks);
     const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
     float dn_max;
     memcpy(&dn_max, &mbits, 4);
@@ -979,18 +1005,20 @@ size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_ro
   // unit: ~23 k cycles against ~250 k for the rows); a list is cut into at most 16 row chunks
   const uint32_t ur = std::max<uint32_t>(4096u, (uint32_t)round_up((int64_t)(max_len + 15) / 16, 64));
   *unit_rows = ur;
-  return (size_t)16 * ((size_t)n_pairs / 64 + idx.n_lists + 1);
+  return (size_t)16 * ((size_t)n_pairs / 32 + idx.n_lists + 1);
 }
 
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
 {
   const pq3_tables tb = pq3_prepare(res, idx);
   profile_begin(res, "pq_scan_kernel");  // bench.py sums the scan phases under this name
+  const int nch        = (int)idx.pq_dim / 16;          // 16-byte code chunks per row
+  const uint32_t group = nch <= 4 ? 64u : 32u;          // queries per work unit (two B-operand groups up to pq_dim 64)
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
-                     r.unit_rows, r.unit_off);
+                     r.unit_rows, r.unit_off, group);
   hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
-                     idx.list_sizes.data(), r.unit_rows, r.unit_off, units);
+                     idx.list_sizes.data(), r.unit_rows, r.unit_off, units, group);
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket;
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = idx.centers_rot.data();
@@ -1013,27 +1041,40 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   else if (r.lut_mode == 1) { f.eps = r.acc_half ? 0.04f : 1.0f / 1024.0f; f.alpha = 64.0f / 16777216.0f; f.bound_max = 60000.f; }
   else                      { f.eps = r.acc_half ? 0.11f : 0.07f; f.alpha = 64.0f / 32768.0f; f.bound_max = 30000.f; }
   if (r.is_ip && r.lut_mode == 2) f.eps = r.acc_half ? 0.18f : 0.14f;  // signed fp8: one value bit less (2^-3 per entry)
+  const size_t fsmem = (size_t)nch * 16 * 1024 + 16;
   auto launch_filter = [&](auto kern) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 + 16));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
     profile_begin(res, "pq_filter_kernel");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFThreads), 64 * 1024 + 16, res.stream, f);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFThreads), fsmem, res.stream, f);
     profile_end(res, "pq_filter_kernel");
   };
-  switch (r.filter_dbg) {  // CUVS_AMD_SCAN_DEBUG bits 16..19: ablation builds of the kernel
-    case 1:  launch_filter(pq_filter_kernel<1>); break;
-    case 2:  launch_filter(pq_filter_kernel<2>); break;
-    case 4:  launch_filter(pq_filter_kernel<4>); break;
-    case 6:  launch_filter(pq_filter_kernel<6>); break;
-    case 8:  launch_filter(pq_filter_kernel<8>); break;
-    case 14: launch_filter(pq_filter_kernel<14>); break;
-    default: launch_filter(pq_filter_kernel<0>); break;
+  if (nch == 4) {
+    switch (r.filter_dbg) {  // CUVS_AMD_SCAN_DEBUG bits 16..19: ablation builds of the kernel (bench shape only)
+      case 1:  launch_filter(pq_filter_kernel<4, 1>); break;
+      case 2:  launch_filter(pq_filter_kernel<4, 2>); break;
+      case 4:  launch_filter(pq_filter_kernel<4, 4>); break;
+      case 6:  launch_filter(pq_filter_kernel<4, 6>); break;
+      case 8:  launch_filter(pq_filter_kernel<4, 8>); break;
+      case 14: launch_filter(pq_filter_kernel<4, 14>); break;
+      default: launch_filter(pq_filter_kernel<4, 0>); break;
+    }
+  } else {
+    switch (nch) {
+      case 1: launch_filter(pq_filter_kernel<1, 0>); break;
+      case 2: launch_filter(pq_filter_kernel<2, 0>); break;
+      case 3: launch_filter(pq_filter_kernel<3, 0>); break;
+      case 5: launch_filter(pq_filter_kernel<5, 0>); break;
+      case 6: launch_filter(pq_filter_kernel<6, 0>); break;
+      case 7: launch_filter(pq_filter_kernel<7, 0>); break;
+      default: launch_filter(pq_filter_kernel<8, 0>); break;
+    }
   }
 
   rescore_params s{};
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
   s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = idx.codes.data();
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
-  s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip;
+  s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = idx.n_chunks;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap;
   const dim3 rg(grid + 1, 8), rb(256);
@@ -1053,10 +1094,10 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   profile_end(res, "pq_scan_kernel");
 }
 
-static size_t head_smem(int lut_mode, bool acc_half, int nt, uint32_t cap_rows)
+static size_t head_smem_fixed(const ivf_pq_index& idx, int lut_mode, bool acc_half, int nt)
 {
   const bool lut32 = lut_mode == 0 || (lut_mode == 2 && !acc_half);
-  return (size_t)64 * 256 * (lut32 ? 4 : 2) + 2 * 128 * 4 + 16 + 32 + (size_t)nt * 4 + 4 * kHCand * 4 + (size_t)cap_rows * 4;
+  return (size_t)idx.pq_dim * 256 * (lut32 ? 4 : 2) + 2 * 256 * 4 + 16 + 32 + (size_t)nt * 4 + 4 * kHCand * 4;
 }
 
 void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
@@ -1066,16 +1107,20 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   a.xcd_ticket = h.xcd_ticket; a.sorted_pairs = h.sorted_pairs; a.rot_queries = h.rot_queries; a.centers_rot = idx.centers_rot.data();
   a.pq_centers = idx.pq_centers.data(); a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data();
   a.list_sizes = idx.list_sizes.data(); a.out_d = h.cand_d; a.out_i = h.cand_i; a.query_kth = h.query_kth;
-  a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip;
+  a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip; a.pq_dim = idx.pq_dim; a.n_chunks = idx.n_chunks;
   a.filter_bits = h.filter_bits; a.indices = idx.indices.data(); a.stats = h.stats;
-  // fp16 LUT (32 KiB): two 512-thread workgroups per CU with 8192 score keys each - one streams its list while the
-  // other selects; fp32 LUT (64 KiB): one 1024-thread workgroup with 16384 keys. Longer lists are scanned in chunks.
+  // A LUT of up to 32 KiB (fp16 entries at pq_dim 64): two 512-thread workgroups per CU, one streams its list while the
+  // other selects; beyond: one 1024-thread workgroup. The rest of the LDS holds the score keys of a list chunk; longer
+  // lists are scanned in chunks.
   const bool lut32 = h.lut_mode == 0 || (h.lut_mode == 2 && !h.acc_half);
-  const int nt = lut32 ? 1024 : 512;
-  a.cap_rows   = lut32 ? 16384u : 8192u;
+  const bool small = (size_t)idx.pq_dim * 256 * (lut32 ? 4 : 2) <= 32 * 1024;
+  const int nt = small ? 512 : 1024;
+  const size_t budget = (small ? 80 : 160) * 1024 - 64, fixed = head_smem_fixed(idx, h.lut_mode, h.acc_half != 0, nt);
+  CUVS_EXPECTS(budget > fixed + 4096, "ivf_pq: the head-phase LUT does not fit the LDS");
+  a.cap_rows = (uint32_t)(((budget - fixed) / 4) & ~size_t(63));
   if (h.max_list_len > 0) a.cap_rows = std::min<uint32_t>(a.cap_rows, (uint32_t)round_up(h.max_list_len, 64));
-  const size_t smem   = head_smem(h.lut_mode, h.acc_half != 0, nt, a.cap_rows);
-  const unsigned grid = pq3_grid(res) * (lut32 ? 1u : 2u);
+  const size_t smem   = fixed + (size_t)a.cap_rows * 4;
+  const unsigned grid = pq3_grid(res) * (small ? 2u : 1u);
   auto go = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     profile_begin(res, "pq_scan_kernel");
@@ -1084,9 +1129,15 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
     profile_end(res, "pq_head_kernel");
     profile_end(res, "pq_scan_kernel");
   };
-  if (h.lut_mode == 0)      go(pq_head_kernel<0, false, 1024>);
-  else if (h.lut_mode == 1) { if (h.acc_half) go(pq_head_kernel<1, true, 512>); else go(pq_head_kernel<1, false, 512>); }
-  else                      { if (h.acc_half) go(pq_head_kernel<2, true, 512>); else go(pq_head_kernel<2, false, 1024>); }
+  auto pick = [&](auto lut_tag, auto acc_tag) {
+    constexpr int LUT = decltype(lut_tag)::value;
+    constexpr bool ACC = decltype(acc_tag)::value;
+    if (small) go(pq_head_kernel<LUT, ACC, 512>); else go(pq_head_kernel<LUT, ACC, 1024>);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  if (h.lut_mode == 0)      pick(I0{}, std::false_type{});
+  else if (h.lut_mode == 1) { if (h.acc_half) pick(I1{}, std::true_type{}); else pick(I1{}, std::false_type{}); }
+  else                      { if (h.acc_half) pick(I2{}, std::true_type{}); else pick(I2{}, std::false_type{}); }
 }
 
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)

@@ -143,6 +143,34 @@ def test_c3_shape_inner_product_and_cosine(metric, lut, acc, monkeypatch):
     assert (gi == si).all() and (gd == sd).all()
 
 
+@pytest.mark.parametrize("dim,pq_dim,metric,lut,acc", [(32, 16, "sqeuclidean", "f16", "f32"), (64, 32, "sqeuclidean", "f16", "f32"),
+                                                        (96, 48, "sqeuclidean", "f32", "f32"), (96, 48, "inner_product", "f16", "f16"),
+                                                        (160, 80, "sqeuclidean", "f16", "f32"), (192, 96, "sqeuclidean", "fp8", "f16"),
+                                                        (256, 128, "sqeuclidean", "f16", "f32"), (256, 128, "cosine", "f16", "f32")])
+def test_matrix_core_tail_phase_at_other_pq_dims(dim, pq_dim, metric, lut, acc, monkeypatch):
+    """pq_len 2 with 1 .. 8 code chunks per row (pq_dim 16 .. 128): the decode / MFMA filter is instantiated per chunk
+    count (two query groups and double-buffered rows up to pq_dim 64, one group beyond), the head kernel and the
+    re-scoring take pq_dim at run time."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(50_000, dim, 320, seed=dim + pq_dim)
+    if metric != "sqeuclidean":
+        x += 0.4
+        q += 0.4
+    index = _pq_build(x, n_lists=16, pq_dim=pq_dim, pq_bits=8, kmeans_n_iters=8, kmeans_trainset_fraction=0.3, metric=metric)
+    assert index.pq_dim == pq_dim and index.pq_len == 2
+    ex = ivf_pq.export_for_oracle(index)
+    k, n_probes = 16, 10
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (gi == si).all() and (gd == sd).all()
+
+
 # ---------------------------------------------------------------------------------------------------------- C4 shape
 @pytest.fixture(scope="module")
 def cagra_768():
