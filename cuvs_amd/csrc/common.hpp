@@ -80,6 +80,7 @@ struct tuning {
   int pq_head_probes    = -1;  // CUVS_AMD_PQ_HEAD_PROBES: probes per query in the cold-bounds phase (-1: default rule)
   int pq_scan2          = 1;   // CUVS_AMD_PQ_SCAN2=0: tail phase through pq_scan_kernel (comparator in the tests)
   int pq_scan3          = 1;   // CUVS_AMD_PQ_SCAN3=0: tail phase without the matrix-core filter (comparator in the tests)
+  int flat_scan3        = 1;   // CUVS_AMD_FLAT_SCAN3=0: IVF-Flat tail phase on the scan kernel (comparator in the tests)
   int pq3_surv_cap      = 0;   // CUVS_AMD_PQ3_SURV_CAP: survivor-list entries of the matrix-core filter (test hook: forces the hand-back path)
   int pq_qcap           = 0;   // CUVS_AMD_PQ_QCAP: survivor-queue rows of pq_scan2_kernel (test hook: forces the overflow path)
   int scan_debug        = 0;   // CUVS_AMD_SCAN_DEBUG: ablation / statistics bits of the PQ scan
@@ -107,6 +108,7 @@ struct resources {
   hipStream_t aux_stream  = nullptr;          // helper stream + events for two-stream pipelines (brute force), made on first use
   hipEvent_t aux_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool cagra_guarantee_connectivity = false;  // cuvsAmdCagraSetGuaranteeConnectivity (cagra.hpp:193 has no C field)
+  uint32_t* host_word = nullptr;              // one pinned word for small device -> host readbacks (made on first use)
   unsigned long long* cagra_work = nullptr;   // device [3]: rows scored / graph rows read / walkers (cuvsAmdCagraWorkCounters)
 };
 
@@ -182,6 +184,15 @@ std::vector<T> to_host(resources& res, const T* d, size_t n)
   copy_async(res, h.data(), d, n * sizeof(T));
   sync(res);
   return h;
+}
+
+// one device word read back through the handle's pinned word (a pageable destination makes the runtime stage the copy)
+inline uint32_t read_word(resources& res, const uint32_t* d)
+{
+  if (res.host_word == nullptr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&res.host_word), 64));
+  HIP_TRY(hipMemcpyAsync(res.host_word, d, sizeof(uint32_t), hipMemcpyDeviceToHost, res.stream));
+  sync(res);
+  return *res.host_word;
 }
 
 // ---------------------------------------------------------------- DLPack checks

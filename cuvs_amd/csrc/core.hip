@@ -97,6 +97,7 @@ tuning load_tuning_from_env()
   t.pq_head_probes   = geti("CUVS_AMD_PQ_HEAD_PROBES", -1);
   t.pq_scan2         = geti("CUVS_AMD_PQ_SCAN2", 1);
   t.pq_scan3         = geti("CUVS_AMD_PQ_SCAN3", 1);
+  t.flat_scan3       = geti("CUVS_AMD_FLAT_SCAN3", 1);
   t.pq3_surv_cap     = geti("CUVS_AMD_PQ3_SURV_CAP", 0);
   t.pq_qcap          = geti("CUVS_AMD_PQ_QCAP", 0);
   t.scan_debug       = geti("CUVS_AMD_SCAN_DEBUG", 0);
@@ -188,6 +189,7 @@ cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
       for (auto& e : r->aux_events) if (e != nullptr) (void)hipEventDestroy(e);
     }
     if (r->cagra_work != nullptr) (void)hipFree(r->cagra_work);
+    if (r->host_word != nullptr) (void)hipHostFree(r->host_word);
     if (r->pool != nullptr) (void)hipMemPoolDestroy(r->pool);
     if (r->owns_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;

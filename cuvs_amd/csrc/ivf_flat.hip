@@ -14,6 +14,9 @@
 // cycles. Per-wave register top lists + shared k-th bounds, two-phase schedule and a per-tile early stop as in
 // the PQ scan. Cosine = dot products + in-kernel row norms. In-list order is ascending source id.
 #include "ivf_common.hpp"
+#include "ivf_pq_scan3.hpp"
+
+#include <chrono>
 #include "serialize.hpp"
 #include "npy_io.hpp"
 
@@ -43,6 +46,7 @@ struct ivf_flat_index {
   dev_buf<int64_t> indices;     // [padded_rows]
   dev_buf<uint32_t> list_sizes, list_offsets;
   std::vector<uint32_t> h_list_sizes, h_list_offsets;
+  mutable flat3_cache scan3;    // fp16 residual copy for the matrix-core tail phase (ivf_pq_scan3.hip), built on first use
 };
 
 namespace {
@@ -755,6 +759,20 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<float> qtiles(res, max_items * (dim_pad + 1) * qpb);
   dev_buf<float> cand_d(res, large_k ? (size_t)bs * scores_ld : (size_t)np_max * k), top_d(res, (size_t)bs * k);
   const size_t esz = elem_size(et);
+  // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): fp32 rows, L2, batches large enough for a head phase
+  const bool use3 = head > 0 && et == elem_t::f32 && metric_is_l2(idx.metric) && !large_k && n_queries >= 256 &&
+                    flat3_supported(idx.dim, k) && res.tune.flat_scan3 != 0;
+  uint32_t max_list_len = 0;
+  for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
+  const uint32_t unit_rows = std::max<uint32_t>(4096u, (uint32_t)round_up((int64_t)(max_list_len + 15) / 16, 64));
+  const size_t max_units   = use3 ? (size_t)16 * ((size_t)np_max / 32 + idx.n_lists + 1) : 0;
+  uint32_t surv_cap        = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(np_max * 16, 1 << 22), 1 << 28) : 0u;
+  if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
+  const uint32_t overflow_cap = use3 ? (res.tune.pq3_surv_cap > 0 ? (uint32_t)res.tune.pq3_surv_cap : (1u << 22)) : 0u;
+  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)np_max * k : 0), qstate(res, use3 ? (size_t)4 * bs + 8 + pq3_grid(res) + 1 : 0);
+  dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0), tickets3(res, use3 ? 8 * 32 : 0);
+  dev_buf<uint2> surv(res, surv_cap);
+  dev_buf<uint4> units3(res, max_units), overflow3(res, (size_t)2 * overflow_cap);
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
     const int64_t nq      = std::min(max_batch, n_queries - q0);
@@ -790,6 +808,12 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data());
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
+    if (use3) {  // the candidate rows start out invalid: the tail of a query's row is its pool
+      HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)n_pairs * k, res.stream));
+      HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)n_pairs * k * sizeof(uint32_t), res.stream));
+      HIP_TRY(hipMemsetAsync(qstate.data(), 0, qstate.bytes(), res.stream));
+      HIP_TRY(hipMemsetAsync(tickets3.data(), 0, tickets3.bytes(), res.stream));
+    }
     if (large_k) {
       HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)nq * scores_ld, res.stream));
       HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)nq * scores_ld * sizeof(uint32_t), res.stream));
@@ -833,16 +857,47 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       profile_end(res, "ivf_flat_scan_kernel");
     };
     // grids are upper bounds of the (device-side) item counts of each phase; surplus workgroups exit at once
+    bool merged = false;
     if (head > 0) {
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
       launch(a, (unsigned)(nq * head / qpb + idx.n_lists + 1));
       a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
-      launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
+      if (use3) {
+        pq3_run r{};
+        r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = 0;
+        r.sorted_pairs = sorted_pairs.data(); r.pair_off = pair_off.data(); r.probes = probes.data();
+        r.rot_queries = qf.data(); r.query_kth = query_kth.data();
+        r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
+        r.qflag = qstate.data(); r.qcnt = qstate.data() + bs; r.counters = qstate.data() + 2 * bs;
+        r.surv_cnt = qstate.data() + 2 * bs + 2;
+        r.ov_cnt = qstate.data() + 2 * bs + 4 + pq3_grid(res); r.ov_off = r.ov_cnt + bs;
+        r.fail = qstate.data() + 4 * bs + 8 + pq3_grid(res);
+        r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
+        r.unit_rows = unit_rows; r.xcd_ticket = tickets3.data(); r.filter_bits = filter_bits;
+        r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
+        flat3_view v{idx.data.data(), idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
+                     idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len};
+        const bool tdbg = (res.tune.scan_debug & 1024) != 0;
+        auto now = [&]() { if (tdbg) sync(res); return std::chrono::steady_clock::now(); };
+        const auto t0 = now();
+        flat3_tail(res, v, idx.scan3, r);
+        const auto t1 = now();
+        pq3_merge(res, r, top_d.data(), top_i.data());
+        const auto t2 = now();
+        if (tdbg)
+          fprintf(stderr, "[flat3] tail %.3f ms, merge %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                  std::chrono::duration<double, std::milli>(t2 - t1).count());
+        // a buffer ran over (bounds too loose to filter: e.g. lists shorter than k): the tail phase again, on the scan kernel
+        merged = read_word(res, r.fail) == 0u;
+      }
+      if (!merged) launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
     } else {
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
       launch(a, (unsigned)(n_pairs / qpb + idx.n_lists + 1));
     }
-    if (!large_k) {
+    if (merged) {
+      // pq3_merge: head lists + pools
+    } else if (!large_k) {
       select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
                                    k, top_d.data(), top_i.data(), true);
     } else {

@@ -173,6 +173,12 @@ struct filter_params {
   int is_ip;
   unsigned long long* stats;  // optional [8]: pairs tested, survivors, subtiles, slow-path subtiles, cycles (see the kernel), units
   int dbg;                    // ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs
+  // IVF-Flat (FLAT builds of the kernel): the rows' residuals against their list centre as scaled fp16, laid out as the
+  // A operands themselves - [32-row tile][K step][lane] x 16 bytes - so a subtile is NST coalesced 1 KiB loads
+  const uint4* rows16;
+  // IVF-Flat has no per-pair hand-back kernel: a query that cannot be served survives every test (its rows are all
+  // re-scored), and a full buffer raises *fail - the caller re-runs the batch's tail phase on the scan kernel
+  uint32_t* fail;
 };
 
 // Largest value B with: exact score > bound  whenever  (row term - 2 dot16 / sc^2) > B   (L2; see the file header).
@@ -213,18 +219,19 @@ __device__ inline float filter_threshold_ip(const float bound, const float qn, c
 // work unit holds two groups of 32 queries (B operands: 16 NCH registers) and the decoded rows are double-buffered;
 // beyond (pq_dim 80 .. 128) one group and one buffer.
 // DBG: ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs, 8 no code loads
-template <int NCH, int DBG>
+template <int NCH, int DBG, bool FLAT = false>
 __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_params a)
 {
   constexpr int NST = 2 * NCH;            // MFMA K steps
   constexpr int NG  = NCH <= 4 ? 2 : 1;   // groups of 32 queries per work unit
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* cb = reinterpret_cast<uint32_t*>(smem);  // [pq_dim subspaces][256 codes] fp16x2 (64 KiB at pq_dim 64)
-  uint32_t* wg_fill = reinterpret_cast<uint32_t*>(smem + NCH * 16 * 1024);  // survivors of this workgroup so far
+  uint32_t* wg_fill = reinterpret_cast<uint32_t*>(smem + (FLAT ? 0 : NCH * 16 * 1024));  // survivors of this workgroup so far
   uint2* my_surv    = a.surv + (size_t)blockIdx.x * a.surv_cap;
   if (threadIdx.x == 0) *wg_fill = 0u;
-  for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * 256u / 4u; i += kFThreads)
-    reinterpret_cast<uint4*>(cb)[i] = reinterpret_cast<const uint4*>(a.cb16)[i];
+  if constexpr (!FLAT)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * 256u / 4u; i += kFThreads)
+      reinterpret_cast<uint4*>(cb)[i] = reinterpret_cast<const uint4*>(a.cb16)[i];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
           rn   = __fmaf_rn(r[e], r[e], rn);
           const float x = a.sc * r[e];
           big  = fmaxf(big, fabsf(x));
-          v[e] = (_Float16)x;
+          v[e] = (_Float16)fminf(fmaxf(x, -60000.f), 60000.f);  // (finite whatever happens: unserved queries may still be screened)
         }
         bop[g][st] = v;
       }
@@ -305,10 +312,12 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
       const float bound = key_to_float(kk);
       // no finite bound yet, an operand beyond the fp16 range, a bound the LUT type cannot represent, or a query that
       // is re-done by the LUT scan anyway: nothing of this query survives here
-      const bool served = valid && kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max && a.qflag[q] == 0u;
-      if (valid && !served) a.qflag[q] = 1u;
+      const bool served = valid && kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max && (FLAT || a.qflag[q] == 0u);
+      if (!FLAT && valid && !served) a.qflag[q] = 1u;
       const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
-      thr[g] = served ? t / a.c1 : INFINITY;  // in accumulator units (c1 < 0: the test flips)
+      // in accumulator units (c1 < 0: the test flips); an unserved query drops everything (PQ: handed back) or survives
+      // everything (FLAT: all its rows are re-scored)
+      thr[g] = served ? t / a.c1 : ((FLAT && valid) ? -INFINITY : INFINITY);
     }
     // B operand of the K-extension step: the row term's two halves times one
     const u32x4_t oq   = {h == 0u ? 0x3c003c00u : 0u, 0u, 0u, 0u};
@@ -340,23 +349,38 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
         }
       }
     };
+    // FLAT: the A operands of subtile u are NST 16-byte loads per lane from the fp16 residual copy
+    auto load_rows = [&](const uint32_t u, u32x4_t (&av)[NST]) {
+      const uint4* p = a.rows16 + ((size_t)((base_row >> 5) + min(u, u1 - 1u)) * NST) * 64 + lane;
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const uint4 v = p[(size_t)st * 64];
+        av[st] = u32x4_t{v.x, v.y, v.z, v.w};
+      }
+    };
     auto run = [&](auto two_tag) {
       constexpr bool TWO = decltype(two_tag)::value;
       constexpr bool DOUBLE = NCH <= 4;  // decoded rows of the current / the next subtile in two buffers (roles alternate)
       uint2 cw1[NCH], cw2[NCH];
       u32x4_t avA[NST], avB[DOUBLE ? NST : 1];
-      load_codes(u0, cw1);
-      load_codes(u0 + 1, cw2);
-      decode(cw1, avA);
+      if constexpr (FLAT) {
+        load_rows(u0, avA);
+      } else {
+        load_codes(u0, cw1);
+        load_codes(u0 + 1, cw2);
+        decode(cw1, avA);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
-      load_codes(u0 + 2, cw2);
+        for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
+        load_codes(u0 + 2, cw2);
+      }
       // one subtile: the gathers that decode subtile u + 1 are issued BEFORE the MFMAs of subtile u, so their trip
       // through the LDS queue (shared with seven other waves) overlaps this wave's own matrix work
       auto step = [&](const uint32_t u, u32x4_t (&cur)[NST], auto& nxt) {
         uint32_t term = 0u;  // the rows' K-extension term (one dword per row, lanes of half 0)
         if (a.row_term != nullptr && h == 0u) term = a.row_term[base_row + (u << 5) + ql];
-        if constexpr (DOUBLE) {
+        if constexpr (FLAT) {
+          if constexpr (DOUBLE) load_rows(u + 1, nxt);
+        } else if constexpr (DOUBLE) {
           decode(cw1, nxt);  // (clamped to the last subtile: a harmless repeat at the end)
 #pragma unroll
           for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
@@ -371,10 +395,14 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
           if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[NG - 1][st], acc1, 0, 0, 0);
         }
         if constexpr (!DOUBLE) {  // one buffer: the next subtile is decoded once this one's MFMAs are issued
-          decode(cw1, cur);
+          if constexpr (FLAT) {
+            load_rows(u + 1, cur);
+          } else {
+            decode(cw1, cur);
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
-          load_codes(u + 3, cw2);
+            for (int c = 0; c < NCH; ++c) cw1[c] = cw2[c];
+            load_codes(u + 3, cw2);
+          }
         }
         if (a.row_term != nullptr) {  // wave-uniform: the extra K step adds -|d|^2 (1 - 2^-9) sc^2 / 2 to every pair of the row
           const u32x4_t tq  = {term, 0u, 0u, 0u};
@@ -413,6 +441,7 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
                   // only when that is full too is the query handed back to the LUT scan
                   const uint32_t sp = atomicAdd(a.surv_cnt + gridDim.x, 1u);
                   if (sp < a.spill_cap) a.surv[(size_t)gridDim.x * a.surv_cap + sp] = make_uint2(pairid[g], base_row + v);
+                  else if (FLAT) *a.fail = 1u;
                   else a.qflag[pairid[g] / a.n_probes] = 1u;
                 }
                 if (a.stats != nullptr) st_surv += 1u;
@@ -475,7 +504,30 @@ struct rescore_params {
   uint4* overflow;        // candidates of queries whose pool is full: (query, score bits, probe rank, row)
   uint32_t* overflow_cnt;
   uint32_t overflow_cap;
+  uint32_t* fail;         // IVF-Flat: raised when the overflow list is full (nullptr: the query is flagged instead)
+  uint32_t dim;           // IVF-Flat: row length
 };
+
+// a re-scored survivor: into the query's pool if it is within the bound, beyond the pool's capacity into the overflow list
+__device__ inline void pool_append(const rescore_params& a, const uint32_t q, const uint32_t pair, const uint32_t row, const float score)
+{
+  if (float_to_key(score) > a.query_kth[q]) return;
+  const uint32_t cap = (a.n_probes - a.head) * a.k;
+  const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
+  if (pos >= cap) {
+    // a loose head bound: the query's further candidates go to a list shared by all such queries (binned by query
+    // before the merge); only when that is full too is the query handed back (IVF-Flat: the batch is re-run)
+    const uint32_t ov = atomicAdd(a.overflow_cnt, 1u);
+    if (ov < a.overflow_cap) a.overflow[ov] = make_uint4(q, __float_as_uint(score), pair % a.n_probes, row);
+    else if (a.fail != nullptr) *a.fail = 1u;
+    else a.qflag[q] = 1u;
+    return;
+  }
+  const size_t o = (size_t)q * a.n_probes * a.k + (size_t)a.head * a.k + pos;
+  a.cand_d[o] = score;
+  a.cand_i[o] = row;
+  a.cand_r[o] = pair % a.n_probes;
+}
 
 template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
 __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
@@ -528,21 +580,121 @@ __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
       }
     }
     const float score = ACC_HALF ? (float)ah : af;
-    if (float_to_key(score) > a.query_kth[q]) continue;
-    const uint32_t cap = (a.n_probes - a.head) * a.k;
-    const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
-    if (pos >= cap) {
-      // a loose head bound: the query's further candidates go to a list shared by all such queries (the merge reads it
-      // for the queries whose pool count went past the capacity); only when that is full too is the query handed back
-      const uint32_t ov = atomicAdd(a.overflow_cnt, 1u);
-      if (ov < a.overflow_cap) a.overflow[ov] = make_uint4(q, __float_as_uint(score), pair % a.n_probes, row);
-      else a.qflag[q] = 1u;
-      continue;
+    pool_append(a, q, pair, row, score);
+  }
+}
+
+// ------------------------------------------------------------------ IVF-Flat through the same filter (fp32 rows, L2)
+// The A operands of the GEMM are the rows' residuals against their list centre, rounded to fp16 after a power-of-two
+// scaling: a derived copy of the index (half its size; 288 GB of HBM pay for it) laid out as the MFMA wants it.
+// max |x - c| over the index (scaling) and |x - c|^2 per row (K-extension term); one thread per row
+__global__ void flat_residual_stats_kernel(const uint8_t* __restrict__ data, const float* __restrict__ centers,
+                                           const uint32_t* __restrict__ row_list, int64_t rows, uint32_t dim, uint32_t n_chunks,
+                                           float* __restrict__ dn, uint32_t* __restrict__ max_bits)
+{
+  const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r  = min(r0, rows - 1);
+  const uint32_t L = row_list[r >> 6];  // list of the row's 64-row group (0xffffffff: padding beyond the last list)
+  float acc = 0.f, mx = 0.f;
+  if (L != 0xffffffffu) {
+    const uint4* cp = reinterpret_cast<const uint4*>(data) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
+    const float* ct = centers + (size_t)L * dim;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      const uint4 w = cp[(size_t)c * 64];
+      const float x[4] = {__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = x[e] - ct[c * 4 + e];
+        acc = __fmaf_rn(d, d, acc);
+        mx  = fmaxf(mx, fabsf(d));
+      }
     }
-    const size_t o = (size_t)q * a.n_probes * a.k + (size_t)a.head * a.k + pos;
-    a.cand_d[o] = score;
-    a.cand_i[o] = row;
-    a.cand_r[o] = pair % a.n_probes;
+  }
+  if (r0 < rows) dn[r] = acc;
+  const float wm = wave_reduce_max_f32(mx);
+  if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(wm));
+}
+
+// list id of every 64-row group (lists start at multiples of 64)
+__global__ void flat_group_lists_kernel(const uint32_t* __restrict__ list_offsets, const uint32_t* __restrict__ list_sizes,
+                                        uint32_t n_lists, uint32_t* __restrict__ row_list)
+{
+  const uint32_t L = blockIdx.x;
+  if (L >= n_lists) return;
+  const uint32_t g0 = list_offsets[L] >> 6, g1 = (list_offsets[L] + list_sizes[L] + 63u) >> 6;
+  for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) row_list[g] = L;
+}
+
+// rows16[tile][step][lane]: lane (row r = lane & 31 of the tile, half h = lane >> 5) holds the residuals of dimensions
+// [32 (step / 2) + 16 h + 8 (step % 2), + 8) - the K-slot order of the B operands - as scaled fp16; term[row]: the K-extension halves of -|x - c|^2 (1 - 2^-9) sc^2 / 2
+__global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float* __restrict__ centers,
+                                   const uint32_t* __restrict__ row_list, const float* __restrict__ dn, int64_t rows, uint32_t dim,
+                                   uint32_t n_chunks, float sc, uint4* __restrict__ rows16, uint32_t* __restrict__ term)
+{
+  const uint32_t nst = dim / 16;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, step, lane)
+  if (t >= rows / 32 * nst * 64) return;
+  const uint32_t lane = (uint32_t)(t & 63), st = (uint32_t)((t >> 6) % nst);
+  const int64_t tile  = (t >> 6) / nst;
+  const int64_t r     = tile * 32 + (lane & 31);
+  const uint32_t h    = lane >> 5, d0 = 32u * (st >> 1) + 16u * h + 8u * (st & 1);  // the filter kernel's K-slot order
+  const uint32_t L    = row_list[r >> 6];
+  _Float16 v[8];
+  if (L != 0xffffffffu) {
+    const uint4* cp = reinterpret_cast<const uint4*>(data) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
+    const float* ct = centers + (size_t)L * dim + d0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const uint4 w = cp[(size_t)(d0 / 4 + c) * 64];
+      const float x[4] = {__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[c * 4 + e] = (_Float16)(sc * (x[e] - ct[c * 4 + e]));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+  }
+  uint32_t w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    w[e] = (uint32_t)__builtin_bit_cast(uint16_t, v[2 * e]) | ((uint32_t)__builtin_bit_cast(uint16_t, v[2 * e + 1]) << 16);
+  rows16[t] = make_uint4(w[0], w[1], w[2], w[3]);
+  if (st == 0 && h == 0) {
+    const float x     = -0.5f * sc * sc * (dn[r] * (1.0f - 1.0f / 512.0f));
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    term[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+  }
+}
+
+// one lane per survivor: the scan kernel's arithmetic (ivf_flat.hip: t = q - x, acc = fma(t, t, acc) in dimension order)
+__global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params a)
+{
+  const bool spill = blockIdx.x + 1 == gridDim.x;
+  const uint32_t n = spill ? min(a.surv_cnt[blockIdx.x], a.spill_cap) : a.surv_cnt[blockIdx.x];
+  const uint2* region = a.surv + (size_t)blockIdx.x * a.surv_cap;
+  for (uint32_t s = blockIdx.y * blockDim.x + threadIdx.x; s < n; s += gridDim.y * blockDim.x) {
+    const uint2 sv = region[s];
+    const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
+    if (a.filter_bits != nullptr) {
+      const int64_t sid = a.indices[row];
+      if (((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) == 0u) continue;
+    }
+    const float* rq = a.rot_queries + (size_t)q * a.dim;
+    const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
+    float acc = 0.f;
+    for (uint32_t c = 0; c < a.n_chunks; ++c) {
+      const uint4 w    = cp[(size_t)c * 64];
+      const float x[4] = {__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+      const float4 qv  = *reinterpret_cast<const float4*>(rq + c * 4);
+      const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t = qq[e] - x[e];
+        acc = __fmaf_rn(t, t, acc);
+      }
+    }
+    pool_append(a, q, pair, row, acc);
   }
 }
 
@@ -1076,7 +1228,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = idx.n_chunks;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
-  s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap;
+  s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
   const dim3 rg(grid + 1, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
   if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_kernel<0, false>), rg, rb, 0, res.stream, s);
@@ -1138,6 +1290,90 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   if (h.lut_mode == 0)      pick(I0{}, std::false_type{});
   else if (h.lut_mode == 1) { if (h.acc_half) pick(I1{}, std::true_type{}); else pick(I1{}, std::false_type{}); }
   else                      { if (h.acc_half) pick(I2{}, std::true_type{}); else pick(I2{}, std::false_type{}); }
+}
+
+bool flat3_supported(uint32_t dim, int k) { return dim % 32 == 0 && dim >= 32 && dim <= 256 && k <= 64; }
+
+static void flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
+{
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (c.data_ptr == v.data && c.rows == v.padded_rows && c.size == v.size) return;
+  const int64_t rows = std::max<int64_t>(v.padded_rows, 64);
+  dev_buf<uint32_t> row_list(res, (size_t)rows / 64), mxd(res, 1);
+  dev_buf<float> dn(res, (size_t)rows);
+  HIP_TRY(hipMemsetAsync(row_list.data(), 0xff, row_list.bytes(), res.stream));
+  HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
+  hipLaunchKernelGGL(flat_group_lists_kernel, dim3(v.n_lists), dim3(64), 0, res.stream, v.list_offsets, v.list_sizes, v.n_lists,
+                     row_list.data());
+  c.rows16   = dev_buf<uint4>::persistent((size_t)rows / 32 * (v.dim / 16) * 64);
+  c.row_term = dev_buf<uint32_t>::persistent((size_t)rows);
+  if (v.padded_rows > 0) {
+    hipLaunchKernelGGL(flat_residual_stats_kernel, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data, v.centers,
+                       row_list.data(), v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
+    const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
+    float mx;
+    memcpy(&mx, &mbits, 4);
+    // both GEMM operands are scaled by a power of two so that the largest residual component lands in (8, 16] (as the
+    // codebook values of the IVF-PQ filter: the K-extension term stays below 16384)
+    c.maxres = mx;
+    c.sc     = mx > 0.f ? std::exp2(std::floor(std::log2(16.0f / mx))) : 1.0f;
+    const int64_t n_t = v.padded_rows / 32 * (v.dim / 16) * 64;
+    hipLaunchKernelGGL(flat_rows16_kernel, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(),
+                       dn.data(), v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
+  }
+  sync(res);
+  c.data_ptr = v.data; c.rows = v.padded_rows; c.size = v.size;
+}
+
+void flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r)
+{
+  flat3_prepare(res, v, cache);
+  profile_begin(res, "ivf_flat_scan_kernel");  // bench.py sums the scan phases under this name
+  const int nch        = (int)v.dim / 32;   // the filter kernel's "chunk" = two K steps of 16 dimensions
+  const uint32_t group = nch <= 4 ? 64u : 32u;
+  auto* units = static_cast<filter_unit*>(r.units);
+  hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes, r.unit_rows, r.unit_off,
+                     group);
+  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(v.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes,
+                     r.unit_rows, r.unit_off, units, group);
+  const unsigned grid = pq3_grid(res);
+  filter_params f{};
+  f.units = units; f.n_units = r.unit_off + v.n_lists; f.xcd_ticket = r.xcd_ticket;
+  f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = v.centers;
+  f.codes = v.data; f.list_offsets = v.list_offsets; f.list_sizes = v.list_sizes;
+  f.row_term = cache.row_term.data(); f.query_kth = r.query_kth; f.qflag = r.qflag;
+  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / grid);
+  f.spill_cap = r.surv_cap - f.surv_cap * grid;
+  f.n_probes = r.n_probes; f.rot_dim = v.dim; f.unit_rows = r.unit_rows;
+  f.sc = cache.sc; f.c1 = -2.0f / (cache.sc * cache.sc); f.cbmax = cache.maxres; f.dmax = 0.f; f.is_ip = 0; f.stats = r.stats;
+  f.eps = 1.0f / 65536.0f; f.alpha = 0.f; f.bound_max = FLT_MAX;  // fp32 fma chain over (q - x)^2: 2 roundings per term + 'dim' adds
+  f.rows16 = cache.rows16.data(); f.fail = r.fail;
+  auto launch_filter = [&](auto kern) {
+    profile_begin(res, "flat_filter_kernel");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFThreads), 16, res.stream, f);
+    profile_end(res, "flat_filter_kernel");
+  };
+  switch (nch) {
+    case 1: launch_filter(pq_filter_kernel<1, 0, true>); break;
+    case 2: launch_filter(pq_filter_kernel<2, 0, true>); break;
+    case 3: launch_filter(pq_filter_kernel<3, 0, true>); break;
+    case 4: launch_filter(pq_filter_kernel<4, 0, true>); break;
+    case 5: launch_filter(pq_filter_kernel<5, 0, true>); break;
+    case 6: launch_filter(pq_filter_kernel<6, 0, true>); break;
+    case 7: launch_filter(pq_filter_kernel<7, 0, true>); break;
+    default: launch_filter(pq_filter_kernel<8, 0, true>); break;
+  }
+  rescore_params s{};
+  s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes;
+  s.rot_queries = r.rot_queries; s.codes = v.data; s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt;
+  s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head;
+  s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices;
+  s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = r.fail;
+  profile_begin(res, "flat_rescore_kernel");
+  hipLaunchKernelGGL(flat_rescore_kernel, dim3(grid + 1, 8), dim3(256), 0, res.stream, s);
+  profile_end(res, "flat_rescore_kernel");
+  profile_end(res, "ivf_flat_scan_kernel");
 }
 
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)

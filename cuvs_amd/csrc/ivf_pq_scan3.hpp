@@ -39,6 +39,7 @@ struct pq3_run {
   uint32_t* xcd_ticket;          // 8 x 32 zeroed words
   void* fb_items;                // work_item[n tail pairs]: single-pair items of the flagged queries
   const uint32_t* filter_bits;
+  uint32_t* fail;                // IVF-Flat: device word raised when a buffer ran over (nullptr for IVF-PQ)
   int filter_dbg;                // ablation bits of the filter kernel (timing only)
   unsigned long long* stats;     // optional device [8]
 };
@@ -60,6 +61,29 @@ struct pq3_head {
   unsigned long long* stats;     // optional device [8] (CUVS_AMD_SCAN_DEBUG=2048)
 };
 void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h);
+
+// ---- IVF-Flat (fp32 rows, L2) through the same filter: a derived fp16 copy of the rows' residuals laid out as MFMA operands
+struct flat3_cache {
+  dev_buf<uint4> rows16;       // [padded_rows / 32][dim / 16][64 lanes] x 16 bytes
+  dev_buf<uint32_t> row_term;  // [padded_rows] K-extension halves of -|x - c|^2 (1 - 2^-9) sc^2 / 2
+  float sc = 1.f, maxres = 0.f;
+  const void* data_ptr = nullptr;
+  int64_t rows = -1, size = -1;
+};
+struct flat3_view {  // the IVF-Flat index as ivf_flat.hip holds it
+  const uint8_t* data;
+  const float* centers;
+  const uint32_t* list_offsets;
+  const uint32_t* list_sizes;
+  const int64_t* indices;
+  uint32_t n_lists, dim, n_chunks;
+  int64_t padded_rows, size;
+  uint32_t max_list_len;
+};
+bool flat3_supported(uint32_t dim, int k);
+// filter + re-score of the tail phase (units from r.pair_off); r.rot_queries = the fp32 queries [nq, dim]; *r.fail is
+// raised when a buffer ran over: the caller then re-runs the tail phase on the scan kernel
+void flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r);
 
 unsigned pq3_grid(const resources& res);  // workgroups of the filter = survivor regions
 bool pq3_supported(const ivf_pq_index& idx, int k);

@@ -171,6 +171,64 @@ def test_matrix_core_tail_phase_at_other_pq_dims(dim, pq_dim, metric, lut, acc, 
     assert (gi == si).all() and (gd == sd).all()
 
 
+# ---------------------------------------------------------------------------------------------------------- C2 shape
+@pytest.fixture(scope="module")
+def flat_big_lists():
+    """IVF-Flat at the C2 shape's list length: 100k x 128 fp32, 32 lists of ~3.1k rows (the bench's hold 2.4k), 384 queries."""
+    import torch
+    from cuvs_amd.neighbors import ivf_flat
+
+    x, q = _mixture(100_000, 128, 384, seed=4096)
+    index = ivf_flat.build(ivf_flat.IndexParams(n_lists=32, kmeans_n_iters=10, kmeans_trainset_fraction=0.3), torch.from_numpy(x).cuda())
+    return x, q, index, ivf_flat.export_for_oracle(index, np.float32)
+
+
+def _flat_search(index, q, k, n_probes):
+    import torch
+    from cuvs_amd.neighbors import ivf_flat
+
+    d, i = ivf_flat.search(ivf_flat.SearchParams(n_probes=n_probes), index, torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy()
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean"])
+def test_c2_shape_matrix_core_tail_phase(flat_big_lists, metric, monkeypatch):
+    """Tail phase of IVF-Flat on the matrix cores (fp16 residual copy as MFMA operands, survivors re-scored with the scan
+    kernel's fp32 fma chain): the oracle's ids / distances, the scan kernel's (CUVS_AMD_FLAT_SCAN3=0), and the re-run on
+    the scan kernel when a buffer runs over (CUVS_AMD_PQ3_SURV_CAP)."""
+    import torch
+    from cuvs_amd.neighbors import ivf_flat
+
+    x, q, index, ex = flat_big_lists
+    if metric != "sqeuclidean":
+        index = ivf_flat.build(ivf_flat.IndexParams(n_lists=32, kmeans_n_iters=10, kmeans_trainset_fraction=0.3, metric=metric),
+                               torch.from_numpy(x).cuda())
+        ex = ivf_flat.export_for_oracle(index, np.float32)
+    k, n_probes = 10, 12
+    gd, gi = _flat_search(index, q, k, n_probes)
+    od, oi = oracle.ivf_flat_search(ex, q, k, n_probes, metric=metric)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ3_SURV_CAP", "2000")  # buffers run over: the tail phase is re-run on the scan kernel
+    hd, hi = _flat_search(index, q, k, n_probes)
+    assert (gi == hi).all() and (gd == hd).all()
+    monkeypatch.delenv("CUVS_AMD_PQ3_SURV_CAP")
+    monkeypatch.setenv("CUVS_AMD_FLAT_SCAN3", "0")
+    sd, si = _flat_search(index, q, k, n_probes)
+    assert (gi == si).all() and (gd == sd).all()
+
+
+def test_c2_shape_far_queries_and_k64(flat_big_lists):
+    """Uniform queries far from every mode (loose head bounds: pools run over into the overflow list) and k = 64."""
+    x, _, index, ex = flat_big_lists
+    rng = np.random.default_rng(6)
+    q = (rng.random((300, 128), dtype=np.float32) * 4.0 - 2.0).astype(np.float32)
+    gd, gi = _flat_search(index, q, 64, 12)
+    od, oi = oracle.ivf_flat_search(ex, q, 64, 12)
+    assert (gi == oi).all() and (gd == od).all()
+
+
 # ---------------------------------------------------------------------------------------------------------- C4 shape
 @pytest.fixture(scope="module")
 def cagra_768():
