@@ -377,24 +377,27 @@ def extra_c2(res, dev):
     bf_dt = timeit(lambda: brute_force.search(bf, q, 10, resources=res), 2, 1)
     bf_tf = 2 * nq * n * 128 / bf_dt / 1e12
     logical = 64 * (n / 4096) * 512 * nq  # 80 MB of list bytes per query
-    # VALU floor of the scan: every (row, query) pair costs 32 pieces x 8 packed instructions / 8 queries = 32 instructions
-    valu_floor_ms = (logical / 16.0) * 8.0 / 8.0 / 64.0 * 2.79 / (N_SIMD * 2.4e9) * 1e3
+    # Round 3: the nearest probe of every query runs on ivf_flat_scan_kernel (fp32 rows), the other 63 on the matrix-core
+    # filter over the fp16 residual copy of the rows (ivf_pq_scan3.hip, FLAT build) + the fp32 re-scoring of the survivors.
+    # Unique bytes the scan phases must fetch: every list once as fp32 (head phase: ~all 4096 lists are some query's nearest)
+    # and once as fp16 (tail phase), plus the 4-byte row terms.
+    unique = n * 512 + n * 256 + n * 4
+    hbm_gbs = unique / (scan_ms * 1e-3) / 1e9
     return {"brute_force_same_data": {"config": "brute_force L2 10000000x128 fp32 batch=10000 k=10", "ms": round(bf_dt * 1e3, 1),
                                       "qps": round(nq / bf_dt, 1),
                                       "roofline": {"bound": "mfma", "achieved": round(bf_tf, 1), "peak": MFMA_F32_TFLOPS,
                                                    "unit": "TFLOP/s", "frac": round(bf_tf / MFMA_F32_TFLOPS, 4)}},
             "config": "C2 IVF-Flat 10000000x128 fp32 n_lists=4096 n_probes=64 batch=10000 k=10", "ms": round(dt * 1e3, 3),
             "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
-            "kernel": "ivf_flat_scan_kernel", "kernel_ms_per_step": round(scan_ms, 3), "launches_per_step": launches,
-            "roofline": {"bound": "valu", "logical_scan_gbs": round(logical / (scan_ms * 1e-3) / 1e9, 1),
-                         "achieved": round(valu_floor_ms, 3), "peak": round(scan_ms, 3), "unit": "ms (VALU floor / kernel)",
-                         "frac": round(valu_floor_ms / max(scan_ms, 1e-9), 4), "unique_list_bytes": n * 512,
-                         "note": "frac = VALU floor / kernel time: 8 packed-fp32 instructions (4 v_pk_add_f32 + 4 v_pk_fma_f32, "
-                                 "2.79 cycles each, profiles/r03_valu_rate_bench.json) per 16-byte row piece and 8 queries, "
-                                 "over all probed rows, on 1024 SIMDs at 2.4 GHz; the early stop skips part of that work, so "
-                                 "the floor is an upper bound of the useful work. logical_scan_gbs = list bytes per kernel "
-                                 "second (SURVEY 8d): the lists are re-served from L2 ~156x (unique bytes 5.12 GB); "
-                                 "PMC summary of this kernel: profiles/r03_c2_ivf_flat_pmc.txt"}}
+            "kernel": "ivf_flat_scan_kernel (head phase) + pq_filter_kernel<FLAT> + flat_rescore_kernel (tail phase)",
+            "kernel_ms_per_step": round(scan_ms, 3), "launches_per_step": launches,
+            "roofline": {"bound": "hbm", "logical_scan_gbs": round(logical / (scan_ms * 1e-3) / 1e9, 1),
+                         "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
+                         "unique_bytes": unique,
+                         "note": "frac = unique bytes the scan phases have to fetch (every list once as fp32 for the head phase, once "
+                                 "as the fp16 residual copy for the matrix-core tail phase, the row terms) / (scan-kernel time x 8 "
+                                 "TB/s); the tail phase re-reads a list chunk once per group of 64 probing queries (L2). "
+                                 "logical_scan_gbs = list bytes per kernel second (SURVEY 8d)"}}
 
 
 def extra_c4_clustered(res, dev, rows=2_000_000, latent=24, modes=4096):

@@ -6,6 +6,11 @@ find $W/kt -name "*kernel_stats.csv" -exec cp {} gpurun_out/r03l_kernel_stats.cs
 python - <<'P'
 import csv
 rows=list(csv.reader(open('gpurun_out/r03l_kernel_stats.csv')))
-for x in rows[1:16]:
-    print(f"{float(x[2])/1e6:10.3f} ms total  calls {x[1]:>6}  avg {float(x[3])/1e6:8.3f} ms  {x[0][:100].replace('cuvs_amd::(anonymous namespace)::','')}")
+tot=0
+for x in rows[1:]:
+    c=int(x[1])
+    if c % 7 == 0 and c <= 70:
+        per=float(x[2])/7/1e6; tot+=per
+        print(f"{per:8.3f} ms/search x{c//7:2d}  {x[0][:110].replace('cuvs_amd::(anonymous namespace)::','')}")
+print('sum',round(tot,3))
 P
