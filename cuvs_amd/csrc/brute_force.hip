@@ -250,7 +250,8 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     // that leaves fewer than k of the first tile) had its candidates cut: such row tiles are redone by the per-tile
     // select path below. One host round trip per search, only to read the flags.
     std::vector<int> h_ovf(n_row_tiles, 0);
-    read_words(res, ovf.data(), n_row_tiles, h_ovf.data());  // (through the handle's pinned buffer: a pageable copy is staged)
+    HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+    HIP_TRY(hipStreamSynchronize(res.stream));
     for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
   } else if (running) {
     const int64_t nt2   = std::max<int64_t>(128, std::min<int64_t>((n_tile / 2) / 128 * 128, round_up((n + 3) / 4, 128)));
@@ -317,7 +318,8 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     // cut: such row tiles are redone by the per-tile select path below. One host round trip per search, only to read
     // the flags - the common case leaves the results where they are.
     std::vector<int> h_ovf(n_row_tiles, 0);
-    read_words(res, ovf.data(), n_row_tiles, h_ovf.data());  // (through the handle's pinned buffer: a pageable copy is staged)
+    HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+    HIP_TRY(hipStreamSynchronize(res.stream));
     for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
   }
   bool any_redo = false;
