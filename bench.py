@@ -367,8 +367,13 @@ def extra_c2(res, dev):
     sp = ivf_flat.SearchParams(n_probes=64)
     nb = torch.empty((nq, 10), dtype=torch.int64, device=dev)
     dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
-    dt, scan_ms, launches = profiled(b"ivf_flat_scan_kernel",
-                                     lambda: ivf_flat.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 5, 2)
+    _, scan_ms, launches = profiled(b"ivf_flat_scan_kernel",
+                                    lambda: ivf_flat.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 5, 2)
+    from cuvs_amd._lib import lib
+    for nm in (b"flat_filter_kernel", b"flat_rescore_kernel"):
+        lib().cuvsAmdProfileCollect(nm, None)
+    # the search time without the per-kernel HIP events of profiled()
+    dt = timeit(lambda: ivf_flat.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 10, 2)
     bf = brute_force.build(x, resources=res)
     _, gt = brute_force.search(bf, q[:1000], 10, resources=res)
     res.sync()
