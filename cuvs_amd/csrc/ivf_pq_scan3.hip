@@ -506,6 +506,7 @@ struct rescore_params {
   uint32_t overflow_cap;
   uint32_t* fail;         // IVF-Flat: raised when the overflow list is full (nullptr: the query is flagged instead)
   uint32_t dim;           // IVF-Flat: row length
+  int cb_lds;             // IVF-PQ: the fp32 codebook fits the LDS of a workgroup
 };
 
 // a re-scored survivor: into the query's pool if it is within the bound, beyond the pool's capacity into the overflow list
@@ -529,9 +530,22 @@ __device__ inline void pool_append(const rescore_params& a, const uint32_t q, co
   a.cand_r[o] = pair % a.n_probes;
 }
 
+constexpr int kRThreads = 1024;
+
+// The codebook (128 KiB of fp32 at pq_dim 64) is staged in LDS once per workgroup: a survivor's 128 codebook values were
+// 128 scattered L2 reads per lane; the query / centre values of a 16-subspace chunk are read as 16-byte vectors.
 template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
-__global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
+__global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_params a)
 {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cb = reinterpret_cast<float*>(smem);  // [pq_dim * 2][256] when it fits (cb_lds), else read from memory
+  if (a.cb_lds) {
+    const uint32_t n4 = a.n_chunks * 16u * 2u * 256u / 4u;
+    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x)
+      reinterpret_cast<float4*>(cb)[i] = reinterpret_cast<const float4*>(a.pq_centers)[i];
+    __syncthreads();
+  }
+  const float* __restrict__ pqc = a.cb_lds ? cb : a.pq_centers;
   // region blockIdx.x of the filter's workgroups; the last one is the shared spill region
   const bool spill = blockIdx.x + 1 == gridDim.x;
   const uint32_t n = spill ? min(a.surv_cnt[blockIdx.x], a.spill_cap) : a.surv_cnt[blockIdx.x];
@@ -554,12 +568,19 @@ __global__ __launch_bounds__(256) void pq_rescore_kernel(const rescore_params a)
     for (int c = 0; c < (int)a.n_chunks; ++c) {
       const uint4 cw       = cp[c * 64];
       const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+      float qq[32], cc[32];  // the chunk's 16 subspaces x 2 components of the query and of the list centre
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 qv = *reinterpret_cast<const float4*>(rq + c * 32 + j * 4), cv = *reinterpret_cast<const float4*>(ct + c * 32 + j * 4);
+        qq[j * 4] = qv.x; qq[j * 4 + 1] = qv.y; qq[j * 4 + 2] = qv.z; qq[j * 4 + 3] = qv.w;
+        cc[j * 4] = cv.x; cc[j * 4 + 1] = cv.y; cc[j * 4 + 2] = cv.z; cc[j * 4 + 3] = cv.w;
+      }
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
         const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
         const uint32_t sb   = c * 16 + b;
-        const float p0 = a.pq_centers[(size_t)(sb * 2 + 0) * 256 + code], p1 = a.pq_centers[(size_t)(sb * 2 + 1) * 256 + code];
-        const float q0 = rq[sb * 2], q1 = rq[sb * 2 + 1], c0 = ct[sb * 2], c1 = ct[sb * 2 + 1];
+        const float p0 = pqc[(size_t)(sb * 2 + 0) * 256 + code], p1 = pqc[(size_t)(sb * 2 + 1) * 256 + code];
+        const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cc[b * 2], c1 = cc[b * 2 + 1];
         float v;
         if (!a.is_ip) {
           const float d0 = (q0 - c0) - p0, d1 = (q1 - c1) - p1;
@@ -1229,13 +1250,18 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = idx.n_chunks;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
-  const dim3 rg(grid + 1, 8), rb(256);
+  const size_t cb_bytes = (size_t)idx.pq_dim * 2 * 256 * sizeof(float);
+  s.cb_lds = cb_bytes <= 128 * 1024 ? 1 : 0;
+  const size_t rsmem = s.cb_lds ? cb_bytes : 16;
+  const dim3 rg(grid + 1, 2), rb(kRThreads);
   profile_begin(res, "pq_rescore_kernel");
-  if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_kernel<0, false>), rg, rb, 0, res.stream, s);
-  else if (r.lut_mode == 1) { if (r.acc_half) hipLaunchKernelGGL((pq_rescore_kernel<1, true>), rg, rb, 0, res.stream, s);
-                              else            hipLaunchKernelGGL((pq_rescore_kernel<1, false>), rg, rb, 0, res.stream, s); }
-  else                      { if (r.acc_half) hipLaunchKernelGGL((pq_rescore_kernel<2, true>), rg, rb, 0, res.stream, s);
-                              else            hipLaunchKernelGGL((pq_rescore_kernel<2, false>), rg, rb, 0, res.stream, s); }
+  auto launch_rescore = [&](auto kern) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));
+    hipLaunchKernelGGL(kern, rg, rb, rsmem, res.stream, s);
+  };
+  if (r.lut_mode == 0)      launch_rescore(pq_rescore_kernel<0, false>);
+  else if (r.lut_mode == 1) { if (r.acc_half) launch_rescore(pq_rescore_kernel<1, true>); else launch_rescore(pq_rescore_kernel<1, false>); }
+  else                      { if (r.acc_half) launch_rescore(pq_rescore_kernel<2, true>); else launch_rescore(pq_rescore_kernel<2, false>); }
   profile_end(res, "pq_rescore_kernel");
   // flagged queries: their candidate rows go back to "per-pair segments, nothing found yet", their tail pairs become
   // single-pair work items of the LUT scan kernel (launched by the caller)
