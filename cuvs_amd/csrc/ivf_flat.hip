@@ -880,15 +880,16 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         const bool tdbg = (res.tune.scan_debug & 1024) != 0;
         auto now = [&]() { if (tdbg) sync(res); return std::chrono::steady_clock::now(); };
         const auto t0 = now();
-        flat3_tail(res, v, idx.scan3, r);
-        const auto t1 = now();
-        pq3_merge(res, r, top_d.data(), top_i.data());
-        const auto t2 = now();
-        if (tdbg)
-          fprintf(stderr, "[flat3] tail %.3f ms, merge %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                  std::chrono::duration<double, std::milli>(t2 - t1).count());
-        // a buffer ran over (bounds too loose to filter: e.g. lists shorter than k): the tail phase again, on the scan kernel
-        merged = read_word(res, r.fail) == 0u;
+        if (flat3_tail(res, v, idx.scan3, r)) {
+          const auto t1 = now();
+          pq3_merge(res, r, top_d.data(), top_i.data());
+          const auto t2 = now();
+          if (tdbg)
+            fprintf(stderr, "[flat3] tail %.3f ms, merge %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count());
+          // a buffer ran over (bounds too loose to filter: e.g. lists shorter than k): the tail phase again, on the scan kernel
+          merged = read_word(res, r.fail) == 0u;
+        }
       }
       if (!merged) launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
     } else {

@@ -1320,12 +1320,22 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
 
 bool flat3_supported(uint32_t dim, int k) { return dim % 32 == 0 && dim >= 32 && dim <= 256 && k <= 64; }
 
-static void flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
+static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
 {
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  if (c.data_ptr == v.data && c.rows == v.padded_rows && c.size == v.size) return;
+  if (c.data_ptr == v.data && c.rows == v.padded_rows && c.size == v.size) return true;
   const int64_t rows = std::max<int64_t>(v.padded_rows, 64);
+  {
+    // the copy takes half the size of the fp32 rows again: only when the device has that much to spare
+    c.rows16   = dev_buf<uint4>();
+    c.row_term = dev_buf<uint32_t>();
+    c.data_ptr = nullptr;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)rows * v.dim * 2 + (size_t)rows * 12 + (size_t(1) << 30);
+    if (free_b < need) return false;
+  }
   dev_buf<uint32_t> row_list(res, (size_t)rows / 64), mxd(res, 1);
   dev_buf<float> dn(res, (size_t)rows);
   HIP_TRY(hipMemsetAsync(row_list.data(), 0xff, row_list.bytes(), res.stream));
@@ -1350,11 +1360,12 @@ static void flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
   }
   sync(res);
   c.data_ptr = v.data; c.rows = v.padded_rows; c.size = v.size;
+  return true;
 }
 
-void flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r)
+bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r)
 {
-  flat3_prepare(res, v, cache);
+  if (!flat3_prepare(res, v, cache)) return false;  // no room for the fp16 copy: the caller stays on the scan kernel
   profile_begin(res, "ivf_flat_scan_kernel");  // bench.py sums the scan phases under this name
   const int nch        = (int)v.dim / 32;   // the filter kernel's "chunk" = two K steps of 16 dimensions
   const uint32_t group = nch <= 4 ? 64u : 32u;
@@ -1400,6 +1411,7 @@ void flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   hipLaunchKernelGGL(flat_rescore_kernel, dim3(grid + 1, 8), dim3(256), 0, res.stream, s);
   profile_end(res, "flat_rescore_kernel");
   profile_end(res, "ivf_flat_scan_kernel");
+  return true;
 }
 
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)

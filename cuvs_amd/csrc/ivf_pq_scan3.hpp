@@ -82,8 +82,9 @@ struct flat3_view {  // the IVF-Flat index as ivf_flat.hip holds it
 };
 bool flat3_supported(uint32_t dim, int k);
 // filter + re-score of the tail phase (units from r.pair_off); r.rot_queries = the fp32 queries [nq, dim]; *r.fail is
-// raised when a buffer ran over: the caller then re-runs the tail phase on the scan kernel
-void flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r);
+// raised when a buffer ran over: the caller then re-runs the tail phase on the scan kernel. Returns false (nothing
+// launched) when the device has no room for the fp16 copy.
+bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r);
 
 unsigned pq3_grid(const resources& res);  // workgroups of the filter = survivor regions
 bool pq3_supported(const ivf_pq_index& idx, int k);
