@@ -1,0 +1,123 @@
+"""CPU check of the rounding margins of the matrix-core filter (cuvs_amd/csrc/ivf_pq_scan3.hip: filter_threshold,
+filter_threshold_ip). The filter may drop a (row, query) pair only when its exact score - the reference's LUT arithmetic
+(create_lut_impl.cuh:17-78, compute_score_impl.cuh:52-79), restated here in numpy for the fp32 and fp16 LUT / score types -
+is above the query's bound. The weakest case is a row exactly AT the bound: with bound := its exact score it has to
+survive, i.e. the screened value must not exceed the threshold. The GEMM is emulated the way the hardware defines it:
+operands scaled by a power of two and rounded to fp16, products exact, accumulation in fp32 (any order)."""
+import numpy as np
+import pytest
+
+F32, F16 = np.float32, np.float16
+pytestmark = pytest.mark.filterwarnings("ignore:overflow encountered")
+
+
+def lut_score(r, cb, codes, lut, acc, ip=False, q=None, c=None):
+    """exact score of one row: entries fma(d1, d1, fma(d0, d0, 0)) (L2) / the four-fma chain (IP), rounded to the LUT type,
+    summed in subspace order in the score type"""
+    s16, s32 = F16(0), F32(0)
+    for s in range(cb.shape[0]):
+        p0, p1 = cb[s, codes[s]]
+        if not ip:
+            d0, d1 = F32(r[2 * s] - p0), F32(r[2 * s + 1] - p1)
+            v = F32(np.float64(d1) * np.float64(d1) + np.float64(F32(np.float64(d0) * np.float64(d0))))  # fma(d1, d1, fma(d0, d0, 0))
+        else:
+            v = F32(np.float64(-q[2 * s]) * np.float64(c[2 * s]))
+            v = F32(np.float64(-q[2 * s]) * np.float64(p0) + np.float64(v))
+            v = F32(np.float64(-q[2 * s + 1]) * np.float64(c[2 * s + 1]) + np.float64(v))
+            v = F32(np.float64(-q[2 * s + 1]) * np.float64(p1) + np.float64(v))
+        e = v if lut == "f32" else F16(v)
+        if acc == "f16":
+            s16 = F16(s16 + e)
+        else:
+            s32 = F32(s32 + F32(e))
+    return float(s16 if acc == "f16" else s32)
+
+
+def gemm16(x, y, sc, rng):
+    """sum of fl16(sc x_i) * fl16(sc y_i) accumulated in fp32, in a random order"""
+    xa, ya = F16(F32(sc) * x).astype(np.float64), F16(F32(sc) * y).astype(np.float64)
+    acc = F32(0)
+    for i in rng.permutation(len(x)):
+        acc = F32(np.float64(acc) + xa[i] * ya[i])
+    return float(acc)
+
+
+def eps_alpha(lut, acc):
+    if lut == "f32":
+        return 1.0 / 65536.0, 0.0
+    return (0.04 if acc == "f16" else 1.0 / 1024.0), 64.0 / 16777216.0
+
+
+@pytest.mark.parametrize("lut,acc", [("f32", "f32"), ("f16", "f32"), ("f16", "f16")])
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 37.0, 2.5e3])
+def test_l2_row_at_the_bound_survives(lut, acc, scale):
+    rng = np.random.default_rng(int(scale * 7) + len(lut) + len(acc))
+    pq_dim, D = 64, 128
+    cb = (rng.standard_normal((pq_dim, 256, 2)) * scale).astype(F32)
+    cbmax = float(np.abs(cb).max())
+    sc = 2.0 ** np.floor(np.log2(16.0 / cbmax))
+    eps, alpha = eps_alpha(lut, acc)
+    worst = -np.inf
+    for trial in range(300):
+        codes = rng.integers(0, 256, pq_dim)
+        d = cb[np.arange(pq_dim), codes].reshape(-1)  # decoded residual
+        # residuals from "right on top of the row" to far away, incl. tiny and lopsided ones
+        kind = trial % 4
+        if kind < 2:
+            r = (d + rng.standard_normal(D).astype(F32) * F32(scale * 10.0 ** rng.uniform(-4, 1))).astype(F32)
+        else:
+            r = (rng.standard_normal(D) * scale * 10.0 ** rng.uniform(-3, 1.5)).astype(F32)
+        if kind == 3:
+            r[rng.integers(0, D, 100)] = 0
+        s_exact = lut_score(r, cb, codes, lut, acc)
+        if not np.isfinite(s_exact) or s_exact > 60000:
+            continue
+        rn = float(np.sum(r.astype(np.float64) ** 2, dtype=np.float64))
+        dn = F32(0)
+        for s in range(pq_dim):  # row_term_kernel's fp32 chain
+            dn = F32(np.float64(cb[s, codes[s], 0]) ** 2 + np.float64(dn))
+            dn = F32(np.float64(cb[s, codes[s], 1]) ** 2 + np.float64(dn))
+        x = F32(-0.5) * F32(sc) * F32(sc) * F32(dn * F32(1.0 - 1.0 / 512.0))
+        hi = F16(x)
+        lo = F16(F32(x) - F32(hi))
+        accv = F32(np.float64(F32(gemm16(r, d, sc, rng))) + np.float64(hi) + np.float64(lo))  # K-extension step
+        c1 = -2.0 / (sc * sc)
+        screened = float(accv) * c1
+        # filter_threshold(bound = s_exact)
+        mabs = 2.0 ** -23 / sc * (np.sqrt(D * rn) + D * cbmax)
+        thr = (s_exact + alpha) * (1.0 + 2.0 * eps) + mabs - rn * (1.0 - 1.0 / 512.0)
+        thr = float(F32(thr)) + abs(float(F32(thr))) * 2.4e-7 + 1e-37
+        worst = max(worst, screened - thr)
+        assert screened <= thr, (trial, screened, thr, s_exact, rn, float(dn))
+    assert worst < 0
+
+
+@pytest.mark.parametrize("lut,acc", [("f32", "f32"), ("f16", "f32"), ("f16", "f16")])
+def test_inner_product_row_at_the_bound_survives(lut, acc):
+    rng = np.random.default_rng(11 + len(lut) + len(acc))
+    pq_dim, D = 64, 128
+    for scale in (0.05, 1.0, 40.0):
+        cb = (rng.standard_normal((pq_dim, 256, 2)) * scale).astype(F32)
+        cbmax = float(np.abs(cb).max())
+        sc = 2.0 ** np.floor(np.log2(16.0 / cbmax))
+        dmax = float(np.sqrt((np.max(np.sum(cb.astype(np.float64) ** 2, axis=2), axis=1)).sum())) * 1.0001
+        eps, alpha = eps_alpha(lut, acc)
+        for trial in range(150):
+            codes = rng.integers(0, 256, pq_dim)
+            d = cb[np.arange(pq_dim), codes].reshape(-1)
+            c = (rng.standard_normal(D) * scale * 10.0 ** rng.uniform(-1, 1)).astype(F32)
+            q = (rng.standard_normal(D) * 10.0 ** rng.uniform(-2, 1)).astype(F32)
+            s_exact = lut_score(None, cb, codes, lut, acc, ip=True, q=q, c=c)
+            if not np.isfinite(s_exact) or abs(s_exact) > 60000:
+                continue
+            qn = float(np.sum(q.astype(np.float64) ** 2))
+            cn = float(np.sum(c.astype(np.float64) ** 2))
+            qc = F32(0)
+            for i in range(D):
+                qc = F32(np.float64(q[i]) * np.float64(c[i]) + np.float64(qc))
+            screened = gemm16(q, d, sc, rng) * (-1.0 / (sc * sc))
+            nq, nc = np.sqrt(qn), np.sqrt(cn)
+            mabs = 2.0 ** -23 / sc * (np.sqrt(D) * nq + D * cbmax)
+            m = nq * ((eps + 7.63e-6) * nc + (eps + 1.0 / 512.0) * dmax)
+            thr = s_exact + float(qc) + (abs(float(qc)) + abs(s_exact)) * 1e-6 + m + mabs + alpha
+            assert screened <= thr, (scale, trial, screened, thr, s_exact)
