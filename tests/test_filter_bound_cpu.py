@@ -8,7 +8,44 @@ import numpy as np
 import pytest
 
 F32, F16 = np.float32, np.float16
-pytestmark = pytest.mark.filterwarnings("ignore:overflow encountered")
+pytestmark = [pytest.mark.filterwarnings("ignore:overflow encountered"), pytest.mark.filterwarnings("ignore:invalid value")]
+
+
+def fp8_round_trip(v, signed, half):
+    """pq_lut_math.hpp fp8_round_trip (the reference's fp_8bit<5, Signed>, ivf_pq_fp_8bit.cuh:32-100): truncating encode,
+    half an ulp added back on decode, float or half decoder"""
+    v = F32(v)
+    av = abs(v) if signed else v
+    if av < F32(1.0 / 32768.0):
+        u = 0
+    elif av >= F32(65536.0 * 1.875):
+        u = 0xFF
+    else:
+        bits = int(np.array(av, F32).view(np.uint32))
+        u = ((bits + (15 << 23) - 0x3F800000) >> 20) & 0xFF
+    neg = signed and v < 0
+    if signed:
+        u &= 0xFE
+    if half:
+        hb = ((0x3C00 | (0x0200 >> 3)) - (15 << 10)) + (u << 7)
+        r = F32(np.array(hb & 0xFFFF, np.uint16).view(F16))
+    else:
+        r = np.array((((0x3F800000 | (0x00400000 >> 3)) - (15 << 23)) + (u << 20)) & 0xFFFFFFFF, np.uint32).view(F32)
+    return F32(-r if neg else r)
+
+
+def test_fp8_emulation_equals_the_oracle():
+    import oracle
+
+    rng = np.random.default_rng(3)
+    v = np.concatenate([rng.standard_normal(500) * 10.0 ** rng.uniform(-6, 6, 500), [0.0, 1e-9, 122880.0, 1e7]]).astype(F32)
+    for signed in (False, True):
+        for half in (False, True):
+            vv = v if signed else np.abs(v)
+            want = oracle.fp8_round_trip(vv, signed=signed, to_half=half)
+            got = np.array([fp8_round_trip(x, signed, half) for x in vv], F32)
+            ok = (got == want) | (np.isnan(got) & np.isnan(want))
+            assert ok.all(), (signed, half, vv[~ok][:5], got[~ok][:5], want[~ok][:5])
 
 
 def lut_score(r, cb, codes, lut, acc, ip=False, q=None, c=None):
@@ -25,7 +62,9 @@ def lut_score(r, cb, codes, lut, acc, ip=False, q=None, c=None):
             v = F32(np.float64(-q[2 * s]) * np.float64(p0) + np.float64(v))
             v = F32(np.float64(-q[2 * s + 1]) * np.float64(c[2 * s + 1]) + np.float64(v))
             v = F32(np.float64(-q[2 * s + 1]) * np.float64(p1) + np.float64(v))
-        e = v if lut == "f32" else F16(v)
+        if lut == "fp8":
+            v = fp8_round_trip(v, ip, acc == "f16")
+        e = v if (lut == "f32" or (lut == "fp8" and acc != "f16")) else F16(v)
         if acc == "f16":
             s16 = F16(s16 + e)
         else:
@@ -42,13 +81,17 @@ def gemm16(x, y, sc, rng):
     return float(acc)
 
 
-def eps_alpha(lut, acc):
+def eps_alpha(lut, acc, ip=False):
     if lut == "f32":
         return 1.0 / 65536.0, 0.0
+    if lut == "fp8":
+        if ip:
+            return (0.18 if acc == "f16" else 0.14), 64.0 / 32768.0
+        return (0.11 if acc == "f16" else 0.07), 64.0 / 32768.0
     return (0.04 if acc == "f16" else 1.0 / 1024.0), 64.0 / 16777216.0
 
 
-@pytest.mark.parametrize("lut,acc", [("f32", "f32"), ("f16", "f32"), ("f16", "f16")])
+@pytest.mark.parametrize("lut,acc", [("f32", "f32"), ("f16", "f32"), ("f16", "f16"), ("fp8", "f16"), ("fp8", "f32")])
 @pytest.mark.parametrize("scale", [1e-3, 1.0, 37.0, 2.5e3])
 def test_l2_row_at_the_bound_survives(lut, acc, scale):
     rng = np.random.default_rng(int(scale * 7) + len(lut) + len(acc))
@@ -70,7 +113,7 @@ def test_l2_row_at_the_bound_survives(lut, acc, scale):
         if kind == 3:
             r[rng.integers(0, D, 100)] = 0
         s_exact = lut_score(r, cb, codes, lut, acc)
-        if not np.isfinite(s_exact) or s_exact > 60000:
+        if not np.isfinite(s_exact) or s_exact > (30000 if lut == "fp8" else 60000):  # bound_max: not served by the filter
             continue
         rn = float(np.sum(r.astype(np.float64) ** 2, dtype=np.float64))
         dn = F32(0)
@@ -92,7 +135,7 @@ def test_l2_row_at_the_bound_survives(lut, acc, scale):
     assert worst < 0
 
 
-@pytest.mark.parametrize("lut,acc", [("f32", "f32"), ("f16", "f32"), ("f16", "f16")])
+@pytest.mark.parametrize("lut,acc", [("f32", "f32"), ("f16", "f32"), ("f16", "f16"), ("fp8", "f16"), ("fp8", "f32")])
 def test_inner_product_row_at_the_bound_survives(lut, acc):
     rng = np.random.default_rng(11 + len(lut) + len(acc))
     pq_dim, D = 64, 128
@@ -101,14 +144,14 @@ def test_inner_product_row_at_the_bound_survives(lut, acc):
         cbmax = float(np.abs(cb).max())
         sc = 2.0 ** np.floor(np.log2(16.0 / cbmax))
         dmax = float(np.sqrt((np.max(np.sum(cb.astype(np.float64) ** 2, axis=2), axis=1)).sum())) * 1.0001
-        eps, alpha = eps_alpha(lut, acc)
+        eps, alpha = eps_alpha(lut, acc, ip=True)
         for trial in range(150):
             codes = rng.integers(0, 256, pq_dim)
             d = cb[np.arange(pq_dim), codes].reshape(-1)
             c = (rng.standard_normal(D) * scale * 10.0 ** rng.uniform(-1, 1)).astype(F32)
             q = (rng.standard_normal(D) * 10.0 ** rng.uniform(-2, 1)).astype(F32)
             s_exact = lut_score(None, cb, codes, lut, acc, ip=True, q=q, c=c)
-            if not np.isfinite(s_exact) or abs(s_exact) > 60000:
+            if not np.isfinite(s_exact) or abs(s_exact) > (30000 if lut == "fp8" else 60000):
                 continue
             qn = float(np.sum(q.astype(np.float64) ** 2))
             cn = float(np.sum(c.astype(np.float64) ** 2))
