@@ -748,7 +748,7 @@ struct head_params {
   unsigned long long* stats;  // optional [8]: workgroup cycles in header / LUT / scores / select / output, items
 };
 
-constexpr int kHCand = 256;  // candidates of a list chunk at or below its threshold (about k of them)
+constexpr int kHCand = 512;  // candidates of a list chunk at or below its threshold (about k of them, k <= 128) + the kept ones
 
 template <int LUT, bool ACC_HALF, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void pq_head_kernel(const head_params a)
@@ -879,25 +879,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         keys[v] = key;
         my_min  = min(my_min, key);
       }
-      // minima of groups of four threads (DPP): NT / 4 >= 128 groups, each a set of rows of its own
+      // minima of groups of four threads (k <= 64) or of two (k <= 128: at least 2 k groups keep the threshold tight) by
+      // DPP: each group is a set of rows of its own
+      const int gshift = k > 64 ? 1 : 2;
       my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0xb1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
-      my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0x4e, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
-      if ((tid & 3) == 0) tk[tid >> 2] = my_min;
+      if (gshift == 2)
+        my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0x4e, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+      if ((tid & ((1 << gshift) - 1)) == 0) tk[tid >> gshift] = my_min;
       __syncthreads();
       phase(2);
       // ---- candidates of the chunk. The scores of a list share their leading bits: a histogram select serializes on a
       // few LDS counters (33 k cycles measured), a bitonic sort is a chain of barriers. Instead: the k-th smallest of the
       // group minima bounds the chunk's k-th smallest key from above (k groups hold k different rows at or below it),
       // found by counting ranks over broadcast reads; the keys at or below it - about k - join the candidates.
-      constexpr int NG = NT / 4;
+      const int NGr   = NT >> gshift;
       const int k_c   = (int)min((uint32_t)k, clen);
       const int kept  = ctrl[0];
-      if (tid < NG) {
+      if (tid < NGr) {
         const uint32_t mine = tk[tid];
         const uint4* tk4    = reinterpret_cast<const uint4*>(tk);
         int r = 0;
 #pragma unroll 4
-        for (int j = 0; j < NG / 4; ++j) {  // 16-byte broadcast reads, four in flight
+        for (int j = 0; j < NGr / 4; ++j) {  // 16-byte broadcast reads, four in flight
           const uint4 o = tk4[j];
           r += (o.x < mine || (o.x == mine && 4 * j + 0 < tid)) ? 1 : 0;
           r += (o.y < mine || (o.y == mine && 4 * j + 1 < tid)) ? 1 : 0;
@@ -1042,26 +1045,53 @@ __global__ void ov_fill_kernel(const uint4* __restrict__ ov, const uint32_t* __r
 }
 
 // ------------------------------------------------------------------ merge: one wave per query
-struct top3 {  // sorted ascending by (d, rank, row), rank r in lane r
-  float d;
-  uint32_t rk, row;
-  __device__ inline void init() { d = INFINITY; rk = 0xffffffffu; row = 0xffffffffu; }
+template <int E>
+struct top3 {  // sorted ascending by (d, rank, row); rank r lives in lane r % 64, slot r / 64
+  float d[E];
+  uint32_t rk[E], row[E];
+  __device__ inline void init()
+  {
+#pragma unroll
+    for (int e = 0; e < E; ++e) { d[e] = INFINITY; rk[e] = 0xffffffffu; row[e] = 0xffffffffu; }
+  }
   __device__ static inline bool before(float da, uint32_t ra, uint32_t wa, float db, uint32_t rb, uint32_t wb)
   {
     return da < db || (da == db && (ra < rb || (ra == rb && wa < wb)));
   }
+  // the entry of (wave-uniform) rank r
+  __device__ inline void at(int r, float& od, uint32_t& ork, uint32_t& orow) const
+  {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if ((r >> 6) == e) {
+        od   = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d[e]), r & 63));
+        ork  = __builtin_amdgcn_readlane(rk[e], r & 63);
+        orow = __builtin_amdgcn_readlane(row[e], r & 63);
+      }
+  }
   __device__ inline void insert(float cd, uint32_t cr, uint32_t cw, int lane)
   {
-    const int pos = __popcll(__ballot(!before(cd, cr, cw, d, rk, row)));  // entries at or before the candidate
-    const uint32_t du = __float_as_uint(d);
-    const uint32_t ud = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)du, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    const uint32_t ur = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rk, 0x138, 0xf, 0xf, false);
-    const uint32_t uw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)row, 0x138, 0xf, 0xf, false);
-    if (lane > pos) { d = __uint_as_float(ud); rk = ur; row = uw; }
-    else if (lane == pos) { d = cd; rk = cr; row = cw; }
+    int pos = 0;  // entries at or before the candidate
+#pragma unroll
+    for (int e = 0; e < E; ++e) pos += __popcll(__ballot(!before(cd, cr, cw, d[e], rk[e], row[e])));
+    uint32_t c_d = 0, c_r = 0, c_w = 0;  // the entry that moves from lane 63 of a slot to lane 0 of the next
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t du = __float_as_uint(d[e]);
+      const uint32_t ud = (uint32_t)__builtin_amdgcn_update_dpp((int)c_d, (int)du, 0x138, 0xf, 0xf, false);  // wave_shr:1
+      const uint32_t ur = (uint32_t)__builtin_amdgcn_update_dpp((int)c_r, (int)rk[e], 0x138, 0xf, 0xf, false);
+      const uint32_t uw = (uint32_t)__builtin_amdgcn_update_dpp((int)c_w, (int)row[e], 0x138, 0xf, 0xf, false);
+      c_d = __builtin_amdgcn_readlane(du, 63);
+      c_r = __builtin_amdgcn_readlane(rk[e], 63);
+      c_w = __builtin_amdgcn_readlane(row[e], 63);
+      const int rank = e * 64 + lane;
+      if (rank > pos) { d[e] = __uint_as_float(ud); rk[e] = ur; row[e] = uw; }
+      else if (rank == pos) { d[e] = cd; rk[e] = cr; row[e] = cw; }
+    }
   }
 };
 
+template <int E>  // k <= 64 E
 __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict__ cand_d, const uint32_t* __restrict__ cand_i,
                                                          const uint32_t* __restrict__ cand_r, const uint32_t* __restrict__ qcnt,
                                                          const uint32_t* __restrict__ qflag, int64_t nq, uint32_t n_probes,
@@ -1077,7 +1107,7 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
   const uint32_t pool = min(qcnt[q], (n_probes - head) * k);
   const uint32_t n    = flagged ? n_probes * k : head * k + pool;
   const int kr        = (int)k - 1;
-  top3 best;
+  top3<E> best;
   best.init();
   float kd = INFINITY;
   uint32_t krk = 0xffffffffu, krow = 0xffffffffu;
@@ -1096,33 +1126,36 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
       const uint4 e = overflow[ov0 + s - n];
       d = __uint_as_float(e.y); rk = e.z; row = e.w;
     }
-    unsigned long long m = __ballot(row != 0xffffffffu && top3::before(d, rk, row, kd, krk, krow));
+    unsigned long long m = __ballot(row != 0xffffffffu && top3<E>::before(d, rk, row, kd, krk, krow));
     while (m != 0ull) {
       const int src = (int)__ffsll((long long)m) - 1;
       m &= m - 1ull;
       const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), src));
       const uint32_t cr = __builtin_amdgcn_readlane(rk, src), cw = __builtin_amdgcn_readlane(row, src);
-      if (top3::before(cd, cr, cw, kd, krk, krow)) {
+      if (top3<E>::before(cd, cr, cw, kd, krk, krow)) {
         best.insert(cd, cr, cw, lane);
-        kd   = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best.d), kr));
-        krk  = __builtin_amdgcn_readlane(best.rk, kr);
-        krow = __builtin_amdgcn_readlane(best.row, kr);
+        best.at(kr, kd, krk, krow);
       }
     }
   }
   // the winners, ordered by (score, row) as select_k orders them
-  wave_top<1> out;
+  wave_top<E> out;
   out.init();
   for (int r = 0; r < (int)k; ++r) {
-    const float cd    = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(best.d), r));
-    const uint32_t cw = __builtin_amdgcn_readlane(best.row, r);
+    float cd = 0.f;
+    uint32_t cr = 0u, cw = 0xffffffffu;
+    best.at(r, cd, cr, cw);
     if (cw == 0xffffffffu) break;
     out.insert(cd, cw, lane);
   }
-  if (lane < (int)k) {
-    const bool ok = out.i[0] != 0xffffffffu;
-    top_d[q * k + lane] = ok ? out.d[0] : FLT_MAX;
-    top_i[q * k + lane] = ok ? out.i[0] : 0xffffffffu;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int r = e * 64 + lane;
+    if (r < (int)k) {
+      const bool ok = out.i[e] != 0xffffffffu;
+      top_d[q * k + r] = ok ? out.d[e] : FLT_MAX;
+      top_i[q * k + r] = ok ? out.i[e] : 0xffffffffu;
+    }
   }
 }
 
@@ -1136,7 +1169,7 @@ bool pq3_supported(const ivf_pq_index& idx, int k)
   // pq_len 2 (a lane's 8 K elements of an MFMA step = 4 subspaces = 4 code bytes), whole 16-byte code chunks, a decode
   // table of at most 128 KiB
   return idx.pq_bits == 8 && idx.pq_len == 2 && idx.pq_dim % 16 == 0 && idx.pq_dim >= 16 && idx.pq_dim <= 128 &&
-         idx.rot_dim == 2 * idx.pq_dim && idx.codebook_kind == 0 && k <= 64;
+         idx.rot_dim == 2 * idx.pq_dim && idx.codebook_kind == 0 && k <= 128;
 }
 
 pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
@@ -1318,7 +1351,7 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   else                      { if (h.acc_half) pick(I2{}, std::true_type{}); else pick(I2{}, std::false_type{}); }
 }
 
-bool flat3_supported(uint32_t dim, int k) { return dim % 32 == 0 && dim >= 32 && dim <= 256 && k <= 64; }
+bool flat3_supported(uint32_t dim, int k) { return dim % 32 == 0 && dim >= 32 && dim <= 256 && k <= 128; }
 
 static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
 {
@@ -1421,8 +1454,12 @@ void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)
   hipLaunchKernelGGL(ov_scan_kernel, dim3(1), dim3(1024), 0, res.stream, r.ov_cnt, r.nq, r.ov_off);
   hipLaunchKernelGGL(ov_fill_kernel, dim3(256), dim3(256), 0, res.stream, ov, r.counters + 1, r.overflow_cap, r.ov_off, r.ov_cnt,
                      ov + r.overflow_cap);
-  hipLaunchKernelGGL(pool_merge_kernel, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
-                     r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, ov + r.overflow_cap, r.ov_off);
+  if (r.k <= 64)
+    hipLaunchKernelGGL(pool_merge_kernel<1>, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
+                       r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, ov + r.overflow_cap, r.ov_off);
+  else
+    hipLaunchKernelGGL(pool_merge_kernel<2>, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
+                       r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, ov + r.overflow_cap, r.ov_off);
 }
 
 }  // namespace cuvs_amd

@@ -93,6 +93,21 @@ def test_c3_shape_lists_of_thousands_of_rows(big_lists, lut, acc, monkeypatch):
     assert (gi == pi).all() and (gd == pd).all()
 
 
+@pytest.mark.parametrize("k", [100, 128])
+def test_c3_shape_k_beyond_64(big_lists, k, monkeypatch):
+    """k = 100 (the usual second setting of ANN benchmarks) and 128: two ranks per lane in the pool merge, groups of two
+    threads in the head kernel's threshold."""
+    x, q, index, ex = big_lists
+    kw = dict(n_probes=12, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, 12, lut="f16", acc="f32")
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (gi == si).all() and (gd == sd).all()
+
+
 def test_c3_shape_cold_bounds_overflow_the_default_queues(big_lists, monkeypatch):
     """Uniform queries far from every mode: bounds stay loose, most rows survive the filter and the default queues
     (3072 rows per group for 12.5k-row lists) overflow without any test hook."""
@@ -219,13 +234,14 @@ def test_c2_shape_matrix_core_tail_phase(flat_big_lists, metric, monkeypatch):
     assert (gi == si).all() and (gd == sd).all()
 
 
-def test_c2_shape_far_queries_and_k64(flat_big_lists):
-    """Uniform queries far from every mode (loose head bounds: pools run over into the overflow list) and k = 64."""
+@pytest.mark.parametrize("k", [64, 100])
+def test_c2_shape_far_queries_and_larger_k(flat_big_lists, k):
+    """Uniform queries far from every mode (loose head bounds: pools run over into the overflow list), k = 64 and 100."""
     x, _, index, ex = flat_big_lists
     rng = np.random.default_rng(6)
     q = (rng.random((300, 128), dtype=np.float32) * 4.0 - 2.0).astype(np.float32)
-    gd, gi = _flat_search(index, q, 64, 12)
-    od, oi = oracle.ivf_flat_search(ex, q, 64, 12)
+    gd, gi = _flat_search(index, q, k, 12)
+    od, oi = oracle.ivf_flat_search(ex, q, k, 12)
     assert (gi == oi).all() and (gd == od).all()
 
 
