@@ -287,6 +287,10 @@ def run_c5(args):
         recall = recall_of(out_i[:ng].cpu().numpy(), best_i.cpu().numpy())
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        try:
+            C.CDLL(None).fflush(None)  # RCCL's start-up banner (C stdio) before the JSON line
+        except Exception:
+            pass
         print(json.dumps({
             "metric": f"QPS, IVF-PQ {rows}x96 int8 list-sharded, batch={args.batch} per GPU", "value": round(nq_total / (ms * 1e-3), 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -906,6 +910,12 @@ def main():
         }
         if sharded:
             out["config"]["all_gather_ms_per_step"] = round(ag_ms / max(args.steps, 1), 3)
+        # RCCL writes its start-up banner through C stdio (the one-rank sharded line initialises a communicator): flush it
+        # first, so that the JSON line is the LAST line on stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
