@@ -195,20 +195,6 @@ inline uint32_t read_word(resources& res, const uint32_t* d)
   return *res.host_word;
 }
 
-// up to 16 device words through the pinned buffer (more: a pageable copy)
-inline void read_words(resources& res, const void* d, size_t n_words, void* out)
-{
-  if (n_words > 16) {
-    HIP_TRY(hipMemcpyAsync(out, d, n_words * 4, hipMemcpyDeviceToHost, res.stream));
-    sync(res);
-    return;
-  }
-  if (res.host_word == nullptr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&res.host_word), 64));
-  HIP_TRY(hipMemcpyAsync(res.host_word, d, n_words * 4, hipMemcpyDeviceToHost, res.stream));
-  sync(res);
-  memcpy(out, res.host_word, n_words * 4);
-}
-
 // ---------------------------------------------------------------- DLPack checks
 // Device-accessible = what the reference accepts (kDLCUDA/kDLCUDAHost/kDLCUDAManaged,
 // c/src/core/detail/interop.hpp:49-53) plus the ROCm spellings.
