@@ -759,8 +759,8 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<float> qtiles(res, max_items * (dim_pad + 1) * qpb);
   dev_buf<float> cand_d(res, large_k ? (size_t)bs * scores_ld : (size_t)np_max * k), top_d(res, (size_t)bs * k);
   const size_t esz = elem_size(et);
-  // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): fp32 rows, L2, batches large enough for a head phase
-  const bool use3 = head > 0 && et == elem_t::f32 && metric_is_l2(idx.metric) && !large_k && n_queries >= 256 &&
+  // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): fp32 / fp16 rows, L2, batches large enough for a head phase
+  const bool use3 = head > 0 && (et == elem_t::f32 || et == elem_t::f16) && metric_is_l2(idx.metric) && !large_k && n_queries >= 256 &&
                     flat3_supported(idx.dim, k) && res.tune.flat_scan3 != 0;
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
@@ -876,7 +876,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         r.unit_rows = unit_rows; r.xcd_ticket = tickets3.data(); r.filter_bits = filter_bits;
         r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
         flat3_view v{idx.data.data(), idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
-                     idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len};
+                     idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len, et == elem_t::f16};
         const bool tdbg = (res.tune.scan_debug & 1024) != 0;
         auto now = [&]() { if (tdbg) sync(res); return std::chrono::steady_clock::now(); };
         const auto t0 = now();

@@ -608,7 +608,21 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
 // ------------------------------------------------------------------ IVF-Flat through the same filter (fp32 rows, L2)
 // The A operands of the GEMM are the rows' residuals against their list centre, rounded to fp16 after a power-of-two
 // scaling: a derived copy of the index (half its size; 288 GB of HBM pay for it) laid out as the MFMA wants it.
+// the VL = 16 / sizeof(T) elements of a 16-byte chunk as floats (fp32 or fp16 rows; exact)
+template <typename T>
+__device__ inline void chunk_to_float(const uint4& w, float (&x)[16 / sizeof(T)])
+{
+  if constexpr (sizeof(T) == 4) {
+    x[0] = __uint_as_float(w.x); x[1] = __uint_as_float(w.y); x[2] = __uint_as_float(w.z); x[3] = __uint_as_float(w.w);
+  } else {
+    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)__builtin_bit_cast(_Float16, (uint16_t)(ws[e >> 1] >> ((e & 1) * 16)));
+  }
+}
+
 // max |x - c| over the index (scaling) and |x - c|^2 per row (K-extension term); one thread per row
+template <typename T>
 __global__ void flat_residual_stats_kernel(const uint8_t* __restrict__ data, const float* __restrict__ centers,
                                            const uint32_t* __restrict__ row_list, int64_t rows, uint32_t dim, uint32_t n_chunks,
                                            float* __restrict__ dn, uint32_t* __restrict__ max_bits)
@@ -620,12 +634,13 @@ __global__ void flat_residual_stats_kernel(const uint8_t* __restrict__ data, con
   if (L != 0xffffffffu) {
     const uint4* cp = reinterpret_cast<const uint4*>(data) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
     const float* ct = centers + (size_t)L * dim;
+    constexpr int VL = 16 / sizeof(T);
     for (uint32_t c = 0; c < n_chunks; ++c) {
-      const uint4 w = cp[(size_t)c * 64];
-      const float x[4] = {__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+      float x[VL];
+      chunk_to_float<T>(cp[(size_t)c * 64], x);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d = x[e] - ct[c * 4 + e];
+      for (int e = 0; e < VL; ++e) {
+        const float d = x[e] - ct[c * VL + e];
         acc = __fmaf_rn(d, d, acc);
         mx  = fmaxf(mx, fabsf(d));
       }
@@ -648,6 +663,7 @@ __global__ void flat_group_lists_kernel(const uint32_t* __restrict__ list_offset
 
 // rows16[tile][step][lane]: lane (row r = lane & 31 of the tile, half h = lane >> 5) holds the residuals of dimensions
 // [32 (step / 2) + 16 h + 8 (step % 2), + 8) - the K-slot order of the B operands - as scaled fp16; term[row]: the K-extension halves of -|x - c|^2 (1 - 2^-9) sc^2 / 2
+template <typename T>
 __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float* __restrict__ centers,
                                    const uint32_t* __restrict__ row_list, const float* __restrict__ dn, int64_t rows, uint32_t dim,
                                    uint32_t n_chunks, float sc, uint4* __restrict__ rows16, uint32_t* __restrict__ term)
@@ -664,12 +680,13 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
   if (L != 0xffffffffu) {
     const uint4* cp = reinterpret_cast<const uint4*>(data) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
     const float* ct = centers + (size_t)L * dim + d0;
+    constexpr int VL = 16 / sizeof(T);  // 8 dimensions = two chunks of fp32 or one of fp16
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const uint4 w = cp[(size_t)(d0 / 4 + c) * 64];
-      const float x[4] = {__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
+    for (int c = 0; c < 8 / VL; ++c) {
+      float x[VL];
+      chunk_to_float<T>(cp[(size_t)(d0 / VL + c) * 64], x);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[c * 4 + e] = (_Float16)(sc * (x[e] - ct[c * 4 + e]));
+      for (int e = 0; e < VL; ++e) v[c * VL + e] = (_Float16)(sc * (x[e] - ct[c * VL + e]));
     }
   } else {
 #pragma unroll
@@ -689,6 +706,7 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
 }
 
 // one lane per survivor: the scan kernel's arithmetic (ivf_flat.hip: t = q - x, acc = fma(t, t, acc) in dimension order)
+template <typename T>
 __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params a)
 {
   const bool spill = blockIdx.x + 1 == gridDim.x;
@@ -704,15 +722,19 @@ __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params 
     const float* rq = a.rot_queries + (size_t)q * a.dim;
     const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
     float acc = 0.f;
+    constexpr int VL = 16 / sizeof(T);
     for (uint32_t c = 0; c < a.n_chunks; ++c) {
-      const uint4 w    = cp[(size_t)c * 64];
-      const float x[4] = {__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)};
-      const float4 qv  = *reinterpret_cast<const float4*>(rq + c * 4);
-      const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
+      float x[VL];
+      chunk_to_float<T>(cp[(size_t)c * 64], x);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float t = qq[e] - x[e];
-        acc = __fmaf_rn(t, t, acc);
+      for (int e4 = 0; e4 < VL / 4; ++e4) {
+        const float4 qv   = *reinterpret_cast<const float4*>(rq + c * VL + e4 * 4);
+        const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = qq[e] - x[e4 * 4 + e];
+          acc = __fmaf_rn(t, t, acc);
+        }
       }
     }
     pool_append(a, q, pair, row, acc);
@@ -1366,7 +1388,7 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
     c.data_ptr = nullptr;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t need = (size_t)rows * v.dim * 2 + (size_t)rows * 12 + (size_t(1) << 30);
+    const size_t need = (size_t)rows * v.dim * 2 + (size_t)rows * 12 + (size_t(1) << 30);  // (fp16 rows: as large as the index again)
     if (free_b < need) return false;
   }
   dev_buf<uint32_t> row_list(res, (size_t)rows / 64), mxd(res, 1);
@@ -1378,8 +1400,12 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
   c.rows16   = dev_buf<uint4>::persistent((size_t)rows / 32 * (v.dim / 16) * 64);
   c.row_term = dev_buf<uint32_t>::persistent((size_t)rows);
   if (v.padded_rows > 0) {
-    hipLaunchKernelGGL(flat_residual_stats_kernel, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data, v.centers,
-                       row_list.data(), v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
+    if (v.half_rows)
+      hipLaunchKernelGGL(flat_residual_stats_kernel<__half>, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data,
+                         v.centers, row_list.data(), v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
+    else
+      hipLaunchKernelGGL(flat_residual_stats_kernel<float>, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data,
+                         v.centers, row_list.data(), v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
     const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
     float mx;
     memcpy(&mx, &mbits, 4);
@@ -1388,8 +1414,12 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
     c.maxres = mx;
     c.sc     = mx > 0.f ? std::exp2(std::floor(std::log2(16.0f / mx))) : 1.0f;
     const int64_t n_t = v.padded_rows / 32 * (v.dim / 16) * 64;
-    hipLaunchKernelGGL(flat_rows16_kernel, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(),
-                       dn.data(), v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
+    if (v.half_rows)
+      hipLaunchKernelGGL(flat_rows16_kernel<__half>, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers,
+                         row_list.data(), dn.data(), v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
+    else
+      hipLaunchKernelGGL(flat_rows16_kernel<float>, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers,
+                         row_list.data(), dn.data(), v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
   }
   sync(res);
   c.data_ptr = v.data; c.rows = v.padded_rows; c.size = v.size;
@@ -1441,7 +1471,8 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices;
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = r.fail;
   profile_begin(res, "flat_rescore_kernel");
-  hipLaunchKernelGGL(flat_rescore_kernel, dim3(grid + 1, 8), dim3(256), 0, res.stream, s);
+  if (v.half_rows) hipLaunchKernelGGL(flat_rescore_kernel<__half>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s);
+  else             hipLaunchKernelGGL(flat_rescore_kernel<float>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s);
   profile_end(res, "flat_rescore_kernel");
   profile_end(res, "ivf_flat_scan_kernel");
   return true;

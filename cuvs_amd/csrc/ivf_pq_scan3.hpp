@@ -62,7 +62,7 @@ struct pq3_head {
 };
 void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h);
 
-// ---- IVF-Flat (fp32 rows, L2) through the same filter: a derived fp16 copy of the rows' residuals laid out as MFMA operands
+// ---- IVF-Flat (fp32 or fp16 rows, L2) through the same filter: a derived fp16 copy of the rows' residuals laid out as MFMA operands
 struct flat3_cache {
   dev_buf<uint4> rows16;       // [padded_rows / 32][dim / 16][64 lanes] x 16 bytes
   dev_buf<uint32_t> row_term;  // [padded_rows] K-extension halves of -|x - c|^2 (1 - 2^-9) sc^2 / 2
@@ -79,6 +79,7 @@ struct flat3_view {  // the IVF-Flat index as ivf_flat.hip holds it
   uint32_t n_lists, dim, n_chunks;
   int64_t padded_rows, size;
   uint32_t max_list_len;
+  bool half_rows;  // fp16 rows (else fp32)
 };
 bool flat3_supported(uint32_t dim, int k);
 // filter + re-score of the tail phase (units from r.pair_off); r.rot_queries = the fp32 queries [nq, dim]; *r.fail is

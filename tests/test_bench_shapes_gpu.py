@@ -245,6 +245,29 @@ def test_c2_shape_far_queries_and_larger_k(flat_big_lists, k):
     assert (gi == oi).all() and (gd == od).all()
 
 
+def test_c2_shape_fp16_rows(monkeypatch):
+    """fp16 rows and queries through the matrix-core tail phase (rows widened exactly, the same fp32 fma chain): the
+    oracle's and the scan kernel's ids / distances, at 128 and at 96 dimensions."""
+    import torch
+    from cuvs_amd.neighbors import ivf_flat
+
+    for dim in (128, 96):
+        monkeypatch.delenv("CUVS_AMD_FLAT_SCAN3", raising=False)
+        x, q = _mixture(60_000, dim, 320, seed=1600 + dim)
+        x, q = x.astype(np.float16), q.astype(np.float16)
+        index = ivf_flat.build(ivf_flat.IndexParams(n_lists=24, kmeans_n_iters=10, kmeans_trainset_fraction=0.3),
+                               torch.from_numpy(x).cuda())
+        ex = ivf_flat.export_for_oracle(index, np.float16)
+        for k in (10, 64):
+            gd, gi = _flat_search(index, q, k, 12)
+            od, oi = oracle.ivf_flat_search(ex, q, k, 12)
+            assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+            assert (gd == od).all()
+        monkeypatch.setenv("CUVS_AMD_FLAT_SCAN3", "0")
+        sd, si = _flat_search(index, q, 64, 12)
+        assert (gi == si).all() and (gd == sd).all()
+
+
 # ---------------------------------------------------------------------------------------------------------- C4 shape
 @pytest.fixture(scope="module")
 def cagra_768():
