@@ -130,10 +130,12 @@ void shard_all_gather_topk(resources& res, cuvsAmdShardComm& c, const float* ld,
   if (nq == 0) return;
   const int64_t n = nq * k;
   const size_t blk = wire_block_bytes(n);
-  dev_buf<char> send(res, blk), recv(res, blk * c.world);
-  hipLaunchKernelGGL(pack_block_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, ld, li, n, send.data());
+  // in place: this rank's block is packed where the all-gather leaves it (no send buffer, no local copy inside RCCL)
+  dev_buf<char> recv(res, blk * c.world);
+  char* send = recv.data() + (size_t)c.rank * blk;
+  hipLaunchKernelGGL(pack_block_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, ld, li, n, send);
   profile_begin(res, "shard_all_gather");
-  RCCL_TRY(rccl().all_gather(send.data(), recv.data(), blk, ncclUint8, c.comm, res.stream));
+  RCCL_TRY(rccl().all_gather(send, recv.data(), blk, ncclUint8, c.comm, res.stream));
   profile_end(res, "shard_all_gather");
   dev_buf<float> vals(res, (size_t)n * c.world);
   dev_buf<int64_t> ids(res, (size_t)n * c.world);
