@@ -18,6 +18,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <chrono>
 #include <vector>
 
 namespace cuvs_amd {
@@ -84,6 +85,7 @@ struct tuning {
   int pq3_surv_cap      = 0;   // CUVS_AMD_PQ3_SURV_CAP: survivor-list entries of the matrix-core filter (test hook: forces the hand-back path)
   int pq_qcap           = 0;   // CUVS_AMD_PQ_QCAP: survivor-queue rows of pq_scan2_kernel (test hook: forces the overflow path)
   int scan_debug        = 0;   // CUVS_AMD_SCAN_DEBUG: ablation / statistics bits of the PQ scan
+  int alloc_cache       = 1;   // CUVS_AMD_ALLOC_CACHE=0: every scratch buffer goes back to the runtime's pool when it is freed
   bool shard_coarse_replicated = false;  // CUVS_AMD_SHARD_COARSE_REPLICATED
   bool bf_fused = false, bf_no_threshold = false, bf_no_fused_filter = false;  // CUVS_AMD_BF_*
   bool dist_old         = false;  // CUVS_AMD_DIST_OLD
@@ -110,6 +112,7 @@ struct resources {
   bool cagra_guarantee_connectivity = false;  // cuvsAmdCagraSetGuaranteeConnectivity (cagra.hpp:193 has no C field)
   uint32_t* host_word = nullptr;              // one pinned word for small device -> host readbacks (made on first use)
   unsigned long long* cagra_work = nullptr;   // device [3]: rows scored / graph rows read / walkers (cuvsAmdCagraWorkCounters)
+  struct scratch_cache* cache = nullptr;      // freed scratch blocks kept for the next call (core.hip); shared by copies of the handle
 };
 
 inline resources* as_res(uintptr_t h)
@@ -194,6 +197,28 @@ inline uint32_t read_word(resources& res, const uint32_t* d)
   sync(res);
   return *res.host_word;
 }
+
+// CUVS_AMD_SCAN_DEBUG bit 8192: host-side timeline of one search call - wall time between marks WITHOUT synchronising
+// (what the host spends enqueueing each section; a section that waits for the device shows the drain time)
+struct host_trace {
+  bool on;
+  const char* what;
+  std::vector<std::pair<const char*, std::chrono::steady_clock::time_point>> marks;
+  host_trace(bool enabled, const char* name) : on(enabled), what(name) { mark("begin"); }
+  void mark(const char* name)
+  {
+    if (on) marks.emplace_back(name, std::chrono::steady_clock::now());
+  }
+  ~host_trace()
+  {
+    if (!on) return;
+    mark("buffers freed");
+    fprintf(stderr, "[host trace %s]", what);
+    for (size_t i = 1; i < marks.size(); ++i)
+      fprintf(stderr, " %s %.3f", marks[i].first, std::chrono::duration<double, std::milli>(marks[i].second - marks[i - 1].second).count());
+    fprintf(stderr, " | total %.3f ms\n", std::chrono::duration<double, std::milli>(marks.back().second - marks.front().second).count());
+  }
+};
 
 // ---------------------------------------------------------------- DLPack checks
 // Device-accessible = what the reference accepts (kDLCUDA/kDLCUDAHost/kDLCUDAManaged,

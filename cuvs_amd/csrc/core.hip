@@ -7,6 +7,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 
 namespace cuvs_amd {
 
@@ -16,13 +17,31 @@ std::string& last_error_text()
   return text;
 }
 
-void* device_alloc(resources& res, size_t bytes)
+// Scratch blocks a call frees are kept by the handle and handed to the next request of exactly that size: a search
+// allocates the same temporaries every batch, and hipFreeAsync on a stream that has just been synchronised (the searches
+// that read a flag back) costs ~80 us PER BLOCK on this runtime - 2.5 of the 6.0 ms of an IVF-Flat search at the C2 shape
+// (profiles/r03_host_trace_flat.log). Same ordering guarantee as hipFreeAsync + hipMallocAsync on one stream: a block is
+// only re-used by work queued later on the stream it was used on; requests on any other stream bypass the cache.
+struct scratch_cache {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  std::unordered_map<void*, size_t> live;              // blocks handed out on `stream`
+  std::unordered_multimap<size_t, void*> free_blocks;  // by exact size
+  size_t cached_bytes = 0;
+  size_t cap_bytes    = 0;                // beyond it the cache is emptied
+  size_t max_block    = size_t(2) << 30;  // larger blocks (build-time buffers) are never kept
+};
+
+namespace {
+
+void* raw_alloc(resources& res, size_t bytes, bool* failed)
 {
   void* p = nullptr;
   hipError_t e = res.pool != nullptr ? hipMallocFromPoolAsync(&p, bytes, res.pool, res.stream)
                                      : hipMallocAsync(&p, bytes, res.stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
+    if (failed != nullptr) { *failed = true; return nullptr; }
     // pool exhausted or unsupported: fall back to a synchronous allocation
     HIP_TRY(hipStreamSynchronize(res.stream));
     HIP_TRY(hipMalloc(&p, bytes));
@@ -30,15 +49,79 @@ void* device_alloc(resources& res, size_t bytes)
   return p;
 }
 
+void raw_free(hipStream_t stream, void* p)
+{
+  hipError_t e = hipFreeAsync(p, stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(p);
+  }
+}
+
+void cache_flush_locked(scratch_cache& c)
+{
+  for (auto& kv : c.free_blocks) raw_free(c.stream, kv.second);
+  c.free_blocks.clear();
+  c.cached_bytes = 0;
+}
+
+}  // namespace
+
+void scratch_cache_flush(resources& res)
+{
+  if (res.cache == nullptr) return;
+  std::lock_guard<std::mutex> lk(res.cache->mu);
+  cache_flush_locked(*res.cache);
+}
+
+void* device_alloc(resources& res, size_t bytes)
+{
+  scratch_cache* c = res.cache;
+  if (c == nullptr) return raw_alloc(res, bytes, nullptr);
+  std::lock_guard<std::mutex> lk(c->mu);
+  const bool cached_path = res.stream == c->stream && bytes <= c->max_block;
+  if (cached_path) {
+    auto it = c->free_blocks.find(bytes);
+    if (it != c->free_blocks.end()) {
+      void* p = it->second;
+      c->free_blocks.erase(it);
+      c->cached_bytes -= bytes;
+      c->live.emplace(p, bytes);
+      return p;
+    }
+  }
+  bool failed = false;
+  void* p = raw_alloc(res, bytes, c->cached_bytes > 0 ? &failed : nullptr);
+  if (failed) {  // the kept blocks may be what is in the way
+    cache_flush_locked(*c);
+    p = raw_alloc(res, bytes, nullptr);
+  }
+  if (cached_path) c->live.emplace(p, bytes);
+  return p;
+}
+
 void device_free(resources& res, void* p)
 {
   if (!p) return;
-  hipError_t e = hipFreeAsync(p, res.stream);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipStreamSynchronize(res.stream);
-    (void)hipFree(p);
+  scratch_cache* c = res.cache;
+  if (c != nullptr) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->live.find(p);
+    if (it != c->live.end()) {
+      const size_t bytes = it->second;
+      c->live.erase(it);
+      if (res.stream == c->stream) {
+        if (c->cached_bytes + bytes > c->cap_bytes) cache_flush_locked(*c);
+        if (bytes <= c->cap_bytes) {
+          c->free_blocks.emplace(bytes, p);
+          c->cached_bytes += bytes;
+          return;
+        }
+      }
+    }
   }
+  raw_free(res.stream, p);
 }
 
 void fill_dl_view(DLManagedTensor* out, void* data, DLDataType dt, int64_t rows, int64_t cols,
@@ -101,6 +184,7 @@ tuning load_tuning_from_env()
   t.pq3_surv_cap     = geti("CUVS_AMD_PQ3_SURV_CAP", 0);
   t.pq_qcap          = geti("CUVS_AMD_PQ_QCAP", 0);
   t.scan_debug       = geti("CUVS_AMD_SCAN_DEBUG", 0);
+  t.alloc_cache      = geti("CUVS_AMD_ALLOC_CACHE", 1);
   t.shard_coarse_replicated = set("CUVS_AMD_SHARD_COARSE_REPLICATED");
   t.bf_fused           = set("CUVS_AMD_BF_FUSED");
   t.bf_no_threshold    = set("CUVS_AMD_BF_NO_THRESHOLD");
@@ -174,6 +258,14 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
       r->pool = nullptr;  // no private pools on this runtime: plain hipMallocAsync from the default pool
     }
     (void)hipGetLastError();
+    if (r->tune.alloc_cache != 0) {
+      r->cache         = new scratch_cache();
+      r->cache->stream = r->stream;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = size_t(64) << 30; }
+      r->cache->cap_bytes = std::min<size_t>(total_b / 8, size_t(16) << 30);
+      if (const char* mb = getenv("CUVS_AMD_ALLOC_CACHE_MB")) r->cache->cap_bytes = (size_t)std::max(0L, atol(mb)) << 20;
+    }
     *res = reinterpret_cast<uintptr_t>(r);
   });
 }
@@ -190,6 +282,12 @@ cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
     }
     if (r->cagra_work != nullptr) (void)hipFree(r->cagra_work);
     if (r->host_word != nullptr) (void)hipHostFree(r->host_word);
+    if (r->cache != nullptr) {
+      scratch_cache_flush(*r);
+      (void)hipStreamSynchronize(r->stream);
+      delete r->cache;
+      r->cache = nullptr;
+    }
     if (r->pool != nullptr) (void)hipMemPoolDestroy(r->pool);
     if (r->owns_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
@@ -200,12 +298,20 @@ cuvsError_t cuvsStreamSet(cuvsResources_t res, cudaStream_t stream)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto* r = as_res(res);
+    if (r->cache != nullptr) {  // kept blocks are ordered on the old stream: give them back before it goes
+      scratch_cache_flush(*r);
+      HIP_TRY(hipStreamSynchronize(r->stream));
+    }
     if (r->owns_stream && r->stream) {
       HIP_TRY(hipStreamSynchronize(r->stream));
       HIP_TRY(hipStreamDestroy(r->stream));
     }
     r->stream      = reinterpret_cast<hipStream_t>(stream);
     r->owns_stream = false;
+    if (r->cache != nullptr) {
+      std::lock_guard<std::mutex> lk(r->cache->mu);
+      r->cache->stream = r->stream;
+    }
   });
 }
 

@@ -745,6 +745,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   }
   const int64_t bs = std::min<int64_t>(max_batch, n_queries);
   const int64_t np_max = bs * n_probes;
+  host_trace trace((res.tune.scan_debug & 8192) != 0, "ivf_flat_search");  // declared before the buffers: destroyed after them
   dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
   // two-phase schedule (ivf_common.hpp): nearest probe of every query first
   uint32_t head = (n_probes > 8 && metric_is_l2(idx.metric) && !large_k) ? 1u : 0u;
@@ -773,6 +774,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0), tickets3(res, use3 ? 8 * 32 : 0);
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, max_units), overflow3(res, (size_t)2 * overflow_cap);
+  trace.mark("buffers allocated");
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
     const int64_t nq      = std::min(max_batch, n_queries - q0);
@@ -799,6 +801,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
                                    probes.data(), true);
     }
+    trace.mark("coarse search");
     const uint32_t* labels = probes.data();
     if (head > 0) {
       hipLaunchKernelGGL(phase_labels_kernel, dim3(grid_blocks(n_pairs, 256)), dim3(256), 0, res.stream, probes.data(),
@@ -807,6 +810,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     }
     build_work_items(res, labels, n_pairs, n_labels, qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data());
+    trace.mark("work items");
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     if (use3) {  // the candidate rows start out invalid: the tail of a query's row is its pool
       HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)n_pairs * k, res.stream));
@@ -856,11 +860,13 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       }
       profile_end(res, "ivf_flat_scan_kernel");
     };
+    trace.mark("memsets + query tiles");
     // grids are upper bounds of the (device-side) item counts of each phase; surplus workgroups exit at once
     bool merged = false;
     if (head > 0) {
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
       launch(a, (unsigned)(nq * head / qpb + idx.n_lists + 1));
+      trace.mark("head launch");
       a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
       if (use3) {
         pq3_run r{};
@@ -881,6 +887,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         auto now = [&]() { if (tdbg) sync(res); return std::chrono::steady_clock::now(); };
         const auto t0 = now();
         if (flat3_tail(res, v, idx.scan3, r)) {
+          trace.mark("tail enqueued");
           const auto t1 = now();
           pq3_merge(res, r, top_d.data(), top_i.data());
           const auto t2 = now();
@@ -888,7 +895,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
             fprintf(stderr, "[flat3] tail %.3f ms, merge %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
                     std::chrono::duration<double, std::milli>(t2 - t1).count());
           // a buffer ran over (bounds too loose to filter: e.g. lists shorter than k): the tail phase again, on the scan kernel
+          trace.mark("merge enqueued");
           merged = read_word(res, r.fail) == 0u;
+          trace.mark("flag read back (device drained)");
         }
       }
       if (!merged) launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
@@ -907,6 +916,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     }
     hipLaunchKernelGGL(flat_postprocess_kernel, dim3(grid_blocks(nq * k, 256)), dim3(256), 0, res.stream, top_i.data(),
                        top_d.data(), nq * k, idx.indices.data(), idx.metric, neighbors + q0 * k, distances + q0 * k);
+    trace.mark("select + post-process");
   }
   HIP_TRY(hipGetLastError());
 }
