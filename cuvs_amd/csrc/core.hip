@@ -87,7 +87,7 @@ void* device_alloc(resources& res, size_t bytes)
       void* p = it->second;
       c->free_blocks.erase(it);
       c->cached_bytes -= bytes;
-      c->live.emplace(p, bytes);
+      c->live[p] = bytes;
       return p;
     }
   }
@@ -97,7 +97,7 @@ void* device_alloc(resources& res, size_t bytes)
     cache_flush_locked(*c);
     p = raw_alloc(res, bytes, nullptr);
   }
-  if (cached_path) c->live.emplace(p, bytes);
+  if (cached_path) c->live[p] = bytes;  // (overwrites a stale entry of an address the caller released behind our back)
   return p;
 }
 
