@@ -91,9 +91,14 @@ def test_searches_do_not_depend_on_the_cache(monkeypatch, env):
     q = (centers[rng.integers(0, 64, 320)] + 0.3 * rng.standard_normal((320, 64))).astype(np.float32)
     xd, qd = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
 
-    def run(res):
-        index = ivf_flat.build(ivf_flat.IndexParams(n_lists=16, kmeans_n_iters=8), xd, resources=res)
-        bf = brute_force.build(xd, metric="sqeuclidean", resources=res)
+    for key in ("CUVS_AMD_ALLOC_CACHE", "CUVS_AMD_ALLOC_CACHE_MB"):
+        monkeypatch.delenv(key, raising=False)
+    base = cuvs_amd.common.Resources()
+    index = ivf_flat.build(ivf_flat.IndexParams(n_lists=16, kmeans_n_iters=8), xd, resources=base)
+    bf = brute_force.build(xd, metric="sqeuclidean", resources=base)
+    base.sync()
+
+    def run(res):  # a built index may be searched through any handle
         out = []
         for _ in range(3):
             d, i = ivf_flat.search(ivf_flat.SearchParams(n_probes=12), index, qd, 10, resources=res)
@@ -102,9 +107,7 @@ def test_searches_do_not_depend_on_the_cache(monkeypatch, env):
             out.append((d.cpu().numpy(), i.cpu().numpy(), bd.cpu().numpy(), bi.cpu().numpy()))
         return out
 
-    for key in ("CUVS_AMD_ALLOC_CACHE", "CUVS_AMD_ALLOC_CACHE_MB"):
-        monkeypatch.delenv(key, raising=False)
-    ref = run(cuvs_amd.common.Resources())
+    ref = run(base)
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     got = run(cuvs_amd.common.Resources())
