@@ -5,9 +5,10 @@
 
 #include <cuvs/core/c_api.h>
 
+#include "scratch_cache.hpp"
+
 #include <cstdlib>
 #include <mutex>
-#include <unordered_map>
 
 namespace cuvs_amd {
 
@@ -16,21 +17,6 @@ std::string& last_error_text()
   thread_local std::string text;
   return text;
 }
-
-// Scratch blocks a call frees are kept by the handle and handed to the next request of exactly that size: a search
-// allocates the same temporaries every batch, and hipFreeAsync on a stream that has just been synchronised (the searches
-// that read a flag back) costs ~80 us PER BLOCK on this runtime - 2.5 of the 6.0 ms of an IVF-Flat search at the C2 shape
-// (profiles/r03_host_trace_flat.log). Same ordering guarantee as hipFreeAsync + hipMallocAsync on one stream: a block is
-// only re-used by work queued later on the stream it was used on; requests on any other stream bypass the cache.
-struct scratch_cache {
-  std::mutex mu;
-  hipStream_t stream = nullptr;
-  std::unordered_map<void*, size_t> live;              // blocks handed out on `stream`
-  std::unordered_multimap<size_t, void*> free_blocks;  // by exact size
-  size_t cached_bytes = 0;
-  size_t cap_bytes    = 0;                // beyond it the cache is emptied
-  size_t max_block    = size_t(2) << 30;  // larger blocks (build-time buffers) are never kept
-};
 
 namespace {
 
@@ -49,8 +35,9 @@ void* raw_alloc(resources& res, size_t bytes, bool* failed)
   return p;
 }
 
-void raw_free(hipStream_t stream, void* p)
+void raw_free(void* stream_v, void* p)
 {
+  hipStream_t stream = static_cast<hipStream_t>(stream_v);
   hipError_t e = hipFreeAsync(p, stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -59,69 +46,26 @@ void raw_free(hipStream_t stream, void* p)
   }
 }
 
-void cache_flush_locked(scratch_cache& c)
-{
-  for (auto& kv : c.free_blocks) raw_free(c.stream, kv.second);
-  c.free_blocks.clear();
-  c.cached_bytes = 0;
-}
-
 }  // namespace
 
+// scratch_cache.hpp: freed scratch blocks are kept by the handle and re-used by exact size on the same stream
 void scratch_cache_flush(resources& res)
 {
-  if (res.cache == nullptr) return;
-  std::lock_guard<std::mutex> lk(res.cache->mu);
-  cache_flush_locked(*res.cache);
+  if (res.cache != nullptr) res.cache->flush(raw_free);
 }
 
 void* device_alloc(resources& res, size_t bytes)
 {
-  scratch_cache* c = res.cache;
-  if (c == nullptr) return raw_alloc(res, bytes, nullptr);
-  std::lock_guard<std::mutex> lk(c->mu);
-  const bool cached_path = res.stream == c->stream && bytes <= c->max_block;
-  if (cached_path) {
-    auto it = c->free_blocks.find(bytes);
-    if (it != c->free_blocks.end()) {
-      void* p = it->second;
-      c->free_blocks.erase(it);
-      c->cached_bytes -= bytes;
-      c->live[p] = bytes;
-      return p;
-    }
-  }
-  bool failed = false;
-  void* p = raw_alloc(res, bytes, c->cached_bytes > 0 ? &failed : nullptr);
-  if (failed) {  // the kept blocks may be what is in the way
-    cache_flush_locked(*c);
-    p = raw_alloc(res, bytes, nullptr);
-  }
-  if (cached_path) c->live[p] = bytes;  // (overwrites a stale entry of an address the caller released behind our back)
-  return p;
+  if (res.cache == nullptr) return raw_alloc(res, bytes, nullptr);
+  return res.cache->alloc(
+    res.stream, bytes, [&](size_t n, bool* failed) { return raw_alloc(res, n, failed); }, raw_free);
 }
 
 void device_free(resources& res, void* p)
 {
   if (!p) return;
-  scratch_cache* c = res.cache;
-  if (c != nullptr) {
-    std::lock_guard<std::mutex> lk(c->mu);
-    auto it = c->live.find(p);
-    if (it != c->live.end()) {
-      const size_t bytes = it->second;
-      c->live.erase(it);
-      if (res.stream == c->stream) {
-        if (c->cached_bytes + bytes > c->cap_bytes) cache_flush_locked(*c);
-        if (bytes <= c->cap_bytes) {
-          c->free_blocks.emplace(bytes, p);
-          c->cached_bytes += bytes;
-          return;
-        }
-      }
-    }
-  }
-  raw_free(res.stream, p);
+  if (res.cache == nullptr) raw_free(res.stream, p);
+  else res.cache->release(res.stream, p, raw_free);
 }
 
 void fill_dl_view(DLManagedTensor* out, void* data, DLDataType dt, int64_t rows, int64_t cols,
