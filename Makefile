@@ -17,6 +17,9 @@ all: cuvs_amd/libcuvs_c.so oracle/liboracle.so
 # the PQ scan kernel lives exactly at the 128-VGPR budget of a 1024-thread workgroup: SLP vectorisation of its
 # scalar fp32 LUT arithmetic into packed pairs costs ~50 spilled registers (the codebook goes to scratch)
 build/ivf_pq_search.o: HIPFLAGS += -fno-slp-vectorize
+# the one-wave-per-SIMD filter: accumulators (screened by the VALU) in architectural registers, the B operands in the
+# accumulation registers; fmaxf chains without canonicalisation (v_max3_f32)
+build/ivf_pq_filter4.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans
 
 build/%.o: cuvs_amd/csrc/%.hip $(HDRS)
 	@mkdir -p build

@@ -111,7 +111,7 @@ def run_pmc_passes(child_args, n_search, timeout_s=240):
     rebuilds this workload and runs `n_search` searches; returns per-search sums for pq_scan_kernel or None."""
     if shutil.which("rocprofv3") is None:
         return None
-    sums = {}
+    sums, fsums = {}, {}
     for i, counters in enumerate(PMC_SETS):
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", *counters.split(), "--output-format", "csv", "-d", d, "-o", "pmc", "--",
@@ -132,14 +132,18 @@ def run_pmc_passes(child_args, n_search, timeout_s=240):
                 return None
             n_disp = 0
             for r in csv.DictReader(open(files[0])):
-                if any(t in r["Kernel_Name"] for t in ("pq_scan", "pq_filter", "pq_rescore", "pool_merge")):
+                if any(t in r["Kernel_Name"] for t in ("pq_scan", "pq_head", "pq_bprep", "pq_filter", "pq_rescore", "pool_merge")):
                     sums[r["Counter_Name"]] = sums.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                     n_disp += 1
+                if "pq_filter" in r["Kernel_Name"]:
+                    fsums[r["Counter_Name"]] = fsums.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             if n_disp == 0:
                 return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return {k: v / n_search for k, v in sums.items()}
+    out = {k: v / n_search for k, v in sums.items()}
+    out["filter"] = {k: v / n_search for k, v in fsums.items()}
+    return out
 
 
 def pmc_child(args, n_search):
@@ -379,8 +383,7 @@ def extra_c2(res, dev):
     # the search time without the per-kernel HIP events of profiled()
     dt = timeit(lambda: ivf_flat.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 10, 2)
     bf = brute_force.build(x, resources=res)
-    _, gt = brute_force.search(bf, q[:1000], 10, resources=res)
-    res.sync()
+    gt = exact_topk_fp64(x, q[:1000], 10)  # fp64 in torch, independent of this library (eval_neighbours, ann_utils.cuh:222-289)
     r = recall_of(nb[:1000].cpu().numpy(), gt.cpu().numpy())
     # the exact search over the same 10M rows and 10k queries (the ground-truth index): the distance GEMM at scale
     bf_dt = timeit(lambda: brute_force.search(bf, q, 10, resources=res), 2, 1)
@@ -390,7 +393,7 @@ def extra_c2(res, dev):
     # filter over the fp16 residual copy of the rows (ivf_pq_scan3.hip, FLAT build) + the fp32 re-scoring of the survivors.
     # Unique bytes the scan phases must fetch: every list once as fp32 (head phase: ~all 4096 lists are some query's nearest)
     # and once as fp16 (tail phase), plus the 4-byte row terms.
-    unique = n * 512 + n * 256 + n * 4
+    unique = n * 512  # the lower bound on HBM bytes per batch = unique probed-list bytes (this library's own fp16 copy is its cost, not algorithmic work)
     hbm_gbs = unique / (scan_ms * 1e-3) / 1e9
     return {"brute_force_same_data": {"config": "brute_force L2 10000000x128 fp32 batch=10000 k=10", "ms": round(bf_dt * 1e3, 1),
                                       "qps": round(nq / bf_dt, 1),
@@ -403,10 +406,9 @@ def extra_c2(res, dev):
             "roofline": {"bound": "hbm", "logical_scan_gbs": round(logical / (scan_ms * 1e-3) / 1e9, 1),
                          "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                          "unique_bytes": unique,
-                         "note": "frac = unique bytes the scan phases have to fetch (every list once as fp32 for the head phase, once "
-                                 "as the fp16 residual copy for the matrix-core tail phase, the row terms) / (scan-kernel time x 8 "
-                                 "TB/s); the tail phase re-reads a list chunk once per group of 64 probing queries (L2). "
-                                 "logical_scan_gbs = list bytes per kernel second (SURVEY 8d)"}}
+                         "note": "frac = algorithmic unique bytes (every row of the index once, 10M x 512 B) / (scan-kernel time x 8 TB/s); "
+                                 "the kernels actually fetch more: fp32 rows for the head phase plus the fp16 residual copy for the "
+                                 "matrix-core tail phase. logical_scan_gbs = list bytes per pair and kernel second (SURVEY 8d)"}}
 
 
 def extra_c4_clustered(res, dev, rows=2_000_000, latent=24, modes=4096):
@@ -419,9 +421,7 @@ def extra_c4_clustered(res, dev, rows=2_000_000, latent=24, modes=4096):
     gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=modes, out=x)
     q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
     gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=modes, out=q)
-    _, gt = brute_force.search(brute_force.build(x, resources=res), q[:1000], 10, resources=res)
-    res.sync()
-    gt = gt.cpu().numpy()
+    gt = exact_topk_fp64(x, q[:1000], 10, chunk=250_000).cpu().numpy()  # fp64 in torch, independent of this library
     out = {"config": f"C4-clustered CAGRA {rows}x768 fp16, {modes} modes in a {latent}-d latent space, graph_degree=64, batch=10000 k=10"}
     for guarantee in (False, True):
         t0 = time.time()
@@ -456,10 +456,7 @@ def extra_c4(res, dev, rows, latent, modes=1):
     build_s = time.time() - t0
     nb = torch.empty((nq, 10), dtype=torch.int32, device=dev)
     dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
-    bf = brute_force.build(x, resources=res)
-    _, gt = brute_force.search(bf, q[:1000], 10, resources=res)
-    res.sync()
-    gt = gt.cpu().numpy()
+    gt = exact_topk_fp64(x, q[:1000], 10, chunk=250_000).cpu().numpy()  # fp64 in torch, independent of this library
     from cuvs_amd._lib import check, lib
 
     def measured_work(sp):
@@ -655,6 +652,28 @@ def main():
     truth = exact_topk_fp64(data, queries[q_lo:q_lo + ng], args.k).cpu().numpy()  # fp64, not this library's brute force
     recall = recall_of(neighbors[q_lo:q_lo + ng].cpu().numpy(), truth)
 
+    # ------------------------------------------------------------------ bit-level check at the bench scale (untimed): the
+    # first 1000 queries searched again by a handle whose tail phase runs the LUT scan kernels (no matrix-core filter) must
+    # return the same ids AND the same distances as the headline path (ivf_pq_search.cuh:421-669: same scores, same top-k)
+    scan3_equals_lut_scan = None
+    if rank == 0 and world == 1:
+        nchk = min(1000, args.batch)
+        sp_chk = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                                     max_internal_batch_size=nq_total)
+        a_i = torch.empty((nchk, kk), dtype=torch.int64, device=dev)
+        a_d = torch.empty((nchk, kk), dtype=torch.float32, device=dev)
+        b_i, b_d = torch.empty_like(a_i), torch.empty_like(a_d)
+        ivf_pq.search(sp_chk, index, queries[:nchk], kk, neighbors=a_i, distances=a_d, resources=res)
+        os.environ["CUVS_AMD_PQ_SCAN3"] = "0"
+        res_lut = cuvs_amd.common.Resources()  # the switches are read once, when a handle is created
+        del os.environ["CUVS_AMD_PQ_SCAN3"]
+        ivf_pq.search(sp_chk, index, queries[:nchk], kk, neighbors=b_i, distances=b_d, resources=res_lut)
+        res.sync(); res_lut.sync()
+        torch.cuda.synchronize()
+        scan3_equals_lut_scan = bool(torch.equal(a_i, b_i) and torch.equal(a_d, b_d))
+        log(f"scan3 == LUT scan on {nchk} queries of the {args.rows}-row index: {scan3_equals_lut_scan}")
+        del res_lut
+
     # ------------------------------------------------------------------ the other precisions (same step, untimed region)
     variants = []
     early_stop_off_ms = None
@@ -681,39 +700,74 @@ def main():
         del res_off
 
     # ------------------------------------------------------------------ roofline of the dominant kernel
-    # algorithmic bytes per step = sum over (query, probe) pairs of list_len * code bytes
+    # Algorithmic work of one search, from the index's list sizes and an independent coarse ranking of the batch:
+    #   logical bytes  = sum over (query, probe) pairs of list_len * code bytes (the reference reads a list once per pair)
+    #   unique bytes   = code bytes of every list probed by at least one pair (the lower bound on HBM bytes per batch)
+    #   useful flop    = 2 * rot_dim per (row, query) pair of the tail phase (the screen is a GEMM of decoded rows x residuals)
+    #   gather cycles  = LDS cycles of the decode if no two lanes ever met in a bank: every 32-row subtile of a probed list
+    #                    once per 128 probing queries, 32 ds_read_b32 x 2 cycles each
     sizes = index.list_sizes.to(torch.int64)
     centers = index.centers
     cn = (centers * centers).sum(1)
     owned = (torch.arange(args.n_lists, device=dev) % world) == rank
     probe_bytes = 0
+    tail_pairs = torch.zeros(args.n_lists, dtype=torch.int64, device=dev)
+    all_pairs = torch.zeros(args.n_lists, dtype=torch.int64, device=dev)
+    code_bytes = args.pq_dim * 8 // 8
     for q0 in range(0, nq_total, 2048):
         qq = queries[q0:q0 + 2048]
         dmat = cn[None, :] - 2.0 * (qq @ centers.T)
         pr = torch.topk(dmat, min(args.n_probes, args.n_lists), dim=1, largest=False).indices
-        probe_bytes += int((sizes[pr] * owned[pr]).sum().item()) * (args.pq_dim * 8 // 8)
+        probe_bytes += int((sizes[pr] * owned[pr]).sum().item()) * code_bytes
+        all_pairs += torch.bincount(pr.reshape(-1), minlength=args.n_lists)
+        tail_pairs += torch.bincount(pr[:, 1:].reshape(-1), minlength=args.n_lists)  # the nearest probe is the head phase
+    tail_pairs, all_pairs = tail_pairs * owned, all_pairs * owned
+    unique_bytes = int((sizes * (all_pairs > 0)).sum().item()) * code_bytes
+    tail_row_pairs = int((sizes * tail_pairs).sum().item())
+    useful_flop = 2.0 * (2 * args.pq_dim) * tail_row_pairs
+    subtile_decodes = int((((sizes + 31) // 32) * ((tail_pairs + 127) // 128)).sum().item())
+    gather_cycles = subtile_decodes * 32 * 2.0
+    SPEC_GHZ, MFMA_F16_TFLOPS = 2.4, 2500.0  # MI355X_MICROARCH.md: peak engine clock, dense fp16 MFMA peak
     # one search = a small head launch (nearest probe of every query) + the tail launch: the same work, bytes and
     # time are averaged over all launches (sum of bytes / sum of time)
     per_step = max(n_launch, 1) / max(args.steps, 1)
     bytes_per_launch = probe_bytes / per_step
     avg_ms = scan_ms / max(n_launch, 1)
     logical = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # `frac` is a real fraction: the busiest pipe's floor (its busy cycles without bank conflicts) over the kernel's
-    # cycles, from the PMC passes below; achieved / peak are that pipe's busy and available cycles per second. The
-    # logical scan rate of SURVEY 8d (code bytes of every probed list per kernel second) is kept as `logical_scan_gbs`:
-    # the list-major schedule serves a list byte from L2 many times per HBM fetch, so that figure exceeds the HBM peak
-    # by design and is no utilisation.
-    roofline = {"bound": None, "kernel": "pq_scan_kernel (head phase) + pq_filter_kernel + pq_rescore_kernel (tail phase)", "achieved": None, "peak": None,
-                "unit": "Gcycles/s", "frac": None, "traffic": None, "logical_scan_gbs": round(logical, 1),
-                "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 3),
-                "launches": n_launch, "launches_per_step": per_step, "algorithmic_bytes_per_step": probe_bytes,
-                "kernel_ms_per_step": round(avg_ms * per_step, 3), "early_stop_off_kernel_ms_per_step": early_stop_off_ms,
-                "tail_phase_ms_per_step": headline_phase_ms,
-                "note": "frac = floor / kernel: busy cycles of the busiest pipe (VALU issue cycles, matrix-core busy cycles, LDS array "
-                        "cycles minus bank-conflict cycles, or HBM bytes / 8 TB/s) over the cycles of the scan kernels of one search, all from rocprofv3 PMC passes "
-                        "of this workload (GRBM_GUI_ACTIVE, SQ_ACTIVE_INST_VALU, SQ_LDS_IDX_ACTIVE, SQ_LDS_BANK_CONFLICT, "
-                        "FETCH_SIZE x 2 + WRITE_SIZE). The per-instruction ceilings behind the floors are microbenchmarked "
-                        "in profiles/r03_lds_gather_bench.json and profiles/r03_valu_rate_bench.json"}
+    # The dominant kernel is pq_filter_kernel (one launch per search). Its speed of light is the largest of three floors, each
+    # a spec peak: unique code bytes / 8 TB/s, useful fp16 MFMA flop / 2.5 PFLOP/s, conflict-free gather cycles / (256 CUs x
+    # 2.4 GHz). `frac` = that floor / the kernel's measured duration (HIP events around the launch, this run); `bound` names it.
+    f_ms = headline_phase_ms.get("pq_filter_kernel", 0.0)
+    floors_ms = {"hbm": unique_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, "mfma": useful_flop / (MFMA_F16_TFLOPS * 1e12) * 1e3,
+                 "lds": gather_cycles / (N_CU * SPEC_GHZ * 1e9) * 1e3}
+    sol_bound = max(floors_ms, key=floors_ms.get)
+    sol_frac = floors_ms[sol_bound] / f_ms if f_ms > 0 else None
+    if sol_bound == "hbm":
+        ach, peak, unit = unique_bytes / max(f_ms, 1e-9) / 1e6, HBM_PEAK_GBS, "GB/s"
+    elif sol_bound == "mfma":
+        ach, peak, unit = useful_flop / max(f_ms, 1e-9) / 1e9, MFMA_F16_TFLOPS, "TFLOP/s"
+    else:
+        ach, peak, unit = gather_cycles / max(f_ms, 1e-9) / 1e6, N_CU * SPEC_GHZ, "Gcycles/s"
+    roofline = {"bound": sol_bound, "kernel": "pq_filter_kernel (the tail phase's matrix-core screen: dominant kernel, one launch per search)",
+                "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": None if sol_frac is None else round(sol_frac, 4),
+                "traffic": None, "avg_launch_ms": round(f_ms, 3),
+                "floors_ms": {k: round(v, 3) for k, v in floors_ms.items()},
+                "frac_hbm_unique_bytes": round(floors_ms["hbm"] / f_ms, 4) if f_ms > 0 else None,
+                "frac_mfma_useful_flop": round(floors_ms["mfma"] / f_ms, 4) if f_ms > 0 else None,
+                "frac_lds_conflict_free_gathers": round(floors_ms["lds"] / f_ms, 4) if f_ms > 0 else None,
+                "algorithmic": {"unique_code_bytes_per_search": unique_bytes, "logical_code_bytes_per_search": probe_bytes,
+                                "tail_row_query_pairs": tail_row_pairs, "useful_mfma_flop": useful_flop,
+                                "subtile_decodes": subtile_decodes, "conflict_free_gather_cycles": gather_cycles},
+                "scan_kernels": {"names": "pq_head_kernel + pq_bprep_kernel + pq_filter_kernel + pq_rescore_kernel (+ hand-backs)",
+                                 "launches_per_step": per_step, "kernel_ms_per_step": round(avg_ms * per_step, 3),
+                                 "phase_ms_per_step": headline_phase_ms, "logical_scan_gbs": round(logical, 1),
+                                 "frac_hbm_unique_bytes": round(unique_bytes / (HBM_PEAK_GBS * 1e9) / max(avg_ms * per_step * 1e-3, 1e-12), 4),
+                                 "early_stop_off_kernel_ms_per_step": early_stop_off_ms},
+                "note": "frac = max(unique code bytes / 8 TB/s, useful fp16 MFMA flop / 2.5 PFLOP/s, conflict-free LDS gather cycles / "
+                        "(256 CUs x 2.4 GHz)) / measured duration of pq_filter_kernel: every term is a spec peak and an algorithmic "
+                        "quantity computed from the index and the batch. logical_scan_gbs (SURVEY 8d: list bytes per pair) exceeds the "
+                        "HBM peak by design - a list chunk is fetched once per up to 128 probing queries - and is no utilisation. "
+                        "pmc.* are busy cycles of each pipe over SPEC-clock cycles (2.4 GHz x kernel time), from rocprofv3 --pmc passes of this workload"}
     if rank == 0 and world == 1 and not args.no_pmc:
         t0 = time.time()
         child = ["--rows", str(args.rows), "--dim", str(args.dim), "--n-lists", str(args.n_lists), "--n-probes",
@@ -722,46 +776,29 @@ def main():
                  str(args.trainset_fraction)]
         pmc = run_pmc_passes(child, n_search=3)
         log(f"PMC passes took {time.time() - t0:.1f}s: {'ok' if pmc else 'unavailable'}")
+
+        def pmc_fracs(c, t_ref):
+            """busy fractions of every pipe over SPEC-clock cycles of the un-profiled kernel time t_ref (seconds)"""
+            spec_cycles = t_ref * SPEC_GHZ * 1e9
+            hbm_bytes = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0  # gfx950: FETCH_SIZE x 2
+            lds_act = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
+            return {"hbm_bytes": int(hbm_bytes), "hbm_frac": round(hbm_bytes / t_ref / 1e9 / HBM_PEAK_GBS, 4),
+                    "lds_busy": round(lds_act / (spec_cycles * N_CU), 4),
+                    "lds_bank_conflict_share": round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(lds_act, 1.0), 4),
+                    "valu_busy": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (spec_cycles * N_SIMD), 4),
+                    "mfma_busy": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (spec_cycles * N_SIMD), 4),
+                    "tcc_hit_rate": round(c.get("TCC_HIT_sum", 0.0) / max(c.get("TCC_HIT_sum", 0.0) + c.get("TCC_MISS_sum", 0.0), 1.0), 4),
+                    "valu_insts": int(c.get("SQ_INSTS_VALU", 0.0)), "lds_insts": int(c.get("SQ_INSTS_LDS", 0.0)),
+                    "effective_clock_ghz": round(c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / max(t_ref, 1e-12) / 1e9, 3)}
+
         if pmc and pmc.get("GRBM_GUI_ACTIVE"):
-            cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
-            kernel_s = cycles / 2.4e9               # at the 2.4 GHz peak clock; the profiled clock is lower (DVFS)
-            hbm_bytes = (2.0 * pmc.get("FETCH_SIZE", 0.0) + pmc.get("WRITE_SIZE", 0.0)) * 1024.0  # gfx950: FETCH_SIZE x 2
-            t_ref = avg_ms * per_step * 1e-3        # un-profiled kernel time of one search (HIP events, this run)
-            fr = {"hbm_frac": hbm_bytes / t_ref / 1e9 / HBM_PEAK_GBS,
-                  "lds_busy": pmc.get("SQ_LDS_IDX_ACTIVE", 0.0) / (cycles * N_CU),
-                  "lds_bank_conflict_share": pmc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(pmc.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0),
-                  "lds_gather_frac": pmc.get("SQ_INSTS_LDS", 0.0) * 2.0 / (cycles * N_CU),
-                  "valu_busy": pmc.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (cycles * N_SIMD),
-                  "mfma_busy": pmc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cycles * N_SIMD),
-                  "tcc_hit_rate": pmc.get("TCC_HIT_sum", 0.0) / max(pmc.get("TCC_HIT_sum", 0.0) + pmc.get("TCC_MISS_sum", 0.0), 1.0)}
-            fr["lds_floor"] = fr["lds_busy"] * (1.0 - fr["lds_bank_conflict_share"])  # conflict-free LDS array cycles
-            fr["valu_insts_per_step"] = pmc.get("SQ_INSTS_VALU", 0.0)
-            fr["lds_insts_per_step"] = pmc.get("SQ_INSTS_LDS", 0.0)
-            roofline.update({k: round(v, 4) for k, v in fr.items()})
-            roofline["traffic"] = int(hbm_bytes / per_step)
-            roofline["hbm_bytes_per_step"] = int(hbm_bytes)
-            roofline["pmc_cycles_per_step"] = int(cycles)
-            roofline["pmc_kernel_ms_at_2p4ghz"] = round(kernel_s * 1e3, 3)
-            bound, frac = max((("lds", fr["lds_floor"]), ("valu", fr["valu_busy"]), ("mfma", fr["mfma_busy"]), ("hbm", fr["hbm_frac"])),
-                              key=lambda t: t[1])
-            roofline["bound"], roofline["frac"] = bound, round(frac, 4)
-            clock_ghz = cycles / max(t_ref, 1e-9) / 1e9  # effective clock of the profiled cycles over the un-profiled time
-            pipes = {"valu": N_SIMD, "mfma": N_SIMD, "lds": N_CU, "hbm": 1}[bound]
-            roofline["peak"] = round(pipes * clock_ghz, 1) if bound != "hbm" else HBM_PEAK_GBS
-            roofline["achieved"] = round(frac * roofline["peak"], 1)
-            roofline["unit"] = "Gcycles/s" if bound != "hbm" else "GB/s"
+            roofline["pmc"] = {"scan_kernels_of_one_search": pmc_fracs(pmc, avg_ms * per_step * 1e-3)}
+            if pmc.get("filter") and f_ms > 0:
+                pf = pmc_fracs(pmc["filter"], f_ms * 1e-3)
+                roofline["pmc"]["pq_filter_kernel"] = pf
+                roofline["traffic"] = pf["hbm_bytes"]  # HBM bytes of the dominant kernel's launch (FETCH_SIZE x 2 + WRITE_SIZE)
+                roofline["traffic_over_unique_bytes"] = round(pf["hbm_bytes"] / max(unique_bytes, 1), 3)
             roofline["pmc_source"] = "live: rocprofv3 --pmc passes of this workload, spawned by this run"
-    if roofline["traffic"] is None:
-        tfile = os.path.join(ROOT, "profiles", "r03_pq_scan_pmc.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                roofline.update({k: tj[k] for k in ("hbm_frac", "lds_busy", "lds_bank_conflict_share", "lds_gather_frac", "lds_floor",
-                                                    "valu_busy", "mfma_busy", "tcc_hit_rate", "bound", "frac", "achieved", "peak", "unit") if k in tj})
-                roofline["traffic"] = int(tj["hbm_bytes_per_step"] / per_step) if "hbm_bytes_per_step" in tj else None
-                roofline["pmc_source"] = "profiles/r03_pq_scan_pmc.json (committed PMC passes of the same command)"
-            except Exception:
-                pass
 
     # ------------------------------------------------------------------ the same workload with inner product / cosine
     # (signed LUT entries: no early stop in a LUT scan; the matrix-core filter works on full-score bounds)
@@ -904,6 +941,7 @@ def main():
                        "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants,
                        "sharded_one_rank": sharded_line},
             "recall_at_10": round(recall, 4),
+            "scan3_equals_lut_scan": scan3_equals_lut_scan,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "extra": extra,

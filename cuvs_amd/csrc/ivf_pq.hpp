@@ -52,6 +52,7 @@ struct ivf_pq_index {
     dev_buf<uint32_t> cb16;
     dev_buf<uint32_t> row_term;
     float sc = 1.f, cbmax = 0.f, dmax = 0.f;
+    bool term_fp32 = false;  // row_term holds fp32 values (pq_filter4_kernel) instead of fp16 (hi, lo) pairs
     const void* codes_ptr = nullptr;
     const void* pq_ptr    = nullptr;
     int64_t rows = -1, size = -1;

@@ -1,0 +1,448 @@
+// IVF-PQ search, warm-bounds phase on the matrix cores (see ivf_pq_scan3.hip for the scheme): the filter kernel of
+// round 4 and its pre-pass. Reference semantics: compute_score_impl.cuh:52-79 / ivf_pq_search.cuh:421-669 - the filter
+// only decides which (row, query) pairs the reference's arithmetic has to look at.
+#include "ivf_pq_filter_common.hpp"
+
+#include <cfloat>
+#include <type_traits>
+
+namespace cuvs_amd {
+
+namespace {
+
+// ================================================================== round 4: the filter with ONE wave per SIMD
+// What the two-waves-per-SIMD kernel above left on the table (profiles/r03_*): a list probed by 65 .. 128 queries decoded
+// its rows twice (64-query units), the unit prologue (B operands from fp32 residuals, thresholds in double: ~23 k cycles
+// per unit and wave) was 10 % of the kernel, the K-extension step was a ninth of the matrix work, and 256 registers per
+// wave did not hold the 64 B-operand registers + double-buffered A operands without spilling (51 VGPRs). Here:
+//   * a pre-pass (pq_bprep_kernel) writes, for every tail pair, the fp16 B operand in MFMA layout (256 B at rot_dim 128)
+//     and the threshold in accumulator units: the filter's prologue is 32 16-byte loads per lane;
+//   * a work unit holds up to FOUR groups of 32 queries (128 B-operand registers): the rows of a list chunk are fetched
+//     and decoded once for up to 128 probing queries - half the LDS gathers, VALU decode work and code fetches per pair;
+//   * the row term -|d|^2 (1 - 2^-9) sc^2 / 2 enters as the INITIAL VALUE of the accumulators (fp32, four 16-byte loads per
+//     subtile, shared by the query groups) instead of through a ninth MFMA step;
+//   * one 256-thread workgroup per CU = one wave per SIMD with up to 512 registers; the overlap that two waves per SIMD
+//     provided by chance is written into the program order: the gathers that decode subtile u + 1 are spread over the K
+//     steps of subtile u's MFMAs, and the accumulators of subtile u - 1 are screened while those of u are being computed
+//     (two accumulator sets), so the matrix pipe never waits for a screen.
+// Results are those of the kernel above: the same threshold, a superset test (the row term is more precise in fp32).
+struct bprep_params {
+  const uint32_t* sorted_pairs;
+  const uint32_t* pair_off;  // [2 n_lists + 1]: the tail pairs are sorted_pairs[pair_off[n_lists] .. pair_off[2 n_lists])
+  uint32_t n_lists;
+  const uint32_t* probes;  // [n_pairs] list of every pair
+  const float* rot_queries;
+  const float* centers_rot;
+  const uint32_t* query_kth;
+  uint32_t* qflag;
+  uint4* bq;   // [tail pair][K step][K half] x 16 bytes: the pair's scaled fp16 residual as the filter's B operand
+  float* thr;  // [tail pair] threshold in accumulator units (+inf: nothing survives, -inf: everything does)
+  uint32_t n_probes, rot_dim;
+  float sc, c1, eps, alpha, cbmax, dmax, bound_max;
+  int is_ip, flat;
+};
+
+// one wave per 32 consecutive tail pairs, lane = (pair ql, K half h) - the B-operand layout of v_mfma_f32_32x32x16_f16
+template <int NCH>
+__global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
+{
+  constexpr int NST = 2 * NCH;
+  const uint32_t s_base = a.pair_off[a.n_lists], s_end = a.pair_off[2 * a.n_lists];
+  const uint32_t lane = threadIdx.x & 63u, ql = lane & 31u, h = lane >> 5;
+  const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 32u;
+  if (s_base + w0 >= s_end) return;  // wave-uniform
+  const uint32_t s  = s_base + w0 + ql;
+  const bool valid  = s < s_end;
+  const uint32_t p  = a.sorted_pairs[valid ? s : s_end - 1u];
+  const uint32_t q  = p / a.n_probes, L = a.probes[p];
+  const float* rq   = a.rot_queries + (size_t)q * a.rot_dim;
+  const float* ct   = a.centers_rot + (size_t)L * a.rot_dim;
+  uint4* out        = a.bq + ((size_t)(s - s_base) * NST * 2 + h);
+  float rn = 0.f, big = 0.f, qc = 0.f, cn = 0.f;
+#pragma unroll
+  for (int st = 0; st < NST; ++st) {
+    const uint32_t s0 = 16u * (st >> 1) + 8u * h + 4u * (st & 1);
+    const float4 q0 = *reinterpret_cast<const float4*>(rq + 2 * s0), q1 = *reinterpret_cast<const float4*>(rq + 2 * s0 + 4);
+    float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    const float4 c0 = *reinterpret_cast<const float4*>(ct + 2 * s0), c1 = *reinterpret_cast<const float4*>(ct + 2 * s0 + 4);
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    if (!a.is_ip) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] -= c[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qc = __fmaf_rn(r[e], c[e], qc); cn = __fmaf_rn(c[e], c[e], cn); }
+    }
+    f16x8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      rn   = __fmaf_rn(r[e], r[e], rn);
+      const float x = a.sc * r[e];
+      big  = fmaxf(big, fabsf(x));
+      v[e] = (_Float16)fminf(fmaxf(x, -60000.f), 60000.f);  // (finite whatever happens: unserved queries may still be screened)
+    }
+    if (valid) out[st * 2] = __builtin_bit_cast(uint4, v);
+  }
+  rn  += __shfl_xor(rn, 32);
+  qc  += __shfl_xor(qc, 32);
+  cn  += __shfl_xor(cn, 32);
+  big  = fmaxf(big, __shfl_xor(big, 32));
+  const uint32_t kk = a.query_kth[q];
+  const float bound = key_to_float(kk);
+  // no finite bound yet, an operand beyond the fp16 range or a bound the LUT type cannot represent: nothing of this query
+  // survives here, it is handed back to the LUT scan (IVF-Flat: everything survives, all its rows are re-scored)
+  const bool served = kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max;
+  if (!a.flat && valid && !served && h == 0u) a.qflag[q] = 1u;
+  const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
+  if (valid && h == 0u) a.thr[s - s_base] = served ? t / a.c1 : (a.flat ? -INFINITY : INFINITY);
+}
+
+constexpr int kF4Threads = 256;  // 4 waves: one per SIMD, up to 512 registers each
+
+struct filter4_params {
+  const filter_unit* units;
+  const uint32_t* n_units;  // device scalar
+  uint32_t* xcd_ticket;     // 8 counters, 32 words apart
+  const uint32_t* sorted_pairs;
+  const uint32_t* pair_off;
+  uint32_t n_lists;
+  const uint4* bq;
+  const float* thr;
+  const uint32_t* cb16;
+  const uint8_t* codes;
+  const uint32_t* list_offsets;
+  const uint32_t* list_sizes;
+  const float* row_term;  // [padded_rows] -|d|^2 (1 - 2^-9) sc^2 / 2 (L2), nullptr for inner product
+  uint32_t* qflag;
+  uint2* surv;
+  uint32_t* surv_cnt;
+  uint32_t surv_cap, spill_cap, n_probes, unit_rows;
+  unsigned long long* stats;  // optional [8] as in pq_filter_kernel
+};
+
+// LDS byte address of a decode-table entry in ONE instruction: the low word of `addr` becomes (byte BYTE of w) << 2, its
+// high word - the lane's K half: the two halves' tables lie 64 KiB apart - stays (v_bfe_u32 + v_lshl_add_u32 otherwise:
+// with one wave per SIMD every instruction of the subtile loop is an issue slot the matrix pipe waits behind)
+template <int BYTE>
+__device__ inline void table_addr(uint32_t& addr, const uint32_t two, const uint32_t w)
+{
+  if constexpr (BYTE == 0)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0" : "+v"(addr) : "v"(two), "v"(w));
+  else if constexpr (BYTE == 1)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1" : "+v"(addr) : "v"(two), "v"(w));
+  else if constexpr (BYTE == 2)
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2" : "+v"(addr) : "v"(two), "v"(w));
+  else
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3" : "+v"(addr) : "v"(two), "v"(w));
+}
+
+typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
+
+// TERM: L2 (the rows' terms are the accumulators' initial values); inner product starts from zero
+// DBG: ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs, 8 no code loads
+template <int NCH, bool TERM, int DBG>
+__global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_params a)
+{
+  constexpr int NST = 2 * NCH;           // MFMA K steps
+  constexpr int NGM = NCH <= 4 ? 4 : 2;  // groups of 32 queries per work unit
+  // LDS: K half 0 of every 16-subspace chunk at [0, NCH * 8 KiB), K half 1 at 64 KiB + the same (table_addr), the
+  // workgroup's survivor counter behind
+  constexpr uint32_t kHalf1 = 65536u, kFill = kHalf1 + NCH * 8u * 1024u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* wg_fill = reinterpret_cast<uint32_t*>(smem + kFill);
+  uint2* my_surv    = a.surv + (size_t)blockIdx.x * a.surv_cap;
+  if (threadIdx.x == 0) *wg_fill = 0u;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * 256u / 4u; i += kF4Threads) {
+    // a.cb16: [subspace s][256 codes]; subspace s = 16 c + 8 half + j goes to half's table at (8 c + j) * 1 KiB
+    const uint32_t s = i >> 6, half = (s >> 3) & 1u, slot = (s >> 4) * 8u + (s & 7u);
+    *reinterpret_cast<uint4*>(smem + half * kHalf1 + slot * 1024u + (i & 63u) * 16u) = reinterpret_cast<const uint4*>(a.cb16)[i];
+  }
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63u, ql = lane & 31u, h = lane >> 5;
+  const uint32_t n_units = *a.n_units;
+  const uint32_t chunk   = (n_units + 7u) / 8u;
+  const uint32_t s_base  = a.pair_off[a.n_lists];
+  uint32_t xcd = blockIdx.x & 7u, hops = 0u;
+  const uint32_t two = 2u;
+  const uint32_t lane_code_off = ql * 16u + h * 8u, lane_term_off = h * 16u;  // byte offsets of this lane inside a subtile
+
+  unsigned long long st_pairs = 0, st_surv = 0, st_sub = 0, st_slow = 0, st_units = 0, st_t[3] = {0, 0, 0};
+  for (;;) {
+    const uint32_t share0 = min(n_units, xcd * chunk), share_len = min(chunk, n_units - share0);
+    const filter_unit* share = a.units + share0;
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= share_len) {
+      if (++hops == 8u) break;
+      xcd = (xcd + 1u) & 7u;
+      continue;
+    }
+    const uint4 uu = *reinterpret_cast<const uint4*>(share + t);
+    const uint32_t L = __builtin_amdgcn_readfirstlane(uu.x), first = __builtin_amdgcn_readfirstlane(uu.y),
+                   count = __builtin_amdgcn_readfirstlane(uu.z), row0 = __builtin_amdgcn_readfirstlane(uu.w);
+    const uint32_t base_row = __builtin_amdgcn_readfirstlane(a.list_offsets[L]), len = __builtin_amdgcn_readfirstlane(a.list_sizes[L]);
+    const uint32_t r_end = min(len, row0 + a.unit_rows);
+    const uint32_t u0 = row0 >> 5, u1 = (r_end + 31u) >> 5;
+    const unsigned long long t_unit = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_loop = 0ull, t_slow = 0ull;
+    // wave-uniform bases (lists start at multiples of 64 rows): subtile u of the list is half (u & 1) of 64-row group u / 2
+    const char* code_base = reinterpret_cast<const char*>(a.codes) + (size_t)(base_row >> 6) * NCH * 1024;
+    const char* term_base = reinterpret_cast<const char*>(a.row_term + base_row);
+
+    auto load_codes = [&](const uint32_t u, uint2 (&cw)[NCH]) {
+      const uint32_t uc = min(u, u1 - 1u);  // (scalar; the subtiles past the end repeat the last one)
+      const char* p = code_base + ((size_t)(uc >> 1) * NCH * 1024 + (uc & 1u) * 512u) + lane_code_off;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr ((DBG & 8) != 0) cw[c] = make_uint2(u * 2654435761u + c, lane);  // ablation: no code loads
+        else cw[c] = *reinterpret_cast<const uint2*>(p + c * 1024);
+      }
+    };
+    // the four gathers of K step st: lane (row, half) looks up the fp16x2 codebook entries of four of its row's codes
+    uint32_t ad[4] = {h << 16, h << 16, h << 16, h << 16};  // table addresses: high word = K half, low word rewritten per gather
+    auto decode_step = [&](const uint2 (&cw)[NCH], const int st, u32x4_t (&av)[NST]) {
+      uint32_t w = (st & 1) ? cw[st >> 1].y : cw[st >> 1].x;
+      if constexpr ((DBG & 1) != 0) w = ql * 0x01010101u;  // ablation: every lane of a half in its own bank
+      constexpr uint32_t kNone = 0u;
+      const uint32_t slot0 = (8u * (st >> 1) + 4u * (st & 1)) * 1024u;
+      table_addr<0>(ad[0], two, w);
+      table_addr<1>(ad[1], two, w);
+      table_addr<2>(ad[2], two, w);
+      table_addr<3>(ad[3], two, w);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr ((DBG & 2) != 0) av[st][e] = ad[e] + kNone;  // ablation: no gathers
+        else av[st][e] = *reinterpret_cast<lds_u32_t*>(ad[e] + slot0 + e * 1024u);
+      }
+    };
+    // accumulator register i of a lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile: its initial value is that row's term
+    auto load_term = [&](const uint32_t u, f32x16_t& tv) {
+      if constexpr (!TERM) { tv = f32x16_t{}; return; }
+      const uint32_t uc = min(u, u1 - 1u);
+      const char* p = term_base + (size_t)uc * 128u + lane_term_off;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(p + j * 32);
+        tv[4 * j] = v.x; tv[4 * j + 1] = v.y; tv[4 * j + 2] = v.z; tv[4 * j + 3] = v.w;
+      }
+    };
+
+    auto run = [&](auto ng_tag) {
+      constexpr int NG = decltype(ng_tag)::value;
+      // ---- B operands, thresholds and pair ids of the unit's queries: lane = (query ql of group g, K half h)
+      f16x8_t bop[NG][NST];
+      float thr[NG];
+      uint32_t pairid[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const uint32_t jj  = g * 32u + ql;
+        const uint32_t jc  = min(jj, count - 1u);
+        const uint4* bp    = a.bq + ((size_t)(first - s_base + jc) * NST * 2 + h);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+          bop[g][st] = __builtin_bit_cast(f16x8_t, bp[st * 2]);
+          // the B operands live in the accumulation registers for the whole unit (MFMA reads them there directly); the
+          // 256 architectural registers hold both accumulator sets, the row terms and everything the VALU touches
+          asm volatile("" : "+a"(bop[g][st]));
+        }
+        thr[g]    = jj < count ? a.thr[first - s_base + jc] : INFINITY;
+        pairid[g] = a.sorted_pairs[first + jc];
+      }
+      uint2 cw1[NCH], cw2[NCH], cw3[NCH];  // code words of subtiles u + 1, u + 2, u + 3
+      u32x4_t avA[NST], avB[NST];
+      f32x16_t tA, tB, accA[NG], accB[NG];
+      load_codes(u0, cw1);
+      load_codes(u0 + 1, cw2);
+      load_codes(u0 + 2, cw3);
+      load_term(u0, tA);
+#pragma unroll
+      for (int st = 0; st < NST; ++st) decode_step(cw1, st, avA);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) { cw1[c] = cw2[c]; cw2[c] = cw3[c]; }
+      load_codes(u0 + 3, cw3);
+      if (a.stats != nullptr) t_loop = __builtin_readcyclecounter();
+
+      // ---- screen of a finished subtile: a pair survives when c1 * acc <= threshold, i.e. acc >= thr (c1 < 0)
+      auto screen = [&](const f32x16_t (&acc)[NG], const uint32_t u) {
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          float m = fmaxf(fmaxf(acc[g][0], acc[g][1]), acc[g][2]);  // (v_max3_f32 chains: this file is built with -fno-honor-nans)
+#pragma unroll
+          for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, acc[g][i]), acc[g][i + 1]);
+          m   = fmaxf(m, acc[g][15]);
+          any = any | (m >= thr[g]);
+        }
+        if (a.stats != nullptr) { st_pairs += 32u * count; st_sub += 1u; }
+        if (__ballot(any) == 0ull) return;  // the usual case
+        // slow path (one or two survivors): a lane that holds one collects its hits in a bit mask and appends them one by
+        // one through the workgroup's LDS counter
+        if (a.stats != nullptr) st_slow += 1u;
+        const unsigned long long t_s0 = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
+        if (any) {
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            uint32_t hits = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hits |= (acc[g][i] >= thr[g] ? 1u : 0u) << i;
+            while (hits != 0u) {
+              const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;
+              hits &= hits - 1u;
+              const uint32_t v = (u << 5) + (i & 3u) + 8u * (i >> 2) + 4u * h;
+              if (v >= len) continue;
+              const uint32_t pos = atomicAdd(wg_fill, 1u);  // LDS
+              if (pos < a.surv_cap) {
+                my_surv[pos] = make_uint2(pairid[g], base_row + v);
+              } else {
+                // this workgroup's region is full: the spill region shared by all (one global counter, rarely touched);
+                // only when that is full too is the query handed back to the LUT scan
+                const uint32_t sp = atomicAdd(a.surv_cnt + gridDim.x, 1u);
+                if (sp < a.spill_cap) a.surv[(size_t)gridDim.x * a.surv_cap + sp] = make_uint2(pairid[g], base_row + v);
+                else a.qflag[pairid[g] / a.n_probes] = 1u;
+              }
+              if (a.stats != nullptr) st_surv += 1u;
+            }
+          }
+        }
+        if (a.stats != nullptr) t_slow += __builtin_readcyclecounter() - t_s0;
+      };
+      // ---- one subtile: K step by K step, the four gathers that decode that step of subtile u + 1, then the step's
+      // MFMAs of subtile u for every query group; the previous subtile's accumulators are screened after the second step
+      auto step = [&](const uint32_t u, u32x4_t (&cur)[NST], u32x4_t (&nxt)[NST], const f32x16_t& tcur, f32x16_t& tnxt,
+                      f32x16_t (&acc)[NG], const f32x16_t (&accp)[NG], const bool has_prev) {
+        load_term(u + 1, tnxt);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+          decode_step(cw1, st, nxt);  // (clamped to the last subtile: a harmless repeat at the end)
+          if (st == NST - 1) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { cw1[c] = cw2[c]; cw2[c] = cw3[c]; }
+            load_codes(u + 4, cw3);
+          }
+          const f16x8_t aop = __builtin_bit_cast(f16x8_t, cur[st]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            if constexpr ((DBG & 4) != 0) {  // ablation: no MFMAs
+              if (st == 0) acc[g] = tcur;
+              acc[g][st & 15] += (float)aop[0] * (float)bop[g][st][0];
+            } else {
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[g][st], st == 0 ? tcur : acc[g], 0, 0, 0);
+            }
+          }
+          if (st == (NST > 1 ? 1 : 0) && has_prev) screen(accp, u - 1u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      uint32_t u = u0;
+      for (; u + 1u < u1; u += 2u) {
+        step(u, avA, avB, tA, tB, accA, accB, u > u0);
+        step(u + 1u, avB, avA, tB, tA, accB, accA, true);
+      }
+      if (u < u1) {
+        step(u, avA, avB, tA, tB, accA, accB, u > u0);
+        screen(accA, u);
+      } else {
+        screen(accB, u - 1u);
+      }
+    };
+    if (u0 < u1) {
+      const uint32_t ng = (count + 31u) >> 5;  // wave-uniform
+      if constexpr (NGM == 4) {
+        if (ng >= 4u) run(std::integral_constant<int, 4>{});
+        else if (ng == 3u) run(std::integral_constant<int, 3>{});
+        else if (ng == 2u) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 1>{});
+      } else {
+        if (ng >= 2u) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 1>{});
+      }
+    }
+    if (a.stats != nullptr) {
+      const unsigned long long t_end = __builtin_readcyclecounter();
+      st_t[0] += t_loop - t_unit;  // unit prologue (B operands, first decode)
+      st_t[1] += t_end - t_loop;   // subtile loop
+      st_t[2] += t_slow;           // of which slow path
+      st_units += 1u;
+    }
+  }
+  if (a.stats != nullptr) atomicAdd(&a.stats[1], st_surv);  // counted per lane
+  if (a.stats != nullptr && lane == 0) {
+    atomicAdd(&a.stats[0], st_pairs); atomicAdd(&a.stats[2], st_sub);
+    atomicAdd(&a.stats[3], st_slow);  atomicAdd(&a.stats[4], st_t[0]); atomicAdd(&a.stats[5], st_t[1]);
+    atomicAdd(&a.stats[6], st_t[2]);  atomicAdd(&a.stats[7], st_units);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(*wg_fill, a.surv_cap);
+}
+
+}  // namespace
+
+void pq4_filter(resources& res, const filter4_launch& l)
+{
+  bprep_params b{};
+  b.sorted_pairs = l.sorted_pairs; b.pair_off = l.pair_off; b.n_lists = l.n_lists; b.probes = l.probes;
+  b.rot_queries = l.rot_queries; b.centers_rot = l.centers_rot; b.query_kth = l.query_kth; b.qflag = l.qflag;
+  b.bq = static_cast<uint4*>(l.bq); b.thr = l.thr; b.n_probes = l.n_probes; b.rot_dim = l.rot_dim;
+  b.sc = l.sc; b.c1 = l.c1; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = l.cbmax; b.dmax = l.dmax; b.bound_max = l.bound_max;
+  b.is_ip = l.is_ip; b.flat = 0;
+  const unsigned pgrid = (unsigned)grid_blocks(l.n_pairs, 128);
+  profile_begin(res, "pq_bprep_kernel");
+  switch (l.nch) {
+#ifndef CUVS_AMD_F4_DEV
+    case 1: hipLaunchKernelGGL(pq_bprep_kernel<1>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    case 2: hipLaunchKernelGGL(pq_bprep_kernel<2>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    case 3: hipLaunchKernelGGL(pq_bprep_kernel<3>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    case 5: hipLaunchKernelGGL(pq_bprep_kernel<5>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    case 6: hipLaunchKernelGGL(pq_bprep_kernel<6>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    case 7: hipLaunchKernelGGL(pq_bprep_kernel<7>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    case 8: hipLaunchKernelGGL(pq_bprep_kernel<8>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+#endif
+    default: hipLaunchKernelGGL(pq_bprep_kernel<4>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+  }
+  profile_end(res, "pq_bprep_kernel");
+  filter4_params g{};
+  g.units = l.units; g.n_units = l.n_units; g.xcd_ticket = l.xcd_ticket; g.sorted_pairs = l.sorted_pairs; g.pair_off = l.pair_off;
+  g.n_lists = l.n_lists; g.bq = b.bq; g.thr = l.thr; g.cb16 = l.cb16; g.codes = l.codes; g.list_offsets = l.list_offsets;
+  g.list_sizes = l.list_sizes; g.row_term = l.row_term; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
+  g.surv_cnt = l.surv_cnt; g.surv_cap = l.surv_cap; g.spill_cap = l.spill_cap; g.n_probes = l.n_probes; g.unit_rows = l.unit_rows;
+  g.stats = l.stats;
+  const size_t fsmem = 65536 + (size_t)l.nch * 8 * 1024 + 16;  // the two K halves of the decode table lie 64 KiB apart
+  const bool term = l.row_term != nullptr;
+  auto launch = [&](auto kern) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
+    profile_begin(res, "pq_filter_kernel");
+    hipLaunchKernelGGL(kern, dim3(l.grid), dim3(kF4Threads), fsmem, res.stream, g);
+    profile_end(res, "pq_filter_kernel");
+  };
+#ifndef CUVS_AMD_F4_DEV
+  if (l.nch == 4) {
+    switch (l.dbg) {  // CUVS_AMD_SCAN_DEBUG bits 16..19: ablation builds of the kernel (bench shape only)
+      case 1:  launch(pq_filter4_kernel<4, true, 1>); break;
+      case 2:  launch(pq_filter4_kernel<4, true, 2>); break;
+      case 4:  launch(pq_filter4_kernel<4, true, 4>); break;
+      case 8:  launch(pq_filter4_kernel<4, true, 8>); break;
+      default: if (term) launch(pq_filter4_kernel<4, true, 0>); else launch(pq_filter4_kernel<4, false, 0>); break;
+    }
+    return;
+  }
+  auto pick = [&](auto nch_tag) {
+    constexpr int N = decltype(nch_tag)::value;
+    if (term) launch(pq_filter4_kernel<N, true, 0>); else launch(pq_filter4_kernel<N, false, 0>);
+  };
+  switch (l.nch) {
+    case 1: pick(std::integral_constant<int, 1>{}); break;
+    case 2: pick(std::integral_constant<int, 2>{}); break;
+    case 3: pick(std::integral_constant<int, 3>{}); break;
+    case 5: pick(std::integral_constant<int, 5>{}); break;
+    case 6: pick(std::integral_constant<int, 6>{}); break;
+    case 7: pick(std::integral_constant<int, 7>{}); break;
+    default: pick(std::integral_constant<int, 8>{}); break;
+  }
+#else
+  launch(pq_filter4_kernel<4, true, 0>);
+#endif
+}
+
+}  // namespace cuvs_amd

@@ -1,0 +1,87 @@
+// Shared by the matrix-core filter kernels of the IVF-PQ / IVF-Flat tail phase (ivf_pq_scan3.hip, ivf_pq_filter4.hip).
+#pragma once
+#include "ivf_pq.hpp"
+#include "device_utils.hpp"
+
+#include <cmath>
+
+namespace cuvs_amd {
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// work unit of the filter: a row chunk of a list x a block of the pairs probing it
+struct filter_unit {
+  uint32_t list, first, count, row0;
+};
+
+// Largest value B with: exact score > bound  whenever  (row term - 2 dot16 / sc^2) > B   (L2; see the file header).
+// With T the real-valued score, S the score in the reference's arithmetic and A the filter's value
+//   S >= T (1 - eps) - alpha                          entry roundings of the LUT type, summation in the score type
+//   T >= A - 2^-9 (rn + dn) - mabs                    fp16 rounding of both GEMM operands: |x^ y^ - x y| <= 2^-10 |x y| +
+//                                                     2^-25 (|x| + |y|) per element (normal + subnormal range), fp32
+//                                                     accumulation; 2 |r.d| <= rn + dn
+// so S > bound is implied by  dn (1 - 2^-9) - 2 dot > (bound + alpha) / (1 - eps) + mabs - rn (1 - 2^-9). The right side
+// is evaluated in double and rounded up.
+template <typename P>
+__device__ inline float filter_threshold(const float bound, const float rn, const P& a)
+{
+  const double mabs = 1.1920929e-07 /* 2^-23 */ / (double)a.sc *
+                      (sqrt((double)a.rot_dim * (double)rn) + (double)a.rot_dim * (double)a.cbmax);
+  const double b = ((double)bound + (double)a.alpha) * (1.0 + 2.0 * (double)a.eps) + mabs - (double)rn * (1.0 - 1.0 / 512.0);
+  float f = (float)b;
+  f += fabsf(f) * 2.4e-7f + 1e-37f;
+  return f;
+}
+
+// Inner product / cosine: T = -(q.c + q.d) (q the rotated query, c the list centre, d the row's decoded residual); the LUT
+// entries have both signs, so the roundings of S scale with sum |entry| <= |q| (|c| + |d|) instead of with T:
+//   S >= T - eps |q| (|c| + |d|) - alpha,   T >= A - 2^-17 |q| |c| - 2^-9.9 |q| |d| - mabs,   A = -(qc + dot16 / sc^2)
+// with qc = q.c in fp32 and |d| <= dmax (the largest decoded norm of the index). S > bound is implied by
+//   -dot16 / sc^2 > bound + qc + |q| ((eps + 2^-17) |c| + (eps + 2^-9) dmax) + mabs + alpha.
+template <typename P>
+__device__ inline float filter_threshold_ip(const float bound, const float qn, const float cn, const float qc, const P& a)
+{
+  const double nq = sqrt((double)qn), nc = sqrt((double)cn);
+  const double mabs = 1.1920929e-07 /* 2^-23 */ / (double)a.sc * (sqrt((double)a.rot_dim) * nq + (double)a.rot_dim * (double)a.cbmax);
+  const double m = nq * (((double)a.eps + 7.63e-6) * nc + ((double)a.eps + 1.0 / 512.0) * (double)a.dmax);
+  const double b = (double)bound + (double)qc + (fabs((double)qc) + fabs((double)bound)) * 1e-6 + m + mabs + (double)a.alpha;
+  float f = (float)b;
+  f += fabsf(f) * 2.4e-7f + 1e-37f;
+  return f;
+}
+
+
+// ---- pq_filter4_kernel (ivf_pq_filter4.hip): pre-pass + filter, one wave per SIMD
+struct filter4_launch {
+  const filter_unit* units;
+  const uint32_t* n_units;
+  uint32_t* xcd_ticket;
+  const uint32_t* sorted_pairs;
+  const uint32_t* pair_off;
+  uint32_t n_lists;
+  const uint32_t* probes;
+  const float* rot_queries;
+  const float* centers_rot;
+  const uint32_t* query_kth;
+  uint32_t* qflag;
+  void* bq;
+  float* thr;
+  const uint32_t* cb16;
+  const uint8_t* codes;
+  const uint32_t* list_offsets;
+  const uint32_t* list_sizes;
+  const float* row_term;
+  void* surv;
+  uint32_t* surv_cnt;
+  uint32_t surv_cap, spill_cap, n_probes, rot_dim, unit_rows;
+  float sc, c1, eps, alpha, cbmax, dmax, bound_max;
+  int is_ip, dbg, nch;
+  int64_t n_pairs;
+  unsigned long long* stats;
+  unsigned grid;
+};
+void pq4_filter(resources& res, const filter4_launch& l);
+
+}  // namespace cuvs_amd

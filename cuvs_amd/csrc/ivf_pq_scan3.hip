@@ -33,6 +33,7 @@
 #include "ivf_common.hpp"
 #include "pq_lut_math.hpp"
 #include "ivf_pq_scan3.hpp"
+#include "ivf_pq_filter_common.hpp"
 
 #include <cfloat>
 #include <cmath>
@@ -47,9 +48,7 @@ namespace {
 constexpr int kFThreads = 512;  // 8 waves: two per SIMD, up to 256 registers each (64 of them the B operands)
 constexpr int kFWaves   = kFThreads / 64;
 
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
 
 // ------------------------------------------------------------------ per-index tables
 __global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, float sc, uint32_t* __restrict__ cb16)
@@ -73,7 +72,7 @@ __device__ inline float wave_reduce_max_f32(float v)
 // the GEMM: x = -|d|^2 (1 - 2^-9) sc^2 / 2 split into two fp16 values (hi + lo = x to 2^-22; |x| <= 16384 by the choice
 // of sc), so that the accumulator of a (row, query) pair ends up holding sc^2 (r.d - |d|^2 (1 - 2^-9) / 2). One thread per row
 __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows, float sc,
-                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks)
+                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks, int fp32)
 {
   const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r  = min(r0, rows - 1);  // (no early exit: the wave reduction below needs every lane)
@@ -97,13 +96,12 @@ __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* 
   const float x     = -0.5f * sc * sc * (dn * (1.0f - 1.0f / 512.0f));
   const _Float16 hi = (_Float16)x;
   const _Float16 lo = (_Float16)(x - (float)hi);
-  if (r0 < rows) term[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+  // (pq_filter4_kernel takes the term as the fp32 initial value of its accumulators, pq_filter_kernel as two fp16 K elements)
+  if (r0 < rows)
+    term[r] = fp32 ? __float_as_uint(x) : ((uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16));
 }
 
 // ------------------------------------------------------------------ work units: (list, <= 64 pairs, row chunk)
-struct filter_unit {
-  uint32_t list, first, count, row0;
-};
 
 __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
                                                            const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
@@ -180,40 +178,6 @@ struct filter_params {
   // re-scored), and a full buffer raises *fail - the caller re-runs the batch's tail phase on the scan kernel
   uint32_t* fail;
 };
-
-// Largest value B with: exact score > bound  whenever  (row term - 2 dot16 / sc^2) > B   (L2; see the file header).
-// With T the real-valued score, S the score in the reference's arithmetic and A the filter's value
-//   S >= T (1 - eps) - alpha                          entry roundings of the LUT type, summation in the score type
-//   T >= A - 2^-9 (rn + dn) - mabs                    fp16 rounding of both GEMM operands: |x^ y^ - x y| <= 2^-10 |x y| +
-//                                                     2^-25 (|x| + |y|) per element (normal + subnormal range), fp32
-//                                                     accumulation; 2 |r.d| <= rn + dn
-// so S > bound is implied by  dn (1 - 2^-9) - 2 dot > (bound + alpha) / (1 - eps) + mabs - rn (1 - 2^-9). The right side
-// is evaluated in double and rounded up.
-__device__ inline float filter_threshold(const float bound, const float rn, const filter_params& a)
-{
-  const double mabs = 1.1920929e-07 /* 2^-23 */ / (double)a.sc *
-                      (sqrt((double)a.rot_dim * (double)rn) + (double)a.rot_dim * (double)a.cbmax);
-  const double b = ((double)bound + (double)a.alpha) * (1.0 + 2.0 * (double)a.eps) + mabs - (double)rn * (1.0 - 1.0 / 512.0);
-  float f = (float)b;
-  f += fabsf(f) * 2.4e-7f + 1e-37f;
-  return f;
-}
-
-// Inner product / cosine: T = -(q.c + q.d) (q the rotated query, c the list centre, d the row's decoded residual); the LUT
-// entries have both signs, so the roundings of S scale with sum |entry| <= |q| (|c| + |d|) instead of with T:
-//   S >= T - eps |q| (|c| + |d|) - alpha,   T >= A - 2^-17 |q| |c| - 2^-9.9 |q| |d| - mabs,   A = -(qc + dot16 / sc^2)
-// with qc = q.c in fp32 and |d| <= dmax (the largest decoded norm of the index). S > bound is implied by
-//   -dot16 / sc^2 > bound + qc + |q| ((eps + 2^-17) |c| + (eps + 2^-9) dmax) + mabs + alpha.
-__device__ inline float filter_threshold_ip(const float bound, const float qn, const float cn, const float qc, const filter_params& a)
-{
-  const double nq = sqrt((double)qn), nc = sqrt((double)cn);
-  const double mabs = 1.1920929e-07 /* 2^-23 */ / (double)a.sc * (sqrt((double)a.rot_dim) * nq + (double)a.rot_dim * (double)a.cbmax);
-  const double m = nq * (((double)a.eps + 7.63e-6) * nc + ((double)a.eps + 1.0 / 512.0) * (double)a.dmax);
-  const double b = (double)bound + (double)qc + (fabs((double)qc) + fabs((double)bound)) * 1e-6 + m + mabs + (double)a.alpha;
-  float f = (float)b;
-  f += fabsf(f) * 2.4e-7f + 1e-37f;
-  return f;
-}
 
 // NCH: 16-byte code chunks per row = pq_dim / 16 (pq_len 2: rot_dim = 32 NCH, 2 NCH MFMA K steps). Up to 4 chunks a
 // work unit holds two groups of 32 queries (B operands: 16 NCH registers) and the decoded rows are double-buffered;
@@ -1194,12 +1158,13 @@ bool pq3_supported(const ivf_pq_index& idx, int k)
          idx.rot_dim == 2 * idx.pq_dim && idx.codebook_kind == 0 && k <= 128;
 }
 
-pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
+pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_fp32)
 {
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   auto& c = idx.scan3;
-  if (c.codes_ptr != idx.codes.data() || c.rows != idx.padded_rows || c.size != idx.size || c.pq_ptr != idx.pq_centers.data()) {
+  if (c.codes_ptr != idx.codes.data() || c.rows != idx.padded_rows || c.size != idx.size || c.pq_ptr != idx.pq_centers.data() ||
+      c.term_fp32 != term_fp32) {
     std::vector<float> h = to_host(res, idx.pq_centers.data(), idx.pq_centers.size());
     float mx = 0.f;
     for (float v : h) mx = std::max(mx, std::fabs(v));
@@ -1215,12 +1180,13 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx)
     HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
     if (idx.padded_rows > 0)
       hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, idx.codes.data(),
-                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)idx.n_chunks);
+                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)idx.n_chunks, term_fp32 ? 1 : 0);
     const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
     float dn_max;
     memcpy(&dn_max, &mbits, 4);
     c.dmax = std::sqrt(dn_max) * 1.0001f;
     c.codes_ptr = idx.codes.data(); c.rows = idx.padded_rows; c.size = idx.size; c.pq_ptr = idx.pq_centers.data();
+    c.term_fp32 = term_fp32;
   }
   return pq3_tables{c.cb16.data(), c.row_term.data(), c.sc, c.cbmax, c.dmax};
 }
@@ -1238,10 +1204,12 @@ size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_ro
 
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
 {
-  const pq3_tables tb = pq3_prepare(res, idx);
+  const bool f4 = r.bq != nullptr;  // pq_filter4_kernel (one wave per SIMD, up to four query groups per unit)
+  const pq3_tables tb = pq3_prepare(res, idx, f4);
   profile_begin(res, "pq_scan_kernel");  // bench.py sums the scan phases under this name
   const int nch        = (int)idx.pq_dim / 16;          // 16-byte code chunks per row
-  const uint32_t group = nch <= 4 ? 64u : 32u;          // queries per work unit (two B-operand groups up to pq_dim 64)
+  // queries per work unit: B-operand groups of 32, four (two beyond pq_dim 64) with 512 registers per wave, else two (one)
+  const uint32_t group = f4 ? (nch <= 4 ? 128u : 64u) : (nch <= 4 ? 64u : 32u);
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
                      r.unit_rows, r.unit_off, group);
@@ -1270,6 +1238,19 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   else                      { f.eps = r.acc_half ? 0.11f : 0.07f; f.alpha = 64.0f / 32768.0f; f.bound_max = 30000.f; }
   if (r.is_ip && r.lut_mode == 2) f.eps = r.acc_half ? 0.18f : 0.14f;  // signed fp8: one value bit less (2^-3 per entry)
   const size_t fsmem = (size_t)nch * 16 * 1024 + 16;
+  if (f4) {
+    // pre-pass (B operands and thresholds of every tail pair), then the filter: ivf_pq_filter4.hip
+    filter4_launch l{};
+    l.units = units; l.n_units = f.n_units; l.xcd_ticket = r.xcd_ticket; l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off;
+    l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries; l.centers_rot = f.centers_rot;
+    l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = r.thr; l.cb16 = tb.cb16; l.codes = f.codes;
+    l.list_offsets = f.list_offsets; l.list_sizes = f.list_sizes; l.row_term = reinterpret_cast<const float*>(f.row_term);
+    l.surv = f.surv; l.surv_cnt = f.surv_cnt; l.surv_cap = f.surv_cap; l.spill_cap = f.spill_cap; l.n_probes = r.n_probes;
+    l.rot_dim = idx.rot_dim; l.unit_rows = r.unit_rows; l.sc = f.sc; l.c1 = f.c1; l.eps = f.eps; l.alpha = f.alpha;
+    l.cbmax = f.cbmax; l.dmax = f.dmax; l.bound_max = f.bound_max; l.is_ip = r.is_ip; l.dbg = r.filter_dbg; l.nch = nch;
+    l.n_pairs = r.nq * (int64_t)r.n_probes; l.stats = r.stats; l.grid = grid;
+    pq4_filter(res, l);
+  } else {
   auto launch_filter = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
     profile_begin(res, "pq_filter_kernel");
@@ -1281,9 +1262,6 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
       case 1:  launch_filter(pq_filter_kernel<4, 1>); break;
       case 2:  launch_filter(pq_filter_kernel<4, 2>); break;
       case 4:  launch_filter(pq_filter_kernel<4, 4>); break;
-      case 6:  launch_filter(pq_filter_kernel<4, 6>); break;
-      case 8:  launch_filter(pq_filter_kernel<4, 8>); break;
-      case 14: launch_filter(pq_filter_kernel<4, 14>); break;
       default: launch_filter(pq_filter_kernel<4, 0>); break;
     }
   } else {
@@ -1296,6 +1274,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
       case 7: launch_filter(pq_filter_kernel<7, 0>); break;
       default: launch_filter(pq_filter_kernel<8, 0>); break;
     }
+  }
   }
 
   rescore_params s{};

@@ -40,6 +40,8 @@ struct pq3_run {
   void* fb_items;                // work_item[n tail pairs]: single-pair items of the flagged queries
   const uint32_t* filter_bits;
   uint32_t* fail;                // IVF-Flat: device word raised when a buffer ran over (nullptr for IVF-PQ)
+  void* bq;                      // pq_filter4_kernel: [tail pairs] x rot_dim fp16 B operands (nullptr: pq_filter_kernel, two waves per SIMD)
+  float* thr;                    //   and [tail pairs] thresholds, both written by the pre-pass
   int filter_dbg;                // ablation bits of the filter kernel (timing only)
   unsigned long long* stats;     // optional device [8]
 };

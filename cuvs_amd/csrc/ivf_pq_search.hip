@@ -2057,6 +2057,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const uint32_t overflow_cap = use3 ? (res.tune.pq3_surv_cap > 0 ? (uint32_t)res.tune.pq3_surv_cap : (1u << 22)) : 0u;
   dev_buf<uint4> overflow3(res, (size_t)2 * overflow_cap);
   dev_buf<work_item> fb_items(res, use3 ? (size_t)n_pairs_max : 0);
+  const bool use_f4 = use3 && res.tune.pq_filter4 != 0;
+  dev_buf<uint4> bq3(res, use_f4 ? (size_t)n_pairs_max * (idx.rot_dim / 8) : 0);  // fp16 B operands of the tail pairs
+  dev_buf<float> thr3(res, use_f4 ? (size_t)n_pairs_max : 0);
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
@@ -2202,6 +2205,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
         r.filter_bits = filter_bits; r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
+        r.bq = use_f4 ? bq3.data() : nullptr; r.thr = thr3.data();
         dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 8 : 0);
         if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
         r.stats = st3.data(); r.filter_dbg = (a.dbg >> 16) & 15;  // CUVS_AMD_SCAN_DEBUG bits 16..19

@@ -48,7 +48,7 @@ def main():
     ds = torch.empty((args.batch, args.k), dtype=torch.float32, device=dev)
     firsts = {}
     keys = {"DBG": "CUVS_AMD_SCAN_DEBUG", "HEAD": "CUVS_AMD_PQ_HEAD_PROBES", "S2": "CUVS_AMD_PQ_SCAN2", "QCAP": "CUVS_AMD_PQ_QCAP",
-            "S3": "CUVS_AMD_PQ_SCAN3", "SCAP": "CUVS_AMD_PQ3_SURV_CAP"}
+            "S3": "CUVS_AMD_PQ_SCAN3", "SCAP": "CUVS_AMD_PQ3_SURV_CAP", "F4": "CUVS_AMD_PQ_FILTER4"}
     for v in args.variants:
         lut, acc = "f16", "f16"
         for name in keys.values():
@@ -84,14 +84,15 @@ def main():
         flt, rsc = C.c_double(0), C.c_double(0)
         lib().cuvsAmdProfileCollect(b"pq_filter_kernel", C.byref(flt))
         lib().cuvsAmdProfileCollect(b"pq_rescore_kernel", C.byref(rsc))
-        hd = C.c_double(0)
+        hd, bp = C.c_double(0), C.c_double(0)
         lib().cuvsAmdProfileCollect(b"pq_head_kernel", C.byref(hd))
+        lib().cuvsAmdProfileCollect(b"pq_bprep_kernel", C.byref(bp))
         cur = (nb.clone(), ds.clone())
         same = "ref" if first is None else str(bool(torch.equal(cur[0], first[0]) and torch.equal(cur[1], first[1])))
         if first is None:
             firsts[(lut, acc)] = cur
         print(f"{v:24s} search {ms:8.3f} ms  scan {scan.value / args.steps:8.3f} ms ({n // args.steps} launches)  "
-              f"filter {flt.value / args.steps:7.3f} rescore {rsc.value / args.steps:7.3f} head+handback {hd.value / args.steps:7.3f}  same_as_first={same}", flush=True)
+              f"bprep {bp.value / args.steps:6.3f} filter {flt.value / args.steps:7.3f} rescore {rsc.value / args.steps:7.3f} head+handback {hd.value / args.steps:7.3f}  same_as_first={same}", flush=True)
 
 
 if __name__ == "__main__":
