@@ -770,10 +770,10 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   uint32_t surv_cap        = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(np_max * 16, 1 << 22), 1 << 28) : 0u;
   if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
   const uint32_t overflow_cap = use3 ? (res.tune.pq3_surv_cap > 0 ? (uint32_t)res.tune.pq3_surv_cap : (1u << 22)) : 0u;
-  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)np_max * k : 0), qstate(res, use3 ? (size_t)4 * bs + 8 + pq3_grid(res) + 1 : 0);
+  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)np_max * k : 0), qstate(res, use3 ? (size_t)4 * bs + 8 + pq3_regions(res) + 1 : 0);
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0), tickets3(res, use3 ? 8 * 32 : 0);
   dev_buf<uint2> surv(res, surv_cap);
-  dev_buf<uint4> units3(res, max_units), overflow3(res, (size_t)2 * overflow_cap);
+  dev_buf<uint4> units3(res, 2 * max_units), overflow3(res, (size_t)2 * overflow_cap);
   trace.mark("buffers allocated");
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -876,8 +876,8 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
         r.qflag = qstate.data(); r.qcnt = qstate.data() + bs; r.counters = qstate.data() + 2 * bs;
         r.surv_cnt = qstate.data() + 2 * bs + 2;
-        r.ov_cnt = qstate.data() + 2 * bs + 4 + pq3_grid(res); r.ov_off = r.ov_cnt + bs;
-        r.fail = qstate.data() + 4 * bs + 8 + pq3_grid(res);
+        r.ov_cnt = qstate.data() + 2 * bs + 4 + pq3_regions(res); r.ov_off = r.ov_cnt + bs;
+        r.fail = qstate.data() + 4 * bs + 8 + pq3_regions(res);
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets3.data(); r.filter_bits = filter_bits;
         r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;

@@ -140,18 +140,21 @@ typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
 
 // TERM: L2 (the rows' terms are the accumulators' initial values); inner product starts from zero
 // DBG: ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs, 8 no code loads
-template <int NCH, bool TERM, int DBG>
+// STATS: the counters / cycle stamps of CUVS_AMD_SCAN_DEBUG=1024 (s_memtime is a scalar memory operation: in the subtile
+// loop it would make every wait on the gathers a wait for everything)
+template <int NCH, bool TERM, int DBG, bool STATS = false>
 __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_params a)
 {
   constexpr int NST = 2 * NCH;           // MFMA K steps
   constexpr int NGM = NCH <= 4 ? 4 : 2;  // groups of 32 queries per work unit
-  // LDS: K half 0 of every 16-subspace chunk at [0, NCH * 8 KiB), K half 1 at 64 KiB + the same (table_addr), the
-  // workgroup's survivor counter behind
-  constexpr uint32_t kHalf1 = 65536u, kFill = kHalf1 + NCH * 8u * 1024u;
+  // LDS: K half 0 of every 16-subspace chunk at [0, NCH * 8 KiB), K half 1 at 64 KiB + the same (table_addr)
+  constexpr uint32_t kHalf1 = 65536u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* wg_fill = reinterpret_cast<uint32_t*>(smem + kFill);
-  uint2* my_surv    = a.surv + (size_t)blockIdx.x * a.surv_cap;
-  if (threadIdx.x == 0) *wg_fill = 0u;
+  // survivors: every WAVE appends to a region of its own and counts in a scalar register - an LDS counter's returning
+  // atomic would sit behind the wave's gathers in the LDS queue (the queue returns in order: a full drain per survivor)
+  const uint32_t n_regions = gridDim.x * (kF4Threads / 64), region = blockIdx.x * (kF4Threads / 64) + (threadIdx.x >> 6);
+  uint2* my_surv  = a.surv + (size_t)region * a.surv_cap;
+  uint32_t s_fill = 0u;  // wave-uniform
   for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * 256u / 4u; i += kF4Threads) {
     // a.cb16: [subspace s][256 codes]; subspace s = 16 c + 8 half + j goes to half's table at (8 c + j) * 1 KiB
     const uint32_t s = i >> 6, half = (s >> 3) & 1u, slot = (s >> 4) * 8u + (s & 7u);
@@ -168,31 +171,51 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
   const uint32_t lane_code_off = ql * 16u + h * 8u, lane_term_off = h * 16u;  // byte offsets of this lane inside a subtile
 
   unsigned long long st_pairs = 0, st_surv = 0, st_sub = 0, st_slow = 0, st_units = 0, st_t[3] = {0, 0, 0};
-  for (;;) {
+  // ---- unit pipeline: the ticket of the NEXT unit is drawn when a unit starts and its descriptor is loaded a few
+  // subtiles later, so that a unit's prologue is ONE memory round trip (B operands, codes and terms together) instead
+  // of a chain of five (ticket -> descriptor -> list offsets -> operands -> codes)
+  uint32_t tk_v = 0u;  // lane 0: the pending ticket
+  uint4 d0 = {0u, 0u, 0u, 0u};
+  uint2 d1 = {0u, 0u};
+  bool desc_ok = false;
+  auto draw_ticket = [&]() {
+    if (lane == 0) tk_v = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
+  };
+  auto load_desc = [&]() {  // resolves the pending ticket; false: this XCD's share has run dry
     const uint32_t share0 = min(n_units, xcd * chunk), share_len = min(chunk, n_units - share0);
-    const filter_unit* share = a.units + share0;
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t >= share_len) {
+    const uint32_t t = __builtin_amdgcn_readfirstlane(tk_v);
+    desc_ok = t < share_len;
+    if (desc_ok) {
+      const filter_unit* up = a.units + share0 + t;
+      d0 = *reinterpret_cast<const uint4*>(up);
+      d1 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(up) + 16);
+    }
+  };
+  draw_ticket();
+  load_desc();
+  for (;;) {
+    while (!desc_ok) {  // a wave whose XCD has run dry moves on to the next XCD's share (equal in units, not in work)
       if (++hops == 8u) break;
       xcd = (xcd + 1u) & 7u;
-      continue;
+      draw_ticket();
+      load_desc();
     }
-    const uint4 uu = *reinterpret_cast<const uint4*>(share + t);
-    const uint32_t L = __builtin_amdgcn_readfirstlane(uu.x), first = __builtin_amdgcn_readfirstlane(uu.y),
-                   count = __builtin_amdgcn_readfirstlane(uu.z), row0 = __builtin_amdgcn_readfirstlane(uu.w);
-    const uint32_t base_row = __builtin_amdgcn_readfirstlane(a.list_offsets[L]), len = __builtin_amdgcn_readfirstlane(a.list_sizes[L]);
-    const uint32_t r_end = min(len, row0 + a.unit_rows);
+    if (!desc_ok) break;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(d0.y), count = __builtin_amdgcn_readfirstlane(d0.z),
+                   row0 = __builtin_amdgcn_readfirstlane(d0.w), base_row = __builtin_amdgcn_readfirstlane(d1.x),
+                   r_end = __builtin_amdgcn_readfirstlane(d1.y);
     const uint32_t u0 = row0 >> 5, u1 = (r_end + 31u) >> 5;
-    const unsigned long long t_unit = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long t_loop = 0ull, t_slow = 0ull;
+    const unsigned long long t_unit = STATS ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_loop = 0ull;
+    draw_ticket();  // the next unit's (resolved a few subtiles into this one)
+    bool desc_pending = true;
     // wave-uniform bases (lists start at multiples of 64 rows): subtile u of the list is half (u & 1) of 64-row group u / 2
     const char* code_base = reinterpret_cast<const char*>(a.codes) + (size_t)(base_row >> 6) * NCH * 1024;
     const char* term_base = reinterpret_cast<const char*>(a.row_term + base_row);
 
     auto load_codes = [&](const uint32_t u, uint2 (&cw)[NCH]) {
-      const uint32_t uc = min(u, u1 - 1u);  // (scalar; the subtiles past the end repeat the last one)
+      uint32_t uc = min(u, u1 - 1u);  // (scalar; the subtiles past the end repeat the last one)
+      if constexpr ((DBG & 64) != 0) uc = u0;  // ablation: cache-hot code loads
       const char* p = code_base + ((size_t)(uc >> 1) * NCH * 1024 + (uc & 1u) * 512u) + lane_code_off;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -202,25 +225,32 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
     };
     // the four gathers of K step st: lane (row, half) looks up the fp16x2 codebook entries of four of its row's codes
     uint32_t ad[4] = {h << 16, h << 16, h << 16, h << 16};  // table addresses: high word = K half, low word rewritten per gather
-    auto decode_step = [&](const uint2 (&cw)[NCH], const int st, u32x4_t (&av)[NST]) {
+    auto decode_addr = [&](const uint2 (&cw)[NCH], const int st) {
       uint32_t w = (st & 1) ? cw[st >> 1].y : cw[st >> 1].x;
       if constexpr ((DBG & 1) != 0) w = ql * 0x01010101u;  // ablation: every lane of a half in its own bank
-      constexpr uint32_t kNone = 0u;
-      const uint32_t slot0 = (8u * (st >> 1) + 4u * (st & 1)) * 1024u;
       table_addr<0>(ad[0], two, w);
       table_addr<1>(ad[1], two, w);
       table_addr<2>(ad[2], two, w);
       table_addr<3>(ad[3], two, w);
+    };
+    auto decode_gather = [&](const int st, u32x4_t (&av)[NST]) {
+      constexpr uint32_t kNone = 0u;
+      const uint32_t slot0 = (8u * (st >> 1) + 4u * (st & 1)) * 1024u;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if constexpr ((DBG & 2) != 0) av[st][e] = ad[e] + kNone;  // ablation: no gathers
         else av[st][e] = *reinterpret_cast<lds_u32_t*>(ad[e] + slot0 + e * 1024u);
       }
     };
+    auto decode_step = [&](const uint2 (&cw)[NCH], const int st, u32x4_t (&av)[NST]) {
+      decode_addr(cw, st);
+      decode_gather(st, av);
+    };
     // accumulator register i of a lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile: its initial value is that row's term
     auto load_term = [&](const uint32_t u, f32x16_t& tv) {
       if constexpr (!TERM) { tv = f32x16_t{}; return; }
-      const uint32_t uc = min(u, u1 - 1u);
+      uint32_t uc = min(u, u1 - 1u);
+      if constexpr ((DBG & 16) != 0) uc = u0;  // ablation: cache-hot term loads
       const char* p = term_base + (size_t)uc * 128u + lane_term_off;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -241,110 +271,137 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
         const uint32_t jc  = min(jj, count - 1u);
         const uint4* bp    = a.bq + ((size_t)(first - s_base + jc) * NST * 2 + h);
 #pragma unroll
+        for (int st = 0; st < NST; ++st) bop[g][st] = __builtin_bit_cast(f16x8_t, bp[st * 2]);
+        thr[g]    = jj < count ? a.thr[first - s_base + jc] : INFINITY;
+        pairid[g] = a.sorted_pairs[first + jc];
+      }
+      // code words: a ring of four subtiles (slot k % 4 holds subtile u0 + k), loaded four subtiles ahead of their decode;
+      // decoded rows, row terms and accumulators: two sets whose roles alternate from subtile to subtile
+      uint2 cw[4][NCH];
+      u32x4_t av[2][NST];
+      f32x16_t tv[2], acc[2][NG];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) load_codes(u0 + k, cw[k]);
+      load_term(u0, tv[0]);
+      load_term(u0 + 1, tv[1]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
         for (int st = 0; st < NST; ++st) {
-          bop[g][st] = __builtin_bit_cast(f16x8_t, bp[st * 2]);
           // the B operands live in the accumulation registers for the whole unit (MFMA reads them there directly); the
           // 256 architectural registers hold both accumulator sets, the row terms and everything the VALU touches
           asm volatile("" : "+a"(bop[g][st]));
         }
-        thr[g]    = jj < count ? a.thr[first - s_base + jc] : INFINITY;
-        pairid[g] = a.sorted_pairs[first + jc];
-      }
-      uint2 cw1[NCH], cw2[NCH], cw3[NCH];  // code words of subtiles u + 1, u + 2, u + 3
-      u32x4_t avA[NST], avB[NST];
-      f32x16_t tA, tB, accA[NG], accB[NG];
-      load_codes(u0, cw1);
-      load_codes(u0 + 1, cw2);
-      load_codes(u0 + 2, cw3);
-      load_term(u0, tA);
 #pragma unroll
-      for (int st = 0; st < NST; ++st) decode_step(cw1, st, avA);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) { cw1[c] = cw2[c]; cw2[c] = cw3[c]; }
-      load_codes(u0 + 3, cw3);
-      if (a.stats != nullptr) t_loop = __builtin_readcyclecounter();
+      for (int st = 0; st < NST; ++st) decode_step(cw[0], st, av[0]);
+      load_codes(u0 + 4, cw[0]);
+      if (STATS) t_loop = __builtin_readcyclecounter();
 
-      // ---- screen of a finished subtile: a pair survives when c1 * acc <= threshold, i.e. acc >= thr (c1 < 0)
-      auto screen = [&](const f32x16_t (&acc)[NG], const uint32_t u) {
-        bool any = false;
+      // ---- screen of a finished subtile: a pair survives when c1 * acc <= threshold, i.e. acc >= thr (c1 < 0). Part 1, per
+      // query group: the lanes whose 16 accumulator registers hold a survivor; part 2: the (rare) survivors themselves
+      unsigned long long gmask[NG];
+      auto screen_group = [&](const f32x16_t (&ac)[NG], const int g, const bool valid) {
+        float m = fmaxf(fmaxf(ac[g][0], ac[g][1]), ac[g][2]);  // (v_max3_f32 chains: this file is built with -fno-honor-nans)
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, ac[g][i]), ac[g][i + 1]);
+        m        = fmaxf(m, ac[g][15]);
+        gmask[g] = valid ? __ballot(m >= thr[g]) : 0ull;
+      };
+      auto screen_finish = [&](const f32x16_t (&ac)[NG], const uint32_t u, const bool valid) {
+        unsigned long long any_mask = 0ull;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) any_mask |= gmask[g];
+        if (STATS && valid) { st_pairs += 32u * count; st_sub += 1u; }
+        if (any_mask == 0ull) return;  // the usual case
+        // slow path (one or two survivors): the lanes that hold one collect their hits in a bit mask; from there on the wave
+        // works through them with scalar control - one lane writes, the fill count lives in a scalar register
+        if (STATS) st_slow += 1u;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-          float m = fmaxf(fmaxf(acc[g][0], acc[g][1]), acc[g][2]);  // (v_max3_f32 chains: this file is built with -fno-honor-nans)
+          if (gmask[g] == 0ull) continue;
+          uint32_t hits = 0u;
 #pragma unroll
-          for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, acc[g][i]), acc[g][i + 1]);
-          m   = fmaxf(m, acc[g][15]);
-          any = any | (m >= thr[g]);
-        }
-        if (a.stats != nullptr) { st_pairs += 32u * count; st_sub += 1u; }
-        if (__ballot(any) == 0ull) return;  // the usual case
-        // slow path (one or two survivors): a lane that holds one collects its hits in a bit mask and appends them one by
-        // one through the workgroup's LDS counter
-        if (a.stats != nullptr) st_slow += 1u;
-        const unsigned long long t_s0 = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
-        if (any) {
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            uint32_t hits = 0u;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) hits |= (acc[g][i] >= thr[g] ? 1u : 0u) << i;
-            while (hits != 0u) {
-              const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;
-              hits &= hits - 1u;
-              const uint32_t v = (u << 5) + (i & 3u) + 8u * (i >> 2) + 4u * h;
-              if (v >= len) continue;
-              const uint32_t pos = atomicAdd(wg_fill, 1u);  // LDS
-              if (pos < a.surv_cap) {
-                my_surv[pos] = make_uint2(pairid[g], base_row + v);
-              } else {
-                // this workgroup's region is full: the spill region shared by all (one global counter, rarely touched);
-                // only when that is full too is the query handed back to the LUT scan
-                const uint32_t sp = atomicAdd(a.surv_cnt + gridDim.x, 1u);
-                if (sp < a.spill_cap) a.surv[(size_t)gridDim.x * a.surv_cap + sp] = make_uint2(pairid[g], base_row + v);
-                else a.qflag[pairid[g] / a.n_probes] = 1u;
+          for (int i = 0; i < 16; ++i) hits |= (ac[g][i] >= thr[g] ? 1u : 0u) << i;
+          unsigned long long lm = gmask[g];
+          while (lm != 0ull) {
+            const uint32_t src = (uint32_t)__ffsll((long long)lm) - 1u;
+            lm &= lm - 1ull;
+            uint32_t hb        = __builtin_amdgcn_readlane(hits, src);
+            const uint32_t pid = __builtin_amdgcn_readlane(pairid[g], src);
+            while (hb != 0u) {
+              const uint32_t i = (uint32_t)__ffs((int)hb) - 1u;
+              hb &= hb - 1u;
+              const uint32_t v = (u << 5) + (i & 3u) + 8u * (i >> 2) + 4u * (src >> 5);  // lane = (query, K half -> rows + 4)
+              if (v >= r_end) continue;
+              if (s_fill < a.surv_cap) {
+                if (lane == 0u) my_surv[s_fill] = make_uint2(pid, base_row + v);
+              } else if (lane == 0u) {
+                // this wave's region is full: the spill region shared by all (one global counter, rarely touched); only
+                // when that is full too is the query handed back to the LUT scan
+                const uint32_t sp = atomicAdd(a.surv_cnt + n_regions, 1u);
+                if (sp < a.spill_cap) a.surv[(size_t)n_regions * a.surv_cap + sp] = make_uint2(pid, base_row + v);
+                else a.qflag[pid / a.n_probes] = 1u;
               }
-              if (a.stats != nullptr) st_surv += 1u;
+              s_fill += 1u;
+              if (STATS) st_surv += 1u;
             }
           }
         }
-        if (a.stats != nullptr) t_slow += __builtin_readcyclecounter() - t_s0;
       };
-      // ---- one subtile: K step by K step, the four gathers that decode that step of subtile u + 1, then the step's
-      // MFMAs of subtile u for every query group; the previous subtile's accumulators are screened after the second step
-      auto step = [&](const uint32_t u, u32x4_t (&cur)[NST], u32x4_t (&nxt)[NST], const f32x16_t& tcur, f32x16_t& tnxt,
-                      f32x16_t (&acc)[NG], const f32x16_t (&accp)[NG], const bool has_prev) {
-        load_term(u + 1, tnxt);
+      // ---- one subtile, phase P = (u - u0) % 4. A single wave issues in order: an MFMA that finds the matrix pipe busy holds
+      // up everything behind it, so the other work of a K step is placed BETWEEN the step's MFMAs (one per query group, 32
+      // cycles each): the four table addresses of the step's gathers for subtile u + 1, the gathers, and one more piece -
+      // the row terms of subtile u + 2 (into the registers the first step's MFMAs have just read), the screen of one query
+      // group of subtile u - 1, or the code words of subtile u + 5 (replacing those of u + 1 once they are decoded)
+      auto step = [&](auto p_tag, const uint32_t u) {
+        constexpr int P = decltype(p_tag)::value;
+        constexpr int C = P & 1, N = (P + 1) & 1, S = (P + 1) & 3;
+        const bool prev = u > u0 && u <= u1;  // subtile u - 1 exists (the loop runs whole groups of four: subtiles past the
+                                              // end repeat the last one and are not screened)
+        auto part_chunk = [](const int p) { return p + 1 < NST ? p + 1 : NST - 1; };  // screen part p runs in K step ...
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-          decode_step(cw1, st, nxt);  // (clamped to the last subtile: a harmless repeat at the end)
-          if (st == NST - 1) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) { cw1[c] = cw2[c]; cw2[c] = cw3[c]; }
-            load_codes(u + 4, cw3);
-          }
-          const f16x8_t aop = __builtin_bit_cast(f16x8_t, cur[st]);
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
+          const f16x8_t aop = __builtin_bit_cast(f16x8_t, av[C][st]);
+          auto mfma = [&](const int g) {
             if constexpr ((DBG & 4) != 0) {  // ablation: no MFMAs
-              if (st == 0) acc[g] = tcur;
-              acc[g][st & 15] += (float)aop[0] * (float)bop[g][st][0];
+              if (st == 0) acc[C][g] = tv[C];
+              acc[C][g][st & 15] += (float)aop[0] * (float)bop[g][st][0];
             } else {
-              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[g][st], st == 0 ? tcur : acc[g], 0, 0, 0);
+              acc[C][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, bop[g][st], st == 0 ? tv[C] : acc[C][g], 0, 0, 0);
             }
-          }
-          if (st == (NST > 1 ? 1 : 0) && has_prev) screen(accp, u - 1u);
+            __builtin_amdgcn_sched_barrier(0);
+          };
+          mfma(0);
+          if (st == 1 || NST == 1) load_term(u + 2, tv[C]);  // (every MFMA of step 0 has read tv[C] by now)
+          decode_addr(cw[S], st);
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (NG >= 2) mfma(1);
+          decode_gather(st, av[N]);  // (clamped to the last subtile: a harmless repeat at the end)
+          if (st == NST - 1) load_codes(u + 5, cw[S]);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (NG >= 3) mfma(2);
+#pragma unroll
+          for (int p = 0; p < NG; ++p)
+            if (part_chunk(p) == st) screen_group(acc[N], p, prev);
+          if (part_chunk(NG) == st) screen_finish(acc[N], u - 1u, prev);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (NG >= 4) mfma(3);
         }
       };
+      using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+      using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
       uint32_t u = u0;
-      for (; u + 1u < u1; u += 2u) {
-        step(u, avA, avB, tA, tB, accA, accB, u > u0);
-        step(u + 1u, avB, avA, tB, tA, accB, accA, true);
+      for (; u < u1; u += 4u) {
+        step(P0{}, u);
+        step(P1{}, u + 1u);
+        step(P2{}, u + 2u);
+        step(P3{}, u + 3u);
+        if (desc_pending && u >= u0 + 4u) { load_desc(); desc_pending = false; }  // (wave-uniform)
       }
-      if (u < u1) {
-        step(u, avA, avB, tA, tB, accA, accB, u > u0);
-        screen(accA, u);
-      } else {
-        screen(accB, u - 1u);
+      if (u == u1) {  // (otherwise the last real subtile was screened inside the loop)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) screen_group(acc[1], g, true);
+        screen_finish(acc[1], u - 1u, true);
       }
     };
     if (u0 < u1) {
@@ -359,22 +416,21 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
         else run(std::integral_constant<int, 1>{});
       }
     }
-    if (a.stats != nullptr) {
+    if (desc_pending) load_desc();
+    if (STATS) {
       const unsigned long long t_end = __builtin_readcyclecounter();
       st_t[0] += t_loop - t_unit;  // unit prologue (B operands, first decode)
       st_t[1] += t_end - t_loop;   // subtile loop
-      st_t[2] += t_slow;           // of which slow path
       st_units += 1u;
     }
   }
-  if (a.stats != nullptr) atomicAdd(&a.stats[1], st_surv);  // counted per lane
-  if (a.stats != nullptr && lane == 0) {
+  if (STATS && lane == 0) {
+    atomicAdd(&a.stats[1], st_surv);
     atomicAdd(&a.stats[0], st_pairs); atomicAdd(&a.stats[2], st_sub);
     atomicAdd(&a.stats[3], st_slow);  atomicAdd(&a.stats[4], st_t[0]); atomicAdd(&a.stats[5], st_t[1]);
     atomicAdd(&a.stats[6], st_t[2]);  atomicAdd(&a.stats[7], st_units);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(*wg_fill, a.surv_cap);
+  if (lane == 0u) a.surv_cnt[region] = min(s_fill, a.surv_cap);
 }
 
 }  // namespace
@@ -408,7 +464,7 @@ void pq4_filter(resources& res, const filter4_launch& l)
   g.list_sizes = l.list_sizes; g.row_term = l.row_term; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
   g.surv_cnt = l.surv_cnt; g.surv_cap = l.surv_cap; g.spill_cap = l.spill_cap; g.n_probes = l.n_probes; g.unit_rows = l.unit_rows;
   g.stats = l.stats;
-  const size_t fsmem = 65536 + (size_t)l.nch * 8 * 1024 + 16;  // the two K halves of the decode table lie 64 KiB apart
+  const size_t fsmem = 65536 + (size_t)l.nch * 8 * 1024;  // the two K halves of the decode table lie 64 KiB apart
   const bool term = l.row_term != nullptr;
   auto launch = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
@@ -423,7 +479,15 @@ void pq4_filter(resources& res, const filter4_launch& l)
       case 2:  launch(pq_filter4_kernel<4, true, 2>); break;
       case 4:  launch(pq_filter4_kernel<4, true, 4>); break;
       case 8:  launch(pq_filter4_kernel<4, true, 8>); break;
-      default: if (term) launch(pq_filter4_kernel<4, true, 0>); else launch(pq_filter4_kernel<4, false, 0>); break;
+      case 16: launch(pq_filter4_kernel<4, true, 16>); break;
+      case 64: launch(pq_filter4_kernel<4, true, 64>); break;
+      case 80: launch(pq_filter4_kernel<4, true, 80>); break;
+      case 81: launch(pq_filter4_kernel<4, true, 81>); break;
+      default:
+        if (l.stats != nullptr && term) launch(pq_filter4_kernel<4, true, 0, true>);
+        else if (term) launch(pq_filter4_kernel<4, true, 0>);
+        else launch(pq_filter4_kernel<4, false, 0>);
+        break;
     }
     return;
   }

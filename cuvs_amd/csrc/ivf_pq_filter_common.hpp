@@ -13,7 +13,9 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // work unit of the filter: a row chunk of a list x a block of the pairs probing it
 struct filter_unit {
-  uint32_t list, first, count, row0;
+  uint32_t list, first, count, row0;  // list, first pair (position in sorted_pairs) and number of pairs, first row of the chunk
+  uint32_t base_row, r_end;           // flat row of the list's first row; end of the chunk (row index inside the list)
+  uint32_t pad0, pad1;
 };
 
 // Largest value B with: exact score > bound  whenever  (row term - 2 dot16 / sc^2) > B   (L2; see the file header).

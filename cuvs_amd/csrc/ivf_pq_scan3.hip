@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __res
     if (i < n_lists) {
       const uint32_t np = pair_off[n_lists + i + 1] - pair_off[n_lists + i];  // tail labels: n_lists + list
       const uint32_t len = list_sizes[i];
-      v = (int)(((np + group - 1u) / group) * ((len + unit_rows - 1u) / unit_rows));
+      v = (int)(((np + group - 1u) / group) * ((len + unit_rows - 1u) / unit_rows));  // (empty lists: no units)
     }
     int total;
     const int excl = block_exclusive_scan(v, smem, &total);
@@ -130,17 +130,28 @@ __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __res
 }
 
 __global__ void fill_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
-                                  const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
-                                  const uint32_t* __restrict__ unit_off, filter_unit* __restrict__ units, uint32_t group)
+                                  const uint32_t* __restrict__ list_offsets, const uint32_t* __restrict__ list_sizes,
+                                  uint32_t unit_rows, const uint32_t* __restrict__ unit_off, filter_unit* __restrict__ units,
+                                  uint32_t group)
 {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= n_lists) return;
   const uint32_t b = pair_off[n_lists + L], e = pair_off[n_lists + L + 1], len = list_sizes[L];
   uint32_t w = unit_off[L];
-  if (b == e) return;
-  // row chunk major: the query groups of one chunk run next to each other and share its rows in L2
-  for (uint32_t r0 = 0; r0 < len; r0 += unit_rows)
-    for (uint32_t p = b; p < e; p += group) units[w++] = filter_unit{L, p, min(group, e - p), r0};
+  if (b == e || len == 0u) return;
+  // the list is cut into ceil(len / unit_rows) chunks of equal length (a multiple of 64 rows); row chunk major: the query
+  // groups of one chunk run next to each other and share its rows in L2
+  const uint32_t n_ch = (len + unit_rows - 1u) / unit_rows;
+  const uint32_t rows = ((len + n_ch - 1u) / n_ch + 63u) & ~63u;
+  const uint32_t base = list_offsets[L];
+  for (uint32_t c = 0; c < n_ch; ++c) {
+    const uint32_t r0 = c * rows, r1 = min(len, r0 + rows);
+    if (r0 >= r1) continue;  // (the rounding can leave the last chunk empty: its units stay zero-length)
+    for (uint32_t p = b; p < e; p += group) units[w++] = filter_unit{L, p, min(group, e - p), r0, base, r1, 0u, 0u};
+  }
+  // units the count reserved but the equal-length cut did not need: zero rows
+  const uint32_t w_end = unit_off[L] + ((e - b + group - 1u) / group) * n_ch;
+  for (; w < w_end; ++w) units[w] = filter_unit{L, b, 1u, 0u, base, 0u, 0u, 0u};
 }
 
 // ------------------------------------------------------------------ the filter
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
     // ---- rows of the unit, 32 at a time. Software pipeline of a wave: the code words are loaded two subtiles ahead;
     // the 32 gathers that decode subtile u + 1 are issued right after the MFMAs of subtile u and land while its
     // accumulators are screened; the other wave of the SIMD fills the matrix pipe meanwhile.
-    const uint32_t r_end = min(len, row0 + a.unit_rows);
+    const uint32_t r_end = __builtin_amdgcn_readfirstlane(share[t].r_end);
     const uint32_t u0 = row0 >> 5, u1 = (r_end + 31u) >> 5;
     auto load_codes = [&](const uint32_t u, uint2 (&cw)[NCH]) {
       const uint32_t fr = base_row + (min(u, u1 - 1u) << 5) + ql;  // this lane's row (padded rows of a group are readable)
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
             for (int i = 0; i < 16; ++i) {
               const uint32_t v = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
               const float x    = g == 0 ? acc0[i] : acc1[i];
-              if (x >= thr[g] && v < len) {
+              if (x >= thr[g] && v < r_end) {
                 const uint32_t pos = atomicAdd(wg_fill, 1u);  // LDS
                 if (pos < a.surv_cap) {
                   my_surv[pos] = make_uint2(pairid[g], base_row + v);
@@ -448,8 +459,9 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
 // ------------------------------------------------------------------ re-score
 struct rescore_params {
   const uint2* surv;         // regions of surv_cap entries, one per workgroup of the filter
-  const uint32_t* surv_cnt;  // [gridDim.x] fill of every region
+  const uint32_t* surv_cnt;  // [n_regions + 1] fill of every region, of the spill region
   uint32_t surv_cap, spill_cap;
+  uint32_t n_regions, sub;   // regions of the filter (one per workgroup or one per wave); regions per workgroup of this kernel
   const uint32_t* probes;  // [n_pairs] list of every pair
   const float* rot_queries;
   const float* centers_rot;
@@ -510,10 +522,12 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
     __syncthreads();
   }
   const float* __restrict__ pqc = a.cb_lds ? cb : a.pq_centers;
-  // region blockIdx.x of the filter's workgroups; the last one is the shared spill region
+  // regions [blockIdx.x * sub, + sub) of the filter; the last workgroup takes the shared spill region
   const bool spill = blockIdx.x + 1 == gridDim.x;
-  const uint32_t n = spill ? min(a.surv_cnt[blockIdx.x], a.spill_cap) : a.surv_cnt[blockIdx.x];
-  const uint2* region = a.surv + (size_t)blockIdx.x * a.surv_cap;
+  for (uint32_t j = 0; j < (spill ? 1u : a.sub); ++j) {
+  const uint32_t ri = spill ? a.n_regions : blockIdx.x * a.sub + j;
+  const uint32_t n = spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri];
+  const uint2* region = a.surv + (size_t)ri * a.surv_cap;
   for (uint32_t s = blockIdx.y * blockDim.x + threadIdx.x; s < n; s += gridDim.y * blockDim.x) {
     const uint2 sv = region[s];
     const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
     }
     const float score = ACC_HALF ? (float)ah : af;
     pool_append(a, q, pair, row, score);
+  }
   }
 }
 
@@ -674,8 +689,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params a)
 {
   const bool spill = blockIdx.x + 1 == gridDim.x;
-  const uint32_t n = spill ? min(a.surv_cnt[blockIdx.x], a.spill_cap) : a.surv_cnt[blockIdx.x];
-  const uint2* region = a.surv + (size_t)blockIdx.x * a.surv_cap;
+  const uint32_t ri = spill ? a.n_regions : blockIdx.x;
+  const uint32_t n = spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri];
+  const uint2* region = a.surv + (size_t)ri * a.surv_cap;
   for (uint32_t s = blockIdx.y * blockDim.x + threadIdx.x; s < n; s += gridDim.y * blockDim.x) {
     const uint2 sv = region[s];
     const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
@@ -1149,6 +1165,7 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ host side
 unsigned pq3_grid(const resources& res) { return (unsigned)std::max(8, res.num_cus / 8 * 8); }
+unsigned pq3_regions(const resources& res) { return 4u * pq3_grid(res); }  // pq_filter4_kernel: one survivor region per wave
 
 bool pq3_supported(const ivf_pq_index& idx, int k)
 {
@@ -1191,13 +1208,14 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_
   return pq3_tables{c.cb16.data(), c.row_term.data(), c.sc, c.cbmax, c.dmax};
 }
 
-size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows)
+size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows, bool filter4)
 {
   uint32_t max_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_len = std::max(max_len, v);
   // a unit is a chunk of 4096 rows of a list for one group of queries (the B operands and thresholds are built once per
   // unit: ~23 k cycles against ~250 k for the rows); a list is cut into at most 16 row chunks
-  const uint32_t ur = std::max<uint32_t>(4096u, (uint32_t)round_up((int64_t)(max_len + 15) / 16, 64));
+  // (pq_filter4_kernel: the prologue is one memory round trip; chunks of up to 8192 rows, lists cut into equal parts)
+  const uint32_t ur = std::max<uint32_t>(filter4 ? 8192u : 4096u, (uint32_t)round_up((int64_t)(max_len + 15) / 16, 64));
   *unit_rows = ur;
   return (size_t)16 * ((size_t)n_pairs / 32 + idx.n_lists + 1);
 }
@@ -1214,16 +1232,18 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
                      r.unit_rows, r.unit_off, group);
   hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
-                     idx.list_sizes.data(), r.unit_rows, r.unit_off, units, group);
+                     idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, group);
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket;
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = idx.centers_rot.data();
   f.cb16 = tb.cb16; f.codes = idx.codes.data(); f.list_offsets = idx.list_offsets.data(); f.list_sizes = idx.list_sizes.data();
   f.row_term = r.is_ip ? nullptr : tb.row_term; f.query_kth = r.query_kth; f.qflag = r.qflag;
   const unsigned grid = pq3_grid(res);
-  // three quarters of the survivor buffer are cut into one region per workgroup, the rest is the shared spill region
-  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / grid);
-  f.spill_cap = r.surv_cap - f.surv_cap * grid;
+  // three quarters of the survivor buffer are cut into one region per workgroup (pq_filter4_kernel: per wave), the rest is
+  // the shared spill region
+  const unsigned regions = f4 ? pq3_regions(res) : grid;
+  f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / regions);
+  f.spill_cap = r.surv_cap - f.surv_cap * regions;
   f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.unit_rows = r.unit_rows;
   f.sc = tb.sc; f.c1 = (r.is_ip ? -1.0f : -2.0f) / (tb.sc * tb.sc);
   f.cbmax = tb.cbmax; f.dmax = tb.dmax; f.is_ip = r.is_ip; f.stats = r.stats; f.dbg = r.filter_dbg;
@@ -1279,6 +1299,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
 
   rescore_params s{};
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
+  s.n_regions = regions; s.sub = regions / grid;
   s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = idx.codes.data();
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = idx.n_chunks;
@@ -1414,8 +1435,8 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes, r.unit_rows, r.unit_off,
                      group);
-  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(v.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes,
-                     r.unit_rows, r.unit_off, units, group);
+  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(v.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, v.n_lists, v.list_offsets,
+                     v.list_sizes, r.unit_rows, r.unit_off, units, group);
   const unsigned grid = pq3_grid(res);
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + v.n_lists; f.xcd_ticket = r.xcd_ticket;
@@ -1445,6 +1466,7 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   }
   rescore_params s{};
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes;
+  s.n_regions = grid; s.sub = 1;
   s.rot_queries = r.rot_queries; s.codes = v.data; s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt;
   s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head;
   s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices;

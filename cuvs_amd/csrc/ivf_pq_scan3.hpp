@@ -30,7 +30,7 @@ struct pq3_run {
   uint32_t overflow_cap;         //   binned by query
   uint32_t* ov_cnt;              // [nq] zeroed
   uint32_t* ov_off;              // [nq + 1]
-  uint32_t* surv_cnt;            // [pq3_grid() + 1] zeroed: fill of every workgroup's survivor region, of the spill region
+  uint32_t* surv_cnt;            // [pq3_regions() + 1] zeroed: fill of every survivor region, of the spill region
   void* surv;                    // [surv_cap] (pair, flat row), cut into one region per workgroup of the filter
   uint32_t surv_cap;
   void* units;                   // work units of the filter, pq3_max_units() entries
@@ -89,9 +89,10 @@ bool flat3_supported(uint32_t dim, int k);
 // launched) when the device has no room for the fp16 copy.
 bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r);
 
-unsigned pq3_grid(const resources& res);  // workgroups of the filter = survivor regions
+unsigned pq3_grid(const resources& res);     // workgroups of the filter
+unsigned pq3_regions(const resources& res);  // survivor regions (at most: one per wave of pq_filter4_kernel)
 bool pq3_supported(const ivf_pq_index& idx, int k);
-size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows);
+size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows, bool filter4);
 // filter + re-score + fallback work items of the flagged queries (the caller launches the LUT scan on them)
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r);
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i);

@@ -2047,13 +2047,13 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const bool metric_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
   const bool use3 = head > 0 && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0;
   uint32_t unit_rows = 0;
-  const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows) : 0;
+  const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows, res.tune.pq_filter4 != 0) : 0;
   uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 16, 1 << 22), 1 << 28) : 0u;
   if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
-  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)4 * bs_alloc + 8 + pq3_grid(res) : 0);
+  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)4 * bs_alloc + 8 + pq3_regions(res) : 0);
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0);
   dev_buf<uint2> surv(res, surv_cap);
-  dev_buf<uint4> units3(res, max_units);
+  dev_buf<uint4> units3(res, 2 * max_units);  // 32-byte unit descriptors
   const uint32_t overflow_cap = use3 ? (res.tune.pq3_surv_cap > 0 ? (uint32_t)res.tune.pq3_surv_cap : (1u << 22)) : 0u;
   dev_buf<uint4> overflow3(res, (size_t)2 * overflow_cap);
   dev_buf<work_item> fb_items(res, use3 ? (size_t)n_pairs_max : 0);
@@ -2201,14 +2201,14 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
         r.qflag = qstate.data(); r.qcnt = qstate.data() + bs_alloc; r.counters = qstate.data() + 2 * bs_alloc;
         r.surv_cnt = qstate.data() + 2 * bs_alloc + 2;
-        r.ov_cnt = qstate.data() + 2 * bs_alloc + 4 + pq3_grid(res); r.ov_off = r.ov_cnt + bs_alloc;
+        r.ov_cnt = qstate.data() + 2 * bs_alloc + 4 + pq3_regions(res); r.ov_off = r.ov_cnt + bs_alloc;
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
         r.filter_bits = filter_bits; r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
         r.bq = use_f4 ? bq3.data() : nullptr; r.thr = thr3.data();
         dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 8 : 0);
         if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
-        r.stats = st3.data(); r.filter_dbg = (a.dbg >> 16) & 15;  // CUVS_AMD_SCAN_DEBUG bits 16..19
+        r.stats = st3.data(); r.filter_dbg = (a.dbg >> 16) & 255;  // CUVS_AMD_SCAN_DEBUG bits 16..23
         pq3_tail(res, idx, r);
         // queries the filter could not serve (no finite bound, operands beyond fp16, full pool): LUT scan of their pairs
         a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters;
