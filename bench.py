@@ -8,7 +8,7 @@ Index build, ground truth and the CPU baseline are outside the timed region; que
 
   python bench.py                      # N=1: headline + the other LUT/score precisions + C1/C2/C4 lines + live PMC passes
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
-                                       # list-sharded index (list L on rank L % N), every step ends in ONE native RCCL
+                                       # list-sharded index (lists dealt to the ranks by size), every step ends in ONE native RCCL
                                        # all-gather of the per-rank [Q, k] blocks (include/cuvs_amd/shard.h)
   [torchrun ...] bench.py --config c5 [--rows R]
                                        # BASELINE configs[4]: IVF-PQ rows x 96 int8 (default 1B), list shards dealt by
@@ -56,7 +56,7 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def gen_rows(n, dim, seed, device, chunk=1 << 22, latent=32, n_modes=65536, row0=0, out=None):
+def gen_rows(n, dim, seed, device, chunk=1 << 22, latent=32, n_modes=65536, row0=0, out=None, spread=0.35):
     """Synthetic corpus with low intrinsic dimension (a `latent`-d Gaussian mixture embedded in R^dim + small noise):
     isotropic dim-d clusters would make every neighbour equidistant and recall meaningless. Rows are
     generated chunk by chunk from (seed, chunk index), so any row range can be produced on any rank."""
@@ -70,7 +70,7 @@ def gen_rows(n, dim, seed, device, chunk=1 << 22, latent=32, n_modes=65536, row0
         c = min(chunk, n - r0)
         g2 = torch.Generator(device=device).manual_seed(seed * 1000003 + (row0 + r0) // chunk)
         which = torch.randint(0, n_modes, (c,), generator=g2, device=device)
-        z = modes[which] + 0.35 * torch.randn(c, latent, generator=g2, device=device)
+        z = modes[which] + spread * torch.randn(c, latent, generator=g2, device=device)
         out[r0:r0 + c] = (z @ A + 0.03 * torch.randn(c, dim, generator=g2, device=device)).to(out.dtype)
     return out
 
@@ -226,28 +226,56 @@ def run_c5(args):
         counts = t.cpu().numpy().astype(np.uint64)
     owners = sh.deal_lists(counts, world)
     sh.set_list_owners(index, owners, rank, world)
-    # pass 2: every rank sees every chunk and keeps the rows of its own lists
+    mine = int(counts[owners == rank].sum())
+    ratio = max(1, args.refine_ratio)
+    owners_t = torch.from_numpy(owners.astype(np.int64)).to(dev)
+    # pass 2: every rank sees every chunk and keeps the rows of its own lists: their codes in the index - under LOCAL ids,
+    # the position in own_rows - and, for the refinement, the int8 rows themselves with the map local id -> global row
+    own_rows = torch.empty((mine if ratio > 1 else 0, dim), dtype=torch.int8, device=dev)
+    gmap = torch.empty(mine if ratio > 1 else 0, dtype=torch.int64, device=dev)
+    n_local = 0
     for c in range(n_chunks):
         r0 = c * chunk
         x = first if c == 0 else gen_int8_rows(min(chunk, rows - r0), dim, 1234, dev, row0=r0)
-        sh.extend(index, x, torch.arange(r0, r0 + x.shape[0], dtype=torch.int64, device=dev), resources=res)
+        if ratio > 1:
+            own = torch.nonzero(owners_t[sh.row_labels(index, x, resources=res)] == rank).flatten()
+            xo = x[own]
+            own_rows[n_local:n_local + xo.shape[0]] = xo
+            gmap[n_local:n_local + xo.shape[0]] = own + r0
+            sh.extend(index, xo, torch.arange(n_local, n_local + xo.shape[0], dtype=torch.int64, device=dev), resources=res)
+            n_local += xo.shape[0]
+            del xo, own
+        else:
+            sh.extend(index, x, torch.arange(r0, r0 + x.shape[0], dtype=torch.int64, device=dev), resources=res)
         del x
+    assert ratio == 1 or n_local == mine, (n_local, mine)
     del first, train
     sh.attach_comm(index, comm)
     res.sync()
     build_s = time.time() - t0
-    mine = int(counts[owners == rank].sum())
     log(f"C5: built {rows} x {dim} int8 in {build_s:.1f}s; this rank holds {len(index)} rows ({mine} by the histogram)")
     queries = torch.cat([gen_int8_rows(args.batch, dim, 4321 + r, dev) for r in range(world)])
     k = args.k
+    kk = k * ratio
     sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
                              max_internal_batch_size=nq_total)
+    pq_i = torch.empty((nq_total, kk), dtype=torch.int64, device=dev)
+    pq_d = torch.empty((nq_total, kk), dtype=torch.float32, device=dev)
     cand_i = torch.empty((nq_total, k), dtype=torch.int64, device=dev)
     cand_d = torch.empty((nq_total, k), dtype=torch.float32, device=dev)
     out_i, out_d = torch.empty_like(cand_i), torch.empty_like(cand_d)
+    from cuvs_amd.neighbors import refine
+    INVALID = torch.iinfo(torch.int64).max
 
     def step():
-        ivf_pq.search(sp, index, queries, k, neighbors=cand_i, distances=cand_d, resources=res)
+        if ratio > 1:
+            # this rank's kk candidates of every query (local ids), re-ranked exactly against its own int8 rows, then global ids
+            ivf_pq.search(sp, index, queries, kk, neighbors=pq_i, distances=pq_d, resources=res)
+            refine(own_rows, queries, pq_i, indices=cand_i, distances=cand_d, metric="sqeuclidean", resources=res)
+            ok = cand_i != INVALID
+            cand_i.copy_(torch.where(ok, gmap[torch.where(ok, cand_i, 0)], cand_i))
+        else:
+            ivf_pq.search(sp, index, queries, k, neighbors=cand_i, distances=cand_d, resources=res)
         comm.all_gather_topk(cand_d, cand_i, out=(out_d, out_i), resources=res)
 
     for _ in range(args.warmup):
@@ -301,8 +329,9 @@ def run_c5(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"u8 codes, {args.lut} LUT, {args.acc} score", "data": "synthetic",
             "config": {"workload": f"C5 IVF-PQ {rows}x96 int8, pq_dim={args.pq_dim} pq_bits=8 n_lists={n_lists} n_probes={args.n_probes} "
-                                   f"batch={args.batch} per GPU k={k}, no refinement",
+                                   f"batch={args.batch} per GPU k={k}, " + (f"shard-local refinement of {kk} candidates per query and rank" if ratio > 1 else "no refinement"),
                        "parallelism": f"list shards x{world} dealt by size (LPT), RCCL all-gather of the per-rank top-k",
+                       "refine_ratio": ratio,
                        "rows_on_rank0": len(index), "build_seconds": round(build_s, 1)},
             f"recall_at_{k}": None if recall is None else round(recall, 4),
             "scan_kernel_ms_per_step": round(scan_ms.value / max(args.steps, 1), 3), "scan_launches_per_step": n_launch // max(args.steps, 1),
@@ -574,6 +603,13 @@ def main():
         comm = (ivf_pq_sharded.ShardComm.from_torch(res) if world > 1
                 else ivf_pq_sharded.ShardComm(0, 1, ivf_pq_sharded.ShardComm.unique_id(), res))
         index = ivf_pq_sharded.build(ip, data, rank, world, resources=res)
+        # lists dealt to the ranks by size (greedy LPT over the list histogram): every rank holds the whole synthetic corpus
+        # here, so each computes the same histogram and the same table - no communication
+        hist = np.zeros(args.n_lists, np.uint64)
+        for r0 in range(0, args.rows, 1 << 24):
+            ivf_pq_sharded.list_histogram(index, data[r0:min(args.rows, r0 + (1 << 24))], hist, resources=res)
+        owners = ivf_pq_sharded.deal_lists(hist, world)
+        ivf_pq_sharded.set_list_owners(index, owners, rank, world)
         step_rows = 1 << 24
         for r0 in range(0, args.rows, step_rows):
             r1 = min(args.rows, r0 + step_rows)
@@ -709,7 +745,8 @@ def main():
     sizes = index.list_sizes.to(torch.int64)
     centers = index.centers
     cn = (centers * centers).sum(1)
-    owned = (torch.arange(args.n_lists, device=dev) % world) == rank
+    owned = ((torch.from_numpy(owners.astype(np.int64)).to(dev) == rank) if sharded
+             else torch.ones(args.n_lists, dtype=torch.bool, device=dev))
     probe_bytes = 0
     tail_pairs = torch.zeros(args.n_lists, dtype=torch.int64, device=dev)
     all_pairs = torch.zeros(args.n_lists, dtype=torch.int64, device=dev)
@@ -880,10 +917,65 @@ def main():
             sharded_line = {"config": "sharded one-rank", "error": repr(e)[:300]}
         torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ the headline on a second, LESS PRUNABLE corpus
+    # (untimed region). The headline corpus has 65536 tight modes in a 32-d latent space: ~1e-4 of the (row, query) pairs of a
+    # probed list survive the screen. Real corpora (deep-100M, datasets.yaml) are less clustered: here the same search on
+    # 4096 wide modes in a 64-d latent space, with the survivors per pair of both corpora (CUVS_AMD_SCAN_DEBUG=1024 counters).
+    def survivors_per_pair(idx_, q_):
+        os.environ["CUVS_AMD_SCAN_DEBUG"] = "1024"
+        r_st = cuvs_amd.common.Resources()
+        del os.environ["CUVS_AMD_SCAN_DEBUG"]
+        sp_ = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                                  max_internal_batch_size=nq_total)
+        old_err = os.dup(2)  # the debug handle prints its counters to stderr: keep the log readable
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 2)
+        try:
+            ivf_pq.search(sp_, idx_, q_, kk, neighbors=cand_i, distances=cand_d, resources=r_st)
+            r_st.sync()
+        finally:
+            os.dup2(old_err, 2); os.close(devnull); os.close(old_err)
+        st = (C.c_uint64 * 4)()
+        lib().cuvsAmdIvfPqLastFilterStats(st)
+        return {"pairs_screened": int(st[0]), "survivors": int(st[1]), "survivors_per_pair": (st[1] / st[0]) if st[0] else None,
+                "subtiles_decoded": int(st[2]), "work_units": int(st[3])}
+
+    corpus_variants = []
+    if rank == 0 and world == 1 and not args.no_variants and not sharded:
+        try:
+            c0 = survivors_per_pair(index, queries)
+            corpus_variants.append({"corpus": "headline: 65536 modes, 32-d latent, spread 0.35", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                                    "recall_at_10": round(recall, 4), "kernel_ms_per_step": round(scan_ms / max(args.steps, 1), 3),
+                                    "phase_ms_per_step": headline_phase_ms, **c0})
+            del index, data
+            torch.cuda.empty_cache()
+            data = gen_rows(args.rows, args.dim, seed=1234, device=dev, latent=64, n_modes=4096, spread=0.7)
+            queries2 = gen_rows(args.batch, args.dim, seed=4321, device=dev, latent=64, n_modes=4096, spread=0.7)
+            t0 = time.time()
+            index = ivf_pq.build(ip, data, resources=res)
+            res.sync()
+            b2 = time.time() - t0
+            q_save, queries = queries, queries2  # make_step() closes over `queries`, `data`, `index`
+            e2, s2, n2, _ = timed(make_step(args.lut, args.acc), 5, 2)
+            ph2 = {k_: round(v_, 3) for k_, v_ in phase_ms.items()}
+            truth2 = exact_topk_fp64(data, queries2[:ng], args.k).cpu().numpy()
+            rec2 = recall_of(neighbors[:ng].cpu().numpy(), truth2)
+            c1 = survivors_per_pair(index, queries2)
+            corpus_variants.append({"corpus": "4096 modes, 64-d latent, spread 0.7 (wide, overlapping clusters)", "ms_per_step": round(e2 / 5 * 1e3, 3),
+                                    "qps": round(args.batch / (e2 / 5), 1), "recall_at_10": round(rec2, 4),
+                                    "kernel_ms_per_step": round(s2 / 5, 3), "phase_ms_per_step": ph2, "build_seconds": round(b2, 1), **c1})
+            queries = q_save
+        except Exception as e:
+            corpus_variants.append({"corpus": "second corpus", "error": repr(e)[:300]})
+        torch.cuda.empty_cache()
+
     # ------------------------------------------------------------------ C1 / C2 / C4 lines + CPU baseline (rank 0, N=1)
     extra, cpu = [], None
     if rank == 0 and world == 1:
-        del index, data
+        try:
+            del index, data
+        except NameError:  # (the second-corpus block failed between dropping and rebuilding them)
+            pass
         torch.cuda.empty_cache()
         c1_x = c1_q = None
         if not args.no_extras:
@@ -934,12 +1026,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"IVF-PQ {args.rows}x{args.dim} fp32, pq_dim={args.pq_dim} pq_bits=8 "
                                    f"n_lists={args.n_lists} n_probes={args.n_probes} batch={args.batch} k={args.k}",
-                       "parallelism": (f"list-sharded index (list L on rank L % {world}), {world} x {args.batch} queries per "
+                       "parallelism": (f"list-sharded index (lists dealt to the {world} ranks by size, LPT), {world} x {args.batch} queries per "
                                        f"step, one native RCCL all-gather of the [Q,k] blocks per step") if sharded
                                       else "single GPU",
                        "lut_dtype": args.lut, "internal_distance_dtype": args.acc, "refine_ratio": args.refine_ratio,
                        "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants,
-                       "sharded_one_rank": sharded_line},
+                       "sharded_one_rank": sharded_line, "corpus_variants": corpus_variants},
             "recall_at_10": round(recall, 4),
             "scan3_equals_lut_scan": scan3_equals_lut_scan,
             "roofline": roofline,

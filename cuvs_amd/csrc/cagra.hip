@@ -425,6 +425,7 @@ struct search_args {
   float* out_dist;
   int64_t n, dim;
   uint32_t degree, itopk, width, max_iter, min_iter, k, np2, hash_bits, reset_interval;
+  uint32_t n_distill;  // num_random_samplings: random candidates per seed slot, the nearest one is kept (device_common_jit.cuh:60-83)
   uint64_t rand_xor_mask;
   int is_ip, idx64;    // is_ip: 0 L2, 1 inner product, 2 cosine (1 - q.x / (|q| |x|), |x| from `norms`)
   const float* norms;  // [n] canonical |x| (cosine)
@@ -567,18 +568,39 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
   float qn = 1.f;  // cosine: canonical |q| (64 strided fma partial sums + butterfly, as row_norms)
   if (a.is_ip == 2) qn = wave_query_norm(qf, a.dim, lane);
 
-  // ---- seeds: itopk pseudo-random nodes (device_common_jit.cuh:36-104: xorshift64(gid ^ mask) % n)
-  for (uint32_t i = lane; i < a.itopk; i += 64) {
-    uint64_t gid  = (uint64_t)qi * a.itopk + i;
-    uint32_t node = (uint32_t)(xorshift64(gid ^ a.rand_xor_mask) % (uint64_t)a.n);
-    idx[i]        = hash_insert(table, a.hash_bits, node) ? node : kInvalidNode;
+  // ---- seeds (compute_distance_to_random_nodes, device_common_jit.cuh:36-104; call site search_single_cta_jit.cuh:157-171):
+  // every slot of the result buffer - itopk + search_width * degree of them - draws num_random_samplings pseudo-random
+  // nodes, gid = slot + n_slots * j -> xorshift64(gid ^ rand_xor_mask) % n, and keeps the nearest (the first on ties); a
+  // winner that is already in the visited table is dropped. The stream does not depend on the query (as in the reference).
+  const uint32_t n_cand = a.width * a.degree;
+  const uint32_t n_seed = a.itopk + n_cand;
+  uint32_t* tkeys   = table + hsize;
+  uint32_t* tidx    = tkeys + n_seed;
+  uint32_t* parents = tidx + n_seed;  // [width]
+  uint32_t n_dist = 0u;
+  for (uint32_t j = 0; j < a.n_distill; ++j) {
+    for (uint32_t i = lane; i < n_seed; i += 64) {
+      const uint64_t gid = (uint64_t)i + (uint64_t)n_seed * j;
+      tidx[i]            = (uint32_t)(xorshift64(gid ^ a.rand_xor_mask) % (uint64_t)a.n);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    n_dist += team_distances<T>(data, a.dim, qf, tkeys, tidx, 0, n_seed, a.is_ip, lane, a.norms, qn);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < n_seed; i += 64)
+      if (tkeys[i] < keys[i]) { keys[i] = tkeys[i]; idx[i] = tidx[i]; }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  uint32_t n_dist = team_distances<T>(data, a.dim, qf, keys, idx, 0, a.itopk, a.is_ip, lane, a.norms, qn);
+  for (uint32_t i = lane; i < n_seed; i += 64) {
+    const uint32_t node = idx[i];
+    if (node != kInvalidNode && !hash_insert(table, a.hash_bits, node)) { idx[i] = kInvalidNode; keys[i] = 0xffffffffu; }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   uint32_t n_rows_read = 0u;  // graph rows read (parents expanded)
 
-  const uint32_t n_cand = a.width * a.degree;
   uint32_t iter         = 0;
   while (true) {
     wave_bitonic_sort<uint32_t>(keys, idx, (int)a.np2);
@@ -595,7 +617,6 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
     }
     // ---- pick up to `width` best entries that were not parents yet (pickup_next_parents)
     uint32_t n_parents = 0;
-    uint32_t parents[8];
     for (uint32_t base = 0; base < a.itopk && n_parents < a.width; base += 64) {
       const uint32_t i = base + lane;
       const bool cand  = i < a.itopk && idx[i] != kInvalidNode && !(idx[i] & kParentFlag);
@@ -604,8 +625,8 @@ __global__ __launch_bounds__(64) void cagra_search_kernel(search_args a)
         const int src = (int)__ffsll((long long)m) - 1;
         m &= m - 1ull;
         const uint32_t pos = base + src;
-        parents[n_parents++] = idx[pos];
-        if (lane == 0) idx[pos] |= kParentFlag;
+        if (lane == 0) { parents[n_parents] = idx[pos]; idx[pos] |= kParentFlag; }
+        ++n_parents;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -727,6 +748,7 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
   uint32_t* mkeys  = trav + tsize;             // merge area [merge_np2]
   uint32_t* midx   = mkeys + m.merge_np2;
   uint32_t* wbase  = midx + m.merge_np2 + (size_t)wave * (2 * np2 + vsize);
+  uint32_t* m_tmp  = midx + m.merge_np2 + (size_t)W * (2 * np2 + vsize);  // seed candidates: 2 * degree words per wave
   uint32_t* keys   = wbase;                    // this wave's list: [np2] = 32 top + degree candidates
   uint32_t* idx    = keys + np2;
   uint32_t* vis    = idx + np2;                // this wave's visited table (rebuilt every iteration)
@@ -741,15 +763,35 @@ __global__ __launch_bounds__(1024) void cagra_search_multi_kernel(mw_args m)
   float qn = 1.f;
   if (a.is_ip == 2) qn = wave_query_norm(qf, a.dim, lane);
 
-  // ---- seeds: 32 pseudo-random nodes per wave, a different stream per (query, wave) (device_common_jit.cuh:72)
-  if (lane < (int)kMwTopk) {
-    const uint64_t gid  = ((uint64_t)qi * W + wave) * kMwTopk + lane;
-    const uint32_t node = (uint32_t)(xorshift64(gid ^ a.rand_xor_mask) % (uint64_t)a.n);
-    idx[lane]           = hash_insert(vis, m.vis_bits, node) ? node : kInvalidNode;
+  // ---- seeds (search_multi_cta_jit.cuh:134-148): `degree` slots per wave, num_random_samplings candidates per slot with
+  // gid = wave + W * (slot + degree * j), the nearest kept; a winner already in this wave's visited table is dropped
+  uint32_t n_dist = 0u;
+  {
+    const uint32_t n_seed = min(a.degree, np2);
+    uint32_t* tkeys = m_tmp + (size_t)wave * 2 * a.degree;
+    uint32_t* tidx  = tkeys + a.degree;
+    for (uint32_t j = 0; j < a.n_distill; ++j) {
+      for (uint32_t i = lane; i < n_seed; i += 64) {
+        const uint64_t gid = (uint64_t)wave + (uint64_t)W * ((uint64_t)i + (uint64_t)n_seed * j);
+        tidx[i]            = (uint32_t)(xorshift64(gid ^ a.rand_xor_mask) % (uint64_t)a.n);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      n_dist += team_distances<T>(data, a.dim, qf, tkeys, tidx, 0, n_seed, a.is_ip, lane, a.norms, qn);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < n_seed; i += 64)
+        if (tkeys[i] < keys[i]) { keys[i] = tkeys[i]; idx[i] = tidx[i]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < n_seed; i += 64) {
+      const uint32_t node = idx[i];
+      if (node != kInvalidNode && !hash_insert(vis, m.vis_bits, node)) { idx[i] = kInvalidNode; keys[i] = 0xffffffffu; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  uint32_t n_dist = team_distances<T>(data, a.dim, qf, keys, idx, 0, kMwTopk, a.is_ip, lane, a.norms, qn);
   uint32_t n_rows_read = 0u;
 
   uint32_t iter = 0;
@@ -1029,7 +1071,8 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
   search_args a;
   a.data = idx.data; a.graph = idx.graph.data(); a.queries = queries; a.filter_bits = filter_bits;
   a.out_idx = out_idx; a.out_dist = out_dist; a.n = idx.n; a.dim = idx.dim; a.degree = idx.degree;
-  a.width = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, p.search_width));
+  a.width = (uint32_t)std::max<size_t>(1, p.search_width);
+  a.n_distill = (uint32_t)std::max<uint32_t>(1u, p.num_random_samplings);
   // share of rows the bitset removes: the reference derives it from the bitset's population count when the caller
   // does not give one (cagra.cuh:374-381; the C search params have no such field) and widens the multi-CTA itopk
   float filtering_rate = 0.f;
@@ -1093,7 +1136,7 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
     while ((1u << m.trav_bits) < 2 * W * (m.s.max_iter + kMwTopk)) ++m.trav_bits;
     m.merge_np2 = (uint32_t)next_pow2((int)(W * kMwTopk));
     size_t msmem = (size_t)((idx.dim + 3) & ~int64_t(3)) * 4 + ((size_t)4 << m.trav_bits) + (size_t)m.merge_np2 * 8 +
-                   (size_t)W * (2 * m.np2_local + (1u << m.vis_bits)) * 4;
+                   (size_t)W * (2 * m.np2_local + (1u << m.vis_bits)) * 4 + (size_t)W * 2 * idx.degree * 4;
     CUVS_EXPECTS(msmem <= 160 * 1024, "cagra::search: dim too large for the multi-wave LDS layout");
     switch (idx.dtype) {
       case elem_t::f32: launch_search_multi<float>(res, m, nq, msmem); break;
@@ -1103,7 +1146,8 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
     }
     return;
   }
-  size_t smem = (size_t)((idx.dim + 3) & ~int64_t(3)) * 4 + (size_t)a.np2 * 8 + ((size_t)4 << bits);
+  size_t smem = (size_t)((idx.dim + 3) & ~int64_t(3)) * 4 + (size_t)a.np2 * 8 + ((size_t)4 << bits) +
+                (size_t)(2 * (itopk + a.width * idx.degree) + a.width) * 4;  // + seed candidates, parent list
   CUVS_EXPECTS(smem <= 160 * 1024, "cagra::search: dim/itopk too large for LDS");
   switch (idx.dtype) {
     case elem_t::f32: launch_search<float>(res, a, nq, smem); break;

@@ -57,8 +57,11 @@ __device__ inline uint32_t main_cluster_candidate(int64_t i, int64_t n, const ui
                                                   uint32_t shift)
 {
   int64_t j = (i + (int64_t)97 * shift) % n;
-  while (label[j] != main_label) j = (j + 97) % n;
-  return (uint32_t)j;
+  // the stride-97 walk visits one residue class only when 97 divides n: after a full turn (n / 97 + 1 steps) the walk
+  // goes on node by node, so it ends after at most n more steps (the main component is never empty)
+  for (int64_t s = 0; s <= n / 97 && label[j] != main_label; ++s) j = (j + 97) % n;
+  for (int64_t s = 0; s < n && label[j] != main_label; ++s) j = (j + 1) % n;
+  return label[j] == main_label ? (uint32_t)j : kNone;
 }
 
 __global__ void mst_propose_kernel(const uint32_t* __restrict__ knn, int64_t n, uint32_t K, uint32_t k, uint32_t degree,

@@ -126,6 +126,7 @@ inline resources* as_res(uintptr_t h)
 // stream; hipMallocAsync gives the same semantics from the driver's pool).
 void* device_alloc(resources& res, size_t bytes);
 void device_free(resources& res, void* p);
+void scratch_cache_flush_all();  // every handle's kept scratch blocks back to the runtime (an allocation failed)
 
 // Two lifetimes: scratch buffers are stream-ordered (freed on the handle's stream); buffers owned by an
 // index outlive the handle that built them, so they use plain hipMalloc/hipFree ("persistent").
@@ -145,7 +146,11 @@ struct dev_buf {
     b.n = count;
     if (count) {
       void* p = nullptr;
-      HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+      if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) {  // idle scratch blocks kept by the handles may be in the way
+        (void)hipGetLastError();
+        scratch_cache_flush_all();
+        HIP_TRY(hipMalloc(&p, count * sizeof(T)));
+      }
       b.ptr = static_cast<T*>(p);
     }
     return b;

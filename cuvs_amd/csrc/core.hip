@@ -7,8 +7,10 @@
 
 #include "scratch_cache.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 namespace cuvs_amd {
 
@@ -48,10 +50,34 @@ void raw_free(void* stream_v, void* p)
 
 }  // namespace
 
+unsigned long long g_pq3_last_stats[4] = {0, 0, 0, 0};  // cuvsAmdIvfPqLastFilterStats (written by ivf_pq_search.hip)
+
 // scratch_cache.hpp: freed scratch blocks are kept by the handle and re-used by exact size on the same stream
 void scratch_cache_flush(resources& res)
 {
   if (res.cache != nullptr) res.cache->flush(raw_free);
+}
+
+// every live cache of the process: a PERSISTENT allocation (an index buffer: plain hipMalloc, no handle in sight) that fails
+// gives all kept scratch blocks back before it tries again
+namespace {
+std::mutex g_caches_mu;
+std::vector<scratch_cache*> g_caches;
+}  // namespace
+void scratch_cache_register(scratch_cache* c, bool add)
+{
+  std::lock_guard<std::mutex> lk(g_caches_mu);
+  if (add) g_caches.push_back(c);
+  else g_caches.erase(std::remove(g_caches.begin(), g_caches.end(), c), g_caches.end());
+}
+void scratch_cache_flush_all()
+{
+  {
+    std::lock_guard<std::mutex> lk(g_caches_mu);
+    for (scratch_cache* c : g_caches) c->flush(raw_free);
+  }
+  (void)hipDeviceSynchronize();  // the frees are stream-ordered: the memory is back once the streams have drained
+  (void)hipGetLastError();
 }
 
 void* device_alloc(resources& res, size_t bytes)
@@ -205,6 +231,7 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
     (void)hipGetLastError();
     if (r->tune.alloc_cache != 0) {
       r->cache         = new scratch_cache();
+      scratch_cache_register(r->cache, true);
       r->cache->stream = r->stream;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = size_t(64) << 30; }
@@ -230,6 +257,7 @@ cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
     if (r->cache != nullptr) {
       scratch_cache_flush(*r);
       (void)hipStreamSynchronize(r->stream);
+      scratch_cache_register(r->cache, false);
       delete r->cache;
       r->cache = nullptr;
     }
@@ -243,9 +271,20 @@ cuvsError_t cuvsStreamSet(cuvsResources_t res, cudaStream_t stream)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto* r = as_res(res);
-    if (r->cache != nullptr) {  // kept blocks are ordered on the old stream: give them back before it goes
-      scratch_cache_flush(*r);
-      HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->cache != nullptr) {
+      // kept blocks are ordered on the old stream: give them back before it goes. A stream the CALLER owns may already
+      // be destroyed (legal: the reference's setter never touches the old stream), so nothing here may fail on it: the
+      // kept blocks are then freed synchronously after a device-wide drain
+      if (r->owns_stream) {
+        scratch_cache_flush(*r);
+        HIP_TRY(hipStreamSynchronize(r->stream));
+      } else {
+        r->cache->flush([](void*, void* p) {
+          (void)hipDeviceSynchronize();
+          (void)hipFree(p);
+          (void)hipGetLastError();
+        });
+      }
     }
     if (r->owns_stream && r->stream) {
       HIP_TRY(hipStreamSynchronize(r->stream));
@@ -366,6 +405,13 @@ cuvsError_t cuvsRMMHostFree(void* ptr, size_t)
   return (cuvsError_t)translate_exceptions([=] { HIP_TRY(hipHostFree(ptr)); });
 }
 
+// extension (not in the reference ABI): counters of the last IVF-PQ search whose handle was created under
+// CUVS_AMD_SCAN_DEBUG=1024 - [0] (row, query) pairs screened by the matrix-core filter, [1] survivors re-scored, [2] 32-row
+// subtiles decoded, [3] work units (bench.py: survivors per pair of a corpus)
+__attribute__((visibility("default"))) void cuvsAmdIvfPqLastFilterStats(unsigned long long* out)
+{
+  for (int i = 0; i < 4; ++i) out[i] = cuvs_amd::g_pq3_last_stats[i];
+}
 // extension (not in the reference ABI): kernel timing for bench.py
 __attribute__((visibility("default"))) void cuvsAmdProfileEnable(int on) { g_prof_on = on != 0; }
 // sums the elapsed ms of every recorded launch called `name`; returns the launch count; resets those records

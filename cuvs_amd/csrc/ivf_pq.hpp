@@ -58,6 +58,9 @@ struct ivf_pq_index {
     int64_t rows = -1, size = -1;
   };
   mutable scan3_cache scan3;
+  // largest source id held by the lists (-1: empty), computed on demand for the bitset-filter bound check
+  mutable int64_t max_id = -1, max_id_rows = -1;
+  mutable const void* max_id_ptr = nullptr;
 
   // List-sharded multi-GPU search (shard_comm.hip): every rank holds the whole model (centres, rotation, codebooks) but
   // only the lists it owns - list L belongs to rank L % shard_world. extend() drops rows of foreign lists, search()

@@ -140,6 +140,32 @@ cuvsError_t cuvsIvfPqBuildPrecomputed(cuvsResources_t res_h, cuvsIvfPqIndexParam
   });
 }
 
+// largest source id stored in the lists (cached per index state): the bitset of a filtered search is indexed by source id
+__global__ void max_source_id_kernel(const int64_t* __restrict__ ids, const uint32_t* __restrict__ list_offsets,
+                                     const uint32_t* __restrict__ list_sizes, uint32_t n_lists, unsigned long long* __restrict__ out)
+{
+  const uint32_t L = blockIdx.x;
+  if (L >= n_lists) return;
+  long long m = -1;
+  for (uint32_t r = threadIdx.x; r < list_sizes[L]; r += blockDim.x) m = max(m, (long long)ids[list_offsets[L] + r]);
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m >= 0) atomicMax(out, (unsigned long long)m);
+}
+static int64_t ivf_pq_max_source_id(resources& res, const ivf_pq_index& idx)
+{
+  if (idx.max_id_ptr == idx.indices.data() && idx.max_id_rows == idx.size) return idx.max_id;
+  int64_t m = -1;
+  if (idx.size > 0) {
+    dev_buf<unsigned long long> d(res, 1);
+    HIP_TRY(hipMemsetAsync(d.data(), 0, sizeof(unsigned long long), res.stream));
+    hipLaunchKernelGGL(max_source_id_kernel, dim3(idx.n_lists), dim3(256), 0, res.stream, idx.indices.data(), idx.list_offsets.data(),
+                       idx.list_sizes.data(), idx.n_lists, d.data());
+    m = (int64_t)to_host(res, d.data(), 1)[0];
+  }
+  idx.max_id = m; idx.max_id_rows = idx.size; idx.max_id_ptr = idx.indices.data();
+  return m;
+}
+
 static cuvsError_t pq_search_entry(cuvsResources_t res_h, cuvsIvfPqSearchParams_t params, cuvsIvfPqIndex_t index_c,
                                    DLManagedTensor* queries_tensor, DLManagedTensor* neighbors_tensor,
                                    DLManagedTensor* distances_tensor, cuvsFilter filter)
@@ -175,6 +201,10 @@ static cuvsError_t pq_search_entry(cuvsResources_t res_h, cuvsIvfPqSearchParams_
       int64_t words = 1;
       for (int i = 0; i < ft.ndim; ++i) words *= ft.shape[i];
       CUVS_EXPECTS(words * 32 >= idx.size, "bitset filter holds %ld bits, the index %ld rows", (long)(words * 32), (long)idx.size);
+      // the kernels index the bitset by SOURCE id (ids given to extend() need not be 0 .. size - 1)
+      const int64_t max_id = ivf_pq_max_source_id(res, idx);
+      CUVS_EXPECTS(words * 32 > max_id, "bitset filter holds %ld bits, the largest source id of the index is %ld", (long)(words * 32),
+                   (long)max_id);
       filter_bits = static_cast<const uint32_t*>(dl_data(ft));
     }
     ivf_pq_search_params sp;

@@ -1380,16 +1380,26 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   if (c.data_ptr == v.data && c.rows == v.padded_rows && c.size == v.size) return true;
+  // (an attempt that found no room is remembered for this state of the index: it is not repeated on every search)
+  if (c.failed_ptr == v.data && c.failed_rows == v.padded_rows && c.failed_size == v.size) return false;
   const int64_t rows = std::max<int64_t>(v.padded_rows, 64);
   {
-    // the copy takes half the size of the fp32 rows again: only when the device has that much to spare
+    // the copy takes half the size of the fp32 rows again: only when the device has that much to spare (idle scratch
+    // blocks kept by the handles count as spare: they are given back first)
     c.rows16   = dev_buf<uint4>();
     c.row_term = dev_buf<uint32_t>();
     c.data_ptr = nullptr;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const size_t need = (size_t)rows * v.dim * 2 + (size_t)rows * 12 + (size_t(1) << 30);  // (fp16 rows: as large as the index again)
-    if (free_b < need) return false;
+    if (free_b < need) {
+      scratch_cache_flush_all();
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    }
+    if (free_b < need) {
+      c.failed_ptr = v.data; c.failed_rows = v.padded_rows; c.failed_size = v.size;
+      return false;
+    }
   }
   dev_buf<uint32_t> row_list(res, (size_t)rows / 64), mxd(res, 1);
   dev_buf<float> dn(res, (size_t)rows);

@@ -71,6 +71,8 @@ struct flat3_cache {
   float sc = 1.f, maxres = 0.f;
   const void* data_ptr = nullptr;
   int64_t rows = -1, size = -1;
+  const void* failed_ptr = nullptr;  // index state for which the device had no room for the copy
+  int64_t failed_rows = -1, failed_size = -1;
 };
 struct flat3_view {  // the IVF-Flat index as ivf_flat.hip holds it
   const uint8_t* data;

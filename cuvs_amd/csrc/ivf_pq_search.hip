@@ -35,6 +35,7 @@
 #include <type_traits>
 
 namespace cuvs_amd {
+extern unsigned long long g_pq3_last_stats[4];  // core.hip: cuvsAmdIvfPqLastFilterStats
 
 void load_range_as_float(resources& res, const void* data, elem_t et, bool is_host, int64_t dim, int64_t r0,
                          int64_t cnt, float* out);
@@ -1916,6 +1917,16 @@ void rotate_queries(resources& res, const ivf_pq_index& idx, const float* qf, co
   if (!half_t) hipLaunchKernelGGL(scale_kernel, dim3(nblk(nq * idx.rot_dim, 256)), dim3(256), 0, res.stream, rot_q, nq * idx.rot_dim, 1.0f / 128.0f / 128.0f);
 }
 
+// the first `seg` slots of every query's candidate row (the head pairs' segments) start out "nothing found"
+__global__ void init_head_rows_kernel(float* __restrict__ cand_d, uint32_t* __restrict__ cand_i, int64_t nq, int64_t row_len, uint32_t seg)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq * (int64_t)seg) return;
+  const int64_t o = (t / seg) * row_len + t % seg;
+  cand_d[o] = FLT_MAX;
+  cand_i[o] = 0xffffffffu;
+}
+
 // flat row -> source id; distance fix-ups (ivf_common.cuh:114-171 postprocess_neighbors, :176-253)
 __global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float* __restrict__ d_in, int64_t n,
                                    const int64_t* __restrict__ indices, int metric, float scale2,
@@ -2110,7 +2121,13 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
     // per-pair candidate rows start out invalid: the scan only writes the rows of pairs that found something
-    if (!large_k) {
+    if (use3) {
+      // matrix-core tail phase: only the head segments of a query's row are read before they are written (the pool behind
+      // them is filled by count, the rows of handed-back queries are reset by reset_flagged_kernel) - no fill of all
+      // n_pairs x k slots (205 MB per batch at the bench shape; on a list shard most of them belong to foreign pairs)
+      hipLaunchKernelGGL(init_head_rows_kernel, dim3(nblk(nq * (int64_t)head * k, 256)), dim3(256), 0, res.stream, cand_d.data(),
+                         cand_i.data(), nq, (int64_t)n_probes * k, (uint32_t)(head * k));
+    } else if (!large_k) {
       HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)n_pairs * k, res.stream));
       HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)n_pairs * k * sizeof(uint32_t), res.stream));
     } else {
@@ -2217,6 +2234,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         pq3_merge(res, r, top_d.data(), top_i.data());
         if (a.dbg & 1024) {
           auto hs = to_host(res, st3.data(), 8);
+          g_pq3_last_stats[0] = hs[0]; g_pq3_last_stats[1] = hs[1]; g_pq3_last_stats[2] = hs[2]; g_pq3_last_stats[3] = hs[7];
           fprintf(stderr, "[pq_scan3] units %llu; wave cycles per unit: prologue %.0f, loop %.0f (slow path %.0f); per subtile %.0f\n", hs[7],
                   (double)hs[4] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[7]),
                   (double)hs[6] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[2]));

@@ -222,6 +222,8 @@ cuvsError_t cuvsAmdIvfPqSetListShard(cuvsIvfPqIndex_t index, int rank, int world
     auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
     CUVS_EXPECTS(idx.size == 0, "list shard: the index already holds rows (build with add_data_on_build = false)");
     idx.shard_rank = rank; idx.shard_world = world;
+    idx.h_list_owner.clear();  // back to "list L on rank L % world": an owner table of an earlier SetListOwners is void
+    idx.list_owner = dev_buf<int32_t>();
   });
 }
 
@@ -275,6 +277,19 @@ cuvsError_t cuvsAmdIvfPqListHistogram(cuvsResources_t res_h, cuvsIvfPqIndex_t in
     ivf_pq_transform(res, idx, dl_data(t), elem_of(t.dtype), n, labels.data(), nullptr);
     auto h = to_host(res, labels.data(), (size_t)n);
     for (int64_t i = 0; i < n; ++i) counts[h[i]] += 1;
+  });
+}
+
+cuvsError_t cuvsAmdIvfPqRowLabels(cuvsResources_t res_h, cuvsIvfPqIndex_t index, DLManagedTensor* rows, uint32_t* labels)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    auto& res = *as_res(res_h);
+    CUVS_EXPECTS(index != nullptr && index->addr != 0 && rows != nullptr && labels != nullptr, "row labels: null argument");
+    auto& idx = *reinterpret_cast<ivf_pq_index*>(index->addr);
+    auto& t   = rows->dl_tensor;
+    CUVS_EXPECTS(t.ndim == 2 && is_c_contiguous(t) && t.shape[1] == idx.dim && is_device_accessible(t),
+                 "row labels: rows must be a device [n, dim] row-major matrix");
+    if (t.shape[0] > 0) ivf_pq_transform(res, idx, dl_data(t), elem_of(t.dtype), t.shape[0], labels, nullptr);
   });
 }
 

@@ -44,6 +44,17 @@ def list_histogram(index, rows, counts=None, resources=None):
     return counts
 
 
+@auto_sync_resources
+def row_labels(index, rows, resources=None):
+    """The list of every row (device tensor [n, dim]) as a device int64 tensor [n] (cuvsAmdIvfPqRowLabels)."""
+    from .._lib import Tensor
+
+    t = Tensor(rows.contiguous())
+    out = torch.empty(rows.shape[0], dtype=torch.int32, device=rows.device)
+    check(lib().cuvsAmdIvfPqRowLabels(resources.get_c_obj(), index._p, t.ptr, C.c_void_p(out.data_ptr())))
+    return out.to(torch.int64)
+
+
 def set_list_owners(index, owners, rank, world):
     """Marks the (still empty) index as the shard of `rank` with an explicit owner per list (same table on every rank)."""
     o = np.ascontiguousarray(owners, dtype=np.int32)

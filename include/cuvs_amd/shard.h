@@ -51,6 +51,10 @@ CUVS_EXPORT cuvsError_t cuvsAmdIvfPqListHistogram(cuvsResources_t res, cuvsIvfPq
                                                   uint64_t* counts);
 CUVS_EXPORT cuvsError_t cuvsAmdIvfPqSetListOwners(cuvsIvfPqIndex_t index, const int32_t* owners, uint32_t n_lists, int rank,
                                                   int world);
+/* The list of every row of `rows` (device, [n, dim], the index dtype) -> labels (device, uint32 [n]): what a rank needs to
+ * keep the raw rows of ITS lists next to their codes (shard-local refinement: every rank re-ranks its own candidates
+ * exactly before the all-gather, refine_ratio of the reference's bench grids; refine_device.cuh). */
+CUVS_EXPORT cuvsError_t cuvsAmdIvfPqRowLabels(cuvsResources_t res, cuvsIvfPqIndex_t index, DLManagedTensor* rows, uint32_t* labels);
 
 /* Optional: gives the shard's searches access to the communicator. cuvsIvfPqSearch then all-reduces (min) the per-query
  * k-th bounds between its two scan phases - one ncclAllReduce of n_queries uint32 per batch - so that every rank prunes

@@ -191,7 +191,7 @@ def ivf_flat_search(exported, queries, k, n_probes, metric="sqeuclidean", coarse
 
 
 def cagra_search(dataset, graph, queries, k, itopk_size=64, search_width=1, max_iterations=0, min_iterations=0,
-                 hashmap_min_bitlen=0, rand_xor_mask=0x128394, metric="sqeuclidean", filter_words=None):
+                 hashmap_min_bitlen=0, rand_xor_mask=0x128394, metric="sqeuclidean", filter_words=None, num_random_samplings=1):
     """CPU twin of cuvsCagraSearch (same parameter derivation as cuvs_amd/csrc/cagra.hip: search_plan.cuh:199-245).
     dataset/queries in the index dtype; graph uint32 [n, degree]. Returns (distances, neighbors)."""
     raw = np.asarray(dataset)
@@ -199,7 +199,7 @@ def cagra_search(dataset, graph, queries, k, itopk_size=64, search_width=1, max_
     x, q = _f32(raw.astype(np.float32)), _f32(np.asarray(queries).astype(np.float32))
     g = np.ascontiguousarray(graph, dtype=np.uint32)
     n, degree = g.shape
-    width = max(1, min(8, int(search_width)))
+    width = max(1, int(search_width))
     itopk = max(int(itopk_size) if itopk_size else 64, k)
     if itopk % 32:
         itopk += 32 - itopk % 32
@@ -224,7 +224,8 @@ def cagra_search(dataset, graph, queries, k, itopk_size=64, search_width=1, max_
     lib().oracle_cagra_search(_p(x), C.c_int64(n), C.c_int64(x.shape[1]), C.c_int(vl), _p(g), C.c_int(degree), _p(q),
                               C.c_int64(nq), C.c_int(k), C.c_int(itopk), C.c_int(width), C.c_int(max_iter),
                               C.c_int(int(min_iterations)), C.c_int(bits), C.c_int(reset), C.c_uint64(rand_xor_mask),
-                              C.c_int({6: 1, 2: 2}.get(_metric(metric), 0)), _p(fw) if fw is not None else None, _p(oi), _p(od))
+                              C.c_int({6: 1, 2: 2}.get(_metric(metric), 0)), _p(fw) if fw is not None else None, _p(oi), _p(od),
+                              C.c_int(max(1, int(num_random_samplings))))
     return od, oi
 
 

@@ -1,8 +1,9 @@
 /*
  * oracle_cagra.c — CPU twin of cuvsCagraSearch on an exported index (TEST INFRASTRUCTURE ONLY, see oracle.c).
  *
- * Restates the reference's single-CTA search loop (search_single_cta_jit.cuh:105-452): seed the internal top
- * list with pseudo-random nodes (device_common_jit.cuh:36-104, xorshift64(gid ^ rand_xor_mask) % n), then
+ * Restates the reference's single-CTA search loop (search_single_cta_jit.cuh:105-452): seed every slot of the result
+ * buffer (itopk + search_width * degree slots) with the nearest of num_random_samplings pseudo-random nodes
+ * (device_common_jit.cuh:36-104: gid = slot + n_slots * j, xorshift64(gid ^ rand_xor_mask) % n, first wins ties), then
  * repeat { sort; pick the best entries that were not parents yet (search_single_cta_device_helpers.cuh:98-136,
  * MSB of the index marks "used"); expand their graph rows; drop children already seen (hashmap.hpp:37-134, a
  * SET here — the small-hash reset of the reference keeps only the current top list); compute child distances }
@@ -102,7 +103,7 @@ static float node_key_value(const float* x, const float* q, int64_t dim, int vl,
 EXPORT void oracle_cagra_search(const float* data, int64_t n, int64_t dim, int vl, const uint32_t* graph, int degree,
                                 const float* queries, int64_t nq, int k, int itopk, int width, int max_iter,
                                 int min_iter, int hash_bits, int reset_interval, uint64_t rand_xor_mask, int is_ip,
-                                const uint32_t* filter_bits, int64_t* out_idx, float* out_dist)
+                                const uint32_t* filter_bits, int64_t* out_idx, float* out_dist, int n_distill)
 {
   int np2 = 1;
   while (np2 < itopk + width * degree) np2 <<= 1;
@@ -119,13 +120,16 @@ EXPORT void oracle_cagra_search(const float* data, int64_t n, int64_t dim, int v
       const float qn = is_ip == 2 ? sqrtf(sqnorm64(q, dim)) : 1.f;
       for (int i = 0; i < np2; ++i) { e[i].key = 0xffffffffu; e[i].idx = INVALID; }
       set_clear(&set);
-      for (int i = 0; i < itopk; ++i) {
-        uint64_t gid  = (uint64_t)qi * (uint64_t)itopk + (uint64_t)i;
-        uint32_t node = (uint32_t)(xorshift64(gid ^ rand_xor_mask) % (uint64_t)n);
-        if (set_insert(&set, node, hash_bits)) {
-          e[i].idx = node;
-          e[i].key = f2key(node_key_value(data + (int64_t)node * dim, q, dim, vl, is_ip, qn));
+      const int n_seed = itopk + width * degree;  /* result_buffer_size (search_single_cta_jit.cuh:110) */
+      for (int i = 0; i < n_seed; ++i) {
+        uint32_t best_key = 0xffffffffu, best = INVALID;
+        for (int j = 0; j < n_distill; ++j) {  /* device_common_jit.cuh:66-83 */
+          uint64_t gid  = (uint64_t)i + (uint64_t)n_seed * (uint64_t)j;
+          uint32_t node = (uint32_t)(xorshift64(gid ^ rand_xor_mask) % (uint64_t)n);
+          uint32_t key  = f2key(node_key_value(data + (int64_t)node * dim, q, dim, vl, is_ip, qn));
+          if (key < best_key) { best_key = key; best = node; }
         }
+        if (best != INVALID && set_insert(&set, best, hash_bits)) { e[i].idx = best; e[i].key = best_key; }
       }
       int iter = 0;
       for (;;) {

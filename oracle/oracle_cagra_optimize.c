@@ -104,8 +104,10 @@ int64_t oracle_cagra_mst(const uint32_t* knn, int64_t n, uint32_t K, uint32_t de
           j = knn[i * K + k];
         } else if (li != main_label) {
           int64_t w = (i + (int64_t)97 * (1 + last_rounds)) % n;
-          while (label[w] != main_label) w = (w + 97) % n;
-          j = (uint32_t)w;
+          /* bounded as in cagra_mst.hip: one turn of stride 97, then node by node */
+          for (int64_t st = 0; st <= n / 97 && label[w] != main_label; ++st) w = (w + 97) % n;
+          for (int64_t st = 0; st < n && label[w] != main_label; ++st) w = (w + 1) % n;
+          j = label[w] == main_label ? (uint32_t)w : NONE;
         }
         if (j < (uint32_t)n && label[j] != li) {
           if (in_cnt[j] < degree - out_max[j]) {

@@ -66,6 +66,35 @@ def test_cagra_search_walk_matches_oracle(dtype, metric):
         assert (d.cpu().numpy() == od).all()
 
 
+@pytest.mark.parametrize("samplings,width", [(1, 1), (4, 1), (4, 3), (16, 1), (1, 12)])
+def test_cagra_num_random_samplings_and_wide_search(samplings, width):
+    """num_random_samplings (device_common_jit.cuh:60-83: every seed slot keeps the nearest of that many pseudo-random
+    nodes) and search_width beyond 8: ids and distances identical to the oracle walk; more samplings never lower the recall
+    of a walk that starts in the wrong place (clustered rows, few iterations)."""
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(11)
+    centres = rng.standard_normal((12, 32)).astype(np.float32) * 4
+    x = (centres[rng.integers(0, 12, 4000)] + 0.3 * rng.standard_normal((4000, 32))).astype(np.float32)
+    q = (centres[rng.integers(0, 12, 96)] + 0.3 * rng.standard_normal((96, 32))).astype(np.float32)
+    index = cagra.build(cagra.IndexParams(intermediate_graph_degree=32, graph_degree=16), torch.from_numpy(x).cuda())
+    graph = index.graph.cpu().numpy().view(np.uint32)
+    sp = cagra.SearchParams(itopk_size=64, search_width=width, algo="single_cta", num_random_samplings=samplings)
+    d, i = cagra.search(sp, index, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    gi = i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    od, oi = oracle.cagra_search(x, graph, q, 10, itopk_size=64, search_width=width, num_random_samplings=samplings)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.4f}"
+    assert (d.cpu().numpy() == od).all()
+    # the multi-wave walk takes the parameter too (claim races: checked by recall)
+    _, ti = oracle.exact_knn(q, x, 10)
+    dm, im = cagra.search(cagra.SearchParams(itopk_size=64, algo="multi_cta", num_random_samplings=samplings), index,
+                          torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    assert oracle.recall(im.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, ti) > 0.9
+
+
 @pytest.mark.parametrize("dtype,dim", [(np.float16, 768), (np.float32, 600), (np.float16, 1024)])
 def test_cagra_search_walk_matches_oracle_large_dim(dtype, dim):
     """The BASELINE C4 row shape (768 fp16) and its neighbours: rows longer than one team pass (dim > 512), so the
