@@ -465,6 +465,15 @@ def extra_c4_clustered(res, dev, rows=2_000_000, latent=24, modes=4096):
             dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 3, 1)
             rec = recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt)
             line[f"itopk_{itopk}"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(rec, 4)}
+        # more random candidates per seed slot (num_random_samplings, device_common_jit.cuh:60-83): does a better start make
+        # the clustered corpus navigable?
+        for samplings in (4, 16):
+            sp = cagra.SearchParams(itopk_size=64, algo="auto", num_random_samplings=samplings)
+            nb = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+            dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+            dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 3, 1)
+            rec = recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt)
+            line[f"itopk_64_samplings_{samplings}"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(rec, 4)}
         out["guarantee_connectivity" if guarantee else "plain"] = line
         del idx
     return out

@@ -68,6 +68,8 @@ struct append_args {
   int k              = 0;
   int cap            = 0;
   int64_t col_off    = 0;        // source id of column 0 of x
+  int64_t col_stride = 1;        // source id of column j = col_off + j * col_stride (strided column sets: the coarse search)
+  const float* thr   = nullptr;  // optional [m] thresholds instead of the rows' k-th values (ties at the k-th value pass)
   int64_t row_off    = 0;        // query row of row 0 of q (bitmap filters)
   int64_t n_total    = 0;        // indexed rows (bitmap row pitch)
   const uint32_t* bits = nullptr;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q
           const int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
           if (row >= m) continue;
           const float qnv = ep.qn != nullptr ? ep.qn[row] : 0.f;
-          const float thr = ap.buf_v[row * ap.ldb + ap.k - 1];
+          const float thr = ap.thr != nullptr ? ap.thr[row] : ap.buf_v[row * ap.ldb + ap.k - 1];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int64_t col = col0 + wn * 64 + j * 16 + l15;
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q
               const int pos = atomicAdd(&ap.cnt[row], 1);
               if (pos < ap.cap) {
                 ap.buf_v[row * ap.ldb + ap.k + pos] = d;
-                ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col;
+                ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col * ap.col_stride;
               }
             }
           }
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
     const int64_t row = row0 + tid;
     s_qn[tid]         = ep.qn != nullptr ? ep.qn[min(row, m - 1)] : 0.f;
     if constexpr (MODE == 2)  // rows past the end never pass
-      s_thr[tid] = row < m ? ap.buf_v[row * ap.ldb + ap.k - 1] : (ap.select_min ? -INFINITY : INFINITY);
+      s_thr[tid] = row < m ? (ap.thr != nullptr ? ap.thr[row] : ap.buf_v[row * ap.ldb + ap.k - 1]) : (ap.select_min ? -INFINITY : INFINITY);
   } else {
     s_xn[tid - BM] = ep.xn != nullptr ? ep.xn[min(col0 + tid - BM, n - 1)] : 0.f;
   }
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
               const int pos = atomicAdd(&ap.cnt[row], 1);
               if (pos < ap.cap) {
                 ap.buf_v[row * ap.ldb + ap.k + pos] = d;
-                ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col;
+                ap.buf_i[row * ap.ldb + ap.k + pos] = ap.col_off + col * ap.col_stride;
               }
             }
           }
@@ -593,7 +595,7 @@ template <typename TQ, typename TX>
 void pairwise_threshold_append(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n, int64_t ldx,
                                int64_t dim, const float* qn, const float* xn, int metric, float* buf_v, int64_t* buf_i,
                                int* cnt, int k, int cap, int64_t col_off, int64_t row_off, int64_t n_total,
-                               const uint32_t* bits, int filter_type)
+                               const uint32_t* bits, int filter_type, int64_t col_stride, const float* thr)
 {
   if (m == 0 || n == 0) return;
   CUVS_EXPECTS(metric_supported(metric), "pairwise_threshold_append: unsupported metric %d", metric);
@@ -601,6 +603,7 @@ void pairwise_threshold_append(resources& res, const TQ* q, int64_t m, int64_t l
   append_args ap;
   ap.buf_v = buf_v; ap.buf_i = buf_i; ap.cnt = cnt; ap.ldb = k + cap; ap.k = k; ap.cap = cap;
   ap.col_off = col_off; ap.row_off = row_off; ap.n_total = n_total; ap.bits = bits; ap.filter_type = filter_type;
+  ap.col_stride = col_stride; ap.thr = thr;
   ap.select_min = metric != M_InnerProduct;
   ap.n_rt = (m + BM - 1) / BM;
   ap.n_ct = (n + BN - 1) / BN;
@@ -680,7 +683,7 @@ INST_P(float, float) INST_P(__half, __half) INST_P(__half, float) INST_P(int8_t,
 #define INST_T(TQ, TX)                                                                                              \
   template void pairwise_threshold_append<TQ, TX>(resources&, const TQ*, int64_t, int64_t, const TX*, int64_t, int64_t, \
                                                   int64_t, const float*, const float*, int, float*, int64_t*, int*, int, int, \
-                                                  int64_t, int64_t, int64_t, const uint32_t*, int);
+                                                  int64_t, int64_t, int64_t, const uint32_t*, int, int64_t, const float*);
 INST_T(float, float) INST_T(__half, __half)
 #undef INST_T
 

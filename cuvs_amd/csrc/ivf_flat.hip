@@ -140,6 +140,7 @@ struct flat_scan_args {
   uint32_t* all_rows;        //   flat row of every column (0xffffffff: nothing there)
   const uint32_t* pair_seg;  //   first column of each pair in its query's row
   size_t scores_ld;
+  const uint32_t* run_if = nullptr;  // optional device word: the launch does nothing when it is zero (fallback pass decided on the device)
 };
 
 // Query tile of every work item, [dim_pad][QPB] fp32 in HBM. The scan kernel reads it with wave-uniform addresses,
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
   constexpr bool IP = METRIC != 0;  // scores that are dot products: no early stop, negated as sort keys
   constexpr bool INT = (std::is_same_v<T, int8_t> || std::is_same_v<T, uint8_t>) && METRIC != 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (a.run_if != nullptr && *a.run_if == 0u) return;
   const uint32_t item0 = a.item_begin ? *a.item_begin : 0u;
   const uint32_t w     = item0 + blockIdx.x;
   if (w >= *a.item_end) return;
@@ -491,6 +493,30 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
       }
     }
     if (lane == 0 && kd < INFINITY) atomicMin(&a.query_kth[pid[j] / a.n_probes], float_to_key(kd));
+  }
+}
+
+// the first `seg` slots of every query's candidate row (the head pairs' segments) start out "nothing found"
+__global__ void flat_init_head_rows_kernel(float* __restrict__ cand_d, uint32_t* __restrict__ cand_i, int64_t nq, int64_t row_len, uint32_t seg)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq * (int64_t)seg) return;
+  const int64_t o = (t / seg) * row_len + t % seg;
+  cand_d[o] = FLT_MAX;
+  cand_i[o] = 0xffffffffu;
+}
+
+// the tail slots of every query's candidate row back to "nothing found" - only when *run_if is set (the matrix-core tail
+// phase gave up: its pool entries must not be read as per-pair lists by the scan-kernel pass that follows)
+__global__ void flat_reset_rows_if_kernel(const uint32_t* __restrict__ run_if, float* __restrict__ cand_d, uint32_t* __restrict__ cand_i,
+                                          int64_t nq, int64_t row_len, uint32_t head_len)
+{
+  if (run_if != nullptr && *run_if == 0u) return;  // (nullptr: unconditional)
+  const int64_t tail = row_len - head_len;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq * tail; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = (t / tail) * row_len + head_len + t % tail;
+    cand_d[o] = FLT_MAX;
+    cand_i[o] = 0xffffffffu;
   }
 }
 
@@ -812,9 +838,11 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
                      items.data());
     trace.mark("work items");
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
-    if (use3) {  // the candidate rows start out invalid: the tail of a query's row is its pool
-      HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cand_d.data()), 0x7f7fffff, (size_t)n_pairs * k, res.stream));
-      HIP_TRY(hipMemsetAsync(cand_i.data(), 0xff, (size_t)n_pairs * k * sizeof(uint32_t), res.stream));
+    if (use3) {
+      // only the head segments of a query's candidate row are read before they are written (the pool behind them is filled by
+      // count; the guarded fallback pass resets the tail itself): no fill of all n_pairs x k slots
+      hipLaunchKernelGGL(flat_init_head_rows_kernel, dim3(grid_blocks(nq * (int64_t)head * k, 256)), dim3(256), 0, res.stream,
+                         cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (uint32_t)(head * k));
       HIP_TRY(hipMemsetAsync(qstate.data(), 0, qstate.bytes(), res.stream));
       HIP_TRY(hipMemsetAsync(tickets3.data(), 0, tickets3.bytes(), res.stream));
     }
@@ -894,13 +922,28 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
           if (tdbg)
             fprintf(stderr, "[flat3] tail %.3f ms, merge %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
                     std::chrono::duration<double, std::milli>(t2 - t1).count());
-          // a buffer ran over (bounds too loose to filter: e.g. lists shorter than k): the tail phase again, on the scan kernel
+          // a buffer ran over (bounds too loose to filter: e.g. lists shorter than k): the tail phase again, on the scan
+          // kernel + select_k - launched now, decided ON THE DEVICE (the word r.fail guards every kernel of the pass: the
+          // call stays asynchronous, no flag comes back to the host). The pass starts from clean per-pair rows.
           trace.mark("merge enqueued");
-          merged = read_word(res, r.fail) == 0u;
-          trace.mark("flag read back (device drained)");
+          hipLaunchKernelGGL(flat_reset_rows_if_kernel, dim3(1024), dim3(256), 0, res.stream, r.fail, cand_d.data(), cand_i.data(),
+                             (int64_t)nq, (int64_t)n_probes * k, (uint32_t)(head * k));
+          a.run_if = r.fail;
+          launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
+          a.run_if = nullptr;
+          select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,
+                                       k, top_d.data(), top_i.data(), true, 0, -1, 0, r.fail);
+          merged = true;
+          trace.mark("guarded fallback enqueued");
         }
       }
-      if (!merged) launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
+      if (!merged) {
+        if (use3) {  // (no room for the fp16 copy: the plain tail phase needs every pair's row "nothing found")
+          hipLaunchKernelGGL(flat_reset_rows_if_kernel, dim3(1024), dim3(256), 0, res.stream, static_cast<const uint32_t*>(nullptr),
+                             cand_d.data(), cand_i.data(), (int64_t)nq, (int64_t)n_probes * k, (uint32_t)(head * k));
+        }
+        launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
+      }
     } else {
       a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
       launch(a, (unsigned)(n_pairs / qpb + idx.n_lists + 1));

@@ -77,7 +77,7 @@ struct filter4_launch {
   const float* row_term;
   void* surv;
   uint32_t* surv_cnt;
-  uint32_t surv_cap, spill_cap, n_probes, rot_dim, unit_rows;
+  uint32_t surv_entries, n_probes, rot_dim, unit_rows;  // surv_entries: size of the survivor buffer (handed out in chunks of 256)
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
   int is_ip, dbg, nch;
   int64_t n_pairs;

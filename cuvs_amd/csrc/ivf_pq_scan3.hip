@@ -461,7 +461,9 @@ struct rescore_params {
   const uint2* surv;         // regions of surv_cap entries, one per workgroup of the filter
   const uint32_t* surv_cnt;  // [n_regions + 1] fill of every region, of the spill region
   uint32_t surv_cap, spill_cap;
-  uint32_t n_regions, sub;   // regions of the filter (one per workgroup or one per wave); regions per workgroup of this kernel
+  uint32_t n_regions, sub;   // regions of the filter (one per workgroup), regions per workgroup of this kernel; sub == 0: the
+                             // buffer was handed out in chunks of 256 entries (pq_filter4_kernel), surv_cnt[0] = chunks drawn,
+                             // unused entries are invalid pairs (0xffffffff)
   const uint32_t* probes;  // [n_pairs] list of every pair
   const float* rot_queries;
   const float* centers_rot;
@@ -522,15 +524,20 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
     __syncthreads();
   }
   const float* __restrict__ pqc = a.cb_lds ? cb : a.pq_centers;
-  // regions [blockIdx.x * sub, + sub) of the filter; the last workgroup takes the shared spill region
+  // region blockIdx.x of the filter's workgroups, the last workgroup takes the shared spill region; chunked buffer
+  // (pq_filter4_kernel): all workgroups stride over the chunks drawn
+  const bool chunked = a.sub == 0u;
   const bool spill = blockIdx.x + 1 == gridDim.x;
-  for (uint32_t j = 0; j < (spill ? 1u : a.sub); ++j) {
-  const uint32_t ri = spill ? a.n_regions : blockIdx.x * a.sub + j;
-  const uint32_t n = spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri];
-  const uint2* region = a.surv + (size_t)ri * a.surv_cap;
-  for (uint32_t s = blockIdx.y * blockDim.x + threadIdx.x; s < n; s += gridDim.y * blockDim.x) {
+  const uint32_t ri = spill ? a.n_regions : blockIdx.x;
+  const uint32_t n = chunked ? min(a.surv_cnt[0], a.surv_cap / 256u) * 256u : (spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri]);
+  const uint2* region = chunked ? a.surv : a.surv + (size_t)ri * a.surv_cap;
+  const uint32_t s_first  = chunked ? (blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x : blockIdx.y * blockDim.x + threadIdx.x;
+  const uint32_t s_stride = chunked ? gridDim.x * gridDim.y * blockDim.x : gridDim.y * blockDim.x;
+  {
+  for (uint32_t s = s_first; s < n; s += s_stride) {
     const uint2 sv = region[s];
     const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
+    if (pair == 0xffffffffu) continue;  // (padding of a chunk's tail)
     if (a.qflag[q] != 0u) continue;  // re-done by the LUT scan
     if (a.filter_bits != nullptr) {
       const int64_t sid = a.indices[row];
@@ -1165,7 +1172,7 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ host side
 unsigned pq3_grid(const resources& res) { return (unsigned)std::max(8, res.num_cus / 8 * 8); }
-unsigned pq3_regions(const resources& res) { return 4u * pq3_grid(res); }  // pq_filter4_kernel: one survivor region per wave
+unsigned pq3_regions(const resources& res) { return pq3_grid(res); }  // survivor regions of pq_filter_kernel (pq_filter4_kernel: chunks)
 
 bool pq3_supported(const ivf_pq_index& idx, int k)
 {
@@ -1241,7 +1248,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   const unsigned grid = pq3_grid(res);
   // three quarters of the survivor buffer are cut into one region per workgroup (pq_filter4_kernel: per wave), the rest is
   // the shared spill region
-  const unsigned regions = f4 ? pq3_regions(res) : grid;
+  const unsigned regions = grid;
   f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / regions);
   f.spill_cap = r.surv_cap - f.surv_cap * regions;
   f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.unit_rows = r.unit_rows;
@@ -1265,7 +1272,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
     l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries; l.centers_rot = f.centers_rot;
     l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = r.thr; l.cb16 = tb.cb16; l.codes = f.codes;
     l.list_offsets = f.list_offsets; l.list_sizes = f.list_sizes; l.row_term = reinterpret_cast<const float*>(f.row_term);
-    l.surv = f.surv; l.surv_cnt = f.surv_cnt; l.surv_cap = f.surv_cap; l.spill_cap = f.spill_cap; l.n_probes = r.n_probes;
+    l.surv = f.surv; l.surv_cnt = f.surv_cnt; l.surv_entries = r.surv_cap; l.n_probes = r.n_probes;
     l.rot_dim = idx.rot_dim; l.unit_rows = r.unit_rows; l.sc = f.sc; l.c1 = f.c1; l.eps = f.eps; l.alpha = f.alpha;
     l.cbmax = f.cbmax; l.dmax = f.dmax; l.bound_max = f.bound_max; l.is_ip = r.is_ip; l.dbg = r.filter_dbg; l.nch = nch;
     l.n_pairs = r.nq * (int64_t)r.n_probes; l.stats = r.stats; l.grid = grid;
@@ -1299,7 +1306,8 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
 
   rescore_params s{};
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
-  s.n_regions = regions; s.sub = regions / grid;
+  s.n_regions = regions; s.sub = f4 ? 0u : 1u;
+  if (f4) s.surv_cap = r.surv_cap;  // chunked: the whole buffer
   s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = idx.codes.data();
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = idx.n_chunks;

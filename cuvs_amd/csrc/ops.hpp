@@ -17,7 +17,8 @@ namespace cuvs_amd {
 template <typename InIdxT, typename OutIdxT>
 void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t rows, int64_t len,
               int64_t in_ld, int k, float* out_val, OutIdxT* out_idx, bool select_min,
-              int64_t idx_offset = 0, int64_t out_ld = -1, int64_t out_col_offset = 0);
+              int64_t idx_offset = 0, int64_t out_ld = -1, int64_t out_col_offset = 0, const uint32_t* run_if = nullptr);
+// (run_if: optional device word - the kernels return at once when it is zero: a fallback pass decided on the device)
 
 // ---------------------------------------------------------------- distance.hip
 // Canonical squared row norms: 64 strided fmaf partials + fixed butterfly (oracle/oracle.c
@@ -45,7 +46,9 @@ template <typename TQ, typename TX>
 void pairwise_threshold_append(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n, int64_t ldx,
                                int64_t dim, const float* qn, const float* xn, int metric, float* buf_v, int64_t* buf_i,
                                int* cnt, int k, int cap, int64_t col_off, int64_t row_off, int64_t n_total,
-                               const uint32_t* bits, int filter_type);
+                               const uint32_t* bits, int filter_type, int64_t col_stride = 1, const float* thr = nullptr);
+// (col_stride: the source id of column j is col_off + j * col_stride - a strided view of a larger matrix; thr: [m] thresholds
+// taken instead of the rows' current k-th values, e.g. the next float up so that ties at the k-th value are appended too)
 
 // labels[i] = argmin_j ( xn_j - 2 dot(Q_i, X_j) ) (ties -> smallest j); optional min value out
 // (= squared L2 distance minus |q|^2). The k-means E-step and IVF list assignment.

@@ -38,8 +38,10 @@ __global__ __launch_bounds__(kSelThreads) void select_k_radix_kernel(const float
                                                                      int64_t idx_offset,
                                                                      int64_t out_ld,
                                                                      int64_t out_col_offset,
-                                                                     char* __restrict__ big_k_scratch)
+                                                                     char* __restrict__ big_k_scratch,
+                                                                     const uint32_t* __restrict__ run_if)
 {
+  if (run_if != nullptr && *run_if == 0u) return;  // device-side guard: a fallback pass that is not needed
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* hist      = reinterpret_cast<int*>(smem_raw);            // kBins
   int* scan      = hist + kBins;                                 // 32
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(kSelThreads) void select_k_radix_kernel(const float
 template <typename InIdxT, typename OutIdxT>
 void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t rows, int64_t len,
               int64_t in_ld, int k, float* out_val, OutIdxT* out_idx, bool select_min,
-              int64_t idx_offset, int64_t out_ld, int64_t out_col_offset)
+              int64_t idx_offset, int64_t out_ld, int64_t out_col_offset, const uint32_t* run_if)
 {
   if (rows == 0 || k == 0) return;
   CUVS_EXPECTS(k > 0 && k <= (1 << 24), "select_k: k must be in [1, 2^24], got %d", k);
@@ -209,12 +211,12 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
       auto kern = select_k_radix_kernel<InIdxT, OutIdxT, true>;
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(kern, grid, block, smem, res.stream, in_r, in_idx_r, len, in_ld, k, kp2, out_val_r, out_idx_r,
-                         select_min, idx_offset, out_ld, out_col_offset, scratch.data());
+                         select_min, idx_offset, out_ld, out_col_offset, scratch.data(), run_if);
     } else {
       auto kern = select_k_radix_kernel<InIdxT, OutIdxT, false>;
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(kern, grid, block, smem, res.stream, in_r, in_idx_r, len, in_ld, k, kp2, out_val_r, out_idx_r,
-                         select_min, idx_offset, out_ld, out_col_offset, scratch.data());
+                         select_min, idx_offset, out_ld, out_col_offset, scratch.data(), run_if);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -222,7 +224,7 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
 
 #define INST(I, O)                                                                                   \
   template void select_k<I, O>(resources&, const float*, const I*, int64_t, int64_t, int64_t, int,   \
-                               float*, O*, bool, int64_t, int64_t, int64_t);
+                               float*, O*, bool, int64_t, int64_t, int64_t, const uint32_t*);
 INST(uint32_t, uint32_t)
 INST(uint32_t, int64_t)
 INST(int64_t, int64_t)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--batch", type=int, default=10000)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--metric", default="sqeuclidean")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
 
@@ -39,7 +40,7 @@ def main():
     res = cuvs_amd.common.Resources()
     data = bench.gen_rows(args.rows, 128, seed=1234, device=dev)
     queries = bench.gen_rows(args.batch, 128, seed=4321, device=dev)
-    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=args.n_lists, pq_dim=64, pq_bits=8, kmeans_n_iters=20,
+    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=args.n_lists, metric=args.metric, pq_dim=64, pq_bits=8, kmeans_n_iters=20,
                                             kmeans_trainset_fraction=0.02), data, resources=res)
     res.sync()
     del data

@@ -486,3 +486,4 @@ def test_bitset_prefilter_recall():
     _, ti = oracle.exact_knn(q, x[keep], k)
     assert oracle.recall(gi, kept_ids[ti]) > 0.7
     assert keep[gi].all()
+
