@@ -45,6 +45,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the comparator handles of this script (LUT-scan check, pruning-off figure, filter counters) select kernels through
+# CUVS_AMD_* switches, which the library only looks at behind this gate; the timed handle is created with none of them set
+os.environ["CUVS_AMD_DEBUG_SWITCHES"] = "1"
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_TFLOPS = 157.3  # fp32 MFMA peak (spec)

@@ -74,7 +74,8 @@ int translate_exceptions(Fn&& fn)
 }
 
 // ---------------------------------------------------------------- resources
-// Test / ablation switches (CUVS_AMD_* environment variables). They are read ONCE, when the handle is created
+// Test / ablation switches (CUVS_AMD_* environment variables), all behind ONE gate: they are only looked at when
+// CUVS_AMD_DEBUG_SWITCHES=1 is set (core.hip). They are read ONCE, when the handle is created
 // (cuvsResourcesCreate -> load_tuning_from_env), never inside a search: a drop-in library must not call getenv on its
 // hot path (not thread-safe against setenv) nor change behaviour under a running caller.
 struct tuning {

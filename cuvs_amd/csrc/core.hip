@@ -142,9 +142,19 @@ void profile_end(resources& res, const char* name)
     if (it->name == name) { HIP_TRY(hipEventRecord(it->stop, res.stream)); return; }
 }
 
+// ONE gate in front of every kernel-selection / ablation switch: without CUVS_AMD_DEBUG_SWITCHES=1 in the environment of the
+// process that creates the handle, none of the CUVS_AMD_* variables below is even looked at - a caller of the drop-in
+// library cannot change its behaviour by accident (tests/conftest.py and the bench / profiling scripts set the gate).
+static bool debug_switches_on()
+{
+  const char* g = getenv("CUVS_AMD_DEBUG_SWITCHES");
+  return g != nullptr && g[0] == '1';
+}
+
 tuning load_tuning_from_env()
 {
   tuning t;
+  if (!debug_switches_on()) return t;
   auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
   auto set  = [](const char* name) { return getenv(name) != nullptr; };
   t.pq_head_probes   = geti("CUVS_AMD_PQ_HEAD_PROBES", -1);
@@ -210,7 +220,7 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
     r->tune = load_tuning_from_env();
     // test hook: shrink the temporary-tile budget so tiling/merge logic runs on small inputs
     // (the reference has max_row_tile_size/max_col_tile_size hooks, knn_brute_force.cuh:90-93)
-    if (const char* ws = getenv("CUVS_AMD_WORKSPACE_MB")) {
+    if (const char* ws = debug_switches_on() ? getenv("CUVS_AMD_WORKSPACE_MB") : nullptr) {
       long mb = atol(ws);
       if (mb > 0) r->workspace_limit = (size_t)mb << 20;
     }
@@ -236,7 +246,7 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = size_t(64) << 30; }
       r->cache->cap_bytes = std::min<size_t>(total_b / 8, size_t(16) << 30);
-      if (const char* mb = getenv("CUVS_AMD_ALLOC_CACHE_MB")) r->cache->cap_bytes = (size_t)std::max(0L, atol(mb)) << 20;
+      if (const char* mb = debug_switches_on() ? getenv("CUVS_AMD_ALLOC_CACHE_MB") : nullptr) r->cache->cap_bytes = (size_t)std::max(0L, atol(mb)) << 20;
     }
     *res = reinterpret_cast<uintptr_t>(r);
   });

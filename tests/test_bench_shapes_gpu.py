@@ -93,6 +93,31 @@ def test_c3_shape_lists_of_thousands_of_rows(big_lists, lut, acc, monkeypatch):
     assert (gi == pi).all() and (gd == pd).all()
 
 
+@pytest.mark.parametrize("n_queries,n_lists", [(300, 96), (260, 32), (700, 48), (1500, 24)])
+def test_c3_shape_query_groups_of_every_width(n_queries, n_lists, monkeypatch):
+    """pq_filter4_kernel holds up to four groups of 32 queries per work unit and is instantiated per group count: batches
+    and list counts chosen so that the lists are probed by ~35 / ~90 / ~160 / ~690 queries (one .. four groups, several
+    units per list chunk, lists cut into row chunks) - ids and distances identical to the oracle, to the round-3 filter
+    (CUVS_AMD_PQ_FILTER4=0) and to the LUT scan."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(120_000, 128, n_queries, seed=n_queries + n_lists, modes=48)
+    index = _pq_build(x, n_lists=n_lists, pq_dim=64, pq_bits=8, kmeans_n_iters=8, kmeans_trainset_fraction=0.2)
+    ex = ivf_pq.export_for_oracle(index)
+    k, n_probes = 20, 12
+    kw = dict(n_probes=n_probes, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut="f16", acc="f32")
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_FILTER4", "0")
+    fd, fi = _pq_search(index, q, k, **kw)
+    assert (fi == oi).all() and (fd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (si == oi).all() and (sd == od).all()
+
+
 @pytest.mark.parametrize("k", [100, 128])
 def test_c3_shape_k_beyond_64(big_lists, k, monkeypatch):
     """k = 100 (the usual second setting of ANN benchmarks) and 128: two ranks per lane in the pool merge, groups of two
