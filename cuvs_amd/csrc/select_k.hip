@@ -39,9 +39,11 @@ __global__ __launch_bounds__(kSelThreads) void select_k_radix_kernel(const float
                                                                      int64_t out_ld,
                                                                      int64_t out_col_offset,
                                                                      char* __restrict__ big_k_scratch,
-                                                                     const uint32_t* __restrict__ run_if)
+                                                                     const uint32_t* __restrict__ run_if,
+                                                                     const uint8_t* __restrict__ done)
 {
   if (run_if != nullptr && *run_if == 0u) return;  // device-side guard: a fallback pass that is not needed
+  if (done != nullptr && done[blockIdx.x] != 0u) return;  // this row was served by select_k_minima_kernel
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int* hist      = reinterpret_cast<int*>(smem_raw);            // kBins
   int* scan      = hist + kBins;                                 // 32
@@ -184,6 +186,120 @@ __global__ __launch_bounds__(kSelThreads) void select_k_radix_kernel(const float
   }
 }
 
+
+// ------------------------------------------------------------------ short rows, small k: ONE read of the row
+// The radix kernel above streams a row four times (three histogram passes + the collect pass): at 10k x 16384 -> 128 (the
+// coarse search of the IVF-PQ bench shape) that is 2.6 GB of reads for 655 MB of distances, 0.71 of the 7.4 ms of a search.
+// For rows of at most 16384 elements the row fits the REGISTERS of a 256-thread workgroup (64 values per thread, all loads
+// of a thread in flight at once): every thread keeps the minima of two groups of its elements; the k-th smallest of the
+// 512 group minima bounds the row's k-th smallest key from above (k different elements are at or below it) and is close
+// to it (k = 128: about the 150th smallest); the ~k elements at or below that bound are collected in LDS straight from the
+// registers, sorted by (key, position) - the order and the tie rule of the radix kernel - and the first k written.
+// A row that collects more than the buffer holds (masses of equal keys) is left to the radix kernel (`done` stays 0).
+constexpr int kMinGroups = 512;   // two per thread
+constexpr int kMinCap    = 2048;  // candidates at or below the bound
+
+template <typename OutIdxT, int NV>  // NV: 16-byte vectors per thread (row length <= 1024 NV)
+__global__ __launch_bounds__(kSelThreads) void select_k_minima_kernel(const float* __restrict__ in, int64_t len, int64_t in_ld, int k,
+                                                                      float* __restrict__ out_val, OutIdxT* __restrict__ out_idx,
+                                                                      bool select_min, int64_t idx_offset, int64_t out_ld,
+                                                                      int64_t out_col_offset, uint8_t* __restrict__ done,
+                                                                      const uint32_t* __restrict__ run_if)
+{
+  if (run_if != nullptr && *run_if == 0u) return;
+  __shared__ __attribute__((aligned(16))) uint32_t tk[kMinGroups];
+  __shared__ unsigned long long cand[kMinCap];
+  __shared__ uint32_t ctrl[2];
+  const int tid        = threadIdx.x;
+  const int64_t row    = blockIdx.x;
+  const float4* r4     = reinterpret_cast<const float4*>(in + row * in_ld);
+  const uint32_t flip  = select_min ? 0u : 0xffffffffu;
+  const int n_vec      = (int)(len >> 2);
+  // ---- the row into registers: vector m of this thread = elements [4 (tid + 256 m), + 4); all loads issued before any use
+  float4 v[NV];
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    const int j = tid + kSelThreads * m;
+    v[m] = j < n_vec ? r4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tid == 0) { ctrl[0] = 0u; ctrl[1] = 0u; }
+  uint32_t gmin[2] = {0xffffffffu, 0xffffffffu};  // groups 2 tid (even m) and 2 tid + 1 (odd m)
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    if (tid + kSelThreads * m < n_vec) {
+      const uint32_t k0 = float_to_key(v[m].x) ^ flip, k1 = float_to_key(v[m].y) ^ flip, k2 = float_to_key(v[m].z) ^ flip,
+                     k3 = float_to_key(v[m].w) ^ flip;
+      gmin[m & 1] = min(gmin[m & 1], min(min(k0, k1), min(k2, k3)));
+    }
+  }
+  tk[2 * tid] = gmin[0];
+  tk[2 * tid + 1] = gmin[1];
+  __syncthreads();
+  // ---- the k-th smallest group minimum (ties by group number), by rank counting over broadcast reads
+  {
+    const uint4* tk4 = reinterpret_cast<const uint4*>(tk);
+    int rk[2] = {0, 0};
+    const uint32_t me[2] = {gmin[0], gmin[1]};
+    const int id[2]      = {2 * tid, 2 * tid + 1};
+#pragma unroll 4
+    for (int j = 0; j < kMinGroups / 4; ++j) {
+      const uint4 o = tk4[j];
+      const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) rk[w] += (ov[e] < me[w] || (ov[e] == me[w] && 4 * j + e < id[w])) ? 1 : 0;
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+      if (rk[w] == k - 1) ctrl[1] = me[w];
+  }
+  __syncthreads();
+  const uint32_t bound = ctrl[1];
+  // ---- the elements at or below the bound, from the registers: (key, position) packed, position = column in the row
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    const int j = tid + kSelThreads * m;
+    if (j < n_vec) {
+      const float e[4] = {v[m].x, v[m].y, v[m].z, v[m].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t key = float_to_key(e[c]) ^ flip;
+        if (key <= bound) {
+          const uint32_t pos = atomicAdd(&ctrl[0], 1u);
+          if (pos < (uint32_t)kMinCap) cand[pos] = ((unsigned long long)key << 32) | (uint32_t)(4 * j + c);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = ctrl[0];
+  if (cnt > (uint32_t)kMinCap || cnt < (uint32_t)k) return;  // (workgroup-uniform) masses of ties at the bound: the radix kernel
+  int P = 1;
+  while (P < (int)cnt) P <<= 1;
+  for (int t = (int)cnt + tid; t < P; t += kSelThreads) cand[t] = ~0ull;
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (P >> 1); t += kSelThreads) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = cand[lo], b = cand[hi];
+        if ((a > b) == up) { cand[lo] = b; cand[hi] = a; }
+      }
+    }
+  }
+  __syncthreads();
+  float* ov   = out_val + row * out_ld + out_col_offset;
+  OutIdxT* oi = out_idx + row * out_ld + out_col_offset;
+  for (int j = tid; j < k; j += kSelThreads) {
+    const unsigned long long c = cand[j];
+    ov[j] = key_to_float((uint32_t)(c >> 32) ^ flip);
+    oi[j] = (OutIdxT)((int64_t)(uint32_t)c + idx_offset);
+  }
+  if (tid == 0) done[row] = 1u;
+}
+
 }  // namespace
 
 template <typename InIdxT, typename OutIdxT>
@@ -201,8 +317,24 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
   // rows per launch when the winners live in global scratch: bounded by the workspace budget
   const int64_t rows_per = in_lds ? rows : std::max<int64_t>(1, (int64_t)(res.workspace_limit / ((size_t)kp2 * 12)));
   dev_buf<char> scratch(res, in_lds ? 0 : (size_t)std::min(rows, rows_per) * kp2 * 12);
+  // short rows and small k without source indices (the coarse searches of the IVF indexes, the per-tile selects of brute
+  // force): the one-read kernel first; the radix kernel below then only runs the rows it left (none, as a rule)
+  const bool minima = in_idx == nullptr && k >= 8 && k <= 256 && len >= 4096 && len <= 16384 && len % 4 == 0 && in_ld % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (int64_t)k * 8 <= len;
+  dev_buf<uint8_t> done(res, minima ? (size_t)rows : 0);
+  if (minima) {
+    HIP_TRY(hipMemsetAsync(done.data(), 0, (size_t)rows, res.stream));
+    auto launch_min = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(kSelThreads), 0, res.stream, in, len, in_ld, k, out_val, out_idx, select_min,
+                         idx_offset, out_ld, out_col_offset, done.data(), run_if);
+    };
+    if (len <= 4096)       launch_min(select_k_minima_kernel<OutIdxT, 4>);
+    else if (len <= 8192)  launch_min(select_k_minima_kernel<OutIdxT, 8>);
+    else                   launch_min(select_k_minima_kernel<OutIdxT, 16>);
+  }
   for (int64_t r0 = 0; r0 < rows; r0 += rows_per) {
     dim3 grid((unsigned)std::min(rows_per, rows - r0)), block(kSelThreads);
+    const uint8_t* done_r = minima ? done.data() + r0 : nullptr;
     const float* in_r      = in + r0 * in_ld;
     const InIdxT* in_idx_r = in_idx ? in_idx + r0 * in_ld : nullptr;
     float* out_val_r       = out_val + r0 * out_ld;
@@ -211,12 +343,12 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
       auto kern = select_k_radix_kernel<InIdxT, OutIdxT, true>;
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(kern, grid, block, smem, res.stream, in_r, in_idx_r, len, in_ld, k, kp2, out_val_r, out_idx_r,
-                         select_min, idx_offset, out_ld, out_col_offset, scratch.data(), run_if);
+                         select_min, idx_offset, out_ld, out_col_offset, scratch.data(), run_if, done_r);
     } else {
       auto kern = select_k_radix_kernel<InIdxT, OutIdxT, false>;
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(kern, grid, block, smem, res.stream, in_r, in_idx_r, len, in_ld, k, kp2, out_val_r, out_idx_r,
-                         select_min, idx_offset, out_ld, out_col_offset, scratch.data(), run_if);
+                         select_min, idx_offset, out_ld, out_col_offset, scratch.data(), run_if, done_r);
     }
   }
   HIP_TRY(hipGetLastError());

@@ -70,3 +70,25 @@ def test_select_k_large_k(rows, ln, k):
     gv, gi = _gpu_select(v, k, True)
     ov, oi = oracle.select_k(v, k, True)
     assert (gi == oi).all() and (gv == ov).all()
+
+
+@pytest.mark.parametrize("rows,ln,k", [(40, 16384, 128), (17, 4096, 64), (9, 8192, 256), (5, 12288, 8), (6, 16380, 100)])
+@pytest.mark.parametrize("select_min", [True, False])
+def test_select_k_one_read_kernel(rows, ln, k, select_min):
+    """Rows of 4096 .. 16384 elements and k <= 256 (the coarse searches): select_k_minima_kernel holds the row in registers
+    and bounds the k-th key by the k-th smallest of 512 group minima. Same values, indices and tie rule as the oracle on
+    random rows, on rows with masses of equal keys at the k-th value (the radix kernel takes those rows over) and with
+    infinities / signed zeros."""
+    rng = np.random.default_rng(ln + k)
+    v = rng.standard_normal((rows, ln)).astype(np.float32)
+    v[0, :] = 3.0                                   # one value everywhere: every element ties at the bound
+    v[1] = rng.integers(0, 4, size=ln)              # four distinct values
+    v[2, ::3] = -0.0
+    v[2, 1::3] = 0.0
+    v[3, :200] = np.inf
+    v[4, 100:400] = -np.inf
+    v[3, 7::11] = v[3, 5]                           # a few hundred ties somewhere in the row
+    gv, gi = _gpu_select(v, k, select_min)
+    ov, oi = oracle.select_k(v, k, select_min)
+    assert (gi == oi).all(), f"first mismatching row {np.nonzero((gi != oi).any(1))[0][:3]}"
+    assert (gv == ov).all()
