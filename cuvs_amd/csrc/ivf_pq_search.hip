@@ -2044,7 +2044,10 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const uint32_t n_labels = n_ranges + (sharded ? 1u : 0u);
   dev_buf<uint32_t> sorted_pairs(res, (size_t)n_pairs_max), pair_off(res, n_labels + 1), item_off(res, n_labels + 1);
   dev_buf<uint32_t> phase_labels(res, (head > 0 || sharded) ? (size_t)n_pairs_max : 0);
-  const int64_t max_items = n_pairs_max / qpb + n_labels + 1;
+  // (with the matrix-core tail phase the head pairs become single-pair items: one item per head pair on top of the
+  // qpb-pair items of the tail labels - the bound used to leave them out and the item array ran over by (queries x head)
+  // items whenever a batch was large against the number of lists: found in round 4 by a 1500-query x 24-list test)
+  const int64_t max_items = n_pairs_max / qpb + bs_alloc * (int64_t)head + n_labels + 1;
   dev_buf<work_item> items(res, (size_t)max_items);
   const size_t scores_ld = largest_total;
   dev_buf<float> cand_d(res, large_k ? (size_t)bs_alloc * scores_ld : (size_t)n_pairs_max * k);

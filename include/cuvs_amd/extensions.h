@@ -41,6 +41,15 @@ CUVS_EXPORT cuvsError_t cuvsAmdCagraSetGuaranteeConnectivity(cuvsResources_t res
 CUVS_EXPORT cuvsError_t cuvsAmdCagraOptimize(cuvsResources_t res, DLManagedTensor* knn_graph, DLManagedTensor* graph,
                                              int guarantee_connectivity);
 
+/* Measurement helpers of bench.py (no reference counterpart). cuvsAmdProfileEnable / cuvsAmdProfileCollect: HIP events
+ * around the named kernels on the handle's stream (Collect sums and resets the records of `name`, returns the launch count).
+ * cuvsAmdIvfPqLastFilterStats: counters of the last IVF-PQ search made by a handle created under CUVS_AMD_SCAN_DEBUG=1024
+ * (behind CUVS_AMD_DEBUG_SWITCHES=1): out = {(row, query) pairs screened by the matrix-core filter, survivors re-scored,
+ * 32-row subtiles decoded, work units}. */
+CUVS_EXPORT void cuvsAmdProfileEnable(int on);
+CUVS_EXPORT int cuvsAmdProfileCollect(const char* name, double* total_ms);
+CUVS_EXPORT void cuvsAmdIvfPqLastFilterStats(unsigned long long out[4]);
+
 #ifdef __cplusplus
 }
 #endif
