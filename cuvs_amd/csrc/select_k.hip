@@ -191,15 +191,14 @@ __global__ __launch_bounds__(kSelThreads) void select_k_radix_kernel(const float
 // The radix kernel above streams a row four times (three histogram passes + the collect pass): at 10k x 16384 -> 128 (the
 // coarse search of the IVF-PQ bench shape) that is 2.6 GB of reads for 655 MB of distances, 0.71 of the 7.4 ms of a search.
 // For rows of at most 16384 elements the row fits the REGISTERS of a 256-thread workgroup (64 values per thread, all loads
-// of a thread in flight at once): every thread keeps the minima of two groups of its elements; the k-th smallest of the
-// 512 group minima bounds the row's k-th smallest key from above (k different elements are at or below it) and is close
-// to it (k = 128: about the 150th smallest); the ~k elements at or below that bound are collected in LDS straight from the
+// of a thread in flight at once): every thread keeps the minimum of its elements (of two groups of them for k > 128); the
+// k-th smallest of the 256 (512) group minima bounds the row's k-th smallest key from above (k different elements are at
+// or below it) and is close to it (k = 128 of 16384: about the 180th smallest); the elements at or below that bound are collected in LDS straight from the
 // registers, sorted by (key, position) - the order and the tie rule of the radix kernel - and the first k written.
 // A row that collects more than the buffer holds (masses of equal keys) is left to the radix kernel (`done` stays 0).
-constexpr int kMinGroups = 512;   // two per thread
-constexpr int kMinCap    = 2048;  // candidates at or below the bound
+constexpr int kMinCap = 2048;  // candidates at or below the bound
 
-template <typename OutIdxT, int NV>  // NV: 16-byte vectors per thread (row length <= 1024 NV)
+template <typename OutIdxT, int NV, int G>  // NV: 16-byte vectors per thread (row length <= 1024 NV); G: groups per thread
 __global__ __launch_bounds__(kSelThreads) void select_k_minima_kernel(const float* __restrict__ in, int64_t len, int64_t in_ld, int k,
                                                                       float* __restrict__ out_val, OutIdxT* __restrict__ out_idx,
                                                                       bool select_min, int64_t idx_offset, int64_t out_ld,
@@ -207,7 +206,8 @@ __global__ __launch_bounds__(kSelThreads) void select_k_minima_kernel(const floa
                                                                       const uint32_t* __restrict__ run_if)
 {
   if (run_if != nullptr && *run_if == 0u) return;
-  __shared__ __attribute__((aligned(16))) uint32_t tk[kMinGroups];
+  constexpr int NGR = kSelThreads * G;
+  __shared__ __attribute__((aligned(16))) uint32_t tk[NGR];
   __shared__ unsigned long long cand[kMinCap];
   __shared__ uint32_t ctrl[2];
   const int tid        = threadIdx.x;
@@ -223,36 +223,38 @@ __global__ __launch_bounds__(kSelThreads) void select_k_minima_kernel(const floa
     v[m] = j < n_vec ? r4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (tid == 0) { ctrl[0] = 0u; ctrl[1] = 0u; }
-  uint32_t gmin[2] = {0xffffffffu, 0xffffffffu};  // groups 2 tid (even m) and 2 tid + 1 (odd m)
+  uint32_t gmin[G];  // group G tid + (m % G)
+#pragma unroll
+  for (int w = 0; w < G; ++w) gmin[w] = 0xffffffffu;
 #pragma unroll
   for (int m = 0; m < NV; ++m) {
     if (tid + kSelThreads * m < n_vec) {
       const uint32_t k0 = float_to_key(v[m].x) ^ flip, k1 = float_to_key(v[m].y) ^ flip, k2 = float_to_key(v[m].z) ^ flip,
                      k3 = float_to_key(v[m].w) ^ flip;
-      gmin[m & 1] = min(gmin[m & 1], min(min(k0, k1), min(k2, k3)));
+      gmin[m % G] = min(gmin[m % G], min(min(k0, k1), min(k2, k3)));
     }
   }
-  tk[2 * tid] = gmin[0];
-  tk[2 * tid + 1] = gmin[1];
+#pragma unroll
+  for (int w = 0; w < G; ++w) tk[G * tid + w] = gmin[w];
   __syncthreads();
   // ---- the k-th smallest group minimum (ties by group number), by rank counting over broadcast reads
   {
     const uint4* tk4 = reinterpret_cast<const uint4*>(tk);
-    int rk[2] = {0, 0};
-    const uint32_t me[2] = {gmin[0], gmin[1]};
-    const int id[2]      = {2 * tid, 2 * tid + 1};
+    int rk[G];
+#pragma unroll
+    for (int w = 0; w < G; ++w) rk[w] = 0;
 #pragma unroll 4
-    for (int j = 0; j < kMinGroups / 4; ++j) {
+    for (int j = 0; j < NGR / 4; ++j) {
       const uint4 o = tk4[j];
       const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int w = 0; w < 2; ++w) rk[w] += (ov[e] < me[w] || (ov[e] == me[w] && 4 * j + e < id[w])) ? 1 : 0;
+        for (int w = 0; w < G; ++w) rk[w] += (ov[e] < gmin[w] || (ov[e] == gmin[w] && 4 * j + e < G * tid + w)) ? 1 : 0;
     }
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
-      if (rk[w] == k - 1) ctrl[1] = me[w];
+    for (int w = 0; w < G; ++w)
+      if (rk[w] == k - 1) ctrl[1] = gmin[w];
   }
   __syncthreads();
   const uint32_t bound = ctrl[1];
@@ -328,9 +330,15 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
       hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(kSelThreads), 0, res.stream, in, len, in_ld, k, out_val, out_idx, select_min,
                          idx_offset, out_ld, out_col_offset, done.data(), run_if);
     };
-    if (len <= 4096)       launch_min(select_k_minima_kernel<OutIdxT, 4>);
-    else if (len <= 8192)  launch_min(select_k_minima_kernel<OutIdxT, 8>);
-    else                   launch_min(select_k_minima_kernel<OutIdxT, 16>);
+    if (k <= 128) {  // one group per thread: the rank counting over 256 minima is the cheaper half of the kernel
+      if (len <= 4096)       launch_min(select_k_minima_kernel<OutIdxT, 4, 1>);
+      else if (len <= 8192)  launch_min(select_k_minima_kernel<OutIdxT, 8, 1>);
+      else                   launch_min(select_k_minima_kernel<OutIdxT, 16, 1>);
+    } else {
+      if (len <= 4096)       launch_min(select_k_minima_kernel<OutIdxT, 4, 2>);
+      else if (len <= 8192)  launch_min(select_k_minima_kernel<OutIdxT, 8, 2>);
+      else                   launch_min(select_k_minima_kernel<OutIdxT, 16, 2>);
+    }
   }
   for (int64_t r0 = 0; r0 < rows; r0 += rows_per) {
     dim3 grid((unsigned)std::min(rows_per, rows - r0)), block(kSelThreads);
