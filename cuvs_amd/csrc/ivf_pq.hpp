@@ -46,6 +46,8 @@ struct ivf_pq_index {
   // fp16: centres / |c|^2 / rotation rounded to half (kept as floats); int8: trunc(x * 128) saturated, and the
   // per-centre norm term of the int8 GEMM (the y / z columns of centers_int8, ivf_pq_index.cu:674-732)
   mutable dev_buf<float> coarse_centers_h, coarse_norms_h, coarse_rot_h, coarse_centers_i8, coarse_normterm_i8, coarse_rot_i8;
+  // the centres packed in the coarse type for the fp16 / int8 matrix cores (coarse_lowp.hip), built on first use
+  mutable dev_buf<uint32_t> coarse_pack_h, coarse_pack_i8;
 
   // decode tables of the matrix-core filter (ivf_pq_scan3.hip), built on first use and rebuilt when the lists change
   struct scan3_cache {

@@ -752,12 +752,14 @@ struct head_params {
   uint32_t* query_kth;
   uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks;
   int is_ip;
+  int hcand;  // capacity of a candidate buffer (head_cand(k))
   const uint32_t* filter_bits;
   const int64_t* indices;
   unsigned long long* stats;  // optional [8]: workgroup cycles in header / LUT / scores / select / output, items
 };
 
-constexpr int kHCand = 512;  // candidates of a list chunk at or below its threshold (about k of them, k <= 128) + the kept ones
+// candidates of a list chunk at or below its threshold (about k of them) + the kept ones (up to k)
+static inline int head_cand(int k) { return k <= 128 ? 512 : 1024; }
 
 template <int LUT, bool ACC_HALF, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void pq_head_kernel(const head_params a)
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   unsigned long long* min64 = reinterpret_cast<unsigned long long*>(cv + 256);           // [2]
   int* ctrl       = reinterpret_cast<int*>(min64 + 2);                           // [8]
   uint32_t* tk    = reinterpret_cast<uint32_t*>(ctrl + 8);                       // [NT] smallest key of every thread
+  const int kHCand = a.hcand;
   uint32_t* ckey  = tk + NT;                                                     // [2][kHCand] candidates (two buffers)
   uint32_t* crow  = ckey + 2 * kHCand;                                           // [2][kHCand]
   uint32_t* keys  = crow + 2 * kHCand;                                           // [cap_rows] score keys of the current chunk
@@ -888,10 +891,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         keys[v] = key;
         my_min  = min(my_min, key);
       }
-      // minima of groups of four threads (k <= 64) or of two (k <= 128: at least 2 k groups keep the threshold tight) by
-      // DPP: each group is a set of rows of its own
-      const int gshift = k > 64 ? 1 : 2;
-      my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0xb1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+      // minima of groups of four threads (k <= 64), of two (k <= 128) or of one (k <= 256: at least 2 k groups keep the
+      // threshold tight) by DPP: each group is a set of rows of its own
+      const int gshift = k > 128 ? 0 : (k > 64 ? 1 : 2);
+      if (gshift >= 1)
+        my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0xb1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
       if (gshift == 2)
         my_min = min(my_min, (uint32_t)__builtin_amdgcn_update_dpp((int)my_min, (int)my_min, 0x4e, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
       if ((tid & ((1 << gshift) - 1)) == 0) tk[tid >> gshift] = my_min;
@@ -1179,7 +1183,7 @@ bool pq3_supported(const ivf_pq_index& idx, int k)
   // pq_len 2 (a lane's 8 K elements of an MFMA step = 4 subspaces = 4 code bytes), whole 16-byte code chunks, a decode
   // table of at most 128 KiB
   return idx.pq_bits == 8 && idx.pq_len == 2 && idx.pq_dim % 16 == 0 && idx.pq_dim >= 16 && idx.pq_dim <= 128 &&
-         idx.rot_dim == 2 * idx.pq_dim && idx.codebook_kind == 0 && k <= 128;
+         idx.rot_dim == 2 * idx.pq_dim && idx.codebook_kind == 0 && k <= 256;
 }
 
 pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_fp32)
@@ -1335,10 +1339,10 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   profile_end(res, "pq_scan_kernel");
 }
 
-static size_t head_smem_fixed(const ivf_pq_index& idx, int lut_mode, bool acc_half, int nt)
+static size_t head_smem_fixed(const ivf_pq_index& idx, int lut_mode, bool acc_half, int nt, int k)
 {
   const bool lut32 = lut_mode == 0 || (lut_mode == 2 && !acc_half);
-  return (size_t)idx.pq_dim * 256 * (lut32 ? 4 : 2) + 2 * 256 * 4 + 16 + 32 + (size_t)nt * 4 + 4 * kHCand * 4;
+  return (size_t)idx.pq_dim * 256 * (lut32 ? 4 : 2) + 2 * 256 * 4 + 16 + 32 + (size_t)nt * 4 + 4 * (size_t)head_cand(k) * 4;
 }
 
 void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
@@ -1349,14 +1353,14 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   a.pq_centers = idx.pq_centers.data(); a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data();
   a.list_sizes = idx.list_sizes.data(); a.out_d = h.cand_d; a.out_i = h.cand_i; a.query_kth = h.query_kth;
   a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip; a.pq_dim = idx.pq_dim; a.n_chunks = idx.n_chunks;
-  a.filter_bits = h.filter_bits; a.indices = idx.indices.data(); a.stats = h.stats;
+  a.filter_bits = h.filter_bits; a.indices = idx.indices.data(); a.stats = h.stats; a.hcand = head_cand((int)h.k);
   // A LUT of up to 32 KiB (fp16 entries at pq_dim 64): two 512-thread workgroups per CU, one streams its list while the
   // other selects; beyond: one 1024-thread workgroup. The rest of the LDS holds the score keys of a list chunk; longer
   // lists are scanned in chunks.
   const bool lut32 = h.lut_mode == 0 || (h.lut_mode == 2 && !h.acc_half);
   const bool small = (size_t)idx.pq_dim * 256 * (lut32 ? 4 : 2) <= 32 * 1024;
   const int nt = small ? 512 : 1024;
-  const size_t budget = (small ? 80 : 160) * 1024 - 64, fixed = head_smem_fixed(idx, h.lut_mode, h.acc_half != 0, nt);
+  const size_t budget = (small ? 80 : 160) * 1024 - 64, fixed = head_smem_fixed(idx, h.lut_mode, h.acc_half != 0, nt, (int)h.k);
   CUVS_EXPECTS(budget > fixed + 4096, "ivf_pq: the head-phase LUT does not fit the LDS");
   a.cap_rows = (uint32_t)(((budget - fixed) / 4) & ~size_t(63));
   if (h.max_list_len > 0) a.cap_rows = std::min<uint32_t>(a.cap_rows, (uint32_t)round_up(h.max_list_len, 64));
@@ -1504,12 +1508,14 @@ void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)
   hipLaunchKernelGGL(ov_scan_kernel, dim3(1), dim3(1024), 0, res.stream, r.ov_cnt, r.nq, r.ov_off);
   hipLaunchKernelGGL(ov_fill_kernel, dim3(256), dim3(256), 0, res.stream, ov, r.counters + 1, r.overflow_cap, r.ov_off, r.ov_cnt,
                      ov + r.overflow_cap);
-  if (r.k <= 64)
-    hipLaunchKernelGGL(pool_merge_kernel<1>, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
-                       r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, ov + r.overflow_cap, r.ov_off);
-  else
-    hipLaunchKernelGGL(pool_merge_kernel<2>, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt,
-                       r.qflag, r.nq, r.n_probes, r.k, r.head, top_d, top_i, ov + r.overflow_cap, r.ov_off);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.cand_d, r.cand_i, r.cand_r, r.qcnt, r.qflag, r.nq,
+                       r.n_probes, r.k, r.head, top_d, top_i, ov + r.overflow_cap, r.ov_off);
+  };
+  if (r.k <= 64)       go(pool_merge_kernel<1>);
+  else if (r.k <= 128) go(pool_merge_kernel<2>);
+  else if (r.k <= 192) go(pool_merge_kernel<3>);
+  else                 go(pool_merge_kernel<4>);
 }
 
 }  // namespace cuvs_amd

@@ -1864,12 +1864,26 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
     const int64_t nqe = nq * idx.dim;
     if (half_t) hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(nqe, 256)), dim3(256), 0, res.stream, qf, qc, nqe, (int64_t)idx.dim, (int64_t)idx.dim);
     else        hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(nqe, 256)), dim3(256), 0, res.stream, qf, qc, nqe, (int64_t)idx.dim, (int64_t)idx.dim);
-    pairwise_distance<float, float>(res, qc, nq, idx.dim, cc.data(), idx.n_lists, idx.dim, idx.dim, nullptr, nullptr,
-                                    M_InnerProduct, dist.data(), idx.n_lists);
     // half: the norm column only takes part for L2 (norm_factor 0 otherwise); int8: the z column always does
     const float* term = (half_t && ip) ? nullptr : ct.data();
-    hipLaunchKernelGGL(coarse_finish_kernel, dim3(nblk(nq * idx.n_lists, 256)), dim3(256), 0, res.stream, dist.data(), nq,
-                       (int)idx.n_lists, term, ip ? -1.0f : -2.0f, half_t);
+    if (res.tune.coarse_lowp != 0) {
+      // the products on the matrix cores of the coarse type, the output arithmetic in the kernel's epilogue
+      const size_t row_b = (size_t)coarse_lowp_ksteps(!half_t, idx.dim) * 32;
+      dev_buf<uint32_t>& cp = half_t ? idx.coarse_pack_h : idx.coarse_pack_i8;
+      if (cp.data() == nullptr) {
+        cp = dev_buf<uint32_t>::persistent((size_t)idx.n_lists * row_b / 4);
+        coarse_lowp_pack(res, !half_t, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim, cp.data());
+      }
+      dev_buf<uint32_t> qp(res, (size_t)nq * row_b / 4);
+      coarse_lowp_pack(res, !half_t, qf, nq, idx.dim, idx.dim, qp.data());
+      coarse_lowp_distances(res, !half_t, qp.data(), nq, cp.data(), idx.n_lists, idx.dim, term, ip ? -1.0f : -2.0f, dist.data(),
+                            idx.n_lists);
+    } else {
+      pairwise_distance<float, float>(res, qc, nq, idx.dim, cc.data(), idx.n_lists, idx.dim, idx.dim, nullptr, nullptr,
+                                      M_InnerProduct, dist.data(), idx.n_lists);
+      hipLaunchKernelGGL(coarse_finish_kernel, dim3(nblk(nq * idx.n_lists, 256)), dim3(256), 0, res.stream, dist.data(), nq,
+                         (int)idx.n_lists, term, ip ? -1.0f : -2.0f, half_t);
+    }
     select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),
                                  probes, true);
     return;

@@ -50,6 +50,14 @@ void pairwise_threshold_append(resources& res, const TQ* q, int64_t m, int64_t l
 // (col_stride: the source id of column j is col_off + j * col_stride - a strided view of a larger matrix; thr: [m] thresholds
 // taken instead of the rows' current k-th values, e.g. the next float up so that ties at the k-th value are appended too)
 
+// Reduced-precision coarse search (coarse_lowp.hip): rows packed as fp16 / int8 K steps of 32 bytes (zero-padded), the
+// query x centre products on the fp16 / int8 matrix cores with the reference's output arithmetic in the epilogue
+// (ivf_pq_search.cuh:171-340): half: out = half(alpha (dot - term / 2)) (term nullptr: half(alpha dot)); int8: alpha (dot + term)
+int coarse_lowp_ksteps(bool i8, int64_t cols);  // 32-byte K steps of a packed row
+void coarse_lowp_pack(resources& res, bool i8, const float* in, int64_t n, int64_t ld_in, int64_t cols, void* out);
+void coarse_lowp_distances(resources& res, bool i8, const void* q_pack, int64_t nq, const void* c_pack, int64_t n, int64_t cols,
+                           const float* term, float alpha, float* out, int64_t ldo);
+
 // labels[i] = argmin_j ( xn_j - 2 dot(Q_i, X_j) ) (ties -> smallest j); optional min value out
 // (= squared L2 distance minus |q|^2). The k-means E-step and IVF list assignment.
 template <typename TQ>

@@ -93,6 +93,23 @@ def test_c3_shape_lists_of_thousands_of_rows(big_lists, lut, acc, monkeypatch):
     assert (gi == pi).all() and (gd == pd).all()
 
 
+@pytest.mark.parametrize("k", [129, 200, 256])
+def test_c3_shape_k_up_to_256(big_lists, k, monkeypatch):
+    """k = 129 .. 256 (the IVF-PQ searches of a CAGRA build ask for 2 x intermediate_graph_degree = 256 candidates,
+    cagra_build.cuh:120-190) on the two-phase path: head kernel with one group minimum per thread and 1024-entry candidate
+    buffers, pool merge with three / four ranks per lane - identical to the oracle and to the LUT scan kernels."""
+    x, q, index, ex = big_lists
+    n_probes = 12
+    kw = dict(n_probes=n_probes, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut="f16", acc="f32")
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (si == oi).all() and (sd == od).all()
+
+
 @pytest.mark.parametrize("n_queries,n_lists", [(300, 96), (260, 32), (700, 48), (1500, 24)])
 def test_c3_shape_query_groups_of_every_width(n_queries, n_lists, monkeypatch):
     """pq_filter4_kernel holds up to four groups of 32 queries per work unit and is instantiated per group count: batches

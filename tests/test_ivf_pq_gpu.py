@@ -417,6 +417,27 @@ def test_coarse_search_dtype_parity(coarse, metric, n, d, n_lists, pq_dim):
     assert (gd == od).all()
 
 
+@pytest.mark.parametrize("coarse", ["f16", "i8"])
+@pytest.mark.parametrize("n,d,n_lists,nq", [(20000, 128, 200, 333), (9000, 300, 50, 130), (12000, 96, 1000, 257)])
+def test_coarse_search_dtype_matrix_core_kernel(coarse, n, d, n_lists, nq, monkeypatch):
+    """coarse_lowp_kernel (fp16 / int8 matrix cores, output arithmetic in the epilogue): ragged query blocks and centre
+    tiles, K steps in registers (d 96 / 128) and re-read (d 300) - identical to the oracle and to the same search with the
+    rounded operands on the fp32 matrix cores (CUVS_AMD_COARSE_LOWP=0)."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d)).astype(np.float32) * 0.3
+    q = rng.standard_normal((nq, d)).astype(np.float32) * 0.3
+    index = _build(x, n_lists=n_lists, pq_dim=32, kmeans_n_iters=6)
+    gd, gi = _search(index, q, 10, n_probes=9, coarse_search_dtype=_COARSE[coarse])
+    od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, 10, 9, coarse=coarse)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_COARSE_LOWP", "0")
+    fd, fi = _search(index, q, 10, n_probes=9, coarse_search_dtype=_COARSE[coarse])
+    assert (fi == gi).all() and (fd == gd).all()
+
+
 def test_coarse_search_dtype_recall_thresholds():
     """ann_ivf_pq.cuh:1036-1046: defaults + coarse_search_dtype = CUDA_R_16F -> min_recall 0.86; CUDA_R_8I -> 0.1
     ("experimental ... no guarantee of any recall if the data is not normalized")."""
