@@ -40,13 +40,15 @@ struct bprep_params {
   uint32_t n_probes, rot_dim;
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
   int is_ip, flat;
+  uint32_t lpl;  // log2(pq_len)
 };
 
-// one wave per 32 consecutive tail pairs, lane = (pair ql, K half h) - the B-operand layout of v_mfma_f32_32x32x16_f16
-template <int NCH>
+// one wave per 32 consecutive tail pairs, lane = (pair ql, K half h) - the B-operand layout of v_mfma_f32_32x32x16_f16.
+// K step st = c * pq_len + t of the filter holds, in K half h, the 8 rotated dimensions from pq_len (16 c + 8 h) + 8 t on:
+// the components of the subspaces whose code bytes are the h-th 8 bytes of the row's 16-byte code chunk c, in order
+template <int NST>
 __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
 {
-  constexpr int NST = 2 * NCH;
   const uint32_t s_base = a.pair_off[a.n_lists], s_end = a.pair_off[2 * a.n_lists];
   const uint32_t lane = threadIdx.x & 63u, ql = lane & 31u, h = lane >> 5;
   const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 32u;
@@ -61,10 +63,10 @@ __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
   float rn = 0.f, big = 0.f, qc = 0.f, cn = 0.f;
 #pragma unroll
   for (int st = 0; st < NST; ++st) {
-    const uint32_t s0 = 16u * (st >> 1) + 8u * h + 4u * (st & 1);
-    const float4 q0 = *reinterpret_cast<const float4*>(rq + 2 * s0), q1 = *reinterpret_cast<const float4*>(rq + 2 * s0 + 4);
+    const uint32_t d0 = ((16u * ((uint32_t)st >> a.lpl) + 8u * h) << a.lpl) + 8u * ((uint32_t)st & ((1u << a.lpl) - 1u));
+    const float4 q0 = *reinterpret_cast<const float4*>(rq + d0), q1 = *reinterpret_cast<const float4*>(rq + d0 + 4);
     float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-    const float4 c0 = *reinterpret_cast<const float4*>(ct + 2 * s0), c1 = *reinterpret_cast<const float4*>(ct + 2 * s0 + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(ct + d0), c1 = *reinterpret_cast<const float4*>(ct + d0 + 4);
     const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     if (!a.is_ip) {
 #pragma unroll
@@ -121,8 +123,8 @@ struct filter4_params {
   unsigned long long* stats;  // optional [8] as in pq_filter_kernel
 };
 
-// LDS byte address of a decode-table entry in ONE instruction: the low word of `addr` becomes (byte BYTE of w) << 2, its
-// high word - the lane's K half: the two halves' tables lie 64 KiB apart - stays (v_bfe_u32 + v_lshl_add_u32 otherwise:
+// LDS byte address of a decode-table entry in ONE instruction: the low word of `addr` becomes (byte BYTE of w) << two (the
+// shift = log2 of an entry's bytes), its high word - the lane's K half: the two halves' tables lie 64 KiB apart - stays (v_bfe_u32 + v_lshl_add_u32 otherwise:
 // with one wave per SIMD every instruction of the subtile loop is an issue slot the matrix pipe waits behind)
 template <int BYTE>
 __device__ inline void table_addr(uint32_t& addr, const uint32_t two, const uint32_t w)
@@ -143,12 +145,17 @@ typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
 // DBG: ablations (timing only, wrong results): 1 conflict-free gathers, 2 no gathers, 4 no MFMAs, 8 no code loads
 // STATS: the counters / cycle stamps of CUVS_AMD_SCAN_DEBUG=1024 (s_memtime is a scalar memory operation: in the subtile
 // loop it would make every wait on the gathers a wait for everything)
-template <int NCH, bool TERM, int DBG, bool STATS = false>
+// PL: pq_len (1, 2, 4, 8): a code byte stands for PL fp16 values - the lane's 8 K elements of an MFMA step are 8 / PL
+// codebook entries of 2 PL bytes; the 8 code bytes a lane holds of a chunk feed PL consecutive K steps
+template <int NCH, int PL, bool TERM, int DBG, bool STATS = false>
 __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_params a)
 {
-  constexpr int NST = 2 * NCH;           // MFMA K steps
-  constexpr int NGM = NCH <= 4 ? 4 : 2;  // groups of 32 queries per work unit
-  // LDS: K half 0 of every 16-subspace chunk at [0, NCH * 8 KiB), K half 1 at 64 KiB + the same (table_addr)
+  constexpr int NST = PL * NCH;          // MFMA K steps
+  constexpr int NGM = NST <= 8 ? 4 : 2;  // groups of 32 queries per work unit
+  constexpr int NGA = 8 / PL;            // gathers (and table addresses) per K step
+  constexpr uint32_t kEntry = 2u * PL;   // bytes of a decode-table entry
+  constexpr uint32_t kSlot  = 256u * kEntry;  // bytes of a subspace's table
+  // LDS: K half 0 of every 16-subspace chunk at [0, NCH * 8 slots), K half 1 at 64 KiB + the same (table_addr)
   constexpr uint32_t kHalf1 = 65536u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // survivors: the buffer is handed out in chunks of kSurvChunk entries - a wave draws a chunk with ONE global atomic and
@@ -156,10 +163,10 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
   // gathers in the LDS queue, which returns in order: a full drain per survivor; fixed per-wave regions run over on the
   // waves whose lists hold the dense regions of the corpus). A chunk's unused tail is padded with invalid entries.
   uint32_t s_chunk = 0xffffffffu, s_fill = kSurvChunk;  // wave-uniform: current chunk, entries written to it
-  for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * 256u / 4u; i += kF4Threads) {
-    // a.cb16: [subspace s][256 codes]; subspace s = 16 c + 8 half + j goes to half's table at (8 c + j) * 1 KiB
-    const uint32_t s = i >> 6, half = (s >> 3) & 1u, slot = (s >> 4) * 8u + (s & 7u);
-    *reinterpret_cast<uint4*>(smem + half * kHalf1 + slot * 1024u + (i & 63u) * 16u) = reinterpret_cast<const uint4*>(a.cb16)[i];
+  for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * (kSlot / 16u); i += kF4Threads) {
+    // a.cb16: [subspace s][256 codes][PL]; subspace s = 16 c + 8 half + j goes to half's table at slot 8 c + j
+    const uint32_t s = i / (kSlot / 16u), half = (s >> 3) & 1u, slot = (s >> 4) * 8u + (s & 7u);
+    *reinterpret_cast<uint4*>(smem + half * kHalf1 + slot * kSlot + (i % (kSlot / 16u)) * 16u) = reinterpret_cast<const uint4*>(a.cb16)[i];
   }
   __syncthreads();
 
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
   const uint32_t chunk   = (n_units + 7u) / 8u;
   const uint32_t s_base  = a.pair_off[a.n_lists];
   uint32_t xcd = blockIdx.x & 7u, hops = 0u;
-  const uint32_t two = 2u;
+  const uint32_t two = PL == 1 ? 1u : PL == 2 ? 2u : PL == 4 ? 3u : 4u;  // log2(kEntry)
   const uint32_t lane_code_off = ql * 16u + h * 8u, lane_term_off = h * 16u;  // byte offsets of this lane inside a subtile
 
   unsigned long long st_pairs = 0, st_surv = 0, st_sub = 0, st_slow = 0, st_units = 0, st_t[3] = {0, 0, 0};
@@ -224,23 +231,62 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
         else cw[c] = *reinterpret_cast<const uint2*>(p + c * 1024);
       }
     };
-    // the four gathers of K step st: lane (row, half) looks up the fp16x2 codebook entries of four of its row's codes
-    uint32_t ad[4] = {h << 16, h << 16, h << 16, h << 16};  // table addresses: high word = K half, low word rewritten per gather
+    // the gathers of K step st = c * PL + t: lane (row, half) looks up the codebook entries of 8 / PL of its row's codes -
+    // bytes t * 8 / PL .. of the 8 it holds of chunk c
+    uint32_t ad[NGA];  // table addresses: high word = K half, low word rewritten per gather
+#pragma unroll
+    for (int e = 0; e < NGA; ++e) ad[e] = h << 16;
     auto decode_addr = [&](const uint2 (&cw)[NCH], const int st) {
-      uint32_t w = (st & 1) ? cw[st >> 1].y : cw[st >> 1].x;
-      if constexpr ((DBG & 1) != 0) w = ql * 0x01010101u;  // ablation: every lane of a half in its own bank
-      table_addr<0>(ad[0], two, w);
-      table_addr<1>(ad[1], two, w);
-      table_addr<2>(ad[2], two, w);
-      table_addr<3>(ad[3], two, w);
+      const int c = st / PL, b0 = (st % PL) * NGA;  // first code byte of the step
+      if constexpr ((DBG & 1) != 0) {  // ablation: every lane of a half in its own bank
+        const uint32_t w = ql * 0x01010101u;
+        if constexpr (NGA >= 1) table_addr<0>(ad[0], two, w);
+        if constexpr (NGA >= 2) table_addr<1>(ad[1], two, w);
+        if constexpr (NGA >= 4) { table_addr<2>(ad[2], two, w); table_addr<3>(ad[3], two, w); }
+        return;
+      }
+      auto one = [&](const int e) {  // byte b0 + e of the lane's 8
+        const int b = b0 + e;
+        const uint32_t w = b < 4 ? cw[c].x : cw[c].y;
+        switch (b & 3) {
+          case 0: table_addr<0>(ad[e], two, w); break;
+          case 1: table_addr<1>(ad[e], two, w); break;
+          case 2: table_addr<2>(ad[e], two, w); break;
+          default: table_addr<3>(ad[e], two, w); break;
+        }
+      };
+#pragma unroll
+      for (int e = 0; e < NGA; ++e) one(e);
     };
     auto decode_gather = [&](const int st, u32x4_t (&av)[NST]) {
       constexpr uint32_t kNone = 0u;
-      const uint32_t slot0 = (8u * (st >> 1) + 4u * (st & 1)) * 1024u;
+      const uint32_t slot0 = (8u * (st / PL) + (uint32_t)((st % PL) * NGA)) * kSlot;
+      if constexpr ((DBG & 2) != 0) {  // ablation: no gathers
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if constexpr ((DBG & 2) != 0) av[st][e] = ad[e] + kNone;  // ablation: no gathers
-        else av[st][e] = *reinterpret_cast<lds_u32_t*>(ad[e] + slot0 + e * 1024u);
+        for (int e = 0; e < 4; ++e) av[st][e] = ad[e % NGA] + kNone;
+        return;
+      }
+      if constexpr (PL == 1) {
+        // eight 2-byte entries: ds_read_u16_d16 / _d16_hi fill the two halves of a register
+        typedef __attribute__((address_space(3))) const _Float16 lds_f16_t;
+        f16x8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<lds_f16_t*>(ad[e] + slot0 + e * kSlot);
+        av[st] = __builtin_bit_cast(u32x4_t, v);
+      } else if constexpr (PL == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[st][e] = *reinterpret_cast<lds_u32_t*>(ad[e] + slot0 + e * kSlot);
+      } else if constexpr (PL == 4) {
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) const u32x2_t lds_u64_t;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const u32x2_t v = *reinterpret_cast<lds_u64_t*>(ad[e] + slot0 + e * kSlot);
+          av[st][2 * e] = v[0]; av[st][2 * e + 1] = v[1];
+        }
+      } else {
+        typedef __attribute__((address_space(3))) const u32x4_t lds_u128_t;
+        av[st] = *reinterpret_cast<lds_u128_t*>(ad[0] + slot0);
       }
     };
     auto decode_step = [&](const uint2 (&cw)[NCH], const int st, u32x4_t (&av)[NST]) {
@@ -377,7 +423,7 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
             __builtin_amdgcn_sched_barrier(0);
           };
           mfma(0);
-          if (st == 1 || NST == 1) load_term(u + 2, tv[C]);  // (every MFMA of step 0 has read tv[C] by now)
+          if (st == 1) load_term(u + 2, tv[C]);  // (every MFMA of step 0 has read tv[C] by now)
           decode_addr(cw[S], st);
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (NG >= 2) mfma(1);
@@ -392,6 +438,7 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (NG >= 4) mfma(3);
         }
+        if constexpr (NST == 1) load_term(u + 2, tv[C]);
       };
       using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
       using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
@@ -449,19 +496,28 @@ void pq4_filter(resources& res, const filter4_launch& l)
   b.bq = static_cast<uint4*>(l.bq); b.thr = l.thr; b.n_probes = l.n_probes; b.rot_dim = l.rot_dim;
   b.sc = l.sc; b.c1 = l.c1; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = l.cbmax; b.dmax = l.dmax; b.bound_max = l.bound_max;
   b.is_ip = l.is_ip; b.flat = 0;
+  b.lpl = l.pl == 1 ? 0u : l.pl == 2 ? 1u : l.pl == 4 ? 2u : 3u;
+  const int nst = l.nch * l.pl;  // MFMA K steps
   const unsigned pgrid = (unsigned)grid_blocks(l.n_pairs, 128);
   profile_begin(res, "pq_bprep_kernel");
-  switch (l.nch) {
+  auto prep = [&](auto nst_tag) {
+    hipLaunchKernelGGL(pq_bprep_kernel<decltype(nst_tag)::value>, dim3(pgrid), dim3(256), 0, res.stream, b);
+  };
+  switch (nst) {
 #ifndef CUVS_AMD_F4_DEV
-    case 1: hipLaunchKernelGGL(pq_bprep_kernel<1>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
-    case 2: hipLaunchKernelGGL(pq_bprep_kernel<2>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
-    case 3: hipLaunchKernelGGL(pq_bprep_kernel<3>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
-    case 5: hipLaunchKernelGGL(pq_bprep_kernel<5>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
-    case 6: hipLaunchKernelGGL(pq_bprep_kernel<6>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
-    case 7: hipLaunchKernelGGL(pq_bprep_kernel<7>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
-    case 8: hipLaunchKernelGGL(pq_bprep_kernel<8>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    case 1: prep(std::integral_constant<int, 1>{}); break;
+    case 2: prep(std::integral_constant<int, 2>{}); break;
+    case 3: prep(std::integral_constant<int, 3>{}); break;
+    case 4: prep(std::integral_constant<int, 4>{}); break;
+    case 5: prep(std::integral_constant<int, 5>{}); break;
+    case 6: prep(std::integral_constant<int, 6>{}); break;
+    case 7: prep(std::integral_constant<int, 7>{}); break;
+    case 10: prep(std::integral_constant<int, 10>{}); break;
+    case 12: prep(std::integral_constant<int, 12>{}); break;
+    case 14: prep(std::integral_constant<int, 14>{}); break;
+    case 16: prep(std::integral_constant<int, 16>{}); break;
 #endif
-    default: hipLaunchKernelGGL(pq_bprep_kernel<4>, dim3(pgrid), dim3(256), 0, res.stream, b); break;
+    default: prep(std::integral_constant<int, 8>{}); break;
   }
   profile_end(res, "pq_bprep_kernel");
   filter4_params g{};
@@ -470,7 +526,7 @@ void pq4_filter(resources& res, const filter4_launch& l)
   g.list_sizes = l.list_sizes; g.row_term = l.row_term; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
   g.surv_cnt = l.surv_cnt; g.n_chunks = l.surv_entries / kSurvChunk; g.n_probes = l.n_probes; g.unit_rows = l.unit_rows;
   g.stats = l.stats;
-  const size_t fsmem = 65536 + (size_t)l.nch * 8 * 1024;  // the two K halves of the decode table lie 64 KiB apart
+  const size_t fsmem = 65536 + (size_t)l.nch * 8 * 512 * l.pl;  // the two K halves of the decode table lie 64 KiB apart
   const bool term = l.row_term != nullptr;
   auto launch = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
@@ -479,39 +535,66 @@ void pq4_filter(resources& res, const filter4_launch& l)
     profile_end(res, "pq_filter_kernel");
   };
 #ifndef CUVS_AMD_F4_DEV
-  if (l.nch == 4) {
+  if (l.nch == 4 && l.pl == 2) {
     switch (l.dbg) {  // CUVS_AMD_SCAN_DEBUG bits 16..19: ablation builds of the kernel (bench shape only)
-      case 1:  launch(pq_filter4_kernel<4, true, 1>); break;
-      case 2:  launch(pq_filter4_kernel<4, true, 2>); break;
-      case 4:  launch(pq_filter4_kernel<4, true, 4>); break;
-      case 8:  launch(pq_filter4_kernel<4, true, 8>); break;
-      case 16: launch(pq_filter4_kernel<4, true, 16>); break;
-      case 64: launch(pq_filter4_kernel<4, true, 64>); break;
-      case 80: launch(pq_filter4_kernel<4, true, 80>); break;
-      case 81: launch(pq_filter4_kernel<4, true, 81>); break;
+      case 1:  launch(pq_filter4_kernel<4, 2, true, 1>); break;
+      case 2:  launch(pq_filter4_kernel<4, 2, true, 2>); break;
+      case 4:  launch(pq_filter4_kernel<4, 2, true, 4>); break;
+      case 8:  launch(pq_filter4_kernel<4, 2, true, 8>); break;
+      case 16: launch(pq_filter4_kernel<4, 2, true, 16>); break;
+      case 64: launch(pq_filter4_kernel<4, 2, true, 64>); break;
+      case 80: launch(pq_filter4_kernel<4, 2, true, 80>); break;
+      case 81: launch(pq_filter4_kernel<4, 2, true, 81>); break;
       default:
-        if (l.stats != nullptr && term) launch(pq_filter4_kernel<4, true, 0, true>);
-        else if (term) launch(pq_filter4_kernel<4, true, 0>);
-        else launch(pq_filter4_kernel<4, false, 0>);
+        if (l.stats != nullptr && term) launch(pq_filter4_kernel<4, 2, true, 0, true>);
+        else if (term) launch(pq_filter4_kernel<4, 2, true, 0>);
+        else launch(pq_filter4_kernel<4, 2, false, 0>);
         break;
     }
     return;
   }
-  auto pick = [&](auto nch_tag) {
-    constexpr int N = decltype(nch_tag)::value;
-    if (term) launch(pq_filter4_kernel<N, true, 0>); else launch(pq_filter4_kernel<N, false, 0>);
+  auto pick = [&](auto nch_tag, auto pl_tag) {
+    constexpr int N = decltype(nch_tag)::value, P = decltype(pl_tag)::value;
+    if (term) launch(pq_filter4_kernel<N, P, true, 0>); else launch(pq_filter4_kernel<N, P, false, 0>);
   };
-  switch (l.nch) {
-    case 1: pick(std::integral_constant<int, 1>{}); break;
-    case 2: pick(std::integral_constant<int, 2>{}); break;
-    case 3: pick(std::integral_constant<int, 3>{}); break;
-    case 5: pick(std::integral_constant<int, 5>{}); break;
-    case 6: pick(std::integral_constant<int, 6>{}); break;
-    case 7: pick(std::integral_constant<int, 7>{}); break;
-    default: pick(std::integral_constant<int, 8>{}); break;
+  using N1 = std::integral_constant<int, 1>; using N2 = std::integral_constant<int, 2>; using N3 = std::integral_constant<int, 3>;
+  using N4 = std::integral_constant<int, 4>; using N5 = std::integral_constant<int, 5>; using N6 = std::integral_constant<int, 6>;
+  using N7 = std::integral_constant<int, 7>; using N8 = std::integral_constant<int, 8>;
+  CUVS_EXPECTS(nst >= 1 && nst <= 16 && l.nch >= 1 && l.nch <= 8, "ivf_pq: shape outside the matrix-core filter (pq3_supported)");
+  if (l.pl == 2) {
+    switch (l.nch) {
+      case 1: pick(N1{}, N2{}); break;
+      case 2: pick(N2{}, N2{}); break;
+      case 3: pick(N3{}, N2{}); break;
+      case 4: pick(N4{}, N2{}); break;
+      case 5: pick(N5{}, N2{}); break;
+      case 6: pick(N6{}, N2{}); break;
+      case 7: pick(N7{}, N2{}); break;
+      default: pick(N8{}, N2{}); break;
+    }
+  } else if (l.pl == 1) {
+    switch (l.nch) {
+      case 1: pick(N1{}, N1{}); break;
+      case 2: pick(N2{}, N1{}); break;
+      case 3: pick(N3{}, N1{}); break;
+      case 4: pick(N4{}, N1{}); break;
+      case 5: pick(N5{}, N1{}); break;
+      case 6: pick(N6{}, N1{}); break;
+      case 7: pick(N7{}, N1{}); break;
+      default: pick(N8{}, N1{}); break;
+    }
+  } else if (l.pl == 4) {
+    switch (l.nch) {
+      case 1: pick(N1{}, N4{}); break;
+      case 2: pick(N2{}, N4{}); break;
+      case 3: pick(N3{}, N4{}); break;
+      default: pick(N4{}, N4{}); break;
+    }
+  } else {
+    if (l.nch == 1) pick(N1{}, N8{}); else pick(N2{}, N8{});
   }
 #else
-  launch(pq_filter4_kernel<4, true, 0>);
+  launch(pq_filter4_kernel<4, 2, true, 0>);
 #endif
 }
 

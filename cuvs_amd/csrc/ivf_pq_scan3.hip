@@ -51,14 +51,14 @@ constexpr int kFWaves   = kFThreads / 64;
 
 
 // ------------------------------------------------------------------ per-index tables
-__global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, float sc, uint32_t* __restrict__ cb16)
+__global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, uint32_t pq_len, float sc, uint16_t* __restrict__ cb16)
 {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // s * 256 + code
   if (e >= pq_dim * 256u) return;
   const uint32_t s = e >> 8, code = e & 255u;
-  const _Float16 h0 = (_Float16)(sc * pq_centers[(size_t)(s * 2 + 0) * 256 + code]);
-  const _Float16 h1 = (_Float16)(sc * pq_centers[(size_t)(s * 2 + 1) * 256 + code]);
-  cb16[e] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+  // [subspace][code][component]: an entry's pq_len fp16 values side by side (pq_len 2: one 32-bit word)
+  for (uint32_t l = 0; l < pq_len; ++l)
+    cb16[(size_t)e * pq_len + l] = __builtin_bit_cast(uint16_t, (_Float16)(sc * pq_centers[(size_t)(s * pq_len + l) * 256 + code]));
 }
 
 __device__ inline float wave_reduce_max_f32(float v)
@@ -72,7 +72,7 @@ __device__ inline float wave_reduce_max_f32(float v)
 // the GEMM: x = -|d|^2 (1 - 2^-9) sc^2 / 2 split into two fp16 values (hi + lo = x to 2^-22; |x| <= 16384 by the choice
 // of sc), so that the accumulator of a (row, query) pair ends up holding sc^2 (r.d - |d|^2 (1 - 2^-9) / 2). One thread per row
 __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows, float sc,
-                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks, int fp32)
+                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks, int fp32, int pq_len)
 {
   const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r  = min(r0, rows - 1);  // (no early exit: the wave reduction below needs every lane)
@@ -85,9 +85,10 @@ __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* 
     for (int b = 0; b < 16; ++b) {
       const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
       const uint32_t s    = c * 16 + b;
-      const float p0 = pq_centers[(size_t)(s * 2 + 0) * 256 + code], p1 = pq_centers[(size_t)(s * 2 + 1) * 256 + code];
-      dn = __fmaf_rn(p0, p0, dn);
-      dn = __fmaf_rn(p1, p1, dn);
+      for (int l = 0; l < pq_len; ++l) {
+        const float p = pq_centers[(size_t)(s * pq_len + l) * 256 + code];
+        dn = __fmaf_rn(p, p, dn);
+      }
     }
   }
   // the largest |d|^2 of the index (bits of a non-negative float order like unsigned integers)
@@ -485,6 +486,7 @@ struct rescore_params {
   uint32_t* fail;         // IVF-Flat: raised when the overflow list is full (nullptr: the query is flagged instead)
   uint32_t dim;           // IVF-Flat: row length
   int cb_lds;             // IVF-PQ: the fp32 codebook fits the LDS of a workgroup
+  uint32_t pq_len;
 };
 
 // a re-scored survivor: into the query's pool if it is within the bound, beyond the pool's capacity into the overflow list
@@ -516,9 +518,9 @@ template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
 __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_params a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* cb = reinterpret_cast<float*>(smem);  // [pq_dim * 2][256] when it fits (cb_lds), else read from memory
+  float* cb = reinterpret_cast<float*>(smem);  // [pq_dim * pq_len][256] when it fits (cb_lds), else read from memory
   if (a.cb_lds) {
-    const uint32_t n4 = a.n_chunks * 16u * 2u * 256u / 4u;
+    const uint32_t n4 = a.n_chunks * 16u * a.pq_len * 256u / 4u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x)
       reinterpret_cast<float4*>(cb)[i] = reinterpret_cast<const float4*>(a.pq_centers)[i];
     __syncthreads();
@@ -549,6 +551,40 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
     const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
     float af       = 0.f;
     _Float16 ah    = (_Float16)0.f;
+    auto add_entry = [&](float v) {  // one LUT entry in the reference's arithmetic: LUT type, then the score type's sum
+      if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
+      if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
+        af += v;  // fp32 entries
+      } else {
+        const _Float16 e = to_lut_half(v);
+        if constexpr (ACC_HALF) ah += e; else af += (float)e;
+      }
+    };
+    if (a.pq_len != 2u) {
+      // any pq_len: entry (s, code) = the components' chain in order (create_lut_impl.cuh:17-78), subspaces in order
+#pragma unroll 1
+      for (int c = 0; c < (int)a.n_chunks; ++c) {
+        const uint4 cw       = cp[c * 64];
+        const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+          const uint32_t d0   = (uint32_t)(c * 16 + b) * a.pq_len;
+          float v = 0.f;
+          for (uint32_t l = 0; l < a.pq_len; ++l) {
+            const float p = pqc[(size_t)(d0 + l) * 256 + code], qv = rq[d0 + l], cv = ct[d0 + l];
+            if (!a.is_ip) {
+              const float d = (qv - cv) - p;
+              v = __fmaf_rn(d, d, v);
+            } else {
+              v = __fmaf_rn(-qv, cv, v);
+              v = __fmaf_rn(-qv, p, v);
+            }
+          }
+          add_entry(v);
+        }
+      }
+    } else {
 #pragma unroll 1
     for (int c = 0; c < (int)a.n_chunks; ++c) {
       const uint4 cw       = cp[c * 64];
@@ -576,14 +612,9 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
           v = __fmaf_rn(-q1, c1, v);
           v = __fmaf_rn(-q1, p1, v);
         }
-        if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
-        if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
-          af += v;  // fp32 entries
-        } else {
-          const _Float16 e = to_lut_half(v);
-          if constexpr (ACC_HALF) ah += e; else af += (float)e;
-        }
+        add_entry(v);
       }
+    }
     }
     const float score = ACC_HALF ? (float)ah : af;
     pool_append(a, q, pair, row, score);
@@ -750,7 +781,7 @@ struct head_params {
   float* out_d;
   uint32_t* out_i;
   uint32_t* query_kth;
-  uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks;
+  uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks, pq_len;
   int is_ip;
   int hcand;  // capacity of a candidate buffer (head_cand(k))
   const uint32_t* filter_bits;
@@ -820,7 +851,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ---- LUT (create_lut_impl.cuh:17-78), entry (s, code) at s * 256 + code; the codebook values of 8 entries are
     // loaded before any is used (one L2 round trip per batch instead of one per entry)
 #pragma unroll 1
-    for (uint32_t e0 = tid; e0 < a.pq_dim * 256u; e0 += 8u * NT) {
+    for (uint32_t e0 = tid; e0 < (a.pq_len == 2u ? a.pq_dim * 256u : 0u); e0 += 8u * NT) {
       float p0[8], p1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -845,6 +876,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
         if constexpr (LUT32) lut[e] = v; else lut[e] = to_lut_half(v);
+      }
+    }
+    if (a.pq_len != 2u) {  // any pq_len: the components' chain in order, four entries in flight
+#pragma unroll 1
+      for (uint32_t e0 = tid; e0 < a.pq_dim * 256u; e0 += 4u * NT) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t l = 0; l < a.pq_len; ++l) {
+          float p[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = e & 255u;
+            p[j] = a.pq_centers[(size_t)(sb * a.pq_len + l) * 256 + code];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), dd = (e >> 8) * a.pq_len + l;
+            const float qv = rv[dd];
+            if (!a.is_ip) {
+              const float d = qv - p[j];
+              v[j] = __fmaf_rn(d, d, v[j]);
+            } else {
+              v[j] = __fmaf_rn(-qv, cv[dd], v[j]);
+              v[j] = __fmaf_rn(-qv, p[j], v[j]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t e = e0 + (uint32_t)j * NT;
+          if (e >= a.pq_dim * 256u) break;
+          float x = v[j];
+          if constexpr (LUT == 2) x = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(x, a.is_ip != 0);
+          if constexpr (LUT32) lut[e] = x; else lut[e] = to_lut_half(x);
+        }
       }
     }
     if (tid == 0) ctrl[0] = 0;  // candidates kept so far (buffer 0)
@@ -1180,10 +1245,12 @@ unsigned pq3_regions(const resources& res) { return pq3_grid(res); }  // survivo
 
 bool pq3_supported(const ivf_pq_index& idx, int k)
 {
-  // pq_len 2 (a lane's 8 K elements of an MFMA step = 4 subspaces = 4 code bytes), whole 16-byte code chunks, a decode
-  // table of at most 128 KiB
-  return idx.pq_bits == 8 && idx.pq_len == 2 && idx.pq_dim % 16 == 0 && idx.pq_dim >= 16 && idx.pq_dim <= 128 &&
-         idx.rot_dim == 2 * idx.pq_dim && idx.codebook_kind == 0 && k <= 256;
+  // 8-bit codes in whole 16-byte chunks; pq_len 1 / 2 / 4 / 8 (a lane's 8 K elements of an MFMA step = 8 / pq_len codebook
+  // entries); at most 16 K steps (the B operands of a unit's queries live in registers) = a decode table of at most
+  // 128 KiB; pq_dim <= 128 (the head phase's LUT in LDS). Round 3's pq_filter_kernel (comparator, inner product): pq_len 2
+  return idx.pq_bits == 8 && (idx.pq_len == 1 || idx.pq_len == 2 || idx.pq_len == 4 || idx.pq_len == 8) && idx.pq_dim % 16 == 0 &&
+         idx.pq_dim >= 16 && idx.pq_dim <= 128 && idx.rot_dim == idx.pq_len * idx.pq_dim && idx.rot_dim <= 256 &&
+         idx.codebook_kind == 0 && k <= 256;
 }
 
 pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_fp32)
@@ -1200,15 +1267,16 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_
     // residuals up to 4096 times larger still fit the fp16 range, values 2^17 times smaller are still normal numbers
     c.sc    = mx > 0.f ? std::exp2(std::floor(std::log2(16.0f / mx))) : 1.0f;
     c.cbmax = mx;
-    c.cb16  = dev_buf<uint32_t>::persistent((size_t)idx.pq_dim * 256);
+    c.cb16  = dev_buf<uint32_t>::persistent((size_t)idx.pq_dim * 256 * idx.pq_len / 2 + 1);
     hipLaunchKernelGGL(cb16_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream,
-                       idx.pq_centers.data(), idx.pq_dim, c.sc, c.cb16.data());
+                       idx.pq_centers.data(), idx.pq_dim, idx.pq_len, c.sc, reinterpret_cast<uint16_t*>(c.cb16.data()));
     c.row_term = dev_buf<uint32_t>::persistent((size_t)std::max<int64_t>(idx.padded_rows, 1));
     dev_buf<uint32_t> mxd(res, 1);
     HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
     if (idx.padded_rows > 0)
       hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, idx.codes.data(),
-                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)idx.n_chunks, term_fp32 ? 1 : 0);
+                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)idx.n_chunks, term_fp32 ? 1 : 0,
+                         (int)idx.pq_len);
     const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
     float dn_max;
     memcpy(&dn_max, &mbits, 4);
@@ -1237,8 +1305,10 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   const pq3_tables tb = pq3_prepare(res, idx, f4);
   profile_begin(res, "pq_scan_kernel");  // bench.py sums the scan phases under this name
   const int nch        = (int)idx.pq_dim / 16;          // 16-byte code chunks per row
-  // queries per work unit: B-operand groups of 32, four (two beyond pq_dim 64) with 512 registers per wave, else two (one)
-  const uint32_t group = f4 ? (nch <= 4 ? 128u : 64u) : (nch <= 4 ? 64u : 32u);
+  const int nst        = nch * (int)idx.pq_len;         // MFMA K steps = rot_dim / 16
+  // queries per work unit: B-operand groups of 32, four (two beyond 8 K steps) with 512 registers per wave, else two (one)
+  const uint32_t group = f4 ? (nst <= 8 ? 128u : 64u) : (nch <= 4 ? 64u : 32u);
+  CUVS_EXPECTS(f4 || idx.pq_len == 2, "ivf_pq: pq_filter_kernel decodes pq_len 2 only");
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
                      r.unit_rows, r.unit_off, group);
@@ -1264,10 +1334,12 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   //   fp8 LUT (5 exponent bits, 3 value bits, truncation, half an ulp added back): 2^-4 per entry, 2^-15 absolute below its
   //   range; it saturates at 1.875 * 2^16, so bounds near that are not served
   f.bound_max = FLT_MAX;
-  if (r.lut_mode == 0)      { f.eps = 1.0f / 65536.0f; f.alpha = 0.f; }
-  else if (r.lut_mode == 1) { f.eps = r.acc_half ? 0.04f : 1.0f / 1024.0f; f.alpha = 64.0f / 16777216.0f; f.bound_max = 60000.f; }
-  else                      { f.eps = r.acc_half ? 0.11f : 0.07f; f.alpha = 64.0f / 32768.0f; f.bound_max = 30000.f; }
-  if (r.is_ip && r.lut_mode == 2) f.eps = r.acc_half ? 0.18f : 0.14f;  // signed fp8: one value bit less (2^-3 per entry)
+  // (the figures are those of pq_dim 64; the per-add and per-entry terms grow with the number of entries summed)
+  const float ne = std::max(1.0f, (float)idx.pq_dim / 64.0f);
+  if (r.lut_mode == 0)      { f.eps = ne / 65536.0f; f.alpha = 0.f; }
+  else if (r.lut_mode == 1) { f.eps = r.acc_half ? 0.04f * ne : 1.0f / 1024.0f; f.alpha = ne * 64.0f / 16777216.0f; f.bound_max = 60000.f; }
+  else                      { f.eps = r.acc_half ? 0.07f + 0.04f * ne : 0.07f; f.alpha = ne * 64.0f / 32768.0f; f.bound_max = 30000.f; }
+  if (r.is_ip && r.lut_mode == 2) f.eps = r.acc_half ? 0.14f + 0.04f * ne : 0.14f;  // signed fp8: one value bit less (2^-3 per entry)
   const size_t fsmem = (size_t)nch * 16 * 1024 + 16;
   if (f4) {
     // pre-pass (B operands and thresholds of every tail pair), then the filter: ivf_pq_filter4.hip
@@ -1279,6 +1351,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
     l.surv = f.surv; l.surv_cnt = f.surv_cnt; l.surv_entries = r.surv_cap; l.n_probes = r.n_probes;
     l.rot_dim = idx.rot_dim; l.unit_rows = r.unit_rows; l.sc = f.sc; l.c1 = f.c1; l.eps = f.eps; l.alpha = f.alpha;
     l.cbmax = f.cbmax; l.dmax = f.dmax; l.bound_max = f.bound_max; l.is_ip = r.is_ip; l.dbg = r.filter_dbg; l.nch = nch;
+    l.pl = (int)idx.pq_len;
     l.n_pairs = r.nq * (int64_t)r.n_probes; l.stats = r.stats; l.grid = grid;
     pq4_filter(res, l);
   } else {
@@ -1317,7 +1390,8 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = idx.n_chunks;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
-  const size_t cb_bytes = (size_t)idx.pq_dim * 2 * 256 * sizeof(float);
+  const size_t cb_bytes = (size_t)idx.rot_dim * 256 * sizeof(float);
+  s.pq_len = idx.pq_len;
   s.cb_lds = cb_bytes <= 128 * 1024 ? 1 : 0;
   const size_t rsmem = s.cb_lds ? cb_bytes : 16;
   const dim3 rg(grid + 1, 2), rb(kRThreads);
@@ -1353,6 +1427,7 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   a.pq_centers = idx.pq_centers.data(); a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data();
   a.list_sizes = idx.list_sizes.data(); a.out_d = h.cand_d; a.out_i = h.cand_i; a.query_kth = h.query_kth;
   a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip; a.pq_dim = idx.pq_dim; a.n_chunks = idx.n_chunks;
+  a.pq_len = idx.pq_len;
   a.filter_bits = h.filter_bits; a.indices = idx.indices.data(); a.stats = h.stats; a.hcand = head_cand((int)h.k);
   // A LUT of up to 32 KiB (fp16 entries at pq_dim 64): two 512-thread workgroups per CU, one streams its list while the
   // other selects; beyond: one 1024-thread workgroup. The rest of the LDS holds the score keys of a list chunk; longer

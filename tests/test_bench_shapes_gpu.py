@@ -93,6 +93,37 @@ def test_c3_shape_lists_of_thousands_of_rows(big_lists, lut, acc, monkeypatch):
     assert (gi == pi).all() and (gd == pd).all()
 
 
+@pytest.mark.parametrize("d,pq_dim,metric,lut,acc", [
+    (64, 64, "sqeuclidean", "f16", "f32"),     # pq_len 1, 4 K steps
+    (96, 96, "sqeuclidean", "f16", "f16"),     # pq_len 1, 6 code chunks
+    (128, 128, "sqeuclidean", "f32", "f32"),   # pq_len 1, 8 K steps
+    (128, 32, "sqeuclidean", "f16", "f32"),    # pq_len 4, 8 K steps
+    (128, 32, "inner_product", "f16", "f32"),  # pq_len 4, no row term, survivors by the thousand
+    (192, 48, "cosine", "f16", "f32"),         # pq_len 4, 12 K steps: two query groups per unit
+    (256, 64, "sqeuclidean", "fp8", "f16"),    # pq_len 4, 16 K steps
+    (128, 16, "sqeuclidean", "f16", "f32"),    # pq_len 8, 8 K steps
+    (256, 32, "sqeuclidean", "f32", "f32"),    # pq_len 8, 16 K steps
+])
+def test_c3_shape_every_pq_len(d, pq_dim, metric, lut, acc, monkeypatch):
+    """pq_filter4_kernel<NCH, PL>: 8-bit codes with pq_len 1 / 4 / 8 (a code byte = 1 / 4 / 8 fp16 values of the decode
+    table: 2 / 8 / 16-byte gathers, 8 / 2 / 1 per K step), head LUT and re-score for any pq_len - ids and distances
+    identical to the oracle and to the LUT scan kernels (CUVS_AMD_PQ_SCAN3=0)."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(100_000, d, 400, seed=d + pq_dim, modes=48)
+    index = _pq_build(x, n_lists=32, pq_dim=pq_dim, pq_bits=8, metric=metric, kmeans_n_iters=8, kmeans_trainset_fraction=0.2)
+    ex = ivf_pq.export_for_oracle(index)
+    k, n_probes = 20, 12
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (si == oi).all() and (sd == od).all()
+
+
 @pytest.mark.parametrize("k", [129, 200, 256])
 def test_c3_shape_k_up_to_256(big_lists, k, monkeypatch):
     """k = 129 .. 256 (the IVF-PQ searches of a CAGRA build ask for 2 x intermediate_graph_degree = 256 candidates,
