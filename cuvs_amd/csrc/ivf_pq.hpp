@@ -58,6 +58,10 @@ struct ivf_pq_index {
     const void* codes_ptr = nullptr;
     const void* pq_ptr    = nullptr;
     int64_t rows = -1, size = -1;
+    // codes of fewer than 8 bits: a derived copy with one byte per code, laid out like 8-bit codes (16 per chunk)
+    dev_buf<uint8_t> codes8;
+    const void* codes8_src = nullptr;
+    int64_t codes8_rows = -1, codes8_size = -1;
   };
   mutable scan3_cache scan3;
   // largest source id held by the lists (-1: empty), computed on demand for the bitset-filter bound check

@@ -51,14 +51,40 @@ constexpr int kFWaves   = kFThreads / 64;
 
 
 // ------------------------------------------------------------------ per-index tables
-__global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, uint32_t pq_len, float sc, uint16_t* __restrict__ cb16)
+__global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, uint32_t pq_len, uint32_t book, float sc,
+                            uint16_t* __restrict__ cb16)
 {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // s * 256 + code
   if (e >= pq_dim * 256u) return;
   const uint32_t s = e >> 8, code = e & 255u;
   // [subspace][code][component]: an entry's pq_len fp16 values side by side (pq_len 2: one 32-bit word)
+  // (codes of fewer than 8 bits: the table keeps 256 slots per subspace, those past the codebook are never looked up)
   for (uint32_t l = 0; l < pq_len; ++l)
-    cb16[(size_t)e * pq_len + l] = __builtin_bit_cast(uint16_t, (_Float16)(sc * pq_centers[(size_t)(s * pq_len + l) * 256 + code]));
+    cb16[(size_t)e * pq_len + l] =
+      code < book ? __builtin_bit_cast(uint16_t, (_Float16)(sc * pq_centers[(size_t)(s * pq_len + l) * book + code])) : (uint16_t)0;
+}
+
+// codes of fewer than 8 bits (a little-endian bit stream of codes_per_chunk codes per 16-byte chunk,
+// ivf_pq_codepacking.cuh:22-52) expanded to one byte per code, 16 per chunk: the layout every kernel of this file reads.
+// One thread per (row, 16-code chunk)
+__global__ void expand_codes_kernel(const uint8_t* __restrict__ codes, int64_t rows, uint32_t n_chunks, uint32_t cpc, uint32_t bits,
+                                    uint32_t pq_dim, uint8_t* __restrict__ out)
+{
+  const uint32_t nch8 = pq_dim / 16;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * nch8) return;
+  const int64_t row = i / nch8;
+  const uint32_t c8 = (uint32_t)(i % nch8);
+  uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const uint32_t s = c8 * 16 + b, ch = s / cpc, bit = (s % cpc) * bits;
+    const uint8_t* base = codes + ((size_t)(row >> 6) * n_chunks + ch) * 1024 + (size_t)(row & 63) * 16;
+    uint32_t v = base[bit >> 3];
+    if ((bit & 7) + bits > 8) v |= (uint32_t)base[(bit >> 3) + 1] << 8;
+    w[b >> 2] |= ((v >> (bit & 7)) & ((1u << bits) - 1u)) << ((b & 3) * 8);
+  }
+  reinterpret_cast<uint4*>(out)[((size_t)(row >> 6) * nch8 + c8) * 64 + (row & 63)] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 __device__ inline float wave_reduce_max_f32(float v)
@@ -72,7 +98,8 @@ __device__ inline float wave_reduce_max_f32(float v)
 // the GEMM: x = -|d|^2 (1 - 2^-9) sc^2 / 2 split into two fp16 values (hi + lo = x to 2^-22; |x| <= 16384 by the choice
 // of sc), so that the accumulator of a (row, query) pair ends up holding sc^2 (r.d - |d|^2 (1 - 2^-9) / 2). One thread per row
 __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows, float sc,
-                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks, int fp32, int pq_len)
+                                uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks, int fp32, int pq_len,
+                                uint32_t book)
 {
   const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r  = min(r0, rows - 1);  // (no early exit: the wave reduction below needs every lane)
@@ -86,7 +113,7 @@ __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* 
       const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
       const uint32_t s    = c * 16 + b;
       for (int l = 0; l < pq_len; ++l) {
-        const float p = pq_centers[(size_t)(s * pq_len + l) * 256 + code];
+        const float p = pq_centers[(size_t)(s * pq_len + l) * book + code];
         dn = __fmaf_rn(p, p, dn);
       }
     }
@@ -486,7 +513,7 @@ struct rescore_params {
   uint32_t* fail;         // IVF-Flat: raised when the overflow list is full (nullptr: the query is flagged instead)
   uint32_t dim;           // IVF-Flat: row length
   int cb_lds;             // IVF-PQ: the fp32 codebook fits the LDS of a workgroup
-  uint32_t pq_len;
+  uint32_t pq_len, book;
 };
 
 // a re-scored survivor: into the query's pool if it is within the bound, beyond the pool's capacity into the overflow list
@@ -520,7 +547,7 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* cb = reinterpret_cast<float*>(smem);  // [pq_dim * pq_len][256] when it fits (cb_lds), else read from memory
   if (a.cb_lds) {
-    const uint32_t n4 = a.n_chunks * 16u * a.pq_len * 256u / 4u;
+    const uint32_t n4 = a.n_chunks * 16u * a.pq_len * a.book / 4u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x)
       reinterpret_cast<float4*>(cb)[i] = reinterpret_cast<const float4*>(a.pq_centers)[i];
     __syncthreads();
@@ -572,7 +599,7 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
           const uint32_t d0   = (uint32_t)(c * 16 + b) * a.pq_len;
           float v = 0.f;
           for (uint32_t l = 0; l < a.pq_len; ++l) {
-            const float p = pqc[(size_t)(d0 + l) * 256 + code], qv = rq[d0 + l], cv = ct[d0 + l];
+            const float p = pqc[(size_t)(d0 + l) * a.book + code], qv = rq[d0 + l], cv = ct[d0 + l];
             if (!a.is_ip) {
               const float d = (qv - cv) - p;
               v = __fmaf_rn(d, d, v);
@@ -600,7 +627,7 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
       for (int b = 0; b < 16; ++b) {
         const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
         const uint32_t sb   = c * 16 + b;
-        const float p0 = pqc[(size_t)(sb * 2 + 0) * 256 + code], p1 = pqc[(size_t)(sb * 2 + 1) * 256 + code];
+        const float p0 = pqc[(size_t)(sb * 2 + 0) * a.book + code], p1 = pqc[(size_t)(sb * 2 + 1) * a.book + code];
         const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cc[b * 2], c1 = cc[b * 2 + 1];
         float v;
         if (!a.is_ip) {
@@ -781,7 +808,7 @@ struct head_params {
   float* out_d;
   uint32_t* out_i;
   uint32_t* query_kth;
-  uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks, pq_len;
+  uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks, pq_len, book;
   int is_ip;
   int hcand;  // capacity of a candidate buffer (head_cand(k))
   const uint32_t* filter_bits;
@@ -855,9 +882,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       float p0[8], p1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = e & 255u;
-        p0[j] = a.pq_centers[(size_t)(sb * 2 + 0) * 256 + code];
-        p1[j] = a.pq_centers[(size_t)(sb * 2 + 1) * 256 + code];
+        // (codes of fewer than 8 bits: the LUT keeps 256 slots per subspace, those past the codebook are never looked up)
+        const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = min(e & 255u, a.book - 1u);
+        p0[j] = a.pq_centers[(size_t)(sb * 2 + 0) * a.book + code];
+        p1[j] = a.pq_centers[(size_t)(sb * 2 + 1) * a.book + code];
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -886,8 +914,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           float p[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = e & 255u;
-            p[j] = a.pq_centers[(size_t)(sb * a.pq_len + l) * 256 + code];
+            const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = min(e & 255u, a.book - 1u);
+            p[j] = a.pq_centers[(size_t)(sb * a.pq_len + l) * a.book + code];
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1245,18 +1273,38 @@ unsigned pq3_regions(const resources& res) { return pq3_grid(res); }  // survivo
 
 bool pq3_supported(const ivf_pq_index& idx, int k)
 {
-  // 8-bit codes in whole 16-byte chunks; pq_len 1 / 2 / 4 / 8 (a lane's 8 K elements of an MFMA step = 8 / pq_len codebook
+  // codes of 4 .. 8 bits (fewer than 8: through a one-byte-per-code copy, pq3_codes), pq_dim a multiple of 16; pq_len 1 / 2 / 4 / 8 (a lane's 8 K elements of an MFMA step = 8 / pq_len codebook
   // entries); at most 16 K steps (the B operands of a unit's queries live in registers) = a decode table of at most
   // 128 KiB; pq_dim <= 128 (the head phase's LUT in LDS). Round 3's pq_filter_kernel (comparator, inner product): pq_len 2
-  return idx.pq_bits == 8 && (idx.pq_len == 1 || idx.pq_len == 2 || idx.pq_len == 4 || idx.pq_len == 8) && idx.pq_dim % 16 == 0 &&
+  return idx.pq_bits >= 4 && idx.pq_bits <= 8 && (idx.pq_len == 1 || idx.pq_len == 2 || idx.pq_len == 4 || idx.pq_len == 8) && idx.pq_dim % 16 == 0 &&
          idx.pq_dim >= 16 && idx.pq_dim <= 128 && idx.rot_dim == idx.pq_len * idx.pq_dim && idx.rot_dim <= 256 &&
          idx.codebook_kind == 0 && k <= 256;
 }
 
+static std::recursive_mutex g_pq3_mu;
+
+// the codes as the kernels of this file read them - one byte per code, 16 per chunk - and the chunks per row: the index's
+// own array for 8-bit codes, a derived copy (built on first use, rebuilt when the lists change) for 4 .. 7 bits
+const uint8_t* pq3_codes(resources& res, const ivf_pq_index& idx, uint32_t* n_chunks)
+{
+  *n_chunks = idx.pq_dim / 16;
+  if (idx.pq_bits == 8) return idx.codes.data();
+  std::lock_guard<std::recursive_mutex> lock(g_pq3_mu);
+  auto& c = idx.scan3;
+  if (c.codes8_src != idx.codes.data() || c.codes8_rows != idx.padded_rows || c.codes8_size != idx.size) {
+    const int64_t rows = std::max<int64_t>(idx.padded_rows, 1);
+    c.codes8 = dev_buf<uint8_t>::persistent((size_t)rows * idx.pq_dim);
+    if (idx.padded_rows > 0)
+      hipLaunchKernelGGL(expand_codes_kernel, dim3(grid_blocks(idx.padded_rows * (int64_t)(idx.pq_dim / 16), 256)), dim3(256), 0, res.stream,
+                         idx.codes.data(), idx.padded_rows, idx.n_chunks, idx.codes_per_chunk, idx.pq_bits, idx.pq_dim, c.codes8.data());
+    c.codes8_src = idx.codes.data(); c.codes8_rows = idx.padded_rows; c.codes8_size = idx.size;
+  }
+  return c.codes8.data();
+}
+
 pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_fp32)
 {
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
+  std::lock_guard<std::recursive_mutex> lock(g_pq3_mu);
   auto& c = idx.scan3;
   if (c.codes_ptr != idx.codes.data() || c.rows != idx.padded_rows || c.size != idx.size || c.pq_ptr != idx.pq_centers.data() ||
       c.term_fp32 != term_fp32) {
@@ -1269,14 +1317,16 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_
     c.cbmax = mx;
     c.cb16  = dev_buf<uint32_t>::persistent((size_t)idx.pq_dim * 256 * idx.pq_len / 2 + 1);
     hipLaunchKernelGGL(cb16_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream,
-                       idx.pq_centers.data(), idx.pq_dim, idx.pq_len, c.sc, reinterpret_cast<uint16_t*>(c.cb16.data()));
+                       idx.pq_centers.data(), idx.pq_dim, idx.pq_len, idx.pq_book, c.sc, reinterpret_cast<uint16_t*>(c.cb16.data()));
     c.row_term = dev_buf<uint32_t>::persistent((size_t)std::max<int64_t>(idx.padded_rows, 1));
     dev_buf<uint32_t> mxd(res, 1);
     HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
+    uint32_t nch8 = 0;
+    const uint8_t* codes8 = pq3_codes(res, idx, &nch8);
     if (idx.padded_rows > 0)
-      hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, idx.codes.data(),
-                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)idx.n_chunks, term_fp32 ? 1 : 0,
-                         (int)idx.pq_len);
+      hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, codes8,
+                         idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)nch8, term_fp32 ? 1 : 0,
+                         (int)idx.pq_len, idx.pq_book);
     const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
     float dn_max;
     memcpy(&dn_max, &mbits, 4);
@@ -1317,7 +1367,9 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket;
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = idx.centers_rot.data();
-  f.cb16 = tb.cb16; f.codes = idx.codes.data(); f.list_offsets = idx.list_offsets.data(); f.list_sizes = idx.list_sizes.data();
+  uint32_t nch8 = 0;
+  const uint8_t* codes8 = pq3_codes(res, idx, &nch8);
+  f.cb16 = tb.cb16; f.codes = codes8; f.list_offsets = idx.list_offsets.data(); f.list_sizes = idx.list_sizes.data();
   f.row_term = r.is_ip ? nullptr : tb.row_term; f.query_kth = r.query_kth; f.qflag = r.qflag;
   const unsigned grid = pq3_grid(res);
   // three quarters of the survivor buffer are cut into one region per workgroup (pq_filter4_kernel: per wave), the rest is
@@ -1385,13 +1437,13 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes; s.rot_queries = r.rot_queries;
   s.n_regions = regions; s.sub = f4 ? 0u : 1u;
   if (f4) s.surv_cap = r.surv_cap;  // chunked: the whole buffer
-  s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = idx.codes.data();
+  s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = codes8;
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
-  s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = idx.n_chunks;
+  s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = nch8;
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
-  const size_t cb_bytes = (size_t)idx.rot_dim * 256 * sizeof(float);
-  s.pq_len = idx.pq_len;
+  const size_t cb_bytes = (size_t)idx.rot_dim * idx.pq_book * sizeof(float);
+  s.pq_len = idx.pq_len; s.book = idx.pq_book;
   s.cb_lds = cb_bytes <= 128 * 1024 ? 1 : 0;
   const size_t rsmem = s.cb_lds ? cb_bytes : 16;
   const dim3 rg(grid + 1, 2), rb(kRThreads);
@@ -1424,10 +1476,10 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   head_params a{};
   a.items = static_cast<const work_item*>(h.items); a.item_begin = h.item_begin; a.item_end = h.item_end; a.n_lists = idx.n_lists;
   a.xcd_ticket = h.xcd_ticket; a.sorted_pairs = h.sorted_pairs; a.rot_queries = h.rot_queries; a.centers_rot = idx.centers_rot.data();
-  a.pq_centers = idx.pq_centers.data(); a.codes = idx.codes.data(); a.list_offsets = idx.list_offsets.data();
+  a.pq_centers = idx.pq_centers.data(); a.codes = pq3_codes(res, idx, &a.n_chunks); a.list_offsets = idx.list_offsets.data();
   a.list_sizes = idx.list_sizes.data(); a.out_d = h.cand_d; a.out_i = h.cand_i; a.query_kth = h.query_kth;
-  a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip; a.pq_dim = idx.pq_dim; a.n_chunks = idx.n_chunks;
-  a.pq_len = idx.pq_len;
+  a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip; a.pq_dim = idx.pq_dim;
+  a.pq_len = idx.pq_len; a.book = idx.pq_book;
   a.filter_bits = h.filter_bits; a.indices = idx.indices.data(); a.stats = h.stats; a.hcand = head_cand((int)h.k);
   // A LUT of up to 32 KiB (fp16 entries at pq_dim 64): two 512-thread workgroups per CU, one streams its list while the
   // other selects; beyond: one 1024-thread workgroup. The rest of the LDS holds the score keys of a list chunk; longer

@@ -124,6 +124,43 @@ def test_c3_shape_every_pq_len(d, pq_dim, metric, lut, acc, monkeypatch):
     assert (si == oi).all() and (sd == od).all()
 
 
+@pytest.mark.parametrize("d,pq_dim,pq_bits,metric,lut,acc", [
+    (128, 64, 5, "sqeuclidean", "f16", "f32"),
+    (128, 64, 4, "sqeuclidean", "f16", "f16"),
+    (96, 48, 6, "sqeuclidean", "f32", "f32"),
+    (96, 96, 7, "sqeuclidean", "f16", "f32"),   # pq_len 1
+    (128, 32, 5, "inner_product", "f16", "f32"),  # pq_len 4
+    (128, 64, 6, "inner_product", "f16", "f32"),  # pq_len 2, inner product: pq_filter_kernel
+])
+def test_c3_shape_codes_of_fewer_than_8_bits(d, pq_dim, pq_bits, metric, lut, acc, monkeypatch):
+    """pq_bits 4 .. 7 on the matrix-core tail phase: head kernel, filter, re-score and row terms read a one-byte-per-code copy
+    of the bit-packed lists (pq3_codes), the decode table keeps 256 slots per subspace - ids and distances identical to the
+    oracle and to the LUT scan kernels (generic bit extraction, CUVS_AMD_PQ_SCAN3=0)."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(100_000, d, 400, seed=d + pq_dim + pq_bits, modes=48)
+    index = _pq_build(x, n_lists=32, pq_dim=pq_dim, pq_bits=pq_bits, metric=metric, kmeans_n_iters=8, kmeans_trainset_fraction=0.2)
+    ex = ivf_pq.export_for_oracle(index)
+    k, n_probes = 20, 12
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (si == oi).all() and (sd == od).all()
+    # rows added after the copy was made: it is rebuilt
+    monkeypatch.delenv("CUVS_AMD_PQ_SCAN3")
+    import torch
+    x2, _ = _mixture(5_000, d, 1, seed=7, modes=48)
+    index = ivf_pq.extend(index, torch.from_numpy(x2).cuda(), torch.arange(100_000, 105_000, dtype=torch.int64).cuda())
+    ex = ivf_pq.export_for_oracle(index)
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all() and (gd == od).all()
+
+
 @pytest.mark.parametrize("k", [129, 200, 256])
 def test_c3_shape_k_up_to_256(big_lists, k, monkeypatch):
     """k = 129 .. 256 (the IVF-PQ searches of a CAGRA build ask for 2 x intermediate_graph_degree = 256 candidates,
