@@ -147,7 +147,9 @@ typedef __attribute__((address_space(3))) const uint32_t lds_u32_t;
 // loop it would make every wait on the gathers a wait for everything)
 // PL: pq_len (1, 2, 4, 8): a code byte stands for PL fp16 values - the lane's 8 K elements of an MFMA step are 8 / PL
 // codebook entries of 2 PL bytes; the 8 code bytes a lane holds of a chunk feed PL consecutive K steps
-template <int NCH, int PL, bool TERM, int DBG, bool STATS = false>
+// PC: PER_CLUSTER codebooks - one decode table of 256 entries per LIST, shared by its subspaces: every wave keeps the table
+// of its current unit's list in a 4 KiB LDS region of its own (loaded at the start of a unit, 32 PL 16-byte loads per wave)
+template <int NCH, int PL, bool TERM, int DBG, bool STATS = false, bool PC = false>
 __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_params a)
 {
   constexpr int NST = PL * NCH;          // MFMA K steps
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
   // gathers in the LDS queue, which returns in order: a full drain per survivor; fixed per-wave regions run over on the
   // waves whose lists hold the dense regions of the corpus). A chunk's unused tail is padded with invalid entries.
   uint32_t s_chunk = 0xffffffffu, s_fill = kSurvChunk;  // wave-uniform: current chunk, entries written to it
-  for (uint32_t i = threadIdx.x; i < (uint32_t)NCH * 16u * (kSlot / 16u); i += kF4Threads) {
+  for (uint32_t i = threadIdx.x; i < (PC ? 0u : (uint32_t)NCH * 16u * (kSlot / 16u)); i += kF4Threads) {
     // a.cb16: [subspace s][256 codes][PL]; subspace s = 16 c + 8 half + j goes to half's table at slot 8 c + j
     const uint32_t s = i / (kSlot / 16u), half = (s >> 3) & 1u, slot = (s >> 4) * 8u + (s & 7u);
     *reinterpret_cast<uint4*>(smem + half * kHalf1 + slot * kSlot + (i % (kSlot / 16u)) * 16u) = reinterpret_cast<const uint4*>(a.cb16)[i];
@@ -209,6 +211,14 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
       load_desc();
     }
     if (!desc_ok) break;
+    if constexpr (PC) {  // this list's decode table into the wave's region (LDS operations of a wave complete in order)
+      const uint32_t list = __builtin_amdgcn_readfirstlane(d0.x);
+      const uint4* src    = reinterpret_cast<const uint4*>(a.cb16) + (size_t)list * (kSlot / 16u);
+      char* dst           = smem + (threadIdx.x >> 6) * 4096u;
+#pragma unroll
+      for (uint32_t i = 0; i < (kSlot / 16u + 63u) / 64u; ++i)
+        if (i * 64u + lane < kSlot / 16u) *reinterpret_cast<uint4*>(dst + (i * 64u + lane) * 16u) = src[i * 64u + lane];
+    }
     const uint32_t first = __builtin_amdgcn_readfirstlane(d0.y), count = __builtin_amdgcn_readfirstlane(d0.z),
                    row0 = __builtin_amdgcn_readfirstlane(d0.w), base_row = __builtin_amdgcn_readfirstlane(d1.x),
                    r_end = __builtin_amdgcn_readfirstlane(d1.y);
@@ -238,6 +248,16 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
     for (int e = 0; e < NGA; ++e) ad[e] = h << 16;
     auto decode_addr = [&](const uint2 (&cw)[NCH], const int st) {
       const int c = st / PL, b0 = (st % PL) * NGA;  // first code byte of the step
+      if constexpr (PC) {
+        const uint32_t base = (threadIdx.x >> 6) * 4096u;
+#pragma unroll
+        for (int e = 0; e < NGA; ++e) {
+          const int b = b0 + e;
+          const uint32_t w = b < 4 ? cw[c].x : cw[c].y;
+          ad[e] = base + (((w >> (8 * (b & 3))) & 255u) << two);
+        }
+        return;
+      }
       if constexpr ((DBG & 1) != 0) {  // ablation: every lane of a half in its own bank
         const uint32_t w = ql * 0x01010101u;
         if constexpr (NGA >= 1) table_addr<0>(ad[0], two, w);
@@ -260,7 +280,8 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
     };
     auto decode_gather = [&](const int st, u32x4_t (&av)[NST]) {
       constexpr uint32_t kNone = 0u;
-      const uint32_t slot0 = (8u * (st / PL) + (uint32_t)((st % PL) * NGA)) * kSlot;
+      const uint32_t slot0 = PC ? 0u : (8u * (st / PL) + (uint32_t)((st % PL) * NGA)) * kSlot;
+      constexpr uint32_t kStep = PC ? 0u : kSlot;  // (PER_CLUSTER: every subspace reads the same table)
       if constexpr ((DBG & 2) != 0) {  // ablation: no gathers
 #pragma unroll
         for (int e = 0; e < 4; ++e) av[st][e] = ad[e % NGA] + kNone;
@@ -271,17 +292,17 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
         typedef __attribute__((address_space(3))) const _Float16 lds_f16_t;
         f16x8_t v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<lds_f16_t*>(ad[e] + slot0 + e * kSlot);
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<lds_f16_t*>(ad[e] + slot0 + e * kStep);
         av[st] = __builtin_bit_cast(u32x4_t, v);
       } else if constexpr (PL == 2) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) av[st][e] = *reinterpret_cast<lds_u32_t*>(ad[e] + slot0 + e * kSlot);
+        for (int e = 0; e < 4; ++e) av[st][e] = *reinterpret_cast<lds_u32_t*>(ad[e] + slot0 + e * kStep);
       } else if constexpr (PL == 4) {
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(3))) const u32x2_t lds_u64_t;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const u32x2_t v = *reinterpret_cast<lds_u64_t*>(ad[e] + slot0 + e * kSlot);
+          const u32x2_t v = *reinterpret_cast<lds_u64_t*>(ad[e] + slot0 + e * kStep);
           av[st][2 * e] = v[0]; av[st][2 * e + 1] = v[1];
         }
       } else {
@@ -526,7 +547,8 @@ void pq4_filter(resources& res, const filter4_launch& l)
   g.list_sizes = l.list_sizes; g.row_term = l.row_term; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
   g.surv_cnt = l.surv_cnt; g.n_chunks = l.surv_entries / kSurvChunk; g.n_probes = l.n_probes; g.unit_rows = l.unit_rows;
   g.stats = l.stats;
-  const size_t fsmem = 65536 + (size_t)l.nch * 8 * 512 * l.pl;  // the two K halves of the decode table lie 64 KiB apart
+  // the two K halves of the decode table lie 64 KiB apart; PER_CLUSTER: a 4 KiB table region per wave
+  const size_t fsmem = l.per_cluster ? 4 * 4096 : 65536 + (size_t)l.nch * 8 * 512 * l.pl;
   const bool term = l.row_term != nullptr;
   auto launch = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
@@ -535,7 +557,7 @@ void pq4_filter(resources& res, const filter4_launch& l)
     profile_end(res, "pq_filter_kernel");
   };
 #ifndef CUVS_AMD_F4_DEV
-  if (l.nch == 4 && l.pl == 2) {
+  if (l.nch == 4 && l.pl == 2 && !l.per_cluster) {
     switch (l.dbg) {  // CUVS_AMD_SCAN_DEBUG bits 16..19: ablation builds of the kernel (bench shape only)
       case 1:  launch(pq_filter4_kernel<4, 2, true, 1>); break;
       case 2:  launch(pq_filter4_kernel<4, 2, true, 2>); break;
@@ -555,7 +577,11 @@ void pq4_filter(resources& res, const filter4_launch& l)
   }
   auto pick = [&](auto nch_tag, auto pl_tag) {
     constexpr int N = decltype(nch_tag)::value, P = decltype(pl_tag)::value;
-    if (term) launch(pq_filter4_kernel<N, P, true, 0>); else launch(pq_filter4_kernel<N, P, false, 0>);
+    if (l.per_cluster) {
+      if (term) launch(pq_filter4_kernel<N, P, true, 0, false, true>); else launch(pq_filter4_kernel<N, P, false, 0, false, true>);
+    } else {
+      if (term) launch(pq_filter4_kernel<N, P, true, 0>); else launch(pq_filter4_kernel<N, P, false, 0>);
+    }
   };
   using N1 = std::integral_constant<int, 1>; using N2 = std::integral_constant<int, 2>; using N3 = std::integral_constant<int, 3>;
   using N4 = std::integral_constant<int, 4>; using N5 = std::integral_constant<int, 5>; using N6 = std::integral_constant<int, 6>;

@@ -79,7 +79,7 @@ struct filter4_launch {
   uint32_t* surv_cnt;
   uint32_t surv_entries, n_probes, rot_dim, unit_rows;  // surv_entries: size of the survivor buffer (handed out in chunks of 256)
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
-  int is_ip, dbg, nch, pl;  // nch: 16-byte code chunks per row (pq_dim / 16); pl: pq_len
+  int is_ip, dbg, nch, pl, per_cluster;  // nch: 16-byte code chunks per row (pq_dim / 16); pl: pq_len
   int64_t n_pairs;
   unsigned long long* stats;
   unsigned grid;

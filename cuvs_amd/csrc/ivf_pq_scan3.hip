@@ -51,6 +51,7 @@ constexpr int kFWaves   = kFThreads / 64;
 
 
 // ------------------------------------------------------------------ per-index tables
+// (PER_CLUSTER: pq_dim = n_lists - one table per list, shared by its subspaces; the indexing is the same)
 __global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, uint32_t pq_len, uint32_t book, float sc,
                             uint16_t* __restrict__ cb16)
 {
@@ -99,10 +100,20 @@ __device__ inline float wave_reduce_max_f32(float v)
 // of sc), so that the accumulator of a (row, query) pair ends up holding sc^2 (r.d - |d|^2 (1 - 2^-9) / 2). One thread per row
 __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* __restrict__ pq_centers, int64_t rows, float sc,
                                 uint32_t* __restrict__ term, uint32_t* __restrict__ dn_max_bits, int n_chunks, int fp32, int pq_len,
-                                uint32_t book)
+                                uint32_t book, const uint32_t* __restrict__ list_offsets, uint32_t n_lists)
 {
   const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r  = min(r0, rows - 1);  // (no early exit: the wave reduction below needs every lane)
+  // PER_CLUSTER (list_offsets != nullptr): the codebook is the row's list's - the last list starting at or before the row
+  uint32_t L = 0u;
+  if (list_offsets != nullptr) {
+    uint32_t lo = 0u, hi = n_lists;  // list_offsets[lo] <= r < list_offsets[hi]
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((int64_t)list_offsets[mid] <= r) lo = mid; else hi = mid;
+    }
+    L = lo;
+  }
   const uint4* cp = reinterpret_cast<const uint4*>(codes) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
   float dn = 0.f;
   for (int c = 0; c < n_chunks; ++c) {
@@ -113,7 +124,7 @@ __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* 
       const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
       const uint32_t s    = c * 16 + b;
       for (int l = 0; l < pq_len; ++l) {
-        const float p = pq_centers[(size_t)(s * pq_len + l) * book + code];
+        const float p = pq_centers[(size_t)((list_offsets != nullptr ? L : s) * pq_len + l) * book + code];
         dn = __fmaf_rn(p, p, dn);
       }
     }
@@ -514,6 +525,7 @@ struct rescore_params {
   uint32_t dim;           // IVF-Flat: row length
   int cb_lds;             // IVF-PQ: the fp32 codebook fits the LDS of a workgroup
   uint32_t pq_len, book;
+  int per_cluster;        // IVF-PQ: one codebook per list (pq_centers [n_lists][pq_len][book])
 };
 
 // a re-scored survivor: into the query's pool if it is within the bound, beyond the pool's capacity into the overflow list
@@ -587,8 +599,8 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
         if constexpr (ACC_HALF) ah += e; else af += (float)e;
       }
     };
-    if (a.pq_len != 2u) {
-      // any pq_len: entry (s, code) = the components' chain in order (create_lut_impl.cuh:17-78), subspaces in order
+    if (a.pq_len != 2u || a.per_cluster) {
+      // any pq_len, PER_CLUSTER codebooks: entry (s, code) = the components' chain in order (create_lut_impl.cuh:17-78), subspaces in order
 #pragma unroll 1
       for (int c = 0; c < (int)a.n_chunks; ++c) {
         const uint4 cw       = cp[c * 64];
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
           const uint32_t d0   = (uint32_t)(c * 16 + b) * a.pq_len;
           float v = 0.f;
           for (uint32_t l = 0; l < a.pq_len; ++l) {
-            const float p = pqc[(size_t)(d0 + l) * a.book + code], qv = rq[d0 + l], cv = ct[d0 + l];
+            const float p = pqc[(size_t)(a.per_cluster ? L * a.pq_len + l : d0 + l) * a.book + code], qv = rq[d0 + l], cv = ct[d0 + l];
             if (!a.is_ip) {
               const float d = (qv - cv) - p;
               v = __fmaf_rn(d, d, v);
@@ -809,7 +821,7 @@ struct head_params {
   uint32_t* out_i;
   uint32_t* query_kth;
   uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks, pq_len, book;
-  int is_ip;
+  int is_ip, per_cluster;
   int hcand;  // capacity of a candidate buffer (head_cand(k))
   const uint32_t* filter_bits;
   const int64_t* indices;
@@ -878,7 +890,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ---- LUT (create_lut_impl.cuh:17-78), entry (s, code) at s * 256 + code; the codebook values of 8 entries are
     // loaded before any is used (one L2 round trip per batch instead of one per entry)
 #pragma unroll 1
-    for (uint32_t e0 = tid; e0 < (a.pq_len == 2u ? a.pq_dim * 256u : 0u); e0 += 8u * NT) {
+    for (uint32_t e0 = tid; e0 < ((a.pq_len == 2u && !a.per_cluster) ? a.pq_dim * 256u : 0u); e0 += 8u * NT) {
       float p0[8], p1[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -906,7 +918,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if constexpr (LUT32) lut[e] = v; else lut[e] = to_lut_half(v);
       }
     }
-    if (a.pq_len != 2u) {  // any pq_len: the components' chain in order, four entries in flight
+    if (a.pq_len != 2u || a.per_cluster) {  // any pq_len / PER_CLUSTER codebooks: the components' chain in order, four entries in flight
 #pragma unroll 1
       for (uint32_t e0 = tid; e0 < a.pq_dim * 256u; e0 += 4u * NT) {
         float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -915,7 +927,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = min(e & 255u, a.book - 1u);
-            p[j] = a.pq_centers[(size_t)(sb * a.pq_len + l) * a.book + code];
+            p[j] = a.pq_centers[(size_t)((a.per_cluster ? L : sb) * a.pq_len + l) * a.book + code];
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1275,10 +1287,22 @@ bool pq3_supported(const ivf_pq_index& idx, int k)
 {
   // codes of 4 .. 8 bits (fewer than 8: through a one-byte-per-code copy, pq3_codes), pq_dim a multiple of 16; pq_len 1 / 2 / 4 / 8 (a lane's 8 K elements of an MFMA step = 8 / pq_len codebook
   // entries); at most 16 K steps (the B operands of a unit's queries live in registers) = a decode table of at most
-  // 128 KiB; pq_dim <= 128 (the head phase's LUT in LDS). Round 3's pq_filter_kernel (comparator, inner product): pq_len 2
+  // 128 KiB; pq_dim <= 128 (the head phase's LUT in LDS); PER_SUBSPACE or PER_CLUSTER codebooks. Round 3's pq_filter_kernel
+  // (comparator, inner product): pq_len 2, PER_SUBSPACE
   return idx.pq_bits >= 4 && idx.pq_bits <= 8 && (idx.pq_len == 1 || idx.pq_len == 2 || idx.pq_len == 4 || idx.pq_len == 8) && idx.pq_dim % 16 == 0 &&
          idx.pq_dim >= 16 && idx.pq_dim <= 128 && idx.rot_dim == idx.pq_len * idx.pq_dim && idx.rot_dim <= 256 &&
-         idx.codebook_kind == 0 && k <= 256;
+         k <= 256;
+}
+
+// The tail phase prunes with the k-th score of the query's NEAREST list: useful while k is a small fraction of a list
+// (k = 10 of 6.1 k rows at the bench shape; k = 100: still 4x faster than the LUT scan), useless when it is not - at
+// k = 256 of 2.4 k-row lists (the IVF-PQ searches of a CAGRA build) a tenth of all pairs survived the screen and the
+// re-score took 2.8x the LUT scan's time. Measured crossover: k around 4 % of the mean list length.
+bool pq3_bound_useful(const ivf_pq_index& idx, int k)
+{
+  uint64_t rows = 0, lists = 0;
+  for (uint32_t v : idx.h_list_sizes) { rows += v; lists += v != 0u; }
+  return lists != 0 && (uint64_t)k * 25u * lists <= rows;
 }
 
 static std::recursive_mutex g_pq3_mu;
@@ -1315,9 +1339,10 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_
     // residuals up to 4096 times larger still fit the fp16 range, values 2^17 times smaller are still normal numbers
     c.sc    = mx > 0.f ? std::exp2(std::floor(std::log2(16.0f / mx))) : 1.0f;
     c.cbmax = mx;
-    c.cb16  = dev_buf<uint32_t>::persistent((size_t)idx.pq_dim * 256 * idx.pq_len / 2 + 1);
-    hipLaunchKernelGGL(cb16_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream,
-                       idx.pq_centers.data(), idx.pq_dim, idx.pq_len, idx.pq_book, c.sc, reinterpret_cast<uint16_t*>(c.cb16.data()));
+    const uint32_t n_tables = idx.codebook_kind == 0 ? idx.pq_dim : idx.n_lists;  // PER_CLUSTER: one decode table per list
+    c.cb16  = dev_buf<uint32_t>::persistent((size_t)n_tables * 256 * idx.pq_len / 2 + 1);
+    hipLaunchKernelGGL(cb16_kernel, dim3(grid_blocks((int64_t)n_tables * 256, 256)), dim3(256), 0, res.stream,
+                       idx.pq_centers.data(), n_tables, idx.pq_len, idx.pq_book, c.sc, reinterpret_cast<uint16_t*>(c.cb16.data()));
     c.row_term = dev_buf<uint32_t>::persistent((size_t)std::max<int64_t>(idx.padded_rows, 1));
     dev_buf<uint32_t> mxd(res, 1);
     HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
@@ -1326,7 +1351,7 @@ pq3_tables pq3_prepare(resources& res, const ivf_pq_index& idx, const bool term_
     if (idx.padded_rows > 0)
       hipLaunchKernelGGL(row_term_kernel, dim3(grid_blocks(idx.padded_rows, 256)), dim3(256), 0, res.stream, codes8,
                          idx.pq_centers.data(), idx.padded_rows, c.sc, c.row_term.data(), mxd.data(), (int)nch8, term_fp32 ? 1 : 0,
-                         (int)idx.pq_len, idx.pq_book);
+                         (int)idx.pq_len, idx.pq_book, idx.codebook_kind == 0 ? nullptr : idx.list_offsets.data(), idx.n_lists);
     const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
     float dn_max;
     memcpy(&dn_max, &mbits, 4);
@@ -1358,7 +1383,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   const int nst        = nch * (int)idx.pq_len;         // MFMA K steps = rot_dim / 16
   // queries per work unit: B-operand groups of 32, four (two beyond 8 K steps) with 512 registers per wave, else two (one)
   const uint32_t group = f4 ? (nst <= 8 ? 128u : 64u) : (nch <= 4 ? 64u : 32u);
-  CUVS_EXPECTS(f4 || idx.pq_len == 2, "ivf_pq: pq_filter_kernel decodes pq_len 2 only");
+  CUVS_EXPECTS(f4 || (idx.pq_len == 2 && idx.codebook_kind == 0), "ivf_pq: pq_filter_kernel decodes pq_len 2, PER_SUBSPACE only");
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
                      r.unit_rows, r.unit_off, group);
@@ -1403,7 +1428,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
     l.surv = f.surv; l.surv_cnt = f.surv_cnt; l.surv_entries = r.surv_cap; l.n_probes = r.n_probes;
     l.rot_dim = idx.rot_dim; l.unit_rows = r.unit_rows; l.sc = f.sc; l.c1 = f.c1; l.eps = f.eps; l.alpha = f.alpha;
     l.cbmax = f.cbmax; l.dmax = f.dmax; l.bound_max = f.bound_max; l.is_ip = r.is_ip; l.dbg = r.filter_dbg; l.nch = nch;
-    l.pl = (int)idx.pq_len;
+    l.pl = (int)idx.pq_len; l.per_cluster = idx.codebook_kind != 0 ? 1 : 0;
     l.n_pairs = r.nq * (int64_t)r.n_probes; l.stats = r.stats; l.grid = grid;
     pq4_filter(res, l);
   } else {
@@ -1443,8 +1468,8 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
   const size_t cb_bytes = (size_t)idx.rot_dim * idx.pq_book * sizeof(float);
-  s.pq_len = idx.pq_len; s.book = idx.pq_book;
-  s.cb_lds = cb_bytes <= 128 * 1024 ? 1 : 0;
+  s.pq_len = idx.pq_len; s.book = idx.pq_book; s.per_cluster = idx.codebook_kind != 0 ? 1 : 0;
+  s.cb_lds = (cb_bytes <= 128 * 1024 && !s.per_cluster) ? 1 : 0;
   const size_t rsmem = s.cb_lds ? cb_bytes : 16;
   const dim3 rg(grid + 1, 2), rb(kRThreads);
   profile_begin(res, "pq_rescore_kernel");
@@ -1479,7 +1504,7 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   a.pq_centers = idx.pq_centers.data(); a.codes = pq3_codes(res, idx, &a.n_chunks); a.list_offsets = idx.list_offsets.data();
   a.list_sizes = idx.list_sizes.data(); a.out_d = h.cand_d; a.out_i = h.cand_i; a.query_kth = h.query_kth;
   a.n_probes = h.n_probes; a.rot_dim = idx.rot_dim; a.k = h.k; a.is_ip = h.is_ip; a.pq_dim = idx.pq_dim;
-  a.pq_len = idx.pq_len; a.book = idx.pq_book;
+  a.pq_len = idx.pq_len; a.book = idx.pq_book; a.per_cluster = idx.codebook_kind != 0 ? 1 : 0;
   a.filter_bits = h.filter_bits; a.indices = idx.indices.data(); a.stats = h.stats; a.hcand = head_cand((int)h.k);
   // A LUT of up to 32 KiB (fp16 entries at pq_dim 64): two 512-thread workgroups per CU, one streams its list while the
   // other selects; beyond: one 1024-thread workgroup. The rest of the LDS holds the score keys of a list chunk; longer

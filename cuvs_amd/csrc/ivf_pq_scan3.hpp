@@ -94,6 +94,7 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
 unsigned pq3_grid(const resources& res);     // workgroups of the filter
 unsigned pq3_regions(const resources& res);  // survivor regions of pq_filter_kernel (pq_filter4_kernel hands out chunks instead)
 bool pq3_supported(const ivf_pq_index& idx, int k);
+bool pq3_bound_useful(const ivf_pq_index& idx, int k);  // k is a small enough fraction of a list for the head bound to prune
 size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows, bool filter4);
 // filter + re-score + fallback work items of the flagged queries (the caller launches the LUT scan on them)
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r);

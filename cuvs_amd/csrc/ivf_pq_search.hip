@@ -2051,8 +2051,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   if (res.tune.pq_head_probes >= 0) head = std::min<uint32_t>((uint32_t)res.tune.pq_head_probes, n_probes);
   // signed LUT entries: no early stop in the LUT scan kernels - unless the tail phase runs on the matrix-core filter,
   // which needs no non-negativity (a full-score bound): then the head phase supplies its bounds as for L2
-  const bool pq3_ok = !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0 && res.tune.pq_head_probes != 0 &&
-                      (idx.pq_len == 2 || res.tune.pq_filter4 != 0);
+  const bool pq3_ok = !large_k && pq3_supported(idx, k) && pq3_bound_useful(idx, k) && res.tune.pq_scan3 != 0 && res.tune.pq_head_probes != 0 &&
+                      ((idx.pq_len == 2 && idx.codebook_kind == 0) || res.tune.pq_filter4 != 0);
   if ((idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) && !pq3_ok) head = 0;
   const bool sharded      = idx.shard_world > 1;  // list-sharded index: foreign probes go to a bucket that is never scanned
   const uint32_t n_ranges = head > 0 ? 2 * idx.n_lists : idx.n_lists;
@@ -2075,9 +2075,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): decode + MFMA filter, exact re-score of the survivors
   const bool metric_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
   // (pq_len other than 2 is decoded by pq_filter4_kernel only)
-  const bool use3 = head > 0 && !large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0 && (idx.pq_len == 2 || res.tune.pq_filter4 != 0);
+  const bool use3 = head > 0 && !large_k && pq3_supported(idx, k) && pq3_bound_useful(idx, k) && res.tune.pq_scan3 != 0 && ((idx.pq_len == 2 && idx.codebook_kind == 0) || res.tune.pq_filter4 != 0);
   uint32_t unit_rows = 0;
-  const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows, res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2)) : 0;
+  const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows, res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2 || idx.codebook_kind != 0)) : 0;
   uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 16, 1 << 22), 1 << 28) : 0u;
   if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
   dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)4 * bs_alloc + 8 + pq3_regions(res) : 0);
@@ -2089,7 +2089,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<work_item> fb_items(res, use3 ? (size_t)n_pairs_max : 0);
   // pq_filter4_kernel serves L2 and cosine; unnormalised inner products (loose margins: ~8x the survivors per pair) keep
   // pq_filter_kernel, whose per-lane survivor loop is cheaper at that rate (C3 shape: 3.9 vs 6.7 ms)
-  const bool use_f4 = use3 && res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2);
+  const bool use_f4 = use3 && res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2 || idx.codebook_kind != 0);
   dev_buf<uint4> bq3(res, use_f4 ? (size_t)n_pairs_max * (idx.rot_dim / 8) : 0);  // fp16 B operands of the tail pairs
   dev_buf<float> thr3(res, use_f4 ? (size_t)n_pairs_max : 0);
   uint32_t max_list_len = 0;

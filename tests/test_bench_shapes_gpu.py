@@ -161,6 +161,34 @@ def test_c3_shape_codes_of_fewer_than_8_bits(d, pq_dim, pq_bits, metric, lut, ac
     assert (gi == oi).all() and (gd == od).all()
 
 
+@pytest.mark.parametrize("d,pq_dim,pq_bits,metric,lut,acc", [
+    (128, 64, 8, "sqeuclidean", "f16", "f32"),
+    (128, 64, 8, "inner_product", "f16", "f32"),
+    (128, 32, 8, "sqeuclidean", "f32", "f32"),   # pq_len 4
+    (96, 96, 6, "sqeuclidean", "f16", "f16"),    # pq_len 1, 6-bit codes
+    (128, 16, 8, "cosine", "f16", "f32"),        # pq_len 8
+])
+def test_c3_shape_per_cluster_codebooks(d, pq_dim, pq_bits, metric, lut, acc, monkeypatch):
+    """codebook_gen::PER_CLUSTER on the matrix-core tail phase: pq_filter4_kernel<.., PC> keeps the decode table of the
+    current unit's list in a per-wave LDS region; head LUT, row terms and re-score index the codebook by list - ids and
+    distances identical to the oracle and to the LUT scan kernels."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(100_000, d, 400, seed=3 * d + pq_dim + pq_bits, modes=48)
+    index = _pq_build(x, n_lists=32, pq_dim=pq_dim, pq_bits=pq_bits, metric=metric, kmeans_n_iters=8, kmeans_trainset_fraction=0.2,
+                      codebook_kind="cluster")
+    ex = ivf_pq.export_for_oracle(index, per_cluster=True)
+    k, n_probes = 20, 12
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi = _pq_search(index, q, k, **kw)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_PQ_SCAN3", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    assert (si == oi).all() and (sd == od).all()
+
+
 @pytest.mark.parametrize("k", [129, 200, 256])
 def test_c3_shape_k_up_to_256(big_lists, k, monkeypatch):
     """k = 129 .. 256 (the IVF-PQ searches of a CAGRA build ask for 2 x intermediate_graph_degree = 256 candidates,
