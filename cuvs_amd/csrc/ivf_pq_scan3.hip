@@ -1127,10 +1127,22 @@ __global__ void fallback_items_kernel(const uint32_t* __restrict__ sorted_pairs,
 }
 
 // ------------------------------------------------------------------ overflow list binned by query (count, scan, fill)
+// (the overflow entries of a query arrive in bursts - its survivors sit in the same survivor chunks - so a wave's 64 entries
+// belong to a handful of queries: one atomic per distinct query of a wave instead of one per entry on a few hot counters)
 __global__ void ov_count_kernel(const uint4* __restrict__ ov, const uint32_t* __restrict__ n_ov, uint32_t cap, uint32_t* __restrict__ cnt)
 {
   const uint32_t n = min(*n_ov, cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&cnt[ov[i].x], 1u);
+  for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; i0 < n; i0 += gridDim.x * blockDim.x) {
+    const uint32_t i = i0 + (threadIdx.x & 63u);
+    const uint32_t q = i < n ? ov[i].x : 0xffffffffu;
+    unsigned long long todo = __ballot(q != 0xffffffffu);
+    while (todo != 0ull) {
+      const uint32_t q0 = __builtin_amdgcn_readlane(q, (int)__ffsll((long long)todo) - 1);
+      const unsigned long long same = __ballot(q == q0);
+      if ((threadIdx.x & 63u) == (uint32_t)__ffsll((long long)same) - 1u) atomicAdd(&cnt[q0], (uint32_t)__popcll(same));
+      todo &= ~same;
+    }
+  }
 }
 
 __global__ __launch_bounds__(1024) void ov_scan_kernel(uint32_t* __restrict__ cnt, int64_t nq, uint32_t* __restrict__ off)
@@ -1156,9 +1168,22 @@ __global__ void ov_fill_kernel(const uint4* __restrict__ ov, const uint32_t* __r
                                const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor, uint4* __restrict__ sorted)
 {
   const uint32_t n = min(*n_ov, cap);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const uint4 e = ov[i];
-    sorted[off[e.x] + atomicAdd(&cursor[e.x], 1u)] = e;
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; i0 < n; i0 += gridDim.x * blockDim.x) {
+    const uint32_t i = i0 + lane;
+    uint4 e = make_uint4(0xffffffffu, 0u, 0u, 0u);
+    if (i < n) e = ov[i];
+    unsigned long long todo = __ballot(e.x != 0xffffffffu);
+    while (todo != 0ull) {
+      const uint32_t q0 = __builtin_amdgcn_readlane(e.x, (int)__ffsll((long long)todo) - 1);
+      const unsigned long long same = __ballot(e.x == q0);
+      const uint32_t leader = (uint32_t)__ffsll((long long)same) - 1u;
+      uint32_t base = 0u;
+      if (lane == leader) base = atomicAdd(&cursor[q0], (uint32_t)__popcll(same));
+      base = __builtin_amdgcn_readlane(base, (int)leader);
+      if (e.x == q0) sorted[off[q0] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = e;
+      todo &= ~same;
+    }
   }
 }
 
