@@ -842,12 +842,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   float* cv       = rv + 256;                                                            // [256] list centre
   unsigned long long* min64 = reinterpret_cast<unsigned long long*>(cv + 256);           // [2]
   int* ctrl       = reinterpret_cast<int*>(min64 + 2);                           // [8]
-  uint32_t* tk    = reinterpret_cast<uint32_t*>(ctrl + 8);                       // [NT] smallest key of every thread
+  // (no static LDS in this kernel: the LUT sits at LDS address 0 and a lookup's address is (code byte) << 1 - one SDWA shift)
+  work_item& cur  = *reinterpret_cast<work_item*>(ctrl + 8);                     // the current item, 16 bytes
+  uint32_t* tk    = reinterpret_cast<uint32_t*>(ctrl + 12);                      // [NT] smallest key of every thread
   const int kHCand = a.hcand;
   uint32_t* ckey  = tk + NT;                                                     // [2][kHCand] candidates (two buffers)
   uint32_t* crow  = ckey + 2 * kHCand;                                           // [2][kHCand]
   uint32_t* keys  = crow + 2 * kHCand;                                           // [cap_rows] score keys of the current chunk
-  __shared__ work_item cur;
+  static_assert(sizeof(work_item) == 16, "work_item");
 
   const int tid = threadIdx.x;
   const uint32_t item0   = a.item_begin ? *a.item_begin : 0u;
@@ -976,13 +978,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const int c = c0c + cc;
             if (c >= (int)a.n_chunks) break;
             const uint32_t ws[4] = {cw[cc].x, cw[cc].y, cw[cc].z, cw[cc].w};
+            // the chunk's 16 lookups are issued together, the sum follows in order (left to the compiler every lookup was
+            // followed by a wait for it: one LDS latency per entry and wave)
+            lut_t e[16];
 #pragma unroll
-          for (int b = 0; b < 16; ++b) {
-            const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-              const lut_t e       = lut[((c * 16 + b) << 8) + code];
-              if constexpr (LUT32) af += e;
-              else if constexpr (ACC_HALF) ah += e;
-              else af += (float)e;
+            for (int b = 0; b < 16; ++b) e[b] = lut[((c * 16 + b) << 8) + ((ws[b >> 2] >> ((b & 3) * 8)) & 0xffu)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+              if constexpr (LUT32) af += e[b];
+              else if constexpr (ACC_HALF) ah += e[b];
+              else af += (float)e[b];
             }
           }
         }
@@ -1518,7 +1524,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
 static size_t head_smem_fixed(const ivf_pq_index& idx, int lut_mode, bool acc_half, int nt, int k)
 {
   const bool lut32 = lut_mode == 0 || (lut_mode == 2 && !acc_half);
-  return (size_t)idx.pq_dim * 256 * (lut32 ? 4 : 2) + 2 * 256 * 4 + 16 + 32 + (size_t)nt * 4 + 4 * (size_t)head_cand(k) * 4;
+  return (size_t)idx.pq_dim * 256 * (lut32 ? 4 : 2) + 2 * 256 * 4 + 16 + 32 + 16 + (size_t)nt * 4 + 4 * (size_t)head_cand(k) * 4;
 }
 
 void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
