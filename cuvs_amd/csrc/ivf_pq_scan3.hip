@@ -549,22 +549,68 @@ __device__ inline void pool_append(const rescore_params& a, const uint32_t q, co
   a.cand_r[o] = pair % a.n_probes;
 }
 
+// the same for a whole wave (every lane calls it, `want`: this lane holds a re-scored survivor): the survivors of a query
+// arrive together - a loose bound means thousands of them in neighbouring chunks - so the lanes of a wave that append to
+// the same pool draw their positions with ONE atomic, and so do the lanes that run over into the shared overflow list
+__device__ inline void pool_append_wave(const rescore_params& a, bool want, const uint32_t q, const uint32_t pair, const uint32_t row,
+                                        const float score)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  want = want && float_to_key(score) <= a.query_kth[want ? q : 0u];
+  const uint32_t cap = (a.n_probes - a.head) * a.k;
+  bool over = false;
+  unsigned long long todo = __ballot(want);
+  while (todo != 0ull) {
+    const uint32_t q0 = __builtin_amdgcn_readlane(q, (int)__ffsll((long long)todo) - 1);
+    const unsigned long long same = __ballot(want && q == q0);
+    const uint32_t leader = (uint32_t)__ffsll((long long)same) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(&a.qcnt[q0], (uint32_t)__popcll(same));
+    base = __builtin_amdgcn_readlane(base, (int)leader);
+    if (want && q == q0) {
+      const uint32_t pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+      if (pos < cap) {
+        const size_t o = (size_t)q * a.n_probes * a.k + (size_t)a.head * a.k + pos;
+        a.cand_d[o] = score;
+        a.cand_i[o] = row;
+        a.cand_r[o] = pair % a.n_probes;
+      } else {
+        over = true;
+      }
+    }
+    todo &= ~same;
+  }
+  const unsigned long long om = __ballot(over);
+  if (om != 0ull) {
+    const uint32_t leader = (uint32_t)__ffsll((long long)om) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(a.overflow_cnt, (uint32_t)__popcll(om));
+    base = __builtin_amdgcn_readlane(base, (int)leader);
+    if (over) {
+      const uint32_t ov = base + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
+      if (ov < a.overflow_cap) a.overflow[ov] = make_uint4(q, __float_as_uint(score), pair % a.n_probes, row);
+      else if (a.fail != nullptr) *a.fail = 1u;
+      else a.qflag[q] = 1u;
+    }
+  }
+}
+
 constexpr int kRThreads = 1024;
 
 // The codebook (128 KiB of fp32 at pq_dim 64) is staged in LDS once per workgroup: a survivor's 128 codebook values were
 // 128 scattered L2 reads per lane; the query / centre values of a 16-subspace chunk are read as 16-byte vectors.
-template <int LUT, bool ACC_HALF>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
+template <int LUT, bool ACC_HALF, bool CB_LDS>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>); CB_LDS: the codebook is staged in LDS
 __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_params a)
 {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* cb = reinterpret_cast<float*>(smem);  // [pq_dim * pq_len][256] when it fits (cb_lds), else read from memory
-  if (a.cb_lds) {
+  if constexpr (CB_LDS) {
     const uint32_t n4 = a.n_chunks * 16u * a.pq_len * a.book / 4u;
     for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x)
       reinterpret_cast<float4*>(cb)[i] = reinterpret_cast<const float4*>(a.pq_centers)[i];
     __syncthreads();
   }
-  const float* __restrict__ pqc = a.cb_lds ? cb : a.pq_centers;
+  const float* pqc = CB_LDS ? cb : a.pq_centers;  // (the generic branch below: any address space)
   // region blockIdx.x of the filter's workgroups, the last workgroup takes the shared spill region; chunked buffer
   // (pq_filter4_kernel): all workgroups stride over the chunks drawn
   const bool chunked = a.sub == 0u;
@@ -575,21 +621,25 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
   const uint32_t s_first  = chunked ? (blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x : blockIdx.y * blockDim.x + threadIdx.x;
   const uint32_t s_stride = chunked ? gridDim.x * gridDim.y * blockDim.x : gridDim.y * blockDim.x;
   {
-  for (uint32_t s = s_first; s < n; s += s_stride) {
-    const uint2 sv = region[s];
-    const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
-    if (pair == 0xffffffffu) continue;  // (padding of a chunk's tail)
-    if (a.qflag[q] != 0u) continue;  // re-done by the LUT scan
-    if (a.filter_bits != nullptr) {
+  const uint32_t lane_ = threadIdx.x & 63u;
+  for (uint32_t sb = s_first - lane_; sb < n; sb += s_stride) {  // (wave-uniform trip count: pool_append_wave is a wave operation)
+    const uint32_t s = sb + lane_;
+    uint2 sv = make_uint2(0xffffffffu, 0u);
+    if (s < n) sv = region[s];
+    bool ok = sv.x != 0xffffffffu;  // (padding of a chunk's tail)
+    const uint32_t pair = ok ? sv.x : 0u, row = ok ? sv.y : 0u, q = pair / a.n_probes;
+    ok = ok && a.qflag[q] == 0u;    // flagged: re-done by the LUT scan
+    if (ok && a.filter_bits != nullptr) {
       const int64_t sid = a.indices[row];
-      if (((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) == 0u) continue;
+      ok = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
     }
+    float af       = 0.f;
+    _Float16 ah    = (_Float16)0.f;
+    if (ok) {
     const uint32_t L = a.probes[pair];
     const float* rq  = a.rot_queries + (size_t)q * a.rot_dim;
     const float* ct  = a.centers_rot + (size_t)L * a.rot_dim;
     const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
-    float af       = 0.f;
-    _Float16 ah    = (_Float16)0.f;
     auto add_entry = [&](float v) {  // one LUT entry in the reference's arithmetic: LUT type, then the score type's sum
       if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
       if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
@@ -624,39 +674,52 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
         }
       }
     } else {
+      // pq_len 2, PER_SUBSPACE: half a chunk (8 subspaces) at a time - its 16 codebook values (LDS when the codebook fits) and
+      // 8 query / centre vectors are all requested before the first is used: a thread holds one or two survivors, so the
+      // kernel's time is its chains of memory latencies, not its arithmetic
 #pragma unroll 1
-    for (int c = 0; c < (int)a.n_chunks; ++c) {
-      const uint4 cw       = cp[c * 64];
-      const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
-      float qq[32], cc[32];  // the chunk's 16 subspaces x 2 components of the query and of the list centre
+      for (int c = 0; c < (int)a.n_chunks; ++c) {
+        const uint4 cw       = cp[c * 64];
+        const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float4 qv = *reinterpret_cast<const float4*>(rq + c * 32 + j * 4), cv = *reinterpret_cast<const float4*>(ct + c * 32 + j * 4);
-        qq[j * 4] = qv.x; qq[j * 4 + 1] = qv.y; qq[j * 4 + 2] = qv.z; qq[j * 4 + 3] = qv.w;
-        cc[j * 4] = cv.x; cc[j * 4 + 1] = cv.y; cc[j * 4 + 2] = cv.z; cc[j * 4 + 3] = cv.w;
-      }
+        for (int hh = 0; hh < 2; ++hh) {
+          float qq[16], cc[16], p0[8], p1[8];
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-        const uint32_t sb   = c * 16 + b;
-        const float p0 = pqc[(size_t)(sb * 2 + 0) * a.book + code], p1 = pqc[(size_t)(sb * 2 + 1) * a.book + code];
-        const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cc[b * 2], c1 = cc[b * 2 + 1];
-        float v;
-        if (!a.is_ip) {
-          const float d0 = (q0 - c0) - p0, d1 = (q1 - c1) - p1;
-          v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-        } else {
-          v = __fmaf_rn(-q0, c0, 0.f);
-          v = __fmaf_rn(-q0, p0, v);
-          v = __fmaf_rn(-q1, c1, v);
-          v = __fmaf_rn(-q1, p1, v);
+          for (int j = 0; j < 4; ++j) {
+            const float4 qv = *reinterpret_cast<const float4*>(rq + c * 32 + hh * 16 + j * 4),
+                         cv = *reinterpret_cast<const float4*>(ct + c * 32 + hh * 16 + j * 4);
+            qq[j * 4] = qv.x; qq[j * 4 + 1] = qv.y; qq[j * 4 + 2] = qv.z; qq[j * 4 + 3] = qv.w;
+            cc[j * 4] = cv.x; cc[j * 4 + 1] = cv.y; cc[j * 4 + 2] = cv.z; cc[j * 4 + 3] = cv.w;
+          }
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const int bb        = hh * 8 + b;
+            const uint32_t code = (ws[bb >> 2] >> ((bb & 3) * 8)) & 0xffu;
+            const uint32_t e0   = (uint32_t)((c * 16 + bb) * 2) * a.book + code;
+            if constexpr (CB_LDS) { p0[b] = cb[e0]; p1[b] = cb[e0 + a.book]; }
+            else                  { p0[b] = a.pq_centers[e0]; p1[b] = a.pq_centers[e0 + a.book]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < 8; ++b) {
+            const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cc[b * 2], c1 = cc[b * 2 + 1];
+            float v;
+            if (!a.is_ip) {
+              const float d0 = (q0 - c0) - p0[b], d1 = (q1 - c1) - p1[b];
+              v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+            } else {
+              v = __fmaf_rn(-q0, c0, 0.f);
+              v = __fmaf_rn(-q0, p0[b], v);
+              v = __fmaf_rn(-q1, c1, v);
+              v = __fmaf_rn(-q1, p1[b], v);
+            }
+            add_entry(v);
+          }
         }
-        add_entry(v);
       }
     }
     }
-    const float score = ACC_HALF ? (float)ah : af;
-    pool_append(a, q, pair, row, score);
+    pool_append_wave(a, ok, q, pair, row, ACC_HALF ? (float)ah : af);
   }
   }
 }
@@ -1508,9 +1571,15 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));
     hipLaunchKernelGGL(kern, rg, rb, rsmem, res.stream, s);
   };
-  if (r.lut_mode == 0)      launch_rescore(pq_rescore_kernel<0, false>);
-  else if (r.lut_mode == 1) { if (r.acc_half) launch_rescore(pq_rescore_kernel<1, true>); else launch_rescore(pq_rescore_kernel<1, false>); }
-  else                      { if (r.acc_half) launch_rescore(pq_rescore_kernel<2, true>); else launch_rescore(pq_rescore_kernel<2, false>); }
+  auto pick_rescore = [&](auto lut_tag, auto acc_tag) {
+    constexpr int LUT = decltype(lut_tag)::value;
+    constexpr bool ACC = decltype(acc_tag)::value;
+    if (s.cb_lds) launch_rescore(pq_rescore_kernel<LUT, ACC, true>); else launch_rescore(pq_rescore_kernel<LUT, ACC, false>);
+  };
+  using L0 = std::integral_constant<int, 0>; using L1 = std::integral_constant<int, 1>; using L2 = std::integral_constant<int, 2>;
+  if (r.lut_mode == 0)      pick_rescore(L0{}, std::false_type{});
+  else if (r.lut_mode == 1) { if (r.acc_half) pick_rescore(L1{}, std::true_type{}); else pick_rescore(L1{}, std::false_type{}); }
+  else                      { if (r.acc_half) pick_rescore(L2{}, std::true_type{}); else pick_rescore(L2{}, std::false_type{}); }
   profile_end(res, "pq_rescore_kernel");
   // flagged queries: their candidate rows go back to "per-pair segments, nothing found yet", their tail pairs become
   // single-pair work items of the LUT scan kernel (launched by the caller)
