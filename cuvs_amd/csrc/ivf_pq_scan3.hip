@@ -528,30 +528,12 @@ struct rescore_params {
   int per_cluster;        // IVF-PQ: one codebook per list (pq_centers [n_lists][pq_len][book])
 };
 
-// a re-scored survivor: into the query's pool if it is within the bound, beyond the pool's capacity into the overflow list
-__device__ inline void pool_append(const rescore_params& a, const uint32_t q, const uint32_t pair, const uint32_t row, const float score)
-{
-  if (float_to_key(score) > a.query_kth[q]) return;
-  const uint32_t cap = (a.n_probes - a.head) * a.k;
-  const uint32_t pos = atomicAdd(&a.qcnt[q], 1u);
-  if (pos >= cap) {
-    // a loose head bound: the query's further candidates go to a list shared by all such queries (binned by query
-    // before the merge); only when that is full too is the query handed back (IVF-Flat: the batch is re-run)
-    const uint32_t ov = atomicAdd(a.overflow_cnt, 1u);
-    if (ov < a.overflow_cap) a.overflow[ov] = make_uint4(q, __float_as_uint(score), pair % a.n_probes, row);
-    else if (a.fail != nullptr) *a.fail = 1u;
-    else a.qflag[q] = 1u;
-    return;
-  }
-  const size_t o = (size_t)q * a.n_probes * a.k + (size_t)a.head * a.k + pos;
-  a.cand_d[o] = score;
-  a.cand_i[o] = row;
-  a.cand_r[o] = pair % a.n_probes;
-}
-
-// the same for a whole wave (every lane calls it, `want`: this lane holds a re-scored survivor): the survivors of a query
-// arrive together - a loose bound means thousands of them in neighbouring chunks - so the lanes of a wave that append to
-// the same pool draw their positions with ONE atomic, and so do the lanes that run over into the shared overflow list
+// A re-scored survivor goes into its query's pool if it is within the bound, beyond the pool's capacity (a loose head
+// bound) into a list shared by all such queries (binned by query before the merge); only when that is full too is the
+// query handed back (IVF-Flat: the batch is re-run). A wave operation - every lane calls it, `want`: this lane holds a
+// re-scored survivor: the survivors of a query arrive together (a loose bound means thousands of them in neighbouring
+// chunks), so the lanes of a wave that append to the same pool draw their positions with ONE atomic, and so do the lanes
+// that run over into the overflow list (one atomic per survivor on a few hot counters was half of the kernel's time)
 __device__ inline void pool_append_wave(const rescore_params& a, bool want, const uint32_t q, const uint32_t pair, const uint32_t row,
                                         const float score)
 {
@@ -832,32 +814,37 @@ __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params 
   const uint32_t ri = spill ? a.n_regions : blockIdx.x;
   const uint32_t n = spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri];
   const uint2* region = a.surv + (size_t)ri * a.surv_cap;
-  for (uint32_t s = blockIdx.y * blockDim.x + threadIdx.x; s < n; s += gridDim.y * blockDim.x) {
-    const uint2 sv = region[s];
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t sb = blockIdx.y * blockDim.x + threadIdx.x - lane; sb < n; sb += gridDim.y * blockDim.x) {  // (wave-uniform trip count)
+    const uint32_t s = sb + lane;
+    bool ok = s < n;
+    const uint2 sv = ok ? region[s] : make_uint2(0u, 0u);
     const uint32_t pair = sv.x, row = sv.y, q = pair / a.n_probes;
-    if (a.filter_bits != nullptr) {
+    if (ok && a.filter_bits != nullptr) {
       const int64_t sid = a.indices[row];
-      if (((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) == 0u) continue;
+      ok = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
     }
-    const float* rq = a.rot_queries + (size_t)q * a.dim;
-    const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
     float acc = 0.f;
-    constexpr int VL = 16 / sizeof(T);
-    for (uint32_t c = 0; c < a.n_chunks; ++c) {
-      float x[VL];
-      chunk_to_float<T>(cp[(size_t)c * 64], x);
+    if (ok) {
+      const float* rq = a.rot_queries + (size_t)q * a.dim;
+      const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
+      constexpr int VL = 16 / sizeof(T);
+      for (uint32_t c = 0; c < a.n_chunks; ++c) {
+        float x[VL];
+        chunk_to_float<T>(cp[(size_t)c * 64], x);
 #pragma unroll
-      for (int e4 = 0; e4 < VL / 4; ++e4) {
-        const float4 qv   = *reinterpret_cast<const float4*>(rq + c * VL + e4 * 4);
-        const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
+        for (int e4 = 0; e4 < VL / 4; ++e4) {
+          const float4 qv   = *reinterpret_cast<const float4*>(rq + c * VL + e4 * 4);
+          const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = qq[e] - x[e4 * 4 + e];
-          acc = __fmaf_rn(t, t, acc);
+          for (int e = 0; e < 4; ++e) {
+            const float t = qq[e] - x[e4 * 4 + e];
+            acc = __fmaf_rn(t, t, acc);
+          }
         }
       }
     }
-    pool_append(a, q, pair, row, acc);
+    pool_append_wave(a, ok, q, pair, row, acc);
   }
 }
 
