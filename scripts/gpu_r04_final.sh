@@ -19,3 +19,7 @@ for x in rows[1:]:
 P
 timeout 600 python bench.py --config c5 --rows 50000000 --steps 10 --warmup 2 > gpurun_out/${T}_c5_50m.json 2> gpurun_out/${T}_c5.err
 echo "c5 rc=$?"; grep '^{"metric"' gpurun_out/${T}_c5_50m.json | cut -c1-300
+timeout 600 python scripts/pq_len_timing.py 2>&1 | grep -v amdgpu.ids | tail -8 > gpurun_out/${T}_pq_len.log; cat gpurun_out/${T}_pq_len.log
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $W/cd -o cd -- python $GRAFT_REPO_ROOT/scripts/coarse_dtype_profile.py 16384 > $GRAFT_REPO_ROOT/gpurun_out/${T}_coarse.log 2>&1)
+find $W/cd -name "*kernel_stats.csv" -exec cp {} gpurun_out/${T}_coarse_kernel_stats.csv \;
+grep "^coarse" gpurun_out/${T}_coarse.log
