@@ -32,8 +32,9 @@ namespace {
 // (reference: cuvs::core::bitset / bitmap_view semantics, sample_filter.cuh)
 __global__ void apply_filter_kernel(float* d, int64_t m, int64_t n_tile, int64_t ldo, int64_t col0,
                                     int64_t row0, int64_t n_total, const uint32_t* bits, bool bitmap,
-                                    float worst)
+                                    float worst, const uint32_t* run_if = nullptr)
 {
+  if (run_if != nullptr && *run_if == 0u) return;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < m * n_tile;
        idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = idx / n_tile, c = idx % n_tile;
@@ -209,13 +210,18 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   const int64_t n0      = std::min<int64_t>(std::min<int64_t>(n_tile, round_up(n, 128)), round_up(n0_want, 128));
   // (a workspace too small for a first tile of k columns: the tile path below)
   const bool fused_filter = running && std::min<int64_t>(n0, n) >= k && !res.tune.bf_no_fused_filter;
+  // rows whose candidates were cut (below) are redone by the per-tile select path. With few column tiles that path is
+  // ENQUEUED behind the fused one, every launch guarded on the device by the row tile's overflow flag (a handful of
+  // no-op launches in the common case, no host round trip: the call stays asynchronous); with many, the flags are read
+  // back once (a sync of tens of microseconds on a search of tens of milliseconds)
+  const bool guarded = fused_filter && n_ct <= 4 && !res.tune.bf_host_flags;
+  dev_buf<int> ovf(res, fused_filter ? redo.size() : 0);
   if (fused_filter) {
     const int64_t ld0 = std::min<int64_t>(n0, n);
     dev_buf<float> buf_v(res, (size_t)m_tile * (k + kBfCap));
     dev_buf<int64_t> buf_i(res, (size_t)m_tile * (k + kBfCap));
     dev_buf<int> cnt(res, (size_t)m_tile);
     const size_t n_row_tiles = redo.size();
-    dev_buf<int> ovf(res, n_row_tiles);
     HIP_TRY(hipMemsetAsync(ovf.data(), 0, ovf.bytes(), res.stream));
     for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
       const int64_t mr = std::min(m_tile, m - r0);
@@ -249,10 +255,14 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     // a row with more than kBfCap better elements in one tile (columns arriving in improving order, or a pre-filter
     // that leaves fewer than k of the first tile) had its candidates cut: such row tiles are redone by the per-tile
     // select path below. One host round trip per search, only to read the flags.
-    std::vector<int> h_ovf(n_row_tiles, 0);
-    HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
-    HIP_TRY(hipStreamSynchronize(res.stream));
-    for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
+    if (guarded) {
+      for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = 1;
+    } else {
+      std::vector<int> h_ovf(n_row_tiles, 0);
+      HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+      HIP_TRY(hipStreamSynchronize(res.stream));
+      for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
+    }
   } else if (running) {
     const int64_t nt2   = std::max<int64_t>(128, std::min<int64_t>((n_tile / 2) / 128 * 128, round_up((n + 3) / 4, 128)));
     const int64_t n_ct2 = (n + nt2 - 1) / nt2;
@@ -317,10 +327,14 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     // a row with more than kBfCap better elements in one tile (columns arriving in improving order) had its candidates
     // cut: such row tiles are redone by the per-tile select path below. One host round trip per search, only to read
     // the flags - the common case leaves the results where they are.
-    std::vector<int> h_ovf(n_row_tiles, 0);
-    HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
-    HIP_TRY(hipStreamSynchronize(res.stream));
-    for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
+    if (guarded) {
+      for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = 1;
+    } else {
+      std::vector<int> h_ovf(n_row_tiles, 0);
+      HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+      HIP_TRY(hipStreamSynchronize(res.stream));
+      for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
+    }
   }
   bool any_redo = false;
   for (char c : redo) any_redo = any_redo || c;
@@ -332,28 +346,29 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
     if (!redo[(size_t)(r0 / m_tile)]) continue;
     const int64_t mr = std::min(m_tile, m - r0);
+    const uint32_t* run_if = guarded ? reinterpret_cast<const uint32_t*>(ovf.data() + r0 / m_tile) : nullptr;
     for (int64_t ct = 0; ct < n_ct; ++ct) {
       const int64_t c0 = ct * n_tile;
       const int64_t nc = std::min(n_tile, n - c0);
       pairwise_distance<T, T>(res, queries + r0 * ldq, mr, ldq, data + c0 * idx.ld, nc, idx.ld, idx.dim,
                               qn.data() ? qn.data() + r0 : nullptr,
-                              idx.norms.data() ? idx.norms.data() + c0 : nullptr, metric, tile.data(), ldo);
+                              idx.norms.data() ? idx.norms.data() + c0 : nullptr, metric, tile.data(), ldo, run_if);
       if (filter_type != NO_FILTER) {
         int64_t total = mr * nc;
         hipLaunchKernelGGL(apply_filter_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 1 << 22)), dim3(256), 0, res.stream,
-                           tile.data(), mr, nc, ldo, c0, r0, n, filter_bits, filter_type == BITMAP, worst);
+                           tile.data(), mr, nc, ldo, c0, r0, n, filter_bits, filter_type == BITMAP, worst, run_if);
       }
       if (n_ct == 1) {
         select_k<int64_t, int64_t>(res, tile.data(), nullptr, mr, nc, ldo, k, distances + r0 * k,
-                                   neighbors + r0 * k, select_min, c0);
+                                   neighbors + r0 * k, select_min, c0, -1, 0, run_if);
       } else {
         select_k<int64_t, int64_t>(res, tile.data(), nullptr, mr, nc, ldo, k, part_v.data(), part_i.data(),
-                                   select_min, c0, n_ct * k, ct * k);
+                                   select_min, c0, n_ct * k, ct * k, run_if);
       }
     }
     if (n_ct > 1) {
       select_k<int64_t, int64_t>(res, part_v.data(), part_i.data(), mr, n_ct * k, n_ct * k, k,
-                                 distances + r0 * k, neighbors + r0 * k, select_min);
+                                 distances + r0 * k, neighbors + r0 * k, select_min, 0, -1, 0, run_if);
     }
   }
   HIP_TRY(hipGetLastError());

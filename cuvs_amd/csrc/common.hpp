@@ -91,6 +91,7 @@ struct tuning {
   int alloc_cache       = 1;   // CUVS_AMD_ALLOC_CACHE=0: every scratch buffer goes back to the runtime's pool when it is freed
   bool shard_coarse_replicated = false;  // CUVS_AMD_SHARD_COARSE_REPLICATED
   bool bf_fused = false, bf_no_threshold = false, bf_no_fused_filter = false;  // CUVS_AMD_BF_*
+  bool bf_host_flags = false;  // CUVS_AMD_BF_HOST_FLAGS=1: the overflow flags of the fused path are read back by the host (rounds 2-3; comparator)
   bool dist_old         = false;  // CUVS_AMD_DIST_OLD
   int tile_dbg          = 0;      // CUVS_AMD_TILE_DBG
   int flat_head_probes  = -1;     // CUVS_AMD_FLAT_HEAD_PROBES

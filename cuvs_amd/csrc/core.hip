@@ -171,6 +171,7 @@ tuning load_tuning_from_env()
   t.bf_fused           = set("CUVS_AMD_BF_FUSED");
   t.bf_no_threshold    = set("CUVS_AMD_BF_NO_THRESHOLD");
   t.bf_no_fused_filter = set("CUVS_AMD_BF_NO_FUSED_FILTER");
+  t.bf_host_flags = set("CUVS_AMD_BF_HOST_FLAGS");
   t.dist_old           = set("CUVS_AMD_DIST_OLD");
   t.tile_dbg           = geti("CUVS_AMD_TILE_DBG", 0);
   t.flat_head_probes   = geti("CUVS_AMD_FLAT_HEAD_PROBES", -1);

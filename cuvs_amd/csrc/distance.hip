@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void dist_mfma_kernel(const TQ* __restrict__ q
 {
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+  if (ep.run_if != nullptr && *ep.run_if == 0u) return;  // a guarded launch whose condition did not arise
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -328,6 +329,7 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
 {
   __shared__ __attribute__((aligned(16))) float As[2][BK * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDT];
+  if (ep.run_if != nullptr && *ep.run_if == 0u) return;  // a guarded launch whose condition did not arise
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -565,12 +567,12 @@ void normalize_rows(resources& res, float* x, int64_t n, int64_t dim)
 template <typename TQ, typename TX>
 void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n,
                        int64_t ldx, int64_t dim, const float* qn, const float* xn, int metric,
-                       float* out, int64_t ldo)
+                       float* out, int64_t ldo, const uint32_t* run_if)
 {
   if (m == 0 || n == 0) return;
   CUVS_EXPECTS(metric_supported(metric), "pairwise_distance: unsupported metric %d", metric);
   if (metric != M_InnerProduct) CUVS_EXPECTS(qn && xn, "pairwise_distance: norms required");
-  epilogue_args ep{qn, xn, metric, (sizeof(TX) == 2 ? 1e-3f : 1e-6f)};
+  epilogue_args ep{qn, xn, metric, (sizeof(TX) == 2 ? 1e-3f : 1e-6f), run_if};
   dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((m + BM - 1) / BM));
   CUVS_EXPECTS((m + BM - 1) / BM <= 65535, "pairwise_distance: too many query rows per call");
   bool vec = vec_ok(q, ldq, dim) && vec_ok(x, ldx, dim);
@@ -676,7 +678,7 @@ INST_N(float) INST_N(__half) INST_N(int8_t) INST_N(uint8_t)
 
 #define INST_P(TQ, TX)                                                                                    \
   template void pairwise_distance<TQ, TX>(resources&, const TQ*, int64_t, int64_t, const TX*, int64_t,    \
-                                          int64_t, int64_t, const float*, const float*, int, float*, int64_t);
+                                          int64_t, int64_t, const float*, const float*, int, float*, int64_t, const uint32_t*);
 INST_P(float, float) INST_P(__half, __half) INST_P(__half, float) INST_P(int8_t, float) INST_P(uint8_t, float)
 #undef INST_P
 

@@ -58,6 +58,7 @@ struct epilogue_args {
   const float* xn;
   int metric;
   float clamp_eps;
+  const uint32_t* run_if = nullptr;  // device word: the launch is a no-op while it is zero (nullptr: always runs)
 };
 
 __device__ inline float finish_distance(float dot, float qn, float xn, int metric, float clamp_eps)

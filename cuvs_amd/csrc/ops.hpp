@@ -37,7 +37,8 @@ void normalize_rows(resources& res, float* x, int64_t n, int64_t dim);
 template <typename TQ, typename TX>
 void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, const TX* x, int64_t n,
                        int64_t ldx, int64_t dim, const float* qn, const float* xn, int metric,
-                       float* out, int64_t ldo);
+                       float* out, int64_t ldo, const uint32_t* run_if = nullptr);
+// (run_if: a device word - the launch is a no-op while it is zero: fallback passes enqueued without a host round trip)
 
 // The same distance tile, kept in registers: every element (i, j) that beats row i's current k-th value
 // buf_v[i * (k + cap) + k - 1] (strictly) and passes the pre-filter is appended - value and source id col_off + j -
