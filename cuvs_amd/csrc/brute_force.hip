@@ -106,7 +106,7 @@ __global__ void bf_store_topk_kernel(const float* __restrict__ v, const int64_t*
 // of the tiled path: ties go to the smaller id - and keeps the first k. Column tiles grow geometrically: after `seen`
 // columns a further `seen * cap / (4 k)` are expected to append cap / 4 per row.
 __global__ __launch_bounds__(256) void bf_merge_appended_kernel(float* __restrict__ buf_v, int64_t* __restrict__ buf_i,
-                                                                const int* __restrict__ cnt, int k, bool select_min,
+                                                                int* __restrict__ cnt, int k, bool select_min,
                                                                 int* __restrict__ overflow)
 {
   __shared__ float sv[2 * kBfCap];
@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256) void bf_merge_appended_kernel(float* __restric
   const int64_t row = blockIdx.x;
   int c             = cnt[row];
   if (c == 0) return;  // workgroup-uniform
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[row] = 0;  // ready for the next tile's appends (no memset between the tiles)
   if (c > kBfCap) { if (threadIdx.x == 0) *overflow = 1; c = kBfCap; }
   const int total   = k + c;
   int P             = 1;
@@ -215,13 +217,14 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
   // no-op launches in the common case, no host round trip: the call stays asynchronous); with many, the flags are read
   // back once (a sync of tens of microseconds on a search of tens of milliseconds)
   const bool guarded = fused_filter && n_ct <= 4 && !res.tune.bf_host_flags;
-  dev_buf<int> ovf(res, fused_filter ? redo.size() : 0);
+  // overflow flags of the row tiles, then the rows' append counters (zeroed once: the merge kernel resets what it used)
+  dev_buf<int> ovf(res, fused_filter ? redo.size() + (size_t)m_tile : 0);
   if (fused_filter) {
     const int64_t ld0 = std::min<int64_t>(n0, n);
     dev_buf<float> buf_v(res, (size_t)m_tile * (k + kBfCap));
     dev_buf<int64_t> buf_i(res, (size_t)m_tile * (k + kBfCap));
-    dev_buf<int> cnt(res, (size_t)m_tile);
     const size_t n_row_tiles = redo.size();
+    int* cnt = ovf.data() + n_row_tiles;
     HIP_TRY(hipMemsetAsync(ovf.data(), 0, ovf.bytes(), res.stream));
     for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
       const int64_t mr = std::min(m_tile, m - r0);
@@ -240,13 +243,12 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
       for (int64_t seen = nc0; seen < n;) {
         int64_t nc = (int64_t)((double)seen * kBfCap / (4.0 * k));
         nc         = std::min<int64_t>(n - seen, std::max<int64_t>(16384, nc / 128 * 128));
-        HIP_TRY(hipMemsetAsync(cnt.data(), 0, (size_t)mr * sizeof(int), res.stream));
         pairwise_threshold_append<T, T>(res, qr, mr, ldq, data + seen * idx.ld, nc, idx.ld, idx.dim, qnr,
                                         idx.norms.data() ? idx.norms.data() + seen : nullptr, metric, buf_v.data(),
-                                        buf_i.data(), cnt.data(), k, kBfCap, seen, r0, n, filter_bits,
+                                        buf_i.data(), cnt, k, kBfCap, seen, r0, n, filter_bits,
                                         filter_type == NO_FILTER ? 0 : (filter_type == BITMAP ? 2 : 1));
         hipLaunchKernelGGL(bf_merge_appended_kernel, dim3((unsigned)mr), dim3(256), 0, res.stream, buf_v.data(), buf_i.data(),
-                           cnt.data(), k, select_min, ovf.data() + r0 / m_tile);
+                           cnt, k, select_min, ovf.data() + r0 / m_tile);
         seen += nc;
       }
       hipLaunchKernelGGL(bf_emit_topk_kernel, dim3(grid_blocks(mr * k, 256)), dim3(256), 0, res.stream, buf_v.data(),
@@ -259,7 +261,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
       for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = 1;
     } else {
       std::vector<int> h_ovf(n_row_tiles, 0);
-      HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+      HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), n_row_tiles * sizeof(int), hipMemcpyDeviceToHost, res.stream));
       HIP_TRY(hipStreamSynchronize(res.stream));
       for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
     }
@@ -331,7 +333,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
       for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = 1;
     } else {
       std::vector<int> h_ovf(n_row_tiles, 0);
-      HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), ovf.bytes(), hipMemcpyDeviceToHost, res.stream));
+      HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), n_row_tiles * sizeof(int), hipMemcpyDeviceToHost, res.stream));
       HIP_TRY(hipStreamSynchronize(res.stream));
       for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
     }

@@ -276,7 +276,10 @@ __global__ __launch_bounds__(kSelThreads) void select_k_minima_kernel(const floa
   }
   __syncthreads();
   const uint32_t cnt = ctrl[0];
-  if (cnt > (uint32_t)kMinCap || cnt < (uint32_t)k) return;  // (workgroup-uniform) masses of ties at the bound: the radix kernel
+  if (cnt > (uint32_t)kMinCap || cnt < (uint32_t)k) {  // (workgroup-uniform) masses of ties at the bound: the radix kernel
+    if (tid == 0) done[row] = 0u;
+    return;
+  }
   int P = 1;
   while (P < (int)cnt) P <<= 1;
   for (int t = (int)cnt + tid; t < P; t += kSelThreads) cand[t] = ~0ull;
@@ -324,8 +327,7 @@ void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t row
   const bool minima = in_idx == nullptr && k >= 8 && k <= 256 && len >= 4096 && len <= 16384 && len % 4 == 0 && in_ld % 4 == 0 &&
                       (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (int64_t)k * 8 <= len;
   dev_buf<uint8_t> done(res, minima ? (size_t)rows : 0);
-  if (minima) {
-    HIP_TRY(hipMemsetAsync(done.data(), 0, (size_t)rows, res.stream));
+  if (minima) {  // (the kernel writes every row's flag - 0 or 1 - unless the whole launch is guarded off, and then so is the next)
     auto launch_min = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(kSelThreads), 0, res.stream, in, len, in_ld, k, out_val, out_idx, select_min,
                          idx_offset, out_ld, out_col_offset, done.data(), run_if);
