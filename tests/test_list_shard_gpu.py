@@ -140,3 +140,59 @@ def test_lists_dealt_by_size_equal_the_unsharded_index():
     assert (md == fd).all()
     for qi in range(len(q)):
         assert sorted(zip(md[qi].tolist(), mi[qi].tolist())) == sorted(zip(fd[qi].tolist(), fi[qi].tolist()))
+
+
+def test_shard_local_refinement_equals_refining_the_union():
+    """bench.py --config c5 (SURVEY 8e / refine_device.cuh): every rank keeps the int8 rows of its own lists
+    (cuvsAmdIvfPqRowLabels tells it which), stores their codes under LOCAL ids, re-ranks its k x refine_ratio candidates
+    exactly against its own rows (cuvsRefine) and hands global ids to the all-gather - no row moves between ranks, and the
+    merged result is the exact re-ranking of the union of the ranks' candidates."""
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import ivf_pq, ivf_pq_sharded as sh, refine
+
+    res = cuvs_amd.common.Resources()
+    rng = np.random.default_rng(21)
+    n, d, nq, k, ratio, world, n_lists = 30000, 96, 300, 10, 2, 2, 24
+    x = rng.integers(1, 20, size=(n, d), dtype=np.int8)   # the reference's int8 generator (ann_ivf_pq.cuh:150-168)
+    q = rng.integers(1, 20, size=(nq, d), dtype=np.int8)
+    xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    kk = k * ratio
+
+    def params():
+        return ivf_pq.IndexParams(n_lists=n_lists, pq_dim=64, kmeans_n_iters=10, add_data_on_build=False)
+
+    sp = ivf_pq.SearchParams(n_probes=8)
+    invalid = np.iinfo(np.int64).max
+    parts_d, parts_i, union = [], [], []
+    for rank in range(world):
+        shard = sh.build(params(), xt, rank, world, resources=res)   # same rows -> same model on every rank
+        labels = sh.row_labels(shard, xt, resources=res)
+        own = torch.nonzero(labels % world == rank).flatten()
+        own_rows = xt[own].contiguous()
+        sh.extend(shard, own_rows, torch.arange(len(own), dtype=torch.int64, device="cuda"), resources=res)
+        res.sync()
+        assert len(shard) == len(own)   # every kept row belongs to an owned list
+        counts = np.bincount(labels.cpu().numpy()[own.cpu().numpy()], minlength=n_lists)
+        assert (shard.list_sizes.cpu().numpy() == counts).all()
+        _, ci = ivf_pq.search(sp, shard, qt, kk, resources=res)                       # local ids
+        rd, ri = refine(own_rows, qt, ci, k=k, metric="sqeuclidean", resources=res)   # exact, against the rank's own rows
+        res.sync()
+        gmap = own.cpu().numpy()
+        ci, ri, rd = ci.cpu().numpy(), ri.cpu().numpy(), rd.cpu().numpy()
+        parts_i.append(np.where(ri != invalid, gmap[np.where(ri != invalid, ri, 0)], invalid))
+        parts_d.append(rd)
+        union.append(np.where(ci != invalid, gmap[np.where(ci != invalid, ci, 0)], invalid))
+    md, mi = sh.merge_gathered(parts_d, parts_i, k, True)
+    # the same candidates - the union over the ranks - re-ranked in one go by the oracle against the whole corpus
+    cand = np.concatenate(union, axis=1)
+    assert (cand != invalid).all()
+    od, oi = oracle.refine(x, q, cand, k)
+    assert (md == od).all()
+    xf, qf = x.astype(np.float32), q.astype(np.float32)
+    for qi in range(nq):
+        # integer distances tie: below the k-th distance the ids are the oracle's, at it any candidate of that distance serves
+        kth = od[qi, -1]
+        assert set(mi[qi][md[qi] < kth].tolist()) == set(oi[qi][od[qi] < kth].tolist())
+        assert len(set(mi[qi].tolist())) == k and set(mi[qi].tolist()) <= set(cand[qi].tolist())
+        assert (((xf[mi[qi]] - qf[qi]) ** 2).sum(1) == md[qi]).all()
