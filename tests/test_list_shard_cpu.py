@@ -76,3 +76,51 @@ def test_merge_rule():
     i = [np.array([[7, 9, np.iinfo(np.int64).max]]), np.array([[11, 1, 3]])]
     md, mi = merge_gathered(d, i, 3)
     assert md.tolist() == [[0.5, 1.0, 2.0]] and mi.tolist() == [[11, 7, 9]]  # the rank-0 candidate wins the tie at k
+
+
+def _refine_worker(rank, world, port, ex, x, q, k, ratio, n_probes, out):
+    """One rank of bench.py --config c5: its shard's k x ratio candidates, re-ranked exactly against the rows of its OWN lists
+    (local row numbers -> global ids only after the refinement), then the all-gather + merge of the [Q, k] blocks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = shard_of(ex, rank, world)
+        own = np.sort(np.concatenate([ids for ids in shard["ids"]]).astype(np.int64))   # global ids of the rank's rows
+        local_of = {int(g): j for j, g in enumerate(own)}
+        shard["ids"] = [np.array([local_of[int(g)] for g in ids], dtype=ids.dtype) for ids in shard["ids"]]   # codes under LOCAL ids
+        own_rows = x[own]                                                                                    # the only rows the rank keeps
+        _, ci = oracle.ivf_pq_search(shard, q, k * ratio, n_probes)
+        invalid = np.iinfo(np.int64).max
+        assert (ci != invalid).all()
+        rd, ri = oracle.refine(own_rows, q, ci, k)
+        gi_local = own[ri]
+        gd = [torch.empty(rd.shape, dtype=torch.float32) for _ in range(world)]
+        gi = [torch.empty(gi_local.shape, dtype=torch.int64) for _ in range(world)]
+        gc = [torch.empty(ci.shape, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gd, torch.from_numpy(rd))
+        dist.all_gather(gi, torch.from_numpy(gi_local))
+        dist.all_gather(gc, torch.from_numpy(own[ci]))   # (for the check only: every rank's candidates under global ids)
+        md, mi = merge_gathered([t.numpy() for t in gd], [t.numpy() for t in gi], k, True)
+        out[rank] = (md, mi, np.concatenate([t.numpy() for t in gc], axis=1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_local_refinement_equals_refining_the_union():
+    """world_size 2 over gloo: no row crosses a rank, yet the merged [Q, k] block is the exact re-ranking of the union of
+    the ranks' candidates (reference recipe refine_ratio 2 - 4, cuvs_ivf_pq.yaml:17, refine_device.cuh)."""
+    rng = np.random.default_rng(8)
+    x, ex, _, _ = _toy_pq_index(rng, n=1200, n_lists=10)
+    q = rng.standard_normal((30, x.shape[1])).astype(np.float32)
+    k, ratio, n_probes = 5, 3, 6
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_refine_worker, args=(2, _free_port(), ex, x, q, k, ratio, n_probes, out), nprocs=2, join=True)
+    md0, mi0, cand = out[0]
+    td, ti = oracle.refine(x, q, cand, k)   # the union of both ranks' candidates, re-ranked in one go over the whole corpus
+    for rank in (0, 1):  # replicated result
+        md, mi, _ = out[rank]
+        assert (md == td).all()
+        for qi in range(len(q)):
+            assert sorted(zip(md[qi].tolist(), mi[qi].tolist())) == sorted(zip(td[qi].tolist(), ti[qi].tolist()))
