@@ -185,6 +185,31 @@ def test_running_threshold_path(monkeypatch, metric, adversarial):
     assert torch.equal(i, i2) and torch.equal(d, d2)
 
 
+@pytest.mark.parametrize("host_flags", [False, True])
+def test_fused_path_overflow_is_redone_without_a_host_round_trip(monkeypatch, host_flags):
+    """One wide column tile (n >= 65536, default workspace) whose columns arrive in improving order for some queries: their
+    candidate buffers overflow in the fused epilogue, the row tile's flag is raised and the per-tile select pass - enqueued
+    behind the fused one, every launch guarded by that flag on the device - redoes it; identical to the oracle, and to the
+    same search with the flags read back by the host (CUVS_AMD_BF_HOST_FLAGS=1, rounds 2-3)."""
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import brute_force
+
+    if host_flags:
+        monkeypatch.setenv("CUVS_AMD_BF_HOST_FLAGS", "1")
+    res = cuvs_amd.common.Resources()   # (switches are read when the handle is created)
+    x, qq = _gen(90000, 16, 50, seed=29)
+    key = ((x - qq[0]) ** 2).sum(1)
+    x = np.ascontiguousarray(x[np.argsort(-key)])   # decreasing distance to query 0: every column beats all before it
+    tx, tq = torch.from_numpy(x).cuda(), torch.from_numpy(qq).cuda()
+    idx = brute_force.build(tx, metric="sqeuclidean", resources=res)
+    for _ in range(2):   # twice: the counters and flags of the first call must not leak into the second
+        d, i = brute_force.search(idx, tq, 10, resources=res)
+        res.sync()
+        od, oi = oracle.brute_force_knn(qq, x, 10)
+        assert (i.cpu().numpy() == oi).all() and (d.cpu().numpy() == od).all()
+
+
 @pytest.mark.parametrize("metric,dtype", [("sqeuclidean", "float32"), ("inner_product", "float32"),
                                           ("cosine", "float16"), ("euclidean", "float32")])
 @pytest.mark.parametrize("filt", ["none", "bitset", "bitmap"])
