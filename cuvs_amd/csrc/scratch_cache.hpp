@@ -23,7 +23,8 @@ struct scratch_cache {
   std::unordered_multimap<size_t, void*> free_blocks;  // kept blocks by exact size
   size_t cached_bytes = 0;
   size_t cap_bytes    = 0;                  // beyond it the cache is emptied
-  size_t max_block    = size_t(2) << 30;    // larger blocks (build-time buffers) are never kept
+  size_t max_block    = size_t(4) << 30;    // larger blocks (build-time buffers) are never kept (4 GiB: the B-operand
+                                            // buffer of a list-sharded search over 8 ranks - 80k queries x 128 probes x 256 B - is kept)
 
   // raw_free(stream, pointer): gives a block back to the runtime, ordered on `stream`
   template <class RawFree>
