@@ -1381,6 +1381,9 @@ bool pq3_supported(const ivf_pq_index& idx, int k)
 // re-score took 2.8x the LUT scan's time. Measured crossover: k around 4 % of the mean list length.
 bool pq3_bound_useful(const ivf_pq_index& idx, int k)
 {
+  // a list shard: every rank must take the same decision (for inner product / cosine it decides whether the search has a
+  // head phase at all, and the head phase ends in an all-reduce of the bounds) - the list sizes differ from rank to rank
+  if (idx.shard_world > 1) return k <= 128;
   uint64_t rows = 0, lists = 0;
   for (uint32_t v : idx.h_list_sizes) { rows += v; lists += v != 0u; }
   return lists != 0 && (uint64_t)k * 25u * lists <= rows;
