@@ -73,6 +73,11 @@ struct ivf_pq_index {
   // scans only owned probes; the per-rank top-k lists are all-gathered and merged. shard_world == 1: not sharded.
   int shard_rank = 0, shard_world = 1;
   void* shard_comm = nullptr;  // cuvsAmdShardComm* (not owned): all-reduce of the k-th bounds between the scan phases
+  // rows / non-empty lists of ALL ranks' shards, exchanged by the first search after the communicator was attached (one
+  // small all-gather): with collectives inside the search every rank must choose the same kernels, so what the choice
+  // looks at (the mean list length) has to be the same number on every rank (pq3_bound_useful)
+  mutable uint64_t shard_global_rows = 0, shard_global_lists = 0;
+  mutable bool shard_stats_valid = false;
   // optional owner of every list (cuvsAmdIvfPqSetListOwners: lists dealt by size, cuvsAmdShardDealLists); empty: L % world
   std::vector<int32_t> h_list_owner;
   dev_buf<int32_t> list_owner;

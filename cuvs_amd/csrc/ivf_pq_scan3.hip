@@ -1381,11 +1381,19 @@ bool pq3_supported(const ivf_pq_index& idx, int k)
 // re-score took 2.8x the LUT scan's time. Measured crossover: k around 4 % of the mean list length.
 bool pq3_bound_useful(const ivf_pq_index& idx, int k)
 {
-  // a list shard: every rank must take the same decision (for inner product / cosine it decides whether the search has a
-  // head phase at all, and the head phase ends in an all-reduce of the bounds) - the list sizes differ from rank to rank
-  if (idx.shard_world > 1) return k <= 128;
+  // A list shard whose searches hold collectives (communicator attached): every rank must take the same decision - for
+  // inner product / cosine it decides whether the search has a head phase at all, and the head phase ends in an
+  // all-reduce of the bounds - while the list sizes differ from rank to rank. The ranks therefore decide on the rows and
+  // non-empty lists of ALL shards (exchanged once, ivf_pq_search.hip: shard_exchange_stats): the same number everywhere,
+  // and the measured crossover of the unsharded index. Without a communicator a search has no collective and a shard
+  // decides on its own lists (foreign lists are empty and do not count).
   uint64_t rows = 0, lists = 0;
-  for (uint32_t v : idx.h_list_sizes) { rows += v; lists += v != 0u; }
+  if (idx.shard_world > 1 && idx.shard_comm != nullptr) {
+    if (!idx.shard_stats_valid) return k <= 128;  // (not reached through cuvsIvfPqSearch: the exchange precedes the decision)
+    rows = idx.shard_global_rows; lists = idx.shard_global_lists;
+  } else {
+    for (uint32_t v : idx.h_list_sizes) { rows += v; lists += v != 0u; }
+  }
   return lists != 0 && (uint64_t)k * 25u * lists <= rows;
 }
 

@@ -1967,6 +1967,29 @@ __global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float
 
 }  // namespace
 
+// rows and non-empty lists over all ranks of a list-sharded index: ONE in-place all-gather of three words per rank, made by
+// the first search after cuvsAmdIvfPqSetShardComm (attaching is collective, so every rank is in the same state)
+static void shard_exchange_stats(resources& res, const ivf_pq_index& idx)
+{
+  uint64_t rows = 0;
+  uint32_t lists = 0;
+  for (uint32_t v : idx.h_list_sizes) { rows += v; lists += v != 0u; }
+  const size_t world = (size_t)std::max(1, idx.shard_world);
+  std::vector<uint32_t> h(3 * world, 0u);
+  h[3 * idx.shard_rank + 0] = (uint32_t)rows; h[3 * idx.shard_rank + 1] = (uint32_t)(rows >> 32); h[3 * idx.shard_rank + 2] = lists;
+  dev_buf<uint32_t> d(res, h.size());
+  copy_async(res, d.data(), h.data(), h.size() * sizeof(uint32_t));
+  sync(res);  // (h is pageable: the copy must have read it before the vector is reused below)
+  shard_allgather_inplace_u32(res, idx.shard_comm, d.data(), 3);
+  h = to_host(res, d.data(), h.size());
+  idx.shard_global_rows = 0; idx.shard_global_lists = 0;
+  for (size_t r = 0; r < world; ++r) {
+    idx.shard_global_rows += (uint64_t)h[3 * r] | ((uint64_t)h[3 * r + 1] << 32);
+    idx.shard_global_lists += h[3 * r + 2];
+  }
+  idx.shard_stats_valid = true;
+}
+
 void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_index& idx, const void* queries,
                    elem_t et, int64_t n_queries, int k, int64_t* neighbors, float* distances, const uint32_t* filter_bits)
 {
@@ -1984,6 +2007,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                "Unsupported coarse_search_dtype (only CUDA_R_32F, CUDA_R_16F, and CUDA_R_8I are supported)");
   CUVS_EXPECTS(!idx.dtype_known || et == idx.dtype, "queries dtype differs from the index dtype");
   if (n_queries == 0) return;
+  if (idx.shard_comm != nullptr && !idx.shard_stats_valid) shard_exchange_stats(res, idx);
   const uint32_t n_probes = std::min<uint32_t>(p.n_probes, idx.n_lists);
   // fp8 LUT (the reference's fp_8bit<5, signed>): entries are rounded through that type and kept in the score type
   const bool lut_fp8      = p.lut_dtype == 8 || p.lut_dtype == 3;

@@ -8,18 +8,25 @@
 // rank ends up with the merged result (no broadcast afterwards).
 #include "ivf_pq.hpp"
 #include "ops.hpp"
+#include "shm_transport.hpp"
 
 #include <cuvs_amd/shard.h>
 
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cfloat>
+#include <cstdlib>
 #include <dlfcn.h>
 #include <mutex>
 #include <string>
 
+// Two transports behind one communicator: RCCL (one process per GPU, xGMI) and the host-staged one of
+// shm_transport.hpp (processes of one host through a mapped file: ranks that SHARE a device, or hosts without RCCL).
+// Which one a communicator uses is decided by the rendezvous id its ranks were created with.
 struct cuvsAmdShardComm {
   ncclComm_t comm = nullptr;
+  std::unique_ptr<cuvs_amd::shm_transport> shm;
   int rank = 0, world = 1, device = 0;
 };
 
@@ -68,6 +75,41 @@ const rccl_api& rccl()
     ncclResult_t r__ = (expr);                                                                           \
     if (r__ != ncclSuccess) CUVS_FAIL("RCCL error %d (%s) in %s", (int)r__, rccl().get_error_string(r__), #expr); \
   } while (0)
+
+// The host-staged forms of the two collectives (shm_transport.hpp): the stream is drained, the rank's block goes
+// device -> mapped file, every rank's block comes back file -> device. In place like the RCCL calls they stand in for:
+// `buf` holds world blocks of `bytes`, this rank's at its rank offset. Host-synchronous - a functional transport for
+// ranks that share a device, not a fast one.
+void staged_all_gather(resources& res, shm_transport& t, void* buf, size_t bytes)
+{
+  char* b = static_cast<char*>(buf);
+  t.begin(1, bytes);
+  HIP_TRY(hipMemcpyAsync(t.own(), b + (size_t)t.rank() * bytes, bytes, hipMemcpyDeviceToHost, res.stream));
+  sync(res);
+  t.publish();
+  for (int r = 0; r < t.world(); ++r)
+    if (r != t.rank()) HIP_TRY(hipMemcpyAsync(b + (size_t)r * bytes, t.block(r), bytes, hipMemcpyHostToDevice, res.stream));
+  sync(res);
+  t.end();
+}
+
+void staged_all_reduce_min(resources& res, shm_transport& t, uint32_t* keys, size_t count)
+{
+  const size_t bytes = count * sizeof(uint32_t);
+  t.begin(2, bytes);
+  HIP_TRY(hipMemcpyAsync(t.own(), keys, bytes, hipMemcpyDeviceToHost, res.stream));
+  sync(res);
+  t.publish();
+  std::vector<uint32_t> m(count);
+  std::memcpy(m.data(), t.block(0), bytes);
+  for (int r = 1; r < t.world(); ++r) {
+    const uint32_t* o = reinterpret_cast<const uint32_t*>(t.block(r));
+    for (size_t i = 0; i < count; ++i) m[i] = o[i] < m[i] ? o[i] : m[i];
+  }
+  t.end();  // (every rank has read the blocks into its own vector)
+  HIP_TRY(hipMemcpyAsync(keys, m.data(), bytes, hipMemcpyHostToDevice, res.stream));
+  sync(res);
+}
 
 // one candidate = 12 bytes on the wire: a rank's block is [n_queries, k] ids (int64) followed by [n_queries, k] distances
 // (fp32), padded to a multiple of 16 bytes so that the ids of every block are 8-byte aligned whatever n_queries * k is
@@ -135,7 +177,8 @@ void shard_all_gather_topk(resources& res, cuvsAmdShardComm& c, const float* ld,
   char* send = recv.data() + (size_t)c.rank * blk;
   hipLaunchKernelGGL(pack_block_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, ld, li, n, send);
   profile_begin(res, "shard_all_gather");
-  RCCL_TRY(rccl().all_gather(send, recv.data(), blk, ncclUint8, c.comm, res.stream));
+  if (c.shm) staged_all_gather(res, *c.shm, recv.data(), blk);
+  else       RCCL_TRY(rccl().all_gather(send, recv.data(), blk, ncclUint8, c.comm, res.stream));
   profile_end(res, "shard_all_gather");
   dev_buf<float> vals(res, (size_t)n * c.world);
   dev_buf<int64_t> ids(res, (size_t)n * c.world);
@@ -152,7 +195,8 @@ void shard_allreduce_min_u32(resources& res, void* comm, uint32_t* keys, size_t 
   auto* c = static_cast<cuvsAmdShardComm*>(comm);
   if (c == nullptr || count == 0) return;  // (a one-rank communicator still makes the call: that is what the tests run)
   profile_begin(res, "shard_all_reduce");
-  RCCL_TRY(rccl().all_reduce(keys, keys, count, ncclUint32, ncclMin, c->comm, res.stream));
+  if (c->shm) staged_all_reduce_min(res, *c->shm, keys, count);
+  else        RCCL_TRY(rccl().all_reduce(keys, keys, count, ncclUint32, ncclMin, c->comm, res.stream));
   profile_end(res, "shard_all_reduce");
 }
 
@@ -161,7 +205,8 @@ void shard_allgather_inplace_u32(resources& res, void* comm, uint32_t* buf, size
   auto* c = static_cast<cuvsAmdShardComm*>(comm);
   if (c == nullptr || count == 0) return;
   profile_begin(res, "shard_all_gather_probes");
-  RCCL_TRY(rccl().all_gather(buf + (size_t)c->rank * count, buf, count, ncclUint32, c->comm, res.stream));
+  if (c->shm) staged_all_gather(res, *c->shm, buf, count * sizeof(uint32_t));
+  else        RCCL_TRY(rccl().all_gather(buf + (size_t)c->rank * count, buf, count, ncclUint32, c->comm, res.stream));
   profile_end(res, "shard_all_gather_probes");
 }
 
@@ -181,6 +226,21 @@ cuvsError_t cuvsAmdShardCommGetUniqueId(char id[CUVS_AMD_SHARD_ID_BYTES])
   });
 }
 
+cuvsError_t cuvsAmdShardCommGetUniqueIdHostStaged(char id[CUVS_AMD_SHARD_ID_BYTES])
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    static std::atomic<unsigned> counter{0};
+    const char* dir = getenv("CUVS_AMD_SHM_DIR");
+    if (dir == nullptr || *dir == 0) dir = access("/dev/shm", W_OK) == 0 ? "/dev/shm" : "/tmp";
+    memset(id, 0, CUVS_AMD_SHARD_ID_BYTES);
+    memcpy(id, kShmIdMagic, sizeof(kShmIdMagic));
+    const auto stamp = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+    const int n = snprintf(id + sizeof(kShmIdMagic), CUVS_AMD_SHARD_ID_BYTES - sizeof(kShmIdMagic), "%s/cuvsamd_comm_%ld_%llx_%u", dir,
+                           (long)getpid(), stamp, counter.fetch_add(1));
+    CUVS_EXPECTS(n > 0 && (size_t)n < CUVS_AMD_SHARD_ID_BYTES - sizeof(kShmIdMagic), "CUVS_AMD_SHM_DIR is too long for a %d-byte id", CUVS_AMD_SHARD_ID_BYTES);
+  });
+}
+
 cuvsError_t cuvsAmdShardCommCreate(cuvsResources_t res_h, const char id[CUVS_AMD_SHARD_ID_BYTES], int rank, int world,
                                    cuvsAmdShardComm_t* comm)
 {
@@ -190,9 +250,18 @@ cuvsError_t cuvsAmdShardCommCreate(cuvsResources_t res_h, const char id[CUVS_AMD
     HIP_TRY(hipSetDevice(res.device));
     auto c = std::make_unique<cuvsAmdShardComm>();
     c->rank = rank; c->world = world; c->device = res.device;
-    ncclUniqueId u;
-    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
-    RCCL_TRY(rccl().comm_init_rank(&c->comm, world, u, rank));
+    if (memcmp(id, kShmIdMagic, sizeof(kShmIdMagic)) == 0) {  // an id of cuvsAmdShardCommGetUniqueIdHostStaged
+      CUVS_EXPECTS(memchr(id + sizeof(kShmIdMagic), 0, CUVS_AMD_SHARD_ID_BYTES - sizeof(kShmIdMagic)) != nullptr, "shard comm: malformed host-staged id");
+      double limit = 120.0;
+      if (const char* e = getenv("CUVS_AMD_SHM_TIMEOUT_S")) limit = std::max(1.0, atof(e));
+      try {
+        c->shm = std::make_unique<shm_transport>(std::string(id + sizeof(kShmIdMagic)), rank, world, limit);
+      } catch (const std::exception& e) { CUVS_FAIL("%s", e.what()); }
+    } else {
+      ncclUniqueId u;
+      memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+      RCCL_TRY(rccl().comm_init_rank(&c->comm, world, u, rank));
+    }
     *comm = c.release();
   });
 }
@@ -302,6 +371,7 @@ cuvsError_t cuvsAmdIvfPqSetShardComm(cuvsIvfPqIndex_t index, cuvsAmdShardComm_t 
                  "shard communicator (rank %d of %d) does not match the index's list shard (rank %d of %d)",
                  comm ? comm->rank : 0, comm ? comm->world : 0, idx.shard_rank, idx.shard_world);
     idx.shard_comm = comm;
+    idx.shard_stats_valid = false;  // the next search exchanges the shards' rows / list counts (collective, like the search)
   });
 }
 

@@ -70,18 +70,20 @@ class ShardComm:
         check(lib().cuvsAmdShardCommCreate(resources.get_c_obj(), buf, C.c_int(rank), C.c_int(world), C.byref(self._c)))
 
     @staticmethod
-    def unique_id():
+    def unique_id(host_staged=False):
+        """128-byte rendezvous id: RCCL's (one process per GPU, xGMI) or - host_staged=True - the name of the mapped file
+        of the host-staged transport (ranks of one host that share a device; cuvsAmdShardCommGetUniqueIdHostStaged)."""
         buf = (C.c_char * ID_BYTES)()
-        check(lib().cuvsAmdShardCommGetUniqueId(buf))
+        check((lib().cuvsAmdShardCommGetUniqueIdHostStaged if host_staged else lib().cuvsAmdShardCommGetUniqueId)(buf))
         return bytes(buf.raw)
 
     @classmethod
-    def from_torch(cls, resources, group=None):
+    def from_torch(cls, resources, group=None, host_staged=False):
         """rank / world / id exchange through an initialised torch.distributed group (control plane only)."""
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [cls.unique_id(host_staged) if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
         return cls(rank, world, box[0], resources)
 

@@ -30,7 +30,15 @@ typedef struct cuvsAmdShardComm* cuvsAmdShardComm_t;
 
 /* rank 0 creates the rendezvous id and hands its 128 bytes to the other ranks by any means (file, MPI, torchrun store) */
 CUVS_EXPORT cuvsError_t cuvsAmdShardCommGetUniqueId(char id[CUVS_AMD_SHARD_ID_BYTES]);
-/* collective: every rank calls it with the same id; binds the communicator to the device of `res` */
+/* The same rendezvous for the HOST-STAGED transport (cuvs_amd/csrc/shm_transport.hpp): the id names a file (directory
+ * CUVS_AMD_SHM_DIR, default /dev/shm) that the ranks - processes of ONE host - map; every collective then travels
+ * device -> mapped file -> device. For ranks that share a device (RCCL refuses two ranks on one GPU: this is how a
+ * one-GPU box runs the world > 1 code paths, tests/test_list_shard_world2_gpu.py) and for hosts without RCCL. Same
+ * semantics and results as the RCCL transport, host-synchronous; a rank that waits longer than CUVS_AMD_SHM_TIMEOUT_S
+ * (default 120) for its peers fails with an error instead of hanging. */
+CUVS_EXPORT cuvsError_t cuvsAmdShardCommGetUniqueIdHostStaged(char id[CUVS_AMD_SHARD_ID_BYTES]);
+/* collective: every rank calls it with the same id; binds the communicator to the device of `res`. The transport
+ * (RCCL or host-staged) is the one the id was made for. */
 CUVS_EXPORT cuvsError_t cuvsAmdShardCommCreate(cuvsResources_t res, const char id[CUVS_AMD_SHARD_ID_BYTES], int rank, int world,
                                    cuvsAmdShardComm_t* comm);
 CUVS_EXPORT cuvsError_t cuvsAmdShardCommDestroy(cuvsAmdShardComm_t comm);
