@@ -7,9 +7,16 @@ A "step" is one cuvsIvfPqSearch (k * refine_ratio candidates) + cuvsRefine over 
 Index build, ground truth and the CPU baseline are outside the timed region; queries/outputs are resident in HBM.
 
   python bench.py                      # N=1: headline + the other LUT/score precisions + C1/C2/C4 lines + live PMC passes
+  python bench.py --gpus N             # N > 1 with no launcher around it: bench.py starts its own N ranks (one per GPU,
+                                       # torch.distributed.run on 127.0.0.1) and fails loudly when the node has fewer than N
+                                       # devices. List-sharded index (lists dealt to the ranks by size), every step ends in
+                                       # ONE native RCCL all-gather of the per-rank [Q, k] blocks (include/cuvs_amd/shard.h)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N
-                                       # list-sharded index (lists dealt to the ranks by size), every step ends in ONE native RCCL
-                                       # all-gather of the per-rank [Q, k] blocks (include/cuvs_amd/shard.h)
+                                       # the same under an external launcher (the driver's form)
+  python bench.py --gpus N --share-devices
+                                       # FUNCTIONAL run of the N-rank path on fewer than N devices (ranks share GPUs, the
+                                       # collectives go through the communicator's host-staged transport): not a scaling
+                                       # figure - the line says so ("transport", "oversubscribed")
   [torchrun ...] bench.py --config c5 [--rows R]
                                        # BASELINE configs[4]: IVF-PQ rows x 96 int8 (default 1B), list shards dealt by
                                        # size over the ranks, rows generated chunk by chunk (no rank holds the corpus)
@@ -57,6 +64,170 @@ N_CU, N_SIMD = 256, 1024
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks (one process per GPU) under
+    torch.distributed.run on the loopback address and pass their output through. The reference starts all its ranks from
+    one process too (cpp/src/neighbors/mg/snmg.cuh:283-341, c/include/cuvs/neighbors/mg_ivf_pq.h:152-190)."""
+    import socket
+
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.share_devices:
+        print(f"[bench] --gpus {args.gpus} needs {args.gpus} devices, this node has {n_dev}: refusing to run fewer ranks than asked "
+              f"for (a functional run of the {args.gpus}-rank path on shared devices: add --share-devices)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if n_dev < 1:
+        print("[bench] no GPU visible", file=sys.stderr, flush=True)
+        sys.exit(2)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("starting", args.gpus, "ranks:", " ".join(cmd[2:]))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dist_setup(args):
+    """rank / world / device of this process and the control-plane process group (barriers, the max over ranks, the id
+    rendezvous; the data path never touches torch.distributed). One rank per GPU; with --share-devices rank r uses device
+    r % n_devices, the control plane runs over gloo and the shard communicator over its host-staged transport (RCCL
+    refuses two ranks on one device)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1 or (local_rank >= n_dev and not args.share_devices):
+        print(f"[bench] rank {rank}: local rank {local_rank} has no device of its own ({n_dev} visible); --share-devices runs the ranks "
+              f"on shared devices (functional run only)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    shared = args.share_devices and world > n_dev
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return rank, world, dev, dist, shared
+
+
+def ctl_tensor(values, dtype, dev, shared):
+    """a small tensor for a control-plane collective: on the device under nccl, on the host under gloo"""
+    return torch.tensor(values, dtype=dtype, device="cpu" if shared else dev)
+
+
+def make_comm(sh, res, world, shared):
+    if world > 1:
+        return sh.ShardComm.from_torch(res, host_staged=shared)
+    return sh.ShardComm(0, 1, sh.ShardComm.unique_id(), res)
+
+
+def cpu_baseline_line(c1_x=None, c1_q=None, dev=None):
+    """The reference's only CPU search code (refine_host: exact distances of candidate rows, OpenMP over queries) restated in
+    oracle/ with every row as a candidate, at SURVEY 8d's C1 shape, on this box's host cores. A reported baseline, never
+    part of the product path. Bounded: 5 runs of ~0.2 s."""
+    import oracle
+
+    if c1_x is None:
+        c1_x = gen_rows(100_000, 128, 1234, dev).cpu().numpy()
+        c1_q = gen_rows(1000, 128, 4321, dev).cpu().numpy()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        oracle.exact_knn(c1_q, c1_x, 10)
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(1000 / med, 1), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+            "gflops": round(2 * 1000 * 100_000 * 128 / med / 1e9, 1),
+            "sample": f"C1 shape (SURVEY 8d): exact kNN of 1000 queries over 100000x128 fp32, k=10, the reference's "
+                      f"refine_host arithmetic restated in oracle/ (OpenMP), median of 5 runs = {med * 1e3:.1f} ms"}
+
+
+SPEC_GHZ, MFMA_F16_TFLOPS = 2.4, 2500.0  # MI355X_MICROARCH.md: peak engine clock, dense fp16 MFMA peak
+
+
+def pq_scan_roofline(index, queries_f32, n_probes, owned, code_bytes, rot_dim, filter_ms, scan_ms, n_launch, steps, phase_ms,
+                     early_stop_off_ms=None):
+    """Roofline block of the dominant kernel (pq_filter_kernel, one launch per search) of THIS rank's search.
+    Algorithmic work of one search, from the index's list sizes and an independent coarse ranking of the batch:
+      logical bytes  = sum over (query, probe) pairs of list_len * code bytes (the reference reads a list once per pair)
+      unique bytes   = code bytes of every list probed by at least one pair (the lower bound on HBM bytes per batch)
+      useful flop    = 2 * rot_dim per (row, query) pair of the tail phase (the screen is a GEMM of decoded rows x residuals)
+      gather cycles  = LDS cycles of the decode if no two lanes ever met in a bank: every 32-row subtile of a probed list
+                       once per 128 probing queries, 32 ds_read_b32 x 2 cycles each
+    `owned`: bool [n_lists], the lists this rank holds (a list shard scans only those). Its speed of light is the largest of
+    three floors, each a spec peak: unique code bytes / 8 TB/s, useful fp16 MFMA flop / 2.5 PFLOP/s, conflict-free gather
+    cycles / (256 CUs x 2.4 GHz). `frac` = that floor / the kernel's measured duration (HIP events around the launch on the
+    handle's stream, this run); `bound` names it."""
+    dev = queries_f32.device
+    sizes = index.list_sizes.to(torch.int64)
+    n_lists = sizes.shape[0]
+    centers = index.centers.float()
+    cn = (centers * centers).sum(1)
+    probe_bytes = 0
+    tail_pairs = torch.zeros(n_lists, dtype=torch.int64, device=dev)
+    all_pairs = torch.zeros(n_lists, dtype=torch.int64, device=dev)
+    for q0 in range(0, queries_f32.shape[0], 2048):
+        qq = queries_f32[q0:q0 + 2048]
+        dmat = cn[None, :] - 2.0 * (qq @ centers.T)
+        pr = torch.topk(dmat, min(n_probes, n_lists), dim=1, largest=False).indices
+        probe_bytes += int((sizes[pr] * owned[pr]).sum().item()) * code_bytes
+        all_pairs += torch.bincount(pr.reshape(-1), minlength=n_lists)
+        tail_pairs += torch.bincount(pr[:, 1:].reshape(-1), minlength=n_lists)  # the nearest probe is the head phase
+    tail_pairs, all_pairs = tail_pairs * owned, all_pairs * owned
+    unique_bytes = int((sizes * (all_pairs > 0)).sum().item()) * code_bytes
+    tail_row_pairs = int((sizes * tail_pairs).sum().item())
+    useful_flop = 2.0 * rot_dim * tail_row_pairs
+    subtile_decodes = int((((sizes + 31) // 32) * ((tail_pairs + 127) // 128)).sum().item())
+    gather_cycles = subtile_decodes * 32 * 2.0
+    # one search = a small head launch (nearest probe of every query) + the tail launch: the same work, bytes and
+    # time are averaged over all launches (sum of bytes / sum of time)
+    per_step = max(n_launch, 1) / max(steps, 1)
+    bytes_per_launch = probe_bytes / per_step
+    avg_ms = scan_ms / max(n_launch, 1)
+    logical = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    f_ms = filter_ms
+    floors_ms = {"hbm": unique_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, "mfma": useful_flop / (MFMA_F16_TFLOPS * 1e12) * 1e3,
+                 "lds": gather_cycles / (N_CU * SPEC_GHZ * 1e9) * 1e3}
+    sol_bound = max(floors_ms, key=floors_ms.get)
+    sol_frac = floors_ms[sol_bound] / f_ms if f_ms > 0 else None
+    if sol_bound == "hbm":
+        ach, peak, unit = unique_bytes / max(f_ms, 1e-9) / 1e6, HBM_PEAK_GBS, "GB/s"
+    elif sol_bound == "mfma":
+        ach, peak, unit = useful_flop / max(f_ms, 1e-9) / 1e9, MFMA_F16_TFLOPS, "TFLOP/s"
+    else:
+        ach, peak, unit = gather_cycles / max(f_ms, 1e-9) / 1e6, N_CU * SPEC_GHZ, "Gcycles/s"
+    return {"bound": sol_bound, "kernel": "pq_filter_kernel (the tail phase's matrix-core screen: dominant kernel, one launch per search)",
+            "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": None if sol_frac is None else round(sol_frac, 4),
+            "traffic": None, "avg_launch_ms": round(f_ms, 3),
+            "floors_ms": {k: round(v, 3) for k, v in floors_ms.items()},
+            "frac_hbm_unique_bytes": round(floors_ms["hbm"] / f_ms, 4) if f_ms > 0 else None,
+            "frac_mfma_useful_flop": round(floors_ms["mfma"] / f_ms, 4) if f_ms > 0 else None,
+            "frac_lds_conflict_free_gathers": round(floors_ms["lds"] / f_ms, 4) if f_ms > 0 else None,
+            "algorithmic": {"unique_code_bytes_per_search": unique_bytes, "logical_code_bytes_per_search": probe_bytes,
+                            "tail_row_query_pairs": tail_row_pairs, "useful_mfma_flop": useful_flop,
+                            "subtile_decodes": subtile_decodes, "conflict_free_gather_cycles": gather_cycles},
+            "scan_kernels": {"names": "pq_head_kernel + pq_bprep_kernel + pq_filter_kernel + pq_rescore_kernel (+ hand-backs)",
+                             "launches_per_step": per_step, "kernel_ms_per_step": round(avg_ms * per_step, 3),
+                             "phase_ms_per_step": phase_ms, "logical_scan_gbs": round(logical, 1),
+                             "frac_hbm_unique_bytes": round(unique_bytes / (HBM_PEAK_GBS * 1e9) / max(avg_ms * per_step * 1e-3, 1e-12), 4),
+                             "early_stop_off_kernel_ms_per_step": early_stop_off_ms},
+            "note": "frac = max(unique code bytes / 8 TB/s, useful fp16 MFMA flop / 2.5 PFLOP/s, conflict-free LDS gather cycles / "
+                    "(256 CUs x 2.4 GHz)) / measured duration of pq_filter_kernel on rank 0: every term is a spec peak and an algorithmic "
+                    "quantity computed from the index (this rank's lists) and the batch. logical_scan_gbs (SURVEY 8d: list bytes per pair) "
+                    "exceeds the HBM peak by design - a list chunk is fetched once per up to 128 probing queries - and is no utilisation. "
+                    "pmc.* (N=1 only) are busy cycles of each pipe over SPEC-clock cycles (2.4 GHz x kernel time), from rocprofv3 --pmc "
+                    "passes of this workload"}
 
 
 def gen_rows(n, dim, seed, device, chunk=1 << 22, latent=32, n_modes=65536, row0=0, out=None, spread=0.35):
@@ -193,16 +364,7 @@ def run_c5(args):
     from cuvs_amd._lib import lib
     from cuvs_amd.neighbors import ivf_pq, ivf_pq_sharded as sh
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    rank, world, dev, dist, shared_dev = dist_setup(args)
     res = cuvs_amd.common.Resources()
     rows = args.rows if args.rows != 100_000_000 else 1_000_000_000
     dim, chunk = 96, 1 << 24
@@ -214,7 +376,7 @@ def run_c5(args):
     train = first[:: max(1, first.shape[0] // 2_000_000)].contiguous()
     ip = ivf_pq.IndexParams(n_lists=n_lists, metric="sqeuclidean", pq_dim=args.pq_dim, pq_bits=8, kmeans_n_iters=20,
                             kmeans_trainset_fraction=1.0, add_data_on_build=False)
-    comm = (sh.ShardComm.from_torch(res) if world > 1 else sh.ShardComm(0, 1, sh.ShardComm.unique_id(), res))
+    comm = make_comm(sh, res, world, shared_dev)
     index = ivf_pq.build(ip, train, resources=res)
     # pass 1: list histogram (every rank counts its share of the chunks, the counts are summed), lists dealt by size
     counts = np.zeros(n_lists, np.uint64)
@@ -224,7 +386,7 @@ def run_c5(args):
         counts += sh.list_histogram(index, x, resources=res)
         del x
     if world > 1:
-        t = torch.from_numpy(counts.astype(np.int64)).to(dev)
+        t = torch.from_numpy(counts.astype(np.int64)).to("cpu" if shared_dev else dev)
         dist.all_reduce(t)
         counts = t.cpu().numpy().astype(np.uint64)
     owners = sh.deal_lists(counts, world)
@@ -298,12 +460,24 @@ def run_c5(args):
     elapsed = time.perf_counter() - t_start
     lib().cuvsAmdProfileEnable(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = ctl_tensor([elapsed], torch.float64, dev, shared_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     scan_ms, ag_ms = C.c_double(0), C.c_double(0)
     n_launch = lib().cuvsAmdProfileCollect(b"pq_scan_kernel", C.byref(scan_ms))
     lib().cuvsAmdProfileCollect(b"shard_all_gather", C.byref(ag_ms))
+    phase_ms = {}
+    for nm in (b"pq_head_kernel", b"pq_filter_kernel", b"pq_rescore_kernel"):
+        v = C.c_double(0)
+        lib().cuvsAmdProfileCollect(nm, C.byref(v))
+        phase_ms[nm.decode()] = round(v.value / max(args.steps, 1), 3)
+    # roofline of the dominant kernel on this rank's lists (same floors as the headline line) + the bounded CPU leg
+    roofline = cpu = None
+    if rank == 0:
+        roofline = pq_scan_roofline(index, queries.float(), args.n_probes, owners_t == rank, args.pq_dim, index.pq_dim * index.pq_len,
+                                    phase_ms["pq_filter_kernel"], scan_ms.value, n_launch, args.steps, phase_ms)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline_line(dev=dev)
     # recall@k of rank 0's slice against an exact search over regenerated chunks (fp32 arithmetic is exact on int8 values)
     ng = min(args.gt_queries, 200, args.batch)
     recall = None
@@ -334,11 +508,16 @@ def run_c5(args):
             "config": {"workload": f"C5 IVF-PQ {rows}x96 int8, pq_dim={args.pq_dim} pq_bits=8 n_lists={n_lists} n_probes={args.n_probes} "
                                    f"batch={args.batch} per GPU k={k}, " + (f"shard-local refinement of {kk} candidates per query and rank" if ratio > 1 else "no refinement"),
                        "parallelism": f"list shards x{world} dealt by size (LPT), RCCL all-gather of the per-rank top-k",
-                       "refine_ratio": ratio,
+                       "transport": "host-staged (mapped file): ranks share devices - functional run, not a scaling figure" if shared_dev
+                                    else "RCCL (ncclAllGather / ncclAllReduce over xGMI)",
+                       "oversubscribed": bool(shared_dev), "refine_ratio": ratio,
                        "rows_on_rank0": len(index), "build_seconds": round(build_s, 1)},
             f"recall_at_{k}": None if recall is None else round(recall, 4),
             "scan_kernel_ms_per_step": round(scan_ms.value / max(args.steps, 1), 3), "scan_launches_per_step": n_launch // max(args.steps, 1),
-            "all_gather_merge_ms_per_step": round(ag_ms.value / max(args.steps, 1), 3)}), flush=True)
+            "all_gather_merge_ms_per_step": round(ag_ms.value / max(args.steps, 1), 3),
+            "roofline": roofline, "cpu_baseline": cpu}), flush=True)
+    if world > 1:
+        dist.barrier()
     comm.close()
     if world > 1:
         dist.destroy_process_group()
@@ -569,24 +748,21 @@ def main():
                          "(BASELINE configs[4]: 1B rows over 8 GPUs; --rows scales it down), rows generated chunk by chunk")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the list-sharded code path (shard build, RCCL all-gather + merge) even with one rank")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="functional run of the N-rank path on fewer than N devices: rank r uses device r %% n_devices, the "
+                         "collectives go through the communicator's host-staged transport (RCCL refuses two ranks on one "
+                         "device). Never a scaling figure: the JSON line carries transport / oversubscribed")
     args = ap.parse_args()
     if args.lut == "f32":
         args.acc = "f32"
     if args.pmc_child:
         return pmc_child(args, args.pmc_child)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # `python bench.py --gpus N`: this process becomes the launcher of N ranks
     if args.config == "c5":
         return run_c5(args)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # control plane: barriers, the max over ranks, the id rendezvous
+    rank, world, dev, dist, shared_dev = dist_setup(args)
 
     import cuvs_amd
     from cuvs_amd._lib import lib
@@ -612,8 +788,7 @@ def main():
         index = ivf_pq.build(ip, data, resources=res)
     else:
         # the same model on every rank (same rows, deterministic k-means); each rank then keeps the rows of its lists
-        comm = (ivf_pq_sharded.ShardComm.from_torch(res) if world > 1
-                else ivf_pq_sharded.ShardComm(0, 1, ivf_pq_sharded.ShardComm.unique_id(), res))
+        comm = make_comm(ivf_pq_sharded, res, world, shared_dev)
         index = ivf_pq_sharded.build(ip, data, rank, world, resources=res)
         # lists dealt to the ranks by size (greedy LPT over the list histogram): every rank holds the whole synthetic corpus
         # here, so each computes the same histogram and the same table - no communication
@@ -678,7 +853,7 @@ def main():
         elapsed = time.perf_counter() - t_start
         lib().cuvsAmdProfileEnable(0)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = ctl_tensor([elapsed], torch.float64, dev, shared_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         scan_ms = C.c_double(0)
@@ -703,22 +878,30 @@ def main():
     # ------------------------------------------------------------------ bit-level check at the bench scale (untimed): the
     # first 1000 queries searched again by a handle whose tail phase runs the LUT scan kernels (no matrix-core filter) must
     # return the same ids AND the same distances as the headline path (ivf_pq_search.cuh:421-669: same scores, same top-k)
+    # A list-sharded index searches collectively: every rank makes the two searches and the merged blocks are compared.
     scan3_equals_lut_scan = None
-    if rank == 0 and world == 1:
+    if world > 1 or rank == 0:
         nchk = min(1000, args.batch)
         sp_chk = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
                                      max_internal_batch_size=nq_total)
         a_i = torch.empty((nchk, kk), dtype=torch.int64, device=dev)
         a_d = torch.empty((nchk, kk), dtype=torch.float32, device=dev)
         b_i, b_d = torch.empty_like(a_i), torch.empty_like(a_d)
-        ivf_pq.search(sp_chk, index, queries[:nchk], kk, neighbors=a_i, distances=a_d, resources=res)
         os.environ["CUVS_AMD_PQ_SCAN3"] = "0"
         res_lut = cuvs_amd.common.Resources()  # the switches are read once, when a handle is created
         del os.environ["CUVS_AMD_PQ_SCAN3"]
-        ivf_pq.search(sp_chk, index, queries[:nchk], kk, neighbors=b_i, distances=b_d, resources=res_lut)
-        res.sync(); res_lut.sync()
+        for r_, o_i, o_d in ((res, a_i, a_d), (res_lut, b_i, b_d)):
+            ivf_pq.search(sp_chk, index, queries[:nchk], kk, neighbors=o_i, distances=o_d, resources=r_)
+            if sharded:
+                g_d, g_i = comm.all_gather_topk(o_d, o_i, resources=r_)
+                o_d.copy_(g_d); o_i.copy_(g_i)
+            r_.sync()
         torch.cuda.synchronize()
         scan3_equals_lut_scan = bool(torch.equal(a_i, b_i) and torch.equal(a_d, b_d))
+        if world > 1:
+            t = ctl_tensor([1 if scan3_equals_lut_scan else 0], torch.int64, dev, shared_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            scan3_equals_lut_scan = bool(t.item())
         log(f"scan3 == LUT scan on {nchk} queries of the {args.rows}-row index: {scan3_equals_lut_scan}")
         del res_lut
 
@@ -747,76 +930,16 @@ def main():
         early_stop_off_ms = round(s / 3, 3)
         del res_off
 
-    # ------------------------------------------------------------------ roofline of the dominant kernel
-    # Algorithmic work of one search, from the index's list sizes and an independent coarse ranking of the batch:
-    #   logical bytes  = sum over (query, probe) pairs of list_len * code bytes (the reference reads a list once per pair)
-    #   unique bytes   = code bytes of every list probed by at least one pair (the lower bound on HBM bytes per batch)
-    #   useful flop    = 2 * rot_dim per (row, query) pair of the tail phase (the screen is a GEMM of decoded rows x residuals)
-    #   gather cycles  = LDS cycles of the decode if no two lanes ever met in a bank: every 32-row subtile of a probed list
-    #                    once per 128 probing queries, 32 ds_read_b32 x 2 cycles each
-    sizes = index.list_sizes.to(torch.int64)
-    centers = index.centers
-    cn = (centers * centers).sum(1)
+    # ------------------------------------------------------------------ roofline of the dominant kernel (every N: the
+    # floors are those of THIS rank's lists - a list shard screens only the probes it owns - against rank 0's kernel time)
     owned = ((torch.from_numpy(owners.astype(np.int64)).to(dev) == rank) if sharded
              else torch.ones(args.n_lists, dtype=torch.bool, device=dev))
-    probe_bytes = 0
-    tail_pairs = torch.zeros(args.n_lists, dtype=torch.int64, device=dev)
-    all_pairs = torch.zeros(args.n_lists, dtype=torch.int64, device=dev)
-    code_bytes = args.pq_dim * 8 // 8
-    for q0 in range(0, nq_total, 2048):
-        qq = queries[q0:q0 + 2048]
-        dmat = cn[None, :] - 2.0 * (qq @ centers.T)
-        pr = torch.topk(dmat, min(args.n_probes, args.n_lists), dim=1, largest=False).indices
-        probe_bytes += int((sizes[pr] * owned[pr]).sum().item()) * code_bytes
-        all_pairs += torch.bincount(pr.reshape(-1), minlength=args.n_lists)
-        tail_pairs += torch.bincount(pr[:, 1:].reshape(-1), minlength=args.n_lists)  # the nearest probe is the head phase
-    tail_pairs, all_pairs = tail_pairs * owned, all_pairs * owned
-    unique_bytes = int((sizes * (all_pairs > 0)).sum().item()) * code_bytes
-    tail_row_pairs = int((sizes * tail_pairs).sum().item())
-    useful_flop = 2.0 * (2 * args.pq_dim) * tail_row_pairs
-    subtile_decodes = int((((sizes + 31) // 32) * ((tail_pairs + 127) // 128)).sum().item())
-    gather_cycles = subtile_decodes * 32 * 2.0
-    SPEC_GHZ, MFMA_F16_TFLOPS = 2.4, 2500.0  # MI355X_MICROARCH.md: peak engine clock, dense fp16 MFMA peak
-    # one search = a small head launch (nearest probe of every query) + the tail launch: the same work, bytes and
-    # time are averaged over all launches (sum of bytes / sum of time)
     per_step = max(n_launch, 1) / max(args.steps, 1)
-    bytes_per_launch = probe_bytes / per_step
     avg_ms = scan_ms / max(n_launch, 1)
-    logical = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # The dominant kernel is pq_filter_kernel (one launch per search). Its speed of light is the largest of three floors, each
-    # a spec peak: unique code bytes / 8 TB/s, useful fp16 MFMA flop / 2.5 PFLOP/s, conflict-free gather cycles / (256 CUs x
-    # 2.4 GHz). `frac` = that floor / the kernel's measured duration (HIP events around the launch, this run); `bound` names it.
     f_ms = headline_phase_ms.get("pq_filter_kernel", 0.0)
-    floors_ms = {"hbm": unique_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, "mfma": useful_flop / (MFMA_F16_TFLOPS * 1e12) * 1e3,
-                 "lds": gather_cycles / (N_CU * SPEC_GHZ * 1e9) * 1e3}
-    sol_bound = max(floors_ms, key=floors_ms.get)
-    sol_frac = floors_ms[sol_bound] / f_ms if f_ms > 0 else None
-    if sol_bound == "hbm":
-        ach, peak, unit = unique_bytes / max(f_ms, 1e-9) / 1e6, HBM_PEAK_GBS, "GB/s"
-    elif sol_bound == "mfma":
-        ach, peak, unit = useful_flop / max(f_ms, 1e-9) / 1e9, MFMA_F16_TFLOPS, "TFLOP/s"
-    else:
-        ach, peak, unit = gather_cycles / max(f_ms, 1e-9) / 1e6, N_CU * SPEC_GHZ, "Gcycles/s"
-    roofline = {"bound": sol_bound, "kernel": "pq_filter_kernel (the tail phase's matrix-core screen: dominant kernel, one launch per search)",
-                "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": None if sol_frac is None else round(sol_frac, 4),
-                "traffic": None, "avg_launch_ms": round(f_ms, 3),
-                "floors_ms": {k: round(v, 3) for k, v in floors_ms.items()},
-                "frac_hbm_unique_bytes": round(floors_ms["hbm"] / f_ms, 4) if f_ms > 0 else None,
-                "frac_mfma_useful_flop": round(floors_ms["mfma"] / f_ms, 4) if f_ms > 0 else None,
-                "frac_lds_conflict_free_gathers": round(floors_ms["lds"] / f_ms, 4) if f_ms > 0 else None,
-                "algorithmic": {"unique_code_bytes_per_search": unique_bytes, "logical_code_bytes_per_search": probe_bytes,
-                                "tail_row_query_pairs": tail_row_pairs, "useful_mfma_flop": useful_flop,
-                                "subtile_decodes": subtile_decodes, "conflict_free_gather_cycles": gather_cycles},
-                "scan_kernels": {"names": "pq_head_kernel + pq_bprep_kernel + pq_filter_kernel + pq_rescore_kernel (+ hand-backs)",
-                                 "launches_per_step": per_step, "kernel_ms_per_step": round(avg_ms * per_step, 3),
-                                 "phase_ms_per_step": headline_phase_ms, "logical_scan_gbs": round(logical, 1),
-                                 "frac_hbm_unique_bytes": round(unique_bytes / (HBM_PEAK_GBS * 1e9) / max(avg_ms * per_step * 1e-3, 1e-12), 4),
-                                 "early_stop_off_kernel_ms_per_step": early_stop_off_ms},
-                "note": "frac = max(unique code bytes / 8 TB/s, useful fp16 MFMA flop / 2.5 PFLOP/s, conflict-free LDS gather cycles / "
-                        "(256 CUs x 2.4 GHz)) / measured duration of pq_filter_kernel: every term is a spec peak and an algorithmic "
-                        "quantity computed from the index and the batch. logical_scan_gbs (SURVEY 8d: list bytes per pair) exceeds the "
-                        "HBM peak by design - a list chunk is fetched once per up to 128 probing queries - and is no utilisation. "
-                        "pmc.* are busy cycles of each pipe over SPEC-clock cycles (2.4 GHz x kernel time), from rocprofv3 --pmc passes of this workload"}
+    roofline = pq_scan_roofline(index, queries, args.n_probes, owned, args.pq_dim * 8 // 8, 2 * args.pq_dim, f_ms, scan_ms, n_launch,
+                                args.steps, headline_phase_ms, early_stop_off_ms)
+    unique_bytes = roofline["algorithmic"]["unique_code_bytes_per_search"]
     if rank == 0 and world == 1 and not args.no_pmc:
         t0 = time.time()
         child = ["--rows", str(args.rows), "--dim", str(args.dim), "--n-lists", str(args.n_lists), "--n-probes",
@@ -1005,21 +1128,9 @@ def main():
                 torch.cuda.empty_cache()
                 log(f"{name} done in {time.time() - t0:.1f}s")
         if not args.no_cpu_baseline:
-            import oracle
-
-            if c1_x is None:
-                c1_x = gen_rows(100_000, 128, 1234, dev).cpu().numpy()
-                c1_q = gen_rows(1000, 128, 4321, dev).cpu().numpy()
-            ts = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                oracle.exact_knn(c1_q, c1_x, 10)
-                ts.append(time.perf_counter() - t0)
-            med = float(np.median(ts))
-            cpu = {"value": round(1000 / med, 1), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
-                   "gflops": round(2 * 1000 * 100_000 * 128 / med / 1e9, 1),
-                   "sample": f"C1 shape (SURVEY 8d): exact kNN of 1000 queries over 100000x128 fp32, k=10, the reference's "
-                             f"refine_host arithmetic restated in oracle/ (OpenMP), median of 5 runs = {med * 1e3:.1f} ms"}
+            cpu = cpu_baseline_line(c1_x, c1_q, dev)
+    elif rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_line(dev=dev)  # N > 1: the same bounded CPU leg on rank 0's host cores (the other ranks wait below)
 
     if rank == 0:
         total_q = args.batch * args.steps * world
@@ -1052,6 +1163,10 @@ def main():
         }
         if sharded:
             out["config"]["all_gather_ms_per_step"] = round(ag_ms / max(args.steps, 1), 3)
+            out["config"]["transport"] = ("host-staged (mapped file): ranks share devices - a FUNCTIONAL run of the N-rank path, not a "
+                                          "scaling figure") if shared_dev else "RCCL (ncclAllGather / ncclAllReduce over xGMI)"
+            out["config"]["oversubscribed"] = bool(shared_dev)
+            out["config"]["devices_visible"] = torch.cuda.device_count()
         # RCCL writes its start-up banner through C stdio (the one-rank sharded line initialises a communicator): flush it
         # first, so that the JSON line is the LAST line on stdout
         try:
@@ -1059,6 +1174,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()  # rank 0 may still be in its CPU leg: nobody tears the communicators down under it
     if comm is not None:
         comm.close()
     if world > 1:

@@ -42,12 +42,18 @@ def _run_world(world, out_dir, timeout=420):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
 
 
-def _same_pairs(d0, i0, d1, i1):
-    """same (distance, id) pairs per query; equal distances may come out in either id order"""
+def _same_pairs(d0, i0, d1, i1, select_min=True):
+    """The same distances, and the same ids for every distance better than a query's k-th: rows with equal codes have equal
+    scores, and WHICH of several rows tied at the k-th score is kept depends on the order the candidates are merged in
+    ((score, probe rank, row) on one GPU, (score, rank, position) across ranks) - as in the reference's knn_merge_parts."""
     assert d0.shape == d1.shape
     assert (np.sort(d0, axis=1) == np.sort(d1, axis=1)).all()
     for q in range(d0.shape[0]):
-        assert sorted(zip(d0[q].tolist(), i0[q].tolist())) == sorted(zip(d1[q].tolist(), i1[q].tolist())), f"query {q}"
+        kth = d0[q].max() if select_min else d0[q].min()
+        a = sorted((d, i) for d, i in zip(d0[q].tolist(), i0[q].tolist()) if d != kth)
+        b = sorted((d, i) for d, i in zip(d1[q].tolist(), i1[q].tolist()) if d != kth)
+        assert a == b, f"query {q}"
+        assert len(set(i0[q].tolist())) == len(set(i1[q].tolist()))
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -74,7 +80,7 @@ def test_ranks_sharing_one_device_equal_the_unsharded_index(world, tmp_path):
             assert (part["counts"] == counts).all()               # the slices' histograms add up to the index's lists
             assert (part["owners"] == parts[0]["owners"]).all()   # every rank dealt the same table
             assert (part["d"] == parts[0]["d"]).all() and (part["i"] == parts[0]["i"]).all()   # replicated result
-            _same_pairs(part["d"], part["i"], fd, fi)
+            _same_pairs(part["d"], part["i"], fd, fi, metric != "inner_product")
         loads = np.array([counts[parts[0]["owners"] == r].sum() for r in range(world)], dtype=np.float64)
         assert loads.max() <= max(float(counts.max()), 1.34 * loads.mean())   # LPT bound
         if name == "c3_two_phase":
