@@ -138,6 +138,7 @@ def cpu_baseline_line(c1_x=None, c1_q=None, dev=None):
     part of the product path. Bounded: 5 runs of ~0.2 s."""
     import oracle
 
+    oracle.set_num_threads(0)  # every host core (torch.distributed.run pins OMP_NUM_THREADS=1 for its workers)
     if c1_x is None:
         c1_x = gen_rows(100_000, 128, 1234, dev).cpu().numpy()
         c1_q = gen_rows(1000, 128, 4321, dev).cpu().numpy()
@@ -561,15 +562,30 @@ def extra_c1(res, dev):
     q = gen_rows(1000, 128, 4321, dev)
     idx = brute_force.build(x, resources=res)
     dt = timeit(lambda: brute_force.search(idx, q, 10, resources=res), 20, 3)
-    _, i = brute_force.search(idx, q, 10, resources=res)
+    d, i = brute_force.search(idx, q, 10, resources=res)
     res.sync()
     d2 = torch.cdist(q.double(), x.double()) ** 2  # fp64 ground truth
     gt = torch.topk(d2, 10, dim=1, largest=False).indices
     tf = 2 * 1000 * 100_000 * 128 / dt / 1e12
-    return {"config": "C1 brute_force L2 100000x128 fp32 batch=1000 k=10", "ms": round(dt * 1e3, 3),
+    xh, qh = x.cpu().numpy(), q.cpu().numpy()
+    line = {"config": "C1 brute_force L2 100000x128 fp32 batch=1000 k=10", "ms": round(dt * 1e3, 3),
             "qps": round(1000 / dt, 1), "recall_at_10": round(recall_of(i.cpu().numpy(), gt.cpu().numpy()), 4),
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / MFMA_F32_TFLOPS, 4)}}, x.cpu().numpy(), q.cpu().numpy()
+                         "frac": round(tf / MFMA_F32_TFLOPS, 4)}}
+    # BASELINE configs[0] asks for bit-exact neighbour indices at exactly this shape: the CPU restatement of the search
+    # (oracle.brute_force_knn: canonical norms, k-ordered fma chain, (value, position) select) as the CHECKER of the GPU result
+    # (untimed; the oracle is never on the measured path)
+    try:
+        import oracle
+
+        oracle.set_num_threads(0)
+        od, oi = oracle.brute_force_knn(qh, xh, 10)
+        line["c1_ids_equal_oracle"] = bool((i.cpu().numpy() == oi).all())
+        line["c1_distances_equal_oracle"] = bool((d.cpu().numpy() == od).all())
+    except Exception as e:
+        line["c1_ids_equal_oracle"] = None
+        line["c1_oracle_error"] = repr(e)[:200]
+    return line, xh, qh
 
 
 def extra_c2(res, dev):

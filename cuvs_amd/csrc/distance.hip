@@ -79,6 +79,8 @@ struct append_args {
   int64_t n_rt = 0, n_ct = 0;
   unsigned long long* stats = nullptr;  // dbg & 4: cycles of [prologue, main loop, epilogue] summed over workgroups, + count
   int dbg = 0;  // timing experiments only (results are wrong): 1 no staging in the main loop, 2 no LDS reads either
+  uint32_t* gkeys = nullptr;  // MODE 3: [m, ldg] best order-preserving key of every 16-column group of a row
+  int64_t ldg     = 0;
 };
 
 // MODE 0: write D tile.  MODE 1: running argmin over all column tiles (grid.x = 1).  MODE 2: threshold + append.
@@ -458,6 +460,41 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
         }
       }
     }
+  } else if constexpr (MODE == 3) {
+    // GROUPED output for a top-k that follows (the coarse search: 128 of 16384 per row). A lane holds, for each of its 16
+    // rows, the columns c0 + j * 16 + l15 (j = 0..3) of its wave's 64-column half: these four values go out as ONE 16-byte
+    // store at position c0 + l15 * 4 + j - the row is written in a permuted order, a fixed permutation inside every
+    // 128-column tile (grouped_col() is its inverse) - and the 16 values of a lane QUAD form a group whose best
+    // order-preserving key (two DPP steps) is written to gkeys[row, column / 16]. The selection then reads the 1 / 16 of
+    // keys and only the groups that can hold one of a row's k best (select_k_grouped, select_k.hip) instead of the matrix.
+    // Columns past n are written as the worst value and never win.
+    constexpr bool smin = METRIC != M_InnerProduct;
+    const float worst   = smin ? INFINITY : -INFINITY;
+    const uint32_t flip = smin ? 0u : 0xffffffffu;
+    bool colok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) colok[j] = col0 + wn * 64 + j * 16 + l15 < n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 qn4 = *reinterpret_cast<const f32x4*>(&s_qn[wm * 64 + i * 16 + lg * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
+        f32x4 v;
+        uint32_t best = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = colok[j] ? finish_distance(acc[i][j][e], qn4[e], xnv[j], METRIC, ep.clamp_eps) : worst;
+          best = min(best, float_to_key(v[j]) ^ flip);
+        }
+        best = min(best, (uint32_t)__builtin_amdgcn_mov_dpp((int)best, 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+        best = min(best, (uint32_t)__builtin_amdgcn_mov_dpp((int)best, 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+        if (row < m) {
+          *reinterpret_cast<f32x4*>(&out[row * ldo + col0 + wn * 64 + l15 * 4]) = v;
+          if ((l15 & 3) == 0) ap.gkeys[row * ap.ldg + (col0 >> 4) + wn * 4 + (l15 >> 2)] = best;
+        }
+      }
+    }
   } else {
     // one straight-line pass: does this lane hold anything that beats its row's k-th value? (norms and thresholds come
     // from LDS four rows at a time: 8 live registers instead of 32)
@@ -591,6 +628,27 @@ void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, cons
                        ldx, dim, ep, out, ldo, (uint32_t*)nullptr, (float*)nullptr, append_args{});
   }
   HIP_TRY(hipGetLastError());
+}
+
+// Distances in GROUPED layout for a following select_k_grouped (dist_tile_kernel MODE 3): out [m, ldo] with ldo >= n rounded
+// up to 128, gkeys [m, ldg] with ldg >= ldo / 16. Returns false - nothing launched - for shapes the tile kernel does not
+// take (rows not 16-byte aligned, dim not a multiple of 16): the caller then uses pairwise_distance + select_k.
+bool pairwise_distance_grouped(resources& res, const float* q, int64_t m, int64_t ldq, const float* x, int64_t n, int64_t ldx,
+                               int64_t dim, const float* qn, const float* xn, int metric, float* out, int64_t ldo, uint32_t* gkeys,
+                               int64_t ldg)
+{
+  if (m == 0 || n == 0) return true;
+  if (!(vec_ok(q, ldq, dim) && vec_ok(x, ldx, dim) && dim % BK == 0) || res.tune.dist_old) return false;
+  if ((m + BM - 1) / BM > 65535 || ldo % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) return false;
+  CUVS_EXPECTS(ldo >= round_up(n, BN) && ldg * 16 >= round_up(n, BN), "pairwise_distance_grouped: row pitch");
+  CUVS_EXPECTS(metric == M_InnerProduct || (qn && xn), "pairwise_distance_grouped: norms required");
+  epilogue_args ep{qn, xn, metric, 1e-6f, nullptr};
+  append_args ap;
+  ap.gkeys = gkeys; ap.ldg = ldg;
+  dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((m + BM - 1) / BM));
+  launch_tile<float, float, 3>(metric, grid, res.stream, q, m, ldq, x, n, ldx, dim, ep, out, ldo, ap);
+  HIP_TRY(hipGetLastError());
+  return true;
 }
 
 template <typename TQ, typename TX>
@@ -862,4 +920,43 @@ extern "C" cuvsError_t cuvsPairwiseDistance(cuvsResources_t res_h, DLManagedTens
       CUVS_FAIL("Unsupported DLtensor dtype: %d and bits: %d", (int)x.dtype.code, (int)x.dtype.bits);
     }
   });
+}
+
+// Test hook (not part of the reference ABI): the coarse search's two forms of "distances of m queries to n rows, the k
+// best per query" - grouped != 0: pairwise_distance_grouped + select_k_grouped (the default of the IVF coarse searches);
+// grouped == 0: pairwise_distance + select_k (rounds 1-4) - so that tests/ can pin one against the other and against
+// oracle/. metric 0 (L2Expanded) or 6 (InnerProduct). Returns 2 when the grouped form does not take the shape.
+extern "C" __attribute__((visibility("default"))) int cuvsAmdPairwiseTopK(uintptr_t res_h, const float* q, int64_t m, const float* x,
+                                                                         int64_t n, int64_t dim, int metric, int k, float* out_val,
+                                                                         uint32_t* out_idx, int grouped)
+{
+  using namespace cuvs_amd;
+  int rc = 1;
+  const int ok = translate_exceptions([&] {
+    resources& res = *as_res(res_h);
+    CUVS_EXPECTS(metric == M_L2Expanded || metric == M_InnerProduct, "cuvsAmdPairwiseTopK: metric %d", metric);
+    const bool ip = metric == M_InnerProduct;
+    dev_buf<float> qn(res, ip ? 0 : m), xn(res, ip ? 0 : n);
+    if (!ip) {
+      row_norms<float>(res, q, m, dim, dim, qn.data(), false);
+      row_norms<float>(res, x, n, dim, dim, xn.data(), false);
+    }
+    if (grouped != 0) {
+      if (!select_k_grouped_ok(n, k)) { rc = 2; return; }
+      const int64_t ldo = round_up(n, 128);
+      dev_buf<float> d(res, (size_t)m * ldo);
+      dev_buf<uint32_t> gk(res, (size_t)m * (ldo / 16));
+      if (!pairwise_distance_grouped(res, q, m, dim, x, n, dim, dim, qn.data(), xn.data(), metric, d.data(), ldo, gk.data(), ldo / 16)) {
+        rc = 2;
+        return;
+      }
+      select_k_grouped(res, d.data(), ldo, gk.data(), ldo / 16, m, n, k, out_val, out_idx, !ip);
+    } else {
+      dev_buf<float> d(res, (size_t)m * n);
+      pairwise_distance<float, float>(res, q, m, dim, x, n, dim, dim, qn.data(), xn.data(), metric, d.data(), n);
+      select_k<uint32_t, uint32_t>(res, d.data(), nullptr, m, n, n, k, out_val, out_idx, !ip);
+    }
+    sync(res);
+  });
+  return ok ? rc : 0;
 }

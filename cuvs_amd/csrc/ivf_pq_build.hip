@@ -200,7 +200,31 @@ struct encode_args {
   int per_cluster;            // codebook of a row = pq_centers[list] instead of pq_centers[subspace]
   uint8_t* codes;
   int64_t* indices;
+  bool pack_each_pass = false;  // the codes of 64 rows do not fit the LDS at once (pq_dim in the thousands): packed per pass
 };
+
+// bit-packs the staged codes of 64 rows into their 16-byte chunks: one thread per (row, chunk); ctile holds the codes of
+// subspaces [sub0, ...) with row pitch ct_ld
+__device__ inline void pack_codes(const encode_args& a, const uint8_t* ctile, uint32_t ct_ld, uint32_t sub0, uint32_t n_ch,
+                                  const int64_t* flat_row, int tid)
+{
+  const uint32_t ch0 = sub0 / a.cpc;
+  for (uint32_t t = tid; t < 64 * n_ch; t += 256) {
+    uint32_t r = t & 63, ch = t >> 6;
+    if (flat_row[r] < 0) continue;
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t b = 0; b < a.cpc; ++b) {
+      uint32_t s = ch * a.cpc + b;
+      if (sub0 + s >= a.pq_dim) break;
+      uint32_t code = ctile[r * ct_ld + s];
+      uint32_t bit  = b * a.pq_bits;
+      w[bit >> 5] |= code << (bit & 31);
+      if ((bit & 31) + a.pq_bits > 32) w[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+    }
+    *reinterpret_cast<uint4*>(a.codes + code_chunk_addr(flat_row[r], a.n_chunks, ch0 + ch)) =
+      make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
 
 // 64 sorted rows per workgroup; wave w encodes subspaces w, w+4, ...; lane = row.
 __global__ __launch_bounds__(256) void encode_kernel(encode_args a)
@@ -211,7 +235,8 @@ __global__ __launch_bounds__(256) void encode_kernel(encode_args a)
   float* r_tile     = reinterpret_cast<float*>(smem);                       // [64][dc + 1]
   int64_t* flat_row = reinterpret_cast<int64_t*>(r_tile + (((size_t)64 * ldr + 1) & ~size_t(1)));  // [64]
   uint32_t* lab     = reinterpret_cast<uint32_t*>(flat_row + 64);           // [64]
-  uint8_t* ctile    = reinterpret_cast<uint8_t*>(lab + 64);                 // [64][pq_dim]
+  uint8_t* ctile    = reinterpret_cast<uint8_t*>(lab + 64);                 // [64][pq_dim], or [64][dc_sub] packed pass by pass
+  const uint32_t ct_ld = a.pack_each_pass ? a.dc_sub : a.pq_dim;
 
   const int tid  = threadIdx.x;
   const int lane = tid & 63;
@@ -279,27 +304,16 @@ __global__ __launch_bounds__(256) void encode_kernel(encode_args a)
           if (d < best) { best = d; code = c; }
         }
       }
-      ctile[lane * a.pq_dim + s] = (uint8_t)code;
+      ctile[lane * ct_ld + (a.pack_each_pass ? s - sub0 : s)] = (uint8_t)code;
     }
     __syncthreads();
+    if (a.pack_each_pass) {  // (dc_sub is a multiple of the codes per chunk: a pass ends on a chunk boundary)
+      pack_codes(a, ctile, ct_ld, sub0, (sub_end - sub0 + a.cpc - 1) / a.cpc, flat_row, tid);
+      __syncthreads();
+    }
   }
 
-  // pack: one thread per (row, chunk)
-  for (uint32_t t = tid; t < 64 * a.n_chunks; t += 256) {
-    uint32_t r = t & 63, ch = t >> 6;
-    if (flat_row[r] < 0) continue;
-    uint32_t w[4] = {0, 0, 0, 0};
-    for (uint32_t b = 0; b < a.cpc; ++b) {
-      uint32_t s = ch * a.cpc + b;
-      if (s >= a.pq_dim) break;
-      uint32_t code = ctile[r * a.pq_dim + s];
-      uint32_t bit  = b * a.pq_bits;
-      w[bit >> 5] |= code << (bit & 31);
-      if ((bit & 31) + a.pq_bits > 32) w[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-    }
-    *reinterpret_cast<uint4*>(a.codes + code_chunk_addr(flat_row[r], a.n_chunks, ch)) =
-      make_uint4(w[0], w[1], w[2], w[3]);
-  }
+  if (!a.pack_each_pass) pack_codes(a, ctile, a.pq_dim, 0u, a.n_chunks, flat_row, tid);
 }
 
 // copy the old flat arrays into the new layout (lists keep their in-list positions)
@@ -533,6 +547,31 @@ __global__ void drop_foreign_labels_kernel(uint32_t* __restrict__ labels, int64_
   if ((owner != nullptr ? (uint32_t)owner[L] : L % world) != rank) labels[i] = n_lists;
 }
 
+// LDS plan of encode_kernel: dc_sub subspaces staged per pass and whether the codes of the 64 rows are packed pass by
+// pass (pq_dim in the thousands - 6144-d rows at pq_len 2 hold 3072 codes per row: 192 KiB for 64 rows) or once at the end
+struct encode_plan { uint32_t dc_sub; bool pack_each_pass; size_t smem; };
+static encode_plan plan_encode(const ivf_pq_index& idx)
+{
+  CUVS_EXPECTS(idx.pq_len <= 240, "encode: pq_len %u too large", idx.pq_len);
+  encode_plan p;
+  p.dc_sub         = std::min<uint32_t>(idx.pq_dim, std::max<uint32_t>(1, 240 / idx.pq_len));
+  p.pack_each_pass = false;
+  auto bytes = [&](uint32_t dc_sub, uint32_t code_cols) {
+    return ((size_t)64 * (dc_sub * idx.pq_len + 1) + 2) * sizeof(float) + 64 * sizeof(int64_t) + 64 * sizeof(uint32_t) + (size_t)64 * code_cols;
+  };
+  p.smem = bytes(p.dc_sub, idx.pq_dim);
+  if (p.smem > 160 * 1024) {
+    // a pass must end on a chunk boundary: dc_sub a multiple of the codes per 16-byte chunk
+    const uint32_t cpc = idx.codes_per_chunk;
+    CUVS_EXPECTS(p.dc_sub >= cpc, "encode: pq_dim %u x pq_len %u does not fit the LDS", idx.pq_dim, idx.pq_len);
+    p.dc_sub         = p.dc_sub / cpc * cpc;
+    p.pack_each_pass = true;
+    p.smem           = bytes(p.dc_sub, p.dc_sub);
+  }
+  CUVS_EXPECTS(p.smem <= 160 * 1024, "encode: tile does not fit LDS");
+  return p;
+}
+
 void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t et, int64_t n_new, bool is_host,
                    const int64_t* new_ids, bool ids_on_host)
 {
@@ -605,11 +644,9 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
   {
     const int64_t eb = std::max<int64_t>(64, std::min<int64_t>(n_new, (int64_t(1) << 27) / std::max<int64_t>(dim, idx.rot_dim)) / 64 * 64);
     dev_buf<float> xb(res, (size_t)eb * dim), rx(res, (size_t)eb * idx.rot_dim);
-    CUVS_EXPECTS(idx.pq_len <= 240, "encode: pq_len %u too large", idx.pq_len);
-    const uint32_t dc_sub = std::min<uint32_t>(idx.pq_dim, std::max<uint32_t>(1, 240 / idx.pq_len));
-    size_t smem = ((size_t)64 * (dc_sub * idx.pq_len + 1) + 2) * sizeof(float) + 64 * sizeof(int64_t) +
-                  64 * sizeof(uint32_t) + (size_t)64 * idx.pq_dim;
-    CUVS_EXPECTS(smem <= 160 * 1024, "encode: tile does not fit LDS");
+    const encode_plan plan = plan_encode(idx);
+    const uint32_t dc_sub  = plan.dc_sub;
+    const size_t smem      = plan.smem;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem));
     for (int64_t j0 = 0; j0 < n_new; j0 += eb) {
@@ -625,7 +662,7 @@ void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t e
       a.new_ids = new_ids; a.id_base = idx.size; a.j0 = j0; a.batch = cnt;
       a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len; a.pq_bits = idx.pq_bits;
       a.book = idx.pq_book; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.dc_sub = dc_sub;
-      a.per_cluster = idx.codebook_kind == 1;
+      a.per_cluster = idx.codebook_kind == 1; a.pack_each_pass = plan.pack_each_pass;
       a.codes = codes.data(); a.indices = indices.data();
       hipLaunchKernelGGL(encode_kernel, dim3(nblk(cnt, 64)), dim3(256), smem, res.stream, a);
     }
@@ -668,9 +705,9 @@ void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data,
     sync(res);
   }
   CUVS_EXPECTS(idx.pq_len <= 240, "encode: pq_len %u too large", idx.pq_len);
-  const uint32_t dc_sub = std::min<uint32_t>(idx.pq_dim, std::max<uint32_t>(1, 240 / idx.pq_len));
-  size_t smem = ((size_t)64 * (dc_sub * idx.pq_len + 1) + 2) * sizeof(float) + 64 * sizeof(int64_t) +
-                64 * sizeof(uint32_t) + (size_t)64 * idx.pq_dim;
+  const encode_plan plan = plan_encode(idx);
+  const uint32_t dc_sub  = plan.dc_sub;
+  const size_t smem      = plan.smem;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem));
   const uint32_t bpr = (idx.pq_dim * idx.pq_bits + 7) / 8;
@@ -691,7 +728,7 @@ void ivf_pq_transform(resources& res, const ivf_pq_index& idx, const void* data,
     a.new_ids = nullptr; a.id_base = 0; a.j0 = 0; a.batch = cnt;
     a.rot_dim = idx.rot_dim; a.pq_dim = idx.pq_dim; a.pq_len = idx.pq_len; a.pq_bits = idx.pq_bits;
     a.book = idx.pq_book; a.n_chunks = idx.n_chunks; a.cpc = idx.codes_per_chunk; a.dc_sub = dc_sub;
-    a.per_cluster = idx.codebook_kind == 1;
+    a.per_cluster = idx.codebook_kind == 1; a.pack_each_pass = plan.pack_each_pass;
     a.codes = tmp_codes.data(); a.indices = ids_tmp.data();
     hipLaunchKernelGGL(encode_kernel, dim3(nblk(cnt, 64)), dim3(256), smem, res.stream, a);
     hipLaunchKernelGGL(unpack_list_kernel, dim3(nblk(cnt * (int64_t)bpr, 256)), dim3(256), 0, res.stream, tmp_codes.data(),

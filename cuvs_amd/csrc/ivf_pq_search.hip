@@ -1837,10 +1837,10 @@ __global__ void coarse_finish_kernel(float* __restrict__ d, int64_t nq, int n_li
 void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, int64_t nq, uint32_t n_probes,
                      uint32_t* probes, int coarse_dtype, float* qc)
 {
-  dev_buf<float> dist(res, (size_t)nq * idx.n_lists);
   dev_buf<float> pd(res, (size_t)nq * n_probes);
   const bool ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;  // cosine: unit queries x unit centres
   if (coarse_dtype != 0) {
+    dev_buf<float> dist(res, (size_t)nq * idx.n_lists);
     const bool half_t  = coarse_dtype == 2;
     const int64_t n_el = (int64_t)idx.n_lists * idx.dim;
     dev_buf<float>& cc = half_t ? idx.coarse_centers_h : idx.coarse_centers_i8;
@@ -1888,6 +1888,23 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
                                  probes, true);
     return;
   }
+  // fp32 coarse search. Common shapes: the distance tile writes rows in GROUPED layout + the best key of every 16-centre
+  // group, and the selection reads the keys and only the groups that can hold one of the n_probes nearest (ops.hpp:
+  // pairwise_distance_grouped / select_k_grouped) - the values, their order and the tie rule are those of the plain form below
+  if (res.tune.coarse_grouped != 0 && select_k_grouped_ok(idx.n_lists, (int)n_probes)) {
+    const int64_t ldo = round_up((int64_t)idx.n_lists, 128);
+    dev_buf<float> gdist(res, (size_t)nq * ldo);
+    dev_buf<uint32_t> gkeys(res, (size_t)nq * (ldo / 16));
+    dev_buf<float> qn(res, ip ? 0 : nq);
+    if (!ip) row_norms<float>(res, qf, nq, idx.dim, idx.dim, qn.data(), false);
+    if (pairwise_distance_grouped(res, qf, nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim, ip ? nullptr : qn.data(),
+                                  ip ? nullptr : idx.center_norms.data(), ip ? (int)M_InnerProduct : (int)M_L2Expanded, gdist.data(), ldo,
+                                  gkeys.data(), ldo / 16)) {
+      select_k_grouped(res, gdist.data(), ldo, gkeys.data(), ldo / 16, nq, idx.n_lists, (int)n_probes, pd.data(), probes, !ip);
+      return;
+    }
+  }
+  dev_buf<float> dist(res, (size_t)nq * idx.n_lists);
   if (ip) {
     pairwise_distance<float, float>(res, qf, nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim,
                                     nullptr, nullptr, M_InnerProduct, dist.data(), idx.n_lists);

@@ -40,6 +40,26 @@ void pairwise_distance(resources& res, const TQ* q, int64_t m, int64_t ldq, cons
                        float* out, int64_t ldo, const uint32_t* run_if = nullptr);
 // (run_if: a device word - the launch is a no-op while it is zero: fallback passes enqueued without a host round trip)
 
+// Distance matrix in GROUPED layout + the best key of every 16-column group, and the top-k that reads them (the coarse
+// search of the IVF indexes: k = n_probes of n_lists per query). pairwise_distance_grouped writes row i in a fixed
+// permutation inside every 128-column tile (position p holds column grouped_col(p)) so that a lane's four values are one
+// 16-byte store and 16 consecutive positions form a group; gkeys[i, p / 16] = the group's best order-preserving key.
+// select_k_grouped = select_k on the same values: the k-th best of a thread's group keys bounds the row's k-th best value,
+// only groups at or below the bound are read (~1.4 k of 16384 values at k = 128), sorted by (value, column). Results
+// are those of pairwise_distance + select_k, ties included. pairwise_distance_grouped returns false (nothing launched) for
+// shapes the tile kernel does not take; select_k_grouped handles every row (rows with masses of ties are re-laid in
+// column order and go through the radix kernel).
+bool pairwise_distance_grouped(resources& res, const float* q, int64_t m, int64_t ldq, const float* x, int64_t n, int64_t ldx,
+                               int64_t dim, const float* qn, const float* xn, int metric, float* out, int64_t ldo, uint32_t* gkeys,
+                               int64_t ldg);
+bool select_k_grouped_ok(int64_t len, int k);  // the shapes select_k_grouped takes (len >= 4096, 8 <= k <= 256, 8 k <= len)
+void select_k_grouped(resources& res, float* in, int64_t in_ld, const uint32_t* gkeys, int64_t ldg, int64_t rows, int64_t len, int k,
+                      float* out_val, uint32_t* out_idx, bool select_min);
+__host__ __device__ inline uint32_t grouped_col(uint32_t p)  // column held at position p of a grouped row
+{
+  return (p & ~63u) | ((p & 3u) << 4) | ((p >> 2) & 15u);
+}
+
 // The same distance tile, kept in registers: every element (i, j) that beats row i's current k-th value
 // buf_v[i * (k + cap) + k - 1] (strictly) and passes the pre-filter is appended - value and source id col_off + j -
 // at buf[i * (k + cap) + k + cnt[i]++] (atomic: the order within a row is arbitrary; cnt may run past cap).

@@ -305,7 +305,146 @@ __global__ __launch_bounds__(kSelThreads) void select_k_minima_kernel(const floa
   if (tid == 0) done[row] = 1u;
 }
 
+
+// ------------------------------------------------------------------ rows in GROUPED layout (ops.hpp: pairwise_distance_grouped)
+// The distance kernel has already reduced every 16 consecutive positions of a row to their best key. One 256-thread
+// workgroup per row: a thread owns the groups tid, tid + 256, ... (G slots: groups of slot w are those with
+// (group / 256) % G == w), the k-th best of the threads' slot minima bounds the row's k-th best key from above (k
+// different elements are at or below it); only groups at or below the bound are read - 64 bytes each - and their
+// elements at or below the bound sorted by (key, column), the order and the tie rule of select_k.
+template <int G>
+__global__ __launch_bounds__(kSelThreads) void select_k_grouped_kernel(const float* __restrict__ in, int64_t in_ld,
+                                                                       const uint32_t* __restrict__ gkeys, int64_t ldg, int n_groups,
+                                                                       int64_t len, int k, float* __restrict__ out_val,
+                                                                       uint32_t* __restrict__ out_idx, bool select_min,
+                                                                       uint8_t* __restrict__ done)
+{
+  constexpr int NGR = kSelThreads * G;
+  __shared__ __attribute__((aligned(16))) uint32_t tk[NGR];
+  __shared__ unsigned long long cand[kMinCap];
+  __shared__ uint32_t ctrl[2];
+  const int tid       = threadIdx.x;
+  const int64_t row   = blockIdx.x;
+  const uint32_t flip = select_min ? 0u : 0xffffffffu;
+  const uint32_t* gk  = gkeys + row * ldg;
+  const float* r      = in + row * in_ld;
+  if (tid == 0) { ctrl[0] = 0u; ctrl[1] = 0xffffffffu; }
+  uint32_t gmin[G];
+#pragma unroll
+  for (int w = 0; w < G; ++w) gmin[w] = 0xffffffffu;
+  for (int g = tid, m = 0; g < n_groups; g += kSelThreads, ++m) gmin[m % G] = min(gmin[m % G], gk[g]);
+#pragma unroll
+  for (int w = 0; w < G; ++w) tk[G * tid + w] = gmin[w];
+  __syncthreads();
+  {
+    const uint4* tk4 = reinterpret_cast<const uint4*>(tk);
+    int rk[G];
+#pragma unroll
+    for (int w = 0; w < G; ++w) rk[w] = 0;
+#pragma unroll 4
+    for (int j = 0; j < NGR / 4; ++j) {
+      const uint4 o = tk4[j];
+      const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int w = 0; w < G; ++w) rk[w] += (ov[e] < gmin[w] || (ov[e] == gmin[w] && 4 * j + e < G * tid + w)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int w = 0; w < G; ++w)
+      if (rk[w] == k - 1) ctrl[1] = gmin[w];
+  }
+  __syncthreads();
+  const uint32_t bound = ctrl[1];
+  for (int g = tid; g < n_groups; g += kSelThreads) {
+    if (gk[g] > bound) continue;  // (served from L1 / L2: the same words as above)
+    const float4* p4 = reinterpret_cast<const float4*>(r + (int64_t)g * 16);
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 v   = p4[c4];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t key = float_to_key(e[c]) ^ flip;
+        const uint32_t col = grouped_col((uint32_t)g * 16u + (uint32_t)(4 * c4 + c));
+        if (key <= bound && (int64_t)col < len) {
+          const uint32_t pos = atomicAdd(&ctrl[0], 1u);
+          if (pos < (uint32_t)kMinCap) cand[pos] = ((unsigned long long)key << 32) | col;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = ctrl[0];
+  if (cnt > (uint32_t)kMinCap || cnt < (uint32_t)k) {  // (workgroup-uniform) masses of ties at the bound: the radix kernel
+    if (tid == 0) done[row] = 0u;
+    return;
+  }
+  int P = 1;
+  while (P < (int)cnt) P <<= 1;
+  for (int t = (int)cnt + tid; t < P; t += kSelThreads) cand[t] = ~0ull;
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (P >> 1); t += kSelThreads) {
+        const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const unsigned long long a = cand[lo], b = cand[hi];
+        if ((a > b) == up) { cand[lo] = b; cand[hi] = a; }
+      }
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < k; j += kSelThreads) {
+    const unsigned long long c = cand[j];
+    out_val[row * k + j] = key_to_float((uint32_t)(c >> 32) ^ flip);
+    out_idx[row * k + j] = (uint32_t)c;
+  }
+  if (tid == 0) done[row] = 1u;
+}
+
+// rows the kernel above left (done == 0) back to column order, in place: the permutation stays inside 128-column tiles
+__global__ __launch_bounds__(128) void ungroup_rows_kernel(float* __restrict__ in, int64_t in_ld, int n_tiles, const uint8_t* __restrict__ done)
+{
+  const int64_t row = blockIdx.x;
+  if (done[row] != 0u) return;
+  float* r = in + row * in_ld;
+  for (int t = 0; t < n_tiles; ++t) {
+    const float v = r[t * 128 + threadIdx.x];
+    __syncthreads();  // (every position of the tile is read before any is overwritten)
+    r[t * 128 + (grouped_col((uint32_t)threadIdx.x))] = v;
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+bool select_k_grouped_ok(int64_t len, int k) { return len >= 4096 && k >= 8 && k <= 256 && (int64_t)k * 8 <= len && len <= (int64_t(1) << 24); }
+
+void select_k_grouped(resources& res, float* in, int64_t in_ld, const uint32_t* gkeys, int64_t ldg, int64_t rows, int64_t len, int k,
+                      float* out_val, uint32_t* out_idx, bool select_min)
+{
+  if (rows == 0) return;
+  CUVS_EXPECTS(select_k_grouped_ok(len, k) && rows < (int64_t(1) << 31), "select_k_grouped: unsupported shape");
+  const int n_groups = (int)(round_up(len, 128) / 16);
+  dev_buf<uint8_t> done(res, (size_t)rows);
+  if (k <= 128)
+    hipLaunchKernelGGL(select_k_grouped_kernel<1>, dim3((unsigned)rows), dim3(kSelThreads), 0, res.stream, in, in_ld, gkeys, ldg, n_groups,
+                       len, k, out_val, out_idx, select_min, done.data());
+  else
+    hipLaunchKernelGGL(select_k_grouped_kernel<2>, dim3((unsigned)rows), dim3(kSelThreads), 0, res.stream, in, in_ld, gkeys, ldg, n_groups,
+                       len, k, out_val, out_idx, select_min, done.data());
+  // the rows it left (none, as a rule): back to column order, then the radix kernel on those rows only
+  hipLaunchKernelGGL(ungroup_rows_kernel, dim3((unsigned)rows), dim3(128), 0, res.stream, in, in_ld, n_groups / 8, done.data());
+  const int kp2     = next_pow2(k);
+  const size_t smem = (kBins + 32 + 8) * sizeof(int) + (size_t)kp2 * (sizeof(int64_t) + sizeof(uint32_t));
+  auto kern = select_k_radix_kernel<uint32_t, uint32_t, false>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3((unsigned)rows), dim3(kSelThreads), smem, res.stream, (const float*)in, (const uint32_t*)nullptr, len, in_ld, k, kp2,
+                     out_val, out_idx, select_min, (int64_t)0, (int64_t)k, (int64_t)0, (char*)nullptr, (const uint32_t*)nullptr,
+                     (const uint8_t*)done.data());
+  HIP_TRY(hipGetLastError());
+}
 
 template <typename InIdxT, typename OutIdxT>
 void select_k(resources& res, const float* in, const InIdxT* in_idx, int64_t rows, int64_t len,

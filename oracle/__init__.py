@@ -40,6 +40,11 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def set_num_threads(n=0):
+    """OpenMP threads of the oracle's loops (0: every online core) - launchers such as torchrun pin OMP_NUM_THREADS=1."""
+    lib().oracle_set_num_threads(int(n))
+
+
 def row_norms(x, sqrt=False):
     x = _f32(x)
     out = np.empty(x.shape[0], np.float32)

@@ -281,6 +281,17 @@ EXPORT void oracle_exact_knn(const float* q, int64_t m, const float* x, int64_t 
   (void)cmp_pair;
 }
 
+/* test / bench infrastructure: a launcher may have pinned OMP_NUM_THREADS to 1 for its worker processes (torchrun does) -
+ * the CPU baseline leg of bench.py asks for the host's cores explicitly; n <= 0: every online core */
+EXPORT void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+  (void)n;
+#endif
+}
+
 EXPORT int oracle_num_threads(void)
 {
 #ifdef _OPENMP

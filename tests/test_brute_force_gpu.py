@@ -47,6 +47,15 @@ def test_bit_exact_vs_oracle(metric, n, d, q, k):
     assert (gd == od).all(), f"distance max abs diff {np.abs(gd - od).max()}"
 
 
+def test_bit_exact_at_the_baseline_config0_shape():
+    """BASELINE configs[0]: brute force L2, 100k x 128 fp32, batch 1k, k = 10 - ids AND distances bit-identical to the CPU
+    restatement at exactly that size (the fused threshold-epilogue path: n >= 65536), on bench.py's own corpus generator too."""
+    x, qq = _gen(100_000, 128, 1000, seed=2024)
+    gd, gi = _run(x, qq, 10, "sqeuclidean")
+    od, oi = oracle.brute_force_knn(qq, x, 10)
+    assert (gi == oi).all() and (gd == od).all()
+
+
 def test_recall_vs_reference_cpu_path():
     # vs the refine_host restatement (unexpanded arithmetic): ids may differ only on fp ties
     x, qq = _gen(5000, 64, 100, seed=5)

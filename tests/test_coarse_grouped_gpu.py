@@ -1,0 +1,84 @@
+"""GPU: the coarse search's grouped form (dist_tile_kernel MODE 3 + select_k_grouped_kernel, round 5) against the plain
+distance matrix + select_k of rounds 1-4 and against the oracle: ids AND values bit-identical, ties included (reference:
+select_clusters, ivf_pq_search.cuh:60-168 - a GEMM, then raft::matrix::select_k over the n_lists distances of a query)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _topk(q, x, k, metric, grouped, res):
+    import torch
+    from cuvs_amd._lib import lib
+
+    qt, xt = torch.from_numpy(q).cuda(), torch.from_numpy(x).cuda()
+    ov = torch.empty((q.shape[0], k), dtype=torch.float32, device="cuda")
+    oi = torch.empty((q.shape[0], k), dtype=torch.int32, device="cuda")
+    fn = lib().cuvsAmdPairwiseTopK
+    fn.argtypes = [C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    fn.restype = C.c_int
+    rc = fn(res.get_c_obj(), qt.data_ptr(), q.shape[0], xt.data_ptr(), x.shape[0], q.shape[1], {"l2": 0, "ip": 6}[metric], k,
+            ov.data_ptr(), oi.data_ptr(), int(grouped))
+    assert rc in (1, 2), "cuvsAmdPairwiseTopK failed"
+    return rc, ov.cpu().numpy(), oi.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+@pytest.mark.parametrize("m,n,dim,k", [(300, 4096, 64, 8), (700, 16384, 128, 128), (130, 5000, 32, 100), (257, 8192 + 17, 48, 256),
+                                       (64, 40000, 16, 200), (1000, 4100, 128, 32)])
+def test_grouped_equals_plain_and_oracle(metric, m, n, dim, k, res):
+    rng = np.random.default_rng(m + n + k)
+    q = rng.standard_normal((m, dim)).astype(np.float32)
+    x = rng.standard_normal((n, dim)).astype(np.float32)
+    rc, gv, gi = _topk(q, x, k, metric, True, res)
+    assert rc == 1, "the grouped form must take this shape"
+    _, pv, pi = _topk(q, x, k, metric, False, res)
+    assert (gi == pi).all() and (gv == pv).all()
+    if metric == "l2" and m * n <= 700 * 16384:
+        od, oi = oracle.brute_force_knn(q, x, k, metric="sqeuclidean")   # the same canonical arithmetic and (value, position) select
+        assert (gi == oi).all() and (gv == od).all()
+
+
+@pytest.mark.parametrize("metric", ["l2", "ip"])
+def test_grouped_with_masses_of_ties(metric, res):
+    """Duplicate rows by the thousand: more elements tie at the bound than the candidate buffer holds - those rows are re-laid in
+    column order and served by the radix kernel; the earliest columns win, as in the plain form."""
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((8, 32)).astype(np.float32)
+    x = base[rng.integers(0, 8, size=8192)]            # 8 distinct rows, ~1000 copies each
+    x[::97] = rng.standard_normal((len(x[::97]), 32)).astype(np.float32)   # plus a few rows of their own
+    q = rng.standard_normal((200, 32)).astype(np.float32)
+    q[:50] = 0.0                                       # all-zero queries: every inner product ties
+    for k in (16, 128):
+        _, gv, gi = _topk(q, x, k, metric, True, res)
+        _, pv, pi = _topk(q, x, k, metric, False, res)
+        assert (gi == pi).all() and (gv == pv).all()
+
+
+def test_ivf_pq_search_same_with_and_without_the_grouped_coarse_search(monkeypatch):
+    """End to end through cuvsIvfPqSearch: n_lists 4096, the default handle (grouped coarse search) against a handle created
+    with CUVS_AMD_COARSE_GROUPED=0."""
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import ivf_pq
+
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((60000, 32)).astype(np.float32)
+    q = rng.standard_normal((500, 32)).astype(np.float32)
+    xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    for metric in ("sqeuclidean", "inner_product", "cosine"):
+        r0 = cuvs_amd.common.Resources()
+        index = ivf_pq.build(ivf_pq.IndexParams(n_lists=4096, pq_dim=16, kmeans_n_iters=4, metric=metric), xt, resources=r0)
+        sp = ivf_pq.SearchParams(n_probes=64)
+        d0, i0 = ivf_pq.search(sp, index, qt, 10, resources=r0)
+        r0.sync()
+        monkeypatch.setenv("CUVS_AMD_COARSE_GROUPED", "0")
+        r1 = cuvs_amd.common.Resources()
+        monkeypatch.delenv("CUVS_AMD_COARSE_GROUPED")
+        d1, i1 = ivf_pq.search(sp, index, qt, 10, resources=r1)
+        r1.sync()
+        assert torch.equal(i0, i1) and torch.equal(d0, d1)
