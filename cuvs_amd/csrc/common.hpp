@@ -83,6 +83,7 @@ struct tuning {
   int pq_scan2          = 1;   // CUVS_AMD_PQ_SCAN2=0: tail phase through pq_scan_kernel (comparator in the tests)
   int pq_scan3          = 1;   // CUVS_AMD_PQ_SCAN3=0: tail phase without the matrix-core filter (comparator in the tests)
   int coarse_lowp       = 1;   // CUVS_AMD_COARSE_LOWP=0: reduced-precision coarse search on the fp32 matrix cores (round 1-3; comparator)
+  int pq_overlap        = 1;   // CUVS_AMD_PQ_OVERLAP=0: the IVF-PQ batch on one stream (rounds 1-4; comparator of the two-stream schedule)
   int coarse_grouped    = 1;   // CUVS_AMD_COARSE_GROUPED=0: coarse search through the plain distance matrix + select_k (rounds 1-4; comparator)
   int pq_filter4        = 1;   // CUVS_AMD_PQ_FILTER4=0: the matrix-core filter of round 3 (two waves per SIMD, 64-query units; comparator)
   int flat_scan3        = 1;   // CUVS_AMD_FLAT_SCAN3=0: IVF-Flat tail phase on the scan kernel (comparator in the tests)

@@ -481,14 +481,18 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
       for (int e = 0; e < 4; ++e) {
         const int64_t row = row0 + wm * 64 + i * 16 + lg * 4 + e;
         f32x4 v;
-        uint32_t best = 0xffffffffu;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = colok[j] ? finish_distance(acc[i][j][e], qn4[e], xnv[j], METRIC, ep.clamp_eps) : worst;
-          best = min(best, float_to_key(v[j]) ^ flip);
-        }
-        best = min(best, (uint32_t)__builtin_amdgcn_mov_dpp((int)best, 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-        best = min(best, (uint32_t)__builtin_amdgcn_mov_dpp((int)best, 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+        for (int j = 0; j < 4; ++j) v[j] = colok[j] ? finish_distance(acc[i][j][e], qn4[e], xnv[j], METRIC, ep.clamp_eps) : worst;
+        // the best VALUE of the lane's four, then of the quad (two DPP steps), as a float - v_min / v_max return one of their
+        // operands, so the key written is the key of an element of the group; an element of the group that compares equal
+        // but has a smaller key (-0 next to +0) is covered by writing the key of -|best| for a zero (the smaller of the two)
+        float bf = smin ? fminf(fminf(v[0], v[1]), fminf(v[2], v[3])) : fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        float o1 = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(bf), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+        bf       = smin ? fminf(bf, o1) : fmaxf(bf, o1);
+        float o2 = __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(bf), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+        bf       = smin ? fminf(bf, o2) : fmaxf(bf, o2);
+        if (bf == 0.f) bf = smin ? -0.f : 0.f;
+        const uint32_t best = float_to_key(bf) ^ flip;
         if (row < m) {
           *reinterpret_cast<f32x4*>(&out[row * ldo + col0 + wn * 64 + l15 * 4]) = v;
           if ((l15 & 3) == 0) ap.gkeys[row * ap.ldg + (col0 >> 4) + wn * 4 + (l15 >> 2)] = best;

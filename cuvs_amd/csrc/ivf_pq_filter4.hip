@@ -41,12 +41,15 @@ struct bprep_params {
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
   int is_ip, flat;
   uint32_t lpl;  // log2(pq_len)
+  float4* norms; // PART 1 / pq_thr_kernel: [tail pair] (|r|^2, |c|^2, q.c, largest scaled operand)
 };
 
 // one wave per 32 consecutive tail pairs, lane = (pair ql, K half h) - the B-operand layout of v_mfma_f32_32x32x16_f16.
 // K step st = c * pq_len + t of the filter holds, in K half h, the 8 rotated dimensions from pq_len (16 c + 8 h) + 8 t on:
 // the components of the subspaces whose code bytes are the h-th 8 bytes of the row's 16-byte code chunk c, in order
-template <int NST>
+// PART 0: B operands and thresholds (the head phase's bounds are known). PART 1: B operands and the norms the thresholds
+// need - this part does not depend on the head phase and runs next to it on a helper stream; pq_thr_kernel finishes.
+template <int NST, int PART>
 __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
 {
   const uint32_t s_base = a.pair_off[a.n_lists], s_end = a.pair_off[2 * a.n_lists];
@@ -89,6 +92,10 @@ __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
   qc  += __shfl_xor(qc, 32);
   cn  += __shfl_xor(cn, 32);
   big  = fmaxf(big, __shfl_xor(big, 32));
+  if constexpr (PART == 1) {
+    if (valid && h == 0u) a.norms[s - s_base] = make_float4(rn, cn, qc, big);
+    return;
+  }
   const uint32_t kk = a.query_kth[q];
   const float bound = key_to_float(kk);
   // no finite bound yet, an operand beyond the fp16 range or a bound the LUT type cannot represent: nothing of this query
@@ -97,6 +104,23 @@ __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
   if (!a.flat && valid && !served && h == 0u) a.qflag[q] = 1u;
   const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
   if (valid && h == 0u) a.thr[s - s_base] = served ? t / a.c1 : (a.flat ? -INFINITY : INFINITY);
+}
+
+// the second half of the pre-pass (two-stream schedule): thresholds of the tail pairs from the head phase's bounds
+__global__ __launch_bounds__(256) void pq_thr_kernel(const bprep_params a)
+{
+  const uint32_t s_base = a.pair_off[a.n_lists], s_end = a.pair_off[2 * a.n_lists];
+  const uint32_t s = s_base + blockIdx.x * 256u + threadIdx.x;
+  if (s >= s_end) return;
+  const uint32_t q  = a.sorted_pairs[s] / a.n_probes;
+  const float4 nm   = a.norms[s - s_base];
+  const float rn = nm.x, cn = nm.y, qc = nm.z, big = nm.w;
+  const uint32_t kk = a.query_kth[q];
+  const float bound = key_to_float(kk);
+  const bool served = kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max;
+  if (!a.flat && !served) a.qflag[q] = 1u;
+  const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
+  a.thr[s - s_base] = served ? t / a.c1 : (a.flat ? -INFINITY : INFINITY);
 }
 
 constexpr int kF4Threads = 256;  // 4 waves: one per SIMD, up to 512 registers each
@@ -520,27 +544,36 @@ void pq4_filter(resources& res, const filter4_launch& l)
   b.lpl = l.pl == 1 ? 0u : l.pl == 2 ? 1u : l.pl == 4 ? 2u : 3u;
   const int nst = l.nch * l.pl;  // MFMA K steps
   const unsigned pgrid = (unsigned)grid_blocks(l.n_pairs, 128);
-  profile_begin(res, "pq_bprep_kernel");
-  auto prep = [&](auto nst_tag) {
-    hipLaunchKernelGGL(pq_bprep_kernel<decltype(nst_tag)::value>, dim3(pgrid), dim3(256), 0, res.stream, b);
-  };
-  switch (nst) {
+  b.norms = static_cast<float4*>(l.pair_norms);
+  if (l.stage != 2) {
+    profile_begin(res, "pq_bprep_kernel");
+    auto prep = [&](auto nst_tag) {
+      constexpr int N = decltype(nst_tag)::value;
+      if (l.stage == 1) hipLaunchKernelGGL((pq_bprep_kernel<N, 1>), dim3(pgrid), dim3(256), 0, res.stream, b);
+      else              hipLaunchKernelGGL((pq_bprep_kernel<N, 0>), dim3(pgrid), dim3(256), 0, res.stream, b);
+    };
+    switch (nst) {
 #ifndef CUVS_AMD_F4_DEV
-    case 1: prep(std::integral_constant<int, 1>{}); break;
-    case 2: prep(std::integral_constant<int, 2>{}); break;
-    case 3: prep(std::integral_constant<int, 3>{}); break;
-    case 4: prep(std::integral_constant<int, 4>{}); break;
-    case 5: prep(std::integral_constant<int, 5>{}); break;
-    case 6: prep(std::integral_constant<int, 6>{}); break;
-    case 7: prep(std::integral_constant<int, 7>{}); break;
-    case 10: prep(std::integral_constant<int, 10>{}); break;
-    case 12: prep(std::integral_constant<int, 12>{}); break;
-    case 14: prep(std::integral_constant<int, 14>{}); break;
-    case 16: prep(std::integral_constant<int, 16>{}); break;
+      case 1: prep(std::integral_constant<int, 1>{}); break;
+      case 2: prep(std::integral_constant<int, 2>{}); break;
+      case 3: prep(std::integral_constant<int, 3>{}); break;
+      case 4: prep(std::integral_constant<int, 4>{}); break;
+      case 5: prep(std::integral_constant<int, 5>{}); break;
+      case 6: prep(std::integral_constant<int, 6>{}); break;
+      case 7: prep(std::integral_constant<int, 7>{}); break;
+      case 10: prep(std::integral_constant<int, 10>{}); break;
+      case 12: prep(std::integral_constant<int, 12>{}); break;
+      case 14: prep(std::integral_constant<int, 14>{}); break;
+      case 16: prep(std::integral_constant<int, 16>{}); break;
 #endif
-    default: prep(std::integral_constant<int, 8>{}); break;
+      default: prep(std::integral_constant<int, 8>{}); break;
+    }
+    profile_end(res, "pq_bprep_kernel");
+    HIP_TRY(hipGetLastError());
+    if (l.stage == 1) return;
+  } else {
+    hipLaunchKernelGGL(pq_thr_kernel, dim3((unsigned)grid_blocks(l.n_pairs, 256)), dim3(256), 0, res.stream, b);
   }
-  profile_end(res, "pq_bprep_kernel");
   filter4_params g{};
   g.units = l.units; g.n_units = l.n_units; g.xcd_ticket = l.xcd_ticket; g.sorted_pairs = l.sorted_pairs; g.pair_off = l.pair_off;
   g.n_lists = l.n_lists; g.bq = b.bq; g.thr = l.thr; g.cb16 = l.cb16; g.codes = l.codes; g.list_offsets = l.list_offsets;

@@ -83,6 +83,8 @@ struct filter4_launch {
   int64_t n_pairs;
   unsigned long long* stats;
   unsigned grid;
+  int stage = 0;              // pq3_run::stage: 1 = pre-pass without thresholds only, 2 = thresholds + filter, 0 = both in one go
+  void* pair_norms = nullptr; // [tail pairs] float4 between stage 1 and stage 2
 };
 void pq4_filter(resources& res, const filter4_launch& l);
 

@@ -918,6 +918,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __syncthreads();
     const work_item item = cur;
     if (item.pad == 0xffffffffu) break;  // workgroup-uniform
+    if (item.count == 0u) continue;      // (direct head items: the nearest list of this query lives on another rank)
     unsigned long long t_prev = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
     auto phase = [&](int which) {
       if (a.stats != nullptr && tid == 0) {
@@ -1466,21 +1467,31 @@ size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_ro
   return (size_t)16 * ((size_t)n_pairs / 32 + idx.n_lists + 1);
 }
 
+void pq3_warm(resources& res, const ivf_pq_index& idx, bool filter4)
+{
+  uint32_t n_chunks = 0;
+  (void)pq3_codes(res, idx, &n_chunks);
+  (void)pq3_prepare(res, idx, filter4);
+}
+
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
 {
   const bool f4 = r.bq != nullptr;  // pq_filter4_kernel (one wave per SIMD, up to four query groups per unit)
+  CUVS_EXPECTS(r.stage == 0 || f4, "ivf_pq: the two-stream schedule is pq_filter4_kernel's");
   const pq3_tables tb = pq3_prepare(res, idx, f4);
-  profile_begin(res, "pq_scan_kernel");  // bench.py sums the scan phases under this name
+  if (r.stage != 1) profile_begin(res, "pq_scan_kernel");  // bench.py sums the scan phases under this name
   const int nch        = (int)idx.pq_dim / 16;          // 16-byte code chunks per row
   const int nst        = nch * (int)idx.pq_len;         // MFMA K steps = rot_dim / 16
   // queries per work unit: B-operand groups of 32, four (two beyond 8 K steps) with 512 registers per wave, else two (one)
   const uint32_t group = f4 ? (nst <= 8 ? 128u : 64u) : (nch <= 4 ? 64u : 32u);
   CUVS_EXPECTS(f4 || (idx.pq_len == 2 && idx.codebook_kind == 0), "ivf_pq: pq_filter_kernel decodes pq_len 2, PER_SUBSPACE only");
   auto* units = static_cast<filter_unit*>(r.units);
-  hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
-                     r.unit_rows, r.unit_off, group);
-  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
-                     idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, group);
+  if (r.stage != 2) {
+    hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
+                       r.unit_rows, r.unit_off, group);
+    hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
+                       idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, group);
+  }
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket;
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = idx.centers_rot.data();
@@ -1522,7 +1533,9 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
     l.cbmax = f.cbmax; l.dmax = f.dmax; l.bound_max = f.bound_max; l.is_ip = r.is_ip; l.dbg = r.filter_dbg; l.nch = nch;
     l.pl = (int)idx.pq_len; l.per_cluster = idx.codebook_kind != 0 ? 1 : 0;
     l.n_pairs = r.nq * (int64_t)r.n_probes; l.stats = r.stats; l.grid = grid;
+    l.stage = r.stage; l.pair_norms = r.pair_norms;
     pq4_filter(res, l);
+    if (r.stage == 1) return;  // (the helper stream's share: units, B operands, norms)
   } else {
   auto launch_filter = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));

@@ -44,6 +44,13 @@ struct pq3_run {
   float* thr;                    //   and [tail pairs] thresholds, both written by the pre-pass
   int filter_dbg;                // ablation bits of the filter kernel (timing only)
   unsigned long long* stats;     // optional device [8]
+  // Two-stream schedule of a batch (ivf_pq_search.hip, round 5): everything of the tail phase that does not depend on the head
+  // phase's bounds - work units, B operands - runs on a helper stream WHILE the head kernel runs.
+  //   stage 0: the whole tail phase on one stream (every shape outside the two-stream schedule)
+  //   stage 1: work units + pre-pass without thresholds (B operands, and the norms the thresholds need -> pair_norms)
+  //   stage 2: thresholds from pair_norms and the head bounds, filter, re-score, fallback work items
+  int stage = 0;
+  void* pair_norms = nullptr;    // [tail pairs] x 16 bytes (|r|^2, |c|^2, q.c, largest scaled operand), written by stage 1
 };
 
 // single-query list scan with the k smallest selected in LDS (head phase, pairs of handed-back queries)
@@ -96,6 +103,10 @@ unsigned pq3_regions(const resources& res);  // survivor regions of pq_filter_ke
 bool pq3_supported(const ivf_pq_index& idx, int k);
 bool pq3_bound_useful(const ivf_pq_index& idx, int k);  // k is a small enough fraction of a list for the head bound to prune
 size_t pq3_max_units(const ivf_pq_index& idx, int64_t n_pairs, uint32_t* unit_rows, bool filter4);
+// the index's derived tables of this path (decode table, row terms, one-byte-per-code copy), built on first use and when the
+// lists change - on the stream of `res`: the two-stream schedule calls this BEFORE it forks, so that no helper-stream kernel
+// ever runs next to the build
+void pq3_warm(resources& res, const ivf_pq_index& idx, bool filter4);
 // filter + re-score + fallback work items of the flagged queries (the caller launches the LUT scan on them)
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r);
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i);

@@ -1948,6 +1948,23 @@ void rotate_queries(resources& res, const ivf_pq_index& idx, const float* qf, co
   if (!half_t) hipLaunchKernelGGL(scale_kernel, dim3(nblk(nq * idx.rot_dim, 256)), dim3(256), 0, res.stream, rot_q, nq * idx.rot_dim, 1.0f / 128.0f / 128.0f);
 }
 
+// Two-stream schedule: the head phase scans ONE pair per query - its nearest probe - so its work items need no grouping:
+// item q = (list probes[q, 0], pair q n_probes), count 0 when that list lives on another rank of a list-sharded index.
+// The head kernel can start as soon as the probes are known, while the grouping of all pairs, the work units and the B
+// operands of the tail phase are made on the helper stream.
+__global__ void head_items_kernel(const uint32_t* __restrict__ probes, int64_t nq, uint32_t n_probes, uint32_t shard_world,
+                                  uint32_t shard_rank, const int32_t* __restrict__ owner, work_item* __restrict__ items,
+                                  uint32_t* __restrict__ pairs, uint32_t* __restrict__ n_items)
+{
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0) *n_items = (uint32_t)nq;
+  if (q >= nq) return;
+  const uint32_t L = probes[q * n_probes];
+  const bool mine  = shard_world <= 1 || (owner != nullptr ? (uint32_t)owner[L] == shard_rank : L % shard_world == shard_rank);
+  items[q] = work_item{L, (uint32_t)q, mine ? 1u : 0u, 0u};
+  pairs[q] = (uint32_t)(q * n_probes);
+}
+
 // the first `seg` slots of every query's candidate row (the head pairs' segments) start out "nothing found"
 __global__ void init_head_rows_kernel(float* __restrict__ cand_d, uint32_t* __restrict__ cand_i, int64_t nq, int64_t row_len, uint32_t seg)
 {
@@ -2133,6 +2150,22 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const bool use_f4 = use3 && res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2 || idx.codebook_kind != 0);
   dev_buf<uint4> bq3(res, use_f4 ? (size_t)n_pairs_max * (idx.rot_dim / 8) : 0);  // fp16 B operands of the tail pairs
   dev_buf<float> thr3(res, use_f4 ? (size_t)n_pairs_max : 0);
+  // two-stream schedule (the bench shape and every other search whose head phase is one single-pair item per query and whose
+  // tail phase runs pq_filter4_kernel): grouping, work units and B operands on the helper stream, next to the head kernel
+  const bool overlap = use3 && use_f4 && head == 1 && !glut && res.tune.pq_overlap != 0;
+  dev_buf<work_item> hitems(res, overlap ? (size_t)bs_alloc : 0);
+  dev_buf<uint32_t> hpairs(res, overlap ? (size_t)bs_alloc + 1 : 0);  // + the item count
+  dev_buf<float4> pair_norms(res, overlap ? (size_t)n_pairs_max : 0);
+  resources aux = res;
+  if (overlap) {
+    if (res.aux_stream == nullptr) {  // the helper stream and its events live with the handle
+      HIP_TRY(hipStreamCreateWithFlags(&res.aux_stream, hipStreamNonBlocking));
+      for (auto& ev : res.aux_events) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    aux.aux_stream = res.aux_stream;
+    aux.stream     = res.aux_stream;
+  }
+  resources& gres = overlap ? aux : res;  // the stream the grouping and the tail phase's preparation are queued on
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
@@ -2162,8 +2195,13 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (p.coarse_search_dtype != 0 && idx.metric == M_CosineExpanded) normalize_rows(res, rot_q.data(), nq, idx.rot_dim);
     // list-major grouping of the (query, probe) pairs
     const uint32_t* labels = probes.data();
+    if (overlap) {  // fork: the helper stream starts behind the probes and the rotated queries
+      pq3_warm(res, idx, true);  // (derived tables of the index: built here, on the handle's stream, if they are not there yet)
+      HIP_TRY(hipEventRecord(res.aux_events[0], res.stream));
+      HIP_TRY(hipStreamWaitEvent(gres.stream, res.aux_events[0], 0));
+    }
     if (head > 0 || sharded) {
-      hipLaunchKernelGGL(phase_labels_kernel, dim3(nblk(n_pairs, 256)), dim3(256), 0, res.stream, probes.data(),
+      hipLaunchKernelGGL(phase_labels_kernel, dim3(nblk(n_pairs, 256)), dim3(256), 0, gres.stream, probes.data(),
                          n_pairs, n_probes, head, idx.n_lists, phase_labels.data(), (uint32_t)idx.shard_world,
                          (uint32_t)idx.shard_rank, n_ranges, idx.list_owner.data());
       labels = phase_labels.data();
@@ -2178,8 +2216,12 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     // single-query LUT (a quarter of the LUT build and of the accumulate work of the 4-query interleave)
     const int lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0);
     const bool head1 = use3 && !glut;
-    build_work_items(res, labels, n_pairs, n_labels, head1 ? 1 : qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
+    build_work_items(gres, labels, n_pairs, n_labels, head1 ? 1 : qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data(), (int)idx.n_lists, use2 ? 8 : qpb);
+    if (overlap)
+      hipLaunchKernelGGL(head_items_kernel, dim3(nblk(nq, 256)), dim3(256), 0, res.stream, probes.data(), nq, n_probes,
+                         (uint32_t)idx.shard_world, (uint32_t)idx.shard_rank, idx.list_owner.data(), hitems.data(), hpairs.data(),
+                         hpairs.data() + bs_alloc);
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
     // per-pair candidate rows start out invalid: the scan only writes the rows of pairs that found something
@@ -2264,7 +2306,11 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (head > 0) {
       a.xcd_ticket = tickets.data();
       a.item_begin = nullptr;                        a.item_end = item_off.data() + idx.n_lists;
-      if (head1) launch1(a); else launch(a);  // head phase: the nearest probes, cold bounds
+      if (overlap) {  // head phase straight from the probes (one single-pair item per query), no grouping in its way
+        scan_args ah = a;
+        ah.items = hitems.data(); ah.sorted_pairs = hpairs.data(); ah.item_end = hpairs.data() + bs_alloc;
+        launch1(ah);
+      } else if (head1) launch1(a); else launch(a);  // head phase: the nearest probes, cold bounds
       // list-sharded index with a communicator: every rank continues with the bound of the query's globally nearest
       // probe (one all-reduce of nq keys), not only the rank that owns that probe
       if (idx.shard_comm != nullptr) shard_allreduce_min_u32(res, idx.shard_comm, query_kth.data(), (size_t)nq);
@@ -2273,6 +2319,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       if (use3) {
         HIP_TRY(hipMemsetAsync(qstate.data(), 0, qstate.bytes(), res.stream));
         pq3_run r{};
+        r.pair_norms = pair_norms.data();
         r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = a.is_ip;
         r.lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0); r.acc_half = acc_half ? 1 : 0;
         r.sorted_pairs = sorted_pairs.data(); r.pair_off = pair_off.data(); r.probes = probes.data();
@@ -2288,6 +2335,15 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 8 : 0);
         if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
         r.stats = st3.data(); r.filter_dbg = (a.dbg >> 16) & 255;  // CUVS_AMD_SCAN_DEBUG bits 16..23
+        if (overlap) {
+          // the helper stream: work units, B operands and norms of the tail pairs (nothing here reads the head phase's bounds);
+          // join; then thresholds, filter and re-score behind the head kernel (and the bound all-reduce) on the handle's stream
+          r.stage = 1;
+          pq3_tail(gres, idx, r);
+          HIP_TRY(hipEventRecord(res.aux_events[1], gres.stream));
+          HIP_TRY(hipStreamWaitEvent(res.stream, res.aux_events[1], 0));
+          r.stage = 2;
+        }
         pq3_tail(res, idx, r);
         // queries the filter could not serve (no finite bound, operands beyond fp16, full pool): LUT scan of their pairs
         a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters;

@@ -307,86 +307,103 @@ __global__ __launch_bounds__(kSelThreads) void select_k_minima_kernel(const floa
 
 
 // ------------------------------------------------------------------ rows in GROUPED layout (ops.hpp: pairwise_distance_grouped)
-// The distance kernel has already reduced every 16 consecutive positions of a row to their best key. One 256-thread
-// workgroup per row: a thread owns the groups tid, tid + 256, ... (G slots: groups of slot w are those with
-// (group / 256) % G == w), the k-th best of the threads' slot minima bounds the row's k-th best key from above (k
-// different elements are at or below it); only groups at or below the bound are read - 64 bytes each - and their
-// elements at or below the bound sorted by (key, column), the order and the tie rule of select_k.
+// The distance kernel has already reduced every 16 consecutive positions of a row to their best key. ONE WAVE per row (four
+// rows per workgroup, no workgroup barrier): the group keys are cut into 256 G classes - class (m % G, lane, c) holds
+// component c of the lane's m-th 16-byte key vector - the k-th best class minimum bounds the row's k-th best key from above
+// (k different elements are at or below it; found by a bitwise radix select over the 4 G class minima a lane holds: 32
+// ballots per register instead of 256 G compares per thread), only groups at or below the bound are read - 64 bytes each -
+// and their elements at or below the bound sorted by (key, column), the order and the tie rule of select_k.
+constexpr int kGrpCap = 512;  // candidates at or below the bound, per row
+
 template <int G>
 __global__ __launch_bounds__(kSelThreads) void select_k_grouped_kernel(const float* __restrict__ in, int64_t in_ld,
                                                                        const uint32_t* __restrict__ gkeys, int64_t ldg, int n_groups,
-                                                                       int64_t len, int k, float* __restrict__ out_val,
+                                                                       int64_t rows, int64_t len, int k, float* __restrict__ out_val,
                                                                        uint32_t* __restrict__ out_idx, bool select_min,
                                                                        uint8_t* __restrict__ done)
 {
-  constexpr int NGR = kSelThreads * G;
-  __shared__ __attribute__((aligned(16))) uint32_t tk[NGR];
-  __shared__ unsigned long long cand[kMinCap];
-  __shared__ uint32_t ctrl[2];
-  const int tid       = threadIdx.x;
-  const int64_t row   = blockIdx.x;
+  __shared__ unsigned long long cand_all[kSelThreads / 64][kGrpCap];
+  const int lane    = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kSelThreads / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;  // wave-uniform
+  unsigned long long* cand = cand_all[threadIdx.x >> 6];
   const uint32_t flip = select_min ? 0u : 0xffffffffu;
-  const uint32_t* gk  = gkeys + row * ldg;
+  const uint4* gk4    = reinterpret_cast<const uint4*>(gkeys + row * ldg);
   const float* r      = in + row * in_ld;
-  if (tid == 0) { ctrl[0] = 0u; ctrl[1] = 0xffffffffu; }
-  uint32_t gmin[G];
+  const int n_vec     = n_groups >> 2;  // (n_groups is a multiple of 8)
+  // ---- class minima
+  uint32_t cm[G][4];
 #pragma unroll
-  for (int w = 0; w < G; ++w) gmin[w] = 0xffffffffu;
-  for (int g = tid, m = 0; g < n_groups; g += kSelThreads, ++m) gmin[m % G] = min(gmin[m % G], gk[g]);
+  for (int w = 0; w < G; ++w)
 #pragma unroll
-  for (int w = 0; w < G; ++w) tk[G * tid + w] = gmin[w];
-  __syncthreads();
-  {
-    const uint4* tk4 = reinterpret_cast<const uint4*>(tk);
-    int rk[G];
-#pragma unroll
-    for (int w = 0; w < G; ++w) rk[w] = 0;
-#pragma unroll 4
-    for (int j = 0; j < NGR / 4; ++j) {
-      const uint4 o = tk4[j];
-      const uint32_t ov[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int w = 0; w < G; ++w) rk[w] += (ov[e] < gmin[w] || (ov[e] == gmin[w] && 4 * j + e < G * tid + w)) ? 1 : 0;
-    }
+    for (int c = 0; c < 4; ++c) cm[w][c] = 0xffffffffu;
+  for (int j = lane, m = 0; j < n_vec; j += 64, ++m) {
+    const uint4 v = gk4[j];
 #pragma unroll
     for (int w = 0; w < G; ++w)
-      if (rk[w] == k - 1) ctrl[1] = gmin[w];
+      if (m % G == w) { cm[w][0] = min(cm[w][0], v.x); cm[w][1] = min(cm[w][1], v.y); cm[w][2] = min(cm[w][2], v.z); cm[w][3] = min(cm[w][3], v.w); }
   }
-  __syncthreads();
-  const uint32_t bound = ctrl[1];
-  for (int g = tid; g < n_groups; g += kSelThreads) {
-    if (gk[g] > bound) continue;  // (served from L1 / L2: the same words as above)
-    const float4* p4 = reinterpret_cast<const float4*>(r + (int64_t)g * 16);
+  // ---- value of the k-th smallest class minimum: one bit per step, counts by ballot
+  uint32_t prefix = 0u, mask = 0u;
+  int need = k;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t b = 1u << bit;
+    int zeros = 0;
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
-      const float4 v   = p4[c4];
-      const float e[4] = {v.x, v.y, v.z, v.w};
+    for (int w = 0; w < G; ++w)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t key = float_to_key(e[c]) ^ flip;
-        const uint32_t col = grouped_col((uint32_t)g * 16u + (uint32_t)(4 * c4 + c));
-        if (key <= bound && (int64_t)col < len) {
-          const uint32_t pos = atomicAdd(&ctrl[0], 1u);
-          if (pos < (uint32_t)kMinCap) cand[pos] = ((unsigned long long)key << 32) | col;
+      for (int c = 0; c < 4; ++c) zeros += __popcll(__ballot(((cm[w][c] & mask) == prefix) && (cm[w][c] & b) == 0u));
+    if (need > zeros) { need -= zeros; prefix |= b; }
+    mask |= b;
+  }
+  const uint32_t bound = prefix;
+  // ---- the elements at or below the bound in the groups at or below it; positions by ballot + prefix count
+  uint32_t cnt = 0u;
+  for (int j0 = 0; j0 < n_vec; j0 += 64) {
+    const int j   = j0 + lane;
+    const uint4 v = j < n_vec ? gk4[j] : make_uint4(~0u, ~0u, ~0u, ~0u);  // (served from L1 / L2: the same words as above)
+    const uint32_t gv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool hit = gv[c] <= bound && j < n_vec;
+      if (__ballot(hit) == 0ull) continue;  // wave-uniform
+      float4 e4[4];
+      if (hit) {
+        const float4* p4 = reinterpret_cast<const float4*>(r + (int64_t)(4 * j + c) * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e4[t] = p4[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float e[4] = {e4[t].x, e4[t].y, e4[t].z, e4[t].w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t key = hit ? (float_to_key(e[u]) ^ flip) : 0xffffffffu;
+          const uint32_t col = grouped_col((uint32_t)(4 * j + c) * 16u + (uint32_t)(4 * t + u));
+          const bool take    = hit && key <= bound && (int64_t)col < len;
+          const unsigned long long mk = __ballot(take);
+          if (take) {
+            const uint32_t pos = cnt + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull));
+            if (pos < (uint32_t)kGrpCap) cand[pos] = ((unsigned long long)key << 32) | col;
+          }
+          cnt += (uint32_t)__popcll(mk);
         }
       }
     }
   }
-  __syncthreads();
-  const uint32_t cnt = ctrl[0];
-  if (cnt > (uint32_t)kMinCap || cnt < (uint32_t)k) {  // (workgroup-uniform) masses of ties at the bound: the radix kernel
-    if (tid == 0) done[row] = 0u;
+  if (cnt > (uint32_t)kGrpCap || cnt < (uint32_t)k) {  // (wave-uniform) masses of ties at the bound: the radix kernel
+    if (lane == 0) done[row] = 0u;
     return;
   }
-  int P = 1;
+  int P = 64;
   while (P < (int)cnt) P <<= 1;
-  for (int t = (int)cnt + tid; t < P; t += kSelThreads) cand[t] = ~0ull;
+  for (int t = (int)cnt + lane; t < P; t += 64) cand[t] = ~0ull;
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      __syncthreads();
-      for (int t = tid; t < (P >> 1); t += kSelThreads) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < (P >> 1); t += 64) {
         const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
         const bool up = (lo & size) == 0;
         const unsigned long long a = cand[lo], b = cand[hi];
@@ -394,13 +411,14 @@ __global__ __launch_bounds__(kSelThreads) void select_k_grouped_kernel(const flo
       }
     }
   }
-  __syncthreads();
-  for (int j = tid; j < k; j += kSelThreads) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < k; j += 64) {
     const unsigned long long c = cand[j];
     out_val[row * k + j] = key_to_float((uint32_t)(c >> 32) ^ flip);
     out_idx[row * k + j] = (uint32_t)c;
   }
-  if (tid == 0) done[row] = 1u;
+  if (lane == 0) done[row] = 1u;
 }
 
 // rows the kernel above left (done == 0) back to column order, in place: the permutation stays inside 128-column tiles
@@ -428,12 +446,13 @@ void select_k_grouped(resources& res, float* in, int64_t in_ld, const uint32_t* 
   CUVS_EXPECTS(select_k_grouped_ok(len, k) && rows < (int64_t(1) << 31), "select_k_grouped: unsupported shape");
   const int n_groups = (int)(round_up(len, 128) / 16);
   dev_buf<uint8_t> done(res, (size_t)rows);
+  const unsigned wgs = (unsigned)((rows + kSelThreads / 64 - 1) / (kSelThreads / 64));  // one wave per row
   if (k <= 128)
-    hipLaunchKernelGGL(select_k_grouped_kernel<1>, dim3((unsigned)rows), dim3(kSelThreads), 0, res.stream, in, in_ld, gkeys, ldg, n_groups,
-                       len, k, out_val, out_idx, select_min, done.data());
+    hipLaunchKernelGGL(select_k_grouped_kernel<1>, dim3(wgs), dim3(kSelThreads), 0, res.stream, in, in_ld, gkeys, ldg, n_groups,
+                       rows, len, k, out_val, out_idx, select_min, done.data());
   else
-    hipLaunchKernelGGL(select_k_grouped_kernel<2>, dim3((unsigned)rows), dim3(kSelThreads), 0, res.stream, in, in_ld, gkeys, ldg, n_groups,
-                       len, k, out_val, out_idx, select_min, done.data());
+    hipLaunchKernelGGL(select_k_grouped_kernel<2>, dim3(wgs), dim3(kSelThreads), 0, res.stream, in, in_ld, gkeys, ldg, n_groups,
+                       rows, len, k, out_val, out_idx, select_min, done.data());
   // the rows it left (none, as a rule): back to column order, then the radix kernel on those rows only
   hipLaunchKernelGGL(ungroup_rows_kernel, dim3((unsigned)rows), dim3(128), 0, res.stream, in, in_ld, n_groups / 8, done.data());
   const int kp2     = next_pow2(k);

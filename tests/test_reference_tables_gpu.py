@@ -12,6 +12,7 @@ reference's generators' ranges and its own pass criterion:
 
 The reference holds no golden OUTPUTS for these searches: thresholds and generator ranges are the pin there is."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -76,6 +77,9 @@ def _eval_neighbours(exp_i, act_i, exp_d, act_d, eps, min_recall, test_unique=Tr
         ratio = torch.where(diff > eps, diff / m, diff)
         hits += int(((ai == ei) | (ratio <= eps)).any(dim=2).sum().item())
     recall = hits / (rows * k)
+    if os.environ.get("CUVS_AMD_TABLE_LOG"):   # margins of every case, for profiles/ (test id from pytest's own variable)
+        with open(os.environ["CUVS_AMD_TABLE_LOG"], "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split('::')[-1].split(' ')[0]} recall {recall:.4f} min_recall {min_recall:.4f}\n")
     assert recall >= min_recall - eps, f"recall {recall:.4f} < min_recall {min_recall:.4f} (eps {eps:g})"
     if test_unique:
         s = torch.sort(act_i, dim=1).values
