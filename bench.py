@@ -250,6 +250,35 @@ def gen_rows(n, dim, seed, device, chunk=1 << 22, latent=32, n_modes=65536, row0
     return out
 
 
+def gen_rows_survey8d(n, dim, seed, device, n_lists, chunk=1 << 22):
+    """SURVEY 8d's generator verbatim: 4 n_lists centres ~ U[-1, 1)^d, points = centre + N(0, 0.1^2 I) (isotropic in all d
+    dimensions), counter-based per chunk. The centres come from the DATA seed (1234) for rows and queries alike - queries are
+    held-out draws around the same centres."""
+    g0 = torch.Generator(device=device)
+    g0.manual_seed(1234)
+    centres = torch.rand((4 * n_lists, dim), generator=g0, device=device) * 2.0 - 1.0
+    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    for c, r0 in enumerate(range(0, n, chunk)):
+        r1 = min(n, r0 + chunk)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1_000_003 + c)
+        a = torch.randint(0, centres.shape[0], (r1 - r0,), generator=g, device=device)
+        out[r0:r1] = centres[a]
+        out[r0:r1].add_(torch.randn((r1 - r0, dim), generator=g, device=device), alpha=0.1)
+    return out
+
+
+def gen_rows_gaussian(n, dim, seed, device, chunk=1 << 22):
+    """N(0, I) in all d dimensions: no cluster structure at all - the corpus on which a bound from the nearest list prunes least."""
+    out = torch.empty((n, dim), dtype=torch.float32, device=device)
+    for c, r0 in enumerate(range(0, n, chunk)):
+        r1 = min(n, r0 + chunk)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1_000_003 + c)
+        out[r0:r1] = torch.randn((r1 - r0, dim), generator=g, device=device)
+    return out
+
+
 def exact_topk_fp64(data, q, k, chunk=500_000):
     """Ground truth independent of the library under test: squared L2 in float64 (torch), row chunks, running top-k."""
     qd = q.double()
@@ -1086,11 +1115,16 @@ def main():
             r_st.sync()
         finally:
             os.dup2(old_err, 2); os.close(devnull); os.close(old_err)
-        st = (C.c_uint64 * 4)()
-        lib().cuvsAmdIvfPqLastFilterStats(st)
+        st = (C.c_uint64 * 6)()
+        lib().cuvsAmdIvfPqLastFilterStats6(st)
         return {"pairs_screened": int(st[0]), "survivors": int(st[1]), "survivors_per_pair": (st[1] / st[0]) if st[0] else None,
-                "subtiles_decoded": int(st[2]), "work_units": int(st[3])}
+                "subtiles_decoded": int(st[2]), "work_units": int(st[3]), "pairs_handed_back_to_the_lut_scan": int(st[4]),
+                "candidates_through_the_overflow_list": int(st[5])}
 
+    # The headline corpus, then the same step (same index parameters, same search parameters) on three others: wider modes; SURVEY
+    # 8d's generator verbatim; an isotropic Gaussian with no cluster structure (the least prunable: the worst case of the two-phase
+    # path is whatever this line says). Every line: ms per step, QPS, recall@10 vs fp64, kernel ms, survivors per (row, query)
+    # pair of the screen, pairs handed back, overflow entries.
     corpus_variants = []
     if rank == 0 and world == 1 and not args.no_variants and not sharded:
         try:
@@ -1098,27 +1132,46 @@ def main():
             corpus_variants.append({"corpus": "headline: 65536 modes, 32-d latent, spread 0.35", "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                                     "recall_at_10": round(recall, 4), "kernel_ms_per_step": round(scan_ms / max(args.steps, 1), 3),
                                     "phase_ms_per_step": headline_phase_ms, **c0})
-            del index, data
-            torch.cuda.empty_cache()
-            data = gen_rows(args.rows, args.dim, seed=1234, device=dev, latent=64, n_modes=4096, spread=0.7)
-            queries2 = gen_rows(args.batch, args.dim, seed=4321, device=dev, latent=64, n_modes=4096, spread=0.7)
-            t0 = time.time()
-            index = ivf_pq.build(ip, data, resources=res)
-            res.sync()
-            b2 = time.time() - t0
-            q_save, queries = queries, queries2  # make_step() closes over `queries`, `data`, `index`
-            e2, s2, n2, _ = timed(make_step(args.lut, args.acc), 5, 2)
-            ph2 = {k_: round(v_, 3) for k_, v_ in phase_ms.items()}
-            truth2 = exact_topk_fp64(data, queries2[:ng], args.k).cpu().numpy()
-            rec2 = recall_of(neighbors[:ng].cpu().numpy(), truth2)
-            c1 = survivors_per_pair(index, queries2)
-            corpus_variants.append({"corpus": "4096 modes, 64-d latent, spread 0.7 (wide, overlapping clusters)", "ms_per_step": round(e2 / 5 * 1e3, 3),
-                                    "qps": round(args.batch / (e2 / 5), 1), "recall_at_10": round(rec2, 4),
-                                    "kernel_ms_per_step": round(s2 / 5, 3), "phase_ms_per_step": ph2, "build_seconds": round(b2, 1), **c1})
-            queries = q_save
         except Exception as e:
-            corpus_variants.append({"corpus": "second corpus", "error": repr(e)[:300]})
-        torch.cuda.empty_cache()
+            corpus_variants.append({"corpus": "headline", "error": repr(e)[:300]})
+        q_save = queries
+        others = [("4096 modes, 64-d latent, spread 0.7 (wide, overlapping clusters)",
+                   lambda n, seed: gen_rows(n, args.dim, seed=seed, device=dev, latent=64, n_modes=4096, spread=0.7)),
+                  (f"SURVEY 8d verbatim: {4 * args.n_lists} centres ~ U[-1,1)^{args.dim}, points = centre + N(0, 0.1^2 I)",
+                   lambda n, seed: gen_rows_survey8d(n, args.dim, seed, dev, args.n_lists)),
+                  (f"isotropic Gaussian N(0, I_{args.dim}): no cluster structure (least prunable)",
+                   lambda n, seed: gen_rows_gaussian(n, args.dim, seed, dev))]
+        ngv = min(ng, 200)
+        for name, gen in others:
+            try:
+                t0 = time.time()
+                del index, data
+                torch.cuda.empty_cache()
+                data = gen(args.rows, 1234)
+                queries = gen(args.batch, 4321)  # make_step() closes over `queries`, `data`, `index`
+                index = ivf_pq.build(ip, data, resources=res)
+                res.sync()
+                b2 = time.time() - t0
+                e2, s2, n2, _ = timed(make_step(args.lut, args.acc), 5, 2)
+                ph2 = {k_: round(v_, 3) for k_, v_ in phase_ms.items()}
+                truth2 = exact_topk_fp64(data, queries[:ngv], args.k).cpu().numpy()
+                rec2 = recall_of(neighbors[:ngv].cpu().numpy(), truth2)
+                c1 = survivors_per_pair(index, queries)
+                # the same step with the tail phase on the LUT scan kernels (the path every shape falls back to): the two-phase path
+                # must not be slower than this on any corpus
+                os.environ["CUVS_AMD_PQ_SCAN3"] = "0"
+                res_lut = cuvs_amd.common.Resources()
+                del os.environ["CUVS_AMD_PQ_SCAN3"]
+                e3, _, _, _ = timed(make_step(args.lut, args.acc, res_lut), 2, 1)
+                del res_lut
+                corpus_variants.append({"corpus": name, "ms_per_step": round(e2 / 5 * 1e3, 3), "qps": round(args.batch / (e2 / 5), 1),
+                                        "recall_at_10": round(rec2, 4), "kernel_ms_per_step": round(s2 / 5, 3), "phase_ms_per_step": ph2,
+                                        "ms_per_step_lut_scan_kernels": round(e3 / 2 * 1e3, 3), "gen_and_build_seconds": round(b2, 1), **c1})
+                log(f"corpus variant '{name[:40]}': {e2 / 5 * 1e3:.2f} ms per step, recall {rec2:.4f}")
+            except Exception as e:
+                corpus_variants.append({"corpus": name, "error": repr(e)[:300]})
+            torch.cuda.empty_cache()
+        queries = q_save
 
     # ------------------------------------------------------------------ C1 / C2 / C4 lines + CPU baseline (rank 0, N=1)
     extra, cpu = [], None

@@ -275,10 +275,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     const size_t n_row_tiles = redo.size();
     dev_buf<int> ovf(res, n_row_tiles);  // one flag per row tile, read back once at the end
     HIP_TRY(hipMemsetAsync(ovf.data(), 0, ovf.bytes(), res.stream));
-    if (res.aux_stream == nullptr) {  // the helper stream and its events live with the handle
-      HIP_TRY(hipStreamCreateWithFlags(&res.aux_stream, hipStreamNonBlocking));
-      for (auto& ev : res.aux_events) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
+    ensure_aux_stream(res);  // the helper stream and its events live with the handle
     hipStream_t sb = res.aux_stream;
     hipEvent_t* eg = res.aux_events;
     hipEvent_t* ed = res.aux_events + 2;

@@ -129,6 +129,11 @@ inline resources* as_res(uintptr_t h)
 
 // Stream-ordered device allocation (the reference uses rmm::device_uvector on the handle's
 // stream; hipMallocAsync gives the same semantics from the driver's pool).
+// the handle's helper stream + events (two-stream pipelines: brute force's select next to the next tile, the IVF-PQ batch's
+// grouping / pre-pass next to the head kernel), made on first use. The helper stream has the HIGHEST priority: its kernels
+// are short and sit on the critical path behind a long kernel of the handle's stream - the workgroup dispatcher then hands
+// freed slots to them first instead of to the long kernel's backlog.
+void ensure_aux_stream(resources& res);
 void* device_alloc(resources& res, size_t bytes);
 void device_free(resources& res, void* p);
 void scratch_cache_flush_all();  // every handle's kept scratch blocks back to the runtime (an allocation failed)

@@ -50,7 +50,7 @@ void raw_free(void* stream_v, void* p)
 
 }  // namespace
 
-unsigned long long g_pq3_last_stats[4] = {0, 0, 0, 0};  // cuvsAmdIvfPqLastFilterStats (written by ivf_pq_search.hip)
+unsigned long long g_pq3_last_stats[6] = {0, 0, 0, 0, 0, 0};  // cuvsAmdIvfPqLastFilterStats (written by ivf_pq_search.hip)
 
 // scratch_cache.hpp: freed scratch blocks are kept by the handle and re-used by exact size on the same stream
 void scratch_cache_flush(resources& res)
@@ -78,6 +78,15 @@ void scratch_cache_flush_all()
   }
   (void)hipDeviceSynchronize();  // the frees are stream-ordered: the memory is back once the streams have drained
   (void)hipGetLastError();
+}
+
+void ensure_aux_stream(resources& res)
+{
+  if (res.aux_stream != nullptr) return;
+  int lo = 0, hi = 0;  // (numerically lower = higher priority)
+  HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIP_TRY(hipStreamCreateWithPriority(&res.aux_stream, hipStreamNonBlocking, hi));
+  for (auto& ev : res.aux_events) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 }
 
 void* device_alloc(resources& res, size_t bytes)
@@ -425,6 +434,12 @@ cuvsError_t cuvsRMMHostFree(void* ptr, size_t)
 __attribute__((visibility("default"))) void cuvsAmdIvfPqLastFilterStats(unsigned long long* out)
 {
   for (int i = 0; i < 4; ++i) out[i] = cuvs_amd::g_pq3_last_stats[i];
+}
+// the same six-fold: + [4] (query, probe) pairs handed back to the LUT scan kernels (queries the filter could not serve),
+// [5] candidates that went through the shared overflow list (their query's pool was full)
+__attribute__((visibility("default"))) void cuvsAmdIvfPqLastFilterStats6(unsigned long long* out)
+{
+  for (int i = 0; i < 6; ++i) out[i] = cuvs_amd::g_pq3_last_stats[i];
 }
 // extension (not in the reference ABI): kernel timing for bench.py
 __attribute__((visibility("default"))) void cuvsAmdProfileEnable(int on) { g_prof_on = on != 0; }

@@ -426,7 +426,10 @@ void train_per_cluster(resources& res, ivf_pq_index& idx, int64_t n_train, const
   for (uint32_t l = 0; l < idx.n_lists; ++l) {
     const int64_t cnt = std::min<int64_t>(h_off[l + 1] - h_off[l], cap_rows);
     const int64_t pq_n_rows = (int64_t)std::min<size_t>(big_enough, (size_t)cnt * idx.pq_dim);
-    if (pq_n_rows < (int64_t)idx.pq_book) continue;  // too few points for a codebook: it stays zero
+    // (the reference trains every non-empty list, however few points it has - ivf_pq_build.cuh:447-449 skips empty lists
+    // only: fewer points than codes leave some codes on top of each other, not the list without a codebook. Rounds 1-4
+    // skipped lists below 2^pq_bits points: found by the reference's own small_dims_per_cluster table, round 5)
+    if (cnt == 0) continue;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk(cnt * idx.dim, 256)), dim3(256), 0, res.stream, trainset,
                        perm.data() + h_off[l], cnt, (int64_t)idx.dim, xb.data());
     pairwise_distance<float, float>(res, xb.data(), cnt, idx.dim, idx.rotation.data(), idx.rot_dim, idx.dim, idx.dim,

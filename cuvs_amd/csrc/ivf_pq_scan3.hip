@@ -873,6 +873,8 @@ struct head_params {
   uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks, pq_len, book;
   int is_ip, per_cluster;
   int hcand;  // capacity of a candidate buffer (head_cand(k))
+  uint32_t one_shot;  // > 0: that many items, ONE per workgroup (item blockIdx.x), no tickets - the two-stream schedule's head launch:
+                      // workgroup slots free up item by item, so the helper stream's kernels get their share of the CUs
   const uint32_t* filter_bits;
   const int64_t* indices;
   unsigned long long* stats;  // optional [8]: workgroup cycles in header / LUT / scores / select / output, items
@@ -902,18 +904,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   static_assert(sizeof(work_item) == 16, "work_item");
 
   const int tid = threadIdx.x;
-  const uint32_t item0   = a.item_begin ? *a.item_begin : 0u;
-  const uint32_t n_items = *a.item_end - item0;
+  const uint32_t item0   = (a.one_shot == 0u && a.item_begin) ? *a.item_begin : 0u;
+  const uint32_t n_items = a.one_shot != 0u ? a.one_shot : *a.item_end - item0;
   const uint32_t xcd = blockIdx.x & 7u, chunk = (n_items + 7u) / 8u;
   const uint32_t share0 = min(n_items, xcd * chunk), share_len = min(chunk, n_items - share0);
   const work_item* share = a.items + item0 + share0;
   const uint4* codes16   = reinterpret_cast<const uint4*>(a.codes);
 
-  for (;;) {
+  for (uint32_t round = 0;; ++round) {
     __syncthreads();
     if (tid == 0) {
-      const uint32_t t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
-      cur = t < share_len ? share[t] : work_item{0u, 0u, 0u, 0xffffffffu};
+      if (a.one_shot != 0u) {
+        cur = (round == 0u && blockIdx.x < a.one_shot) ? a.items[blockIdx.x] : work_item{0u, 0u, 0u, 0xffffffffu};
+      } else {
+        const uint32_t t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
+        cur = t < share_len ? share[t] : work_item{0u, 0u, 0u, 0xffffffffu};
+      }
     }
     __syncthreads();
     const work_item item = cur;
@@ -1628,7 +1634,8 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   a.cap_rows = (uint32_t)(((budget - fixed) / 4) & ~size_t(63));
   if (h.max_list_len > 0) a.cap_rows = std::min<uint32_t>(a.cap_rows, (uint32_t)round_up(h.max_list_len, 64));
   const size_t smem   = fixed + (size_t)a.cap_rows * 4;
-  const unsigned grid = pq3_grid(res) * (small ? 2u : 1u);
+  a.one_shot          = h.one_shot;
+  const unsigned grid = h.one_shot != 0u ? h.one_shot : pq3_grid(res) * (small ? 2u : 1u);
   auto go = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     profile_begin(res, "pq_scan_kernel");

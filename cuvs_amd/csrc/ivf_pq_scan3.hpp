@@ -68,6 +68,7 @@ struct pq3_head {
   int is_ip, lut_mode, acc_half;
   const uint32_t* filter_bits;
   unsigned long long* stats;     // optional device [8] (CUVS_AMD_SCAN_DEBUG=2048)
+  uint32_t one_shot = 0;         // > 0: the number of items, one workgroup each (no tickets): the two-stream schedule's head launch
 };
 void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h);
 

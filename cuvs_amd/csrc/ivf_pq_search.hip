@@ -35,7 +35,7 @@
 #include <type_traits>
 
 namespace cuvs_amd {
-extern unsigned long long g_pq3_last_stats[4];  // core.hip: cuvsAmdIvfPqLastFilterStats
+extern unsigned long long g_pq3_last_stats[6];  // core.hip: cuvsAmdIvfPqLastFilterStats
 
 void load_range_as_float(resources& res, const void* data, elem_t et, bool is_host, int64_t dim, int64_t r0,
                          int64_t cnt, float* out);
@@ -164,6 +164,7 @@ enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QU
                  ST_ALIVE3, ST_CAND, ST_ITEMS, ST_F_LOAD, ST_F_GATHER, ST_F_FLUSH, ST_COUNT };
 
 struct scan_args {
+  uint32_t one_shot = 0;         // head launch of the two-stream schedule: the item count, one workgroup per item (pq3_head::one_shot)
   const work_item* items;
   const uint32_t* item_begin;    // device scalars: this launch walks items [*item_begin, *item_end)
   const uint32_t* item_end;      //   (item_begin == nullptr: from 0)
@@ -2158,10 +2159,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<float4> pair_norms(res, overlap ? (size_t)n_pairs_max : 0);
   resources aux = res;
   if (overlap) {
-    if (res.aux_stream == nullptr) {  // the helper stream and its events live with the handle
-      HIP_TRY(hipStreamCreateWithFlags(&res.aux_stream, hipStreamNonBlocking));
-      for (auto& ev : res.aux_events) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
+    ensure_aux_stream(res);
     aux.aux_stream = res.aux_stream;
     aux.stream     = res.aux_stream;
   }
@@ -2292,6 +2290,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       h.sorted_pairs = sa.sorted_pairs; h.rot_queries = sa.rot_queries; h.cand_d = sa.out_d; h.cand_i = sa.out_i;
       h.query_kth = sa.query_kth; h.n_probes = n_probes; h.k = (uint32_t)k; h.max_list_len = max_list_len; h.is_ip = sa.is_ip;
       h.lut_mode = lut_mode; h.acc_half = acc_half ? 1 : 0; h.filter_bits = filter_bits;
+      h.one_shot = sa.one_shot;
       dev_buf<unsigned long long> hst(res, (sa.dbg & 2048) ? 8 : 0);
       if (sa.dbg & 2048) HIP_TRY(hipMemsetAsync(hst.data(), 0, hst.bytes(), res.stream));
       h.stats = hst.data();
@@ -2309,6 +2308,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       if (overlap) {  // head phase straight from the probes (one single-pair item per query), no grouping in its way
         scan_args ah = a;
         ah.items = hitems.data(); ah.sorted_pairs = hpairs.data(); ah.item_end = hpairs.data() + bs_alloc;
+        ah.one_shot = (uint32_t)nq;  // one workgroup per item: slots free up item by item, the helper stream's kernels fit in between
         launch1(ah);
       } else if (head1) launch1(a); else launch(a);  // head phase: the nearest probes, cold bounds
       // list-sharded index with a communicator: every rank continues with the bound of the query's globally nearest
@@ -2357,6 +2357,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
                   (double)hs[4] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[7]),
                   (double)hs[6] / std::max<unsigned long long>(1, hs[7]), (double)hs[5] / std::max<unsigned long long>(1, hs[2]));
           auto hc = to_host(res, r.counters, 2);
+          g_pq3_last_stats[4] = hc[0]; g_pq3_last_stats[5] = hc[1];
           fprintf(stderr, "[pq_scan3] overflow entries %u\n", hc[1]);
           hc[1] = hc[0];
           fprintf(stderr, "[pq_scan3] pairs screened %llu, survivors %llu (%.4f%%), subtiles %llu (slow path %llu), fallback pairs %u\n",

@@ -49,6 +49,9 @@ CUVS_EXPORT cuvsError_t cuvsAmdCagraOptimize(cuvsResources_t res, DLManagedTenso
 CUVS_EXPORT void cuvsAmdProfileEnable(int on);
 CUVS_EXPORT int cuvsAmdProfileCollect(const char* name, double* total_ms);
 CUVS_EXPORT void cuvsAmdIvfPqLastFilterStats(unsigned long long out[4]);
+/* the same + out[4] = (query, probe) pairs handed back to the LUT scan kernels, out[5] = candidates that went through the
+ * shared overflow list */
+CUVS_EXPORT void cuvsAmdIvfPqLastFilterStats6(unsigned long long out[6]);
 
 #ifdef __cplusplus
 }
