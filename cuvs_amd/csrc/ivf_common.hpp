@@ -164,15 +164,124 @@ inline size_t largest_lists_total(const std::vector<uint32_t>& sizes, uint32_t n
   return t;
 }
 
+// ------------------------------------------------------------------ (query, probe) pairs grouped by label, no radix sort
+// group_by_label (kmeans_balanced.hip) sorts with hipcub's one-sweep radix sort, whose workgroups wait for their predecessors'
+// prefixes (decoupled look-back): next to a long kernel of another stream those workgroups trickle in one by one and the ones
+// already resident spin - 0.87 ms for a 0.07 ms sort in the two-stream schedule of the IVF-PQ batch (profiles/r05_*). This
+// grouping has no dependency between workgroups: histogram, exclusive scan, scatter by atomic cursor (arbitrary order inside a
+// label), then every label's segment is put into ascending pair order by rank counting - pair ids are unique, so the result is
+// the stable order of the radix sort, bit for bit, whatever the atomics did.
+constexpr int kSegCap = 2048;  // pairs of a label sorted from one wave's LDS region; longer segments: sort_big_segments_kernel
+
+__global__ void pair_histogram_kernel(const uint32_t* __restrict__ labels, int64_t n, uint32_t* __restrict__ counts)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&counts[labels[i]], 1u);
+}
+__global__ __launch_bounds__(1024) void pair_scan_kernel(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ offsets)
+{
+  __shared__ int smem[17];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < n ? (int)counts[i] : 0;
+    int total;
+    const int excl = block_exclusive_scan(v, smem, &total);
+    if (i < n) offsets[i] = (uint32_t)(carry + excl);
+    __syncthreads();
+    if (threadIdx.x == 0) carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[n] = (uint32_t)carry;
+}
+__global__ void pair_scatter_kernel(const uint32_t* __restrict__ labels, int64_t n, const uint32_t* __restrict__ offsets,
+                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t L = labels[i];
+  out[offsets[L] + atomicAdd(&cursor[L], 1u)] = (uint32_t)i;
+}
+// one wave per label: the segment into LDS, every element to the position of its rank (broadcast reads: all lanes read the
+// same word)
+__global__ __launch_bounds__(256) void sort_segments_kernel(const uint32_t* __restrict__ offsets, uint32_t n_labels,
+                                                            uint32_t* __restrict__ pairs)
+{
+  __shared__ uint32_t seg_all[4][kSegCap];
+  const uint32_t L = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (L >= n_labels) return;  // wave-uniform
+  const int lane   = threadIdx.x & 63;
+  const uint32_t b = offsets[L], n = offsets[L + 1] - b;
+  if (n <= 1u || n > (uint32_t)kSegCap) return;
+  uint32_t* seg = seg_all[threadIdx.x >> 6];
+  for (uint32_t i = lane; i < n; i += 64u) seg[i] = pairs[b + i];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < n; i += 64u) {
+    const uint32_t v = seg[i];
+    uint32_t rank = 0u;
+    for (uint32_t j = 0; j < n; ++j) rank += seg[j] < v ? 1u : 0u;
+    pairs[b + rank] = v;
+  }
+}
+// segments beyond kSegCap (a list probed by thousands of queries of the batch): one 1024-thread workgroup per such label,
+// rank counting over LDS tiles, through a second buffer (the segment is read while ranks are still being computed)
+__global__ __launch_bounds__(1024) void sort_big_segments_kernel(const uint32_t* __restrict__ offsets, uint32_t n_labels,
+                                                                 uint32_t* __restrict__ pairs, uint32_t* __restrict__ tmp)
+{
+  __shared__ uint32_t tile[4096];
+  for (uint32_t L = blockIdx.x; L < n_labels; L += gridDim.x) {
+    const uint32_t b = offsets[L], n = offsets[L + 1] - b;
+    if (n <= (uint32_t)kSegCap) continue;  // workgroup-uniform
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024u) {
+      const uint32_t i = i0 + threadIdx.x;
+      const uint32_t v = i < n ? pairs[b + i] : 0xffffffffu;
+      uint32_t rank = 0u;
+      for (uint32_t t0 = 0; t0 < n; t0 += 4096u) {
+        __syncthreads();
+        for (uint32_t t = threadIdx.x; t < 4096u; t += 1024u) tile[t] = t0 + t < n ? pairs[b + t0 + t] : 0xffffffffu;
+        __syncthreads();
+        const uint32_t m = min(4096u, n - t0);
+        for (uint32_t j = 0; j < m; ++j) rank += tile[j] < v ? 1u : 0u;
+      }
+      if (i < n) tmp[b + rank] = v;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) pairs[b + i] = tmp[b + i];
+    __syncthreads();
+  }
+}
+
+// labels [n] -> sorted_pairs [n] (pair ids ordered by (label, pair id)), pair_off [n_labels + 1]; scratch: cursor
+// [n_labels + 1] (counts, then cursors), tmp [n]. Everything on res.stream, no allocation.
+inline void group_pairs(resources& res, const uint32_t* labels, int64_t n, uint32_t n_labels, uint32_t* sorted_pairs, uint32_t* pair_off,
+                        uint32_t* cursor, uint32_t* tmp)
+{
+  CUVS_EXPECTS(n < (int64_t(1) << 32), "group_pairs: more than 2^32 pairs");
+  HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n_labels * sizeof(uint32_t), res.stream));
+  hipLaunchKernelGGL(pair_histogram_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, labels, n, cursor);
+  hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, res.stream, cursor, (int)n_labels, pair_off);
+  HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n_labels * sizeof(uint32_t), res.stream));
+  hipLaunchKernelGGL(pair_scatter_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, labels, n, pair_off, cursor, sorted_pairs);
+  hipLaunchKernelGGL(sort_segments_kernel, dim3(grid_blocks(n_labels, 4)), dim3(256), 0, res.stream, pair_off, n_labels, sorted_pairs);
+  hipLaunchKernelGGL(sort_big_segments_kernel, dim3(64), dim3(1024), 0, res.stream, pair_off, n_labels, sorted_pairs, tmp);
+  HIP_TRY(hipGetLastError());
+}
+
 // (query, probe) pairs grouped by list and cut into work items of up to `qpb` pairs of ONE list.
 // probes: [n_pairs] list id of pair p (p = query * n_probes + probe rank). Outputs: sorted_pairs[n_pairs],
 // items[<= n_pairs / qpb + n_lists + 1], item_off[n_lists] = number of items (device scalar).
+// group_scratch: optional [n_lists + 1 + n_pairs] words - with it the grouping runs without the radix sort and without
+// allocations (group_pairs above: what the two-stream schedule needs); without it through group_by_label. Same output.
 inline void build_work_items(resources& res, const uint32_t* probes, int64_t n_pairs, uint32_t n_lists, int qpb,
                              uint32_t* sorted_pairs, uint32_t* pair_off, uint32_t* item_off, work_item* items,
-                             int split = -1, int qpb_hi = 0)
+                             int split = -1, int qpb_hi = 0, uint32_t* group_scratch = nullptr)
 {
   if (split < 0) { split = (int)n_lists; qpb_hi = qpb; }
-  group_by_label(res, probes, n_pairs, n_lists, sorted_pairs, pair_off);
+  if (group_scratch != nullptr) group_pairs(res, probes, n_pairs, n_lists, sorted_pairs, pair_off, group_scratch, group_scratch + n_lists + 1);
+  else                          group_by_label(res, probes, n_pairs, n_lists, sorted_pairs, pair_off);
   hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off, (int)n_lists, qpb, item_off,
                      split, qpb_hi);
   hipLaunchKernelGGL(fill_items_kernel, dim3(grid_blocks(n_lists, 256)), dim3(256), 0, res.stream, pair_off,

@@ -2157,6 +2157,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   dev_buf<work_item> hitems(res, overlap ? (size_t)bs_alloc : 0);
   dev_buf<uint32_t> hpairs(res, overlap ? (size_t)bs_alloc + 1 : 0);  // + the item count
   dev_buf<float4> pair_norms(res, overlap ? (size_t)n_pairs_max : 0);
+  dev_buf<uint32_t> group_scratch(res, overlap ? (size_t)n_pairs_max + n_labels + 1 : 0);  // cursors + second buffer of group_pairs
   resources aux = res;
   if (overlap) {
     ensure_aux_stream(res);
@@ -2215,7 +2216,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     const int lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0);
     const bool head1 = use3 && !glut;
     build_work_items(gres, labels, n_pairs, n_labels, head1 ? 1 : qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
-                     items.data(), (int)idx.n_lists, use2 ? 8 : qpb);
+                     items.data(), (int)idx.n_lists, use2 ? 8 : qpb, overlap ? group_scratch.data() : nullptr);
     if (overlap)
       hipLaunchKernelGGL(head_items_kernel, dim3(nblk(nq, 256)), dim3(256), 0, res.stream, probes.data(), nq, n_probes,
                          (uint32_t)idx.shard_world, (uint32_t)idx.shard_rank, idx.list_owner.data(), hitems.data(), hpairs.data(),

@@ -84,9 +84,13 @@ def test_ivf_pq_search_same_with_and_without_the_grouped_coarse_search(monkeypat
         assert torch.equal(i0, i1) and torch.equal(d0, d1)
 
 
-@pytest.mark.parametrize("metric,pq_bits,pq_dim,dim", [("sqeuclidean", 8, 64, 128), ("cosine", 8, 64, 128), ("sqeuclidean", 5, 48, 96),
-                                                      ("sqeuclidean", 8, 32, 128)])
-def test_two_stream_schedule_equals_one_stream(metric, pq_bits, pq_dim, dim, monkeypatch):
+@pytest.mark.parametrize("metric,pq_bits,pq_dim,dim,n_lists,n_probes,nq",
+                         [("sqeuclidean", 8, 64, 128, 24, 12, 900), ("cosine", 8, 64, 128, 24, 12, 900), ("sqeuclidean", 5, 48, 96, 24, 12, 900),
+                          ("sqeuclidean", 8, 32, 128, 24, 12, 900),
+                          # 4000 queries x 9 probes over 12 lists: ~2700 pairs per list - segments beyond one wave's LDS region in
+                          # the grouping without radix sort (sort_big_segments_kernel)
+                          ("sqeuclidean", 8, 32, 64, 12, 9, 4000)])
+def test_two_stream_schedule_equals_one_stream(metric, pq_bits, pq_dim, dim, n_lists, n_probes, nq, monkeypatch):
     """Round 5: the head kernel runs straight from the probes while grouping, work units and B operands are made on the helper
     stream (ivf_pq_search.hip `overlap`). Same ids and distances as the one-stream schedule (CUVS_AMD_PQ_OVERLAP=0) and as the
     oracle - on the FIRST search of an index too (the derived tables are built before the fork), over several batches
@@ -97,21 +101,21 @@ def test_two_stream_schedule_equals_one_stream(metric, pq_bits, pq_dim, dim, mon
 
     rng = np.random.default_rng(31)
     x = (rng.random((40000, dim), dtype=np.float32) * 1.9 + 0.1)
-    q = (rng.random((900, dim), dtype=np.float32) * 1.9 + 0.1)
+    q = (rng.random((nq, dim), dtype=np.float32) * 1.9 + 0.1)
     xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
     r0 = cuvs_amd.common.Resources()
     monkeypatch.setenv("CUVS_AMD_PQ_OVERLAP", "0")
     r1 = cuvs_amd.common.Resources()
     monkeypatch.delenv("CUVS_AMD_PQ_OVERLAP")
-    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=24, pq_dim=pq_dim, pq_bits=pq_bits, kmeans_n_iters=8, metric=metric), xt, resources=r0)
+    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=n_lists, pq_dim=pq_dim, pq_bits=pq_bits, kmeans_n_iters=8, metric=metric), xt, resources=r0)
     r0.sync()
     for mib in (4096, 300):
-        sp = ivf_pq.SearchParams(n_probes=12, max_internal_batch_size=mib, lut_dtype=np.float16)
+        sp = ivf_pq.SearchParams(n_probes=n_probes, max_internal_batch_size=mib, lut_dtype=np.float16)
         d0, i0 = ivf_pq.search(sp, index, qt, 10, resources=r0)   # (first call: derived tables built inside this search)
         d1, i1 = ivf_pq.search(sp, index, qt, 10, resources=r1)
         d2, i2 = ivf_pq.search(sp, index, qt, 10, resources=r0)
         r0.sync(); r1.sync()
         assert torch.equal(i0, i1) and torch.equal(d0, d1)
         assert torch.equal(i0, i2) and torch.equal(d0, d2)
-    od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, 10, 12, metric=metric, lut="f16")
+    od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, 10, n_probes, metric=metric, lut="f16")
     assert (i0.cpu().numpy() == oi).all() and (d0.cpu().numpy() == od).all()
