@@ -273,8 +273,8 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     dev_buf<float> buf_v(res, (size_t)m_tile * (k + kBfCap)), cur_v(res, (size_t)m_tile * k);
     dev_buf<int64_t> buf_i(res, (size_t)m_tile * (k + kBfCap)), cur_i(res, (size_t)m_tile * k);
     const size_t n_row_tiles = redo.size();
-    dev_buf<int> ovf(res, n_row_tiles);  // one flag per row tile, read back once at the end
-    HIP_TRY(hipMemsetAsync(ovf.data(), 0, ovf.bytes(), res.stream));
+    dev_buf<int> ovf2(res, n_row_tiles);  // one flag per row tile, read back once at the end (NOT the guard word of the fused path)
+    HIP_TRY(hipMemsetAsync(ovf2.data(), 0, ovf2.bytes(), res.stream));
     ensure_aux_stream(res);  // the helper stream and its events live with the handle
     hipStream_t sb = res.aux_stream;
     hipEvent_t* eg = res.aux_events;
@@ -286,7 +286,7 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     HIP_TRY(hipStreamWaitEvent(sb, e0, 0));
     for (int64_t r0 = 0; r0 < m; r0 += m_tile) {
       const int64_t mr = std::min(m_tile, m - r0);
-      int* ovf_r       = ovf.data() + r0 / m_tile;
+      int* ovf_r       = ovf2.data() + r0 / m_tile;
       for (int64_t ct = 0; ct < n_ct2; ++ct) {
         const int b      = (int)(ct & 1);
         const int64_t c0 = ct * nt2, nc = std::min(nt2, n - c0);
@@ -326,14 +326,11 @@ void bf_search_typed(resources& res, const bf_index& idx, const T* queries, int6
     // a row with more than kBfCap better elements in one tile (columns arriving in improving order) had its candidates
     // cut: such row tiles are redone by the per-tile select path below. One host round trip per search, only to read
     // the flags - the common case leaves the results where they are.
-    if (guarded) {
-      for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = 1;
-    } else {
-      std::vector<int> h_ovf(n_row_tiles, 0);
-      HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf.data(), n_row_tiles * sizeof(int), hipMemcpyDeviceToHost, res.stream));
-      HIP_TRY(hipStreamSynchronize(res.stream));
-      for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
-    }
+    // (`guarded` implies the fused path: this one always reads its flags back)
+    std::vector<int> h_ovf(n_row_tiles, 0);
+    HIP_TRY(hipMemcpyAsync(h_ovf.data(), ovf2.data(), n_row_tiles * sizeof(int), hipMemcpyDeviceToHost, res.stream));
+    HIP_TRY(hipStreamSynchronize(res.stream));
+    for (size_t t = 0; t < n_row_tiles; ++t) redo[t] = h_ovf[t] != 0;
   }
   bool any_redo = false;
   for (char c : redo) any_redo = any_redo || c;

@@ -24,23 +24,23 @@ __global__ __launch_bounds__(1024) void count_items_kernel(const uint32_t* __res
                                                            int qpb_lo, uint32_t* __restrict__ item_off, int split,
                                                            int qpb_hi)
 {
+  // (a thread takes a run of consecutive labels, one block scan of the run totals: see pair_scan_kernel)
   __shared__ int smem[17];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n_lists; base += 1024) {
-    int i = base + threadIdx.x;
-    int v = 0;
+  const int per = (n_lists + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(n_lists, b + per);
+  auto items_of = [&](int i) {
     const int qpb = i < split ? qpb_lo : qpb_hi;
-    if (i < n_lists) v = ((int)(pair_off[i + 1] - pair_off[i]) + qpb - 1) / qpb;
-    int total;
-    int excl = block_exclusive_scan(v, smem, &total);
-    if (i < n_lists) item_off[i] = (uint32_t)(carry + excl);
-    __syncthreads();
-    if (threadIdx.x == 0) carry += total;
-    __syncthreads();
+    return ((int)(pair_off[i + 1] - pair_off[i]) + qpb - 1) / qpb;
+  };
+  int s = 0;
+  for (int i = b; i < e; ++i) s += items_of(i);
+  int total;
+  int run = block_exclusive_scan(s, smem, &total);
+  for (int i = b; i < e; ++i) {
+    item_off[i] = (uint32_t)run;
+    run += items_of(i);
   }
-  if (threadIdx.x == 0) item_off[n_lists] = (uint32_t)carry;
+  if (threadIdx.x == 0) item_off[n_lists] = (uint32_t)total;
 }
 
 __global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const uint32_t* __restrict__ item_off,
@@ -178,23 +178,23 @@ __global__ void pair_histogram_kernel(const uint32_t* __restrict__ labels, int64
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) atomicAdd(&counts[labels[i]], 1u);
 }
+// exclusive scan by ONE workgroup: a thread takes a run of consecutive elements (its own running sum), one block scan of the
+// 1024 run totals - two passes over the array instead of n / 1024 block scans with three barriers each
 __global__ __launch_bounds__(1024) void pair_scan_kernel(const uint32_t* __restrict__ counts, int n, uint32_t* __restrict__ offsets)
 {
   __shared__ int smem[17];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < n ? (int)counts[i] : 0;
-    int total;
-    const int excl = block_exclusive_scan(v, smem, &total);
-    if (i < n) offsets[i] = (uint32_t)(carry + excl);
-    __syncthreads();
-    if (threadIdx.x == 0) carry += total;
-    __syncthreads();
+  const int per = (n + 1023) / 1024;
+  const int b = threadIdx.x * per, e = min(n, b + per);
+  int s = 0;
+  for (int i = b; i < e; ++i) s += (int)counts[i];
+  int total;
+  int run = block_exclusive_scan(s, smem, &total);
+  for (int i = b; i < e; ++i) {
+    const int c = (int)counts[i];
+    offsets[i] = (uint32_t)run;
+    run += c;
   }
-  if (threadIdx.x == 0) offsets[n] = (uint32_t)carry;
+  if (threadIdx.x == 0) offsets[n] = (uint32_t)total;
 }
 __global__ void pair_scatter_kernel(const uint32_t* __restrict__ labels, int64_t n, const uint32_t* __restrict__ offsets,
                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ out)
@@ -232,24 +232,39 @@ __global__ __launch_bounds__(1024) void sort_big_segments_kernel(const uint32_t*
                                                                  uint32_t* __restrict__ pairs, uint32_t* __restrict__ tmp)
 {
   __shared__ uint32_t tile[4096];
-  for (uint32_t L = blockIdx.x; L < n_labels; L += gridDim.x) {
-    const uint32_t b = offsets[L], n = offsets[L + 1] - b;
-    if (n <= (uint32_t)kSegCap) continue;  // workgroup-uniform
-    for (uint32_t i0 = 0; i0 < n; i0 += 1024u) {
-      const uint32_t i = i0 + threadIdx.x;
-      const uint32_t v = i < n ? pairs[b + i] : 0xffffffffu;
-      uint32_t rank = 0u;
-      for (uint32_t t0 = 0; t0 < n; t0 += 4096u) {
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < 4096u; t += 1024u) tile[t] = t0 + t < n ? pairs[b + t0 + t] : 0xffffffffu;
-        __syncthreads();
-        const uint32_t m = min(4096u, n - t0);
-        for (uint32_t j = 0; j < m; ++j) rank += tile[j] < v ? 1u : 0u;
-      }
-      if (i < n) tmp[b + rank] = v;
-    }
+  __shared__ uint32_t big[1024];
+  __shared__ uint32_t n_big;
+  // the workgroup's share of the labels, checked by all threads at once (as a rule there is no long segment at all)
+  const uint32_t per = (n_labels + gridDim.x - 1) / gridDim.x;
+  const uint32_t l0 = blockIdx.x * per, l1 = min(n_labels, l0 + per);
+  for (uint32_t base = l0; base < l1; base += 1024u) {
+    if (threadIdx.x == 0) n_big = 0u;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 1024u) pairs[b + i] = tmp[b + i];
+    const uint32_t Lc = base + threadIdx.x;
+    if (Lc < l1 && offsets[Lc + 1] - offsets[Lc] > (uint32_t)kSegCap) big[atomicAdd(&n_big, 1u)] = Lc;
+    __syncthreads();
+    const uint32_t nb = n_big;
+    for (uint32_t w = 0; w < nb; ++w) {
+      // (the order in which a workgroup takes its long segments does not matter: each is sorted on its own)
+      const uint32_t L = big[w];
+      const uint32_t b = offsets[L], n = offsets[L + 1] - b;
+      for (uint32_t i0 = 0; i0 < n; i0 += 1024u) {
+        const uint32_t i = i0 + threadIdx.x;
+        const uint32_t v = i < n ? pairs[b + i] : 0xffffffffu;
+        uint32_t rank = 0u;
+        for (uint32_t t0 = 0; t0 < n; t0 += 4096u) {
+          __syncthreads();
+          for (uint32_t t = threadIdx.x; t < 4096u; t += 1024u) tile[t] = t0 + t < n ? pairs[b + t0 + t] : 0xffffffffu;
+          __syncthreads();
+          const uint32_t m = min(4096u, n - t0);
+          for (uint32_t j = 0; j < m; ++j) rank += tile[j] < v ? 1u : 0u;
+        }
+        if (i < n) tmp[b + rank] = v;
+      }
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < n; i += 1024u) pairs[b + i] = tmp[b + i];
+      __syncthreads();
+    }
     __syncthreads();
   }
 }

@@ -146,26 +146,25 @@ __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __res
                                                            const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
                                                            uint32_t* __restrict__ unit_off, uint32_t group)
 {
+  // a thread takes a run of consecutive lists, one block scan of the 1024 run totals (two passes instead of n_lists / 1024
+  // block scans with three barriers each)
   __shared__ int smem[17];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < n_lists; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    int v = 0;
-    if (i < n_lists) {
-      const uint32_t np = pair_off[n_lists + i + 1] - pair_off[n_lists + i];  // tail labels: n_lists + list
-      const uint32_t len = list_sizes[i];
-      v = (int)(((np + group - 1u) / group) * ((len + unit_rows - 1u) / unit_rows));  // (empty lists: no units)
-    }
-    int total;
-    const int excl = block_exclusive_scan(v, smem, &total);
-    if (i < n_lists) unit_off[i] = (uint32_t)(carry + excl);
-    __syncthreads();
-    if (threadIdx.x == 0) carry += total;
-    __syncthreads();
+  const uint32_t per = (n_lists + 1023u) / 1024u;
+  const uint32_t b = threadIdx.x * per, e = min(n_lists, b + per);
+  auto units_of = [&](uint32_t i) {
+    const uint32_t np = pair_off[n_lists + i + 1] - pair_off[n_lists + i];  // tail labels: n_lists + list
+    const uint32_t len = list_sizes[i];
+    return (int)(((np + group - 1u) / group) * ((len + unit_rows - 1u) / unit_rows));  // (empty lists: no units)
+  };
+  int s = 0;
+  for (uint32_t i = b; i < e; ++i) s += units_of(i);
+  int total;
+  int run = block_exclusive_scan(s, smem, &total);
+  for (uint32_t i = b; i < e; ++i) {
+    unit_off[i] = (uint32_t)run;
+    run += units_of(i);
   }
-  if (threadIdx.x == 0) unit_off[n_lists] = (uint32_t)carry;
+  if (threadIdx.x == 0) unit_off[n_lists] = (uint32_t)total;
 }
 
 __global__ void fill_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,

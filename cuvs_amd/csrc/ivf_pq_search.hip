@@ -2091,6 +2091,10 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     // keep the coarse distance matrix and the candidate buffers inside the workspace budget
     int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k_scan * 8 + (int64_t)idx.rot_dim * 4 + idx.dim * 4;
     if (large_k) per_q += (int64_t)largest_total * 8;
+    // the matrix-core tail phase's buffers, per (query, probe) pair: fp16 B operand, threshold, probe ranks of the pool, >= 16
+    // survivor entries, a fallback work item, two unit descriptors' share, norms and grouping scratch of the two-stream schedule
+    if (!large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0)
+      per_q += (int64_t)n_probes * ((int64_t)idx.rot_dim * 2 + (int64_t)k * 4 + 128 + 16 + 4 + 16 + 8);
     int64_t fit   = std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q);
     max_batch     = std::min(max_batch, fit);
   }
