@@ -44,66 +44,76 @@ struct bprep_params {
   float4* norms; // PART 1 / pq_thr_kernel: [tail pair] (|r|^2, |c|^2, q.c, largest scaled operand)
 };
 
-// one wave per 32 consecutive tail pairs, lane = (pair ql, K half h) - the B-operand layout of v_mfma_f32_32x32x16_f16.
+// One wave per 32 consecutive tail pairs, LPP lanes per pair - lane slot = (K step st, K half h) = one 16-byte piece of the
+// pair's B operand in the layout of v_mfma_f32_32x32x16_f16 - so a pair's 2 NST pieces leave the wave as one contiguous run
+// (round 4: lane = (pair, K half), every store instruction wrote 32-byte pieces 256 bytes apart and every load pulled 16-byte
+// pieces of 64 different rows: 0.20 ms for a 325 MB stream) and its rotated query / list centre are read as whole rows.
 // K step st = c * pq_len + t of the filter holds, in K half h, the 8 rotated dimensions from pq_len (16 c + 8 h) + 8 t on:
-// the components of the subspaces whose code bytes are the h-th 8 bytes of the row's 16-byte code chunk c, in order
+// the components of the subspaces whose code bytes are the h-th 8 bytes of the row's 16-byte code chunk c, in order.
 // PART 0: B operands and thresholds (the head phase's bounds are known). PART 1: B operands and the norms the thresholds
 // need - this part does not depend on the head phase and runs next to it on a helper stream; pq_thr_kernel finishes.
 template <int NST, int PART>
 __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
 {
+  constexpr uint32_t LPP = 2 * NST <= 2 ? 2u : 2 * NST <= 4 ? 4u : 2 * NST <= 8 ? 8u : 2 * NST <= 16 ? 16u : 32u;  // lanes per pair
+  constexpr uint32_t PPW = 64u / LPP;                                                                            // pairs per pass
   const uint32_t s_base = a.pair_off[a.n_lists], s_end = a.pair_off[2 * a.n_lists];
-  const uint32_t lane = threadIdx.x & 63u, ql = lane & 31u, h = lane >> 5;
+  const uint32_t lane = threadIdx.x & 63u, slot = lane % LPP, st = slot >> 1, h = slot & 1u;
   const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 32u;
   if (s_base + w0 >= s_end) return;  // wave-uniform
-  const uint32_t s  = s_base + w0 + ql;
-  const bool valid  = s < s_end;
-  const uint32_t p  = a.sorted_pairs[valid ? s : s_end - 1u];
-  const uint32_t q  = p / a.n_probes, L = a.probes[p];
-  const float* rq   = a.rot_queries + (size_t)q * a.rot_dim;
-  const float* ct   = a.centers_rot + (size_t)L * a.rot_dim;
-  uint4* out        = a.bq + ((size_t)(s - s_base) * NST * 2 + h);
-  float rn = 0.f, big = 0.f, qc = 0.f, cn = 0.f;
+  const uint32_t d0 = ((16u * (st >> a.lpl) + 8u * h) << a.lpl) + 8u * (st & ((1u << a.lpl) - 1u));
+#pragma unroll 2
+  for (uint32_t pass = 0; pass < 32u / PPW; ++pass) {
+    const uint32_t s  = s_base + w0 + pass * PPW + lane / LPP;
+    const bool pair_ok = s < s_end;
+    const bool valid  = pair_ok && slot < 2u * NST;
+    const uint32_t p  = a.sorted_pairs[pair_ok ? s : s_end - 1u];
+    const uint32_t q  = p / a.n_probes, L = a.probes[p];
+    float rn = 0.f, big = 0.f, qc = 0.f, cn = 0.f;
+    if (valid) {
+      const float* rq = a.rot_queries + (size_t)q * a.rot_dim + d0;
+      const float* ct = a.centers_rot + (size_t)L * a.rot_dim + d0;
+      const float4 q0 = *reinterpret_cast<const float4*>(rq), q1 = *reinterpret_cast<const float4*>(rq + 4);
+      float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      const float4 c0 = *reinterpret_cast<const float4*>(ct), c1 = *reinterpret_cast<const float4*>(ct + 4);
+      const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      if (!a.is_ip) {
 #pragma unroll
-  for (int st = 0; st < NST; ++st) {
-    const uint32_t d0 = ((16u * ((uint32_t)st >> a.lpl) + 8u * h) << a.lpl) + 8u * ((uint32_t)st & ((1u << a.lpl) - 1u));
-    const float4 q0 = *reinterpret_cast<const float4*>(rq + d0), q1 = *reinterpret_cast<const float4*>(rq + d0 + 4);
-    float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-    const float4 c0 = *reinterpret_cast<const float4*>(ct + d0), c1 = *reinterpret_cast<const float4*>(ct + d0 + 4);
-    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    if (!a.is_ip) {
+        for (int e = 0; e < 8; ++e) r[e] -= c[e];
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) r[e] -= c[e];
+        for (int e = 0; e < 8; ++e) { qc = __fmaf_rn(r[e], c[e], qc); cn = __fmaf_rn(c[e], c[e], cn); }
+      }
+      f16x8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        rn   = __fmaf_rn(r[e], r[e], rn);
+        const float x = a.sc * r[e];
+        big  = fmaxf(big, fabsf(x));
+        v[e] = (_Float16)fminf(fmaxf(x, -60000.f), 60000.f);  // (finite whatever happens: unserved queries may still be screened)
+      }
+      a.bq[(size_t)(s - s_base) * NST * 2 + slot] = __builtin_bit_cast(uint4, v);
+    }
+    // the pair's norms: sums / maximum over its LPP lanes (idle lanes hold zeros)
+#pragma unroll
+    for (uint32_t o = 1; o < LPP; o <<= 1) {
+      rn += __shfl_xor(rn, o); qc += __shfl_xor(qc, o); cn += __shfl_xor(cn, o);
+      big = fmaxf(big, __shfl_xor(big, o));
+    }
+    if (!pair_ok || slot != 0u) continue;
+    if constexpr (PART == 1) {
+      a.norms[s - s_base] = make_float4(rn, cn, qc, big);
     } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { qc = __fmaf_rn(r[e], c[e], qc); cn = __fmaf_rn(c[e], c[e], cn); }
+      const uint32_t kk = a.query_kth[q];
+      const float bound = key_to_float(kk);
+      // no finite bound yet, an operand beyond the fp16 range or a bound the LUT type cannot represent: nothing of this query
+      // survives here, it is handed back to the LUT scan (IVF-Flat: everything survives, all its rows are re-scored)
+      const bool served = kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max;
+      if (!a.flat && !served) a.qflag[q] = 1u;
+      const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
+      a.thr[s - s_base] = served ? t / a.c1 : (a.flat ? -INFINITY : INFINITY);
     }
-    f16x8_t v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      rn   = __fmaf_rn(r[e], r[e], rn);
-      const float x = a.sc * r[e];
-      big  = fmaxf(big, fabsf(x));
-      v[e] = (_Float16)fminf(fmaxf(x, -60000.f), 60000.f);  // (finite whatever happens: unserved queries may still be screened)
-    }
-    if (valid) out[st * 2] = __builtin_bit_cast(uint4, v);
   }
-  rn  += __shfl_xor(rn, 32);
-  qc  += __shfl_xor(qc, 32);
-  cn  += __shfl_xor(cn, 32);
-  big  = fmaxf(big, __shfl_xor(big, 32));
-  if constexpr (PART == 1) {
-    if (valid && h == 0u) a.norms[s - s_base] = make_float4(rn, cn, qc, big);
-    return;
-  }
-  const uint32_t kk = a.query_kth[q];
-  const float bound = key_to_float(kk);
-  // no finite bound yet, an operand beyond the fp16 range or a bound the LUT type cannot represent: nothing of this query
-  // survives here, it is handed back to the LUT scan (IVF-Flat: everything survives, all its rows are re-scored)
-  const bool served = kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max;
-  if (!a.flat && valid && !served && h == 0u) a.qflag[q] = 1u;
-  const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
-  if (valid && h == 0u) a.thr[s - s_base] = served ? t / a.c1 : (a.flat ? -INFINITY : INFINITY);
 }
 
 // the second half of the pre-pass (two-stream schedule): thresholds of the tail pairs from the head phase's bounds
