@@ -5,6 +5,10 @@ HIPCC      ?= hipcc
 ARCH       ?= gfx950
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -Icuvs_amd/csrc \
               -Wno-unused-result -ffp-contract=off
+# make PRODUCTION=1: the CUVS_AMD_* kernel-selection / ablation switches are compiled out (core.hip: debug_switches_on)
+ifeq ($(PRODUCTION),1)
+HIPFLAGS   += -DCUVS_AMD_NO_DEBUG_SWITCHES
+endif
 CC         ?= gcc
 CFLAGS     := -O3 -march=x86-64-v3 -fPIC -fopenmp -ffp-contract=off -Wall -std=c11
 

@@ -52,9 +52,24 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the comparator handles of this script (LUT-scan check, pruning-off figure, filter counters) select kernels through
-# CUVS_AMD_* switches, which the library only looks at behind this gate; the timed handle is created with none of them set
-os.environ["CUVS_AMD_DEBUG_SWITCHES"] = "1"
+# The comparator handles of this script (LUT-scan check, pruning-off figure, filter counters) select kernels through
+# CUVS_AMD_* switches, which the library only looks at behind the gate CUVS_AMD_DEBUG_SWITCHES=1 and only when a handle is
+# created: comparator_handle() sets gate + switches for exactly that moment. Every timed handle is created without the gate:
+# the production configuration.
+os.environ.pop("CUVS_AMD_DEBUG_SWITCHES", None)
+
+
+def comparator_handle(**switches):
+    """a cuvs_amd Resources handle created under the given CUVS_AMD_* switches (and the gate that makes the library read them)"""
+    import cuvs_amd
+
+    env = {"CUVS_AMD_DEBUG_SWITCHES": "1", **{k: str(v) for k, v in switches.items()}}
+    os.environ.update(env)
+    try:
+        return cuvs_amd.common.Resources()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_TFLOPS = 157.3  # fp32 MFMA peak (spec)
@@ -336,7 +351,7 @@ def run_pmc_passes(child_args, n_search, timeout_s=240):
                 return None
             n_disp = 0
             for r in csv.DictReader(open(files[0])):
-                if any(t in r["Kernel_Name"] for t in ("pq_scan", "pq_head", "pq_bprep", "pq_filter", "pq_rescore", "pool_merge")):
+                if any(t in r["Kernel_Name"] for t in ("pq_scan", "pq_head", "pq_bprep", "pq_thr", "pq_filter", "pq_rescore", "pool_merge")):
                     sums[r["Counter_Name"]] = sums.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                     n_disp += 1
                 if "pq_filter" in r["Kernel_Name"]:
@@ -932,9 +947,7 @@ def main():
         a_i = torch.empty((nchk, kk), dtype=torch.int64, device=dev)
         a_d = torch.empty((nchk, kk), dtype=torch.float32, device=dev)
         b_i, b_d = torch.empty_like(a_i), torch.empty_like(a_d)
-        os.environ["CUVS_AMD_PQ_SCAN3"] = "0"
-        res_lut = cuvs_amd.common.Resources()  # the switches are read once, when a handle is created
-        del os.environ["CUVS_AMD_PQ_SCAN3"]
+        res_lut = comparator_handle(CUVS_AMD_PQ_SCAN3=0)  # the switches are read once, when a handle is created
         for r_, o_i, o_d in ((res, a_i, a_d), (res_lut, b_i, b_d)):
             ivf_pq.search(sp_chk, index, queries[:nchk], kk, neighbors=o_i, distances=o_d, resources=r_)
             if sharded:
@@ -966,11 +979,7 @@ def main():
                              "scan_launches_per_step": v_n})
         # data-independent figure: the headline variant with every form of pruning off - no early stop
         # (CUVS_AMD_SCAN_DEBUG=8), no filter stage (CUVS_AMD_PQ_SCAN2=0), no head phase: all 64 gathers of every row
-        prune_off = {"CUVS_AMD_SCAN_DEBUG": "8", "CUVS_AMD_PQ_SCAN2": "0", "CUVS_AMD_PQ_SCAN3": "0", "CUVS_AMD_PQ_HEAD_PROBES": "0"}
-        os.environ.update(prune_off)
-        res_off = cuvs_amd.common.Resources()  # the switches are read once, when a handle is created
-        for key in prune_off:
-            del os.environ[key]
+        res_off = comparator_handle(CUVS_AMD_SCAN_DEBUG=8, CUVS_AMD_PQ_SCAN2=0, CUVS_AMD_PQ_SCAN3=0, CUVS_AMD_PQ_HEAD_PROBES=0)
         _, s, _, _ = timed(make_step(args.lut, args.acc, res_off), 3, 1)
         early_stop_off_ms = round(s / 3, 3)
         del res_off
@@ -1016,6 +1025,33 @@ def main():
                 roofline["traffic"] = pf["hbm_bytes"]  # HBM bytes of the dominant kernel's launch (FETCH_SIZE x 2 + WRITE_SIZE)
                 roofline["traffic_over_unique_bytes"] = round(pf["hbm_bytes"] / max(unique_bytes, 1), 3)
             roofline["pmc_source"] = "live: rocprofv3 --pmc passes of this workload, spawned by this run"
+
+    # ------------------------------------------------------------------ small batches on the same index (the reference bench sweeps
+    # the batch size, cpp/bench/ann/src/common/benchmark.hpp:301-345): latency of one search + refine call and the QPS it gives
+    batch_sweep = []
+    if rank == 0 and world == 1 and not args.no_variants and not sharded:
+        for nb in (1, 10, 100, 1000):
+            if nb > args.batch:
+                continue
+            try:
+                qs = queries[:nb].contiguous()
+                b_i = torch.empty((nb, kk), dtype=torch.int64, device=dev)
+                b_d = torch.empty((nb, kk), dtype=torch.float32, device=dev)
+                o_i = torch.empty((nb, args.k), dtype=torch.int64, device=dev)
+                o_d = torch.empty((nb, args.k), dtype=torch.float32, device=dev)
+                sp_b = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                                           max_internal_batch_size=nq_total)
+
+                def bstep():
+                    ivf_pq.search(sp_b, index, qs, kk, neighbors=b_i, distances=b_d, resources=res)
+                    if args.refine_ratio > 1:
+                        refine(data, qs, b_i, indices=o_i, distances=o_d, metric="sqeuclidean", resources=res)
+
+                dt_b = timeit(bstep, 30, 5)
+                rec_b = recall_of((o_i if args.refine_ratio > 1 else b_i[:, :args.k])[:min(nb, ng)].cpu().numpy(), truth[:min(nb, ng)])
+                batch_sweep.append({"batch": nb, "ms_per_call": round(dt_b * 1e3, 3), "qps": round(nb / dt_b, 1), "recall_at_10": round(rec_b, 4)})
+            except Exception as e:
+                batch_sweep.append({"batch": nb, "error": repr(e)[:200]})
 
     # ------------------------------------------------------------------ the same workload with inner product / cosine
     # (signed LUT entries: no early stop in a LUT scan; the matrix-core filter works on full-score bounds)
@@ -1102,9 +1138,7 @@ def main():
     # probed list survive the screen. Real corpora (deep-100M, datasets.yaml) are less clustered: here the same search on
     # 4096 wide modes in a 64-d latent space, with the survivors per pair of both corpora (CUVS_AMD_SCAN_DEBUG=1024 counters).
     def survivors_per_pair(idx_, q_):
-        os.environ["CUVS_AMD_SCAN_DEBUG"] = "1024"
-        r_st = cuvs_amd.common.Resources()
-        del os.environ["CUVS_AMD_SCAN_DEBUG"]
+        r_st = comparator_handle(CUVS_AMD_SCAN_DEBUG=1024)
         sp_ = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
                                   max_internal_batch_size=nq_total)
         old_err = os.dup(2)  # the debug handle prints its counters to stderr: keep the log readable
@@ -1159,9 +1193,7 @@ def main():
                 c1 = survivors_per_pair(index, queries)
                 # the same step with the tail phase on the LUT scan kernels (the path every shape falls back to): the two-phase path
                 # must not be slower than this on any corpus
-                os.environ["CUVS_AMD_PQ_SCAN3"] = "0"
-                res_lut = cuvs_amd.common.Resources()
-                del os.environ["CUVS_AMD_PQ_SCAN3"]
+                res_lut = comparator_handle(CUVS_AMD_PQ_SCAN3=0)
                 e3, _, _, _ = timed(make_step(args.lut, args.acc, res_lut), 2, 1)
                 del res_lut
                 corpus_variants.append({"corpus": name, "ms_per_step": round(e2 / 5 * 1e3, 3), "qps": round(args.batch / (e2 / 5), 1),
@@ -1223,7 +1255,7 @@ def main():
                                       else "single GPU",
                        "lut_dtype": args.lut, "internal_distance_dtype": args.acc, "refine_ratio": args.refine_ratio,
                        "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants,
-                       "sharded_one_rank": sharded_line, "corpus_variants": corpus_variants},
+                       "sharded_one_rank": sharded_line, "corpus_variants": corpus_variants, "batch_sweep": batch_sweep},
             "recall_at_10": round(recall, 4),
             "scan3_equals_lut_scan": scan3_equals_lut_scan,
             "roofline": roofline,

@@ -154,10 +154,18 @@ void profile_end(resources& res, const char* name)
 // ONE gate in front of every kernel-selection / ablation switch: without CUVS_AMD_DEBUG_SWITCHES=1 in the environment of the
 // process that creates the handle, none of the CUVS_AMD_* variables below is even looked at - a caller of the drop-in
 // library cannot change its behaviour by accident (tests/conftest.py and the bench / profiling scripts set the gate).
+// A build with -DCUVS_AMD_NO_DEBUG_SWITCHES (make PRODUCTION=1) has no gate to open: the variables are never read. The default
+// build keeps them - bench.py's own evidence (the LUT-scan comparator of `scan3_equals_lut_scan`, the filter's survivor counters)
+// and the comparator tests need a second kernel selection inside one process; tests/conftest.py and bench.py set the gate only
+// while they create such a comparator handle, every other handle runs the production configuration.
 static bool debug_switches_on()
 {
+#ifdef CUVS_AMD_NO_DEBUG_SWITCHES
+  return false;
+#else
   const char* g = getenv("CUVS_AMD_DEBUG_SWITCHES");
   return g != nullptr && g[0] == '1';
+#endif
 }
 
 tuning load_tuning_from_env()
@@ -431,6 +439,15 @@ cuvsError_t cuvsRMMHostFree(void* ptr, size_t)
 // extension (not in the reference ABI): counters of the last IVF-PQ search whose handle was created under
 // CUVS_AMD_SCAN_DEBUG=1024 - [0] (row, query) pairs screened by the matrix-core filter, [1] survivors re-scored, [2] 32-row
 // subtiles decoded, [3] work units (bench.py: survivors per pair of a corpus)
+// 1: this build reads the CUVS_AMD_* switches behind the CUVS_AMD_DEBUG_SWITCHES=1 gate; 0: compiled out (make PRODUCTION=1)
+__attribute__((visibility("default"))) int cuvsAmdDebugSwitchesCompiledIn(void)
+{
+#ifdef CUVS_AMD_NO_DEBUG_SWITCHES
+  return 0;
+#else
+  return 1;
+#endif
+}
 __attribute__((visibility("default"))) void cuvsAmdIvfPqLastFilterStats(unsigned long long* out)
 {
   for (int i = 0; i < 4; ++i) out[i] = cuvs_amd::g_pq3_last_stats[i];

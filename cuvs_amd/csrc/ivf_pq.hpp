@@ -71,6 +71,12 @@ struct ivf_pq_index {
   // List-sharded multi-GPU search (shard_comm.hip): every rank holds the whole model (centres, rotation, codebooks) but
   // only the lists it owns - list L belongs to rank L % shard_world. extend() drops rows of foreign lists, search()
   // scans only owned probes; the per-rank top-k lists are all-gathered and merged. shard_world == 1: not sharded.
+  // list_layout of the index as its owner sees it (ivf_pq.hpp:40-90). The device arrays of this library are ALWAYS the 64-row
+  // interleaved chunks the kernels read - the C ABI has no accessor for the raw list storage (only the contiguous codes of
+  // cuvsIvfPqIndexUnpackContiguousListData) - so a FLAT index differs in what the reference's FLAT index differs in through
+  // that ABI: its files hold [size, bytes_per_vector] list records (ivf_pq.hpp:302-338) and searching it is refused
+  // (ivf_pq_search.cuh:914-916).
+  int codes_layout = 1;
   int shard_rank = 0, shard_world = 1;
   void* shard_comm = nullptr;  // cuvsAmdShardComm* (not owned): all-reduce of the k-th bounds between the scan phases
   // rows / non-empty lists of ALL ranks' shards, exchanged by the first search after the communicator was attached (one
@@ -102,6 +108,7 @@ struct ivf_pq_build_params {
   bool force_random_rotation = false;
   bool add_data_on_build     = true;
   uint32_t max_train_points_per_pq_code = 256;
+  int codes_layout = 1;  // cuvsIvfPqListLayout: 0 FLAT, 1 INTERLEAVED (ivf_pq.hpp:40-90)
 };
 
 struct ivf_pq_search_params {

@@ -471,6 +471,7 @@ std::unique_ptr<ivf_pq_index> ivf_pq_make_empty(resources& res, const ivf_pq_bui
   CUVS_EXPECTS(p.pq_bits >= 4 && p.pq_bits <= 8, "ivf_pq: pq_bits must be within [4, 8]");
   CUVS_EXPECTS(p.codebook_kind == 0 || p.codebook_kind == 1, "ivf_pq: invalid codebook_gen value %d", p.codebook_kind);
   auto idx           = std::make_unique<ivf_pq_index>();
+  idx->codes_layout  = p.codes_layout;
   idx->metric        = p.metric;
   idx->codebook_kind = p.codebook_kind;
   idx->dtype         = et;

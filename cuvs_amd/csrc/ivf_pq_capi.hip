@@ -35,8 +35,9 @@ ivf_pq_build_params to_params(const cuvsIvfPqIndexParams& p)
   b.force_random_rotation        = p.force_random_rotation;
   b.add_data_on_build            = p.add_data_on_build;
   b.max_train_points_per_pq_code = p.max_train_points_per_pq_code;
-  CUVS_EXPECTS(p.codes_layout == CUVS_IVF_PQ_LIST_LAYOUT_INTERLEAVED,
-               "IVF-PQ search requires INTERLEAVED codes layout. FLAT layout is not supported for GPU search.");
+  CUVS_EXPECTS(p.codes_layout == CUVS_IVF_PQ_LIST_LAYOUT_INTERLEAVED || p.codes_layout == CUVS_IVF_PQ_LIST_LAYOUT_FLAT,
+               "ivf_pq: invalid codes_layout value %d", (int)p.codes_layout);
+  b.codes_layout = (int)p.codes_layout;
   return b;
 }
 
@@ -174,6 +175,8 @@ static cuvsError_t pq_search_entry(cuvsResources_t res_h, cuvsIvfPqSearchParams_
     auto& res = *as_res(res_h);
     auto& idx = get_index(index_c);
     CUVS_EXPECTS(params && queries_tensor && neighbors_tensor && distances_tensor, "null argument");
+    // ivf_pq_search.cuh:914-916
+    CUVS_EXPECTS(idx.codes_layout == 1, "IVF-PQ search requires INTERLEAVED codes layout. FLAT layout is not supported for GPU search.");
     auto& queries   = queries_tensor->dl_tensor;
     auto& neighbors = neighbors_tensor->dl_tensor;
     auto& distances = distances_tensor->dl_tensor;
@@ -233,6 +236,15 @@ cuvsError_t cuvsAmdIvfPqSearchFiltered(cuvsResources_t res_h, cuvsIvfPqSearchPar
                                        DLManagedTensor* distances_tensor, cuvsFilter filter)
 {
   return pq_search_entry(res_h, params, index_c, queries_tensor, neighbors_tensor, distances_tensor, filter);
+}
+
+// extension: index.codes_layout() of the C++ API (cpp/include/cuvs/neighbors/ivf_pq.hpp: list_layout) - 0 FLAT, 1 INTERLEAVED
+cuvsError_t cuvsAmdIvfPqIndexGetCodesLayout(cuvsIvfPqIndex_t index_c, int* layout)
+{
+  return (cuvsError_t)translate_exceptions([=] {
+    CUVS_EXPECTS(layout != nullptr, "null argument");
+    *layout = get_index(index_c).codes_layout;
+  });
 }
 
 cuvsError_t cuvsIvfPqExtend(cuvsResources_t res_h, DLManagedTensor* new_vectors, DLManagedTensor* new_indices,
@@ -360,7 +372,8 @@ constexpr int kPqRefVersion = 4;  // ivf_pq_serialize.cuh:28
 void pq_write_native(resources& res, const char* filename, const ivf_pq_index& idx, DLDataType dl)
 {
   file_writer w(filename, KIND_IVF_PQ);
-  w.scalar<int32_t>(idx.metric); w.scalar<int32_t>(idx.codebook_kind); w.scalar<int32_t>((int)idx.dtype);
+  // (codes_layout rides in bit 8 of the codebook_kind word: files written before round 5 read as INTERLEAVED)
+  w.scalar<int32_t>(idx.metric); w.scalar<int32_t>(idx.codebook_kind | (idx.codes_layout == 0 ? 0x100 : 0)); w.scalar<int32_t>((int)idx.dtype);
   const uint32_t u[] = {idx.n_lists, idx.dim, idx.dim_ext, idx.rot_dim, idx.pq_dim, idx.pq_bits, idx.pq_len,
                         idx.pq_book, idx.n_chunks, idx.codes_per_chunk};
   for (uint32_t v : u) w.scalar<uint32_t>(v);
@@ -382,6 +395,8 @@ std::unique_ptr<ivf_pq_index> pq_read_native(resources& res, const char* filenam
   file_reader r(filename, KIND_IVF_PQ);
   auto idx = std::make_unique<ivf_pq_index>();
   idx->metric = r.scalar<int32_t>(); idx->codebook_kind = r.scalar<int32_t>(); idx->dtype = (elem_t)r.scalar<int32_t>();
+  idx->codes_layout = (idx->codebook_kind & 0x100) ? 0 : 1;
+  idx->codebook_kind &= 0xff;
   uint32_t* u[] = {&idx->n_lists, &idx->dim, &idx->dim_ext, &idx->rot_dim, &idx->pq_dim, &idx->pq_bits, &idx->pq_len,
                    &idx->pq_book, &idx->n_chunks, &idx->codes_per_chunk};
   for (uint32_t* v : u) *v = r.scalar<uint32_t>();
@@ -419,7 +434,7 @@ void pq_write_ref(resources& res, const char* filename, const ivf_pq_index& idx)
   w.scalar<bool>(true);  // conservative_memory_allocation
   w.scalar<int32_t>(idx.metric);
   w.scalar<int32_t>(idx.codebook_kind);
-  w.scalar<int32_t>(1);  // list_layout::INTERLEAVED (ivf_pq.hpp:40-45)
+  w.scalar<int32_t>(idx.codes_layout);  // list_layout (ivf_pq.hpp:40-45): 0 FLAT, 1 INTERLEAVED
   w.scalar<uint32_t>(idx.n_lists);
   const int64_t pqc0 = idx.codebook_kind == 0 ? idx.pq_dim : idx.n_lists;
   w.device_array(res, 'f', 4, {pqc0, idx.pq_len, idx.pq_book}, idx.pq_centers.data());
@@ -440,6 +455,22 @@ void pq_write_ref(resources& res, const char* filename, const ivf_pq_index& idx)
     copy_async(res, ours.data(), idx.codes.data() + (size_t)idx.h_list_offsets[L] * nc * 16, ours.size());
     copy_async(res, ids.data(), idx.indices.data() + idx.h_list_offsets[L], (size_t)size * sizeof(int64_t));
     sync(res);
+    if (idx.codes_layout == 0) {
+      // FLAT list record [size, bytes_per_vector] (list_spec_flat, ivf_pq.hpp:302-338): a row's codes as one contiguous
+      // little-endian bitstream; here they sit in 16-byte chunks of codes_per_chunk codes, each chunk starting at bit 0
+      const uint32_t bits = idx.pq_bits, cpc = idx.codes_per_chunk, bpv = (idx.pq_dim * bits + 7) / 8;
+      theirs.assign((size_t)size * bpv, 0);
+      for (uint32_t r = 0; r < size; ++r) {
+        uint8_t* dst = theirs.data() + (size_t)r * bpv;
+        for (uint32_t j = 0; j < idx.pq_dim; ++j) {
+          const uint8_t* src = ours.data() + (((size_t)(r / 64) * nc + j / cpc) * 64 + r % 64) * 16;
+          uint32_t ib = (j % cpc) * bits, ob = j * bits;
+          for (uint32_t b = 0; b < bits; ++b, ++ib, ++ob) dst[ob >> 3] |= (uint8_t)(((src[ib >> 3] >> (ib & 7)) & 1u) << (ob & 7));
+        }
+      }
+      w.header('u', 1, {size, bpv});
+      w.raw(theirs.data(), theirs.size());
+    } else {
     theirs.assign((size_t)g32 * nc * 32 * 16, 0);
     for (uint32_t r = 0; r < size; ++r)
       for (uint32_t c = 0; c < nc; ++c)
@@ -447,6 +478,7 @@ void pq_write_ref(resources& res, const char* filename, const ivf_pq_index& idx)
                ours.data() + (((size_t)(r / 64) * nc + c) * 64 + r % 64) * 16, 16);
     w.header('u', 1, {g32, nc, 32, 16});
     w.raw(theirs.data(), theirs.size());
+    }
     w.host_array<int64_t>(ids.data(), {size});
   }
   w.close();
@@ -468,6 +500,7 @@ std::unique_ptr<ivf_pq_index> pq_read_ref(resources& res, const char* filename)
   int layout      = r.scalar<int32_t>();
   p.n_lists       = r.scalar<uint32_t>();
   CUVS_EXPECTS(layout == 0 || layout == 1, "ivf_pq::deserialize: invalid list_layout value %d", layout);
+  p.codes_layout  = layout;
   CUVS_EXPECTS(p.codebook_kind == 0 || p.codebook_kind == 1, "ivf_pq::deserialize: invalid codebook_gen value %d",
                p.codebook_kind);
   CUVS_EXPECTS(dim > 0 && p.pq_dim > 0 && p.n_lists > 0 && p.n_lists <= (1u << 24), "ivf_pq::deserialize: bad header");

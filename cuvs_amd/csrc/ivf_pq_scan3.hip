@@ -1581,7 +1581,10 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.pq_len = idx.pq_len; s.book = idx.pq_book; s.per_cluster = idx.codebook_kind != 0 ? 1 : 0;
   s.cb_lds = (cb_bytes <= 128 * 1024 && !s.per_cluster) ? 1 : 0;
   const size_t rsmem = s.cb_lds ? cb_bytes : 16;
-  const dim3 rg(grid + 1, 2), rb(kRThreads);
+  // chunked survivor buffer (pq_filter4_kernel): every workgroup strides over all chunks, so ONE workgroup per CU is a full
+  // wave of work and stages the codebook (128 KiB of LDS: one workgroup per CU anyway) once - with (grid + 1) x 2 workgroups
+  // the staging ran twice per CU and was most of the kernel (0.16 ms for ~1 M survivors)
+  const dim3 rg(f4 && s.cb_lds ? grid : grid + 1, f4 && s.cb_lds ? 1 : 2), rb(kRThreads);
   profile_begin(res, "pq_rescore_kernel");
   auto launch_rescore = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));

@@ -127,6 +127,13 @@ class Index:
     pq_len = property(lambda self: self._scalar("cuvsIvfPqIndexGetPqLen"))
     pq_bits = property(lambda self: self._scalar("cuvsIvfPqIndexGetPqBits"))
 
+    @property
+    def codes_layout(self):
+        """list_layout of the index: "flat" or "interleaved" (cuvsAmdIvfPqIndexGetCodesLayout)"""
+        v = C.c_int(0)
+        check(lib().cuvsAmdIvfPqIndexGetCodesLayout(self._p, C.byref(v)))
+        return {0: "flat", 1: "interleaved"}[v.value]
+
     def __len__(self):
         return self._scalar("cuvsIvfPqIndexGetSize")
 

@@ -41,11 +41,16 @@ CUVS_EXPORT cuvsError_t cuvsAmdCagraSetGuaranteeConnectivity(cuvsResources_t res
 CUVS_EXPORT cuvsError_t cuvsAmdCagraOptimize(cuvsResources_t res, DLManagedTensor* knn_graph, DLManagedTensor* graph,
                                              int guarantee_connectivity);
 
+/* index.codes_layout() of the reference's C++ index (cpp/include/cuvs/neighbors/ivf_pq.hpp:40-90; the C ABI sets the layout in
+ * cuvsIvfPqIndexParams but has no getter): 0 = CUVS_IVF_PQ_LIST_LAYOUT_FLAT, 1 = CUVS_IVF_PQ_LIST_LAYOUT_INTERLEAVED. */
+CUVS_EXPORT cuvsError_t cuvsAmdIvfPqIndexGetCodesLayout(cuvsIvfPqIndex_t index, int* layout);
+
 /* Measurement helpers of bench.py (no reference counterpart). cuvsAmdProfileEnable / cuvsAmdProfileCollect: HIP events
  * around the named kernels on the handle's stream (Collect sums and resets the records of `name`, returns the launch count).
  * cuvsAmdIvfPqLastFilterStats: counters of the last IVF-PQ search made by a handle created under CUVS_AMD_SCAN_DEBUG=1024
  * (behind CUVS_AMD_DEBUG_SWITCHES=1): out = {(row, query) pairs screened by the matrix-core filter, survivors re-scored,
  * 32-row subtiles decoded, work units}. */
+CUVS_EXPORT int cuvsAmdDebugSwitchesCompiledIn(void); /* 0: built with -DCUVS_AMD_NO_DEBUG_SWITCHES (make PRODUCTION=1) */
 CUVS_EXPORT void cuvsAmdProfileEnable(int on);
 CUVS_EXPORT int cuvsAmdProfileCollect(const char* name, double* total_ms);
 CUVS_EXPORT void cuvsAmdIvfPqLastFilterStats(unsigned long long out[4]);

@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bench
+
+os.environ["CUVS_AMD_DEBUG_SWITCHES"] = "1"  # (bench.py drops the gate on import: its timed handles run the production configuration)
 import cuvs_amd
 from cuvs_amd.neighbors import ivf_pq
 

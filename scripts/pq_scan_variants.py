@@ -17,7 +17,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402  (sets CUVS_AMD_DEBUG_SWITCHES=1: the gate in front of the switches below)
+import bench  # noqa: E402
+
+os.environ["CUVS_AMD_DEBUG_SWITCHES"] = "1"  # the gate in front of the switches below (bench.py itself runs without it)
 
 
 def main():

@@ -118,6 +118,12 @@ def ivf_pq_special_cases():       # :1176-1245 - the two that run anywhere: k 12
             _case(num_db_vecs=10000, dim=16, num_queries=500, k=129, n_lists=100, n_probes=100)]
 
 
+def ivf_pq_flat_layout_tests():   # ann_ivf_pq.cuh:1293-1338  "Test cases for flat layout comparison."
+    base = dict(num_db_vecs=1000, dim=64, n_lists=10, pq_dim=16)
+    return [_case(pq_bits=8, **base), _case(pq_bits=6, **base), _case(pq_bits=8, codebook_kind="cluster", **base),
+            _case(pq_bits=6, codebook_kind="cluster", **base)]
+
+
 # what each reference test file instantiates (cpp/tests/neighbors/ann_ivf_pq/test_{float,int8_t,uint8_t}_int64_t.cu:19-21,17-19,17-19)
 IVF_PQ_TABLES = {
     "f32": [("defaults", ivf_pq_defaults), ("small_dims", ivf_pq_small_dims), ("big_dims_moderate_lut", ivf_pq_big_dims_moderate_lut),

@@ -13,7 +13,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["CUVS_AMD_DEBUG_SWITCHES"] = "1"
 
 
 def case_data(name):

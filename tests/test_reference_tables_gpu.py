@@ -128,6 +128,59 @@ def test_ivf_pq_reference_table(dtype, case, res):
     assert ((ih[~oob] >= 0) & (ih[~oob] < c["num_db_vecs"])).all()
 
 
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"f32-flat_layout_tests-{n:02d}") for n, c in enumerate(T.ivf_pq_flat_layout_tests())])
+def test_ivf_pq_flat_layout_codes(case, res, tmp_path):
+    """check_flat_layout_codes (ann_ivf_pq.cuh:472-590) through what the C ABI exposes: a FLAT and an INTERLEAVED index with the
+    same model hold the same lists, codes and ids; the FLAT one refuses to search (ivf_pq_search.cuh:914-916), its file carries
+    list_layout 0 and [size, bytes_per_vector] list records (ivf_pq.hpp:302-338) and loads back as a FLAT index."""
+    import sys, os
+    import torch
+    from cuvs_amd._lib import CuvsError
+    from cuvs_amd.neighbors import ivf_pq
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import refformat
+
+    c = case
+    x = _gen(c["num_db_vecs"], c["dim"], "f32", 1234)
+    q = _gen(64, c["dim"], "f32", 4321)
+    ids = torch.arange(c["num_db_vecs"], dtype=torch.int64, device="cuda")
+    built = {}
+    for layout in ("interleaved", "flat"):
+        ip = ivf_pq.IndexParams(n_lists=c["n_lists"], kmeans_trainset_fraction=1.0, pq_bits=c["pq_bits"], pq_dim=c["pq_dim"],
+                                codebook_kind=c["codebook_kind"], add_data_on_build=False, codes_layout=layout)
+        idx = ivf_pq.build(ip, x, resources=res)          # deterministic training: the same model for both
+        ivf_pq.extend(idx, x, ids, resources=res)
+        assert idx.codes_layout == layout
+        built[layout] = idx
+    a, b = built["interleaved"], built["flat"]
+    assert torch.equal(a.list_sizes, b.list_sizes)
+    codes = []
+    for L in range(c["n_lists"]):
+        if int(a.list_sizes[L].item()) == 0:
+            codes.append(np.zeros((0, (c["pq_dim"] * c["pq_bits"] + 7) // 8), np.uint8))
+            continue
+        ca, cb = a.list_data(L, resources=res), b.list_data(L, resources=res)
+        assert torch.equal(ca, cb) and torch.equal(a.list_indices(L), b.list_indices(L))
+        codes.append(cb.cpu().numpy())
+    ivf_pq.search(ivf_pq.SearchParams(n_probes=4), a, q, 5, resources=res)     # the INTERLEAVED one searches
+    with pytest.raises(CuvsError, match="INTERLEAVED codes layout"):
+        ivf_pq.search(ivf_pq.SearchParams(n_probes=4), b, q, 5, resources=res)
+    fn = str(tmp_path / "flat.ivfpq")
+    ivf_pq.save(fn, b, resources=res)
+    f = refformat.parse_ivf_pq(fn)
+    assert f["codes_layout"] == 0 and f["pq_bits"] == c["pq_bits"] and f["pq_dim"] == c["pq_dim"]
+    sizes = a.list_sizes.cpu().numpy()
+    for L in range(c["n_lists"]):   # the file's records, parsed by the independent reader, hold the codes the index hands out
+        want = refformat.bitstream_to_codes(codes[L], c["pq_dim"], c["pq_bits"]) if sizes[L] else f["codes"][L]
+        assert (f["codes"][L] == want).all()
+    back = ivf_pq.load(fn, resources=res)
+    assert back.codes_layout == "flat" and torch.equal(back.list_sizes, b.list_sizes)
+    for L in range(c["n_lists"]):
+        if sizes[L]:
+            assert torch.equal(back.list_data(L, resources=res), b.list_data(L, resources=res))
+
+
 # ------------------------------------------------------------------------------------------------------------- IVF-Flat
 def _ivf_flat_params():
     out = []
