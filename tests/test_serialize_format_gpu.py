@@ -115,7 +115,18 @@ def test_ivf_pq_file(tmp_path, pq_bits, pq_dim, metric):
         g = str(tmp_path / ("pq_np%d.bin" % layout))
         rf.write_ivf_pq(g, 32, pq_bits, pq_dim, code, ex["pq_centers"], p["centers"], ex["centers_rot"], ex["rotation"],
                         codes, ex["ids"], layout=layout)
-        assert _same(want, ivf_pq.search(sp, ivf_pq.load(g), tq, 10))
+        back = ivf_pq.load(g)
+        if layout == 1:
+            assert back.codes_layout == "interleaved" and _same(want, ivf_pq.search(sp, back, tq, 10))
+        else:
+            # a FLAT file loads as a FLAT index: same lists (contiguous codes, ids), and the search is refused as in the
+            # reference (ivf_pq_search.cuh:914-916)
+            assert back.codes_layout == "flat"
+            for L in range(24):
+                if len(ex["ids"][L]):
+                    assert torch.equal(back.list_data(L), idx.list_data(L)) and torch.equal(back.list_indices(L), idx.list_indices(L))
+            with pytest.raises(Exception, match="INTERLEAVED codes layout"):
+                ivf_pq.search(sp, back, tq, 10)
     idx2 = ivf_pq.load(f)
     assert _same(want, ivf_pq.search(sp, idx2, tq, 10))
     assert len(idx2) == 3000 and idx2.pq_dim == pq_dim and idx2.pq_bits == pq_bits
