@@ -83,6 +83,8 @@ struct tuning {
   int pq_scan2          = 1;   // CUVS_AMD_PQ_SCAN2=0: tail phase through pq_scan_kernel (comparator in the tests)
   int pq_scan3          = 1;   // CUVS_AMD_PQ_SCAN3=0: tail phase without the matrix-core filter (comparator in the tests)
   int coarse_lowp       = 1;   // CUVS_AMD_COARSE_LOWP=0: reduced-precision coarse search on the fp32 matrix cores (round 1-3; comparator)
+  int pq_head_rows      = -1;  // CUVS_AMD_PQ_HEAD_ROWS: rows of a query's nearest list the head phase scores exactly for its bound (the rest of
+                               // that list goes through the filter like any other probe); 0: the whole list (rounds 3-4); -1: default rule
   int pq_overlap        = 1;   // CUVS_AMD_PQ_OVERLAP=0: the IVF-PQ batch on one stream (rounds 1-4; comparator of the two-stream schedule)
   int coarse_grouped    = 1;   // CUVS_AMD_COARSE_GROUPED=0: coarse search through the plain distance matrix + select_k (rounds 1-4; comparator)
   int pq_filter4        = 1;   // CUVS_AMD_PQ_FILTER4=0: the matrix-core filter of round 3 (two waves per SIMD, 64-query units; comparator)

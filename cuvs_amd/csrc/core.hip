@@ -180,6 +180,7 @@ tuning load_tuning_from_env()
   t.pq_filter4       = geti("CUVS_AMD_PQ_FILTER4", 1);
   t.coarse_grouped   = geti("CUVS_AMD_COARSE_GROUPED", 1);
   t.pq_overlap       = geti("CUVS_AMD_PQ_OVERLAP", 1);
+  t.pq_head_rows     = geti("CUVS_AMD_PQ_HEAD_ROWS", -1);
   t.coarse_lowp      = geti("CUVS_AMD_COARSE_LOWP", 1);
   t.flat_scan3       = geti("CUVS_AMD_FLAT_SCAN3", 1);
   t.pq3_surv_cap     = geti("CUVS_AMD_PQ3_SURV_CAP", 0);

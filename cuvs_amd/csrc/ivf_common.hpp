@@ -67,15 +67,17 @@ __global__ void fill_items_kernel(const uint32_t* __restrict__ pair_off, const u
 // tail phase bite. Results do not depend on the order in which pairs are scanned.
 // List-sharded search (shard_world > 1): pairs that probe a list of another rank get the label `skip` - a bucket
 // past the scanned ranges, so that no work item is ever run for them.
+// head_in_tail (partial head): the head pairs get their list's TAIL label as well - the head phase takes its items straight
+// from the probes (head_items_kernel) and scores only the first rows of those lists; all their rows are screened with the others.
 __global__ void phase_labels_kernel(const uint32_t* __restrict__ probes, int64_t n_pairs, uint32_t n_probes,
                                     uint32_t head, uint32_t n_lists, uint32_t* __restrict__ out,
                                     uint32_t shard_world = 1, uint32_t shard_rank = 0, uint32_t skip = 0,
-                                    const int32_t* __restrict__ owner = nullptr)
+                                    const int32_t* __restrict__ owner = nullptr, bool head_in_tail = false)
 {
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t L = probes[p];
     const bool mine  = shard_world <= 1 || (owner != nullptr ? (uint32_t)owner[L] == shard_rank : L % shard_world == shard_rank);
-    out[p] = !mine ? skip : L + (((uint32_t)(p % n_probes) < head || head == 0) ? 0u : n_lists);
+    out[p] = !mine ? skip : L + ((((uint32_t)(p % n_probes) < head && !head_in_tail) || head == 0) ? 0u : n_lists);
   }
 }
 

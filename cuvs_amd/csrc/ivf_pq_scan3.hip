@@ -514,6 +514,8 @@ struct rescore_params {
   uint32_t* cand_i;
   uint32_t* cand_r;
   uint32_t n_probes, rot_dim, k, head, n_chunks;
+  uint32_t head_rows;             // partial head: survivors of a head pair below this row of its list were scored by the head phase
+  const uint32_t* list_offsets;   //   (the list's first flat row)
   int is_ip;
   const uint32_t* filter_bits;
   const int64_t* indices;
@@ -614,6 +616,8 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
       const int64_t sid = a.indices[row];
       ok = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
     }
+    // partial head: the first head_rows rows of a head pair's list were scored by the head phase (no duplicates)
+    if (ok && a.head_rows != 0u && pair % a.n_probes < a.head) ok = row - a.list_offsets[a.probes[pair]] >= a.head_rows;
     float af       = 0.f;
     _Float16 ah    = (_Float16)0.f;
     if (ok) {
@@ -872,6 +876,7 @@ struct head_params {
   uint32_t n_probes, rot_dim, k, cap_rows, pq_dim, n_chunks, pq_len, book;
   int is_ip, per_cluster;
   int hcand;  // capacity of a candidate buffer (head_cand(k))
+  uint32_t row_limit; // > 0: only the first row_limit rows of a list are scored (partial head)
   uint32_t one_shot;  // > 0: that many items, ONE per workgroup (item blockIdx.x), no tickets - the two-stream schedule's head launch:
                       // workgroup slots free up item by item, so the helper stream's kernels get their share of the CUs
   const uint32_t* filter_bits;
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       }
     };
     const uint32_t L        = item.list >= a.n_lists ? item.list - a.n_lists : item.list;
-    const uint32_t base_row = a.list_offsets[L], len = a.list_sizes[L];
+    const uint32_t base_row = a.list_offsets[L], len = a.row_limit != 0u ? min(a.list_sizes[L], a.row_limit) : a.list_sizes[L];
     const uint32_t pair     = a.sorted_pairs[item.first];
     const uint32_t q        = pair / a.n_probes;
     if (tid < (int)a.rot_dim) {
@@ -1575,6 +1580,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data(); s.codes = codes8;
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.n_probes = r.n_probes; s.rot_dim = idx.rot_dim; s.k = r.k; s.head = r.head; s.is_ip = r.is_ip; s.n_chunks = nch8;
+  s.head_rows = r.head_rows; s.list_offsets = idx.list_offsets.data();
   s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
   const size_t cb_bytes = (size_t)idx.rot_dim * idx.pq_book * sizeof(float);
@@ -1637,6 +1643,7 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   if (h.max_list_len > 0) a.cap_rows = std::min<uint32_t>(a.cap_rows, (uint32_t)round_up(h.max_list_len, 64));
   const size_t smem   = fixed + (size_t)a.cap_rows * 4;
   a.one_shot          = h.one_shot;
+  a.row_limit         = h.row_limit;
   const unsigned grid = h.one_shot != 0u ? h.one_shot : pq3_grid(res) * (small ? 2u : 1u);
   auto go = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

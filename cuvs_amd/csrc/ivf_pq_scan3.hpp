@@ -50,7 +50,11 @@ struct pq3_run {
   //   stage 1: work units + pre-pass without thresholds (B operands, and the norms the thresholds need -> pair_norms)
   //   stage 2: thresholds from pair_norms and the head bounds, filter, re-score, fallback work items
   int stage = 0;
-  void* pair_norms = nullptr;    // [tail pairs] x 16 bytes (|r|^2, |c|^2, q.c, largest scaled operand), written by stage 1
+  void* pair_norms = nullptr;
+  // Partial head (round 5): the head phase scored only the first head_rows rows of every query's nearest list; that pair is
+  // ALSO a tail pair of its list (all its rows are screened against the bound), and the re-score drops what the head phase
+  // has already scored - survivors of a head pair (probe rank < head) below head_rows. 0: the head phase scored whole lists.
+  uint32_t head_rows = 0;    // [tail pairs] x 16 bytes (|r|^2, |c|^2, q.c, largest scaled operand), written by stage 1
 };
 
 // single-query list scan with the k smallest selected in LDS (head phase, pairs of handed-back queries)
@@ -69,6 +73,7 @@ struct pq3_head {
   const uint32_t* filter_bits;
   unsigned long long* stats;     // optional device [8] (CUVS_AMD_SCAN_DEBUG=2048)
   uint32_t one_shot = 0;         // > 0: the number of items, one workgroup each (no tickets): the two-stream schedule's head launch
+  uint32_t row_limit = 0;        // > 0: score only the first row_limit rows of a list (partial head: pq3_run::head_rows)
 };
 void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h);
 

@@ -165,6 +165,7 @@ enum scan_stat { ST_HEADER, ST_LUT, ST_SCAN, ST_STAGE2, ST_MERGE, ST_ROWS, ST_QU
 
 struct scan_args {
   uint32_t one_shot = 0;         // head launch of the two-stream schedule: the item count, one workgroup per item (pq3_head::one_shot)
+  uint32_t row_limit = 0;        //   and the partial head's row limit (pq3_head::row_limit)
   const work_item* items;
   const uint32_t* item_begin;    // device scalars: this launch walks items [*item_begin, *item_end)
   const uint32_t* item_end;      //   (item_begin == nullptr: from 0)
@@ -2169,6 +2170,15 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     aux.stream     = res.aux_stream;
   }
   resources& gres = overlap ? aux : res;  // the stream the grouping and the tail phase's preparation are queued on
+  // Partial head (two-stream schedule only: the head items come straight from the probes): the head phase scores the first
+  // head_rows rows of a query's nearest list - its k-th best of those bounds the query's final k-th score like the whole list's
+  // does, a little less tightly - and the list's remaining rows are screened by the filter with all the other probes.
+  uint32_t head_rows = 0u;
+  if (overlap) {
+    if (res.tune.pq_head_rows >= 0) head_rows = (uint32_t)res.tune.pq_head_rows / 64u * 64u;
+    else                            head_rows = 0u;  // (default rule: see DESIGN 3.1f - set by measurement)
+    if (head_rows != 0u && head_rows < 4u * (uint32_t)k) head_rows = 0u;  // (a bound needs a few times k rows to mean anything)
+  }
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
@@ -2206,7 +2216,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (head > 0 || sharded) {
       hipLaunchKernelGGL(phase_labels_kernel, dim3(nblk(n_pairs, 256)), dim3(256), 0, gres.stream, probes.data(),
                          n_pairs, n_probes, head, idx.n_lists, phase_labels.data(), (uint32_t)idx.shard_world,
-                         (uint32_t)idx.shard_rank, n_ranges, idx.list_owner.data());
+                         (uint32_t)idx.shard_rank, n_ranges, idx.list_owner.data(), head_rows != 0u);
       labels = phase_labels.data();
     }
     // the tail phase (warm bounds) of the common configuration runs pq_scan2_kernel on items of 2 * qpb pairs
@@ -2295,7 +2305,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       h.sorted_pairs = sa.sorted_pairs; h.rot_queries = sa.rot_queries; h.cand_d = sa.out_d; h.cand_i = sa.out_i;
       h.query_kth = sa.query_kth; h.n_probes = n_probes; h.k = (uint32_t)k; h.max_list_len = max_list_len; h.is_ip = sa.is_ip;
       h.lut_mode = lut_mode; h.acc_half = acc_half ? 1 : 0; h.filter_bits = filter_bits;
-      h.one_shot = sa.one_shot;
+      h.one_shot = sa.one_shot; h.row_limit = sa.row_limit;
       dev_buf<unsigned long long> hst(res, (sa.dbg & 2048) ? 8 : 0);
       if (sa.dbg & 2048) HIP_TRY(hipMemsetAsync(hst.data(), 0, hst.bytes(), res.stream));
       h.stats = hst.data();
@@ -2314,6 +2324,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         scan_args ah = a;
         ah.items = hitems.data(); ah.sorted_pairs = hpairs.data(); ah.item_end = hpairs.data() + bs_alloc;
         ah.one_shot = (uint32_t)nq;  // one workgroup per item: slots free up item by item, the helper stream's kernels fit in between
+        ah.row_limit = head_rows;
         launch1(ah);
       } else if (head1) launch1(a); else launch(a);  // head phase: the nearest probes, cold bounds
       // list-sharded index with a communicator: every rank continues with the bound of the query's globally nearest
@@ -2324,7 +2335,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       if (use3) {
         HIP_TRY(hipMemsetAsync(qstate.data(), 0, qstate.bytes(), res.stream));
         pq3_run r{};
-        r.pair_norms = pair_norms.data();
+        r.pair_norms = pair_norms.data(); r.head_rows = head_rows;
         r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = a.is_ip;
         r.lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0); r.acc_half = acc_half ? 1 : 0;
         r.sorted_pairs = sorted_pairs.data(); r.pair_off = pair_off.data(); r.probes = probes.data();

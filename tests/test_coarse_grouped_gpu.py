@@ -109,6 +109,13 @@ def test_two_stream_schedule_equals_one_stream(metric, pq_bits, pq_dim, dim, n_l
     monkeypatch.delenv("CUVS_AMD_PQ_OVERLAP")
     index = ivf_pq.build(ivf_pq.IndexParams(n_lists=n_lists, pq_dim=pq_dim, pq_bits=pq_bits, kmeans_n_iters=8, metric=metric), xt, resources=r0)
     r0.sync()
+    # partial head: only the first 512 (256) rows of a query's nearest list are scored by the head phase, the list's other rows go
+    # through the filter; 0: the head phase scores whole lists. Same results all three ways.
+    handles = []
+    for rows in (512, 256, 0):
+        monkeypatch.setenv("CUVS_AMD_PQ_HEAD_ROWS", str(rows))
+        handles.append(cuvs_amd.common.Resources())
+    monkeypatch.delenv("CUVS_AMD_PQ_HEAD_ROWS")
     for mib in (4096, 300):
         sp = ivf_pq.SearchParams(n_probes=n_probes, max_internal_batch_size=mib, lut_dtype=np.float16)
         d0, i0 = ivf_pq.search(sp, index, qt, 10, resources=r0)   # (first call: derived tables built inside this search)
@@ -117,5 +124,9 @@ def test_two_stream_schedule_equals_one_stream(metric, pq_bits, pq_dim, dim, n_l
         r0.sync(); r1.sync()
         assert torch.equal(i0, i1) and torch.equal(d0, d1)
         assert torch.equal(i0, i2) and torch.equal(d0, d2)
+        for rh in handles:
+            d3, i3 = ivf_pq.search(sp, index, qt, 10, resources=rh)
+            rh.sync()
+            assert torch.equal(i0, i3) and torch.equal(d0, d3)
     od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, 10, n_probes, metric=metric, lut="f16")
     assert (i0.cpu().numpy() == oi).all() and (d0.cpu().numpy() == od).all()
