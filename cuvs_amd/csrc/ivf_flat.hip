@@ -807,8 +807,24 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     const int64_t n_pairs = nq * n_probes;
     const char* qptr      = static_cast<const char*>(queries) + (size_t)q0 * idx.dim * esz;
     load_range_as_float(res, queries, et, false, idx.dim, q0, nq, qf.data());
-    // coarse search (ivf_flat_search.cuh:104-187)
-    if (idx.metric == M_InnerProduct) {
+    // coarse search (ivf_flat_search.cuh:104-187). Common shapes: distances in grouped layout + the best key of every 16-centre
+    // group, selection from the keys and the qualifying groups only (ops.hpp: pairwise_distance_grouped / select_k_grouped,
+    // DESIGN 3.1f) - the values, their order and the tie rule are those of the plain form below
+    bool coarse_done = false;
+    if (res.tune.coarse_grouped != 0 && select_k_grouped_ok(idx.n_lists, (int)n_probes)) {
+      const int64_t ldo = round_up((int64_t)idx.n_lists, 128);
+      dev_buf<float> gdist(res, (size_t)nq * ldo);
+      dev_buf<uint32_t> gkeys(res, (size_t)nq * (ldo / 16));
+      const bool ipm = idx.metric == M_InnerProduct, cosm = idx.metric == M_CosineExpanded;
+      if (!ipm) row_norms<float>(res, qf.data(), nq, idx.dim, idx.dim, qn.data(), cosm);
+      coarse_done = pairwise_distance_grouped(res, qf.data(), nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim, idx.dim,
+                                              ipm ? nullptr : qn.data(), ipm ? nullptr : (cosm ? idx.center_norms_sqrt.data() : idx.center_norms.data()),
+                                              ipm ? (int)M_InnerProduct : (cosm ? (int)M_CosineExpanded : (int)M_L2Expanded), gdist.data(), ldo,
+                                              gkeys.data(), ldo / 16);
+      if (coarse_done) select_k_grouped(res, gdist.data(), ldo, gkeys.data(), ldo / 16, nq, idx.n_lists, (int)n_probes, pd.data(), probes.data(), !ipm);
+    }
+    if (coarse_done) {
+    } else if (idx.metric == M_InnerProduct) {
       pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim, idx.dim,
                                       nullptr, nullptr, M_InnerProduct, dist.data(), idx.n_lists);
       select_k<uint32_t, uint32_t>(res, dist.data(), nullptr, nq, idx.n_lists, idx.n_lists, (int)n_probes, pd.data(),

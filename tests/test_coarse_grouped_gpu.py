@@ -130,3 +130,27 @@ def test_two_stream_schedule_equals_one_stream(metric, pq_bits, pq_dim, dim, n_l
             assert torch.equal(i0, i3) and torch.equal(d0, d3)
     od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, 10, n_probes, metric=metric, lut="f16")
     assert (i0.cpu().numpy() == oi).all() and (d0.cpu().numpy() == od).all()
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "inner_product", "cosine"])
+def test_ivf_flat_search_same_with_and_without_the_grouped_coarse_search(metric, monkeypatch):
+    """cuvsIvfFlatSearch at n_lists 4096: the default handle (grouped coarse search) against CUVS_AMD_COARSE_GROUPED=0."""
+    import torch
+    import cuvs_amd
+    from cuvs_amd.neighbors import ivf_flat
+
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((50000, 32)).astype(np.float32)
+    q = rng.standard_normal((400, 32)).astype(np.float32)
+    xt, qt = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    r0 = cuvs_amd.common.Resources()
+    index = ivf_flat.build(ivf_flat.IndexParams(n_lists=4096, kmeans_n_iters=4, metric=metric), xt, resources=r0)
+    sp = ivf_flat.SearchParams(n_probes=48)
+    d0, i0 = ivf_flat.search(sp, index, qt, 10, resources=r0)
+    r0.sync()
+    monkeypatch.setenv("CUVS_AMD_COARSE_GROUPED", "0")
+    r1 = cuvs_amd.common.Resources()
+    monkeypatch.delenv("CUVS_AMD_COARSE_GROUPED")
+    d1, i1 = ivf_flat.search(sp, index, qt, 10, resources=r1)
+    r1.sync()
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
