@@ -27,7 +27,8 @@ oi = torch.empty((10000, 10), dtype=torch.int64, device=dev)
 od = torch.empty((10000, 10), dtype=torch.float32, device=dev)
 sp = ivf_pq.SearchParams(n_probes=128, lut_dtype=bench.LUTS["f16"], internal_distance_dtype=bench.LUTS["f32"], max_internal_batch_size=10000)
 ref_i = None
-for hr in (0, 4096, 3072, 2048, 1536, 1024):
+sweep = [int(v) for v in sys.argv[2:]] or [0, 4096, 3072, 2048, 1536, 1024]
+for hr in sweep:
     r = bench.comparator_handle(CUVS_AMD_PQ_HEAD_ROWS=hr)
 
     def step():
