@@ -426,23 +426,6 @@ __global__ __launch_bounds__(kF4Threads) void pq_filter4_kernel(const filter4_pa
           uint32_t hits = 0u;
 #pragma unroll
           for (int i = 0; i < 16; ++i) hits |= (ac[g][i] >= thr[g] ? 1u : 0u) << i;
-          // fast path (round 5): at most one hit per lane - nearly always - and room in the current chunk: the hits are appended
-          // by their own lanes, positions from the ballot (the scalar walk below costs ~0.3 us of wave time per survivor: a
-          // tenth of this kernel at the C3 shape)
-          {
-            const bool one  = (hits & (hits - 1u)) == 0u;
-            const uint32_t i = (uint32_t)__ffs((int)hits) - 1u;  // (no hit: 0xffffffff, unused)
-            const uint32_t v = (u << 5) + (i & 3u) + 8u * (i >> 2) + 4u * h;
-            const bool mine  = hits != 0u && v < r_end;
-            const unsigned long long m = __ballot(mine);
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            if (__ballot(!one) == 0ull && s_fill + cnt <= kSurvChunk && s_chunk < a.n_chunks) {
-              if (mine) a.surv[(size_t)s_chunk * kSurvChunk + s_fill + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(pairid[g], base_row + v);
-              s_fill += cnt;
-              if (STATS) st_surv += cnt;
-              gmask[g] = 0ull;  // (done: the walk below finds nothing left)
-            }
-          }
           unsigned long long lm = gmask[g];
           while (lm != 0ull) {
             const uint32_t src = (uint32_t)__ffsll((long long)lm) - 1u;
