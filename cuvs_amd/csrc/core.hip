@@ -53,9 +53,22 @@ void raw_free(void* stream_v, void* p)
 unsigned long long g_pq3_last_stats[6] = {0, 0, 0, 0, 0, 0};  // cuvsAmdIvfPqLastFilterStats (written by ivf_pq_search.hip)
 
 // scratch_cache.hpp: freed scratch blocks are kept by the handle and re-used by exact size on the same stream
+// Kept blocks back to the runtime OUTSIDE a call (stream change, handle destruction, another thread's failed allocation): on the
+// handle's own stream stream-ordered; on a stream the CALLER owns - which may already be destroyed (legal: the reference's setter
+// never touches the old stream) - after ONE device-wide drain, synchronously (every flush site, one sync for all blocks)
+static void flush_cache(scratch_cache& c)
+{
+  if (!c.caller_stream) { c.flush(raw_free); return; }
+  bool drained = false;
+  c.flush([&](void*, void* p) {
+    if (!drained) { (void)hipDeviceSynchronize(); drained = true; }
+    (void)hipFree(p);
+    (void)hipGetLastError();
+  });
+}
 void scratch_cache_flush(resources& res)
 {
-  if (res.cache != nullptr) res.cache->flush(raw_free);
+  if (res.cache != nullptr) flush_cache(*res.cache);
 }
 
 // every live cache of the process: a PERSISTENT allocation (an index buffer: plain hipMalloc, no handle in sight) that fails
@@ -74,7 +87,7 @@ void scratch_cache_flush_all()
 {
   {
     std::lock_guard<std::mutex> lk(g_caches_mu);
-    for (scratch_cache* c : g_caches) c->flush(raw_free);
+    for (scratch_cache* c : g_caches) flush_cache(*c);
   }
   (void)hipDeviceSynchronize();  // the frees are stream-ordered: the memory is back once the streams have drained
   (void)hipGetLastError();
@@ -307,16 +320,8 @@ cuvsError_t cuvsStreamSet(cuvsResources_t res, cudaStream_t stream)
       // kept blocks are ordered on the old stream: give them back before it goes. A stream the CALLER owns may already
       // be destroyed (legal: the reference's setter never touches the old stream), so nothing here may fail on it: the
       // kept blocks are then freed synchronously after a device-wide drain
-      if (r->owns_stream) {
-        scratch_cache_flush(*r);
-        HIP_TRY(hipStreamSynchronize(r->stream));
-      } else {
-        r->cache->flush([](void*, void* p) {
-          (void)hipDeviceSynchronize();
-          (void)hipFree(p);
-          (void)hipGetLastError();
-        });
-      }
+      scratch_cache_flush(*r);  // (own stream: stream-ordered frees; caller's stream: one drain, then synchronous frees)
+      if (r->owns_stream) HIP_TRY(hipStreamSynchronize(r->stream));
     }
     if (r->owns_stream && r->stream) {
       HIP_TRY(hipStreamSynchronize(r->stream));
@@ -326,7 +331,8 @@ cuvsError_t cuvsStreamSet(cuvsResources_t res, cudaStream_t stream)
     r->owns_stream = false;
     if (r->cache != nullptr) {
       std::lock_guard<std::mutex> lk(r->cache->mu);
-      r->cache->stream = r->stream;
+      r->cache->stream        = r->stream;
+      r->cache->caller_stream = true;
     }
   });
 }

@@ -19,6 +19,8 @@ namespace cuvs_amd {
 struct scratch_cache {
   std::mutex mu;
   void* stream = nullptr;                              // the stream the kept blocks are ordered on
+  bool caller_stream = false;                          // `stream` belongs to the caller (cuvsStreamSet): it may be gone by the time the
+                                                       // kept blocks are given back outside a call - those sites free synchronously
   std::unordered_map<void*, size_t> live;              // blocks handed out on `stream`
   std::unordered_multimap<size_t, void*> free_blocks;  // kept blocks by exact size
   size_t cached_bytes = 0;
