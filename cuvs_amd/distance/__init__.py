@@ -2,6 +2,8 @@
 DISTANCE_TYPES = {
     "l2": 1,
     "sqeuclidean": 0,
+    "l2_unexpanded": 4,        # cuvsDistanceType L2Unexpanded / L2SqrtUnexpanded: the same values as the expanded forms,
+    "l2_sqrt_unexpanded": 5,   # computed as a sum of squared differences in the reference
     "euclidean": 1,
     "l1": 3,
     "cityblock": 3,

@@ -241,3 +241,39 @@ def cagra_cases():
                                 max_queries=0, team_size=0, itopk_size=256, search_width=1, metric=metric, host_dataset=False,
                                 include_serialized_dataset=True, use_source_indices=False, min_recall=0.995))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------- brute force
+# cpp/tests/neighbors/ann_brute_force.cuh:167-212: {num_queries, num_db_vecs, dim, k, metric}; pass = devArrMatchKnnPair with
+# eps 0.001 after sorting both sides (knn_utils.cuh:19-70: position by position, id OR distance), before and after a
+# serialize / deserialize round trip (:106-127); data uniform [0.1, 2.0) (:131-145)
+L2U = "l2_unexpanded"
+BRUTE_FORCE_CASES = [
+    # test various dims (aligned and not aligned to vector sizes)
+    (1000, 10000, 1, 16, L2), (1000, 10000, 2, 16, L2), (1000, 10000, 3, 16, L2), (1000, 10000, 4, 16, L2), (1000, 10000, 5, 16, IP),
+    (1000, 10000, 8, 16, IP), (1000, 10000, 5, 16, L2S), (1000, 10000, 8, 16, L2S),
+    # test dims that do not fit into kernel shared memory limits
+    (1000, 10000, 2048, 16, L2), (1000, 10000, 2049, 16, L2), (1000, 10000, 2050, 16, IP), (1000, 10000, 2051, 16, IP),
+    (1000, 10000, 2052, 16, IP), (1000, 10000, 2053, 16, L2), (1000, 10000, 2056, 16, L2),
+    # test fused_l2_knn
+    (100, 1000, 16, 10, L2), (256, 256, 30, 10, L2), (1000, 10000, 16, 10, L2), (100, 1000, 16, 50, L2), (20, 10000, 16, 10, L2),
+    (1000, 10000, 16, 50, L2), (1000, 10000, 32, 50, L2), (10000, 40000, 32, 30, L2), (100, 1000, 16, 10, L2U), (1000, 10000, 16, 10, L2U),
+    (100, 1000, 16, 50, L2U), (20, 10000, 16, 50, L2U), (1000, 10000, 16, 50, L2U), (1000, 10000, 32, 50, L2U), (10000, 40000, 32, 30, L2U),
+    # test tile
+    (256, 512, 16, 8, L2), (256, 512, 16, 8, L2U), (256, 512, 16, 8, IP), (256, 512, 16, 8, L2S), (10000, 40000, 32, 30, L2),
+    (789, 20516, 64, 256, L2S), (4, 12, 32, 6, L2), (1, 40, 32, 30, L2), (1000, 500000, 128, 128, L2),
+]
+
+# --------------------------------------------------------------------------------------------------------------- refine
+# cpp/tests/neighbors/refine.cu:93-101: product {n_queries 137} x {n_rows 1000} x {dim 16} x {k 1, 10, 33} x {k0 33} x {L2Expanded,
+# InnerProduct} x {host_data false, true}, float and uint8 rows (:103-110); candidates = the k0 exact neighbours
+# (refine_helper.cuh:60-90), min_recall 1 with eps 0.001 (refine.cu:72-81); float rows uniform [-10, 10), uint8 integers [1, 20)
+REFINE_CASES = [(137, 1000, 16, k, 33, metric, host) for k in (1, 10, 33) for metric in (L2, IP) for host in (False, True)]
+
+# ----------------------------------------------------------------------------------------------------------- NN-descent
+# cpp/tests/neighbors/ann_nn_descent.cuh:466-477: product {n_rows 2000, 4000} x {dim 4, 16, 31, 64, 256, 1024} x {graph_degree 32,
+# 64} x {BitwiseHamming, L2Expanded, L2SqrtExpanded, InnerProduct, CosineExpanded, L1} x {host_dataset false, true} x
+# {min_recall 0.90}; float rows ~ N(0.1, 2.0) (:162-164); pass = eval_neighbours of the graph rows against the exact kNN graph
+# (self included), eps 0.001 (:150-158). BitwiseHamming / L1 rows are listed and skipped (outside this repo's scope).
+NN_DESCENT_CASES = [(n, d, deg, metric, host, 0.90) for n in (2000, 4000) for d in (4, 16, 31, 64, 256, 1024) for deg in (32, 64)
+                    for metric in ("bitwise_hamming", L2, L2S, IP, COS, "l1") for host in (False, True)]

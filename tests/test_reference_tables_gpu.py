@@ -275,3 +275,96 @@ def test_cagra_reference_table(c, res, tmp_path):
     else:
         exact = ((rows - qd[:, None, :]) ** 2).sum(2)
     assert torch.allclose(d.double(), exact, atol=1e-4, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------- brute force
+def _match_knn_pair(exp_i, act_i, exp_d, act_d, eps):
+    """knn_utils.cuh:19-70 with sort_inputs: both sides sorted by (distance, id), then position by position id OR CompareApprox."""
+    import torch
+
+    def srt(d, i):
+        # lexicographic (distance, id): sort by id first, then stable by distance
+        o = torch.argsort(i, dim=1, stable=True)
+        d, i = torch.gather(d, 1, o), torch.gather(i, 1, o)
+        o = torch.argsort(d, dim=1, stable=True)
+        return torch.gather(d, 1, o), torch.gather(i, 1, o)
+
+    ed, ei = srt(exp_d.double(), exp_i)
+    ad, ai = srt(act_d.double(), act_i)
+    diff = (ad - ed).abs()
+    m = torch.maximum(ad.abs(), ed.abs())
+    ratio = torch.where(diff > eps, diff / m, diff)
+    bad = ~((ai == ei) | (ratio <= eps))
+    assert not bool(bad.any()), f"{int(bad.sum())} positions differ, first at {torch.nonzero(bad)[0].tolist()}"
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"f32-inputs-{n:02d}") for n, c in enumerate(T.BRUTE_FORCE_CASES)])
+def test_brute_force_reference_table(case, res, tmp_path):
+    from cuvs_amd.neighbors import brute_force
+
+    nq, n, dim, k, metric = case
+    x = _gen(n, dim, "f32", 1234)
+    q = _gen(nq, dim, "f32", 4321)
+    td, ti = _naive_knn(q, x, k, {"l2_unexpanded": "sqeuclidean"}.get(metric, metric), chunk=1024 if n >= 500000 else 4096)
+    index = brute_force.build(x, metric=metric, resources=res)
+    d, i = brute_force.search(index, q, k, resources=res)
+    res.sync()
+    _match_knn_pair(ti, i, td, d, 0.001)
+    fn = str(tmp_path / "bf.bin")            # :106-127: the same after serialize / deserialize
+    brute_force.save(fn, index, resources=res)
+    d2, i2 = brute_force.search(brute_force.load(fn, resources=res), q, k, resources=res)
+    res.sync()
+    _match_knn_pair(ti, i2, td, d2, 0.001)
+
+
+# --------------------------------------------------------------------------------------------------------------- refine
+@pytest.mark.parametrize("dtype", ["f32", "u8"])
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"inputs-{n:02d}") for n, c in enumerate(T.REFINE_CASES)])
+def test_refine_reference_table(case, dtype, res):
+    import torch
+    from cuvs_amd.neighbors import refine
+
+    nq, n, dim, k, k0, metric, host = case
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    if dtype == "f32":   # refine_helper.cuh:56-68
+        x = torch.rand((n, dim), generator=g, device="cuda") * 20.0 - 10.0
+        q = torch.rand((nq, dim), generator=g, device="cuda") * 20.0 - 10.0
+    else:
+        x = torch.randint(1, 20, (n, dim), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+        q = torch.randint(1, 20, (nq, dim), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8)
+    _, cand = _naive_knn(q, x, k0, metric)      # the k0 exact neighbours as candidates (:70-90)
+    td, ti = _naive_knn(q, x, k, metric)
+    if host:
+        d, i = refine(x.cpu().numpy(), q.cpu().numpy(), cand.cpu().numpy(), k=k, metric=metric, resources=res)
+        d, i = torch.as_tensor(np.asarray(d)).cuda(), torch.as_tensor(np.asarray(i)).cuda()
+    else:
+        d, i = refine(x, q, cand, k=k, metric=metric, resources=res)
+        res.sync()
+    _eval_neighbours(ti, i, td, d, 0.001, 1.0)
+
+
+# ----------------------------------------------------------------------------------------------------------- NN-descent
+def _nn_descent_params():
+    out = []
+    for n, c in enumerate(T.NN_DESCENT_CASES):
+        marks = [pytest.mark.skip(reason="metric outside this repo's scope (DESIGN 7)")] if c[3] in ("bitwise_hamming", "l1") else []
+        out.append(pytest.param(c, id=f"f32-inputs-{n:03d}-{c[3]}-n{c[0]}-d{c[1]}-deg{c[2]}-{'host' if c[4] else 'device'}", marks=marks))
+    return out
+
+
+@pytest.mark.parametrize("case", _nn_descent_params())
+def test_nn_descent_reference_table(case, res):
+    import torch
+    from cuvs_amd.neighbors import nn_descent
+
+    n, dim, degree, metric, host, min_recall = case
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    x = torch.randn((n, dim), generator=g, device="cuda") * 2.0 + 0.1    # N(0.1, 2.0): ann_nn_descent.cuh:162-164
+    index = nn_descent.build(nn_descent.IndexParams(metric=metric, graph_degree=degree, intermediate_graph_degree=2 * degree, max_iterations=100),   # :108-112
+                             x.cpu().numpy() if host else x, resources=res)
+    graph = index.graph.to(torch.int64) & 0xFFFFFFFF
+    dist = index.distances
+    td, ti = _naive_knn(x, x, degree, metric)     # the exact kNN graph (a row is its own nearest neighbour, as in the reference)
+    _eval_neighbours(ti, graph, td, dist, 0.001, min_recall, test_unique=False)
