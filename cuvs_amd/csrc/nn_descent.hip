@@ -307,7 +307,7 @@ void nnd_run(resources& res, const T* data, elem_t et, int64_t n, int64_t dim, u
   // the descent on 4000 x 1024 rows / inner product / 64 settles at a graph recall of 0.84, with 96 at 0.9+ - found by the
   // reference's own ann_nn_descent table (min_recall 0.9), round 5
   const uint32_t K = (uint32_t)std::min<int64_t>(n - 1, K_out <= 32 ? K_out : (uint32_t)round_up((int64_t)(K_out * 1.3), 32));
-  const uint32_t P = std::max<uint32_t>(64, K);
+  const uint32_t P = std::max<uint32_t>(64, 2 * K);  // proposals a node accepts per round (first come, first kept)
   dev_buf<uint32_t> ids(res, (size_t)n * K), keys(res, (size_t)n * K), worst(res, n), prop_ids(res, (size_t)n * P),
     prop_keys(res, (size_t)n * P), prop_cnt(res, n), fwd_new(res, (size_t)n * kSamples), fwd_old(res, (size_t)n * kSamples),
     rev_new(res, (size_t)n * kSamples), rev_old(res, (size_t)n * kSamples), rev_new_cnt(res, n), rev_old_cnt(res, n);
