@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
   } else {
     s_xn[tid - BM] = ep.xn != nullptr ? ep.xn[min(col0 + tid - BM, n - 1)] : 0.f;
   }
-  const bool stat = MODE == 2 && (ap.dbg & 4);
+  const bool stat = (MODE == 2 || MODE == 3) && (ap.dbg & 4);
   const unsigned long long t_start = stat ? __builtin_readcyclecounter() : 0ull;
 
   // staging: thread t moves rows t / 4 and 64 + t / 4, k-chunk t % 4 of both operands
@@ -498,6 +498,13 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
           if ((l15 & 3) == 0) ap.gkeys[row * ap.ldg + (col0 >> 4) + wn * 4 + (l15 >> 2)] = best;
         }
       }
+    }
+    if (stat && tid == 0) {
+      const unsigned long long t_end = __builtin_readcyclecounter();
+      atomicAdd(&ap.stats[0], t_loop - t_start);
+      atomicAdd(&ap.stats[1], t_epi - t_loop);
+      atomicAdd(&ap.stats[2], t_end - t_epi);
+      atomicAdd(&ap.stats[3], 1ull);
     }
   } else {
     // one straight-line pass: does this lane hold anything that beats its row's k-th value? (norms and thresholds come
@@ -649,9 +656,23 @@ bool pairwise_distance_grouped(resources& res, const float* q, int64_t m, int64_
   epilogue_args ep{qn, xn, metric, 1e-6f, nullptr};
   append_args ap;
   ap.gkeys = gkeys; ap.ldg = ldg;
+  ap.dbg = res.tune.tile_dbg & 4;  // CUVS_AMD_TILE_DBG=4: cycles of prologue / main loop / epilogue per tile (stderr)
+  dev_buf<unsigned long long> stats;
+  if (ap.dbg & 4) {
+    stats = dev_buf<unsigned long long>(res, 4);
+    HIP_TRY(hipMemsetAsync(stats.data(), 0, stats.bytes(), res.stream));
+    ap.stats = stats.data();
+  }
   dim3 grid((unsigned)((n + BN - 1) / BN), (unsigned)((m + BM - 1) / BM));
   launch_tile<float, float, 3>(metric, grid, res.stream, q, m, ldq, x, n, ldx, dim, ep, out, ldo, ap);
   HIP_TRY(hipGetLastError());
+  if (ap.dbg & 4) {
+    unsigned long long h[4];
+    HIP_TRY(hipMemcpyAsync(h, stats.data(), sizeof(h), hipMemcpyDeviceToHost, res.stream));
+    HIP_TRY(hipStreamSynchronize(res.stream));
+    fprintf(stderr, "[dist_tile grouped stats] tiles %llu, cycles per tile (wave 0): prologue %.0f main loop %.0f epilogue %.0f\n", h[3],
+            (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3]);
+  }
   return true;
 }
 
