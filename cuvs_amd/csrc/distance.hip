@@ -322,6 +322,11 @@ __device__ inline void load4v(const T* __restrict__ p, float (&v)[4])
 }
 
 constexpr int kTileOcc = 3;  // waves per SIMD the register budget is set for
+// MODE 3 (grouped output, the coarse search: K = dim is short): the epilogue - 64 KiB of stores per tile - waits on HBM writes
+// for 38 % of a tile's time (CUVS_AMD_TILE_DBG=4: prologue 7 k, main loop 54 k, epilogue 38 k cycles at 10k x 16384 x 128), and
+// with one wave per SIMD and workgroup only the OTHER workgroups of the CU can keep the matrix pipe busy meanwhile. A register
+// budget for four workgroups per CU measured the same (0.638 ms for GEMM + selection at that shape, round 5): kept at three.
+constexpr int kTileOccGrouped = 3;
 
 template <typename TQ, typename TX, int MODE, int OCC, int METRIC>
 __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restrict__ q, int64_t m, int64_t ldq,
@@ -581,7 +586,7 @@ void launch_tile(int metric, dim3 grid, hipStream_t stream, const TQ* q, int64_t
 {
 #define TILE_CASE(M)                                                                                                     \
   case M:                                                                                                                \
-    hipLaunchKernelGGL((dist_tile_kernel<TQ, TX, MODE, kTileOcc, M>), grid, dim3(256), 0, stream, q, m, ldq, x, n, ldx, dim, \
+    hipLaunchKernelGGL((dist_tile_kernel<TQ, TX, MODE, (MODE == 3 ? kTileOccGrouped : kTileOcc), M>), grid, dim3(256), 0, stream, q, m, ldq, x, n, ldx, dim, \
                        ep, out, ldo, ap);                                                                                \
     break;
   switch (metric) {
