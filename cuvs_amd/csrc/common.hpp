@@ -113,6 +113,9 @@ struct resources {
   int num_cus             = 256;
   size_t lds_per_block    = 160 * 1024;
   size_t workspace_limit  = size_t(2) << 30;  // temporary distance tiles etc.
+  size_t ivf_batch_limit  = size_t(8) << 30;  // scratch an IVF search may use for ONE internal batch of queries (288 GB of HBM: a
+                                              // list-sharded search of 8 x 10k queries would otherwise run as six batches); the
+                                              // CUVS_AMD_WORKSPACE_MB test hook sets both
   std::vector<int> mg_devices;                // multi-GPU handle: participating devices
   hipMemPool_t pool       = nullptr;          // the handle's own stream-ordered pool (scratch buffers stay cached in it)
   hipStream_t aux_stream  = nullptr;          // helper stream + events for two-stream pipelines (brute force), made on first use
@@ -336,6 +339,15 @@ inline unsigned grid_blocks(int64_t n_items, int per_block)
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// n queries in batches of at most `fit`: the batch size that makes the batches EQUAL (10000 queries at fit 9900 are two batches
+// of 5000, not 9900 + 100 - a remainder below 256 queries runs without a head phase on the slow kernels)
+inline int64_t balanced_batch(int64_t n, int64_t fit)
+{
+  fit = std::max<int64_t>(1, fit);
+  if (n <= fit) return std::max<int64_t>(n, 1);
+  const int64_t nb = (n + fit - 1) / fit;
+  return (n + nb - 1) / nb;
+}
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 }  // namespace cuvs_amd

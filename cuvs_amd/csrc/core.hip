@@ -257,7 +257,7 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
     // (the reference has max_row_tile_size/max_col_tile_size hooks, knn_brute_force.cuh:90-93)
     if (const char* ws = debug_switches_on() ? getenv("CUVS_AMD_WORKSPACE_MB") : nullptr) {
       long mb = atol(ws);
-      if (mb > 0) r->workspace_limit = (size_t)mb << 20;
+      if (mb > 0) r->workspace_limit = r->ivf_batch_limit = (size_t)mb << 20;
     }
     // Scratch buffers come from a pool of the handle's own that keeps freed blocks (search allocates the same
     // temporaries every batch). The device's default pool is left alone: raising ITS release threshold would keep

@@ -228,14 +228,23 @@ __global__ __launch_bounds__(256) void sort_segments_kernel(const uint32_t* __re
     pairs[b + rank] = v;
   }
 }
-// segments beyond kSegCap (a list probed by thousands of queries of the batch): one 1024-thread workgroup per such label,
-// rank counting over LDS tiles, through a second buffer (the segment is read while ranks are still being computed)
+// segments beyond kSegCap (a list probed by thousands of queries of the batch): one 1024-thread workgroup per such label. A
+// label holds at most ONE pair per query (a query probes a list once), and pair order = query order, so the position of a
+// pair is the number of the label's queries before its own: a bitmap over the batch's queries in LDS, a prefix sum over its
+// words - O(segment + queries / 32) per label. Batches beyond kBitmapQueries queries: rank counting over LDS tiles (quadratic
+// in the segment: correct, slow). Through a second buffer (the segment is read while positions are still being computed).
+constexpr uint32_t kBitmapQueries = 1u << 19;  // 2 x 64 KiB of LDS: bitmap + word prefixes
+
 __global__ __launch_bounds__(1024) void sort_big_segments_kernel(const uint32_t* __restrict__ offsets, uint32_t n_labels,
-                                                                 uint32_t* __restrict__ pairs, uint32_t* __restrict__ tmp)
+                                                                 uint32_t* __restrict__ pairs, uint32_t* __restrict__ tmp,
+                                                                 uint32_t n_probes, uint32_t n_queries)
 {
-  __shared__ uint32_t tile[4096];
+  extern __shared__ __attribute__((aligned(16))) uint32_t sb_smem[];  // bitmap [words] | prefix [words]   or   tile [4096]
   __shared__ uint32_t big[1024];
   __shared__ uint32_t n_big;
+  __shared__ int scan_smem[17];
+  const bool bitmap_ok = n_probes != 0u && n_queries <= kBitmapQueries;
+  const uint32_t words = (n_queries + 31u) / 32u;
   // the workgroup's share of the labels, checked by all threads at once (as a rule there is no long segment at all)
   const uint32_t per = (n_labels + gridDim.x - 1) / gridDim.x;
   const uint32_t l0 = blockIdx.x * per, l1 = min(n_labels, l0 + per);
@@ -250,18 +259,43 @@ __global__ __launch_bounds__(1024) void sort_big_segments_kernel(const uint32_t*
       // (the order in which a workgroup takes its long segments does not matter: each is sorted on its own)
       const uint32_t L = big[w];
       const uint32_t b = offsets[L], n = offsets[L + 1] - b;
-      for (uint32_t i0 = 0; i0 < n; i0 += 1024u) {
-        const uint32_t i = i0 + threadIdx.x;
-        const uint32_t v = i < n ? pairs[b + i] : 0xffffffffu;
-        uint32_t rank = 0u;
-        for (uint32_t t0 = 0; t0 < n; t0 += 4096u) {
-          __syncthreads();
-          for (uint32_t t = threadIdx.x; t < 4096u; t += 1024u) tile[t] = t0 + t < n ? pairs[b + t0 + t] : 0xffffffffu;
-          __syncthreads();
-          const uint32_t m = min(4096u, n - t0);
-          for (uint32_t j = 0; j < m; ++j) rank += tile[j] < v ? 1u : 0u;
+      if (bitmap_ok) {
+        uint32_t* bits = sb_smem;
+        uint32_t* pref = sb_smem + words;
+        for (uint32_t i = threadIdx.x; i < words; i += 1024u) bits[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
+          const uint32_t q = pairs[b + i] / n_probes;
+          atomicOr(&bits[q >> 5], 1u << (q & 31u));
         }
-        if (i < n) tmp[b + rank] = v;
+        __syncthreads();
+        // exclusive prefix over the words' popcounts: a run of words per thread, one block scan of the run totals
+        const uint32_t run = (words + 1023u) / 1024u, w0 = threadIdx.x * run, w1 = min(words, w0 + run);
+        int sum = 0;
+        for (uint32_t i = w0; i < w1; ++i) sum += __popc(bits[i]);
+        int total;
+        int acc = block_exclusive_scan(sum, scan_smem, &total);
+        for (uint32_t i = w0; i < w1; ++i) { pref[i] = (uint32_t)acc; acc += __popc(bits[i]); }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
+          const uint32_t p = pairs[b + i], q = p / n_probes;
+          tmp[b + pref[q >> 5] + (uint32_t)__popc(bits[q >> 5] & ((1u << (q & 31u)) - 1u))] = p;
+        }
+      } else {
+        uint32_t* tile = sb_smem;
+        for (uint32_t i0 = 0; i0 < n; i0 += 1024u) {
+          const uint32_t i = i0 + threadIdx.x;
+          const uint32_t v = i < n ? pairs[b + i] : 0xffffffffu;
+          uint32_t rank = 0u;
+          for (uint32_t t0 = 0; t0 < n; t0 += 4096u) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < 4096u; t += 1024u) tile[t] = t0 + t < n ? pairs[b + t0 + t] : 0xffffffffu;
+            __syncthreads();
+            const uint32_t m = min(4096u, n - t0);
+            for (uint32_t j = 0; j < m; ++j) rank += tile[j] < v ? 1u : 0u;
+          }
+          if (i < n) tmp[b + rank] = v;
+        }
       }
       __syncthreads();
       for (uint32_t i = threadIdx.x; i < n; i += 1024u) pairs[b + i] = tmp[b + i];
@@ -272,9 +306,12 @@ __global__ __launch_bounds__(1024) void sort_big_segments_kernel(const uint32_t*
 }
 
 // labels [n] -> sorted_pairs [n] (pair ids ordered by (label, pair id)), pair_off [n_labels + 1]; scratch: cursor
-// [n_labels + 1] (counts, then cursors), tmp [n]. Everything on res.stream, no allocation.
+// [n_labels + 1] (counts, then cursors), tmp [n]. Everything on res.stream, no allocation. Only the first n_sorted labels are
+// put into pair order (a list shard's last label is the bucket of the foreign pairs: most pairs of the batch at 8 ranks, never
+// scanned - its order does not matter); n_probes / n_queries: pair p belongs to query p / n_probes (0: unknown - long segments
+// are then ranked the slow way).
 inline void group_pairs(resources& res, const uint32_t* labels, int64_t n, uint32_t n_labels, uint32_t* sorted_pairs, uint32_t* pair_off,
-                        uint32_t* cursor, uint32_t* tmp)
+                        uint32_t* cursor, uint32_t* tmp, uint32_t n_sorted, uint32_t n_probes, int64_t n_queries)
 {
   CUVS_EXPECTS(n < (int64_t(1) << 32), "group_pairs: more than 2^32 pairs");
   HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n_labels * sizeof(uint32_t), res.stream));
@@ -282,8 +319,14 @@ inline void group_pairs(resources& res, const uint32_t* labels, int64_t n, uint3
   hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, res.stream, cursor, (int)n_labels, pair_off);
   HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n_labels * sizeof(uint32_t), res.stream));
   hipLaunchKernelGGL(pair_scatter_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, labels, n, pair_off, cursor, sorted_pairs);
-  hipLaunchKernelGGL(sort_segments_kernel, dim3(grid_blocks(n_labels, 4)), dim3(256), 0, res.stream, pair_off, n_labels, sorted_pairs);
-  hipLaunchKernelGGL(sort_big_segments_kernel, dim3(64), dim3(1024), 0, res.stream, pair_off, n_labels, sorted_pairs, tmp);
+  n_sorted = std::min(n_sorted, n_labels);
+  hipLaunchKernelGGL(sort_segments_kernel, dim3(grid_blocks(n_sorted, 4)), dim3(256), 0, res.stream, pair_off, n_sorted, sorted_pairs);
+  const bool bitmap   = n_probes != 0u && n_queries <= (int64_t)kBitmapQueries;
+  const size_t sbytes = bitmap ? (size_t)2 * ((n_queries + 31) / 32) * sizeof(uint32_t) : (size_t)4096 * sizeof(uint32_t);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_big_segments_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)std::max<size_t>(sbytes, 16384)));
+  hipLaunchKernelGGL(sort_big_segments_kernel, dim3(64), dim3(1024), std::max<size_t>(sbytes, 16384), res.stream, pair_off, n_sorted,
+                     sorted_pairs, tmp, n_probes, (uint32_t)std::min<int64_t>(n_queries, 0xffffffff));
   HIP_TRY(hipGetLastError());
 }
 
@@ -294,10 +337,12 @@ inline void group_pairs(resources& res, const uint32_t* labels, int64_t n, uint3
 // allocations (group_pairs above: what the two-stream schedule needs); without it through group_by_label. Same output.
 inline void build_work_items(resources& res, const uint32_t* probes, int64_t n_pairs, uint32_t n_lists, int qpb,
                              uint32_t* sorted_pairs, uint32_t* pair_off, uint32_t* item_off, work_item* items,
-                             int split = -1, int qpb_hi = 0, uint32_t* group_scratch = nullptr)
+                             int split = -1, int qpb_hi = 0, uint32_t* group_scratch = nullptr, uint32_t n_sorted = 0xffffffffu,
+                             uint32_t n_probes = 0, int64_t n_queries = 0)
 {
   if (split < 0) { split = (int)n_lists; qpb_hi = qpb; }
-  if (group_scratch != nullptr) group_pairs(res, probes, n_pairs, n_lists, sorted_pairs, pair_off, group_scratch, group_scratch + n_lists + 1);
+  if (group_scratch != nullptr)
+    group_pairs(res, probes, n_pairs, n_lists, sorted_pairs, pair_off, group_scratch, group_scratch + n_lists + 1, n_sorted, n_probes, n_queries);
   else                          group_by_label(res, probes, n_pairs, n_lists, sorted_pairs, pair_off);
   hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off, (int)n_lists, qpb, item_off,
                      split, qpb_hi);

@@ -767,7 +767,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k_scan * 8 + idx.dim * 4 +
                     ((int64_t)n_probes / qpb + 1) * (dim_pad + 1) * qpb * 4;  // + the query tiles of its work items
     if (large_k) per_q += (int64_t)scores_ld * 8 + (int64_t)k * 12;
-    max_batch     = std::min(max_batch, std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q));
+    max_batch     = balanced_batch(n_queries, std::min(max_batch, std::max<int64_t>(1, (int64_t)res.ivf_batch_limit / per_q)));
   }
   const int64_t bs = std::min<int64_t>(max_batch, n_queries);
   const int64_t np_max = bs * n_probes;

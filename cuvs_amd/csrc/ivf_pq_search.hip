@@ -2096,8 +2096,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     // survivor entries, a fallback work item, two unit descriptors' share, norms and grouping scratch of the two-stream schedule
     if (!large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0)
       per_q += (int64_t)n_probes * ((int64_t)idx.rot_dim * 2 + (int64_t)k * 4 + 128 + 16 + 4 + 16 + 8);
-    int64_t fit   = std::max<int64_t>(1, (int64_t)res.workspace_limit / per_q);
-    max_batch     = std::min(max_batch, fit);
+    int64_t fit   = std::max<int64_t>(1, (int64_t)res.ivf_batch_limit / per_q);
+    max_batch     = balanced_batch(n_queries, std::min(max_batch, fit));  // (the same on every rank of a list shard: same inputs)
   }
   const int64_t bs_alloc = std::min<int64_t>(max_batch, n_queries);
   const int64_t n_pairs_max = bs_alloc * n_probes;
@@ -2230,7 +2230,8 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     const int lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0);
     const bool head1 = use3 && !glut;
     build_work_items(gres, labels, n_pairs, n_labels, head1 ? 1 : qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
-                     items.data(), (int)idx.n_lists, use2 ? 8 : qpb, overlap ? group_scratch.data() : nullptr);
+                     items.data(), (int)idx.n_lists, use2 ? 8 : qpb, overlap ? group_scratch.data() : nullptr,
+                     n_ranges /* the shard's bucket of foreign pairs stays as the scatter left it */, n_probes, nq);
     if (overlap)
       hipLaunchKernelGGL(head_items_kernel, dim3(nblk(nq, 256)), dim3(256), 0, res.stream, probes.data(), nq, n_probes,
                          (uint32_t)idx.shard_world, (uint32_t)idx.shard_rank, idx.list_owner.data(), hitems.data(), hpairs.data(),
