@@ -175,10 +175,25 @@ inline size_t largest_lists_total(const std::vector<uint32_t>& sizes, uint32_t n
 // the stable order of the radix sort, bit for bit, whatever the atomics did.
 constexpr int kSegCap = 2048;  // pairs of a label sorted from one wave's LDS region; longer segments: sort_big_segments_kernel
 
-__global__ void pair_histogram_kernel(const uint32_t* __restrict__ labels, int64_t n, uint32_t* __restrict__ counts)
+// labels >= n_plain (the list shard's bucket of foreign pairs: up to (world - 1) / world of ALL pairs under ONE label) are
+// counted per workgroup and added once - a million atomics on one address run one after the other (13 ms at two ranks)
+__global__ __launch_bounds__(256) void pair_histogram_kernel(const uint32_t* __restrict__ labels, int64_t n, uint32_t* __restrict__ counts,
+                                                             uint32_t n_plain, uint32_t n_labels)
 {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) atomicAdd(&counts[labels[i]], 1u);
+  __shared__ uint32_t bulk;
+  if (threadIdx.x == 0) bulk = 0u;
+  __syncthreads();
+  uint32_t mine = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t L = labels[i];
+    if (L < n_plain) atomicAdd(&counts[L], 1u);
+    else             ++mine;
+  }
+  if (n_plain >= n_labels) return;  // (uniform: no bulk label)
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine != 0u) atomicAdd(&bulk, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && bulk != 0u) atomicAdd(&counts[n_plain], bulk);  // (one bulk label: n_labels == n_plain + 1)
 }
 // exclusive scan by ONE workgroup: a thread takes a run of consecutive elements (its own running sum), one block scan of the
 // 1024 run totals - two passes over the array instead of n / 1024 block scans with three barriers each
@@ -198,12 +213,14 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const uint32_t* __restr
   }
   if (threadIdx.x == 0) offsets[n] = (uint32_t)total;
 }
+// (pairs of a label >= n_plain are not placed: nothing reads the segment of the foreign pairs)
 __global__ void pair_scatter_kernel(const uint32_t* __restrict__ labels, int64_t n, const uint32_t* __restrict__ offsets,
-                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ out)
+                                    uint32_t* __restrict__ cursor, uint32_t* __restrict__ out, uint32_t n_plain)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t L = labels[i];
+  if (L >= n_plain) return;
   out[offsets[L] + atomicAdd(&cursor[L], 1u)] = (uint32_t)i;
 }
 // one wave per label: the segment into LDS, every element to the position of its rank (broadcast reads: all lanes read the
@@ -315,11 +332,13 @@ inline void group_pairs(resources& res, const uint32_t* labels, int64_t n, uint3
 {
   CUVS_EXPECTS(n < (int64_t(1) << 32), "group_pairs: more than 2^32 pairs");
   HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n_labels * sizeof(uint32_t), res.stream));
-  hipLaunchKernelGGL(pair_histogram_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, labels, n, cursor);
+  n_sorted = std::min(n_sorted, n_labels);
+  CUVS_EXPECTS(n_sorted + 1u >= n_labels, "group_pairs: at most one bulk label");
+  hipLaunchKernelGGL(pair_histogram_kernel, dim3((unsigned)std::min<int64_t>(grid_blocks(n, 256), 2048)), dim3(256), 0, res.stream, labels, n,
+                     cursor, n_sorted, n_labels);
   hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, res.stream, cursor, (int)n_labels, pair_off);
   HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)n_labels * sizeof(uint32_t), res.stream));
-  hipLaunchKernelGGL(pair_scatter_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, labels, n, pair_off, cursor, sorted_pairs);
-  n_sorted = std::min(n_sorted, n_labels);
+  hipLaunchKernelGGL(pair_scatter_kernel, dim3(grid_blocks(n, 256)), dim3(256), 0, res.stream, labels, n, pair_off, cursor, sorted_pairs, n_sorted);
   hipLaunchKernelGGL(sort_segments_kernel, dim3(grid_blocks(n_sorted, 4)), dim3(256), 0, res.stream, pair_off, n_sorted, sorted_pairs);
   const bool bitmap   = n_probes != 0u && n_queries <= (int64_t)kBitmapQueries;
   const size_t sbytes = bitmap ? (size_t)2 * ((n_queries + 31) / 32) * sizeof(uint32_t) : (size_t)4096 * sizeof(uint32_t);
@@ -344,10 +363,13 @@ inline void build_work_items(resources& res, const uint32_t* probes, int64_t n_p
   if (group_scratch != nullptr)
     group_pairs(res, probes, n_pairs, n_lists, sorted_pairs, pair_off, group_scratch, group_scratch + n_lists + 1, n_sorted, n_probes, n_queries);
   else                          group_by_label(res, probes, n_pairs, n_lists, sorted_pairs, pair_off);
-  hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off, (int)n_lists, qpb, item_off,
+  // no items for the labels from n_sorted on (fill_items_kernel writes a label's items from ONE thread, and the foreign pairs of a
+  // list shard are never scanned): item_off[n_item_labels] is the end of the last scanned range
+  const int n_item_labels = (int)std::min(n_lists, n_sorted);
+  hipLaunchKernelGGL(count_items_kernel, dim3(1), dim3(1024), 0, res.stream, pair_off, n_item_labels, qpb, item_off,
                      split, qpb_hi);
-  hipLaunchKernelGGL(fill_items_kernel, dim3(grid_blocks(n_lists, 256)), dim3(256), 0, res.stream, pair_off,
-                     item_off, (int)n_lists, qpb, items, split, qpb_hi);
+  hipLaunchKernelGGL(fill_items_kernel, dim3(grid_blocks(n_item_labels, 256)), dim3(256), 0, res.stream, pair_off,
+                     item_off, n_item_labels, qpb, items, split, qpb_hi);
 }
 
 }  // namespace
