@@ -664,12 +664,37 @@ def extra_c2(res, dev):
     # filter over the fp16 residual copy of the rows (ivf_pq_scan3.hip, FLAT build) + the fp32 re-scoring of the survivors.
     # Unique bytes the scan phases must fetch: every list once as fp32 (head phase: ~all 4096 lists are some query's nearest)
     # and once as fp16 (tail phase), plus the 4-byte row terms.
+    # the same rows as int8 (x 24, rounded, clipped): the matrix-core tail phase serves every row type since round 5; the comparator
+    # handle runs the round-4 path for int8 (ivf_flat_scan_kernel for all 64 probes)
+    del bf
+    int8_line = None
+    try:
+        xi = torch.empty((n, 128), dtype=torch.int8, device=dev)
+        for r0 in range(0, n, 1 << 22):
+            xi[r0:r0 + (1 << 22)] = torch.clamp(torch.round(x[r0:r0 + (1 << 22)] * 24.0), -128, 127).to(torch.int8)
+        qi = torch.clamp(torch.round(q * 24.0), -128, 127).to(torch.int8)
+        idx8 = ivf_flat.build(ivf_flat.IndexParams(n_lists=4096, kmeans_trainset_fraction=0.1), xi, resources=res)
+        res.sync()
+        dt8 = timeit(lambda: ivf_flat.search(sp, idx8, qi, 10, neighbors=nb, distances=dd, resources=res), 10, 2)
+        gt8 = exact_topk_fp64(xi, qi[:1000], 10)
+        r8 = recall_of(nb[:1000].cpu().numpy(), gt8.cpu().numpy())
+        keep_i, keep_d = nb.clone(), dd.clone()
+        res_s = comparator_handle(CUVS_AMD_FLAT_SCAN3=0)
+        dt8s = timeit(lambda: ivf_flat.search(sp, idx8, qi, 10, neighbors=nb, distances=dd, resources=res_s), 3, 1)
+        int8_line = {"config": "C2 rows as int8 (x 24, rounded): IVF-Flat 10000000x128 int8 n_lists=4096 n_probes=64 batch=10000 k=10",
+                     "ms": round(dt8 * 1e3, 3), "qps": round(nq / dt8, 1), "recall_at_10": round(r8, 4),
+                     "ms_scan_kernel_only": round(dt8s * 1e3, 3),
+                     "equals_scan_kernel": bool(torch.equal(keep_i, nb) and torch.equal(keep_d, dd))}
+        del idx8, xi
+    except Exception as e:  # (a failed side line must not take the C2 line with it)
+        int8_line = {"error": repr(e)[:200]}
     unique = n * 512  # the lower bound on HBM bytes per batch = unique probed-list bytes (this library's own fp16 copy is its cost, not algorithmic work)
     hbm_gbs = unique / (scan_ms * 1e-3) / 1e9
     return {"brute_force_same_data": {"config": "brute_force L2 10000000x128 fp32 batch=10000 k=10", "ms": round(bf_dt * 1e3, 1),
                                       "qps": round(nq / bf_dt, 1),
                                       "roofline": {"bound": "mfma", "achieved": round(bf_tf, 1), "peak": MFMA_F32_TFLOPS,
                                                    "unit": "TFLOP/s", "frac": round(bf_tf / MFMA_F32_TFLOPS, 4)}},
+            "int8_rows": int8_line,
             "config": "C2 IVF-Flat 10000000x128 fp32 n_lists=4096 n_probes=64 batch=10000 k=10", "ms": round(dt * 1e3, 3),
             "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
             "kernel": "ivf_flat_scan_kernel (head phase) + pq_filter_kernel<FLAT> + flat_rescore_kernel (tail phase)",
@@ -1042,14 +1067,23 @@ def main():
                 sp_b = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
                                            max_internal_batch_size=nq_total)
 
-                def bstep():
-                    ivf_pq.search(sp_b, index, qs, kk, neighbors=b_i, distances=b_d, resources=res)
+                def bstep(r=res):
+                    ivf_pq.search(sp_b, index, qs, kk, neighbors=b_i, distances=b_d, resources=r)
                     if args.refine_ratio > 1:
-                        refine(data, qs, b_i, indices=o_i, distances=o_d, metric="sqeuclidean", resources=res)
+                        refine(data, qs, b_i, indices=o_i, distances=o_d, metric="sqeuclidean", resources=r)
 
                 dt_b = timeit(bstep, 30, 5)
                 rec_b = recall_of((o_i if args.refine_ratio > 1 else b_i[:, :args.k])[:min(nb, ng)].cpu().numpy(), truth[:min(nb, ng)])
-                batch_sweep.append({"batch": nb, "ms_per_call": round(dt_b * 1e3, 3), "qps": round(nb / dt_b, 1), "recall_at_10": round(rec_b, 4)})
+                line_b = {"batch": nb, "ms_per_call": round(dt_b * 1e3, 3), "qps": round(nb / dt_b, 1), "recall_at_10": round(rec_b, 4)}
+                if 10 <= nb < 256:
+                    # below 256 queries the search runs ONE phase (no head phase, LUT scan); the comparator forces the two-phase
+                    # schedule (head + matrix-core tail) on the same batch: what the threshold is worth
+                    res_h = comparator_handle(CUVS_AMD_PQ_HEAD_PROBES=1)
+                    keep_i = b_i.clone()
+                    dt_h = timeit(lambda: bstep(res_h), 30, 5)
+                    line_b["ms_per_call_two_phase_forced"] = round(dt_h * 1e3, 3)
+                    line_b["two_phase_ids_equal"] = bool(torch.equal(keep_i, b_i))
+                batch_sweep.append(line_b)
             except Exception as e:
                 batch_sweep.append({"batch": nb, "error": repr(e)[:200]})
 

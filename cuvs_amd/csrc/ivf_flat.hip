@@ -58,6 +58,15 @@ constexpr int kFlatWaves   = kFlatThreads / 64;
 constexpr int kFlatQPB     = 8;
 constexpr int kStopEvery   = 4;  // early-stop test every 4 chunks of 16 bytes (power of two)
 
+// out = in * mult (a power of two: exact). The matrix-core tail phase of int8 / uint8 indexes works on the RAW element values - the
+// space the scan kernel's integer distances and the head phase's bounds live in - while queries and centres are kept in the
+// reference's mapped space (utils::mapping<float>: x / 128, x / 256)
+__global__ void scale_floats_kernel(const float* __restrict__ in, int64_t n, float mult, float* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] * mult;
+}
+
 __global__ void strided_ids_kernel2(uint32_t* ids, int64_t n, int64_t stride)
 {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -786,8 +795,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<float> qtiles(res, max_items * (dim_pad + 1) * qpb);
   dev_buf<float> cand_d(res, large_k ? (size_t)bs * scores_ld : (size_t)np_max * k), top_d(res, (size_t)bs * k);
   const size_t esz = elem_size(et);
-  // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): fp32 / fp16 rows, L2, batches large enough for a head phase
-  const bool use3 = head > 0 && (et == elem_t::f32 || et == elem_t::f16) && metric_is_l2(idx.metric) && !large_k && n_queries >= 256 &&
+  // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): every row type (int8 / uint8 values and the distances between them
+  // are exact in fp16 / fp32 up to dim 256), L2, batches large enough for a head phase
+  const bool use3 = head > 0 && metric_is_l2(idx.metric) && !large_k && n_queries >= 256 &&
                     flat3_supported(idx.dim, k) && res.tune.flat_scan3 != 0;
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
@@ -800,6 +810,12 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0), tickets3(res, use3 ? 8 * 32 : 0);
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, 2 * max_units), overflow3(res, (size_t)2 * overflow_cap);
+  const float raw_mult = et == elem_t::i8 ? 128.0f : et == elem_t::u8 ? 256.0f : 1.0f;
+  const bool raw3      = use3 && raw_mult != 1.0f;
+  dev_buf<float> q_raw(res, raw3 ? (size_t)bs * idx.dim : 0), c_raw(res, raw3 ? (size_t)idx.n_lists * idx.dim : 0);
+  if (raw3)
+    hipLaunchKernelGGL(scale_floats_kernel, dim3(grid_blocks((int64_t)c_raw.n, 256)), dim3(256), 0, res.stream, idx.centers.data(),
+                       (int64_t)c_raw.n, raw_mult, c_raw.data());
   trace.mark("buffers allocated");
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -916,7 +932,10 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         pq3_run r{};
         r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = 0;
         r.sorted_pairs = sorted_pairs.data(); r.pair_off = pair_off.data(); r.probes = probes.data();
-        r.rot_queries = qf.data(); r.query_kth = query_kth.data();
+        if (raw3)
+          hipLaunchKernelGGL(scale_floats_kernel, dim3(grid_blocks(nq * (int64_t)idx.dim, 256)), dim3(256), 0, res.stream, qf.data(),
+                             nq * (int64_t)idx.dim, raw_mult, q_raw.data());
+        r.rot_queries = raw3 ? q_raw.data() : qf.data(); r.query_kth = query_kth.data();
         r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
         r.qflag = qstate.data(); r.qcnt = qstate.data() + bs; r.counters = qstate.data() + 2 * bs;
         r.surv_cnt = qstate.data() + 2 * bs + 2;
@@ -925,8 +944,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets3.data(); r.filter_bits = filter_bits;
         r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
-        flat3_view v{idx.data.data(), idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
-                     idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len, et == elem_t::f16};
+        flat3_view v{idx.data.data(), raw3 ? c_raw.data() : idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
+                     idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len,
+                     et == elem_t::f32 ? 0 : et == elem_t::f16 ? 1 : et == elem_t::i8 ? 2 : 3};
         const bool tdbg = (res.tune.scan_debug & 1024) != 0;
         auto now = [&]() { if (tdbg) sync(res); return std::chrono::steady_clock::now(); };
         const auto t0 = now();

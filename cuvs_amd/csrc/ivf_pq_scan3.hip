@@ -712,16 +712,20 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
 // ------------------------------------------------------------------ IVF-Flat through the same filter (fp32 rows, L2)
 // The A operands of the GEMM are the rows' residuals against their list centre, rounded to fp16 after a power-of-two
 // scaling: a derived copy of the index (half its size; 288 GB of HBM pay for it) laid out as the MFMA wants it.
-// the VL = 16 / sizeof(T) elements of a 16-byte chunk as floats (fp32 or fp16 rows; exact)
+// the VL = 16 / sizeof(T) elements of a 16-byte chunk as floats (fp32, fp16, int8 or uint8 rows; exact)
 template <typename T>
 __device__ inline void chunk_to_float(const uint4& w, float (&x)[16 / sizeof(T)])
 {
+  const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
   if constexpr (sizeof(T) == 4) {
-    x[0] = __uint_as_float(w.x); x[1] = __uint_as_float(w.y); x[2] = __uint_as_float(w.z); x[3] = __uint_as_float(w.w);
-  } else {
-    const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = __uint_as_float(ws[e]);
+  } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = (float)__builtin_bit_cast(_Float16, (uint16_t)(ws[e >> 1] >> ((e & 1) * 16)));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = (float)(T)(uint8_t)(ws[e >> 2] >> ((e & 3) * 8));
   }
 }
 
@@ -784,13 +788,21 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
   if (L != 0xffffffffu) {
     const uint4* cp = reinterpret_cast<const uint4*>(data) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
     const float* ct = centers + (size_t)L * dim + d0;
-    constexpr int VL = 16 / sizeof(T);  // 8 dimensions = two chunks of fp32 or one of fp16
+    constexpr int VL = 16 / sizeof(T);  // 8 dimensions = two chunks of fp32, one of fp16 or half a chunk of int8 / uint8
+    if constexpr (VL <= 8) {
 #pragma unroll
-    for (int c = 0; c < 8 / VL; ++c) {
+      for (int c = 0; c < 8 / VL; ++c) {
+        float x[VL];
+        chunk_to_float<T>(cp[(size_t)(d0 / VL + c) * 64], x);
+#pragma unroll
+        for (int e = 0; e < VL; ++e) v[c * VL + e] = (_Float16)(sc * (x[e] - ct[c * VL + e]));
+      }
+    } else {
       float x[VL];
-      chunk_to_float<T>(cp[(size_t)(d0 / VL + c) * 64], x);
+      chunk_to_float<T>(cp[(size_t)(d0 / VL) * 64], x);
+      const bool upper = (d0 & 8u) != 0u;
 #pragma unroll
-      for (int e = 0; e < VL; ++e) v[c * VL + e] = (_Float16)(sc * (x[e] - ct[c * VL + e]));
+      for (int e = 0; e < 8; ++e) v[e] = (_Float16)(sc * ((upper ? x[8 + e] : x[e]) - ct[e]));
     }
   } else {
 #pragma unroll
@@ -809,7 +821,9 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
   }
 }
 
-// one lane per survivor: the scan kernel's arithmetic (ivf_flat.hip: t = q - x, acc = fma(t, t, acc) in dimension order)
+// one lane per survivor: the scan kernel's arithmetic (ivf_flat.hip: t = q - x, acc = fma(t, t, acc) in dimension order;
+// int8 / uint8 rows: the scan kernel's integer sum converted to float - every partial sum here is an integer below 2^24 for
+// dim <= 256, so the fp32 chain gives that same number)
 template <typename T>
 __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params a)
 {
@@ -1701,12 +1715,16 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
   c.rows16   = dev_buf<uint4>::persistent((size_t)rows / 32 * (v.dim / 16) * 64);
   c.row_term = dev_buf<uint32_t>::persistent((size_t)rows);
   if (v.padded_rows > 0) {
-    if (v.half_rows)
-      hipLaunchKernelGGL(flat_residual_stats_kernel<__half>, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data,
-                         v.centers, row_list.data(), v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
-    else
-      hipLaunchKernelGGL(flat_residual_stats_kernel<float>, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data,
-                         v.centers, row_list.data(), v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
+    auto stats = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(),
+                         v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
+    };
+    switch (v.elem) {
+      case 0: stats(flat_residual_stats_kernel<float>); break;
+      case 1: stats(flat_residual_stats_kernel<__half>); break;
+      case 2: stats(flat_residual_stats_kernel<int8_t>); break;
+      default: stats(flat_residual_stats_kernel<uint8_t>); break;
+    }
     const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
     float mx;
     memcpy(&mx, &mbits, 4);
@@ -1715,12 +1733,16 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
     c.maxres = mx;
     c.sc     = mx > 0.f ? std::exp2(std::floor(std::log2(16.0f / mx))) : 1.0f;
     const int64_t n_t = v.padded_rows / 32 * (v.dim / 16) * 64;
-    if (v.half_rows)
-      hipLaunchKernelGGL(flat_rows16_kernel<__half>, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers,
-                         row_list.data(), dn.data(), v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
-    else
-      hipLaunchKernelGGL(flat_rows16_kernel<float>, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers,
-                         row_list.data(), dn.data(), v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
+    auto rows16 = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(), dn.data(),
+                         v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
+    };
+    switch (v.elem) {
+      case 0: rows16(flat_rows16_kernel<float>); break;
+      case 1: rows16(flat_rows16_kernel<__half>); break;
+      case 2: rows16(flat_rows16_kernel<int8_t>); break;
+      default: rows16(flat_rows16_kernel<uint8_t>); break;
+    }
   }
   sync(res);
   c.data_ptr = v.data; c.rows = v.padded_rows; c.size = v.size;
@@ -1773,8 +1795,12 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices;
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = r.fail;
   profile_begin(res, "flat_rescore_kernel");
-  if (v.half_rows) hipLaunchKernelGGL(flat_rescore_kernel<__half>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s);
-  else             hipLaunchKernelGGL(flat_rescore_kernel<float>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s);
+  switch (v.elem) {
+    case 0: hipLaunchKernelGGL(flat_rescore_kernel<float>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s); break;
+    case 1: hipLaunchKernelGGL(flat_rescore_kernel<__half>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s); break;
+    case 2: hipLaunchKernelGGL(flat_rescore_kernel<int8_t>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s); break;
+    default: hipLaunchKernelGGL(flat_rescore_kernel<uint8_t>, dim3(grid + 1, 8), dim3(256), 0, res.stream, s); break;
+  }
   profile_end(res, "flat_rescore_kernel");
   profile_end(res, "ivf_flat_scan_kernel");
   return true;

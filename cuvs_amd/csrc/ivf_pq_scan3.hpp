@@ -96,7 +96,7 @@ struct flat3_view {  // the IVF-Flat index as ivf_flat.hip holds it
   uint32_t n_lists, dim, n_chunks;
   int64_t padded_rows, size;
   uint32_t max_list_len;
-  bool half_rows;  // fp16 rows (else fp32)
+  int elem;  // row type: 0 fp32, 1 fp16, 2 int8, 3 uint8
 };
 bool flat3_supported(uint32_t dim, int k);
 // filter + re-score of the tail phase (units from r.pair_off); r.rot_queries = the fp32 queries [nq, dim]; *r.fail is

@@ -406,6 +406,37 @@ def test_c2_shape_fp16_rows(monkeypatch):
         assert (gi == si).all() and (gd == sd).all()
 
 
+@pytest.mark.parametrize("dtype,scale", [(np.int8, 1 / 128), (np.uint8, 1 / 256)])
+def test_c2_shape_int8_rows(dtype, scale, monkeypatch):
+    """int8 / uint8 rows through the matrix-core tail phase (round 5; reference: interleaved_scan_impl.cuh:71-206 with the dp4a
+    metrics of metric_impl.cuh:12-49). The fp16 copy holds the residuals against the list centre, the survivors' distances are
+    integers below 2^24 in an fp32 chain = the scan kernel's integer sums: ids and distances equal the integer oracle and the
+    scan kernel (CUVS_AMD_FLAT_SCAN3=0), with the many exact ties integer data has, at 128 and 96 dimensions."""
+    import torch
+    from cuvs_amd.neighbors import ivf_flat
+
+    for dim in (128, 96):
+        monkeypatch.delenv("CUVS_AMD_FLAT_SCAN3", raising=False)
+        x, q = _mixture(60_000, dim, 320, seed=1700 + dim)
+        amp = 20.0 if dtype == np.int8 else 18.0
+        off = 0.0 if dtype == np.int8 else 128.0
+        lo, hi = (-128, 127) if dtype == np.int8 else (0, 255)
+        x = np.clip(np.rint(x * amp + off), lo, hi).astype(dtype)
+        q = np.clip(np.rint(q * amp + off), lo, hi).astype(dtype)
+        x[100:140] = x[50_000:50_040]  # exact duplicates: ties at equal distance are kept by row order
+        index = ivf_flat.build(ivf_flat.IndexParams(n_lists=24, kmeans_n_iters=10, kmeans_trainset_fraction=0.3),
+                               torch.from_numpy(x).cuda())
+        ex = ivf_flat.export_for_oracle(index, dtype)
+        for k in (10, 64):
+            gd, gi = _flat_search(index, q, k, 12)
+            od, oi = oracle.ivf_flat_search(ex, q, k, 12, coarse_scale=scale)
+            assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+            assert (gd == od).all()
+        monkeypatch.setenv("CUVS_AMD_FLAT_SCAN3", "0")
+        sd, si = _flat_search(index, q, 64, 12)
+        assert (gi == si).all() and (gd == sd).all()
+
+
 # ---------------------------------------------------------------------------------------------------------- C4 shape
 @pytest.fixture(scope="module")
 def cagra_768():
