@@ -783,7 +783,11 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   host_trace trace((res.tune.scan_debug & 8192) != 0, "ivf_flat_search");  // declared before the buffers: destroyed after them
   dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
   // two-phase schedule (ivf_common.hpp): nearest probe of every query first
-  uint32_t head = (n_probes > 8 && metric_is_l2(idx.metric) && !large_k) ? 1u : 0u;
+  // (inner product, round 5: a head phase only where the matrix-core tail phase follows it - the scan kernel has no early stop
+  // for dot products, but the filter prunes on the full-score bound the head phase leaves)
+  const bool ip3 = idx.metric == M_InnerProduct && !large_k && n_queries >= 256 && flat3_supported(idx.dim, k) &&
+                   res.tune.flat_scan3 != 0;
+  uint32_t head = (n_probes > 8 && (metric_is_l2(idx.metric) || ip3) && !large_k) ? 1u : 0u;
   if (res.tune.flat_head_probes >= 0) head = std::min<uint32_t>((uint32_t)res.tune.flat_head_probes, n_probes);
   const uint32_t n_labels = head > 0 ? 2 * idx.n_lists : idx.n_lists;
   dev_buf<uint32_t> probes(res, np_max), sorted_pairs(res, np_max), pair_off(res, n_labels + 1),
@@ -797,7 +801,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   const size_t esz = elem_size(et);
   // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): every row type (int8 / uint8 values and the distances between them
   // are exact in fp16 / fp32 up to dim 256), L2, batches large enough for a head phase
-  const bool use3 = head > 0 && metric_is_l2(idx.metric) && !large_k && n_queries >= 256 &&
+  const bool use3 = head > 0 && (metric_is_l2(idx.metric) || ip3) && !large_k && n_queries >= 256 &&
                     flat3_supported(idx.dim, k) && res.tune.flat_scan3 != 0;
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
@@ -930,7 +934,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
       if (use3) {
         pq3_run r{};
-        r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = 0;
+        r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = idx.metric == M_InnerProduct ? 1 : 0;
         r.sorted_pairs = sorted_pairs.data(); r.pair_off = pair_off.data(); r.probes = probes.data();
         if (raw3)
           hipLaunchKernelGGL(scale_floats_kernel, dim3(grid_blocks(nq * (int64_t)idx.dim, 256)), dim3(256), 0, res.stream, qf.data(),

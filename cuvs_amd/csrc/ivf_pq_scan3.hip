@@ -755,8 +755,11 @@ __global__ void flat_residual_stats_kernel(const uint8_t* __restrict__ data, con
     }
   }
   if (r0 < rows) dn[r] = acc;
-  const float wm = wave_reduce_max_f32(mx);
-  if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(wm));
+  const float wm = wave_reduce_max_f32(mx), wn = wave_reduce_max_f32(acc);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(max_bits, __float_as_uint(wm));
+    atomicMax(max_bits + 1, __float_as_uint(wn));  // (inner product: the threshold's bound on |x - c|)
+  }
 }
 
 // list id of every 64-row group (lists start at multiples of 64)
@@ -821,7 +824,8 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
   }
 }
 
-// one lane per survivor: the scan kernel's arithmetic (ivf_flat.hip: t = q - x, acc = fma(t, t, acc) in dimension order;
+// one lane per survivor: the scan kernel's arithmetic (ivf_flat.hip: t = q - x, acc = fma(t, t, acc) - inner product: acc =
+// fma(x, q, acc), score -acc - in dimension order;
 // int8 / uint8 rows: the scan kernel's integer sum converted to float - every partial sum here is an integer below 2^24 for
 // dim <= 256, so the fp32 chain gives that same number)
 template <typename T>
@@ -855,13 +859,17 @@ __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params 
           const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float t = qq[e] - x[e4 * 4 + e];
-            acc = __fmaf_rn(t, t, acc);
+            if (a.is_ip) {
+              acc = __fmaf_rn(x[e4 * 4 + e], qq[e], acc);
+            } else {
+              const float t = qq[e] - x[e4 * 4 + e];
+              acc = __fmaf_rn(t, t, acc);
+            }
           }
         }
       }
     }
-    pool_append_wave(a, ok, q, pair, row, acc);
+    pool_append_wave(a, ok, q, pair, row, a.is_ip ? -acc : acc);  // (inner product: smaller is better, as in the scan kernel)
   }
 }
 
@@ -1706,10 +1714,10 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
       return false;
     }
   }
-  dev_buf<uint32_t> row_list(res, (size_t)rows / 64), mxd(res, 1);
+  dev_buf<uint32_t> row_list(res, (size_t)rows / 64), mxd(res, 2);
   dev_buf<float> dn(res, (size_t)rows);
   HIP_TRY(hipMemsetAsync(row_list.data(), 0xff, row_list.bytes(), res.stream));
-  HIP_TRY(hipMemsetAsync(mxd.data(), 0, sizeof(uint32_t), res.stream));
+  HIP_TRY(hipMemsetAsync(mxd.data(), 0, 2 * sizeof(uint32_t), res.stream));
   hipLaunchKernelGGL(flat_group_lists_kernel, dim3(v.n_lists), dim3(64), 0, res.stream, v.list_offsets, v.list_sizes, v.n_lists,
                      row_list.data());
   c.rows16   = dev_buf<uint4>::persistent((size_t)rows / 32 * (v.dim / 16) * 64);
@@ -1725,9 +1733,11 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
       case 2: stats(flat_residual_stats_kernel<int8_t>); break;
       default: stats(flat_residual_stats_kernel<uint8_t>); break;
     }
-    const uint32_t mbits = to_host(res, mxd.data(), 1)[0];
-    float mx;
-    memcpy(&mx, &mbits, 4);
+    const auto mbits = to_host(res, mxd.data(), 2);
+    float mx, mn2;
+    memcpy(&mx, &mbits[0], 4);
+    memcpy(&mn2, &mbits[1], 4);
+    c.maxnorm = std::sqrt(mn2) * (1.0f + 1e-6f);
     // both GEMM operands are scaled by a power of two so that the largest residual component lands in (8, 16] (as the
     // codebook values of the IVF-PQ filter: the K-extension term stays below 16384)
     c.maxres = mx;
@@ -1765,12 +1775,15 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   f.units = units; f.n_units = r.unit_off + v.n_lists; f.xcd_ticket = r.xcd_ticket;
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = v.centers;
   f.codes = v.data; f.list_offsets = v.list_offsets; f.list_sizes = v.list_sizes;
-  f.row_term = cache.row_term.data(); f.query_kth = r.query_kth; f.qflag = r.qflag;
+  f.row_term = r.is_ip ? nullptr : cache.row_term.data(); f.query_kth = r.query_kth; f.qflag = r.qflag;
   f.surv = static_cast<uint2*>(r.surv); f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / grid);
   f.spill_cap = r.surv_cap - f.surv_cap * grid;
   f.n_probes = r.n_probes; f.rot_dim = v.dim; f.unit_rows = r.unit_rows;
-  f.sc = cache.sc; f.c1 = -2.0f / (cache.sc * cache.sc); f.cbmax = cache.maxres; f.dmax = 0.f; f.is_ip = 0; f.stats = r.stats;
+  f.sc = cache.sc; f.c1 = (r.is_ip ? -1.0f : -2.0f) / (cache.sc * cache.sc); f.cbmax = cache.maxres; f.dmax = r.is_ip ? cache.maxnorm : 0.f;
+  f.is_ip = r.is_ip; f.stats = r.stats;
   f.eps = 1.0f / 65536.0f; f.alpha = 0.f; f.bound_max = FLT_MAX;  // fp32 fma chain over (q - x)^2: 2 roundings per term + 'dim' adds
+  // inner product: score -(q . x) with x = c + d; the exact chain's error is below dim 2^-24 sum |q_i x_i| <= dim 2^-24 |q| (|c| + |d|)
+  if (r.is_ip) f.eps = (float)v.dim * (1.0f / 4194304.0f);
   f.rows16 = cache.rows16.data(); f.fail = r.fail;
   auto launch_filter = [&](auto kern) {
     profile_begin(res, "flat_filter_kernel");
@@ -1792,7 +1805,7 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   s.n_regions = grid; s.sub = 1;
   s.rot_queries = r.rot_queries; s.codes = v.data; s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt;
   s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head;
-  s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices;
+  s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices; s.is_ip = r.is_ip;
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = r.fail;
   profile_begin(res, "flat_rescore_kernel");
   switch (v.elem) {

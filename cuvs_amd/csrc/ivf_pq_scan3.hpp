@@ -81,7 +81,7 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h);
 struct flat3_cache {
   dev_buf<uint4> rows16;       // [padded_rows / 32][dim / 16][64 lanes] x 16 bytes
   dev_buf<uint32_t> row_term;  // [padded_rows] K-extension halves of -|x - c|^2 (1 - 2^-9) sc^2 / 2
-  float sc = 1.f, maxres = 0.f;
+  float sc = 1.f, maxres = 0.f, maxnorm = 0.f;  // scaling, largest |component| and largest norm of a residual
   const void* data_ptr = nullptr;
   int64_t rows = -1, size = -1;
   const void* failed_ptr = nullptr;  // index state for which the device had no room for the copy

@@ -437,6 +437,37 @@ def test_c2_shape_int8_rows(dtype, scale, monkeypatch):
         assert (gi == si).all() and (gd == sd).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8])
+def test_c2_shape_inner_product(dtype, monkeypatch):
+    """Inner product through the matrix-core tail phase (round 5): a head phase on the scan kernel leaves the k-th full score of the
+    nearest probe, the filter screens -(q.c + q.(x - c)) against it (filter_threshold_ip), survivors are re-scored with the scan
+    kernel's chain acc = fma(x, q, acc). Ids and distances equal the oracle's and the scan kernel's one-phase search
+    (CUVS_AMD_FLAT_SCAN3=0), k 10 and 64; rows of very different norms (the large ones win most dot products)."""
+    import torch
+    from cuvs_amd.neighbors import ivf_flat
+
+    monkeypatch.delenv("CUVS_AMD_FLAT_SCAN3", raising=False)
+    x, q = _mixture(60_000, 128, 320, seed=1800)
+    rng = np.random.default_rng(18)
+    x *= rng.uniform(0.5, 1.5, size=(len(x), 1)).astype(np.float32)
+    scale = 1.0
+    if dtype == np.int8:
+        x, q = np.clip(np.rint(x * 20.0), -128, 127), np.clip(np.rint(q * 20.0), -128, 127)
+        scale = 1 / 128
+    x, q = x.astype(dtype), q.astype(dtype)
+    index = ivf_flat.build(ivf_flat.IndexParams(n_lists=24, kmeans_n_iters=10, kmeans_trainset_fraction=0.3, metric="inner_product"),
+                           torch.from_numpy(x).cuda())
+    ex = ivf_flat.export_for_oracle(index, dtype)
+    for k in (10, 64):
+        gd, gi = _flat_search(index, q, k, 12)
+        od, oi = oracle.ivf_flat_search(ex, q, k, 12, metric="inner_product", coarse_scale=scale)
+        assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+        assert (gd == od).all()
+    monkeypatch.setenv("CUVS_AMD_FLAT_SCAN3", "0")
+    sd, si = _flat_search(index, q, 64, 12)
+    assert (gi == si).all() and (gd == sd).all()
+
+
 # ---------------------------------------------------------------------------------------------------------- C4 shape
 @pytest.fixture(scope="module")
 def cagra_768():
