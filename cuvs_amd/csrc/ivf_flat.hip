@@ -785,7 +785,8 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   // two-phase schedule (ivf_common.hpp): nearest probe of every query first
   // (inner product, round 5: a head phase only where the matrix-core tail phase follows it - the scan kernel has no early stop
   // for dot products, but the filter prunes on the full-score bound the head phase leaves)
-  const bool ip3 = idx.metric == M_InnerProduct && !large_k && n_queries >= 256 && flat3_supported(idx.dim, k) &&
+  const bool cos3 = idx.metric == M_CosineExpanded;
+  const bool ip3 = (idx.metric == M_InnerProduct || cos3) && !large_k && n_queries >= 256 && flat3_supported(idx.dim, k) &&
                    res.tune.flat_scan3 != 0;
   uint32_t head = (n_probes > 8 && (metric_is_l2(idx.metric) || ip3) && !large_k) ? 1u : 0u;
   if (res.tune.flat_head_probes >= 0) head = std::min<uint32_t>((uint32_t)res.tune.flat_head_probes, n_probes);
@@ -816,6 +817,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<uint4> units3(res, 2 * max_units), overflow3(res, (size_t)2 * overflow_cap);
   const float raw_mult = et == elem_t::i8 ? 128.0f : et == elem_t::u8 ? 256.0f : 1.0f;
   const bool raw3      = use3 && raw_mult != 1.0f;
+  dev_buf<float> q_unit(res, use3 && cos3 ? (size_t)bs * idx.dim : 0);  // cosine: unit-length queries for the filter
   dev_buf<float> q_raw(res, raw3 ? (size_t)bs * idx.dim : 0), c_raw(res, raw3 ? (size_t)idx.n_lists * idx.dim : 0);
   if (raw3)
     hipLaunchKernelGGL(scale_floats_kernel, dim3(grid_blocks((int64_t)c_raw.n, 256)), dim3(256), 0, res.stream, idx.centers.data(),
@@ -934,12 +936,21 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
       a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
       if (use3) {
         pq3_run r{};
-        r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = idx.metric == M_InnerProduct ? 1 : 0;
+        r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = (idx.metric == M_InnerProduct || cos3) ? 1 : 0;
         r.sorted_pairs = sorted_pairs.data(); r.pair_off = pair_off.data(); r.probes = probes.data();
         if (raw3)
           hipLaunchKernelGGL(scale_floats_kernel, dim3(grid_blocks(nq * (int64_t)idx.dim, 256)), dim3(256), 0, res.stream, qf.data(),
                              nq * (int64_t)idx.dim, raw_mult, q_raw.data());
         r.rot_queries = raw3 ? q_raw.data() : qf.data(); r.query_kth = query_kth.data();
+        if (cos3) {
+          // cos = q^ . x^ with x^ = c + (x^ - c): the filter's inner-product form on unit-length queries and rows (scale-free:
+          // the centres are means of unit-length rows); the exact chain works on the values the scan kernel reads
+          HIP_TRY(hipMemcpyAsync(q_unit.data(), qf.data(), (size_t)nq * idx.dim * sizeof(float), hipMemcpyDeviceToDevice, res.stream));
+          normalize_rows(res, q_unit.data(), nq, idx.dim);
+          r.rescore_queries = r.rot_queries;
+          r.rot_queries     = q_unit.data();
+          r.cosine          = 1;
+        }
         r.cand_d = cand_d.data(); r.cand_i = cand_i.data(); r.cand_r = cand_r.data();
         r.qflag = qstate.data(); r.qcnt = qstate.data() + bs; r.counters = qstate.data() + 2 * bs;
         r.surv_cnt = qstate.data() + 2 * bs + 2;
@@ -948,9 +959,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets3.data(); r.filter_bits = filter_bits;
         r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
-        flat3_view v{idx.data.data(), raw3 ? c_raw.data() : idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
+        flat3_view v{idx.data.data(), (raw3 && !cos3) ? c_raw.data() : idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
                      idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len,
-                     et == elem_t::f32 ? 0 : et == elem_t::f16 ? 1 : et == elem_t::i8 ? 2 : 3};
+                     et == elem_t::f32 ? 0 : et == elem_t::f16 ? 1 : et == elem_t::i8 ? 2 : 3, cos3};
         const bool tdbg = (res.tune.scan_debug & 1024) != 0;
         auto now = [&]() { if (tdbg) sync(res); return std::chrono::steady_clock::now(); };
         const auto t0 = now();

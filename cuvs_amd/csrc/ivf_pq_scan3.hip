@@ -733,7 +733,7 @@ __device__ inline void chunk_to_float(const uint4& w, float (&x)[16 / sizeof(T)]
 template <typename T>
 __global__ void flat_residual_stats_kernel(const uint8_t* __restrict__ data, const float* __restrict__ centers,
                                            const uint32_t* __restrict__ row_list, int64_t rows, uint32_t dim, uint32_t n_chunks,
-                                           float* __restrict__ dn, uint32_t* __restrict__ max_bits)
+                                           float* __restrict__ dn, uint32_t* __restrict__ max_bits, float* __restrict__ inv_norm)
 {
   const int64_t r0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r  = min(r0, rows - 1);
@@ -743,16 +743,30 @@ __global__ void flat_residual_stats_kernel(const uint8_t* __restrict__ data, con
     const uint4* cp = reinterpret_cast<const uint4*>(data) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
     const float* ct = centers + (size_t)L * dim;
     constexpr int VL = 16 / sizeof(T);
+    float inv = 1.0f;
+    if (inv_norm != nullptr) {  // cosine: residuals of the unit-length row
+      float n2 = 0.f;
+      for (uint32_t c = 0; c < n_chunks; ++c) {
+        float x[VL];
+        chunk_to_float<T>(cp[(size_t)c * 64], x);
+#pragma unroll
+        for (int e = 0; e < VL; ++e) n2 = __fmaf_rn(x[e], x[e], n2);
+      }
+      inv = n2 > 0.f ? 1.0f / sqrtf(n2) : 0.f;
+    }
     for (uint32_t c = 0; c < n_chunks; ++c) {
       float x[VL];
       chunk_to_float<T>(cp[(size_t)c * 64], x);
 #pragma unroll
       for (int e = 0; e < VL; ++e) {
-        const float d = x[e] - ct[c * VL + e];
+        const float d = x[e] * inv - ct[c * VL + e];
         acc = __fmaf_rn(d, d, acc);
         mx  = fmaxf(mx, fabsf(d));
       }
     }
+    if (inv_norm != nullptr && r0 < rows) inv_norm[r] = inv;
+  } else if (inv_norm != nullptr && r0 < rows) {
+    inv_norm[r] = 0.f;
   }
   if (r0 < rows) dn[r] = acc;
   const float wm = wave_reduce_max_f32(mx), wn = wave_reduce_max_f32(acc);
@@ -777,7 +791,8 @@ __global__ void flat_group_lists_kernel(const uint32_t* __restrict__ list_offset
 template <typename T>
 __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float* __restrict__ centers,
                                    const uint32_t* __restrict__ row_list, const float* __restrict__ dn, int64_t rows, uint32_t dim,
-                                   uint32_t n_chunks, float sc, uint4* __restrict__ rows16, uint32_t* __restrict__ term)
+                                   uint32_t n_chunks, float sc, uint4* __restrict__ rows16, uint32_t* __restrict__ term,
+                                   const float* __restrict__ inv_norm)
 {
   const uint32_t nst = dim / 16;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, step, lane)
@@ -791,6 +806,7 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
   if (L != 0xffffffffu) {
     const uint4* cp = reinterpret_cast<const uint4*>(data) + ((size_t)(r >> 6) * n_chunks) * 64 + (r & 63);
     const float* ct = centers + (size_t)L * dim + d0;
+    const float inv = inv_norm != nullptr ? inv_norm[r] : 1.0f;
     constexpr int VL = 16 / sizeof(T);  // 8 dimensions = two chunks of fp32, one of fp16 or half a chunk of int8 / uint8
     if constexpr (VL <= 8) {
 #pragma unroll
@@ -798,14 +814,14 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
         float x[VL];
         chunk_to_float<T>(cp[(size_t)(d0 / VL + c) * 64], x);
 #pragma unroll
-        for (int e = 0; e < VL; ++e) v[c * VL + e] = (_Float16)(sc * (x[e] - ct[c * VL + e]));
+        for (int e = 0; e < VL; ++e) v[c * VL + e] = (_Float16)(sc * (x[e] * inv - ct[c * VL + e]));
       }
     } else {
       float x[VL];
       chunk_to_float<T>(cp[(size_t)(d0 / VL) * 64], x);
       const bool upper = (d0 & 8u) != 0u;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (_Float16)(sc * ((upper ? x[8 + e] : x[e]) - ct[e]));
+      for (int e = 0; e < 8; ++e) v[e] = (_Float16)(sc * ((upper ? x[8 + e] : x[e]) * inv - ct[e]));
     }
   } else {
 #pragma unroll
@@ -845,7 +861,7 @@ __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params 
       const int64_t sid = a.indices[row];
       ok = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
     }
-    float acc = 0.f;
+    float acc = 0.f, xn2 = 0.f, qn2 = 0.f;  // (cosine: |x|^2 and |q|^2 by the scan kernel's / the query tiles' chains)
     if (ok) {
       const float* rq = a.rot_queries + (size_t)q * a.dim;
       const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
@@ -861,6 +877,10 @@ __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params 
           for (int e = 0; e < 4; ++e) {
             if (a.is_ip) {
               acc = __fmaf_rn(x[e4 * 4 + e], qq[e], acc);
+              if (a.is_ip == 2) {
+                xn2 = __fmaf_rn(x[e4 * 4 + e], x[e4 * 4 + e], xn2);
+                qn2 = __fmaf_rn(qq[e], qq[e], qn2);
+              }
             } else {
               const float t = qq[e] - x[e4 * 4 + e];
               acc = __fmaf_rn(t, t, acc);
@@ -869,6 +889,7 @@ __global__ __launch_bounds__(256) void flat_rescore_kernel(const rescore_params 
         }
       }
     }
+    if (a.is_ip == 2) acc = acc / (sqrtf(qn2) * sqrtf(xn2));  // cos, as ivf_flat_scan_kernel<.., 2> forms it
     pool_append_wave(a, ok, q, pair, row, a.is_ip ? -acc : acc);  // (inner product: smaller is better, as in the scan kernel)
   }
 }
@@ -1715,7 +1736,7 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
     }
   }
   dev_buf<uint32_t> row_list(res, (size_t)rows / 64), mxd(res, 2);
-  dev_buf<float> dn(res, (size_t)rows);
+  dev_buf<float> dn(res, (size_t)rows), inv_norm(res, v.unit_rows ? (size_t)rows : 0);
   HIP_TRY(hipMemsetAsync(row_list.data(), 0xff, row_list.bytes(), res.stream));
   HIP_TRY(hipMemsetAsync(mxd.data(), 0, 2 * sizeof(uint32_t), res.stream));
   hipLaunchKernelGGL(flat_group_lists_kernel, dim3(v.n_lists), dim3(64), 0, res.stream, v.list_offsets, v.list_sizes, v.n_lists,
@@ -1725,7 +1746,7 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
   if (v.padded_rows > 0) {
     auto stats = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(),
-                         v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data());
+                         v.padded_rows, v.dim, v.n_chunks, dn.data(), mxd.data(), inv_norm.data());
     };
     switch (v.elem) {
       case 0: stats(flat_residual_stats_kernel<float>); break;
@@ -1745,7 +1766,7 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
     const int64_t n_t = v.padded_rows / 32 * (v.dim / 16) * 64;
     auto rows16 = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(), dn.data(),
-                         v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data());
+                         v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data(), inv_norm.data());
     };
     switch (v.elem) {
       case 0: rows16(flat_rows16_kernel<float>); break;
@@ -1803,9 +1824,9 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   rescore_params s{};
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes;
   s.n_regions = grid; s.sub = 1;
-  s.rot_queries = r.rot_queries; s.codes = v.data; s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt;
+  s.rot_queries = r.rescore_queries != nullptr ? r.rescore_queries : r.rot_queries; s.codes = v.data; s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt;
   s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head;
-  s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices; s.is_ip = r.is_ip;
+  s.n_chunks = v.n_chunks; s.dim = v.dim; s.filter_bits = r.filter_bits; s.indices = v.indices; s.is_ip = r.cosine ? 2 : r.is_ip;
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = r.fail;
   profile_begin(res, "flat_rescore_kernel");
   switch (v.elem) {

@@ -19,6 +19,8 @@ struct pq3_run {
   const uint32_t* pair_off;      // [2 n_lists + 1] label offsets into sorted_pairs (head labels, then tail labels)
   const uint32_t* probes;        // [n_pairs] list of every pair
   const float* rot_queries;
+  const float* rescore_queries = nullptr;  // IVF-Flat cosine: the raw queries of the exact chain (rot_queries: unit length)
+  int cosine = 0;
   const uint32_t* query_kth;     // bound keys after the head phase
   float* cand_d;                 // [nq, n_probes * k]: head segments first, the rest is the query's pool
   uint32_t* cand_i;
@@ -97,6 +99,7 @@ struct flat3_view {  // the IVF-Flat index as ivf_flat.hip holds it
   int64_t padded_rows, size;
   uint32_t max_list_len;
   int elem;  // row type: 0 fp32, 1 fp16, 2 int8, 3 uint8
+  bool unit_rows = false;  // cosine: the fp16 copy holds x / |x| - c (the centres are means of unit-length rows)
 };
 bool flat3_supported(uint32_t dim, int k);
 // filter + re-score of the tail phase (units from r.pair_off); r.rot_queries = the fp32 queries [nq, dim]; *r.fail is

@@ -437,12 +437,15 @@ def test_c2_shape_int8_rows(dtype, scale, monkeypatch):
         assert (gi == si).all() and (gd == sd).all()
 
 
+@pytest.mark.parametrize("metric", ["inner_product", "cosine"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float16, np.int8])
-def test_c2_shape_inner_product(dtype, monkeypatch):
+def test_c2_shape_inner_product(dtype, metric, monkeypatch):
     """Inner product through the matrix-core tail phase (round 5): a head phase on the scan kernel leaves the k-th full score of the
     nearest probe, the filter screens -(q.c + q.(x - c)) against it (filter_threshold_ip), survivors are re-scored with the scan
     kernel's chain acc = fma(x, q, acc). Ids and distances equal the oracle's and the scan kernel's one-phase search
-    (CUVS_AMD_FLAT_SCAN3=0), k 10 and 64; rows of very different norms (the large ones win most dot products)."""
+    (CUVS_AMD_FLAT_SCAN3=0), k 10 and 64; rows of very different norms (the large ones win most dot products). Cosine: the same
+    filter on unit-length queries and rows (the fp16 copy holds x / |x| - c), the exact chain forms dot / (|q| |x|) as the scan kernel
+    does."""
     import torch
     from cuvs_amd.neighbors import ivf_flat
 
@@ -455,12 +458,12 @@ def test_c2_shape_inner_product(dtype, monkeypatch):
         x, q = np.clip(np.rint(x * 20.0), -128, 127), np.clip(np.rint(q * 20.0), -128, 127)
         scale = 1 / 128
     x, q = x.astype(dtype), q.astype(dtype)
-    index = ivf_flat.build(ivf_flat.IndexParams(n_lists=24, kmeans_n_iters=10, kmeans_trainset_fraction=0.3, metric="inner_product"),
+    index = ivf_flat.build(ivf_flat.IndexParams(n_lists=24, kmeans_n_iters=10, kmeans_trainset_fraction=0.3, metric=metric),
                            torch.from_numpy(x).cuda())
     ex = ivf_flat.export_for_oracle(index, dtype)
     for k in (10, 64):
         gd, gi = _flat_search(index, q, k, 12)
-        od, oi = oracle.ivf_flat_search(ex, q, k, 12, metric="inner_product", coarse_scale=scale)
+        od, oi = oracle.ivf_flat_search(ex, q, k, 12, metric=metric, coarse_scale=scale)
         assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
         assert (gd == od).all()
     monkeypatch.setenv("CUVS_AMD_FLAT_SCAN3", "0")
