@@ -235,6 +235,18 @@ __global__ void flat_query_tiles_int_kernel(const work_item* __restrict__ items,
   }
 }
 
+// the compiler sinks every load of a group to its first use (one load, one wait, sixteen fmas, next load ...); an empty asm that
+// takes all four as operands keeps them issued back to back
+__device__ inline void keep_loads_together(uint4 (&w)[kStopEvery])
+{
+  static_assert(kStopEvery == 4, "four chunks per group");
+  // (not volatile: an asm with unmodelled side effects counts as a memory clobber, and the wave-uniform loads of the query tile
+  // stop being scalar loads)
+  asm(""
+      : "+v"(w[0].x), "+v"(w[0].y), "+v"(w[0].z), "+v"(w[0].w), "+v"(w[1].x), "+v"(w[1].y), "+v"(w[1].z), "+v"(w[1].w),
+                 "+v"(w[2].x), "+v"(w[2].y), "+v"(w[2].z), "+v"(w[2].w), "+v"(w[3].x), "+v"(w[3].y), "+v"(w[3].z), "+v"(w[3].w));
+}
+
 // IP (inner product) is a template argument: tested at run time inside the unrolled element loop it became a
 // scalar branch per element
 // ALL: the non-fused path (every score written out, no top lists) - a template argument so that the fused kernels
@@ -318,53 +330,72 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
         else return __builtin_amdgcn_udot4(x, y, c, false);
       };
       uint32_t done = 0;
-      for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-        if (!IP && !ALL && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
+      // the kStopEvery chunk loads between two early-stop tests are issued together (one load, one wait per chunk left the
+      // wave with 1 KiB in flight: the head phase of C2 ran at half the HBM rate)
+      for (uint32_t ch0 = 0; ch0 < a.n_chunks; ch0 += kStopEvery) {
+        if (!IP && !ALL && ch0 > 0) {
           bool below = false;
 #pragma unroll
           for (int j = 0; j < QPB; ++j)
-            below = below || ((float)(iacc_t)(sx2 + (iacc_t)q2[(ch - 1) * QPB + j] - 2 * dot[j]) <= bf[j]);
+            below = below || ((float)(iacc_t)(sx2 + (iacc_t)q2[(ch0 - 1) * QPB + j] - 2 * dot[j]) <= bf[j]);
           if (__ballot(valid && below) == 0ull) break;  // wave-uniform
         }
-        const uint4 cw       = cp[(size_t)ch * 64];
-        const uint32_t xw[4] = {cw.x, cw.y, cw.z, cw.w};
-        const uint32_t* qr   = qw + (size_t)ch * QPB * 4;
+        uint4 cws[kStopEvery];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (!IP) sx2 = dot4(xw[u], xw[u], sx2);
+        for (int c = 0; c < kStopEvery; ++c) cws[c] = cp[(size_t)min(ch0 + (uint32_t)c, a.n_chunks - 1u) * 64];
+        keep_loads_together(cws);
 #pragma unroll
-          for (int j = 0; j < QPB; ++j) dot[j] = dot4(xw[u], qr[j * 4 + u], dot[j]);
+        for (int c = 0; c < kStopEvery; ++c) {
+          const uint32_t ch = ch0 + (uint32_t)c;
+          if (ch >= a.n_chunks) break;  // wave-uniform
+          const uint32_t xw[4] = {cws[c].x, cws[c].y, cws[c].z, cws[c].w};
+          const uint32_t* qr   = qw + (size_t)ch * QPB * 4;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (!IP) sx2 = dot4(xw[u], xw[u], sx2);
+#pragma unroll
+            for (int j = 0; j < QPB; ++j) dot[j] = dot4(xw[u], qr[j * 4 + u], dot[j]);
+          }
+          done = ch + 1;
         }
-        done = ch + 1;
       }
       // after an early stop the partial sums (all above every bound) stand in for the scores: rejected below
 #pragma unroll
       for (int j = 0; j < QPB; ++j)
         acc[j] = IP ? (float)dot[j] : (float)(iacc_t)(sx2 + (iacc_t)q2[(done - 1) * QPB + j] - 2 * dot[j]);
     } else {
-    for (uint32_t ch = 0; ch < a.n_chunks; ++ch) {
-      if (!IP && !ALL && ch > 0 && (ch & (kStopEvery - 1)) == 0) {
+    for (uint32_t ch0 = 0; ch0 < a.n_chunks; ch0 += kStopEvery) {
+      if (!IP && !ALL && ch0 > 0) {
         bool below = false;
 #pragma unroll
         for (int j = 0; j < QPB; ++j) below = below || (accv[j >> 1][j & 1] <= bf[j]);
         if (__ballot(valid && below) == 0ull) break;  // wave-uniform
       }
-      const uint4 cw = cp[(size_t)ch * 64];  // padded rows of a group are zero-filled: always readable
-      const T* el    = reinterpret_cast<const T*>(&cw);
+      // (the chunk loads between two early-stop tests issued together: see the integer path)
+      uint4 cws[kStopEvery];  // padded rows of a group are zero-filled: always readable
 #pragma unroll
-      for (int e = 0; e < VL; ++e) {
-        const float x   = to_float(el[e]);
-        const float* qr = qt + (size_t)(ch * VL + e) * QPB;
-        const f32x2_t qv[QPB / 2] = {f32x2_t{qr[0], qr[1]}, f32x2_t{qr[2], qr[3]}, f32x2_t{qr[4], qr[5]}, f32x2_t{qr[6], qr[7]}};
-        const f32x2_t xx = f32x2_t{x, x};
-        if (METRIC == 2) xn2 = __fmaf_rn(x, x, xn2);
+      for (int c = 0; c < kStopEvery; ++c) cws[c] = cp[(size_t)min(ch0 + (uint32_t)c, a.n_chunks - 1u) * 64];
+      keep_loads_together(cws);
 #pragma unroll
-        for (int j = 0; j < QPB / 2; ++j) {
-          if (!IP) {
-            const f32x2_t t = qv[j] - xx;
-            accv[j]         = __builtin_elementwise_fma(t, t, accv[j]);
-          } else {
-            accv[j] = __builtin_elementwise_fma(xx, qv[j], accv[j]);
+      for (int c = 0; c < kStopEvery; ++c) {
+        const uint32_t ch = ch0 + (uint32_t)c;
+        if (ch >= a.n_chunks) break;  // wave-uniform
+        const T* el = reinterpret_cast<const T*>(&cws[c]);
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+          const float x   = to_float(el[e]);
+          const float* qr = qt + (size_t)(ch * VL + e) * QPB;
+          const f32x2_t qv[QPB / 2] = {f32x2_t{qr[0], qr[1]}, f32x2_t{qr[2], qr[3]}, f32x2_t{qr[4], qr[5]}, f32x2_t{qr[6], qr[7]}};
+          const f32x2_t xx = f32x2_t{x, x};
+          if (METRIC == 2) xn2 = __fmaf_rn(x, x, xn2);
+#pragma unroll
+          for (int j = 0; j < QPB / 2; ++j) {
+            if (!IP) {
+              const f32x2_t t = qv[j] - xx;
+              accv[j]         = __builtin_elementwise_fma(t, t, accv[j]);
+            } else {
+              accv[j] = __builtin_elementwise_fma(xx, qv[j], accv[j]);
+            }
           }
         }
       }
