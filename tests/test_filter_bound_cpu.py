@@ -164,3 +164,119 @@ def test_inner_product_row_at_the_bound_survives(lut, acc):
             m = nq * ((eps + 7.63e-6) * nc + (eps + 1.0 / 512.0) * dmax)
             thr = s_exact + float(qc) + (abs(float(qc)) + abs(s_exact)) * 1e-6 + m + mabs + alpha
             assert screened <= thr, (scale, trial, screened, thr, s_exact)
+
+
+# ---------------------------------------------------------------------------------------------- IVF-Flat (FLAT builds of the filter)
+# ivf_pq_scan3.hip flat3_prepare / flat3_tail: A operands = fl16(sc (x - c)) (cosine: x / |x| - c), B operands = fl16(sc (q - c))
+# (dot-product metrics: fl16(sc q)), the exact score is the scan kernel's fp32 fma chain in dimension order.
+def chain_l2(q, x):
+    acc = F32(0)
+    for i in range(len(q)):
+        t = F32(q[i] - x[i])
+        acc = F32(np.float64(t) * np.float64(t) + np.float64(acc))
+    return acc
+
+
+def chain_dot(x, q):
+    acc = F32(0)
+    for i in range(len(q)):
+        acc = F32(np.float64(x[i]) * np.float64(q[i]) + np.float64(acc))
+    return acc
+
+
+def flat_rows(rng, n, D, kind):
+    """rows of one list around a centre: floats of any scale, or integer-valued rows as int8 / uint8 indexes hold them"""
+    if kind == "int8":
+        c = rng.uniform(-40, 40, D).astype(F32)
+        x = np.clip(np.rint(c + rng.standard_normal((n, D)) * rng.uniform(1, 60)), -128, 127).astype(F32)
+    elif kind == "uint8":
+        c = rng.uniform(60, 200, D).astype(F32)
+        x = np.clip(np.rint(c + rng.standard_normal((n, D)) * rng.uniform(1, 60)), 0, 255).astype(F32)
+    else:
+        scale = 10.0 ** rng.uniform(-3, 3)
+        c = (rng.standard_normal(D) * scale).astype(F32)
+        x = (c + rng.standard_normal((n, D)).astype(F32) * F32(scale * 10.0 ** rng.uniform(-2, 0.5))).astype(F32)
+    return c, x
+
+
+def flat_tables(c, x):
+    """what flat_residual_stats_kernel leaves: the scaling, the largest |component| and the largest norm of a residual"""
+    d = (x - c).astype(F32)
+    maxres = float(np.abs(d).max())
+    sc = 2.0 ** np.floor(np.log2(16.0 / maxres)) if maxres > 0 else 1.0
+    dn = np.array([float(chain_dot(r, r)) for r in d], F32)  # the kernel's fp32 chain of squares
+    return d, sc, maxres, dn
+
+
+@pytest.mark.parametrize("kind", ["float", "int8", "uint8"])
+def test_flat_l2_row_at_the_bound_survives(kind):
+    rng = np.random.default_rng({"float": 21, "int8": 22, "uint8": 23}[kind])
+    D = 128
+    for rep in range(12):
+        c, x = flat_rows(rng, 24, D, kind)
+        d, sc, maxres, dn = flat_tables(c, x)
+        for i in range(len(x)):
+            # queries from "on top of the row" to far away (integer-valued for the integer kinds: the queries' type is the rows')
+            q = (x[i] + rng.standard_normal(D) * maxres * 10.0 ** rng.uniform(-3, 1)).astype(F32)
+            if kind != "float":
+                q = np.clip(np.rint(q), -128 if kind == "int8" else 0, 127 if kind == "int8" else 255).astype(F32)
+            s_exact = float(chain_l2(q, x[i]))
+            r = (q - c).astype(F32)
+            if np.abs(F32(sc) * r).max() >= 60000:  # not served: the query survives everything
+                continue
+            rn = float(chain_dot(r, r))
+            t = F32(-0.5) * F32(sc) * F32(sc) * F32(dn[i] * F32(1.0 - 1.0 / 512.0))
+            hi = F16(t)
+            lo = F16(F32(t) - F32(hi))
+            acc = F32(np.float64(F32(gemm16(r, d[i], sc, rng))) + np.float64(hi) + np.float64(lo))
+            screened = float(acc) * (-2.0 / (sc * sc))
+            eps = 1.0 / 65536.0
+            mabs = 2.0 ** -23 / sc * (np.sqrt(D * rn) + D * maxres)
+            thr = s_exact * (1.0 + 2.0 * eps) + mabs - rn * (1.0 - 1.0 / 512.0)
+            thr = float(F32(thr)) + abs(float(F32(thr))) * 2.4e-7 + 1e-37
+            assert screened <= thr, (kind, rep, i, screened, thr, s_exact, rn, float(dn[i]))
+
+
+@pytest.mark.parametrize("cosine", [False, True])
+@pytest.mark.parametrize("kind", ["float", "int8"])
+def test_flat_dot_product_row_at_the_bound_survives(kind, cosine):
+    """inner product: score -(x . q) by the chain acc = fma(x, q, acc); cosine: -(x . q) / (|q| |x|) with the norms' own chains,
+    screened on unit-length operands (flat3_view::unit_rows, ivf_flat.hip q_unit)"""
+    rng = np.random.default_rng(31 + (kind == "int8") + 2 * cosine)
+    D = 128
+    for rep in range(12):
+        c, x = flat_rows(rng, 24, D, kind)
+        if cosine:
+            inv = np.array([F32(1.0) / np.sqrt(chain_dot(r, r)) if chain_dot(r, r) > 0 else F32(0) for r in x], F32)
+            xu = (x * inv[:, None]).astype(F32)
+            c = xu.mean(0).astype(F32)  # the centres of a cosine index are means of unit-length rows
+            d, sc, maxres, dn = flat_tables(c, xu)
+        else:
+            d, sc, maxres, dn = flat_tables(c, x)
+        dmax = float(np.sqrt(dn.max())) * (1.0 + 1e-6)
+        eps = D / 4194304.0
+        for i in range(len(x)):
+            q = (x[i] * 10.0 ** rng.uniform(-1, 1) + rng.standard_normal(D) * np.abs(x[i]).max() * 10.0 ** rng.uniform(-2, 1)).astype(F32)
+            if kind != "float":
+                q = np.clip(np.rint(q), -128, 127).astype(F32)
+            if not np.any(q):
+                continue
+            dot = chain_dot(x[i], q)
+            if cosine:
+                s_exact = -float(F32(dot / F32(np.sqrt(chain_dot(q, q)) * np.sqrt(chain_dot(x[i], x[i])))))
+                qf = (q / F32(np.sqrt(np.sum(q.astype(np.float64) ** 2)))).astype(F32)  # normalize_rows
+            else:
+                s_exact = -float(dot)
+                qf = q
+            if np.abs(F32(sc) * qf).max() >= 60000:
+                continue
+            qn = float(np.sum(qf.astype(np.float64) ** 2))
+            cn = float(np.sum(c.astype(np.float64) ** 2))
+            qc = float(chain_dot(qf, c))
+            screened = gemm16(qf, d[i], sc, rng) * (-1.0 / (sc * sc))
+            nq, nc = np.sqrt(qn), np.sqrt(cn)
+            mabs = 2.0 ** -23 / sc * (np.sqrt(D) * nq + D * maxres)
+            m = nq * ((eps + 7.63e-6) * nc + (eps + 1.0 / 512.0) * dmax)
+            thr = s_exact + qc + (abs(qc) + abs(s_exact)) * 1e-6 + m + mabs
+            thr = float(F32(thr)) + abs(float(F32(thr))) * 2.4e-7 + 1e-37
+            assert screened <= thr, (kind, cosine, rep, i, screened, thr, s_exact, qc)
