@@ -135,6 +135,25 @@ struct wave_top {
 };
 
 
+// 64 (distance, row) pairs, one per lane, into ascending (distance, row) order: lane r ends up with rank r - a bitonic network
+// of 21 compare-exchange steps. What a scan kernel's wave does with the candidates of its FIRST tile instead of 64 serial
+// insertions into an empty list (no NaNs among the distances: the caller checks).
+__device__ inline void wave_sort64(float& d, uint32_t& i, const int lane)
+{
+#pragma unroll
+  for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      const float od    = __shfl_xor(d, j2, 64);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)i, j2, 64);
+      const bool other_less = (od < d) || (od == d && oi < i);
+      const bool same       = od == d && oi == i;
+      const bool take_min   = ((lane & j2) == 0) == ((lane & k2) == 0);  // (k2 == 64: every block ascends)
+      if (take_min ? other_less : (!other_less && !same)) { d = od; i = oi; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ non-fused path: k beyond the register top lists
 // The reference falls back from its fused top-k to "write every score, then select_k" when k exceeds the warp-sort
 // capacity (is_local_topk_feasible, ivf_pq_compute_similarity_impl.cuh:39-45; ivf_pq_search.cuh:620,

@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
 #pragma unroll
   for (int j = 0; j < QPB; ++j) top[j].init();
   const int kr          = (int)a.k - 1;
+  uint32_t fresh        = 0xffu;  // bit j: this wave's list of query j is still empty (wave-uniform)
   const size_t g0       = (size_t)(base_row >> 6);
   const uint4* data16   = reinterpret_cast<const uint4*>(a.data);
   const uint32_t n_tile = (len + 63) / 64;
@@ -442,6 +443,21 @@ __global__ __launch_bounds__(kFlatThreads) void ivf_flat_scan_kernel(flat_scan_a
       const uint32_t bound = kthb[j];
       unsigned long long m = __ballot(valid && float_to_key(dj) <= bound);
       if (m == 0ull) continue;
+      // the wave's first candidates of query j (its list is empty: cold bounds let nearly every row of the first tile through):
+      // one sorting network instead of up to 64 serial insertions - the list that results is the same, entry for entry
+      const bool first = ((fresh >> j) & 1u) != 0u;
+      fresh &= ~(1u << j);
+      if (first && a.filter_bits == nullptr && __popcll(m) >= 12 && __ballot(dj != dj) == 0ull) {
+        const bool c = ((m >> lane) & 1ull) != 0ull;
+        float sd     = c ? dj : INFINITY;
+        uint32_t si  = c ? tile0 + (uint32_t)lane : 0xffffffffu;
+        wave_sort64(sd, si, lane);
+        top[j].d[0] = sd;
+        top[j].i[0] = si;
+        const float kd0 = top[j].rank_d(kr);
+        if (lane == 0 && kd0 < INFINITY) atomicMin(&kthb[j], float_to_key(kd0));
+        continue;
+      }
       float kd      = top[j].rank_d(kr);
       uint32_t ki   = top[j].rank_i(kr);
       bool improved = false;
