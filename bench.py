@@ -724,24 +724,24 @@ def extra_c2(res, dev):
                                  "matrix-core tail phase. logical_scan_gbs = list bytes per pair and kernel second (SURVEY 8d)"}}
 
 
-def extra_c4_clustered(res, dev, rows=2_000_000, latent=24, modes=4096):
-    """CAGRA on the clustered generator family of C2 / C3 (many tight modes: the kNN graph falls apart into components),
-    with and without index_params.guarantee_connectivity (cagra.hpp:193; graph_core.cuh:1186-1581), itopk 64 and 256."""
-    from cuvs_amd.neighbors import brute_force, cagra
+def extra_c4_family(res, dev, rows=2_000_000, latent=24):
+    """CAGRA (degree 64, intermediate 128) on the two ends of the generator family, 2M x 768 fp16 each: ONE cloud (what rounds 2-5 quoted
+    C4 on) and 4096 TIGHT modes (spread 0.35: the kNN graph falls apart into components, a walk from random seeds stays in the modes
+    it lands in - guarantee_connectivity joins the components but not the walk). itopk 64 and 256, k = 10, 10k queries."""
+    from cuvs_amd.neighbors import cagra
 
     nq = 10000
-    x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
-    gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=modes, out=x)
-    q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
-    gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=modes, out=q)
-    gt = exact_topk_fp64(x, q[:1000], 10, chunk=250_000).cpu().numpy()  # fp64 in torch, independent of this library
-    out = {"config": f"C4-clustered CAGRA {rows}x768 fp16, {modes} modes in a {latent}-d latent space, graph_degree=64, batch=10000 k=10"}
-    for guarantee in (False, True):
+    out = {"config": f"CAGRA {rows}x768 fp16 graph_degree=64 batch=10000 k=10, generator bench.gen_rows with a {latent}-d latent space", "corpora": []}
+    for modes, spread in ((1, 0.35), (4096, 0.35)):
+        x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
+        gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=modes, out=x, spread=spread)
+        q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
+        gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=modes, out=q, spread=spread)
+        gt = exact_topk_fp64(x, q[:1000], 10, chunk=250_000).cpu().numpy()  # fp64 in torch, independent of this library
         t0 = time.time()
-        idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64, guarantee_connectivity=guarantee), x,
-                          resources=res)
+        idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res)
         res.sync()
-        line = {"build_seconds": round(time.time() - t0, 1)}
+        line = {"modes": modes, "spread": spread, "build_seconds": round(time.time() - t0, 1)}
         for itopk in (64, 256):
             sp = cagra.SearchParams(itopk_size=itopk, algo="auto")
             nb = torch.empty((nq, 10), dtype=torch.int32, device=dev)
@@ -749,29 +749,21 @@ def extra_c4_clustered(res, dev, rows=2_000_000, latent=24, modes=4096):
             dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 3, 1)
             rec = recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt)
             line[f"itopk_{itopk}"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(rec, 4)}
-        # more random candidates per seed slot (num_random_samplings, device_common_jit.cuh:60-83): does a better start make
-        # the clustered corpus navigable?
-        for samplings in (4, 16):
-            sp = cagra.SearchParams(itopk_size=64, algo="auto", num_random_samplings=samplings)
-            nb = torch.empty((nq, 10), dtype=torch.int32, device=dev)
-            dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
-            dt = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 3, 1)
-            rec = recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt)
-            line[f"itopk_64_samplings_{samplings}"] = {"ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(rec, 4)}
-        out["guarantee_connectivity" if guarantee else "plain"] = line
-        del idx
+        out["corpora"].append(line)
+        del idx, x, q
+        torch.cuda.empty_cache()
     return out
 
 
-def extra_c4(res, dev, rows, latent, modes=1):
+def extra_c4(res, dev, rows, latent, modes=1, spread=0.35):
     """C4: CAGRA rows x 768 fp16, graph_degree 64 (intermediate 128), itopk 64, batch 10k, k = 10."""
     from cuvs_amd.neighbors import brute_force, cagra
 
     nq = 10000
     x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
-    gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=modes, out=x)
+    gen_rows(rows, 768, 1234, dev, latent=latent, n_modes=modes, out=x, spread=spread)
     q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
-    gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=modes, out=q)
+    gen_rows(nq, 768, 4321, dev, latent=latent, n_modes=modes, out=q, spread=spread)
     t0 = time.time()
     idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=res)
     res.sync()
@@ -806,7 +798,8 @@ def extra_c4(res, dev, rows, latent, modes=1):
     best = max(algos, key=lambda a: algos[a]["qps"] if algos[a]["recall_at_10"] >= 0.9 else 0.0)
     dt, r = algos[best]["ms"] * 1e-3, algos[best]["recall_at_10"]
     gbs = algos[best]["gathered_gbs"]
-    return {"config": f"C4 CAGRA {rows}x768 fp16 graph_degree=64 itopk=64 batch=10000 k=10 algo={best} (data: {latent}-d latent, {modes} modes)",
+    return {"config": f"C4 CAGRA {rows}x768 fp16 graph_degree=64 itopk=64 batch=10000 k=10 algo={best} (data: bench.gen_rows - Gaussian mixture of {modes} modes "
+                      f"~ N(0, I) in a {latent}-d latent space, spread {spread} per mode, embedded in R^768 + 0.03 noise)",
             "ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
             "algos": algos,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -844,6 +837,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true")
     ap.add_argument("--c4-rows", type=int, default=10_000_000)
     ap.add_argument("--c4-latent", type=int, default=24)
+    ap.add_argument("--c4-modes", type=int, default=4096)
+    ap.add_argument("--c4-spread", type=float, default=0.7)
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--config", choices=["c3", "c5"], default="c3",
                     help="c3: the headline (IVF-PQ 100M x 128 fp32); c5: IVF-PQ rows x 96 int8 list-sharded over the ranks "
@@ -1210,6 +1205,45 @@ def main():
     # 8d's generator verbatim; an isotropic Gaussian with no cluster structure (the least prunable: the worst case of the two-phase
     # path is whatever this line says). Every line: ms per step, QPS, recall@10 vs fp64, kernel ms, survivors per (row, query)
     # pair of the screen, pairs handed back, overflow entries.
+    contract_corpus = None
+
+    def contract_point(name, idx_, data_, q_, truth_, ng_, ratios):
+        """Sweep of the refine ratio on one corpus; returns the top-level `contract_corpus` entry: the first ratio whose recall@10
+        reaches 0.9, timed with the headline's steps / warmup, with its phases and the roofline of its dominant kernel."""
+        sweep, chosen = [], None
+        for ratio in sorted(set(ratios)):
+            kr = args.k * ratio
+            c_i = torch.empty((args.batch, kr), dtype=torch.int64, device=dev)
+            c_d = torch.empty((args.batch, kr), dtype=torch.float32, device=dev)
+            sp_ = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[args.lut], internal_distance_dtype=LUTS[args.acc],
+                                      max_internal_batch_size=nq_total)
+
+            def step_(c_i=c_i, c_d=c_d, sp_=sp_):
+                ivf_pq.search(sp_, idx_, q_, kr, neighbors=c_i, distances=c_d, resources=res)
+                refine(data_, q_, c_i, indices=neighbors, distances=distances, metric="sqeuclidean", resources=res)
+
+            st_, wu_ = (args.steps, args.warmup) if chosen is None else (3, 1)
+            e_, s_, n_, _ = timed(step_, st_, wu_)
+            rec_ = recall_of(neighbors[:ng_].cpu().numpy(), truth_)
+            ph_ = {k_: round(v_, 3) for k_, v_ in phase_ms.items()}
+            pt = {"refine_ratio": ratio, "ms_per_step": round(e_ / st_ * 1e3, 3), "qps": round(args.batch / (e_ / st_), 1),
+                  "recall_at_10": round(rec_, 4), "kernel_ms_per_step": round(s_ / st_, 3), "phase_ms_per_step": ph_}
+            sweep.append(pt)
+            if chosen is None and rec_ >= 0.9:
+                rf = pq_scan_roofline(idx_, q_, args.n_probes, torch.ones(args.n_lists, dtype=torch.bool, device=dev), args.pq_dim,
+                                      2 * args.pq_dim, ph_.get("pq_filter_kernel", 0.0), s_, n_, st_, ph_)
+                rf.pop("note", None)
+                chosen = {"corpus": name, "n_probes": args.n_probes, "refine_ratio": ratio, "k_searched": kr, "value": pt["qps"],
+                          "unit": "queries/s", "ms_per_step": pt["ms_per_step"], "steps": st_, "warmup": wu_,
+                          "recall_at_10": pt["recall_at_10"], "recall_queries": ng_, "phase_ms_per_step": ph_, "roofline": rf}
+            del c_i, c_d
+        out_ = chosen or {"corpus": name, "n_probes": args.n_probes, "value": None,
+                          "note": "no refine ratio of the sweep reaches recall@10 0.9 at this n_probes"}
+        out_["refine_ratio_sweep"] = sweep
+        out_["note_sweep"] = ("n_probes 256 changes no recall on this corpus (profiles/r06_contract_sweep.log: the true neighbours' lists are "
+                              "among the first 128; what misses them at a small ratio is the PQ ranking of ~1500 near-equidistant rows of a mode)")
+        return out_
+
     corpus_variants = []
     if rank == 0 and world == 1 and not args.no_variants and not sharded:
         try:
@@ -1251,6 +1285,16 @@ def main():
                                         "recall_at_10": round(rec2, 4), "kernel_ms_per_step": round(s2 / 5, 3), "phase_ms_per_step": ph2,
                                         "ms_per_step_lut_scan_kernels": round(e3 / 2 * 1e3, 3), "gen_and_build_seconds": round(b2, 1), **c1})
                 log(f"corpus variant '{name[:40]}': {e2 / 5 * 1e3:.2f} ms per step, recall {rec2:.4f}")
+                if name.startswith("SURVEY 8d"):
+                    # the metric's operating point ON THE CONTRACT CORPUS: the smallest refine ratio of the reference's bench grid
+                    # style sweep (cuvs_ivf_pq.yaml: refine_ratio) that reaches recall@10 >= 0.9 at the metric's n_probes; every
+                    # point = the whole step (search of k * ratio candidates + cuvsRefine), timed like the headline
+                    contract_corpus = contract_point(name, index, data, queries, truth2, ngv, (args.refine_ratio, 4, 6, 8, 16))
+                elif name.startswith("isotropic"):
+                    corpus_variants[-1]["best_reachable"] = (
+                        "recall@10 0.18 at n_probes 128 and 0.27 at n_probes 256 for EVERY refine ratio up to 32 (profiles/r06_contract_sweep.log: "
+                        "the candidates' own recall equals the refined one): without cluster structure 128 of 16384 lists hold 18 % of the true "
+                        "neighbours - the coarse quantizer, not the PQ ranking, is what misses them; no operating point of this index reaches 0.9")
             except Exception as e:
                 corpus_variants.append({"corpus": name, "error": repr(e)[:300]})
             torch.cuda.empty_cache()
@@ -1266,9 +1310,13 @@ def main():
         torch.cuda.empty_cache()
         c1_x = c1_q = None
         if not args.no_extras:
+            # C4's corpus (round 6): 4096 OVERLAPPING modes (spread 0.7: a mode's radius is about the distance to its nearest modes) in
+            # the 24-d latent space - a multi-modal corpus on which recall means something; the single cloud of rounds 2-5 (the
+            # easiest corpus for a graph walk) and the 4096 TIGHT modes on which no walk from random seeds leaves its mode are the
+            # two side lines (2M rows each, profiles/r06_c4_corpus_sweep.log has the whole family)
             for name, fn in (("C1", lambda: extra_c1(res, dev)), ("C2", lambda: extra_c2(res, dev)),
-                             ("C4", lambda: extra_c4(res, dev, args.c4_rows, args.c4_latent)),
-                             ("C4-clustered", lambda: extra_c4_clustered(res, dev))):
+                             ("C4", lambda: extra_c4(res, dev, args.c4_rows, args.c4_latent, modes=args.c4_modes, spread=args.c4_spread)),
+                             ("C4-corpus-family", lambda: extra_c4_family(res, dev))):
                 t0 = time.time()
                 try:
                     out = fn()
@@ -1300,7 +1348,10 @@ def main():
             "dtype": f"u8 codes, {args.lut} LUT, {args.acc} score",
             "data": "synthetic",
             "config": {"workload": f"IVF-PQ {args.rows}x{args.dim} fp32, pq_dim={args.pq_dim} pq_bits=8 "
-                                   f"n_lists={args.n_lists} n_probes={args.n_probes} batch={args.batch} k={args.k}",
+                                   f"n_lists={args.n_lists} n_probes={args.n_probes} batch={args.batch} k={args.k}; rows and held-out queries "
+                                   f"from bench.gen_rows (seed 1234 / 4321): Gaussian mixture of 65536 modes ~ N(0, I) in a 32-d latent space, "
+                                   f"spread 0.35 per mode, embedded in R^{args.dim} by a fixed random map + N(0, 0.03^2 I) - NOT SURVEY 8d's "
+                                   f"generator: the same step on that one is the top-level entry contract_corpus",
                        "parallelism": (f"list-sharded index (lists dealt to the {world} ranks by size, LPT), {world} x {args.batch} queries per "
                                        f"step, one native RCCL all-gather of the [Q,k] blocks per step") if sharded
                                       else "single GPU",
@@ -1308,6 +1359,7 @@ def main():
                        "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants,
                        "sharded_one_rank": sharded_line, "corpus_variants": corpus_variants, "batch_sweep": batch_sweep},
             "recall_at_10": round(recall, 4),
+            "contract_corpus": contract_corpus,
             "scan3_equals_lut_scan": scan3_equals_lut_scan,
             "roofline": roofline,
             "cpu_baseline": cpu,
