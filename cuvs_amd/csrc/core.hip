@@ -253,6 +253,15 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamDefault));
     r->owns_stream = true;
     r->tune = load_tuning_from_env();
+    // the scratch of one internal batch of an IVF search: at most a quarter of what is free on the device right now (a nearly
+    // full or a smaller device splits the batch instead of failing with out-of-memory), never below 256 MiB
+    {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0)
+        r->ivf_batch_limit = std::max<size_t>(size_t(256) << 20, std::min<size_t>(r->ivf_batch_limit, free_b / 4));
+      else
+        (void)hipGetLastError();
+    }
     // test hook: shrink the temporary-tile budget so tiling/merge logic runs on small inputs
     // (the reference has max_row_tile_size/max_col_tile_size hooks, knn_brute_force.cuh:90-93)
     if (const char* ws = debug_switches_on() ? getenv("CUVS_AMD_WORKSPACE_MB") : nullptr) {
@@ -287,11 +296,17 @@ cuvsError_t cuvsResourcesCreate(cuvsResources_t* res)
   });
 }
 
+// Handles are created and destroyed by the threads that use them (benchmark.hpp:296-307: one copy of the handle per bench thread).
+// Tearing down the runtime objects of several handles at once - pools that still give blocks back, streams, events - is
+// serialised: tests/test_concurrent_search_gpu.py had three threads die inside this call (round 6).
+static std::mutex g_handle_teardown_mu;
+
 cuvsError_t cuvsResourcesDestroy(cuvsResources_t res)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto* r = as_res(res);
     (void)hipStreamSynchronize(r->stream);
+    std::lock_guard<std::mutex> teardown(g_handle_teardown_mu);
     if (r->aux_stream != nullptr) {
       (void)hipStreamSynchronize(r->aux_stream);
       (void)hipStreamDestroy(r->aux_stream);

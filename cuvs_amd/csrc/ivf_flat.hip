@@ -835,12 +835,18 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k_scan * 8 + idx.dim * 4 +
                     ((int64_t)n_probes / qpb + 1) * (dim_pad + 1) * qpb * 4;  // + the query tiles of its work items
     if (large_k) per_q += (int64_t)scores_ld * 8 + (int64_t)k * 12;
+    // the matrix-core tail phase: fp16 B operands + thresholds + norms + candidate rows of every pair, the raw / unit copies of
+    // the query, the survivor list (16 entries per pair) and work units; the coarse search's grouped distances + keys
+    if (!large_k && flat3_supported(idx.dim, k) && res.tune.flat_scan3 != 0)
+      per_q += (int64_t)n_probes * ((int64_t)dim_pad * 2 + 4 + 16 + (int64_t)k * 4 + 16 * 8 + 16) + (int64_t)idx.dim * 8;
+    per_q += round_up((int64_t)idx.n_lists, 128) * 4 + round_up((int64_t)idx.n_lists, 128) / 4;
     max_batch     = balanced_batch(n_queries, std::min(max_batch, std::max<int64_t>(1, (int64_t)res.ivf_batch_limit / per_q)));
   }
   const int64_t bs = std::min<int64_t>(max_batch, n_queries);
   const int64_t np_max = bs * n_probes;
   host_trace trace((res.tune.scan_debug & 8192) != 0, "ivf_flat_search");  // declared before the buffers: destroyed after them
-  dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), dist(res, (size_t)bs * idx.n_lists), pd(res, (size_t)np_max);
+  dev_buf<float> qf(res, (size_t)bs * idx.dim), qn(res, bs), pd(res, (size_t)np_max);
+  dev_buf<float> dist;  // [bs, n_lists] coarse distances of the plain form: allocated by the first batch that does not take the grouped form
   // two-phase schedule (ivf_common.hpp): nearest probe of every query first
   // (inner product, round 5: a head phase only where the matrix-core tail phase follows it - the scan kernel has no early stop
   // for dot products, but the filter prunes on the full-score bound the head phase leaves)
@@ -904,6 +910,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
                                               gkeys.data(), ldo / 16);
       if (coarse_done) select_k_grouped(res, gdist.data(), ldo, gkeys.data(), ldo / 16, nq, idx.n_lists, (int)n_probes, pd.data(), probes.data(), !ipm);
     }
+    if (!coarse_done && dist.data() == nullptr) dist = dev_buf<float>(res, (size_t)bs * idx.n_lists);
     if (coarse_done) {
     } else if (idx.metric == M_InnerProduct) {
       pairwise_distance<float, float>(res, qf.data(), nq, idx.dim, idx.centers.data(), idx.n_lists, idx.dim, idx.dim,

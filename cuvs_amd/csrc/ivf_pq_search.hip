@@ -2170,6 +2170,17 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     aux.stream     = res.aux_stream;
   }
   resources& gres = overlap ? aux : res;  // the stream the grouping and the tail phase's preparation are queued on
+  // Between fork and join the helper stream's kernels read and write scratch blocks that belong to the handle's stream
+  // (sorted_pairs, pair_off, item_off, items, group_scratch, bq3, pair_norms, units3, ...). If anything throws in between
+  // (a HIP error, a shard collective's timeout), unwinding would hand those blocks back to the handle's scratch cache while
+  // the helper stream may still be using them, and the next call on the handle's stream would re-use them at once. The guard
+  // is declared AFTER every such buffer (destroyed first): while armed, its destructor drains the helper stream.
+  struct aux_fork_guard {
+    hipStream_t s = nullptr;
+    bool armed    = false;
+    ~aux_fork_guard() { if (armed && s != nullptr) (void)hipStreamSynchronize(s); }
+  } fork_guard;
+  fork_guard.s = overlap ? aux.stream : nullptr;
   // Partial head (two-stream schedule only: the head items come straight from the probes): the head phase scores the first
   // head_rows rows of a query's nearest list - its k-th best of those bounds the query's final k-th score like the whole list's
   // does, a little less tightly - and the list's remaining rows are screened by the filter with all the other probes.
@@ -2212,6 +2223,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       pq3_warm(res, idx, true);  // (derived tables of the index: built here, on the handle's stream, if they are not there yet)
       HIP_TRY(hipEventRecord(res.aux_events[0], res.stream));
       HIP_TRY(hipStreamWaitEvent(gres.stream, res.aux_events[0], 0));
+      fork_guard.armed = true;
     }
     if (head > 0 || sharded) {
       hipLaunchKernelGGL(phase_labels_kernel, dim3(nblk(n_pairs, 256)), dim3(256), 0, gres.stream, probes.data(),
@@ -2359,6 +2371,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
           pq3_tail(gres, idx, r);
           HIP_TRY(hipEventRecord(res.aux_events[1], gres.stream));
           HIP_TRY(hipStreamWaitEvent(res.stream, res.aux_events[1], 0));
+          fork_guard.armed = false;  // joined: everything the helper stream was given is ordered before the handle's stream again
           r.stage = 2;
         }
         pq3_tail(res, idx, r);

@@ -44,7 +44,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const T* __restrict__ data,
   }
   for (int c = wave; c < n_cand; c += 4) {
     const int64_t id = cand[q * n_cand + c];
-    if (id < 0 || id >= n) continue;  // wave-uniform
+    if (id < 0 || id >= n) {  // wave-uniform. refine_host.hpp:440-442: the candidate stays, with distance = max and its own id
+      if (lane == 0) {
+        s_key[c] = float_to_key(FLT_MAX);  // (inner product: the sort key is -q.x there too - max sorts last under either rule)
+        s_idx[c] = id;
+      }
+      continue;
+    }
     const T* row = data + id * dim;
     float acc    = 0.f, xn = 0.f;
     for (int64_t j = lane; j < dim; j += kWave) {
@@ -73,13 +79,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const T* __restrict__ data,
   }
   __syncthreads();
   block_bitonic_sort<int64_t>(s_key, s_idx, np2);
-  for (int j = threadIdx.x; j < k; j += 256) {
-    const bool ok = s_idx[j] != INT64_MAX;
-    uint32_t key  = ip ? ~s_key[j] : s_key[j];
-    float d       = key_to_float(key);
+  for (int j = threadIdx.x; j < k; j += 256) {  // (k <= n_cand: every slot read here holds a candidate)
+    const bool bad = s_key[j] == float_to_key(FLT_MAX) && (s_idx[j] < 0 || s_idx[j] >= n);
+    uint32_t key   = ip ? ~s_key[j] : s_key[j];
+    float d        = bad ? (ip ? -FLT_MAX : FLT_MAX) : key_to_float(key);  // postprocess(max): -max for inner product (:465-505)
     if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d);
-    out_i[q * k + j] = ok ? s_idx[j] : INT64_MAX;
-    out_d[q * k + j] = ok ? d : FLT_MAX;
+    out_i[q * k + j] = s_idx[j];
+    out_d[q * k + j] = d;
   }
 }
 
@@ -139,7 +145,7 @@ void refine_host_typed(const void* data_v, int64_t n, int64_t dim, const void* q
         int cnt = 0;
         for (int c = 0; c < n_cand; ++c) {
           const int64_t id = cand[q * n_cand + c];
-          if (id < 0 || id >= n) continue;
+          if (id < 0 || id >= n) { buf[cnt++] = {FLT_MAX, id}; continue; }  // refine_host.hpp:440-442
           const T* row = data + id * dim;
           float v = host_strided(qv, row, dim, (ip || cosm) ? 1 : 0);
           if (cosm) v = 1.0f - v / (qn * sqrtf(host_strided(qv, row, dim, 2)));
@@ -148,7 +154,7 @@ void refine_host_typed(const void* data_v, int64_t n, int64_t dim, const void* q
         std::sort(buf.begin(), buf.begin() + cnt);  // (distance, id) tuples, refine_host.hpp:430-460
         for (int j = 0; j < k; ++j) {
           if (j < cnt) {
-            float d = ip ? -buf[j].first : buf[j].first;
+            float d = ip ? -buf[j].first : buf[j].first;  // (an out-of-range candidate: postprocess(max) = -max for inner product)
             if (metric == M_L2SqrtExpanded || metric == M_L2SqrtUnexpanded) d = sqrtf(d);
             out_i[q * k + j] = buf[j].second;
             out_d[q * k + j] = d;

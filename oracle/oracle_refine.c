@@ -1,8 +1,10 @@
 /*
  * oracle_refine.c — CPU twin of cuvsRefine (TEST INFRASTRUCTURE ONLY, see oracle.c header).
  * Restates cpp/src/neighbors/refine/refine_host.hpp:353-462: exact distance of every candidate, then a
- * per-query sort of (distance, id) tuples; ids outside [0, n) are skipped (the reference gives them
- * distance = max, :440-442). Arithmetic is the HIP kernel's: 64 strided fmaf partial sums + butterfly.
+ * per-query sort of (distance, id) tuples; a candidate id outside [0, n) STAYS in the list with
+ * distance = max (:440-442) - it sorts behind every real row, among its like by id, and comes out with its
+ * own id and postprocess(max) (sqrt for the L2Sqrt metrics, -max for inner product, :465-505).
+ * Arithmetic is the HIP kernel's: 64 strided fmaf partial sums + butterfly.
  */
 #include <float.h>
 #include <math.h>
@@ -48,7 +50,10 @@ EXPORT void oracle_refine(const float* data, int64_t n, int64_t dim, const float
       int cnt = 0;
       for (int c = 0; c < n_cand; ++c) {
         int64_t id = cand[q * n_cand + c];
-        if (id < 0 || id >= n) continue;
+        if (id < 0 || id >= n) {  /* static_cast<size_t>(id) >= n_rows: distance = max, the id is kept */
+          buf[cnt].d = FLT_MAX; buf[cnt].id = id; ++cnt;
+          continue;
+        }
         float v = lane_reduce(queries + q * dim, data + id * dim, dim, ip || cosm);
         if (cosm) {
           const float qn = sqrtf(lane_reduce(queries + q * dim, queries + q * dim, dim, 1));

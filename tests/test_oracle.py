@@ -77,3 +77,25 @@ def test_canonical_dot_is_fma_chain():
     for k in range(64):
         acc = np.float32(np.float64(a[0, k]) * np.float64(b[0, k]) + np.float64(acc))  # exact product, one rounding
     assert got == acc
+
+
+def test_refine_cos_zero_denominator_is_distance_one():
+    """refine_host.hpp:333-350: denom > 0 ? 1 - dot / denom : 1 (a zero vector is at cosine distance 1 from everything)"""
+    x = np.zeros((3, 8), np.float32)
+    x[1] = 1.0
+    q = np.ones((1, 8), np.float32)
+    d, i = oracle.exact_knn(q, x, 3, metric="cosine")
+    assert i[0, 0] == 1 and abs(d[0, 0]) < 1e-6
+    assert (d[0, 1:] == 1.0).all() and sorted(i[0, 1:]) == [0, 2]
+
+
+def test_oracle_refine_keeps_out_of_range_candidates():
+    """refine_host.hpp:440-442: id >= n_rows -> distance = max, the id stays; sorted (distance, id)"""
+    x = np.arange(12, dtype=np.float32).reshape(6, 2)
+    q = np.zeros((1, 2), np.float32)
+    cand = np.array([[5, -1, 2, np.iinfo(np.int64).max, 6, 0]], np.int64)
+    d, i = oracle.refine(x, q, cand, 6, metric="sqeuclidean")
+    assert list(i[0]) == [0, 2, 5, -1, 6, np.iinfo(np.int64).max]
+    assert (d[0, 3:] == np.finfo(np.float32).max).all()
+    d, i = oracle.refine(x, q, cand, 6, metric="inner_product")
+    assert (d[0, 3:] == -np.finfo(np.float32).max).all()

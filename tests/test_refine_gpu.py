@@ -17,7 +17,7 @@ def test_refine_matches_oracle(metric, n, d, m, n_cand, k):
     x = rng.standard_normal((n, d)).astype(np.float32)
     q = rng.standard_normal((m, d)).astype(np.float32)
     cand = rng.integers(0, n, size=(m, n_cand)).astype(np.int64)
-    cand[0, 0] = -1  # invalid ids are skipped
+    cand[0, 0] = -1  # invalid ids stay in the list at distance = max (refine_host.hpp:440-442)
     cand[1, 1] = n + 5
     gd, gi = refine(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(cand).cuda(), k=k,
                     metric=metric)
@@ -85,3 +85,52 @@ def test_refine_mixed_memory_is_an_error():
     assert rc == 0  # CUVS_ERROR
     lib().cuvsGetLastErrorText.restype = C.c_char_p
     assert b"all in device memory or all in host memory" in lib().cuvsGetLastErrorText()
+
+
+def _host_refine_rule(x, q, cand, k, metric):
+    """refine_host.hpp:430-460 transcribed with numpy, float64 distances only for RANKING real rows apart from invalid ones:
+    every candidate whose id is outside [0, n) gets distance = max and keeps its id; tuples sorted by (distance, id)."""
+    fmax = np.finfo(np.float32).max
+    out_i = np.empty((q.shape[0], k), np.int64)
+    tail = np.empty((q.shape[0], k), bool)
+    for r in range(q.shape[0]):
+        ids = cand[r]
+        bad = (ids < 0) | (ids >= x.shape[0])
+        n_good = int((~bad).sum())
+        order_bad = np.sort(ids[bad])
+        out_i[r, max(0, n_good):] = order_bad[:k - n_good] if n_good < k else []
+        tail[r] = np.arange(k) >= n_good
+    post = {"sqeuclidean": fmax, "euclidean": np.sqrt(np.float32(fmax)), "inner_product": -fmax, "cosine": fmax}[metric]
+    return out_i, tail, np.float32(post)
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "inner_product", "cosine"])
+@pytest.mark.parametrize("host", [False, True])
+def test_refine_keeps_out_of_range_candidates_at_max_distance(metric, host):
+    """the reference's host refine gives a candidate id outside [0, n) distance = max and sorts it with its OWN id behind the real
+    rows (refine_host.hpp:440-442, postprocess :465-505): -1, n, INT64_MAX (the padding of an IVF search) all come back as they
+    went in; oracle, device path and host path agree on ids and distances"""
+    import torch
+    from cuvs_amd.neighbors import refine
+
+    rng = np.random.default_rng(5)
+    n, d, m, n_cand, k = 300, 24, 12, 16, 16
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((m, d)).astype(np.float32)
+    cand = rng.integers(0, n, size=(m, n_cand)).astype(np.int64)
+    cand[0, 3] = -1
+    cand[1, [0, 5, 9]] = [np.iinfo(np.int64).max, -7, n]
+    cand[2, :] = np.iinfo(np.int64).max           # nothing but padding
+    cand[3, 10:] = np.iinfo(np.int64).max
+    od, oi = oracle.refine(x, q, cand, k, metric=metric)
+    want_i, tail, post = _host_refine_rule(x, q, cand, k, metric)
+    assert (oi[tail] == want_i[tail]).all() and (od[tail] == post).all(), "oracle vs the reference's rule"
+    assert ((oi[~tail] >= 0) & (oi[~tail] < n)).all()
+    if host:
+        gd, gi = refine(x, q, cand, k=k, metric=metric)
+    else:
+        gd, gi = refine(torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda(), torch.from_numpy(cand).cuda(), k=k, metric=metric)
+        torch.cuda.synchronize()
+        gd, gi = gd.cpu().numpy(), gi.cpu().numpy()
+    assert (gi == oi).all()
+    assert (gd == od).all()
