@@ -851,6 +851,11 @@ def main():
                          "(BASELINE configs[4]: 1B rows over 8 GPUs; --rows scales it down), rows generated chunk by chunk")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the list-sharded code path (shard build, RCCL all-gather + merge) even with one rank")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank brings its own batch (N x batch queries per step over the N list shards: the "
+                         "driver's SCALE run); strong = ONE batch of `batch` queries per step over the N list shards - BASELINE's metric "
+                         "('batch=10k; 1/2/4/8 GPU'), the reference's SHARDED search (cpp/src/neighbors/mg/snmg.cuh:248-375: every rank "
+                         "searches the same batch on its shard)")
     ap.add_argument("--share-devices", action="store_true",
                     help="functional run of the N-rank path on fewer than N devices: rank r uses device r %% n_devices, the "
                          "collectives go through the communicator's host-staged transport (RCCL refuses two ranks on one "
@@ -873,13 +878,15 @@ def main():
 
     res = cuvs_amd.common.Resources()
     sharded = world > 1 or args.force_sharded
-    nq_total = args.batch * world  # list-sharded search: every rank sees the whole (world x batch) query batch
+    strong = args.scaling == "strong" and world > 1
+    # list-sharded search: every rank sees the whole query batch of a step - world x batch queries (weak), one batch (strong)
+    nq_total = args.batch if strong else args.batch * world
     kk = args.k * max(1, args.refine_ratio)
 
     # ------------------------------------------------------------------ data + index (untimed)
     t0 = time.time()
     data = gen_rows(args.rows, args.dim, seed=1234, device=dev)
-    queries = torch.cat([gen_rows(args.batch, args.dim, seed=4321 + r, device=dev) for r in range(world)])
+    queries = torch.cat([gen_rows(args.batch, args.dim, seed=4321 + r, device=dev) for r in range(1 if strong else world)])
     torch.cuda.synchronize()
     log(f"generated {args.rows}x{args.dim} fp32 in {time.time() - t0:.1f}s")
     t0 = time.time()
@@ -915,7 +922,8 @@ def main():
     cand_i = torch.empty((nq_total, kk), dtype=torch.int64, device=dev)
     cand_d = torch.empty((nq_total, kk), dtype=torch.float32, device=dev)
     mrg_i, mrg_d = torch.empty_like(cand_i), torch.empty_like(cand_d)
-    q_lo, q_hi = rank * args.batch, (rank + 1) * args.batch  # the slice of the batch this rank refines
+    per_rank = (nq_total + world - 1) // world
+    q_lo, q_hi = min(nq_total, rank * per_rank), min(nq_total, (rank + 1) * per_rank)  # the slice of the batch this rank refines
 
     def make_step(lut, acc, res=res):
         sp = ivf_pq.SearchParams(n_probes=args.n_probes, lut_dtype=LUTS[lut], internal_distance_dtype=LUTS[acc],
@@ -974,7 +982,7 @@ def main():
     headline_phase_ms = {k: round(v, 3) for k, v in phase_ms.items()}
 
     # ------------------------------------------------------------------ recall@10 vs exact search (untimed)
-    ng = min(args.gt_queries, args.batch)
+    ng = min(args.gt_queries, q_hi - q_lo)
     truth = exact_topk_fp64(data, queries[q_lo:q_lo + ng], args.k).cpu().numpy()  # fp64, not this library's brute force
     recall = recall_of(neighbors[q_lo:q_lo + ng].cpu().numpy(), truth)
 
@@ -1339,7 +1347,7 @@ def main():
         cpu = cpu_baseline_line(dev=dev)  # N > 1: the same bounded CPU leg on rank 0's host cores (the other ranks wait below)
 
     if rank == 0:
-        total_q = args.batch * args.steps * world
+        total_q = nq_total * args.steps
         out = {
             "metric": "QPS @ recall@10>=0.9, 100Mx128 fp32 IVF-PQ, batch=10k",
             "value": round(total_q / elapsed, 1),
@@ -1349,7 +1357,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": f"u8 codes, {args.lut} LUT, {args.acc} score",
             "data": "synthetic",
@@ -1358,8 +1366,10 @@ def main():
                                    f"from bench.gen_rows (seed 1234 / 4321): Gaussian mixture of 65536 modes ~ N(0, I) in a 32-d latent space, "
                                    f"spread 0.35 per mode, embedded in R^{args.dim} by a fixed random map + N(0, 0.03^2 I) - NOT SURVEY 8d's "
                                    f"generator: the same step on that one is the top-level entry contract_corpus",
-                       "parallelism": (f"list-sharded index (lists dealt to the {world} ranks by size, LPT), {world} x {args.batch} queries per "
-                                       f"step, one native RCCL all-gather of the [Q,k] blocks per step") if sharded
+                       "parallelism": (f"list-sharded index (lists dealt to the {world} ranks by size, LPT), "
+                                       + (f"ONE batch of {args.batch} queries per step searched by every rank on its lists (strong scaling), "
+                                          if strong else f"{world} x {args.batch} queries per step, ")
+                                       + "one native RCCL all-gather of the [Q,k] blocks per step, every rank refines its slice of the batch") if sharded
                                       else "single GPU",
                        "lut_dtype": args.lut, "internal_distance_dtype": args.acc, "refine_ratio": args.refine_ratio,
                        "build_seconds": round(build_s, 1), "variants": variants, "metric_variants": metric_variants,

@@ -69,7 +69,8 @@ def main():
     import cuvs_amd
     from cuvs_amd.neighbors import ivf_flat, ivf_pq, ivf_pq_sharded as sh, refine, row_sharded as rs
 
-    torch.cuda.set_device(0)
+    # ranks share device 0 (host-staged transport) unless the launcher gives every rank a device of its own (RCCL)
+    torch.cuda.set_device(rank if os.environ.get("CUVS_AMD_WORLD_OWN_DEVICES") == "1" else 0)
     res = cuvs_amd.common.Resources()
     comm = sh.ShardComm(rank, world, bytes.fromhex(id_hex), res)
     for name in LIST_CASES:

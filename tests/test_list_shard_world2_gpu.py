@@ -26,7 +26,14 @@ sys.path.insert(0, HERE)
 def _run_world(world, out_dir, timeout=420):
     from cuvs_amd.neighbors import ivf_pq_sharded as sh
 
-    comm_id = sh.ShardComm.unique_id(host_staged=True).hex()
+    # CUVS_AMD_WORLD_OWN_DEVICES=1 (scripts/gpu_first_8gpu.sh, a multi-GPU node): rank r on device r, the communicator over RCCL
+    own = os.environ.get("CUVS_AMD_WORLD_OWN_DEVICES") == "1"
+    if own:
+        import torch
+
+        if torch.cuda.device_count() < world:
+            pytest.skip(f"{world} ranks on their own devices need {world} devices")
+    comm_id = sh.ShardComm.unique_id(host_staged=not own).hex()
     env = dict(os.environ, CUVS_AMD_SHM_TIMEOUT_S="90")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_world_worker.py"), str(r), str(world), comm_id, str(out_dir)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
