@@ -880,6 +880,10 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0), tickets3(res, use3 ? 8 * 32 : 0);
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, 2 * max_units), overflow3(res, (size_t)2 * overflow_cap);
+  // flat_filter2_kernel's pre-pass: fp16 B operand (2 x dim bytes) and threshold of every pair
+  const bool f2 = use3 && res.tune.flat_filter2 != 0 && idx.dim <= 128;
+  dev_buf<uint4> bq3(res, f2 ? (size_t)np_max * (idx.dim / 8) : 0);
+  dev_buf<float> thr3(res, f2 ? (size_t)np_max : 0);
   const float raw_mult = et == elem_t::i8 ? 128.0f : et == elem_t::u8 ? 256.0f : 1.0f;
   const bool raw3      = use3 && raw_mult != 1.0f;
   dev_buf<float> q_unit(res, use3 && cos3 ? (size_t)bs * idx.dim : 0);  // cosine: unit-length queries for the filter
@@ -1025,6 +1029,8 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets3.data(); r.filter_bits = filter_bits;
         r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
+        r.bq = f2 ? bq3.data() : nullptr; r.thr = thr3.data();
+        r.filter_dbg = (res.tune.scan_debug >> 16) & 255;  // CUVS_AMD_SCAN_DEBUG bits 16..23: ablations of the filter (timing only)
         flat3_view v{idx.data.data(), (raw3 && !cos3) ? c_raw.data() : idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
                      idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len,
                      et == elem_t::f32 ? 0 : et == elem_t::f16 ? 1 : et == elem_t::i8 ? 2 : 3, cos3};

@@ -579,6 +579,7 @@ static encode_plan plan_encode(const ivf_pq_index& idx)
 void ivf_pq_extend(resources& res, ivf_pq_index& idx, const void* data, elem_t et, int64_t n_new, bool is_host,
                    const int64_t* new_ids, bool ids_on_host)
 {
+  idx.shard_stats_valid = false;  // a list shard: the rows / non-empty lists of ALL ranks are exchanged again by the next search (extend is collective for a shard)
   if (n_new == 0) return;
   if (!idx.dtype_known) { idx.dtype = et; idx.dtype_known = true; }
   CUVS_EXPECTS(et == idx.dtype, "extend: vector dtype differs from the index dtype");

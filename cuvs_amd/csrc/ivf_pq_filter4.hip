@@ -550,7 +550,7 @@ void pq4_filter(resources& res, const filter4_launch& l)
   b.rot_queries = l.rot_queries; b.centers_rot = l.centers_rot; b.query_kth = l.query_kth; b.qflag = l.qflag;
   b.bq = static_cast<uint4*>(l.bq); b.thr = l.thr; b.n_probes = l.n_probes; b.rot_dim = l.rot_dim;
   b.sc = l.sc; b.c1 = l.c1; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = l.cbmax; b.dmax = l.dmax; b.bound_max = l.bound_max;
-  b.is_ip = l.is_ip; b.flat = 0;
+  b.is_ip = l.is_ip; b.flat = l.flat;
   b.lpl = l.pl == 1 ? 0u : l.pl == 2 ? 1u : l.pl == 4 ? 2u : 3u;
   const int nst = l.nch * l.pl;  // MFMA K steps
   const unsigned pgrid = (unsigned)grid_blocks(l.n_pairs, 128);
@@ -580,7 +580,7 @@ void pq4_filter(resources& res, const filter4_launch& l)
     }
     profile_end(res, "pq_bprep_kernel");
     HIP_TRY(hipGetLastError());
-    if (l.stage == 1) return;
+    if (l.stage == 1 || l.bprep_only) return;
   } else {
     hipLaunchKernelGGL(pq_thr_kernel, dim3((unsigned)grid_blocks(l.n_pairs, 256)), dim3(256), 0, res.stream, b);
   }

@@ -85,6 +85,8 @@ struct filter4_launch {
   unsigned grid;
   int stage = 0;              // pq3_run::stage: 1 = pre-pass without thresholds only, 2 = thresholds + filter, 0 = both in one go
   void* pair_norms = nullptr; // [tail pairs] float4 between stage 1 and stage 2
+  int flat = 0;               // IVF-Flat's pairs (an unserved query survives everything instead of being handed back)
+  int bprep_only = 0;         // the pre-pass alone (B operands + thresholds): IVF-Flat's flat_filter2_kernel follows it
 };
 void pq4_filter(resources& res, const filter4_launch& l);
 

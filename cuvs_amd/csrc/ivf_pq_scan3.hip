@@ -226,6 +226,11 @@ struct filter_params {
   // IVF-Flat has no per-pair hand-back kernel: a query that cannot be served survives every test (its rows are all
   // re-scored), and a full buffer raises *fail - the caller re-runs the batch's tail phase on the scan kernel
   uint32_t* fail;
+  // flat_filter2_kernel: B operands and thresholds of the tail pairs from the pre-pass (pq_bprep_kernel, ivf_pq_filter4.hip)
+  const uint4* bq;
+  const float* thr_pair;
+  const uint32_t* pair_off;
+  uint32_t n_lists;
 };
 
 // NCH: 16-byte code chunks per row = pq_dim / 16 (pq_len 2: rot_dim = 32 NCH, 2 NCH MFMA K steps). Up to 4 chunks a
@@ -492,6 +497,241 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
   }
   __syncthreads();
   if (threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(*wg_fill, a.surv_cap);
+}
+
+// ------------------------------------------------------------------ IVF-Flat: the filter with the B operands in LDS (round 6)
+// pq_filter_kernel<.., FLAT> is bound by HBM on its OWN re-reads (profiles/r04_pmc_c4_c2.json: 6.57 GB per search at 7.8 TB/s
+// for a 2.56 GB fp16 copy): a unit is (list chunk, 64 queries) and every wave streams its unit's rows by itself, so a list probed
+// by 156 queries (C2's mean) is fetched 2.6 times - the units of a chunk run on one XCD, but 256 streams share its 4 MiB of L2
+// and a line is gone before the neighbour asks for it. Here a unit is (list chunk, up to 256 queries) and belongs to the whole
+// WORKGROUP: its waves build the B operands of the unit's eight query groups into LDS once (8 KiB per group at 128 dimensions),
+// then every wave takes every eighth 32-row subtile, loads its A operands from the fp16 copy ONCE and multiplies them with group
+// after group (B operand: eight ds_read_b128 per group - the LDS delivers them ten times faster than HBM delivers rows).
+// Same operands, same accumulation order (K steps, then the row term's K-extension step), same thresholds as the kernel
+// above: the same survivors.
+constexpr int kF2Threads = 256;  // 4 waves; two workgroups per CU (one builds its unit's operands while the other streams rows)
+constexpr int kF2Waves   = kF2Threads / 64;
+
+template <int NST>
+__global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filter_params a)
+{
+  constexpr int NGM      = 8;          // query groups per unit
+  constexpr bool DOUBLE  = NST <= 8;   // A operands of the wave's next two subtiles in registers of their own (beyond: one set)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* Bs        = reinterpret_cast<uint4*>(smem);                             // [NGM][NST][64 lanes] x 16 B
+  float* s_thr     = reinterpret_cast<float*>(smem + (size_t)NGM * NST * 1024);  // [NGM][32]
+  uint32_t* s_pair = reinterpret_cast<uint32_t*>(s_thr + NGM * 32);              // [NGM][32]
+  uint32_t* ctrl   = s_pair + NGM * 32;                                          // [0] survivors of this workgroup, [1] current unit
+  uint2* my_surv   = a.surv + (size_t)blockIdx.x * a.surv_cap;
+  if (threadIdx.x == 0) ctrl[0] = 0u;
+
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t ql = lane & 31u, h = lane >> 5;
+  const uint32_t n_units = *a.n_units;
+  const uint32_t chunk   = (n_units + 7u) / 8u;
+  const uint32_t s_base  = a.pair_off[a.n_lists];  // first tail pair in sorted_pairs
+  uint32_t xcd = blockIdx.x & 7u, hops = 0u;  // (thread 0's: the workgroup's position in the XCD shares)
+  unsigned long long st_pairs = 0, st_surv = 0, st_sub = 0, st_units = 0;
+  const u32x4_t oq   = {h == 0u ? 0x3c003c00u : 0u, 0u, 0u, 0u};
+  const f16x8_t ones = __builtin_bit_cast(f16x8_t, oq);  // B operand of the K-extension step: the row term's two halves times one
+
+  for (;;) {
+    __syncthreads();  // nobody reads the previous unit's operands any more
+    if (threadIdx.x == 0) {
+      uint32_t ui = 0xffffffffu;
+      for (;;) {  // XCD x owns the x-th eighth of the (list-sorted) units; a workgroup whose XCD has run dry moves on to the next share
+        const uint32_t share0 = min(n_units, xcd * chunk), share_len = min(chunk, n_units - share0);
+        const uint32_t t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
+        if (t < share_len) { ui = share0 + t; break; }
+        if (++hops == 8u) break;
+        xcd = (xcd + 1u) & 7u;
+      }
+      ctrl[1] = ui;
+    }
+    __syncthreads();
+    const uint32_t ui = ctrl[1];
+    if (ui == 0xffffffffu) break;  // workgroup-uniform
+    const filter_unit* up = a.units + ui;
+    const uint4 uu = *reinterpret_cast<const uint4*>(up);
+    const uint32_t L = __builtin_amdgcn_readfirstlane(uu.x), first = __builtin_amdgcn_readfirstlane(uu.y),
+                   count = __builtin_amdgcn_readfirstlane(uu.z), row0 = __builtin_amdgcn_readfirstlane(uu.w);
+    const uint32_t r_end    = __builtin_amdgcn_readfirstlane(up->r_end);
+    const uint32_t base_row = a.list_offsets[L];
+    const uint32_t ng       = (count + 31u) >> 5;  // 1 .. NGM, workgroup-uniform
+    const uint32_t u0 = row0 >> 5, u1 = (r_end + 31u) >> 5;
+    // the rows' K-extension terms (one dword per row, used by the lanes of half 0) travel WITH the rows: loaded where the rows are
+    // loaded, unconditionally (inner product: a readable dummy address) - a conditional load at the top of a subtile made the
+    // compiler wait for EVERY outstanding load (s_waitcnt vmcnt(0)) before the term's MFMA, i.e. for the rows it had just asked
+    // for two subtiles ahead: one exposed HBM round trip per subtile
+    const uint32_t* term_base = a.row_term != nullptr ? a.row_term + base_row : reinterpret_cast<const uint32_t*>(a.rows16);
+    auto load_rows = [&](const uint32_t u, u32x4_t (&av)[NST], uint32_t& tm) {
+      const uint32_t uc = min(u, u1 - 1u);
+      const uint4* p = a.rows16 + ((size_t)((base_row >> 5) + uc) * NST) * 64 + lane;
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const uint4 v = p[(size_t)st * 64];
+        av[st] = u32x4_t{v.x, v.y, v.z, v.w};
+      }
+      tm = term_base[(a.row_term != nullptr ? (uc << 5) : 0u) + ql];
+    };
+    // the wave's first two subtiles are on their way while the unit's operands are built (three register sets: a subtile's rows
+    // are asked for two subtiles - ~1.5 us of matrix work - before they are multiplied; one subtile ahead, 0.8 us, is less than
+    // a loaded HBM takes to answer)
+    u32x4_t avA[NST], avB[DOUBLE ? NST : 1], avC[DOUBLE ? NST : 1];
+    uint32_t tmA = 0u, tmB = 0u, tmC = 0u;
+    if (u0 < u1) {
+      load_rows(u0 + wave, avA, tmA);
+      if constexpr (DOUBLE) load_rows(u0 + wave + kF2Waves, avB, tmB);
+    }
+    // ---- B operands, thresholds and pair ids of the unit's queries, from the pre-pass (fp16 residuals in B-operand layout, 32 NST
+    // bytes per pair; thresholds in accumulator units): wave w copies the groups w, w + 4; lane = (query ql, K half h)
+    for (uint32_t g = wave; g < ng; g += kF2Waves) {
+      const uint32_t jj = g * 32u + ql;
+      const uint32_t jc = min(jj, count - 1u);
+      const uint4* bp   = a.bq + ((size_t)(first - s_base + jc) * NST * 2 + h);
+#pragma unroll
+      for (int st = 0; st < NST; ++st) Bs[(g * NST + st) * 64 + lane] = bp[st * 2];
+      if (h == 0u) {
+        s_thr[g * 32 + ql]  = jj < count ? a.thr_pair[first - s_base + jc] : INFINITY;  // (a padding slot keeps nothing)
+        s_pair[g * 32 + ql] = a.sorted_pairs[first + jc];
+      }
+    }
+    __syncthreads();
+
+    // ---- the unit's rows: wave w takes the subtiles u0 + w, u0 + w + 4, ...; the A operands of its next subtile are loaded
+    // while this one is multiplied (two register sets up to 128 dimensions)
+    // B operands of a group in two halves (K steps [0, H) and [H, NST)): the halves of group g + 1 are read from LDS while the
+    // MFMAs of the other half of group g run - one register set, no exposed LDS round trip per group (a wave that reads all of a
+    // group's operands and then waits for them spends ~700 cycles per group on ~300 cycles of matrix work)
+    constexpr int H = NST >= 2 ? NST / 2 : 1;
+    auto load_b_half = [&](const uint32_t g, const int half, u32x4_t (&bq)[NST]) {
+      const uint4* p = Bs + (size_t)g * NST * 64 + lane;
+      if (half == 0) {
+#pragma unroll
+        for (int st = 0; st < H; ++st) {
+          const uint4 v = p[st * 64];
+          bq[st] = u32x4_t{v.x, v.y, v.z, v.w};
+        }
+      } else {
+#pragma unroll
+        for (int st = H; st < NST; ++st) {
+          const uint4 v = p[st * 64];
+          bq[st] = u32x4_t{v.x, v.y, v.z, v.w};
+        }
+      }
+    };
+    u32x4_t bq[NST];
+    float th_next = INFINITY;
+    load_b_half(0u, 0, bq);
+    load_b_half(0u, 1, bq);
+    th_next = s_thr[ql];
+    auto step = [&](const uint32_t u, u32x4_t (&cur)[NST], uint32_t& tcur, auto& nxt, uint32_t& tnxt) {
+      const uint32_t term = h == 0u ? tcur : 0u;
+      if constexpr (DOUBLE) load_rows(u + 2u * kF2Waves, nxt, tnxt);  // (nxt: the set the subtile before this one has just left)
+      const u32x4_t tq  = {term, 0u, 0u, 0u};
+      const f16x8_t top = __builtin_bit_cast(f16x8_t, tq);
+      auto one = [&](const uint32_t gg, const bool last) {
+        const uint32_t gn = gg + 1u < ng ? gg + 1u : 0u;  // the group whose operands are read next (group 0: of the wave's next subtile)
+        const float thg   = th_next;
+        f32x16_t acc = {};
+#pragma unroll
+        for (int st = 0; st < H; ++st)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, cur[st]), __builtin_bit_cast(f16x8_t, bq[st]), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b_half(gn, 0, bq);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = H; st < NST; ++st)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, cur[st]), __builtin_bit_cast(f16x8_t, bq[st]), acc, 0, 0, 0);
+        if (a.row_term != nullptr) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(top, ones, acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b_half(gn, 1, bq);
+        th_next = s_thr[gn * 32 + ql];
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!DOUBLE) {
+          if (last) load_rows(u + kF2Waves, cur, tcur);  // one register set: the next subtile's rows once this one's last MFMAs are issued
+        }
+        // accumulator register i of this lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile; a pair survives when acc >= thr
+        float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, acc[i]), acc[i + 1]);
+        m = fmaxf(m, acc[15]);
+        const bool any = m >= thg;
+        if (a.stats != nullptr) { st_pairs += 32u * min(32u, count - gg * 32u); }
+        if (__ballot(any) == 0ull) return;
+        // ---- survivors. On fp32 rows screened through their fp16 copy they are NOT rare (C2: 2.3e-3 per pair, two per 32 x 32
+        // tile): the lanes that hold some count them (a 16-bit mask), ONE wave scan + ONE LDS atomic hand out the positions
+        // (round 3's per-lane loop drew one returning LDS atomic per survivor: most of the kernel's wait cycles at this rate)
+        uint32_t hits = 0u;
+        if (any) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const uint32_t v = (u << 5) + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+            hits |= (acc[i] >= thg && v < r_end) ? (1u << i) : 0u;
+          }
+        }
+        const uint32_t n_mine = (uint32_t)__popc(hits);
+        // the few lanes that hold hits, one after the other under scalar control: a lane's offset = the hits of the lanes before
+        // it (a wave scan by shuffles is six dependent trips through the LDS crossbar: ~600 cycles for usually two survivors)
+        unsigned long long lm = __ballot(hits != 0u);
+        uint32_t total = 0u, my_off = 0u;
+        while (lm != 0ull) {
+          const uint32_t src = (uint32_t)__ffsll((long long)lm) - 1u;
+          lm &= lm - 1ull;
+          if (lane == src) my_off = total;
+          total += (uint32_t)__builtin_amdgcn_readlane(n_mine, src);
+        }
+        if (total == 0u) return;  // (every hit lay past the chunk's end)
+        uint32_t base = 0u;
+        if (lane == 0u) base = atomicAdd(&ctrl[0], total);  // LDS
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t pid = s_pair[gg * 32 + ql];
+        uint32_t pos = base + my_off;
+        uint32_t hb = hits;
+        if (base + total <= a.surv_cap) {  // wave-uniform, the usual case: plain stores (nothing here waits for a memory operation)
+          while (hb != 0u) {
+            const uint32_t i = (uint32_t)__ffs((int)hb) - 1u;
+            hb &= hb - 1u;
+            my_surv[pos++] = make_uint2(pid, base_row + (u << 5) + (i & 3u) + 8u * (i >> 2) + 4u * h);
+          }
+        } else {  // this workgroup's region is (nearly) full: the shared spill region; when that is full too the batch is re-run on the scan kernel
+          while (hb != 0u) {
+            const uint32_t i = (uint32_t)__ffs((int)hb) - 1u;
+            hb &= hb - 1u;
+            const uint32_t v = (u << 5) + (i & 3u) + 8u * (i >> 2) + 4u * h;
+            if (pos < a.surv_cap) {
+              my_surv[pos] = make_uint2(pid, base_row + v);
+            } else {
+              const uint32_t sp = atomicAdd(a.surv_cnt + gridDim.x, 1u);
+              if (sp < a.spill_cap) a.surv[(size_t)gridDim.x * a.surv_cap + sp] = make_uint2(pid, base_row + v);
+              else *a.fail = 1u;
+            }
+            ++pos;
+          }
+        }
+        if (a.stats != nullptr) st_surv += n_mine;
+      };
+      for (uint32_t g = 0; g < ng; ++g) one(g, g + 1u == ng);
+      if (a.stats != nullptr) st_sub += 1u;
+    };
+    if constexpr (DOUBLE) {
+      for (uint32_t u = u0 + wave; u < u1; u += 3u * kF2Waves) {
+        step(u, avA, tmA, avC, tmC);
+        if (u + kF2Waves < u1) step(u + kF2Waves, avB, tmB, avA, tmA);
+        if (u + 2u * kF2Waves < u1) step(u + 2u * kF2Waves, avC, tmC, avB, tmB);
+      }
+    } else {
+      for (uint32_t u = u0 + wave; u < u1; u += kF2Waves) step(u, avA, tmA, avA, tmA);
+    }
+    if (a.stats != nullptr) st_units += 1u;
+  }
+  if (a.stats != nullptr) atomicAdd(&a.stats[1], st_surv);  // counted per lane
+  if (a.stats != nullptr && lane == 0) {
+    atomicAdd(&a.stats[0], st_pairs); atomicAdd(&a.stats[2], st_sub);
+    if (wave == 0) atomicAdd(&a.stats[7], st_units);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(ctrl[0], a.surv_cap);
 }
 
 // ------------------------------------------------------------------ re-score
@@ -1416,7 +1656,8 @@ __global__ __launch_bounds__(256) void pool_merge_kernel(const float* __restrict
 
 // ------------------------------------------------------------------ host side
 unsigned pq3_grid(const resources& res) { return (unsigned)std::max(8, res.num_cus / 8 * 8); }
-unsigned pq3_regions(const resources& res) { return pq3_grid(res); }  // survivor regions of pq_filter_kernel (pq_filter4_kernel: chunks)
+unsigned pq3_regions(const resources& res) { return 2 * pq3_grid(res); }  // room for the survivor-region counters: pq_filter_kernel one region per
+                                                                           // workgroup, flat_filter2_kernel two workgroups per CU (pq_filter4_kernel: chunks)
 
 bool pq3_supported(const ivf_pq_index& idx, int k)
 {
@@ -1785,13 +2026,17 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   if (!flat3_prepare(res, v, cache)) return false;  // no room for the fp16 copy: the caller stays on the scan kernel
   profile_begin(res, "ivf_flat_scan_kernel");  // bench.py sums the scan phases under this name
   const int nch        = (int)v.dim / 32;   // the filter kernel's "chunk" = two K steps of 16 dimensions
-  const uint32_t group = nch <= 4 ? 64u : 32u;
+  // flat_filter2_kernel: units of up to 256 queries per workgroup, B operands in LDS (the caller provides the pre-pass buffers)
+  // (up to 128 dimensions: beyond, the operand registers of the subtile loop spill - 17 .. 148 registers - and round 3's kernel stays)
+  const bool f2        = res.tune.flat_filter2 != 0 && r.bq != nullptr && v.dim <= 128;
+  const uint32_t group = f2 ? 256u : (nch <= 4 ? 64u : 32u);
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes, r.unit_rows, r.unit_off,
                      group);
   hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(v.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, v.n_lists, v.list_offsets,
                      v.list_sizes, r.unit_rows, r.unit_off, units, group);
-  const unsigned grid = pq3_grid(res);
+  // flat_filter2_kernel: two 256-thread workgroups per CU while their operands fit the LDS twice (up to 128 dimensions)
+  const unsigned grid = f2 ? 2 * pq3_grid(res) : pq3_grid(res);  // (two 256-thread workgroups per CU: 2 x 66 KiB of LDS)
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + v.n_lists; f.xcd_ticket = r.xcd_ticket;
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = v.centers;
@@ -1801,7 +2046,7 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   f.spill_cap = r.surv_cap - f.surv_cap * grid;
   f.n_probes = r.n_probes; f.rot_dim = v.dim; f.unit_rows = r.unit_rows;
   f.sc = cache.sc; f.c1 = (r.is_ip ? -1.0f : -2.0f) / (cache.sc * cache.sc); f.cbmax = cache.maxres; f.dmax = r.is_ip ? cache.maxnorm : 0.f;
-  f.is_ip = r.is_ip; f.stats = r.stats;
+  f.is_ip = r.is_ip; f.stats = r.stats; f.dbg = r.filter_dbg;
   f.eps = 1.0f / 65536.0f; f.alpha = 0.f; f.bound_max = FLT_MAX;  // fp32 fma chain over (q - x)^2: 2 roundings per term + 'dim' adds
   // inner product: score -(q . x) with x = c + d; the exact chain's error is below dim 2^-24 sum |q_i x_i| <= dim 2^-24 |q| (|c| + |d|)
   if (r.is_ip) f.eps = (float)v.dim * (1.0f / 4194304.0f);
@@ -1811,6 +2056,30 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kFThreads), 16, res.stream, f);
     profile_end(res, "flat_filter_kernel");
   };
+  auto launch_filter2 = [&](auto kern) {
+    const size_t fsmem = (size_t)8 * (v.dim / 16) * 1024 + 2 * 8 * 32 * 4 + 16;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
+    profile_begin(res, "flat_filter_kernel");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kF2Threads), fsmem, res.stream, f);
+    profile_end(res, "flat_filter_kernel");
+  };
+  if (f2) {
+    // pre-pass: every tail pair's fp16 B operand + threshold (the filter's unit prologue is a copy into LDS)
+    filter4_launch l{};
+    l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = v.n_lists; l.probes = r.probes;
+    l.rot_queries = r.rot_queries; l.centers_rot = v.centers; l.query_kth = r.query_kth; l.qflag = r.qflag;
+    l.bq = r.bq; l.thr = r.thr; l.n_probes = r.n_probes; l.rot_dim = v.dim;
+    l.sc = f.sc; l.c1 = f.c1; l.eps = f.eps; l.alpha = f.alpha; l.cbmax = f.cbmax; l.dmax = f.dmax; l.bound_max = f.bound_max;
+    l.is_ip = r.is_ip; l.nch = (int)v.dim / 32; l.pl = 2; l.n_pairs = r.nq * (int64_t)r.n_probes; l.flat = 1; l.bprep_only = 1;
+    pq4_filter(res, l);
+    f.bq = static_cast<const uint4*>(r.bq); f.thr_pair = r.thr; f.pair_off = r.pair_off; f.n_lists = v.n_lists;
+    switch (v.dim / 16) {
+      case 2:  launch_filter2(flat_filter2_kernel<2>); break;
+      case 4:  launch_filter2(flat_filter2_kernel<4>); break;
+      case 6:  launch_filter2(flat_filter2_kernel<6>); break;
+      default: launch_filter2(flat_filter2_kernel<8>); break;
+    }
+  } else
   switch (nch) {
     case 1: launch_filter(pq_filter_kernel<1, 0, true>); break;
     case 2: launch_filter(pq_filter_kernel<2, 0, true>); break;

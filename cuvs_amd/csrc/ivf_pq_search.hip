@@ -32,6 +32,7 @@
 
 #include <cfloat>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace cuvs_amd {
@@ -2007,6 +2008,11 @@ __global__ void postprocess_kernel(const uint32_t* __restrict__ pos, const float
 // the first search after cuvsAmdIvfPqSetShardComm (attaching is collective, so every rank is in the same state)
 static void shard_exchange_stats(resources& res, const ivf_pq_index& idx)
 {
+  // (threads sharing the index: one of them exchanges - the all-gather is collective ACROSS RANKS, every rank's first searcher
+  // makes it once - the others find the numbers in place)
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (idx.shard_stats_valid) return;
   uint64_t rows = 0;
   uint32_t lists = 0;
   for (uint32_t v : idx.h_list_sizes) { rows += v; lists += v != 0u; }

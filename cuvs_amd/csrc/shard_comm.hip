@@ -84,12 +84,17 @@ void staged_all_gather(resources& res, shm_transport& t, void* buf, size_t bytes
 {
   char* b = static_cast<char*>(buf);
   t.begin(1, bytes);
-  HIP_TRY(hipMemcpyAsync(t.own(), b + (size_t)t.rank() * bytes, bytes, hipMemcpyDeviceToHost, res.stream));
-  sync(res);
-  t.publish();
-  for (int r = 0; r < t.world(); ++r)
-    if (r != t.rank()) HIP_TRY(hipMemcpyAsync(b + (size_t)r * bytes, t.block(r), bytes, hipMemcpyHostToDevice, res.stream));
-  sync(res);
+  try {
+    HIP_TRY(hipMemcpyAsync(t.own(), b + (size_t)t.rank() * bytes, bytes, hipMemcpyDeviceToHost, res.stream));
+    sync(res);
+    t.publish();
+    for (int r = 0; r < t.world(); ++r)
+      if (r != t.rank()) HIP_TRY(hipMemcpyAsync(b + (size_t)r * bytes, t.block(r), bytes, hipMemcpyHostToDevice, res.stream));
+    sync(res);
+  } catch (...) {
+    t.mark_failed();  // (the peers are inside the same collective: they raise instead of waiting out the time limit)
+    throw;
+  }
   t.end();
 }
 
@@ -97,14 +102,19 @@ void staged_all_reduce_min(resources& res, shm_transport& t, uint32_t* keys, siz
 {
   const size_t bytes = count * sizeof(uint32_t);
   t.begin(2, bytes);
-  HIP_TRY(hipMemcpyAsync(t.own(), keys, bytes, hipMemcpyDeviceToHost, res.stream));
-  sync(res);
-  t.publish();
   std::vector<uint32_t> m(count);
-  std::memcpy(m.data(), t.block(0), bytes);
-  for (int r = 1; r < t.world(); ++r) {
-    const uint32_t* o = reinterpret_cast<const uint32_t*>(t.block(r));
-    for (size_t i = 0; i < count; ++i) m[i] = o[i] < m[i] ? o[i] : m[i];
+  try {
+    HIP_TRY(hipMemcpyAsync(t.own(), keys, bytes, hipMemcpyDeviceToHost, res.stream));
+    sync(res);
+    t.publish();
+    std::memcpy(m.data(), t.block(0), bytes);
+    for (int r = 1; r < t.world(); ++r) {
+      const uint32_t* o = reinterpret_cast<const uint32_t*>(t.block(r));
+      for (size_t i = 0; i < count; ++i) m[i] = o[i] < m[i] ? o[i] : m[i];
+    }
+  } catch (...) {
+    t.mark_failed();
+    throw;
   }
   t.end();  // (every rank has read the blocks into its own vector)
   HIP_TRY(hipMemcpyAsync(keys, m.data(), bytes, hipMemcpyHostToDevice, res.stream));

@@ -82,13 +82,21 @@ class shm_transport {
   {
     const std::string& path = path_;
     const int world = world_;
-    fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+    fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
     if (fd_ >= 0) {
       creator = true;
       if (::ftruncate(fd_, (off_t)kShmHeaderBytes) != 0) fail_errno("ftruncate");
     } else if (errno == EEXIST) {
-      fd_ = ::open(path.c_str(), O_RDWR, 0600);
+      // the name comes from a 128-byte id another process handed over, and the fallback directory (/tmp) is world-writable: no
+      // symlinks are followed, and what is mapped must be a regular file of this user with the creator's mode
+      fd_ = ::open(path.c_str(), O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
       if (fd_ < 0) fail_errno("open");
+      {
+        struct stat st0;
+        if (::fstat(fd_, &st0) != 0) fail_errno("fstat");
+        if (!S_ISREG(st0.st_mode) || st0.st_uid != ::geteuid() || (st0.st_mode & 0777) != 0600)
+          throw std::runtime_error("shm transport: " + path + " is not a regular 0600 file of this user - refusing to map it");
+      }
       // wait until the creator has sized the header page
       const auto t0 = now();
       for (;;) {
@@ -147,6 +155,9 @@ class shm_transport {
   char* block(int r) { return data_ + (size_t)r * capacity_; }
   void publish() { barrier(); }  // every block is written
   void end() { barrier(); }      // every block is read: the next collective may overwrite
+  // a rank that leaves a collective by an exception (a HIP error between begin() and end()) tells its peers: they raise at their
+  // next wait instead of spinning until the time limit
+  void mark_failed() noexcept { if (hdr_ != nullptr) hdr_->failed.store(1, std::memory_order_release); }
 
   // host-side forms (what the CPU unit test drives; shard_comm.hip stages device buffers around the same steps)
   void all_gather(const void* send, void* recv, size_t bytes)

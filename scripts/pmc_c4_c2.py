@@ -24,6 +24,9 @@ import bench  # noqa: E402
 D = "/tmp/pmc_idx"
 
 
+ONLY_C2 = os.environ.get("PMC_ONLY_C2") == "1"  # round 6: C2 alone (scripts/gpu_r06_pmc_c2.sh)
+
+
 def build(c4_rows):
     import cuvs_amd
     from cuvs_amd.neighbors import cagra, ivf_flat
@@ -31,6 +34,8 @@ def build(c4_rows):
     os.makedirs(D, exist_ok=True)
     dev = torch.device("cuda", 0)
     res = cuvs_amd.common.Resources()
+    if ONLY_C2:
+        return build_c2(res, dev)
     x = torch.empty((c4_rows, 768), dtype=torch.float16, device=dev)
     bench.gen_rows(c4_rows, 768, 1234, dev, latent=24, n_modes=1, out=x)
     q = torch.empty((10000, 768), dtype=torch.float16, device=dev)
@@ -43,6 +48,12 @@ def build(c4_rows):
     torch.save(q.cpu(), f"{D}/c4_q.pt")
     del idx, x, q
     torch.cuda.empty_cache()
+    build_c2(res, dev)
+
+
+def build_c2(res, dev):
+    from cuvs_amd.neighbors import ivf_flat
+
     x = bench.gen_rows(10_000_000, 128, 1234, dev)
     q = bench.gen_rows(10000, 128, 4321, dev)
     idx = ivf_flat.build(ivf_flat.IndexParams(n_lists=4096, kmeans_trainset_fraction=0.1), x, resources=res)
@@ -58,17 +69,18 @@ def run():
 
     dev = torch.device("cuda", 0)
     res = cuvs_amd.common.Resources()
-    idx = cagra.load(f"{D}/c4.idx", resources=res)
-    q = torch.load(f"{D}/c4_q.pt").to(dev)
-    nb = torch.empty((10000, 10), dtype=torch.int32, device=dev)
     dd = torch.empty((10000, 10), dtype=torch.float32, device=dev)
-    for algo in ("single_cta", "multi_cta"):
-        sp = cagra.SearchParams(itopk_size=64, algo=algo)
-        for _ in range(3):
-            cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res)
-    res.sync()
-    del idx
-    torch.cuda.empty_cache()
+    if not ONLY_C2:
+        idx = cagra.load(f"{D}/c4.idx", resources=res)
+        q = torch.load(f"{D}/c4_q.pt").to(dev)
+        nb = torch.empty((10000, 10), dtype=torch.int32, device=dev)
+        for algo in ("single_cta", "multi_cta"):
+            sp = cagra.SearchParams(itopk_size=64, algo=algo)
+            for _ in range(3):
+                cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res)
+        res.sync()
+        del idx
+        torch.cuda.empty_cache()
     idx = ivf_flat.load(f"{D}/c2.idx", resources=res)
     q = torch.load(f"{D}/c2_q.pt").to(dev)
     nb = torch.empty((10000, 10), dtype=torch.int64, device=dev)
@@ -85,7 +97,7 @@ def summarize(d, out):
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
             name = None
-            for tag in ("cagra_search_multi_kernel", "cagra_search_kernel", "ivf_flat_scan_kernel", "pq_filter_kernel", "flat_rescore_kernel"):
+            for tag in ("cagra_search_multi_kernel", "cagra_search_kernel", "ivf_flat_scan_kernel", "pq_filter_kernel", "flat_filter2_kernel", "flat_rescore_kernel"):
                 if tag in kn:
                     name = tag
             if name is None:
