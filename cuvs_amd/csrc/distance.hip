@@ -499,7 +499,8 @@ __global__ __launch_bounds__(256, OCC) void dist_tile_kernel(const TQ* __restric
         if (bf == 0.f) bf = smin ? -0.f : 0.f;
         const uint32_t best = float_to_key(bf) ^ flip;
         if (row < m) {
-          *reinterpret_cast<f32x4*>(&out[row * ldo + col0 + wn * 64 + l15 * 4]) = v;
+          if (ap.dbg & 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(&out[row * ldo + col0 + wn * 64 + l15 * 4]));
+          else *reinterpret_cast<f32x4*>(&out[row * ldo + col0 + wn * 64 + l15 * 4]) = v;
           if ((l15 & 3) == 0) ap.gkeys[row * ap.ldg + (col0 >> 4) + wn * 4 + (l15 >> 2)] = best;
         }
       }
@@ -662,6 +663,10 @@ bool pairwise_distance_grouped(resources& res, const float* q, int64_t m, int64_
   append_args ap;
   ap.gkeys = gkeys; ap.ldg = ldg;
   ap.dbg = res.tune.tile_dbg & 4;  // CUVS_AMD_TILE_DBG=4: cycles of prologue / main loop / epilogue per tile (stderr)
+  // the selection that follows reads a sixteenth of the matrix (keys) plus the few qualifying groups: from 4096 rows on (the IVF
+  // coarse searches: 10k x 16384 = 655 MB) the tile's 16-byte stores are non-temporal - nothing of the matrix is worth a line of
+  // L2 (10k x 16384 x 128, GEMM + selection: 0.625 -> 0.568 ms, profiles/r06_coarse_nt_probe.log; 1000 x 100000: 3 % slower, plain)
+  if ((m >= 4096 && !(res.tune.tile_dbg & 16)) || (res.tune.tile_dbg & 8)) ap.dbg |= 8;
   dev_buf<unsigned long long> stats;
   if (ap.dbg & 4) {
     stats = dev_buf<unsigned long long>(res, 4);

@@ -1835,6 +1835,8 @@ __global__ void coarse_finish_kernel(float* __restrict__ d, int64_t nq, int n_li
   d[i] = half_out ? (float)(_Float16)v : v;
 }
 
+static std::mutex g_coarse_cache_mu;  // the reduced-precision copies of an index's centres / rotation, built on first use
+
 // n_probes clusters closest to each query (select_clusters, ivf_pq_search.cuh:60-168 fp32, :171-340 int8 / half).
 // qf: [nq, dim] fp32 queries (normalised for cosine); qc: the copy in the coarse type (== qf for fp32)
 void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, int64_t nq, uint32_t n_probes,
@@ -1848,20 +1850,30 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
     const int64_t n_el = (int64_t)idx.n_lists * idx.dim;
     dev_buf<float>& cc = half_t ? idx.coarse_centers_h : idx.coarse_centers_i8;
     dev_buf<float>& ct = half_t ? idx.coarse_norms_h : idx.coarse_normterm_i8;
-    if (cc.data() == nullptr) {
-      cc = dev_buf<float>::persistent((size_t)n_el);
-      ct = dev_buf<float>::persistent(idx.n_lists);
-      if (half_t) {
-        hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.centers.data(),
-                           cc.data(), n_el, (int64_t)idx.dim_ext, (int64_t)idx.dim);
-        hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream,
-                           idx.center_norms.data(), ct.data(), (int64_t)idx.n_lists, (int64_t)1, (int64_t)1);
-      } else {
-        hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.centers.data(),
-                           cc.data(), n_el, (int64_t)idx.dim_ext, (int64_t)idx.dim);
-        const int m = (int)(round_up((int64_t)idx.dim + 2, 16) - idx.dim);  // dim_ext_int8 - dim (ivf_pq_index.cu:668)
-        hipLaunchKernelGGL(int8_norm_term_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream,
-                           idx.center_norms.data(), (int)idx.n_lists, m, !ip, ct.data());
+    {
+      // Derived copies of the index, made by the first search that asks for them - possibly while other host threads search the
+      // same index through handles of their own (benchmark.hpp:296-307). A copy is PUBLISHED (the member's pointer set) under the
+      // lock and only after the kernels that fill it have run: a thread that finds the pointer set may read it from any stream
+      // (tests/test_concurrent_search_gpu.py caught three threads reading the fp16 centres while the fourth's fill was still queued).
+      std::lock_guard<std::mutex> lock(g_coarse_cache_mu);
+      if (cc.data() == nullptr) {
+        auto cc_new = dev_buf<float>::persistent((size_t)n_el);
+        auto ct_new = dev_buf<float>::persistent(idx.n_lists);
+        if (half_t) {
+          hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.centers.data(),
+                             cc_new.data(), n_el, (int64_t)idx.dim_ext, (int64_t)idx.dim);
+          hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream,
+                             idx.center_norms.data(), ct_new.data(), (int64_t)idx.n_lists, (int64_t)1, (int64_t)1);
+        } else {
+          hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.centers.data(),
+                             cc_new.data(), n_el, (int64_t)idx.dim_ext, (int64_t)idx.dim);
+          const int m = (int)(round_up((int64_t)idx.dim + 2, 16) - idx.dim);  // dim_ext_int8 - dim (ivf_pq_index.cu:668)
+          hipLaunchKernelGGL(int8_norm_term_kernel, dim3(nblk(idx.n_lists, 256)), dim3(256), 0, res.stream,
+                             idx.center_norms.data(), (int)idx.n_lists, m, !ip, ct_new.data());
+        }
+        sync(res);
+        ct = std::move(ct_new);
+        cc = std::move(cc_new);
       }
     }
     const int64_t nqe = nq * idx.dim;
@@ -1873,9 +1885,14 @@ void select_clusters(resources& res, const ivf_pq_index& idx, const float* qf, i
       // the products on the matrix cores of the coarse type, the output arithmetic in the kernel's epilogue
       const size_t row_b = (size_t)coarse_lowp_ksteps(!half_t, idx.dim) * 32;
       dev_buf<uint32_t>& cp = half_t ? idx.coarse_pack_h : idx.coarse_pack_i8;
-      if (cp.data() == nullptr) {
-        cp = dev_buf<uint32_t>::persistent((size_t)idx.n_lists * row_b / 4);
-        coarse_lowp_pack(res, !half_t, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim, cp.data());
+      {
+        std::lock_guard<std::mutex> lock(g_coarse_cache_mu);
+        if (cp.data() == nullptr) {
+          auto cp_new = dev_buf<uint32_t>::persistent((size_t)idx.n_lists * row_b / 4);
+          coarse_lowp_pack(res, !half_t, idx.centers.data(), idx.n_lists, idx.dim_ext, idx.dim, cp_new.data());
+          sync(res);
+          cp = std::move(cp_new);
+        }
       }
       dev_buf<uint32_t> qp(res, (size_t)nq * row_b / 4);
       coarse_lowp_pack(res, !half_t, qf, nq, idx.dim, idx.dim, qp.data());
@@ -1941,10 +1958,15 @@ void rotate_queries(resources& res, const ivf_pq_index& idx, const float* qf, co
   const bool half_t  = coarse_dtype == 2;
   dev_buf<float>& rr = half_t ? idx.coarse_rot_h : idx.coarse_rot_i8;
   const int64_t n_el = (int64_t)idx.rot_dim * idx.dim;
-  if (rr.data() == nullptr) {
-    rr = dev_buf<float>::persistent((size_t)n_el);
-    if (half_t) hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.rotation.data(), rr.data(), n_el, (int64_t)idx.dim, (int64_t)idx.dim);
-    else        hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.rotation.data(), rr.data(), n_el, (int64_t)idx.dim, (int64_t)idx.dim);
+  {
+    std::lock_guard<std::mutex> lock(g_coarse_cache_mu);  // (published once filled: see select_clusters)
+    if (rr.data() == nullptr) {
+      auto rr_new = dev_buf<float>::persistent((size_t)n_el);
+      if (half_t) hipLaunchKernelGGL(round_to_half_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.rotation.data(), rr_new.data(), n_el, (int64_t)idx.dim, (int64_t)idx.dim);
+      else        hipLaunchKernelGGL(scale_to_int8_kernel, dim3(nblk(n_el, 256)), dim3(256), 0, res.stream, idx.rotation.data(), rr_new.data(), n_el, (int64_t)idx.dim, (int64_t)idx.dim);
+      sync(res);
+      rr = std::move(rr_new);
+    }
   }
   pairwise_distance<float, float>(res, qc, nq, idx.dim, rr.data(), idx.rot_dim, idx.dim, idx.dim, nullptr, nullptr,
                                   M_InnerProduct, rot_q, idx.rot_dim);

@@ -13,7 +13,7 @@ fn.restype = C.c_int
 for (m, n, dim, k) in ((10000, 16384, 128, 128), (1000, 100000, 128, 10)):
     q = torch.randn((m, dim), device="cuda"); x = torch.randn((n, dim), device="cuda")
     ov = torch.empty((m, k), device="cuda"); oi = torch.empty((m, k), dtype=torch.int32, device="cuda")
-    for dbg in (0, 4):
+    for dbg in (0, 8, 4):
         r = bench.comparator_handle(CUVS_AMD_TILE_DBG=dbg)
         for grouped in (1, 0):
             if grouped and n % 1 != 0:
