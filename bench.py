@@ -720,14 +720,15 @@ def extra_c2(res, dev):
             "int8_rows": int8_line, "other_metrics": ip_line,
             "config": "C2 IVF-Flat 10000000x128 fp32 n_lists=4096 n_probes=64 batch=10000 k=10", "ms": round(dt * 1e3, 3),
             "qps": round(nq / dt, 1), "recall_at_10": round(r, 4), "build_seconds": round(build_s, 1),
-            "kernel": "ivf_flat_scan_kernel (head phase) + pq_filter_kernel<FLAT> + flat_rescore_kernel (tail phase)",
+            "kernel": "bound-only head phase (flat_filter2_kernel<EMIT> over the nearest lists + select_k + exact bound of the k best) + flat_filter2_kernel + flat_rescore_kernel (all 64 probes)",
             "kernel_ms_per_step": round(scan_ms, 3), "launches_per_step": launches,
             "roofline": {"bound": "hbm", "logical_scan_gbs": round(logical / (scan_ms * 1e-3) / 1e9, 1),
                          "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                          "unique_bytes": unique,
                          "note": "frac = algorithmic unique bytes (every row of the index once, 10M x 512 B) / (scan-kernel time x 8 TB/s); "
-                                 "the kernels actually fetch more: fp32 rows for the head phase plus the fp16 residual copy for the "
-                                 "matrix-core tail phase. logical_scan_gbs = list bytes per pair and kernel second (SURVEY 8d)"}}
+                                 "what the kernels fetch (profiles/r06_pmc_c2.json): the fp16 residual copy twice (bound-only head phase over "
+                                 "the nearest lists 2.50 GB, filter 2.83 GB) and the fp32 rows of the survivors (re-score 2.32 GB) = 7.7 GB. "
+                                 "logical_scan_gbs = list bytes per pair and kernel second (SURVEY 8d)"}}
 
 
 def extra_c4_family(res, dev, rows=2_000_000, latent=24):

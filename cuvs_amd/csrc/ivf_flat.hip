@@ -884,6 +884,15 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   const bool f2 = use3 && res.tune.flat_filter2 != 0 && idx.dim <= 128;
   dev_buf<uint4> bq3(res, f2 ? (size_t)np_max * (idx.dim / 8) : 0);
   dev_buf<float> thr3(res, f2 ? (size_t)np_max : 0);
+  // Bound-only head phase (round 6, L2 family without a bitset filter; CUVS_AMD_FLAT_BOUND_HEAD=0: the exact head phase on the scan
+  // kernel): the nearest list of every query is screened through its fp16 copy like the other 63 - the head pass only has to leave
+  // an upper bound of the query's k-th best score (ivf_pq_scan3.hpp: flat3_head_bounds)
+  const bool bound_head = f2 && head == 1 && metric_is_l2(idx.metric) && filter_bits == nullptr && res.tune.flat_bound_head != 0;
+  // (rows of at least 4096 values: select_k's one-read kernel serves them; the padding is -inf)
+  const uint32_t hb_ldx = (uint32_t)std::max<int64_t>(4096, round_up((int64_t)max_list_len + 64, 64));
+  dev_buf<float> hb_x(res, bound_head ? (size_t)bs * hb_ldx : 0), hb_kv(res, bound_head ? (size_t)bs * k : 0), hb_thr(res, bound_head ? (size_t)bs : 0);
+  dev_buf<uint32_t> hb_ki(res, bound_head ? (size_t)bs * k : 0), hb_tk(res, bound_head ? 8 * 32 : 0);
+  dev_buf<float4> hb_nm(res, bound_head ? (size_t)bs : 0);
   const float raw_mult = et == elem_t::i8 ? 128.0f : et == elem_t::u8 ? 256.0f : 1.0f;
   const bool raw3      = use3 && raw_mult != 1.0f;
   dev_buf<float> q_unit(res, use3 && cos3 ? (size_t)bs * idx.dim : 0);  // cosine: unit-length queries for the filter
@@ -1000,10 +1009,17 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     // grids are upper bounds of the (device-side) item counts of each phase; surplus workgroups exit at once
     bool merged = false;
     if (head > 0) {
-      a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
-      launch(a, (unsigned)(nq * head / qpb + idx.n_lists + 1));
-      trace.mark("head launch");
-      a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
+      // the bound-only head phase needs the tail phase's run description (pairs, queries in the tail's space): set up below, the exact
+      // head launch happens there when the bound-only pass is not taken
+      bool head_done = false;
+      auto exact_head = [&]() {
+        a.item_begin = nullptr; a.item_end = item_off.data() + idx.n_lists;
+        launch(a, (unsigned)(nq * head / qpb + idx.n_lists + 1));
+        trace.mark("head launch");
+        a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
+        head_done = true;
+      };
+      if (!(use3 && bound_head)) exact_head();
       if (use3) {
         pq3_run r{};
         r.nq = nq; r.n_probes = n_probes; r.k = (uint32_t)k; r.head = head; r.is_ip = (idx.metric == M_InnerProduct || cos3) ? 1 : 0;
@@ -1036,6 +1052,19 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
                      et == elem_t::f32 ? 0 : et == elem_t::f16 ? 1 : et == elem_t::i8 ? 2 : 3, cos3};
         const bool tdbg = (res.tune.scan_debug & 1024) != 0;
         auto now = [&]() { if (tdbg) sync(res); return std::chrono::steady_clock::now(); };
+        bool hb_used = false;
+        if (!head_done) {
+          HIP_TRY(hipMemsetAsync(hb_tk.data(), 0, hb_tk.bytes(), res.stream));
+          flat3_head_bufs hb{hb_x.data(), hb_ldx, hb_kv.data(), hb_ki.data(), hb_thr.data(), hb_nm.data(), hb_tk.data()};
+          if (flat3_head_bounds(res, v, idx.scan3, r, hb)) {
+            r.hb_xbuf = hb_x.data(); r.hb_ldx = hb_ldx; r.hb_thr = hb_thr.data();
+            a.item_begin = item_off.data() + idx.n_lists; a.item_end = item_off.data() + 2 * idx.n_lists;
+            hb_used = true;
+            trace.mark("bound-only head enqueued");
+          } else {
+            exact_head();  // (no room for the fp16 copy)
+          }
+        }
         const auto t0 = now();
         if (flat3_tail(res, v, idx.scan3, r)) {
           trace.mark("tail enqueued");
@@ -1052,6 +1081,11 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
           hipLaunchKernelGGL(flat_reset_rows_if_kernel, dim3(1024), dim3(256), 0, res.stream, r.fail, cand_d.data(), cand_i.data(),
                              (int64_t)nq, (int64_t)n_probes * k, (uint32_t)(head * k));
           a.run_if = r.fail;
+          if (hb_used) {  // the head pairs' lists as well: the bound-only head phase left bounds, not candidates
+            flat_scan_args ah = a;
+            ah.item_begin = nullptr; ah.item_end = item_off.data() + idx.n_lists;
+            launch(ah, (unsigned)(nq * head / qpb + idx.n_lists + 1));
+          }
           launch(a, (unsigned)(nq * (n_probes - head) / qpb + idx.n_lists + 1));
           a.run_if = nullptr;
           select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,

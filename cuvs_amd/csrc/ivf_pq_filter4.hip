@@ -30,6 +30,7 @@ struct bprep_params {
   const uint32_t* sorted_pairs;
   const uint32_t* pair_off;  // [2 n_lists + 1]: the tail pairs are sorted_pairs[pair_off[n_lists] .. pair_off[2 n_lists])
   uint32_t n_lists;
+  uint32_t lbase;          // first label of the pairs served: n_lists (tail pairs) or 0 (head pairs: IVF-Flat's bound-only head phase)
   const uint32_t* probes;  // [n_pairs] list of every pair
   const float* rot_queries;
   const float* centers_rot;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
 {
   constexpr uint32_t LPP = 2 * NST <= 2 ? 2u : 2 * NST <= 4 ? 4u : 2 * NST <= 8 ? 8u : 2 * NST <= 16 ? 16u : 32u;  // lanes per pair
   constexpr uint32_t PPW = 64u / LPP;                                                                            // pairs per pass
-  const uint32_t s_base = a.pair_off[a.n_lists], s_end = a.pair_off[2 * a.n_lists];
+  const uint32_t s_base = a.pair_off[a.lbase], s_end = a.pair_off[a.lbase + a.n_lists];
   const uint32_t lane = threadIdx.x & 63u, slot = lane % LPP, st = slot >> 1, h = slot & 1u;
   const uint32_t w0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 32u;
   if (s_base + w0 >= s_end) return;  // wave-uniform
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void pq_bprep_kernel(const bprep_params a)
 // the second half of the pre-pass (two-stream schedule): thresholds of the tail pairs from the head phase's bounds
 __global__ __launch_bounds__(256) void pq_thr_kernel(const bprep_params a)
 {
-  const uint32_t s_base = a.pair_off[a.n_lists], s_end = a.pair_off[2 * a.n_lists];
+  const uint32_t s_base = a.pair_off[a.lbase], s_end = a.pair_off[a.lbase + a.n_lists];
   const uint32_t s = s_base + blockIdx.x * 256u + threadIdx.x;
   if (s >= s_end) return;
   const uint32_t q  = a.sorted_pairs[s] / a.n_probes;
@@ -550,7 +551,7 @@ void pq4_filter(resources& res, const filter4_launch& l)
   b.rot_queries = l.rot_queries; b.centers_rot = l.centers_rot; b.query_kth = l.query_kth; b.qflag = l.qflag;
   b.bq = static_cast<uint4*>(l.bq); b.thr = l.thr; b.n_probes = l.n_probes; b.rot_dim = l.rot_dim;
   b.sc = l.sc; b.c1 = l.c1; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = l.cbmax; b.dmax = l.dmax; b.bound_max = l.bound_max;
-  b.is_ip = l.is_ip; b.flat = l.flat;
+  b.is_ip = l.is_ip; b.flat = l.flat; b.lbase = l.head_labels ? 0u : l.n_lists;
   b.lpl = l.pl == 1 ? 0u : l.pl == 2 ? 1u : l.pl == 4 ? 2u : 3u;
   const int nst = l.nch * l.pl;  // MFMA K steps
   const unsigned pgrid = (unsigned)grid_blocks(l.n_pairs, 128);

@@ -87,6 +87,7 @@ struct filter4_launch {
   void* pair_norms = nullptr; // [tail pairs] float4 between stage 1 and stage 2
   int flat = 0;               // IVF-Flat's pairs (an unserved query survives everything instead of being handed back)
   int bprep_only = 0;         // the pre-pass alone (B operands + thresholds): IVF-Flat's flat_filter2_kernel follows it
+  int head_labels = 0;        // the pre-pass over the HEAD pairs (labels [0, n_lists)) instead of the tail pairs: IVF-Flat's bound-only head phase
 };
 void pq4_filter(resources& res, const filter4_launch& l);
 

@@ -144,7 +144,7 @@ __global__ void row_term_kernel(const uint8_t* __restrict__ codes, const float* 
 
 __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
                                                            const uint32_t* __restrict__ list_sizes, uint32_t unit_rows,
-                                                           uint32_t* __restrict__ unit_off, uint32_t group)
+                                                           uint32_t* __restrict__ unit_off, uint32_t group, uint32_t lbase)
 {
   // a thread takes a run of consecutive lists, one block scan of the 1024 run totals (two passes instead of n_lists / 1024
   // block scans with three barriers each)
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __res
   const uint32_t per = (n_lists + 1023u) / 1024u;
   const uint32_t b = threadIdx.x * per, e = min(n_lists, b + per);
   auto units_of = [&](uint32_t i) {
-    const uint32_t np = pair_off[n_lists + i + 1] - pair_off[n_lists + i];  // tail labels: n_lists + list
+    const uint32_t np = pair_off[lbase + i + 1] - pair_off[lbase + i];  // tail labels: lbase = n_lists (head labels: 0)
     const uint32_t len = list_sizes[i];
     return (int)(((np + group - 1u) / group) * ((len + unit_rows - 1u) / unit_rows));  // (empty lists: no units)
   };
@@ -170,11 +170,11 @@ __global__ __launch_bounds__(1024) void count_units_kernel(const uint32_t* __res
 __global__ void fill_units_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists,
                                   const uint32_t* __restrict__ list_offsets, const uint32_t* __restrict__ list_sizes,
                                   uint32_t unit_rows, const uint32_t* __restrict__ unit_off, filter_unit* __restrict__ units,
-                                  uint32_t group)
+                                  uint32_t group, uint32_t lbase)
 {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= n_lists) return;
-  const uint32_t b = pair_off[n_lists + L], e = pair_off[n_lists + L + 1], len = list_sizes[L];
+  const uint32_t b = pair_off[lbase + L], e = pair_off[lbase + L + 1], len = list_sizes[L];
   uint32_t w = unit_off[L];
   if (b == e || len == 0u) return;
   // the list is cut into ceil(len / unit_rows) chunks of equal length (a multiple of 64 rows); row chunk major: the query
@@ -231,6 +231,10 @@ struct filter_params {
   const float* thr_pair;
   const uint32_t* pair_off;
   uint32_t n_lists;
+  // EMIT build of flat_filter2_kernel (the bound-only head phase): the screened value of every (head pair, row) goes to
+  // xbuf[pair position][row of the list], ldx floats per pair; lbase: first label of the pairs served (0: head pairs)
+  float* xbuf;
+  uint32_t ldx, lbase;
 };
 
 // NCH: 16-byte code chunks per row = pq_dim / 16 (pq_len 2: rot_dim = 32 NCH, 2 NCH MFMA K steps). Up to 4 chunks a
@@ -512,7 +516,9 @@ __global__ __launch_bounds__(kFThreads) void pq_filter_kernel(const filter_param
 constexpr int kF2Threads = 256;  // 4 waves; two workgroups per CU (one builds its unit's operands while the other streams rows)
 constexpr int kF2Waves   = kF2Threads / 64;
 
-template <int NST>
+// EMIT (the bound-only head phase, 3.1c): no screen - the value of every (pair, row) is written to a.xbuf (rows past the chunk's
+// end: -inf); the pairs are the head pairs (a.lbase = 0), thresholds and pair ids are not read
+template <int NST, bool EMIT = false>
 __global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filter_params a)
 {
   constexpr int NGM      = 8;          // query groups per unit
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filte
   const uint32_t ql = lane & 31u, h = lane >> 5;
   const uint32_t n_units = *a.n_units;
   const uint32_t chunk   = (n_units + 7u) / 8u;
-  const uint32_t s_base  = a.pair_off[a.n_lists];  // first tail pair in sorted_pairs
+  const uint32_t s_base  = a.pair_off[EMIT ? a.lbase : a.n_lists];  // first pair served (tail pairs; EMIT: head pairs) in sorted_pairs
   uint32_t xcd = blockIdx.x & 7u, hops = 0u;  // (thread 0's: the workgroup's position in the XCD shares)
   unsigned long long st_pairs = 0, st_surv = 0, st_sub = 0, st_units = 0;
   const u32x4_t oq   = {h == 0u ? 0x3c003c00u : 0u, 0u, 0u, 0u};
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filte
       const uint4* bp   = a.bq + ((size_t)(first - s_base + jc) * NST * 2 + h);
 #pragma unroll
       for (int st = 0; st < NST; ++st) Bs[(g * NST + st) * 64 + lane] = bp[st * 2];
-      if (h == 0u) {
+      if (!EMIT && h == 0u) {
         s_thr[g * 32 + ql]  = jj < count ? a.thr_pair[first - s_base + jc] : INFINITY;  // (a padding slot keeps nothing)
         s_pair[g * 32 + ql] = a.sorted_pairs[first + jc];
       }
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filte
     float th_next = INFINITY;
     load_b_half(0u, 0, bq);
     load_b_half(0u, 1, bq);
-    th_next = s_thr[ql];
+    if constexpr (!EMIT) th_next = s_thr[ql];
     auto step = [&](const uint32_t u, u32x4_t (&cur)[NST], uint32_t& tcur, auto& nxt, uint32_t& tnxt) {
       const uint32_t term = h == 0u ? tcur : 0u;
       if constexpr (DOUBLE) load_rows(u + 2u * kF2Waves, nxt, tnxt);  // (nxt: the set the subtile before this one has just left)
@@ -646,10 +652,29 @@ __global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filte
         if (a.row_term != nullptr) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(top, ones, acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         load_b_half(gn, 1, bq);
-        th_next = s_thr[gn * 32 + ql];
+        if constexpr (!EMIT) th_next = s_thr[gn * 32 + ql];
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!DOUBLE) {
           if (last) load_rows(u + kF2Waves, cur, tcur);  // one register set: the next subtile's rows once this one's last MFMAs are issued
+        }
+        if constexpr (EMIT) {
+          // registers 4 j .. 4 j + 3 of a lane are the rows 8 j + 4 h .. + 3 of the subtile: one 16-byte store each
+          const uint32_t jj = gg * 32u + ql;
+          if (jj < count) {
+            float* xp = a.xbuf + (size_t)(first - s_base + jj) * a.ldx + (u << 5) + 4u * h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t v0 = (u << 5) + 8u * j + 4u * h;
+              // (gfx950 counts loads and stores in one counter: with both kinds outstanding the compiler waits for everything before a
+              // loaded row is used, so the stores cost this loop part of its prefetch - 0.53 ms for 2.5 GB. Issuing them from inline asm,
+              // hidden from the wait insertion, measured the same and broke a parity test: taken out again.)
+              float4 o;
+              o.x = v0 + 0u < r_end ? acc[4 * j + 0] : -INFINITY; o.y = v0 + 1u < r_end ? acc[4 * j + 1] : -INFINITY;
+              o.z = v0 + 2u < r_end ? acc[4 * j + 2] : -INFINITY; o.w = v0 + 3u < r_end ? acc[4 * j + 3] : -INFINITY;
+              *reinterpret_cast<float4*>(xp + 8 * j) = o;
+            }
+          }
+          return;
         }
         // accumulator register i of this lane is row (i & 3) + 8 (i >> 2) + 4 h of the subtile; a pair survives when acc >= thr
         float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
@@ -731,7 +756,142 @@ __global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filte
     if (wave == 0) atomicAdd(&a.stats[7], st_units);
   }
   __syncthreads();
-  if (threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(ctrl[0], a.surv_cap);
+  if (!EMIT && threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(ctrl[0], a.surv_cap);
+}
+
+template <typename T>
+__device__ inline void chunk_to_float(const uint4& w, float (&x)[16 / sizeof(T)]);  // (defined with the FLAT kernels below)
+
+// ---- the bound-only head phase of IVF-Flat (L2; 3.1c): bounds and head-pair survivors from the emitted values
+// value of a (pair, row): acc = sc^2 (r . d16) - |d|^2 (1 - 2^-9) sc^2 / 2 - larger is nearer, up to the fp16 roundings. The bound of a
+// query is NOT derived from the values' error terms (in a 32-d latent space a bound 10 % looser in the squared distance lets 4.6 x
+// the rows through: measured, re-score 0.35 -> 2.7 ms): the k rows with the largest values are scored EXACTLY - the re-score's
+// chain, t = q - x, acc = fma(t, t, acc) in dimension order - and the largest of those k exact scores is the bound: k rows of the
+// list are at or below it, so it bounds the query's k-th best score from above, and it IS the exact head phase's bound whenever
+// the screen ranks the list's best k rows first.
+struct head_bound_params {
+  const float* kth_val;          // [n_head, k] the k largest values of every head pair (select_k, select_min = false)
+  const uint32_t* kth_idx;       // [n_head, k] their rows (inside the list)
+  const float4* norms;           // [n_head] (|r|^2, ., ., largest scaled operand) from the pre-pass
+  const uint32_t* sorted_pairs;  // head pairs first (labels [0, n_lists))
+  const uint32_t* pair_off;
+  const uint32_t* probes;
+  const uint32_t* list_offsets;
+  const uint8_t* data;           // the index's rows (interleaved chunks)
+  const float* queries;          // the exact chain's queries (rescore_params::rot_queries)
+  uint32_t n_lists, n_probes, k, dim, n_chunks;
+  float sc, eps, alpha, cbmax, c1;
+  uint32_t rot_dim;
+  uint32_t* query_kth;           // out: bound keys
+  float* thr_head;               // out: [n_head] the head pair's threshold in accumulator units (as pq_bprep_kernel forms it)
+  float bound_max;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void flat_head_bound_kernel(const head_bound_params a)
+{
+  const uint32_t n_head = a.pair_off[a.n_lists];
+  const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (i >= n_head) return;  // wave-uniform
+  const uint32_t p = a.sorted_pairs[i], q = p / a.n_probes, L = a.probes[p];
+  const uint32_t base_row = a.list_offsets[L];
+  const float* rq = a.queries + (size_t)q * a.dim;
+  float worst = 0.f;   // largest exact score among the k candidates (scores are sums of squares: >= 0)
+  bool short_list = false;
+  for (uint32_t j0 = 0; j0 < a.k; j0 += 64u) {
+    const uint32_t j = j0 + lane;
+    if (j < a.k) {
+      if (!(a.kth_val[(size_t)i * a.k + j] > -INFINITY)) {
+        short_list = true;  // fewer than k rows in the list: no finite bound
+      } else {
+        const uint32_t row = base_row + a.kth_idx[(size_t)i * a.k + j];
+        const uint4* cp = reinterpret_cast<const uint4*>(a.data) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
+        constexpr int VL = 16 / sizeof(T);
+        float acc = 0.f;
+        for (uint32_t c = 0; c < a.n_chunks; ++c) {
+          float x[VL];
+          chunk_to_float<T>(cp[(size_t)c * 64], x);
+#pragma unroll
+          for (int e4 = 0; e4 < VL / 4; ++e4) {
+            const float4 qv   = *reinterpret_cast<const float4*>(rq + c * VL + e4 * 4);
+            const float qq[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float t = qq[e] - x[e4 * 4 + e];
+              acc = __fmaf_rn(t, t, acc);
+            }
+          }
+        }
+        worst = fmaxf(worst, acc);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+  const bool no_bound = __ballot(short_list) != 0ull;
+  if (lane != 0u) return;
+  const float rn = a.norms[i].x, big = a.norms[i].w;
+  const float bound  = no_bound ? INFINITY : worst;
+  const uint32_t key = no_bound ? 0xffffffffu : float_to_key(bound);
+  a.query_kth[q] = key;
+  const bool served = key < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max;
+  a.thr_head[i] = served ? filter_threshold(bound, rn, a) / a.c1 : -INFINITY;  // (unserved: everything survives, as in the pre-pass)
+}
+
+// the head pair's own candidates: rows of its list whose value reaches the threshold -> the survivor buffer. Runs BEHIND the filter:
+// the regions' fills are final, a wave appends to the region (head pair index mod regions) with one atomic - spread over all regions,
+// because the re-score gives every region one workgroup column (all of them in the shared region: 8 workgroups for 300 k entries,
+// 1.5 ms) - and to the shared region only when its region is full
+__global__ __launch_bounds__(256) void flat_head_survivors_kernel(const float* __restrict__ xbuf, uint32_t ldx, const float* __restrict__ thr_head,
+                                                                  const uint32_t* __restrict__ sorted_pairs, const uint32_t* __restrict__ pair_off,
+                                                                  uint32_t n_lists, const uint32_t* __restrict__ probes,
+                                                                  const uint32_t* __restrict__ list_offsets, const uint32_t* __restrict__ list_sizes,
+                                                                  uint2* __restrict__ surv, uint32_t* __restrict__ surv_cnt, uint32_t n_regions,
+                                                                  uint32_t surv_cap, uint32_t spill_cap, uint32_t* __restrict__ fail)
+{
+  const uint32_t n_head = pair_off[n_lists];
+  const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (i >= n_head) return;  // wave-uniform
+  const uint32_t p = sorted_pairs[i], L = probes[p];
+  const uint32_t len = list_sizes[L], base_row = list_offsets[L];
+  const float th = thr_head[i];
+  const float* x = xbuf + (size_t)i * ldx;
+  uint32_t total = 0u;
+  for (uint32_t r0 = 0; r0 < len; r0 += 64u) {
+    const uint32_t r = r0 + lane;
+    total += (uint32_t)__popcll(__ballot(r < len && x[r] >= th));
+  }
+  if (total == 0u) return;
+  const uint32_t ri = i % n_regions;
+  uint32_t base = 0u;
+  if (lane == 0u) base = atomicAdd(surv_cnt + ri, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const uint32_t n_fit = base >= surv_cap ? 0u : min(total, surv_cap - base);  // what the region still holds; the rest: shared region
+  uint32_t sbase = 0u;
+  if (n_fit < total) {  // wave-uniform
+    if (lane == 0u) { atomicMin(surv_cnt + ri, surv_cap); sbase = atomicAdd(surv_cnt + n_regions, total - n_fit); }
+    sbase = __builtin_amdgcn_readfirstlane(sbase);
+    if (sbase + (total - n_fit) > spill_cap && lane == 0u) *fail = 1u;  // (the batch is re-run on the scan kernel; what fits is still
+                                                                         // written: the re-score reads min(count, capacity) entries)
+  }
+  uint2* region = surv + (size_t)ri * surv_cap;
+  uint2* shared = surv + (size_t)n_regions * surv_cap;
+  uint32_t done = 0u;
+  for (uint32_t r0 = 0; r0 < len; r0 += 64u) {
+    const uint32_t r = r0 + lane;
+    const bool hit = r < len && x[r] >= th;
+    const unsigned long long m = __ballot(hit);
+    const uint32_t kth = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (hit) {
+      if (kth < n_fit) region[base + kth] = make_uint2(p, base_row + r);
+      else if (sbase + (kth - n_fit) < spill_cap) shared[sbase + (kth - n_fit)] = make_uint2(p, base_row + r);
+    }
+    done += (uint32_t)__popcll(m);
+  }
+}
+
+__global__ void fill_f32_kernel(float* __restrict__ p, size_t n, float v)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
 // ------------------------------------------------------------------ re-score
@@ -1782,9 +1942,9 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   auto* units = static_cast<filter_unit*>(r.units);
   if (r.stage != 2) {
     hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(),
-                       r.unit_rows, r.unit_off, group);
+                       r.unit_rows, r.unit_off, group, idx.n_lists);
     hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
-                       idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, group);
+                       idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, group, idx.n_lists);
   }
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket;
@@ -2021,6 +2181,66 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
   return true;
 }
 
+bool flat3_head_bounds(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r, const flat3_head_bufs& hb)
+{
+  if (!flat3_prepare(res, v, cache)) return false;
+  CUVS_EXPECTS(v.dim <= 128 && r.bq != nullptr && !r.is_ip, "ivf_flat: the bound-only head phase serves L2 up to 128 dimensions");
+  profile_begin(res, "ivf_flat_scan_kernel");
+  profile_begin(res, "flat_head_kernel");
+  const float c1 = -2.0f / (cache.sc * cache.sc);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(1024), dim3(256), 0, res.stream, hb.xbuf, (size_t)r.nq * hb.ldx, -INFINITY);
+  // B operands + norms of the head pairs (the pre-pass without thresholds)
+  filter4_launch l{};
+  l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = v.n_lists; l.probes = r.probes;
+  l.rot_queries = r.rot_queries; l.centers_rot = v.centers; l.query_kth = r.query_kth; l.qflag = r.qflag;
+  l.bq = r.bq; l.thr = hb.thr_head; l.n_probes = r.n_probes; l.rot_dim = v.dim;
+  l.sc = cache.sc; l.c1 = c1; l.eps = 1.0f / 65536.0f; l.alpha = 0.f; l.cbmax = cache.maxres; l.dmax = 0.f; l.bound_max = FLT_MAX;
+  l.is_ip = 0; l.nch = (int)v.dim / 32; l.pl = 2; l.n_pairs = r.nq; l.flat = 1; l.head_labels = 1; l.stage = 1; l.pair_norms = hb.norms;
+  pq4_filter(res, l);
+  auto* units = static_cast<filter_unit*>(r.units);
+  hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes, r.unit_rows, r.unit_off,
+                     256u, 0u);
+  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(v.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, v.n_lists, v.list_offsets,
+                     v.list_sizes, r.unit_rows, r.unit_off, units, 256u, 0u);
+  filter_params f{};
+  f.units = units; f.n_units = r.unit_off + v.n_lists; f.xcd_ticket = hb.tickets; f.sorted_pairs = r.sorted_pairs;
+  f.list_offsets = v.list_offsets; f.list_sizes = v.list_sizes; f.row_term = cache.row_term.data(); f.rows16 = cache.rows16.data();
+  f.bq = static_cast<const uint4*>(r.bq); f.pair_off = r.pair_off; f.n_lists = v.n_lists; f.lbase = 0u; f.xbuf = hb.xbuf; f.ldx = hb.ldx;
+  f.n_probes = r.n_probes; f.rot_dim = v.dim; f.sc = cache.sc; f.c1 = c1;
+  const unsigned grid = 2 * pq3_grid(res);
+  auto launch_emit = [&](auto kern) {
+    const size_t fsmem = (size_t)8 * (v.dim / 16) * 1024 + 2 * 8 * 32 * 4 + 16;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kF2Threads), fsmem, res.stream, f);
+  };
+  switch (v.dim / 16) {
+    case 2:  launch_emit(flat_filter2_kernel<2, true>); break;
+    case 4:  launch_emit(flat_filter2_kernel<4, true>); break;
+    case 6:  launch_emit(flat_filter2_kernel<6, true>); break;
+    default: launch_emit(flat_filter2_kernel<8, true>); break;
+  }
+  // the k largest values of every head pair (value = -(approximate score) up to a per-pair constant: larger is nearer)
+  select_k<uint32_t, uint32_t>(res, hb.xbuf, nullptr, r.nq, (int64_t)hb.ldx, (int64_t)hb.ldx, (int)r.k, hb.kth_val, hb.kth_idx, false);
+  head_bound_params b{};
+  b.kth_val = hb.kth_val; b.kth_idx = hb.kth_idx; b.norms = static_cast<const float4*>(hb.norms); b.sorted_pairs = r.sorted_pairs;
+  b.pair_off = r.pair_off; b.probes = r.probes; b.list_offsets = v.list_offsets; b.data = v.data;
+  b.queries = r.rescore_queries != nullptr ? r.rescore_queries : r.rot_queries;
+  b.n_lists = v.n_lists; b.n_probes = r.n_probes; b.k = r.k; b.dim = v.dim; b.n_chunks = v.n_chunks;
+  b.sc = cache.sc; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = cache.maxres; b.c1 = c1; b.rot_dim = v.dim;
+  b.query_kth = const_cast<uint32_t*>(r.query_kth); b.thr_head = hb.thr_head; b.bound_max = FLT_MAX;
+  const dim3 bgrid((unsigned)grid_blocks(r.nq, 4));
+  switch (v.elem) {
+    case 0: hipLaunchKernelGGL(flat_head_bound_kernel<float>, bgrid, dim3(256), 0, res.stream, b); break;
+    case 1: hipLaunchKernelGGL(flat_head_bound_kernel<__half>, bgrid, dim3(256), 0, res.stream, b); break;
+    case 2: hipLaunchKernelGGL(flat_head_bound_kernel<int8_t>, bgrid, dim3(256), 0, res.stream, b); break;
+    default: hipLaunchKernelGGL(flat_head_bound_kernel<uint8_t>, bgrid, dim3(256), 0, res.stream, b); break;
+  }
+  profile_end(res, "flat_head_kernel");
+  profile_end(res, "ivf_flat_scan_kernel");
+  HIP_TRY(hipGetLastError());
+  return true;
+}
+
 bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r)
 {
   if (!flat3_prepare(res, v, cache)) return false;  // no room for the fp16 copy: the caller stays on the scan kernel
@@ -2032,9 +2252,9 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   const uint32_t group = f2 ? 256u : (nch <= 4 ? 64u : 32u);
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes, r.unit_rows, r.unit_off,
-                     group);
+                     group, v.n_lists);
   hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(v.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, v.n_lists, v.list_offsets,
-                     v.list_sizes, r.unit_rows, r.unit_off, units, group);
+                     v.list_sizes, r.unit_rows, r.unit_off, units, group, v.n_lists);
   // flat_filter2_kernel: two 256-thread workgroups per CU while their operands fit the LDS twice (up to 128 dimensions)
   const unsigned grid = f2 ? 2 * pq3_grid(res) : pq3_grid(res);  // (two 256-thread workgroups per CU: 2 x 66 KiB of LDS)
   filter_params f{};
@@ -2090,6 +2310,10 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
     case 7: launch_filter(pq_filter_kernel<7, 0, true>); break;
     default: launch_filter(pq_filter_kernel<8, 0, true>); break;
   }
+  if (r.hb_xbuf != nullptr)  // the bound-only head phase: the head pairs' own candidates join the survivors (shared region)
+    hipLaunchKernelGGL(flat_head_survivors_kernel, dim3((unsigned)grid_blocks(r.nq, 4)), dim3(256), 0, res.stream, r.hb_xbuf, r.hb_ldx, r.hb_thr,
+                       r.sorted_pairs, r.pair_off, v.n_lists, r.probes, v.list_offsets, v.list_sizes,
+                       f.surv, r.surv_cnt, grid, f.surv_cap, f.spill_cap, r.fail);
   rescore_params s{};
   s.surv = f.surv; s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap; s.probes = r.probes;
   s.n_regions = grid; s.sub = 1;

@@ -56,6 +56,11 @@ struct pq3_run {
   // Partial head (round 5): the head phase scored only the first head_rows rows of every query's nearest list; that pair is
   // ALSO a tail pair of its list (all its rows are screened against the bound), and the re-score drops what the head phase
   // has already scored - survivors of a head pair (probe rank < head) below head_rows. 0: the head phase scored whole lists.
+  // IVF-Flat's bound-only head phase (flat3_head_bounds): values of every (head pair, row) and the head pairs' thresholds; the tail
+  // phase turns them into the head pairs' survivors. nullptr: the head phase scored its lists exactly (ivf_flat_scan_kernel)
+  const float* hb_xbuf = nullptr;
+  uint32_t hb_ldx = 0;
+  const float* hb_thr = nullptr;
   uint32_t head_rows = 0;    // [tail pairs] x 16 bytes (|r|^2, |c|^2, q.c, largest scaled operand), written by stage 1
 };
 
@@ -106,6 +111,18 @@ bool flat3_supported(uint32_t dim, int k);
 // raised when a buffer ran over: the caller then re-runs the tail phase on the scan kernel. Returns false (nothing
 // launched) when the device has no room for the fp16 copy.
 bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r);
+// The head phase as a BOUND-ONLY pass through the fp16 copy (L2, up to 128 dimensions): the head pairs (labels [0, n_lists) of
+// r.pair_off) grouped by list go through flat_filter2_kernel in its emit form, the k-th largest value of every pair + the error terms
+// of the screen give r.query_kth (an upper bound of the query's k-th best exact score), hb.thr_head the pairs' thresholds. Buffers are
+// the caller's. Returns false (nothing launched) when the fp16 copy cannot be made.
+struct flat3_head_bufs {
+  float* xbuf; uint32_t ldx;          // [nq, ldx] values, ldx >= the longest list rounded up to 64
+  float* kth_val; uint32_t* kth_idx;  // [nq, k]
+  float* thr_head;                    // [nq]
+  void* norms;                        // [nq] x 16 bytes
+  uint32_t* tickets;                  // 8 x 32 zeroed words
+};
+bool flat3_head_bounds(resources& res, const flat3_view& v, flat3_cache& cache, const pq3_run& r, const flat3_head_bufs& hb);
 
 unsigned pq3_grid(const resources& res);     // workgroups of the filter
 unsigned pq3_regions(const resources& res);  // survivor regions of pq_filter_kernel (pq_filter4_kernel hands out chunks instead)

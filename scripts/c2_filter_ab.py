@@ -30,8 +30,10 @@ sp = ivf_flat.SearchParams(n_probes=64)
 nb = torch.empty((nq, 10), dtype=torch.int64, device=dev)
 dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
 ref = None
-cases = [("flat_filter2_kernel (256-query units, B in LDS)", res), ("pq_filter_kernel<FLAT> (64-query units)", bench.comparator_handle(CUVS_AMD_FLAT_FILTER2=0)),
-         ("flat_filter2_kernel again", res)]
+cases = [("bound-only head + flat_filter2_kernel (default)", res),
+         ("exact head on the scan kernel + flat_filter2_kernel", bench.comparator_handle(CUVS_AMD_FLAT_BOUND_HEAD=0)),
+         ("exact head + pq_filter_kernel<FLAT> (rounds 3-5)", bench.comparator_handle(CUVS_AMD_FLAT_FILTER2=0)),
+         ("default again", res)]
 for name, r in cases:
     step = lambda: ivf_flat.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=r)
     for _ in range(3):
@@ -43,7 +45,7 @@ for name, r in cases:
     r.sync(); torch.cuda.synchronize()
     lib().cuvsAmdProfileEnable(0)
     ph = {}
-    for nm in (b"ivf_flat_scan_kernel", b"flat_filter_kernel", b"flat_rescore_kernel"):
+    for nm in (b"ivf_flat_scan_kernel", b"flat_head_kernel", b"flat_filter_kernel", b"flat_rescore_kernel"):
         v = C.c_double(0)
         lib().cuvsAmdProfileCollect(nm, C.byref(v))
         ph[nm.decode()] = round(v.value / 5, 3)

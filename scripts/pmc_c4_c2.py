@@ -100,6 +100,8 @@ def summarize(d, out):
             for tag in ("cagra_search_multi_kernel", "cagra_search_kernel", "ivf_flat_scan_kernel", "pq_filter_kernel", "flat_filter2_kernel", "flat_rescore_kernel"):
                 if tag in kn:
                     name = tag
+            if name == "flat_filter2_kernel" and ", true>" in kn:
+                name = "flat_filter2_kernel<EMIT> (bound-only head phase)"
             if name is None:
                 continue
             a = agg.setdefault(name, {})
