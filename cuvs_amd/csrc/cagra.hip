@@ -37,6 +37,9 @@ struct cagra_index {
   dev_buf<char> owned;
   dev_buf<uint32_t> graph;     // [n, degree]
   dev_buf<float> norms;        // [n] canonical |x| (cosine only; the reference's dataset_norms)
+  // optional: the source id of every row (cagra.hpp index::source_indices, written by the reference's serializer as content-map
+  // bit 1, cagra_serialize.cuh:72-83): a search reports source_indices[row] instead of the row (search_multi_cta.cuh:266-272)
+  dev_buf<uint32_t> source_indices;
 };
 
 // canonical row norms of the dataset for the cosine metric (no-op otherwise)
@@ -1061,6 +1064,21 @@ cagra_plan make_cagra_plan(const cuvsCagraSearchParams& p, int64_t n_rows, uint3
   return pl;
 }
 
+// rows -> source ids of an index that carries them (search_multi_cta.cuh:266-272, search_multi_kernel.cuh:658-668); slots without a
+// neighbour stay as they are
+__global__ void cagra_source_ids_kernel(void* out_idx, int64_t n_out, int idx64, const uint32_t* __restrict__ source, int64_t n)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out) return;
+  if (idx64) {
+    int64_t* o = static_cast<int64_t*>(out_idx);
+    if (o[t] >= 0 && o[t] < n) o[t] = (int64_t)source[o[t]];
+  } else {
+    uint32_t* o = static_cast<uint32_t*>(out_idx);
+    if ((int64_t)o[t] < n) o[t] = source[o[t]];
+  }
+}
+
 void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchParams& p, const void* queries,
                   int64_t nq, int k, void* out_idx, bool idx64, float* out_dist, const uint32_t* filter_bits)
 {
@@ -1144,6 +1162,9 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
       case elem_t::i8: launch_search_multi<int8_t>(res, m, nq, msmem); break;
       case elem_t::u8: launch_search_multi<uint8_t>(res, m, nq, msmem); break;
     }
+    if (idx.source_indices.data() != nullptr)
+      hipLaunchKernelGGL(cagra_source_ids_kernel, dim3((unsigned)grid_blocks(nq * k, 256)), dim3(256), 0, res.stream, out_idx, nq * (int64_t)k,
+                         idx64 ? 1 : 0, idx.source_indices.data(), idx.n);
     return;
   }
   size_t smem = (size_t)((idx.dim + 3) & ~int64_t(3)) * 4 + (size_t)a.np2 * 8 + ((size_t)4 << bits) +
@@ -1155,6 +1176,9 @@ void cagra_search(resources& res, const cagra_index& idx, const cuvsCagraSearchP
     case elem_t::i8: launch_search<int8_t>(res, a, nq, smem); break;
     case elem_t::u8: launch_search<uint8_t>(res, a, nq, smem); break;
   }
+  if (idx.source_indices.data() != nullptr)
+    hipLaunchKernelGGL(cagra_source_ids_kernel, dim3((unsigned)grid_blocks(nq * k, 256)), dim3(256), 0, res.stream, out_idx, nq * (int64_t)k,
+                       idx64 ? 1 : 0, idx.source_indices.data(), idx.n);
 }
 
 // ------------------------------------------------------------------ extend (add_nodes.cuh)
@@ -1549,7 +1573,8 @@ cuvsError_t cuvsCagraSerialize(cuvsResources_t res_h, const char* filename, cuvs
     w.scalar<int32_t>(idx.metric);
     w.device_array(res, 'u', 4, {idx.n, idx.degree}, idx.graph.data());
     const bool with_data = include_dataset && idx.data != nullptr && idx.n > 0;
-    w.scalar<uint32_t>(with_data ? 1u : 0u);
+    const bool with_src = idx.source_indices.data() != nullptr;
+    w.scalar<uint32_t>((with_data ? 1u : 0u) | (with_src ? 2u : 0u));
     if (with_data) {
       const size_t es = elem_size(idx.dtype);
       w.scalar<uint32_t>(2u);
@@ -1559,6 +1584,7 @@ cuvsError_t cuvsCagraSerialize(cuvsResources_t res_h, const char* filename, cuvs
       w.scalar<uint32_t>((uint32_t)(round_up(idx.dim * (int64_t)es, 16) / es));  // 16-byte aligned row stride
       w.device_array(res, npy_kind(idx.dtype), (uint32_t)es, {idx.n, idx.dim}, idx.data);
     }
+    if (with_src) w.device_array(res, 'u', 4, {idx.n}, idx.source_indices.data());  // cagra_serialize.cuh:83
     w.close();
   });
 }
@@ -1615,7 +1641,7 @@ cuvsError_t cuvsCagraDeserialize(cuvsResources_t res_h, const char* filename, cu
           idx->data  = idx->owned.data();
         }
       }
-      CUVS_EXPECTS((content & 2u) == 0, "cagra::deserialize: source_indices are not supported");
+      if (content & 2u) idx->source_indices = r.device_array<uint32_t>(res, idx->n);  // cagra_serialize.cuh:314-321
       dl = dl_of(idx->dtype);
     }
     cagra_set_norms(res, *idx);

@@ -296,11 +296,13 @@ def parse_cagra(path):
             out["tag"], out["cuda_dtype"] = scalar(f), scalar(f)
             out["n_rows"], out["ds_dim"], out["stride"] = scalar(f), scalar(f), scalar(f)
             out["dataset"] = read_record(f)
+        if out["content_map"] & 2:  # cagra_serialize.cuh:83: the source id of every row, after the dataset
+            out["source_indices"] = read_record(f)
         assert f.read(1) == b""
     return out
 
 
-def write_cagra(path, graph, dataset=None, metric=0, dtype=np.float32):
+def write_cagra(path, graph, dataset=None, metric=0, dtype=np.float32, source_indices=None):
     dtype = np.dtype(dtype)
     with open(path, "wb") as f:
         f.write(PREFIX[dtype])
@@ -310,7 +312,7 @@ def write_cagra(path, graph, dataset=None, metric=0, dtype=np.float32):
         write_scalar(f, graph.shape[1], np.uint32)
         write_scalar(f, metric, np.int32)
         write_record(f, graph.astype(np.uint32))
-        write_scalar(f, 1 if dataset is not None else 0, np.uint32)
+        write_scalar(f, (1 if dataset is not None else 0) | (2 if source_indices is not None else 0), np.uint32)
         if dataset is not None:
             write_scalar(f, 2, np.uint32)
             write_scalar(f, CUDA_DTYPE[dtype], np.uint32)
@@ -318,6 +320,8 @@ def write_cagra(path, graph, dataset=None, metric=0, dtype=np.float32):
             write_scalar(f, dataset.shape[1], np.uint32)
             write_scalar(f, -(-dataset.shape[1] * dtype.itemsize // 16) * 16 // dtype.itemsize, np.uint32)
             write_record(f, dataset.astype(dtype))
+        if source_indices is not None:
+            write_record(f, np.asarray(source_indices, np.uint32))
 
 
 def parse_hnswlib(path, dim, dtype):

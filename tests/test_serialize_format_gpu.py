@@ -167,6 +167,35 @@ def test_cagra_file(tmp_path, dtype):
     assert p["content_map"] == 0 and (p["graph"] == graph).all()
 
 
+def test_cagra_file_with_source_indices(tmp_path):
+    """content-map bit 1 (cagra_serialize.cuh:72-83, :314-321): an index file that carries the source id of every row. A search
+    reports source_indices[row] (search_multi_cta.cuh:266-272), saving the loaded index writes the array back."""
+    import torch
+    from cuvs_amd.neighbors import cagra
+
+    x, q = _data(n=2000, dtype=np.float32)
+    tx, tq = torch.from_numpy(x).cuda(), torch.from_numpy(q).cuda()
+    idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=32, graph_degree=16), tx)
+    graph = idx.graph.cpu().numpy().view(np.uint32)
+    src = (np.arange(2000, dtype=np.uint32)[::-1] * 3 + 7).astype(np.uint32)  # an injective map that is not the identity
+    g = str(tmp_path / "cagra_src.bin")
+    rf.write_cagra(g, graph, x, metric=0, dtype=np.float32, source_indices=src)
+    for algo in ("single_cta", "multi_cta"):
+        sp = cagra.SearchParams(itopk_size=64, algo=algo)
+        wd, wi = cagra.search(sp, idx, tq, 10)
+        loaded = cagra.load(g)
+        gd, gi = cagra.search(sp, loaded, tq, 10)
+        torch.cuda.synchronize()
+        wi_np, gi_np = wi.cpu().numpy().view(np.uint32), gi.cpu().numpy().view(np.uint32)
+        if algo == "single_cta":  # (the multi-wave walk is not bit-reproducible: checked through the id map's image only)
+            assert (gi_np == src[wi_np]).all() and (gd.cpu().numpy() == wd.cpu().numpy()).all()
+        assert np.isin(gi_np, src).all()
+    h = str(tmp_path / "cagra_src_again.bin")
+    cagra.save(h, loaded)
+    p = rf.parse_cagra(h)
+    assert p["content_map"] == 3 and (p["source_indices"] == src).all() and (p["graph"] == graph).all()
+
+
 def test_cagra_hnswlib_export(tmp_path):
     import ctypes as C
     import torch
