@@ -323,7 +323,11 @@ void nnd_run(resources& res, const T* data, elem_t et, int64_t n, int64_t dim, u
   CUVS_EXPECTS(n < (int64_t(1) << 31), "nn_descent: at most 2^31 rows");
   const int np2     = next_pow2((int)(K + P));
   const size_t msm  = (size_t)4 * 2 * np2 * sizeof(uint32_t);
-  CUVS_EXPECTS(msm <= 160 * 1024, "nn_descent: intermediate_graph_degree too large for the merge step");
+  // (a node's list and its proposals are merged in LDS: K + P = 3 x roundUp32(1.3 x degree) entries <= 4096, i.e. a graph degree up
+  // to 1024 - the reference's own tables stop at 64; memory: n x (K + 2 P) x 8 bytes, ~30 GB at 10M rows and degree 128)
+  CUVS_EXPECTS(msm <= 160 * 1024,
+               "nn_descent: graph degree %u is too large for the merge step (internal lists of %u + %u proposals must fit 4096 LDS entries: "
+               "at most degree 1024)", K_out, K, P);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(nnd_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)msm));
   const unsigned g4 = grid_blocks(n, 4);
