@@ -666,8 +666,9 @@ __global__ __launch_bounds__(kF2Threads, 2) void flat_filter2_kernel(const filte
             for (int j = 0; j < 4; ++j) {
               const uint32_t v0 = (u << 5) + 8u * j + 4u * h;
               // (measured and rejected, round 6: the same stores from inline asm, hidden from the compiler's wait insertion - no faster,
-              // and a parity test failed; the values staged in LDS and flushed once per unit - 0.74 ms for the head pass either way:
-              // the pass runs at 4.7 TB/s with its ~9 units per workgroup and a barrier + operand copy between them, not behind its stores)
+              // and a parity test failed; the values staged in LDS and flushed once per unit; the pass on round 3's wave-independent
+              // kernel, B operands in registers, no LDS, no barrier: 0.53 - 0.57 ms = 4.4 - 4.7 TB/s every time - the emit pass is not
+              // behind its stores, its barriers or its prefetch depth)
               float4 o;
               o.x = v0 + 0u < r_end ? acc[4 * j + 0] : -INFINITY; o.y = v0 + 1u < r_end ? acc[4 * j + 1] : -INFINITY;
               o.z = v0 + 2u < r_end ? acc[4 * j + 2] : -INFINITY; o.w = v0 + 3u < r_end ? acc[4 * j + 3] : -INFINITY;
