@@ -1722,13 +1722,35 @@ cuvsError_t cuvsCagraExtend(cuvsResources_t res_h, cuvsCagraExtendParams_t param
 
 // Physical merge (cagra_merge.cuh): the datasets of the input indexes are concatenated in order and a new graph is
 // built over all rows with `params`; ids of index i are shifted by the sizes of the indexes before it.
+namespace {
+// rows[keep[i]] -> out[i] (row_bytes is a multiple of the element size; byte copy, one workgroup per row, strided over the rows)
+__global__ void gather_rows_kernel(const char* __restrict__ rows, const int64_t* __restrict__ keep, int64_t n_keep, size_t row_bytes,
+                                   char* __restrict__ out)
+{
+  for (int64_t i = blockIdx.x; i < n_keep; i += gridDim.x) {
+    const char* src = rows + (size_t)keep[i] * row_bytes;
+    char* dst       = out + (size_t)i * row_bytes;
+    for (size_t b = threadIdx.x; b < row_bytes; b += blockDim.x) dst[b] = src[b];
+  }
+}
+}  // namespace
+
 cuvsError_t cuvsCagraMerge(cuvsResources_t res_h, cuvsCagraIndexParams_t params, cuvsCagraIndex_t* indices,
                            size_t num_indices, cuvsFilter filter, cuvsCagraIndex_t output_index)
 {
   return (cuvsError_t)translate_exceptions([=] {
     auto& res = *as_res(res_h);
     CUVS_EXPECTS(params && indices && output_index && num_indices > 0, "null argument");
-    CUVS_EXPECTS(filter.type == NO_FILTER, "cagra::merge: filters are not supported");
+    // a BITSET over the concatenated rows keeps the rows whose bit is set (cagra_merge.cuh:94-131: the merged index is built on
+    // the kept rows, in order); bitmaps are refused as in the reference (:45-46)
+    CUVS_EXPECTS(filter.type == NO_FILTER || filter.type == BITSET, "Bitmap filter isn't supported inside cagra::merge");
+    const uint32_t* bits = nullptr;
+    if (filter.type == BITSET) {
+      CUVS_EXPECTS(filter.addr != 0, "cagra::merge: the filter has no tensor");
+      auto& ft = reinterpret_cast<DLManagedTensor*>(filter.addr)->dl_tensor;
+      CUVS_EXPECTS(dtype_is(ft.dtype, kDLUInt, 32) && is_device_accessible(ft), "filter must be a device uint32 tensor");
+      bits = static_cast<const uint32_t*>(dl_data(ft));
+    }
     auto& first = get_cagra(indices[0]);
     int64_t total = 0;
     for (size_t i = 0; i < num_indices; ++i) {
@@ -1746,6 +1768,23 @@ cuvsError_t cuvsCagraMerge(cuvsResources_t res_h, cuvsCagraIndexParams_t params,
       off += (size_t)ix.n * row_bytes;
     }
     sync(res);
+    if (bits != nullptr) {  // the kept rows, compacted in order
+      const size_t words = ((size_t)total + 31) / 32;
+      std::vector<uint32_t> hb = to_host(res, bits, words);
+      std::vector<int64_t> keep;
+      keep.reserve((size_t)total);
+      for (int64_t r = 0; r < total; ++r)
+        if ((hb[(size_t)r >> 5] >> (r & 31)) & 1u) keep.push_back(r);
+      CUVS_EXPECTS(!keep.empty(), "cagra::merge: the filter keeps no row");
+      dev_buf<int64_t> kd(res, keep.size());
+      copy_async(res, kd.data(), keep.data(), keep.size() * sizeof(int64_t));
+      auto kept = dev_buf<char>::persistent(keep.size() * row_bytes);
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<int64_t>((int64_t)keep.size(), 65535)), dim3(256), 0, res.stream,
+                         all.data(), kd.data(), (int64_t)keep.size(), row_bytes, kept.data());
+      sync(res);  // (keep is pageable host memory)
+      all   = std::move(kept);
+      total = (int64_t)keep.size();
+    }
     auto idx   = cagra_build(res, *params, all.data(), first.dtype, total, first.dim, false);
     idx->owned = std::move(all);  // the merged index owns the concatenated rows (idx->data already points at them)
     delete reinterpret_cast<cagra_index*>(output_index->addr);

@@ -232,16 +232,17 @@ def load(filename, resources=None):
 
 
 @auto_sync_resources
-def merge(index_params, indices, resources=None):
-    """cuvsCagraMerge: one index over the concatenated datasets of `indices` (ids shifted by the preceding sizes)."""
+def merge(index_params, indices, resources=None, filter=None):
+    """cuvsCagraMerge: one index over the concatenated datasets of `indices` (ids shifted by the preceding sizes); filter: None or a
+    bitset over the concatenated rows (uint32 words on the device, BITSET) - only rows whose bit is set are kept (cagra_merge.cuh:94-131)."""
     out = Index()
     arr = (C.POINTER(_CIndex) * len(indices))(*[ix._p for ix in indices])
-
-    class _Filter(C.Structure):
-        _fields_ = [("addr", C.c_size_t), ("type", C.c_int)]
-
+    flt, keep = make_filter(filter)
+    fn = lib().cuvsCagraMerge
+    fn.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, cuvsFilter, C.c_void_p]
     index_params._p.contents.build_algo = max(index_params._algo, 1) if index_params._algo != 3 else 3
-    check(lib().cuvsCagraMerge(resources.get_c_obj(), index_params._p, arr, C.c_size_t(len(indices)), _Filter(0, 0), out._p))
+    check(fn(resources.get_c_obj(), index_params._p, arr, C.c_size_t(len(indices)), flt, out._p))
+    del keep
     index_params._p.contents.build_algo = 1
     out.trained = True
     return out

@@ -241,3 +241,30 @@ def test_merge():
     torch.cuda.synchronize()
     _, truth = oracle.exact_knn(q, x, 10)
     assert oracle.recall(i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, truth) >= 0.95
+
+
+def test_merge_with_a_bitset_filter():
+    """cuvsCagraMerge with a BITSET over the concatenated rows (cagra_merge.cuh:94-131): the merged index holds the kept rows, in
+    order - searching it equals searching an index built on exactly those rows; a bitmap is refused (:45-46)"""
+    import torch
+    from cuvs_amd._lib import BITMAP, BITSET
+    from cuvs_amd.neighbors import cagra
+
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal((6000, 24)).astype(np.float32)
+    q = rng.standard_normal((100, 24)).astype(np.float32)
+    p = cagra.IndexParams(intermediate_graph_degree=48, graph_degree=24)
+    parts = [cagra.build(p, torch.from_numpy(x[a:b]).cuda()) for a, b in ((0, 2500), (2500, 6000))]
+    keep = rng.random(6000) < 0.7
+    words = np.zeros((6000 + 31) // 32, np.uint32)
+    for r in np.nonzero(keep)[0]:
+        words[r >> 5] |= np.uint32(1) << np.uint32(r & 31)
+    merged = cagra.merge(p, parts, filter=(torch.from_numpy(words.view(np.int32)).cuda(), BITSET))
+    assert len(merged) == int(keep.sum())
+    kept_rows = x[keep]
+    d, i = cagra.search(cagra.SearchParams(itopk_size=64), merged, torch.from_numpy(q).cuda(), 10)
+    torch.cuda.synchronize()
+    _, truth = oracle.exact_knn(q, kept_rows, 10)
+    assert oracle.recall(i.cpu().numpy().astype(np.int64) & 0xFFFFFFFF, truth) >= 0.95
+    with pytest.raises(Exception, match="[Bb]itmap"):
+        cagra.merge(p, parts, filter=(torch.from_numpy(words.view(np.int32)).cuda(), BITMAP))
