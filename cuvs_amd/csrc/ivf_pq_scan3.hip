@@ -1346,9 +1346,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   work_item& cur  = *reinterpret_cast<work_item*>(ctrl + 8);                     // the current item, 16 bytes
   uint32_t* tk    = reinterpret_cast<uint32_t*>(ctrl + 12);                      // [NT] smallest key of every thread
   const int kHCand = a.hcand;
-  uint32_t* ckey  = tk + NT;                                                     // [2][kHCand] candidates (two buffers)
-  uint32_t* crow  = ckey + 2 * kHCand;                                           // [2][kHCand]
-  uint32_t* keys  = crow + 2 * kHCand;                                           // [cap_rows] score keys of the current chunk
+  uint2* cand     = reinterpret_cast<uint2*>(tk + NT);                           // [2][kHCand] candidates (key, row), two buffers: 16-byte aligned -
+                                                                                 // the rank pass reads two entries per ds_read_b128
+  uint32_t* keys  = reinterpret_cast<uint32_t*>(cand + 2 * kHCand);              // [cap_rows] score keys of the current chunk
   static_assert(sizeof(work_item) == 16, "work_item");
 
   const int tid = threadIdx.x;
@@ -1541,13 +1541,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       }
       __syncthreads();
       const uint32_t tau = (uint32_t)ctrl[1];
-      uint32_t* bk = ckey + buf * kHCand;
-      uint32_t* br = crow + buf * kHCand;
+      uint2* bc = cand + buf * kHCand;
       for (uint32_t i = tid; i < clen; i += NT) {
         const uint32_t key = keys[i];
         if (key <= tau && key != 0xffffffffu) {
           const int pos = atomicAdd(&ctrl[2], 1);
-          if (pos < kHCand) { bk[pos] = key; br[pos] = c0 + i; }
+          if (pos < kHCand) bc[pos] = make_uint2(key, c0 + i);
         }
       }
       __syncthreads();
@@ -1570,22 +1569,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           last  = min64[0];
           first = false;
           if (last == ~0ull) break;  // workgroup-uniform
-          if (tid == 0) { bk[cnt] = (uint32_t)(last >> 32); br[cnt] = (uint32_t)last; }
+          if (tid == 0) bc[cnt] = make_uint2((uint32_t)(last >> 32), (uint32_t)last);
           ++cnt;
           __syncthreads();
         }
       }
       // ---- keep the k best of the candidates, in (key, row) order, in the other buffer
-      uint32_t* nk = ckey + (buf ^ 1) * kHCand;
-      uint32_t* nr = crow + (buf ^ 1) * kHCand;
+      // (rank counting over broadcast reads; (key, row) pairs side by side: one 16-byte read serves two comparisons - the pass is a
+      // chain of LDS round trips behind the OTHER workgroup's gathers, 41 k of an item's 127 k cycles at k = 60)
+      uint2* nc = cand + (buf ^ 1) * kHCand;
+      const uint4* b4 = reinterpret_cast<const uint4*>(bc);
       for (int t = tid; t < cnt; t += NT) {
-        const uint32_t key = bk[t], row = br[t];
+        const uint2 me = bc[t];
         int r = 0;
-        for (int j = 0; j < cnt; ++j) {
-          const uint32_t ok = bk[j], orow = br[j];
-          r += (ok < key || (ok == key && orow < row)) ? 1 : 0;
+#pragma unroll 4
+        for (int j = 0; j < (cnt + 1) / 2; ++j) {
+          const uint4 o = b4[j];
+          r += (o.x < me.x || (o.x == me.x && o.y < me.y)) ? 1 : 0;
+          r += (2 * j + 1 < cnt && (o.z < me.x || (o.z == me.x && o.w < me.y))) ? 1 : 0;
         }
-        if (r < k) { nk[r] = key; nr[r] = row; }
+        if (r < k) nc[r] = me;
       }
       if (tid == 0) ctrl[0] = min(cnt, k);
       buf ^= 1;
@@ -1595,13 +1598,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ---- the pair's candidate row, ordered by (score, row) (the caller pre-filled it "invalid")
     {
       const int cnt = ctrl[0];
-      const uint32_t* bk = ckey + buf * kHCand;
-      const uint32_t* br = crow + buf * kHCand;
+      const uint2* bc = cand + buf * kHCand;
       if (tid < cnt) {
-        const uint32_t key = bk[tid];
+        const uint32_t key = bc[tid].x;
         const size_t o     = (size_t)pair * a.k + tid;
         a.out_d[o]         = key_to_float(key);
-        a.out_i[o]         = base_row + br[tid];
+        a.out_i[o]         = base_row + bc[tid].y;
         if (tid == k - 1 && key < 0xff800000u) atomicMin(&a.query_kth[q], key);
       }
     }
