@@ -24,6 +24,8 @@ build/ivf_pq_search.o: HIPFLAGS += -fno-slp-vectorize
 # the one-wave-per-SIMD filter: accumulators (screened by the VALU) in architectural registers, the B operands in the
 # accumulation registers; fmaxf chains without canonicalisation (v_max3_f32)
 build/ivf_pq_filter4.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans
+# the wide filter: fmaxf chains without canonicalisation (v_max3_f32); its accumulators stay in the accumulation registers
+build/ivf_pq_wide.o: HIPFLAGS += -fno-honor-nans
 
 build/%.o: cuvs_amd/csrc/%.hip $(HDRS)
 	@mkdir -p build

@@ -198,6 +198,8 @@ tuning load_tuning_from_env()
   t.flat_scan3       = geti("CUVS_AMD_FLAT_SCAN3", 1);
   t.flat_filter2     = geti("CUVS_AMD_FLAT_FILTER2", 1);
   t.flat_bound_head  = geti("CUVS_AMD_FLAT_BOUND_HEAD", 1);
+  t.pq_wide          = geti("CUVS_AMD_PQ_WIDE", 1);
+  t.pq_wide_heads    = geti("CUVS_AMD_PQ_WIDE_HEADS", 0);
   t.pq3_surv_cap     = geti("CUVS_AMD_PQ3_SURV_CAP", 0);
   t.pq_qcap          = geti("CUVS_AMD_PQ_QCAP", 0);
   t.scan_debug       = geti("CUVS_AMD_SCAN_DEBUG", 0);

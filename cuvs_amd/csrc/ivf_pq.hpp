@@ -62,6 +62,14 @@ struct ivf_pq_index {
     dev_buf<uint8_t> codes8;
     const void* codes8_src = nullptr;
     int64_t codes8_rows = -1, codes8_size = -1;
+    // the rows DECODED (scaled fp16, MFMA A-operand layout) for the wide filter (ivf_pq_wide.hip): rows x rot_dim x 2 bytes, made
+    // when a search first takes that path and the device has the room; w_failed_*: the index state that found none
+    dev_buf<uint4> rows16w;
+    const void* w_codes = nullptr;
+    const void* w_pq    = nullptr;
+    int64_t w_rows = -1, w_size = -1;
+    const void* w_failed_codes = nullptr;
+    int64_t w_failed_rows = -1, w_failed_size = -1;
   };
   mutable scan3_cache scan3;
   // largest source id held by the lists (-1: empty), computed on demand for the bitset-filter bound check

@@ -91,4 +91,52 @@ struct filter4_launch {
 };
 void pq4_filter(resources& res, const filter4_launch& l);
 
+// ---- pqw_filter_kernel (ivf_pq_wide.hip): the filter over the index's DECODED rows (fp16, A-operand layout), for rot_dim beyond
+// pq_filter4_kernel's decode table and for bounds from several head lists
+bool pqw_shape(uint32_t rot_dim);  // rot_dim the kernel is built for (256, 384, 512, 768)
+uint32_t pqw_group();              // queries per work unit
+// rows16 [padded_rows / 32][rot_dim / 16][64 lanes] x 16 bytes from the one-byte-per-code copy and the decode table (cb16_kernel)
+void pqw_decode(resources& res, const uint8_t* codes8, uint32_t n_chunks, const uint32_t* cb16, uint32_t pq_len, int64_t padded_rows,
+                uint32_t rot_dim, void* rows16);
+struct wide_prep {  // pre-pass: fp16 B operands of the head (labels [0, n_lists)) or tail pairs, + norms (head) / thresholds (tail)
+  const uint32_t* sorted_pairs;
+  const uint32_t* pair_off;
+  uint32_t n_lists;
+  const uint32_t* probes;
+  const float* rot_queries;
+  const float* centers_rot;
+  const uint32_t* query_kth;
+  uint32_t* qflag;
+  void* bq;
+  float* thr;    // tail: thresholds in accumulator units; head: the pairs' constants -|r|^2 sc^2 / 2 (values of different lists become comparable)
+  void* norms;   // head: [query * heads + probe rank] x 16 bytes
+  uint32_t n_probes, rot_dim, heads;
+  float sc, c1, eps, alpha, cbmax, dmax, bound_max;
+  int head;
+  int64_t n_pairs;  // upper bound of the pairs served (grid size)
+};
+void pqw_bprep(resources& res, const wide_prep& l);
+struct wide_filter {
+  const filter_unit* units;
+  const uint32_t* n_units;
+  uint32_t* xcd_ticket;
+  const uint32_t* sorted_pairs;
+  const uint32_t* pair_off;
+  uint32_t n_lists;
+  const void* bq;
+  const float* thr;
+  const void* rows16;
+  const float* row_term;  // [padded_rows] fp32 -|d|^2 (1 - 2^-9) sc^2 / 2: the accumulators' initial values
+  uint32_t* qflag;
+  void* surv;             // one region of surv_cap entries per workgroup + a shared spill region of spill_cap entries
+  uint32_t* surv_cnt;     // [grid + 1]
+  uint32_t surv_cap, spill_cap, n_probes, rot_dim;
+  float* xbuf;            // emit: values of (head pair, row) at xbuf[(query * heads + probe rank) * ldx + row of the list]
+  uint32_t ldx, heads;
+  int emit;
+  unsigned grid;
+  unsigned long long* stats;
+};
+void pqw_filter(resources& res, const wide_filter& l);
+
 }  // namespace cuvs_amd

@@ -981,6 +981,99 @@ __device__ inline void pool_append_wave(const rescore_params& a, bool want, cons
 
 constexpr int kRThreads = 1024;
 
+// The score of (query q, row `row` of list L) in the reference's arithmetic for the requested LUT / score types: every LUT entry
+// from its components in order (create_lut_impl.cuh:17-78), rounded to the LUT type, summed in subspace order in the score type
+// (compute_score_impl.cuh:52-79) - bit-identical to the LUT scan's score. cb: the fp32 codebook staged in LDS (CB_LDS).
+template <int LUT, bool ACC_HALF, bool CB_LDS>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>)
+__device__ inline float pq_exact_score(const rescore_params& a, const float* cb, const uint32_t q, const uint32_t L, const uint32_t row)
+{
+  const float* pqc = CB_LDS ? cb : a.pq_centers;  // (the generic branch below: any address space)
+  float af       = 0.f;
+  _Float16 ah    = (_Float16)0.f;
+  const float* rq  = a.rot_queries + (size_t)q * a.rot_dim;
+  const float* ct  = a.centers_rot + (size_t)L * a.rot_dim;
+  const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
+  auto add_entry = [&](float v) {  // one LUT entry in the reference's arithmetic: LUT type, then the score type's sum
+    if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
+    if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
+      af += v;  // fp32 entries
+    } else {
+      const _Float16 e = to_lut_half(v);
+      if constexpr (ACC_HALF) ah += e; else af += (float)e;
+    }
+  };
+  if (a.pq_len != 2u || a.per_cluster) {
+    // any pq_len, PER_CLUSTER codebooks: entry (s, code) = the components' chain in order (create_lut_impl.cuh:17-78), subspaces in order
+#pragma unroll 1
+    for (int c = 0; c < (int)a.n_chunks; ++c) {
+      const uint4 cw       = cp[c * 64];
+      const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+        const uint32_t d0   = (uint32_t)(c * 16 + b) * a.pq_len;
+        float v = 0.f;
+        for (uint32_t l = 0; l < a.pq_len; ++l) {
+          const float p = pqc[(size_t)(a.per_cluster ? L * a.pq_len + l : d0 + l) * a.book + code], qv = rq[d0 + l], cv = ct[d0 + l];
+          if (!a.is_ip) {
+            const float d = (qv - cv) - p;
+            v = __fmaf_rn(d, d, v);
+          } else {
+            v = __fmaf_rn(-qv, cv, v);
+            v = __fmaf_rn(-qv, p, v);
+          }
+        }
+        add_entry(v);
+      }
+    }
+  } else {
+    // pq_len 2, PER_SUBSPACE: half a chunk (8 subspaces) at a time - its 16 codebook values (LDS when the codebook fits) and
+    // 8 query / centre vectors are all requested before the first is used: a thread holds one or two survivors, so the
+    // kernel's time is its chains of memory latencies, not its arithmetic
+#pragma unroll 1
+    for (int c = 0; c < (int)a.n_chunks; ++c) {
+      const uint4 cw       = cp[c * 64];
+      const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float qq[16], cc[16], p0[8], p1[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 qv = *reinterpret_cast<const float4*>(rq + c * 32 + hh * 16 + j * 4),
+                       cv = *reinterpret_cast<const float4*>(ct + c * 32 + hh * 16 + j * 4);
+          qq[j * 4] = qv.x; qq[j * 4 + 1] = qv.y; qq[j * 4 + 2] = qv.z; qq[j * 4 + 3] = qv.w;
+          cc[j * 4] = cv.x; cc[j * 4 + 1] = cv.y; cc[j * 4 + 2] = cv.z; cc[j * 4 + 3] = cv.w;
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const int bb        = hh * 8 + b;
+          const uint32_t code = (ws[bb >> 2] >> ((bb & 3) * 8)) & 0xffu;
+          const uint32_t e0   = (uint32_t)((c * 16 + bb) * 2) * a.book + code;
+          if constexpr (CB_LDS) { p0[b] = cb[e0]; p1[b] = cb[e0 + a.book]; }
+          else                  { p0[b] = a.pq_centers[e0]; p1[b] = a.pq_centers[e0 + a.book]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cc[b * 2], c1 = cc[b * 2 + 1];
+          float v;
+          if (!a.is_ip) {
+            const float d0 = (q0 - c0) - p0[b], d1 = (q1 - c1) - p1[b];
+            v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+          } else {
+            v = __fmaf_rn(-q0, c0, 0.f);
+            v = __fmaf_rn(-q0, p0[b], v);
+            v = __fmaf_rn(-q1, c1, v);
+            v = __fmaf_rn(-q1, p1[b], v);
+          }
+          add_entry(v);
+        }
+      }
+    }
+  }
+  return ACC_HALF ? (float)ah : af;
+}
+
 // The codebook (128 KiB of fp32 at pq_dim 64) is staged in LDS once per workgroup: a survivor's 128 codebook values were
 // 128 scattered L2 reads per lane; the query / centre values of a 16-subspace chunk are read as 16-byte vectors.
 template <int LUT, bool ACC_HALF, bool CB_LDS>  // LUT: 0 fp32, 1 fp16, 2 fp8 (fp_8bit<5>); CB_LDS: the codebook is staged in LDS
@@ -994,7 +1087,6 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
       reinterpret_cast<float4*>(cb)[i] = reinterpret_cast<const float4*>(a.pq_centers)[i];
     __syncthreads();
   }
-  const float* pqc = CB_LDS ? cb : a.pq_centers;  // (the generic branch below: any address space)
   // region blockIdx.x of the filter's workgroups, the last workgroup takes the shared spill region; chunked buffer
   // (pq_filter4_kernel): all workgroups stride over the chunks drawn
   const bool chunked = a.sub == 0u;
@@ -1004,7 +1096,6 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
   const uint2* region = chunked ? a.surv : a.surv + (size_t)ri * a.surv_cap;
   const uint32_t s_first  = chunked ? (blockIdx.x * gridDim.y + blockIdx.y) * blockDim.x + threadIdx.x : blockIdx.y * blockDim.x + threadIdx.x;
   const uint32_t s_stride = chunked ? gridDim.x * gridDim.y * blockDim.x : gridDim.y * blockDim.x;
-  {
   const uint32_t lane_ = threadIdx.x & 63u;
   for (uint32_t sb = s_first - lane_; sb < n; sb += s_stride) {  // (wave-uniform trip count: pool_append_wave is a wave operation)
     const uint32_t s = sb + lane_;
@@ -1019,94 +1110,120 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
     }
     // partial head: the first head_rows rows of a head pair's list were scored by the head phase (no duplicates)
     if (ok && a.head_rows != 0u && pair % a.n_probes < a.head) ok = row - a.list_offsets[a.probes[pair]] >= a.head_rows;
-    float af       = 0.f;
-    _Float16 ah    = (_Float16)0.f;
-    if (ok) {
-    const uint32_t L = a.probes[pair];
-    const float* rq  = a.rot_queries + (size_t)q * a.rot_dim;
-    const float* ct  = a.centers_rot + (size_t)L * a.rot_dim;
-    const uint4* cp  = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row >> 6) * a.n_chunks) * 64 + (row & 63u);
-    auto add_entry = [&](float v) {  // one LUT entry in the reference's arithmetic: LUT type, then the score type's sum
-      if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
-      if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
-        af += v;  // fp32 entries
-      } else {
-        const _Float16 e = to_lut_half(v);
-        if constexpr (ACC_HALF) ah += e; else af += (float)e;
-      }
-    };
-    if (a.pq_len != 2u || a.per_cluster) {
-      // any pq_len, PER_CLUSTER codebooks: entry (s, code) = the components' chain in order (create_lut_impl.cuh:17-78), subspaces in order
-#pragma unroll 1
-      for (int c = 0; c < (int)a.n_chunks; ++c) {
-        const uint4 cw       = cp[c * 64];
-        const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-          const uint32_t code = (ws[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-          const uint32_t d0   = (uint32_t)(c * 16 + b) * a.pq_len;
-          float v = 0.f;
-          for (uint32_t l = 0; l < a.pq_len; ++l) {
-            const float p = pqc[(size_t)(a.per_cluster ? L * a.pq_len + l : d0 + l) * a.book + code], qv = rq[d0 + l], cv = ct[d0 + l];
-            if (!a.is_ip) {
-              const float d = (qv - cv) - p;
-              v = __fmaf_rn(d, d, v);
-            } else {
-              v = __fmaf_rn(-qv, cv, v);
-              v = __fmaf_rn(-qv, p, v);
-            }
-          }
-          add_entry(v);
-        }
-      }
-    } else {
-      // pq_len 2, PER_SUBSPACE: half a chunk (8 subspaces) at a time - its 16 codebook values (LDS when the codebook fits) and
-      // 8 query / centre vectors are all requested before the first is used: a thread holds one or two survivors, so the
-      // kernel's time is its chains of memory latencies, not its arithmetic
-#pragma unroll 1
-      for (int c = 0; c < (int)a.n_chunks; ++c) {
-        const uint4 cw       = cp[c * 64];
-        const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          float qq[16], cc[16], p0[8], p1[8];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 qv = *reinterpret_cast<const float4*>(rq + c * 32 + hh * 16 + j * 4),
-                         cv = *reinterpret_cast<const float4*>(ct + c * 32 + hh * 16 + j * 4);
-            qq[j * 4] = qv.x; qq[j * 4 + 1] = qv.y; qq[j * 4 + 2] = qv.z; qq[j * 4 + 3] = qv.w;
-            cc[j * 4] = cv.x; cc[j * 4 + 1] = cv.y; cc[j * 4 + 2] = cv.z; cc[j * 4 + 3] = cv.w;
-          }
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const int bb        = hh * 8 + b;
-            const uint32_t code = (ws[bb >> 2] >> ((bb & 3) * 8)) & 0xffu;
-            const uint32_t e0   = (uint32_t)((c * 16 + bb) * 2) * a.book + code;
-            if constexpr (CB_LDS) { p0[b] = cb[e0]; p1[b] = cb[e0 + a.book]; }
-            else                  { p0[b] = a.pq_centers[e0]; p1[b] = a.pq_centers[e0 + a.book]; }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int b = 0; b < 8; ++b) {
-            const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cc[b * 2], c1 = cc[b * 2 + 1];
-            float v;
-            if (!a.is_ip) {
-              const float d0 = (q0 - c0) - p0[b], d1 = (q1 - c1) - p1[b];
-              v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
-            } else {
-              v = __fmaf_rn(-q0, c0, 0.f);
-              v = __fmaf_rn(-q0, p0[b], v);
-              v = __fmaf_rn(-q1, c1, v);
-              v = __fmaf_rn(-q1, p1[b], v);
-            }
-            add_entry(v);
-          }
-        }
-      }
-    }
-    }
-    pool_append_wave(a, ok, q, pair, row, ACC_HALF ? (float)ah : af);
+    float score = 0.f;
+    if (ok) score = pq_exact_score<LUT, ACC_HALF, CB_LDS>(a, cb, q, a.probes[pair], row);
+    pool_append_wave(a, ok, q, pair, row, score);
   }
+}
+
+// ------------------------------------------------------------------ the wide path's bound-only head phase (ivf_pq_wide.hip)
+// As IVF-Flat's (flat_head_bound_kernel): the emit pass left a value for every (head pair, row) - larger is nearer, comparable
+// across a query's head lists (the pair's constant -|r|^2 sc^2 / 2 is added) - and select_k the k largest of every QUERY over the
+// union of its `heads` lists. Those k rows are scored EXACTLY, in the reference's arithmetic: the largest of the k scores bounds
+// the query's k-th best score from above (k rows are at or below it). One wave per query.
+struct wbound_params {
+  rescore_params rs;  // the exact score's inputs
+  const float* kth_val;
+  const uint32_t* kth_idx;  // position in the query's value row: probe rank * ldx + row of the list
+  const float4* norms;      // [query * heads + rank] (|r|^2, ., ., largest scaled operand)
+  const uint32_t* probes;
+  const uint32_t* list_offsets;
+  int64_t nq;
+  uint32_t k, heads, ldx, n_probes, rot_dim;
+  uint32_t* query_kth;
+  uint32_t* qflag;
+  float* thr_head;          // out: [query * heads + rank] threshold in the units of the value buffer
+  float sc, c1, eps, alpha, cbmax, bound_max;
+};
+template <int LUT, bool ACC_HALF>
+__global__ __launch_bounds__(256) void pqw_head_bound_kernel(const wbound_params a)
+{
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (q >= a.nq) return;  // wave-uniform
+  float worst = -INFINITY;
+  bool short_list = false;
+  for (uint32_t j0 = 0; j0 < a.k; j0 += 64u) {
+    const uint32_t j = j0 + lane;
+    if (j < a.k) {
+      if (!(a.kth_val[(size_t)q * a.k + j] > -INFINITY)) {
+        short_list = true;  // fewer than k rows in the head lists: no finite bound
+      } else {
+        const uint32_t id = a.kth_idx[(size_t)q * a.k + j], rank = id / a.ldx, r = id - rank * a.ldx;
+        const uint32_t L = a.probes[(size_t)q * a.n_probes + rank];
+        worst = fmaxf(worst, pq_exact_score<LUT, ACC_HALF, false>(a.rs, nullptr, (uint32_t)q, L, a.list_offsets[L] + r));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+  const bool no_bound = __ballot(short_list) != 0ull;
+  const float bound  = no_bound ? INFINITY : worst;
+  const uint32_t key = no_bound ? 0xffffffffu : float_to_key(bound);
+  bool hand_back = no_bound;
+  for (uint32_t rank = lane; rank < a.heads; rank += 64u) {
+    const float4 nm   = a.norms[(size_t)q * a.heads + rank];
+    const bool served = key < 0xff800000u && nm.w < 60000.f && fabsf(bound) <= a.bound_max;
+    hand_back = hand_back || !served;
+    // (the same expression as the emit pass's constant: x = fl(acc + c) >= fl(t + c) whenever acc >= t)
+    a.thr_head[(size_t)q * a.heads + rank] = served ? filter_threshold(bound, nm.x, a) / a.c1 + -0.5f * a.sc * a.sc * nm.x : INFINITY;
+  }
+  const bool any_back = __ballot(hand_back) != 0ull;
+  if (lane == 0u) {
+    a.query_kth[q] = key;
+    if (any_back) a.qflag[q] = 1u;  // no bound, or a pair the filter cannot serve: the query goes back to the LUT scan, all its pairs
+  }
+}
+
+// the head pairs' own candidates: rows whose value reaches the pair's threshold -> the survivor regions, BEHIND the filter (the
+// regions' fills are final); one wave per head pair (flat_head_survivors_kernel's scheme; a full buffer flags the query)
+__global__ __launch_bounds__(256) void pqw_head_survivors_kernel(const float* __restrict__ xbuf, uint32_t ldx, const float* __restrict__ thr_head,
+                                                                 uint32_t heads, const uint32_t* __restrict__ sorted_pairs,
+                                                                 const uint32_t* __restrict__ pair_off, uint32_t n_lists,
+                                                                 const uint32_t* __restrict__ probes, uint32_t n_probes,
+                                                                 const uint32_t* __restrict__ list_offsets, const uint32_t* __restrict__ list_sizes,
+                                                                 uint2* __restrict__ surv, uint32_t* __restrict__ surv_cnt, uint32_t n_regions,
+                                                                 uint32_t surv_cap, uint32_t spill_cap, uint32_t* __restrict__ qflag)
+{
+  const uint32_t n_head = pair_off[n_lists];
+  const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (i >= n_head) return;  // wave-uniform
+  const uint32_t p = sorted_pairs[i], L = probes[p], q = p / n_probes;
+  if (qflag[q] != 0u) return;  // (handed back: its survivors would not be re-scored)
+  const uint32_t len = list_sizes[L], base_row = list_offsets[L];
+  const size_t xrow = (size_t)q * heads + p % n_probes;
+  const float th = thr_head[xrow];
+  const float* x = xbuf + xrow * ldx;
+  uint32_t total = 0u;
+  for (uint32_t r0 = 0; r0 < len; r0 += 64u) {
+    const uint32_t r = r0 + lane;
+    total += (uint32_t)__popcll(__ballot(r < len && x[r] >= th));
+  }
+  if (total == 0u) return;
+  const uint32_t ri = i % n_regions;
+  uint32_t base = 0u;
+  if (lane == 0u) base = atomicAdd(surv_cnt + ri, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const uint32_t n_fit = base >= surv_cap ? 0u : min(total, surv_cap - base);  // what the region still holds; the rest: shared region
+  uint32_t sbase = 0u;
+  if (n_fit < total) {  // wave-uniform
+    if (lane == 0u) { atomicMin(surv_cnt + ri, surv_cap); sbase = atomicAdd(surv_cnt + n_regions, total - n_fit); }
+    sbase = __builtin_amdgcn_readfirstlane(sbase);
+    if (sbase + (total - n_fit) > spill_cap && lane == 0u) qflag[q] = 1u;
+  }
+  uint2* region = surv + (size_t)ri * surv_cap;
+  uint2* shared = surv + (size_t)n_regions * surv_cap;
+  uint32_t done = 0u;
+  for (uint32_t r0 = 0; r0 < len; r0 += 64u) {
+    const uint32_t r = r0 + lane;
+    const bool hit = r < len && x[r] >= th;
+    const unsigned long long m = __ballot(hit);
+    const uint32_t kth = done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (hit) {
+      if (kth < n_fit) region[base + kth] = make_uint2(p, base_row + r);
+      else if (sbase + (kth - n_fit) < spill_cap) shared[sbase + (kth - n_fit)] = make_uint2(p, base_row + r);
+    }
+    done += (uint32_t)__popcll(m);
   }
 }
 
@@ -1394,20 +1511,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     __syncthreads();
     phase(0);
-    // ---- LUT (create_lut_impl.cuh:17-78), entry (s, code) at s * 256 + code; the codebook values of 8 entries are
-    // loaded before any is used (one L2 round trip per batch instead of one per entry)
+    // ---- LUT (create_lut_impl.cuh:17-78), entry (s, code) at s * 256 + code; the codebook values of 16 entries are
+    // loaded before any is used (one L2 round trip per batch instead of one per entry; round 6: 16 instead of 8 - two round trips
+    // per item at pq_dim 64 instead of four)
+    constexpr int LB = 16;
 #pragma unroll 1
-    for (uint32_t e0 = tid; e0 < ((a.pq_len == 2u && !a.per_cluster) ? a.pq_dim * 256u : 0u); e0 += 8u * NT) {
-      float p0[8], p1[8];
+    for (uint32_t e0 = tid; e0 < ((a.pq_len == 2u && !a.per_cluster) ? a.pq_dim * 256u : 0u); e0 += (uint32_t)LB * NT) {
+      float p0[LB], p1[LB];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < LB; ++j) {
         // (codes of fewer than 8 bits: the LUT keeps 256 slots per subspace, those past the codebook are never looked up)
         const uint32_t e = min(e0 + (uint32_t)j * NT, a.pq_dim * 256u - 1u), sb = e >> 8, code = min(e & 255u, a.book - 1u);
         p0[j] = a.pq_centers[(size_t)(sb * 2 + 0) * a.book + code];
         p1[j] = a.pq_centers[(size_t)(sb * 2 + 1) * a.book + code];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < LB; ++j) {
         const uint32_t e = e0 + (uint32_t)j * NT, sb = e >> 8;
         if (e >= a.pq_dim * 256u) break;
         const float q0 = rv[sb * 2], q1 = rv[sb * 2 + 1];
@@ -1628,14 +1747,16 @@ __global__ void reset_flagged_kernel(const uint32_t* __restrict__ qflag, int64_t
 __global__ void fallback_items_kernel(const uint32_t* __restrict__ sorted_pairs, const uint32_t* __restrict__ pair_off,
                                       uint32_t n_lists, const uint32_t* __restrict__ probes, uint32_t n_probes,
                                       const uint32_t* __restrict__ qflag, work_item* __restrict__ items,
-                                      uint32_t* __restrict__ n_items)
+                                      uint32_t* __restrict__ n_items, int from_head)
 {
-  const uint32_t b = pair_off[n_lists], e = pair_off[2 * n_lists];
+  // from_head: the head pairs too (the wide path's bound-only head phase left no candidates of theirs)
+  const uint32_t h_end = pair_off[n_lists];
+  const uint32_t b = from_head ? pair_off[0] : h_end, e = pair_off[2 * n_lists];
   for (uint32_t s = b + blockIdx.x * blockDim.x + threadIdx.x; s < e; s += gridDim.x * blockDim.x) {
     const uint32_t p = sorted_pairs[s];
     if (qflag[p / n_probes] == 0u) continue;
     const uint32_t w = atomicAdd(n_items, 1u);
-    items[w] = work_item{n_lists + probes[p], s, 1u, 0u};
+    items[w] = work_item{(s < h_end ? 0u : n_lists) + probes[p], s, 1u, 0u};
   }
 }
 
@@ -2058,7 +2179,7 @@ void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r)
   hipLaunchKernelGGL(reset_flagged_kernel, dim3((unsigned)r.nq), dim3(256), 0, res.stream, r.qflag, r.nq, r.n_probes, r.k, r.head,
                      r.cand_d, r.cand_i);
   hipLaunchKernelGGL(fallback_items_kernel, dim3(grid * 4), dim3(256), 0, res.stream, r.sorted_pairs, r.pair_off, idx.n_lists,
-                     r.probes, r.n_probes, r.qflag, static_cast<work_item*>(r.fb_items), r.counters);
+                     r.probes, r.n_probes, r.qflag, static_cast<work_item*>(r.fb_items), r.counters, 0);
   profile_end(res, "pq_scan_kernel");
 }
 
@@ -2334,6 +2455,208 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   profile_end(res, "flat_rescore_kernel");
   profile_end(res, "ivf_flat_scan_kernel");
   return true;
+}
+
+// ------------------------------------------------------------------ the wide path (ivf_pq_wide.hip)
+bool pqw_supported(const ivf_pq_index& idx, int k)
+{
+  return idx.codebook_kind == 0 && idx.pq_bits >= 4 && idx.pq_bits <= 8 && idx.pq_dim % 16 == 0 && idx.pq_dim >= 16 &&
+         idx.rot_dim == idx.pq_len * idx.pq_dim && pqw_shape(idx.rot_dim) && k <= 256 && idx.shard_world <= 1 &&
+         (idx.metric == M_L2Expanded || idx.metric == M_L2SqrtExpanded || idx.metric == M_L2Unexpanded || idx.metric == M_L2SqrtUnexpanded);
+}
+
+uint32_t pqw_heads(const ivf_pq_index& idx, int k, uint32_t n_probes)
+{
+  uint64_t rows = 0, lists = 0;
+  for (uint32_t v : idx.h_list_sizes) { rows += v; lists += v != 0u; }
+  if (lists == 0 || rows == 0) return 0u;
+  // k <= 4 % of the head lists' rows (pq3_bound_useful's crossover): heads * rows / lists >= 25 k
+  const uint64_t h = std::max<uint64_t>(1, ((uint64_t)25 * (uint64_t)k * lists + rows - 1) / rows);
+  return 2 * h <= n_probes ? (uint32_t)h : 0u;
+}
+
+// exact score >= real score * (1 - eps) - alpha for the requested LUT / score types (L2: all entries are >= 0)
+//   fp32 LUT / fp32 score: 2 roundings per entry + 64 adds
+//   fp16 LUT: + 2^-11 per entry (2^-24 absolute below the normal range); fp16 score: + 2^-11 of the partial sum per add
+//   fp8 LUT (5 exponent bits, 3 value bits, truncation, half an ulp added back): 2^-4 per entry, 2^-15 absolute below its
+//   range; it saturates at 1.875 * 2^16, so bounds near that are not served
+// (the figures are those of pq_dim 64 and pq_len 2; the per-add and per-entry terms grow with the number of entries summed, the
+// entries' own chains - pq_len fused multiply-adds in fp32 - with pq_len: 2^-24 each, far inside the fp32 figure's slack)
+static void pqw_margins(const ivf_pq_index& idx, const pq3_run& r, float* eps, float* alpha, float* bound_max)
+{
+  const float ne = std::max(1.0f, (float)idx.pq_dim / 64.0f) * std::max(1.0f, (float)idx.pq_len / 8.0f);
+  *bound_max = FLT_MAX;
+  if (r.lut_mode == 0)      { *eps = ne / 65536.0f; *alpha = 0.f; }
+  else if (r.lut_mode == 1) { *eps = r.acc_half ? 0.04f * ne : 1.0f / 1024.0f; *alpha = ne * 64.0f / 16777216.0f; *bound_max = 60000.f; }
+  else                      { *eps = r.acc_half ? 0.07f + 0.04f * ne : 0.07f; *alpha = ne * 64.0f / 32768.0f; *bound_max = 30000.f; }
+}
+
+// the decoded rows (nullptr: no room on the device - remembered for this state of the index)
+static const void* pqw_rows(resources& res, const ivf_pq_index& idx, pq3_tables* tb_out)
+{
+  std::lock_guard<std::recursive_mutex> lock(g_pq3_mu);
+  const pq3_tables tb = pq3_prepare(res, idx, true);
+  if (tb_out != nullptr) *tb_out = tb;
+  auto& c = idx.scan3;
+  if (c.w_codes == idx.codes.data() && c.w_rows == idx.padded_rows && c.w_size == idx.size && c.w_pq == idx.pq_centers.data())
+    return c.rows16w.data();
+  if (c.w_failed_codes == idx.codes.data() && c.w_failed_rows == idx.padded_rows && c.w_failed_size == idx.size) return nullptr;
+  c.rows16w = dev_buf<uint4>();
+  c.w_codes = nullptr;
+  const int64_t rows = std::max<int64_t>(idx.padded_rows, 64);
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  const size_t need = (size_t)rows * idx.rot_dim * 2 + (size_t(1) << 30);
+  if (free_b < need) {
+    scratch_cache_flush_all();
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  }
+  if (free_b < need) {
+    c.w_failed_codes = idx.codes.data(); c.w_failed_rows = idx.padded_rows; c.w_failed_size = idx.size;
+    return nullptr;
+  }
+  c.rows16w = dev_buf<uint4>::persistent((size_t)rows * idx.rot_dim / 8);
+  uint32_t nch8 = 0;
+  const uint8_t* codes8 = pq3_codes(res, idx, &nch8);
+  pqw_decode(res, codes8, nch8, tb.cb16, idx.pq_len, idx.padded_rows, idx.rot_dim, c.rows16w.data());
+  sync(res);  // published (to the other threads sharing the index) only once it is filled
+  c.w_codes = idx.codes.data(); c.w_rows = idx.padded_rows; c.w_size = idx.size; c.w_pq = idx.pq_centers.data();
+  return c.rows16w.data();
+}
+
+bool pqw_ready(resources& res, const ivf_pq_index& idx) { return pqw_rows(res, idx, nullptr) != nullptr; }
+
+static rescore_params pqw_score_inputs(const ivf_pq_index& idx, const pq3_run& r, const uint8_t* codes8, uint32_t nch8)
+{
+  rescore_params s{};
+  s.probes = r.probes; s.rot_queries = r.rot_queries; s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data();
+  s.codes = codes8; s.n_chunks = nch8; s.rot_dim = idx.rot_dim; s.pq_len = idx.pq_len; s.book = idx.pq_book; s.per_cluster = 0;
+  s.is_ip = 0; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head;
+  return s;
+}
+
+bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, const pqw_bufs& hb)
+{
+  pq3_tables tb{};
+  const void* rows16 = pqw_rows(res, idx, &tb);
+  if (rows16 == nullptr) return false;
+  profile_begin(res, "pq_scan_kernel");
+  profile_begin(res, "pq_head_kernel");
+  const float c1 = -2.0f / (tb.sc * tb.sc);
+  float eps = 0.f, alpha = 0.f, bound_max = FLT_MAX;
+  pqw_margins(idx, r, &eps, &alpha, &bound_max);
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(1024), dim3(256), 0, res.stream, hb.xbuf, (size_t)r.nq * r.head * hb.ldx, -INFINITY);
+  // B operands, norms and constants of the head pairs
+  wide_prep l{};
+  l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries;
+  l.centers_rot = idx.centers_rot.data(); l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = hb.head_c; l.norms = hb.norms;
+  l.n_probes = r.n_probes; l.rot_dim = idx.rot_dim; l.heads = r.head; l.sc = tb.sc; l.c1 = c1; l.eps = eps; l.alpha = alpha;
+  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 1; l.n_pairs = r.nq * (int64_t)r.head;
+  pqw_bprep(res, l);
+  auto* units = static_cast<filter_unit*>(r.units);
+  hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(), r.unit_rows,
+                     r.unit_off, pqw_group(), 0u);
+  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
+                     idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, pqw_group(), 0u);
+  wide_filter f{};
+  f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = hb.tickets; f.sorted_pairs = r.sorted_pairs; f.pair_off = r.pair_off;
+  f.n_lists = idx.n_lists; f.bq = r.bq; f.thr = hb.head_c; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
+  f.qflag = r.qflag; f.surv = r.surv; f.surv_cnt = r.surv_cnt; f.surv_cap = 0; f.spill_cap = 0; f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim;
+  f.xbuf = hb.xbuf; f.ldx = hb.ldx; f.heads = r.head; f.emit = 1; f.grid = pq3_grid(res); f.stats = nullptr;
+  pqw_filter(res, f);
+  // the k largest values of every query over its head lists
+  select_k<uint32_t, uint32_t>(res, hb.xbuf, nullptr, r.nq, (int64_t)r.head * hb.ldx, (int64_t)r.head * hb.ldx, (int)r.k, hb.kth_val, hb.kth_idx,
+                               false);
+  uint32_t nch8 = 0;
+  const uint8_t* codes8 = pq3_codes(res, idx, &nch8);
+  wbound_params b{};
+  b.rs = pqw_score_inputs(idx, r, codes8, nch8);
+  b.kth_val = hb.kth_val; b.kth_idx = hb.kth_idx; b.norms = static_cast<const float4*>(hb.norms); b.probes = r.probes;
+  b.list_offsets = idx.list_offsets.data(); b.nq = r.nq; b.k = r.k; b.heads = r.head; b.ldx = hb.ldx; b.n_probes = r.n_probes;
+  b.rot_dim = idx.rot_dim; b.query_kth = const_cast<uint32_t*>(r.query_kth); b.qflag = r.qflag; b.thr_head = hb.thr_head;
+  b.sc = tb.sc; b.c1 = c1; b.eps = eps; b.alpha = alpha; b.cbmax = tb.cbmax; b.bound_max = bound_max;
+  const dim3 bgrid((unsigned)grid_blocks(r.nq, 4));
+  if (r.lut_mode == 0)      hipLaunchKernelGGL((pqw_head_bound_kernel<0, false>), bgrid, dim3(256), 0, res.stream, b);
+  else if (r.lut_mode == 1) {
+    if (r.acc_half) hipLaunchKernelGGL((pqw_head_bound_kernel<1, true>), bgrid, dim3(256), 0, res.stream, b);
+    else            hipLaunchKernelGGL((pqw_head_bound_kernel<1, false>), bgrid, dim3(256), 0, res.stream, b);
+  } else {
+    if (r.acc_half) hipLaunchKernelGGL((pqw_head_bound_kernel<2, true>), bgrid, dim3(256), 0, res.stream, b);
+    else            hipLaunchKernelGGL((pqw_head_bound_kernel<2, false>), bgrid, dim3(256), 0, res.stream, b);
+  }
+  profile_end(res, "pq_head_kernel");
+  profile_end(res, "pq_scan_kernel");
+  HIP_TRY(hipGetLastError());
+  return true;
+}
+
+void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const pqw_bufs& hb)
+{
+  pq3_tables tb{};
+  const void* rows16 = pqw_rows(res, idx, &tb);
+  CUVS_EXPECTS(rows16 != nullptr, "ivf_pq: the wide path's decoded rows are gone between the head and the tail phase");
+  profile_begin(res, "pq_scan_kernel");
+  const float c1 = -2.0f / (tb.sc * tb.sc);
+  float eps = 0.f, alpha = 0.f, bound_max = FLT_MAX;
+  pqw_margins(idx, r, &eps, &alpha, &bound_max);
+  wide_prep l{};
+  l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries;
+  l.centers_rot = idx.centers_rot.data(); l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = r.thr; l.norms = nullptr;
+  l.n_probes = r.n_probes; l.rot_dim = idx.rot_dim; l.heads = r.head; l.sc = tb.sc; l.c1 = c1; l.eps = eps; l.alpha = alpha;
+  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 0; l.n_pairs = r.nq * (int64_t)r.n_probes;
+  profile_begin(res, "pq_bprep_kernel");
+  pqw_bprep(res, l);
+  profile_end(res, "pq_bprep_kernel");
+  auto* units = static_cast<filter_unit*>(r.units);
+  hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(), r.unit_rows,
+                     r.unit_off, pqw_group(), idx.n_lists);
+  hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(idx.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, idx.n_lists,
+                     idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, pqw_group(), idx.n_lists);
+  const unsigned grid = pq3_grid(res);
+  wide_filter f{};
+  f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket; f.sorted_pairs = r.sorted_pairs; f.pair_off = r.pair_off;
+  f.n_lists = idx.n_lists; f.bq = r.bq; f.thr = r.thr; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
+  f.qflag = r.qflag; f.surv = r.surv; f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / grid);
+  f.spill_cap = r.surv_cap - f.surv_cap * grid; f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.xbuf = nullptr; f.ldx = 0; f.heads = r.head;
+  f.emit = 0; f.grid = grid; f.stats = r.stats;
+  pqw_filter(res, f);
+  hipLaunchKernelGGL(pqw_head_survivors_kernel, dim3((unsigned)grid_blocks(r.nq * (int64_t)r.head, 4)), dim3(256), 0, res.stream, hb.xbuf, hb.ldx,
+                     hb.thr_head, r.head, r.sorted_pairs, r.pair_off, idx.n_lists, r.probes, r.n_probes, idx.list_offsets.data(),
+                     idx.list_sizes.data(), static_cast<uint2*>(r.surv), r.surv_cnt, grid, f.surv_cap, f.spill_cap, r.qflag);
+  uint32_t nch8 = 0;
+  const uint8_t* codes8 = pq3_codes(res, idx, &nch8);
+  rescore_params s = pqw_score_inputs(idx, r, codes8, nch8);
+  s.surv = static_cast<const uint2*>(r.surv); s.surv_cnt = r.surv_cnt; s.surv_cap = f.surv_cap; s.spill_cap = f.spill_cap;
+  s.n_regions = grid; s.sub = 1u;
+  s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
+  s.head_rows = 0u; s.list_offsets = idx.list_offsets.data(); s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
+  s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
+  const size_t cb_bytes = (size_t)idx.rot_dim * idx.pq_book * sizeof(float);
+  s.cb_lds = cb_bytes <= 128 * 1024 ? 1 : 0;
+  const size_t rsmem = s.cb_lds ? cb_bytes : 16;
+  const dim3 rg(grid + 1, 2), rb(kRThreads);
+  profile_begin(res, "pq_rescore_kernel");
+  auto launch_rescore = [&](auto kern) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));
+    hipLaunchKernelGGL(kern, rg, rb, rsmem, res.stream, s);
+  };
+  auto pick_rescore = [&](auto lut_tag, auto acc_tag) {
+    constexpr int LUT = decltype(lut_tag)::value;
+    constexpr bool ACC = decltype(acc_tag)::value;
+    if (s.cb_lds) launch_rescore(pq_rescore_kernel<LUT, ACC, true>); else launch_rescore(pq_rescore_kernel<LUT, ACC, false>);
+  };
+  using L0 = std::integral_constant<int, 0>; using L1 = std::integral_constant<int, 1>; using L2 = std::integral_constant<int, 2>;
+  if (r.lut_mode == 0)      pick_rescore(L0{}, std::false_type{});
+  else if (r.lut_mode == 1) { if (r.acc_half) pick_rescore(L1{}, std::true_type{}); else pick_rescore(L1{}, std::false_type{}); }
+  else                      { if (r.acc_half) pick_rescore(L2{}, std::true_type{}); else pick_rescore(L2{}, std::false_type{}); }
+  profile_end(res, "pq_rescore_kernel");
+  // flagged queries: ALL their candidate rows back to "nothing found yet", ALL their pairs single-pair items of the LUT scan
+  hipLaunchKernelGGL(reset_flagged_kernel, dim3((unsigned)r.nq), dim3(256), 0, res.stream, r.qflag, r.nq, r.n_probes, r.k, 0u, r.cand_d,
+                     r.cand_i);
+  hipLaunchKernelGGL(fallback_items_kernel, dim3(grid * 4), dim3(256), 0, res.stream, r.sorted_pairs, r.pair_off, idx.n_lists, r.probes,
+                     r.n_probes, r.qflag, static_cast<work_item*>(r.fb_items), r.counters, 1);
+  profile_end(res, "pq_scan_kernel");
+  HIP_TRY(hipGetLastError());
 }
 
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i)

@@ -137,4 +137,28 @@ void pq3_warm(resources& res, const ivf_pq_index& idx, bool filter4);
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r);
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i);
 
+// ---- the wide path (ivf_pq_wide.hip): rot_dim 256 .. 768 in steps the kernel is built for, any pq_len, PER_SUBSPACE, L2; the head
+// phase is a BOUND-ONLY pass over the `heads` nearest lists of every query (their union bounds the k-th score: k may be a large
+// fraction of ONE list), through the filter in its emit form; both phases read the index's decoded fp16 rows (scan3_cache::rows16w)
+bool pqw_supported(const ivf_pq_index& idx, int k);
+// head lists per query so that k is at most ~4 % of their rows (the measured crossover of pq3_bound_useful); 0: more than half of
+// the probes would be head lists - the LUT scan stays
+uint32_t pqw_heads(const ivf_pq_index& idx, int k, uint32_t n_probes);
+// the decoded copy is there (made now, on the stream of `res`, if the device has the room)
+bool pqw_ready(resources& res, const ivf_pq_index& idx);
+struct pqw_bufs {
+  float* xbuf; uint32_t ldx;          // [nq * heads, ldx] values of (head pair, row), ldx >= the longest list rounded up to 64
+  float* kth_val; uint32_t* kth_idx;  // [nq, k]
+  float* thr_head;                    // [nq * heads] thresholds of the head pairs, in the units of xbuf
+  float* head_c;                      // [nq * heads] the head pairs' constants (by pair position)
+  void* norms;                        // [nq * heads] x 16 bytes
+  uint32_t* tickets;                  // 8 x 32 zeroed words
+};
+// r.head = heads. Returns false (nothing launched) when the decoded copy cannot be made: the caller runs the exact head phase and
+// the LUT scan. Leaves r.query_kth (bounds) and hb.thr_head; queries without a bound (fewer than k rows in their head lists) flagged.
+bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, const pqw_bufs& hb);
+// filter + head-pair survivors + re-score + fallback work items of the flagged queries (ALL their pairs: the head phase left no
+// candidates); the caller launches the LUT scan on those and pq3_merge
+void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const pqw_bufs& hb);
+
 }  // namespace cuvs_amd

@@ -2114,6 +2114,21 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     shard_allreduce_min_u32(res, idx.shard_comm, key.data(), 1);
     largest_total = (size_t)~to_host(res, key.data(), 1)[0];
   }
+  // The wide matrix-core path (ivf_pq_wide.hip): shapes pq_filter4_kernel does not decode (rot_dim beyond 256, pq_len not a power
+  // of two) and searches whose k is too large a fraction of ONE list for its bound to prune (pq3_bound_useful) - the bound then
+  // comes from the union of `wheads` head lists. L2, no pre-filter (the bound-only head phase scores k rows per query: with a
+  // pre-filter they might not all be admissible), not on a list shard, batches large enough for a head phase.
+  uint32_t wheads = 0;
+  if (!large_k && n_probes > 8 && n_queries >= 256 && res.tune.pq_scan3 != 0 && res.tune.pq_wide != 0 && res.tune.pq_head_probes < 0 &&
+      filter_bits == nullptr && idx.shard_world <= 1 && idx.shard_comm == nullptr && pqw_supported(idx, k) &&
+      !(pq3_supported(idx, k) && pq3_bound_useful(idx, k) && ((idx.pq_len == 2 && idx.codebook_kind == 0) || res.tune.pq_filter4 != 0))) {
+    wheads = res.tune.pq_wide_heads > 0 ? std::min<uint32_t>((uint32_t)res.tune.pq_wide_heads, n_probes / 2) : pqw_heads(idx, k, n_probes);
+    if (wheads > 0 && !pqw_ready(res, idx)) wheads = 0;  // (no room for the decoded rows)
+  }
+  const bool usew = wheads > 0;
+  uint32_t max_list_len = 0;
+  for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
+  const uint32_t w_ldx = usew ? (uint32_t)round_up((int64_t)max_list_len + 64, 64) : 0u;
   // batch of queries per pass (reference: max_internal_batch_size bounds the coarse batch, :814-857)
   int64_t max_batch = std::max<uint32_t>(1, p.max_internal_batch_size);
   {
@@ -2122,8 +2137,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (large_k) per_q += (int64_t)largest_total * 8;
     // the matrix-core tail phase's buffers, per (query, probe) pair: fp16 B operand, threshold, probe ranks of the pool, >= 16
     // survivor entries, a fallback work item, two unit descriptors' share, norms and grouping scratch of the two-stream schedule
-    if (!large_k && pq3_supported(idx, k) && res.tune.pq_scan3 != 0)
+    if (!large_k && (pq3_supported(idx, k) || usew) && res.tune.pq_scan3 != 0)
       per_q += (int64_t)n_probes * ((int64_t)idx.rot_dim * 2 + (int64_t)k * 4 + 128 + 16 + 4 + 16 + 8);
+    if (usew) per_q += (int64_t)wheads * ((int64_t)w_ldx * 4 + 32) + (int64_t)k * 8;  // values of the head lists' rows, the k best
     int64_t fit   = std::max<int64_t>(1, (int64_t)res.ivf_batch_limit / per_q);
     max_batch     = balanced_batch(n_queries, std::min(max_batch, fit));  // (the same on every rank of a list shard: same inputs)
   }
@@ -2146,6 +2162,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   const bool pq3_ok = !large_k && pq3_supported(idx, k) && pq3_bound_useful(idx, k) && res.tune.pq_scan3 != 0 && res.tune.pq_head_probes != 0 &&
                       ((idx.pq_len == 2 && idx.codebook_kind == 0) || res.tune.pq_filter4 != 0);
   if ((idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded) && !pq3_ok) head = 0;
+  if (usew) head = wheads;
   const bool sharded      = idx.shard_world > 1;  // list-sharded index: foreign probes go to a bucket that is never scanned
   const uint32_t n_ranges = head > 0 ? 2 * idx.n_lists : idx.n_lists;
   const uint32_t n_labels = n_ranges + (sharded ? 1u : 0u);
@@ -2167,23 +2184,29 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): decode + MFMA filter, exact re-score of the survivors
   const bool metric_ip = idx.metric == M_InnerProduct || idx.metric == M_CosineExpanded;
   // (pq_len other than 2 is decoded by pq_filter4_kernel only)
-  const bool use3 = head > 0 && !large_k && pq3_supported(idx, k) && pq3_bound_useful(idx, k) && res.tune.pq_scan3 != 0 && ((idx.pq_len == 2 && idx.codebook_kind == 0) || res.tune.pq_filter4 != 0);
+  const bool use3 = !usew && head > 0 && !large_k && pq3_supported(idx, k) && pq3_bound_useful(idx, k) && res.tune.pq_scan3 != 0 && ((idx.pq_len == 2 && idx.codebook_kind == 0) || res.tune.pq_filter4 != 0);
+  const bool use3x = use3 || usew;  // the buffers both matrix-core paths need
   uint32_t unit_rows = 0;
-  const size_t max_units = use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows, res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2 || idx.codebook_kind != 0)) : 0;
-  uint32_t surv_cap = use3 ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 16, 1 << 22), 1 << 28) : 0u;
-  if (use3 && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
-  dev_buf<uint32_t> cand_r(res, use3 ? (size_t)n_pairs_max * k : 0), qstate(res, use3 ? (size_t)4 * bs_alloc + 8 + pq3_regions(res) : 0);
-  dev_buf<uint32_t> unit_off(res, use3 ? (size_t)idx.n_lists + 1 : 0);
+  const size_t max_units = usew ? pq3_max_units(idx, n_pairs_max, &unit_rows, false) : use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows, res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2 || idx.codebook_kind != 0)) : 0;
+  uint32_t surv_cap = use3x ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 16, 1 << 22), 1 << 28) : 0u;
+  if (use3x && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
+  dev_buf<uint32_t> cand_r(res, use3x ? (size_t)n_pairs_max * k : 0), qstate(res, use3x ? (size_t)4 * bs_alloc + 8 + pq3_regions(res) : 0);
+  dev_buf<uint32_t> unit_off(res, use3x ? (size_t)idx.n_lists + 1 : 0);
   dev_buf<uint2> surv(res, surv_cap);
   dev_buf<uint4> units3(res, 2 * max_units);  // 32-byte unit descriptors
-  const uint32_t overflow_cap = use3 ? (res.tune.pq3_surv_cap > 0 ? (uint32_t)res.tune.pq3_surv_cap : (1u << 22)) : 0u;
+  const uint32_t overflow_cap = use3x ? (res.tune.pq3_surv_cap > 0 ? (uint32_t)res.tune.pq3_surv_cap : (1u << 22)) : 0u;
   dev_buf<uint4> overflow3(res, (size_t)2 * overflow_cap);
-  dev_buf<work_item> fb_items(res, use3 ? (size_t)n_pairs_max : 0);
+  dev_buf<work_item> fb_items(res, use3x ? (size_t)n_pairs_max : 0);
   // pq_filter4_kernel serves L2 and cosine; unnormalised inner products (loose margins: ~8x the survivors per pair) keep
   // pq_filter_kernel, whose per-lane survivor loop is cheaper at that rate (C3 shape: 3.9 vs 6.7 ms)
   const bool use_f4 = use3 && res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2 || idx.codebook_kind != 0);
-  dev_buf<uint4> bq3(res, use_f4 ? (size_t)n_pairs_max * (idx.rot_dim / 8) : 0);  // fp16 B operands of the tail pairs
-  dev_buf<float> thr3(res, use_f4 ? (size_t)n_pairs_max : 0);
+  dev_buf<uint4> bq3(res, (use_f4 || usew) ? (size_t)n_pairs_max * (idx.rot_dim / 8) : 0);  // fp16 B operands of the tail pairs
+  dev_buf<float> thr3(res, (use_f4 || usew) ? (size_t)n_pairs_max : 0);
+  // the wide path's bound-only head phase: values of every (head pair, row), the k best of every query, the head pairs' thresholds
+  dev_buf<float> w_x(res, usew ? (size_t)bs_alloc * wheads * w_ldx : 0), w_kv(res, usew ? (size_t)bs_alloc * k : 0);
+  dev_buf<float> w_thr(res, usew ? (size_t)bs_alloc * wheads : 0), w_c(res, usew ? (size_t)bs_alloc * wheads : 0);
+  dev_buf<uint32_t> w_ki(res, usew ? (size_t)bs_alloc * k : 0);
+  dev_buf<float4> w_nm(res, usew ? (size_t)bs_alloc * wheads : 0);
   // two-stream schedule (the bench shape and every other search whose head phase is one single-pair item per query and whose
   // tail phase runs pq_filter4_kernel): grouping, work units and B operands on the helper stream, next to the head kernel
   const bool overlap = use3 && use_f4 && head == 1 && !glut && res.tune.pq_overlap != 0;
@@ -2218,8 +2241,6 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     else                            head_rows = 0u;  // (default rule: see DESIGN 3.1f - set by measurement)
     if (head_rows != 0u && head_rows < 4u * (uint32_t)k) head_rows = 0u;  // (a bound needs a few times k rows to mean anything)
   }
-  uint32_t max_list_len = 0;
-  for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
   const bool q_is_host = false;  // the C layer guarantees device-accessible queries
 
   for (int64_t q0 = 0; q0 < n_queries; q0 += max_batch) {
@@ -2263,12 +2284,13 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     // (8 pairs whatever the LUT type: two groups of four with an fp16 LUT, four groups of two with an fp32 LUT)
     bool use2 = head > 0 && bits8 && idx.pq_len == 2 && idx.codebook_kind == 0 && k <= 64 &&  // (k <= 64 excludes the non-fused path)
                 ((lut_half && qpb == 4) || (!lut_half && qpb == 2));
-    use2 = use2 && res.tune.pq_scan2 != 0 && !use3;
+    use2 = use2 && res.tune.pq_scan2 != 0 && !use3x;
     // with the matrix-core tail phase the LUT scan only sees the head pairs - nearly always one query per list at the
     // bench shape (10k queries, 16384 lists) - and the pairs of handed-back queries: single-query items and a
     // single-query LUT (a quarter of the LUT build and of the accumulate work of the 4-query interleave)
     const int lut_mode = lut_fp8 ? 2 : (p.lut_dtype != 0 ? 1 : 0);
-    const bool head1 = use3 && !glut;
+    // (the wide path: pq_head_kernel only serves the pairs of handed-back queries, when its LUT fits next to its score keys)
+    const bool head1 = (use3 && !glut) || (usew && !glut && idx.rot_dim <= 256 /* its residual buffers */ && (size_t)idx.pq_dim * 256 * ((p.lut_dtype == 0 || (lut_fp8 && !acc_half)) ? 4 : 2) <= 96 * 1024);
     build_work_items(gres, labels, n_pairs, n_labels, head1 ? 1 : qpb, sorted_pairs.data(), pair_off.data(), item_off.data(),
                      items.data(), (int)idx.n_lists, use2 ? 8 : qpb, overlap ? group_scratch.data() : nullptr,
                      n_ranges /* the shard's bucket of foreign pairs stays as the scatter left it */, n_probes, nq);
@@ -2279,7 +2301,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     HIP_TRY(hipMemsetAsync(query_kth.data(), 0xff, (size_t)nq * sizeof(uint32_t), res.stream));
     HIP_TRY(hipMemsetAsync(tickets.data(), 0, tickets.bytes(), res.stream));
     // per-pair candidate rows start out invalid: the scan only writes the rows of pairs that found something
-    if (use3) {
+    if (use3x) {
       // matrix-core tail phase: only the head segments of a query's row are read before they are written (the pool behind
       // them is filled by count, the rows of handed-back queries are reset by reset_flagged_kernel) - no fill of all
       // n_pairs x k slots (205 MB per batch at the bench shape; on a list shard most of them belong to foreign pairs)
@@ -2361,7 +2383,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (head > 0) {
       a.xcd_ticket = tickets.data();
       a.item_begin = nullptr;                        a.item_end = item_off.data() + idx.n_lists;
-      if (overlap) {  // head phase straight from the probes (one single-pair item per query), no grouping in its way
+      if (usew) {
+        // the wide path's head phase is a bound-only pass through the filter: below, with the tail phase's run description
+      } else if (overlap) {  // head phase straight from the probes (one single-pair item per query), no grouping in its way
         scan_args ah = a;
         ah.items = hitems.data(); ah.sorted_pairs = hpairs.data(); ah.item_end = hpairs.data() + bs_alloc;
         ah.one_shot = (uint32_t)nq;  // one workgroup per item: slots free up item by item, the helper stream's kernels fit in between
@@ -2373,7 +2397,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
       if (idx.shard_comm != nullptr) shard_allreduce_min_u32(res, idx.shard_comm, query_kth.data(), (size_t)nq);
       a.xcd_ticket = tickets.data() + 8 * 32;
       a.item_begin = item_off.data() + idx.n_lists;  a.item_end = item_off.data() + 2 * idx.n_lists;
-      if (use3) {
+      if (use3x) {
         HIP_TRY(hipMemsetAsync(qstate.data(), 0, qstate.bytes(), res.stream));
         pq3_run r{};
         r.pair_norms = pair_norms.data(); r.head_rows = head_rows;
@@ -2388,7 +2412,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets.data() + 2 * 8 * 32; r.fb_items = fb_items.data();
         r.filter_bits = filter_bits; r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
-        r.bq = use_f4 ? bq3.data() : nullptr; r.thr = thr3.data();
+        r.bq = (use_f4 || usew) ? bq3.data() : nullptr; r.thr = thr3.data();
         dev_buf<unsigned long long> st3(res, (a.dbg & 1024) ? 8 : 0);
         if (a.dbg & 1024) HIP_TRY(hipMemsetAsync(st3.data(), 0, st3.bytes(), res.stream));
         r.stats = st3.data(); r.filter_dbg = (a.dbg >> 16) & 255;  // CUVS_AMD_SCAN_DEBUG bits 16..23
@@ -2402,7 +2426,14 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
           fork_guard.armed = false;  // joined: everything the helper stream was given is ordered before the handle's stream again
           r.stage = 2;
         }
-        pq3_tail(res, idx, r);
+        if (usew) {
+          const pqw_bufs hb{w_x.data(), w_ldx, w_kv.data(), w_ki.data(), w_thr.data(), w_c.data(), w_nm.data(), tickets.data()};
+          const bool ok = pqw_head_bounds(res, idx, r, hb);
+          CUVS_EXPECTS(ok, "ivf_pq: the wide path's decoded rows are gone");
+          pqw_tail(res, idx, r, hb);
+        } else {
+          pq3_tail(res, idx, r);
+        }
         // queries the filter could not serve (no finite bound, operands beyond fp16, full pool): LUT scan of their pairs
         a.items = fb_items.data(); a.item_begin = nullptr; a.item_end = r.counters;
         a.xcd_ticket = tickets.data() + 3 * 8 * 32;
@@ -2461,7 +2492,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
               h[ST_F_LOAD] * w, h[ST_F_GATHER] * w, h[ST_F_FLUSH] * w);
     }
     // per-query merge of n_probes * k candidates (ivf_pq_search.cuh:646-655)
-    if (use3) {
+    if (use3x) {
       // merged already (pq3_merge: head lists + pool)
     } else if (!large_k) {
       select_k<uint32_t, uint32_t>(res, cand_d.data(), cand_i.data(), nq, (int64_t)n_probes * k, (int64_t)n_probes * k,

@@ -1,0 +1,161 @@
+"""GPU: the wide matrix-core path of the IVF-PQ search (ivf_pq_wide.hip) - rot_dim beyond pq_filter4_kernel's decode
+table (the reference's default at 768 dimensions: pq_dim 384 x pq_len 2, ivf_pq_index.cu:350-364; a CAGRA build's kNN-graph search:
+pq_dim 64 x pq_len 12), and k too large a fraction of ONE list for its k-th score to prune (the bound then comes from the union of
+several head lists). The decoded fp16 copy of the index, the bound-only head phase through the filter's emit form, the filter, the
+head pairs' survivors, the re-score and the pool merge against:
+  * the CPU oracle (oracle.ivf_pq_search: compute_score_impl.cuh:52-79 / ivf_pq_search.cuh:421-669 restated) - ids and distances
+    bit for bit;
+  * the same search on the LUT scan kernels (CUVS_AMD_PQ_WIDE=0).
+Every case asserts through the filter's counters that the wide path is what ran.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+_LUTS = {"f32": np.float32, "f16": np.float16, "fp8": np.uint8}
+
+
+def _mixture(n, d, q, seed, modes=48, latent=16, sigma=0.35):
+    rng = np.random.default_rng(seed)
+    basis = rng.standard_normal((latent, d)).astype(np.float32) / math.sqrt(latent)
+    centres = rng.standard_normal((modes, latent)).astype(np.float32) * 2.0
+
+    def draw(m):
+        z = centres[rng.integers(0, modes, size=m)] + sigma * rng.standard_normal((m, latent)).astype(np.float32)
+        return (z @ basis + 0.02 * rng.standard_normal((m, d)).astype(np.float32)).astype(np.float32)
+
+    return draw(n), draw(q)
+
+
+def _pq_build(x, **kw):
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    return ivf_pq.build(ivf_pq.IndexParams(**kw), torch.from_numpy(x).cuda())
+
+
+def _pq_search(index, q, k, **kw):
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    d, i = ivf_pq.search(ivf_pq.SearchParams(**kw), index, torch.from_numpy(q).cuda(), k)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy()
+
+
+def _filter_stats():
+    from cuvs_amd._lib import lib
+
+    st = (C.c_uint64 * 6)()
+    lib().cuvsAmdIvfPqLastFilterStats6(st)
+    return [int(v) for v in st]
+
+
+def _wide_and_lut(index, q, k, monkeypatch, capfd, **kw):
+    """the search on the wide path (counters on: proves the path), then on the LUT scan kernels"""
+    monkeypatch.setenv("CUVS_AMD_SCAN_DEBUG", "1024")
+    gd, gi = _pq_search(index, q, k, **kw)
+    st = _filter_stats()
+    capfd.readouterr()  # (the counters' stderr lines)
+    monkeypatch.delenv("CUVS_AMD_SCAN_DEBUG")
+    monkeypatch.setenv("CUVS_AMD_PQ_WIDE", "0")
+    sd, si = _pq_search(index, q, k, **kw)
+    monkeypatch.delenv("CUVS_AMD_PQ_WIDE")
+    return gd, gi, sd, si, st
+
+
+@pytest.mark.parametrize("d,pq_dim,lut,acc,k", [
+    (768, 64, "f16", "f32", 10),    # pq_len 12: the CAGRA build's shape
+    (768, 64, "f16", "f16", 100),   # k = a fifth of a list: bound from several head lists
+    (768, 384, "f16", "f32", 10),   # pq_len 2: the reference's default pq_dim at 768 dimensions (LUT beyond the LDS: global LUT fallback)
+    (768, 192, "f32", "f32", 32),   # pq_len 4: the reference's CAGRA default (dim / 4)
+    (512, 64, "fp8", "f16", 20),    # pq_len 8, 32 K steps (4 chunks, ring of 2)
+    (384, 96, "f16", "f32", 20),    # pq_len 4, 24 K steps (3 chunks)
+    (256, 16, "f16", "f32", 20),    # pq_len 16, 16 K steps (2 chunks)
+])
+def test_wide_path_equals_oracle_and_lut_scan(d, pq_dim, lut, acc, k, monkeypatch, capfd):
+    from cuvs_amd.neighbors import ivf_pq
+
+    # (modes as wide as they are apart: a query's neighbours sit in several of its probed lists - tail-phase survivors)
+    x, q = _mixture(60_000, d, 400, seed=d + pq_dim, modes=200, sigma=1.0)
+    index = _pq_build(x, n_lists=32, pq_dim=pq_dim, pq_bits=8, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
+    ex = ivf_pq.export_for_oracle(index)
+    n_probes = 12
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi, sd, si, st = _wide_and_lut(index, q, k, monkeypatch, capfd, **kw)
+    assert st[0] > 0, "the wide filter did not run"
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    assert (si == oi).all() and (sd == od).all()
+    # the tail phase has survivors, and most pairs are dropped by the screen (the point of the path)
+    assert 0 < st[1] < 0.1 * st[0], st
+
+
+def test_wide_path_large_k_of_short_lists(monkeypatch, capfd):
+    """k = 256 of lists of ~470 rows at 128 probed of 256 lists (a CAGRA build's search in miniature): pq3_bound_useful says no, the
+    wide path bounds with the union of its head lists; 256 dimensions with pq_len 8 - a shape pq_filter4_kernel serves at small k"""
+    x, q = _mixture(120_000, 256, 600, seed=77, modes=64)
+    index = _pq_build(x, n_lists=256, pq_dim=32, pq_bits=8, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
+    kw = dict(n_probes=128, lut_dtype=np.float16, internal_distance_dtype=np.float16)
+    gd, gi, sd, si, st = _wide_and_lut(index, q, 256, monkeypatch, capfd, **kw)
+    assert st[0] > 0, "the wide filter did not run"
+    assert (gi == si).all(), f"id mismatch rate {(gi != si).mean():.5f}"
+    assert (gd == sd).all()
+
+
+def test_wide_path_codes_of_fewer_than_8_bits(monkeypatch, capfd):
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(60_000, 384, 400, seed=5)
+    index = _pq_build(x, n_lists=32, pq_dim=48, pq_bits=5, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
+    ex = ivf_pq.export_for_oracle(index)
+    kw = dict(n_probes=12, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+    gd, gi, sd, si, st = _wide_and_lut(index, q, 20, monkeypatch, capfd, **kw)
+    assert st[0] > 0
+    od, oi = oracle.ivf_pq_search(ex, q, 20, 12, lut="f16", acc="f32")
+    assert (gi == oi).all() and (gd == od).all()
+    assert (si == oi).all() and (sd == od).all()
+
+
+def test_wide_path_hands_back_and_rebuilds(monkeypatch, capfd):
+    """(1) a survivor buffer of 2000 entries: the regions run over, queries are handed back to the LUT scan pair by pair - head pairs
+    included (the bound-only head phase left no candidates of theirs); (2) queries whose head lists hold fewer than k rows have no
+    bound: handed back as well; (3) rows added after the decoded copy was made: it is rebuilt."""
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    x_all, q = _mixture(65_000, 768, 400, seed=9)
+    x, x2 = x_all[:60_000], x_all[60_000:]
+    index = _pq_build(x, n_lists=32, pq_dim=64, pq_bits=8, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
+    kw = dict(n_probes=12, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+    gd, gi, sd, si, st = _wide_and_lut(index, q, 20, monkeypatch, capfd, **kw)
+    assert st[0] > 0 and (gi == si).all() and (gd == sd).all()
+    monkeypatch.setenv("CUVS_AMD_PQ3_SURV_CAP", "2000")
+    monkeypatch.setenv("CUVS_AMD_SCAN_DEBUG", "1024")
+    hd, hi = _pq_search(index, q, 20, **kw)
+    st = _filter_stats()
+    capfd.readouterr()
+    monkeypatch.delenv("CUVS_AMD_SCAN_DEBUG")
+    monkeypatch.delenv("CUVS_AMD_PQ3_SURV_CAP")
+    assert st[4] > 0, "no pair was handed back"
+    assert (hi == si).all() and (hd == sd).all()
+    # one head list per query forced, k = 250 of lists that hold ~1900 rows on average but as few as a few hundred
+    monkeypatch.setenv("CUVS_AMD_PQ_WIDE_HEADS", "1")
+    g2d, g2i = _pq_search(index, q, 250, **kw)
+    monkeypatch.delenv("CUVS_AMD_PQ_WIDE_HEADS")
+    monkeypatch.setenv("CUVS_AMD_PQ_WIDE", "0")
+    s2d, s2i = _pq_search(index, q, 250, **kw)
+    monkeypatch.delenv("CUVS_AMD_PQ_WIDE")
+    assert (g2i == s2i).all() and (g2d == s2d).all()
+    # extend: the decoded copy follows the lists
+    index = ivf_pq.extend(index, torch.from_numpy(x2).cuda(), torch.arange(60_000, 65_000, dtype=torch.int64).cuda())
+    ed, ei, fd, fi, st = _wide_and_lut(index, q, 20, monkeypatch, capfd, **kw)
+    assert st[0] > 0 and (ei == fi).all() and (ed == fd).all()
+    assert (ei >= 60_000).any(), "the extension's rows are found"
