@@ -65,6 +65,15 @@ __global__ void cb16_kernel(const float* __restrict__ pq_centers, uint32_t pq_di
       code < book ? __builtin_bit_cast(uint16_t, (_Float16)(sc * pq_centers[(size_t)(s * pq_len + l) * book + code])) : (uint16_t)0;
 }
 
+// the fp32 codebook entry-major (PER_SUBSPACE): [subspace][256 codes][component] - a code's pq_len values side by side
+__global__ void cbt_kernel(const float* __restrict__ pq_centers, uint32_t pq_dim, uint32_t pq_len, uint32_t book, float* __restrict__ cbt)
+{
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;  // s * 256 + code
+  if (e >= pq_dim * 256u) return;
+  const uint32_t s = e >> 8, code = e & 255u;
+  for (uint32_t l = 0; l < pq_len; ++l) cbt[(size_t)e * pq_len + l] = code < book ? pq_centers[(size_t)(s * pq_len + l) * book + code] : 0.f;
+}
+
 // codes of fewer than 8 bits (a little-endian bit stream of codes_per_chunk codes per 16-byte chunk,
 // ivf_pq_codepacking.cuh:22-52) expanded to one byte per code, 16 per chunk: the layout every kernel of this file reads.
 // One thread per (row, 16-code chunk)
@@ -928,6 +937,7 @@ struct rescore_params {
   int cb_lds;             // IVF-PQ: the fp32 codebook fits the LDS of a workgroup
   uint32_t pq_len, book;
   int per_cluster;        // IVF-PQ: one codebook per list (pq_centers [n_lists][pq_len][book])
+  const float* cbt;       // the wide path: the codebook entry-major, [subspace][256][pq_len] fp32 (pq_exact_score_wave)
 };
 
 // A re-scored survivor goes into its query's pool if it is within the bound, beyond the pool's capacity (a loose head
@@ -1116,6 +1126,150 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
   }
 }
 
+// ------------------------------------------------------------------ the exact score by a whole wave (the wide path)
+// pq_exact_score's generic branch gives every LANE a survivor: its pq_dim x pq_len codebook values, query and centre components are
+// scalar loads of 64 unrelated (query, list, row)s per instruction - 51 ms for 15.8 M survivors at pq_dim 64 x pq_len 12 (3.3 ns each,
+// measured: most of the wide path's batch). Here a WAVE takes a survivor: lane = subspace (64 at a time) - its code byte, then per
+// component one codebook value and the query's / centre's component (48-byte stride across the lanes: whole lines) - the entry in the
+// LUT type, and the sum over the subspaces in subspace order in the score type, as the reference's loop (compute_score_impl.cuh:52-79)
+// adds them: lane by lane, every lane computing the same chain (v_readlane + add). Bit-identical to pq_exact_score.
+// cache: the residual (query - centre; L2) of the lane's subspace for the pair (q, L) scored last, kept across calls while the index has
+// at most 64 subspaces: consecutive survivors of a region mostly belong to the same pair (a head pair's rows; a bound's candidates from
+// the nearest list), and two thirds of a score's bytes were the query's and the centre's components read again
+struct wave_score_cache {
+  uint32_t q = 0xffffffffu, L = 0xffffffffu;
+  float4 r4[4];
+};
+template <int LUT, bool ACC_HALF>
+__device__ inline float pq_exact_score_wave(const rescore_params& a, const uint32_t q, const uint32_t L, const uint32_t row, wave_score_cache& cache)
+{
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t pq_dim = a.n_chunks * 16u;
+  const float* rq = a.rot_queries + (size_t)q * a.rot_dim;
+  const float* ct = a.centers_rot + (size_t)L * a.rot_dim;
+  const uint8_t* cr = a.codes + ((size_t)(row >> 6) * a.n_chunks) * 1024 + (size_t)(row & 63u) * 16;
+  float af    = 0.f;
+  _Float16 ah = (_Float16)0.f;
+  for (uint32_t s0 = 0; s0 < pq_dim; s0 += 64u) {  // wave-uniform
+    const uint32_t sub = min(s0 + lane, pq_dim - 1u);
+    const uint32_t code = cr[(size_t)(sub >> 4) * 1024 + (sub & 15u)];
+    const uint32_t d0 = sub * a.pq_len;
+    // the codebook entry from the entry-major copy (a.cbt: [subspace][code][component], 4 pq_len bytes side by side): with the
+    // index's own layout ([subspace * pq_len + component][code]) every lane read a different 1 KiB row per component - 64 lines per
+    // load instruction, pq_len times; here a lane's whole entry, the query's and the centre's components are 16-byte loads, all
+    // asked for before the first is used
+    const float* e = a.cbt + ((size_t)sub * 256 + code) * a.pq_len;
+    float v = 0.f;
+    auto add = [&](const float p, const float qv, const float cv) {
+      if (!a.is_ip) {
+        const float d = (qv - cv) - p;
+        v = __fmaf_rn(d, d, v);
+      } else {
+        v = __fmaf_rn(-qv, cv, v);
+        v = __fmaf_rn(-qv, p, v);
+      }
+    };
+    if ((a.pq_len & 3u) == 0u && a.pq_len <= 16u && !a.is_ip && pq_dim <= 64u) {  // wave-uniform: L2 with the residual kept
+      float4 p4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const float4*>(e + min((uint32_t)i * 4u, a.pq_len - 4u));
+      if (cache.q != q || cache.L != L) {  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t o = min((uint32_t)i * 4u, a.pq_len - 4u);  // (past the entry: a repeat of its last piece, not used)
+          const float4 q4 = *reinterpret_cast<const float4*>(rq + d0 + o), c4 = *reinterpret_cast<const float4*>(ct + d0 + o);
+          cache.r4[i] = make_float4(q4.x - c4.x, q4.y - c4.y, q4.z - c4.z, q4.w - c4.w);
+        }
+        cache.q = q; cache.L = L;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((uint32_t)i * 4u < a.pq_len) {
+          float d;
+          d = cache.r4[i].x - p4[i].x; v = __fmaf_rn(d, d, v);
+          d = cache.r4[i].y - p4[i].y; v = __fmaf_rn(d, d, v);
+          d = cache.r4[i].z - p4[i].z; v = __fmaf_rn(d, d, v);
+          d = cache.r4[i].w - p4[i].w; v = __fmaf_rn(d, d, v);
+        }
+      }
+    } else if ((a.pq_len & 3u) == 0u && a.pq_len <= 16u) {  // wave-uniform
+      float4 p4[4], q4[4], c4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t o = min((uint32_t)i * 4u, a.pq_len - 4u);  // (past the entry: a repeat of its last piece, not used)
+        p4[i] = *reinterpret_cast<const float4*>(e + o);
+        q4[i] = *reinterpret_cast<const float4*>(rq + d0 + o);
+        c4[i] = *reinterpret_cast<const float4*>(ct + d0 + o);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((uint32_t)i * 4u < a.pq_len) {
+          add(p4[i].x, q4[i].x, c4[i].x); add(p4[i].y, q4[i].y, c4[i].y); add(p4[i].z, q4[i].z, c4[i].z); add(p4[i].w, q4[i].w, c4[i].w);
+        }
+      }
+    } else {
+      for (uint32_t l = 0; l < a.pq_len; ++l) add(e[l], rq[d0 + l], ct[d0 + l]);
+    }
+    // the entry as the LUT holds it
+    if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
+    uint32_t bits;
+    if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) bits = __float_as_uint(v);
+    else bits = (uint32_t)__builtin_bit_cast(uint16_t, to_lut_half(v));
+    auto chain = [&](const uint32_t eb) {
+      if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
+        af += __uint_as_float(eb);
+      } else {
+        const _Float16 e = __builtin_bit_cast(_Float16, (uint16_t)eb);
+        if constexpr (ACC_HALF) ah += e; else af += (float)e;
+      }
+    };
+    const uint32_t n_here = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, pq_dim - s0));
+    if (n_here == 64u) {  // the usual case: lane indices in the instructions (a loop with a run-time bound was five instructions and a branch per entry)
+#pragma unroll
+      for (int j = 0; j < 64; ++j) chain(__builtin_amdgcn_readlane(bits, j));
+    } else {
+      for (uint32_t j = 0; j < n_here; ++j) chain(__builtin_amdgcn_readlane(bits, j));
+    }
+  }
+  return ACC_HALF ? (float)ah : af;
+}
+
+// the re-score with a wave per survivor: a wave takes 64 consecutive survivors of its region, scores them one after the other
+// (lane j keeps the score of the j-th) and appends them together (pool_append_wave)
+template <int LUT, bool ACC_HALF>
+__global__ __launch_bounds__(256) void pq_rescore_wave_kernel(const rescore_params a)
+{
+  const bool spill = blockIdx.x + 1 == gridDim.x;
+  const uint32_t ri = spill ? a.n_regions : blockIdx.x;
+  const uint32_t n = spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri];
+  const uint2* region = a.surv + (size_t)ri * a.surv_cap;
+  const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.y * (blockDim.x >> 6);
+  wave_score_cache cache;
+  for (uint32_t sb = wave * 64u; sb < n; sb += n_waves * 64u) {  // wave-uniform
+    const uint32_t s = sb + lane;
+    uint2 sv = make_uint2(0xffffffffu, 0u);
+    if (s < n) sv = region[s];
+    bool ok = sv.x != 0xffffffffu;
+    const uint32_t pair = ok ? sv.x : 0u, row = ok ? sv.y : 0u, q = pair / a.n_probes;
+    ok = ok && a.qflag[q] == 0u;  // flagged: re-done by the LUT scan
+    if (ok && a.filter_bits != nullptr) {
+      const int64_t sid = a.indices[row];
+      ok = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
+    }
+    const uint32_t L = ok ? a.probes[pair] : 0u;
+    float score = 0.f;
+    unsigned long long todo = __ballot(ok);
+    while (todo != 0ull) {
+      const int j = (int)__ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const float sc = pq_exact_score_wave<LUT, ACC_HALF>(a, __builtin_amdgcn_readlane(q, j), __builtin_amdgcn_readlane(L, j),
+                                                          __builtin_amdgcn_readlane(row, j), cache);
+      if ((int)lane == j) score = sc;
+    }
+    pool_append_wave(a, ok, q, pair, row, score);
+  }
+}
+
 // ------------------------------------------------------------------ the wide path's bound-only head phase (ivf_pq_wide.hip)
 // As IVF-Flat's (flat_head_bound_kernel): the emit pass left a value for every (head pair, row) - larger is nearer, comparable
 // across a query's head lists (the pair's constant -|r|^2 sc^2 / 2 is added) - and select_k the k largest of every QUERY over the
@@ -1141,22 +1295,30 @@ __global__ __launch_bounds__(256) void pqw_head_bound_kernel(const wbound_params
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
   if (q >= a.nq) return;  // wave-uniform
-  float worst = -INFINITY;
+  float worst = -INFINITY;  // (wave-uniform)
   bool short_list = false;
+  wave_score_cache cache;
   for (uint32_t j0 = 0; j0 < a.k; j0 += 64u) {
     const uint32_t j = j0 + lane;
+    bool have = false;
+    uint32_t L = 0u, row = 0u;
     if (j < a.k) {
       if (!(a.kth_val[(size_t)q * a.k + j] > -INFINITY)) {
         short_list = true;  // fewer than k rows in the head lists: no finite bound
       } else {
         const uint32_t id = a.kth_idx[(size_t)q * a.k + j], rank = id / a.ldx, r = id - rank * a.ldx;
-        const uint32_t L = a.probes[(size_t)q * a.n_probes + rank];
-        worst = fmaxf(worst, pq_exact_score<LUT, ACC_HALF, false>(a.rs, nullptr, (uint32_t)q, L, a.list_offsets[L] + r));
+        L    = a.probes[(size_t)q * a.n_probes + rank];
+        row  = a.list_offsets[L] + r;
+        have = true;
       }
     }
+    unsigned long long todo = __ballot(have);
+    while (todo != 0ull) {  // a wave per candidate (pq_exact_score_wave)
+      const int jj = (int)__ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      worst = fmaxf(worst, pq_exact_score_wave<LUT, ACC_HALF>(a.rs, (uint32_t)q, __builtin_amdgcn_readlane(L, jj), __builtin_amdgcn_readlane(row, jj), cache));
+    }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
   const bool no_bound = __ballot(short_list) != 0ull;
   const float bound  = no_bound ? INFINITY : worst;
   const uint32_t key = no_bound ? 0xffffffffu : float_to_key(bound);
@@ -2516,6 +2678,9 @@ static const void* pqw_rows(resources& res, const ivf_pq_index& idx, pq3_tables*
     return nullptr;
   }
   c.rows16w = dev_buf<uint4>::persistent((size_t)rows * idx.rot_dim / 8);
+  c.cbt     = dev_buf<float>::persistent((size_t)idx.pq_dim * 256 * idx.pq_len);
+  hipLaunchKernelGGL(cbt_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream, idx.pq_centers.data(), idx.pq_dim,
+                     idx.pq_len, idx.pq_book, c.cbt.data());
   uint32_t nch8 = 0;
   const uint8_t* codes8 = pq3_codes(res, idx, &nch8);
   pqw_decode(res, codes8, nch8, tb.cb16, idx.pq_len, idx.padded_rows, idx.rot_dim, c.rows16w.data());
@@ -2531,7 +2696,7 @@ static rescore_params pqw_score_inputs(const ivf_pq_index& idx, const pq3_run& r
   rescore_params s{};
   s.probes = r.probes; s.rot_queries = r.rot_queries; s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data();
   s.codes = codes8; s.n_chunks = nch8; s.rot_dim = idx.rot_dim; s.pq_len = idx.pq_len; s.book = idx.pq_book; s.per_cluster = 0;
-  s.is_ip = 0; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head;
+  s.is_ip = 0; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head; s.cbt = idx.scan3.cbt.data();
   return s;
 }
 
@@ -2631,24 +2796,18 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   s.query_kth = r.query_kth; s.qflag = r.qflag; s.qcnt = r.qcnt; s.cand_d = r.cand_d; s.cand_i = r.cand_i; s.cand_r = r.cand_r;
   s.head_rows = 0u; s.list_offsets = idx.list_offsets.data(); s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
-  const size_t cb_bytes = (size_t)idx.rot_dim * idx.pq_book * sizeof(float);
-  s.cb_lds = cb_bytes <= 128 * 1024 ? 1 : 0;
-  const size_t rsmem = s.cb_lds ? cb_bytes : 16;
-  const dim3 rg(grid + 1, 2), rb(kRThreads);
+  s.cb_lds = 0;
+  // a wave per survivor (pq_rescore_wave_kernel): region ri = blockIdx.x, 8 workgroups of 4 waves stride over it
+  const dim3 rg(grid + 1, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
-  auto launch_rescore = [&](auto kern) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rsmem));
-    hipLaunchKernelGGL(kern, rg, rb, rsmem, res.stream, s);
-  };
-  auto pick_rescore = [&](auto lut_tag, auto acc_tag) {
-    constexpr int LUT = decltype(lut_tag)::value;
-    constexpr bool ACC = decltype(acc_tag)::value;
-    if (s.cb_lds) launch_rescore(pq_rescore_kernel<LUT, ACC, true>); else launch_rescore(pq_rescore_kernel<LUT, ACC, false>);
-  };
-  using L0 = std::integral_constant<int, 0>; using L1 = std::integral_constant<int, 1>; using L2 = std::integral_constant<int, 2>;
-  if (r.lut_mode == 0)      pick_rescore(L0{}, std::false_type{});
-  else if (r.lut_mode == 1) { if (r.acc_half) pick_rescore(L1{}, std::true_type{}); else pick_rescore(L1{}, std::false_type{}); }
-  else                      { if (r.acc_half) pick_rescore(L2{}, std::true_type{}); else pick_rescore(L2{}, std::false_type{}); }
+  if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_wave_kernel<0, false>), rg, rb, 0, res.stream, s);
+  else if (r.lut_mode == 1) {
+    if (r.acc_half) hipLaunchKernelGGL((pq_rescore_wave_kernel<1, true>), rg, rb, 0, res.stream, s);
+    else            hipLaunchKernelGGL((pq_rescore_wave_kernel<1, false>), rg, rb, 0, res.stream, s);
+  } else {
+    if (r.acc_half) hipLaunchKernelGGL((pq_rescore_wave_kernel<2, true>), rg, rb, 0, res.stream, s);
+    else            hipLaunchKernelGGL((pq_rescore_wave_kernel<2, false>), rg, rb, 0, res.stream, s);
+  }
   profile_end(res, "pq_rescore_kernel");
   // flagged queries: ALL their candidate rows back to "nothing found yet", ALL their pairs single-pair items of the LUT scan
   hipLaunchKernelGGL(reset_flagged_kernel, dim3((unsigned)r.nq), dim3(256), 0, res.stream, r.qflag, r.nq, r.n_probes, r.k, 0u, r.cand_d,

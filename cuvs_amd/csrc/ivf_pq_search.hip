@@ -2126,6 +2126,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     if (wheads > 0 && !pqw_ready(res, idx)) wheads = 0;  // (no room for the decoded rows)
   }
   const bool usew = wheads > 0;
+  if (res.tune.scan_debug & 1024)
+    fprintf(stderr, "[pq_wide] heads %u (supported %d, matrix-core tail of the narrow shapes %d, probes %u, queries %ld, k %d)\n", wheads,
+            (int)pqw_supported(idx, k), (int)(pq3_supported(idx, k) && pq3_bound_useful(idx, k)), n_probes, (long)n_queries, k);
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
   const uint32_t w_ldx = usew ? (uint32_t)round_up((int64_t)max_list_len + 64, 64) : 0u;
@@ -2139,7 +2142,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
     // survivor entries, a fallback work item, two unit descriptors' share, norms and grouping scratch of the two-stream schedule
     if (!large_k && (pq3_supported(idx, k) || usew) && res.tune.pq_scan3 != 0)
       per_q += (int64_t)n_probes * ((int64_t)idx.rot_dim * 2 + (int64_t)k * 4 + 128 + 16 + 4 + 16 + 8);
-    if (usew) per_q += (int64_t)wheads * ((int64_t)w_ldx * 4 + 32) + (int64_t)k * 8;  // values of the head lists' rows, the k best
+    if (usew) per_q += (int64_t)wheads * ((int64_t)w_ldx * 4 + 32) + (int64_t)k * (8 + 32 * 8);  // values of the head lists' rows, the k best
     int64_t fit   = std::max<int64_t>(1, (int64_t)res.ivf_batch_limit / per_q);
     max_batch     = balanced_batch(n_queries, std::min(max_batch, fit));  // (the same on every rank of a list shard: same inputs)
   }
@@ -2189,6 +2192,9 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   uint32_t unit_rows = 0;
   const size_t max_units = usew ? pq3_max_units(idx, n_pairs_max, &unit_rows, false) : use3 ? pq3_max_units(idx, n_pairs_max, &unit_rows, res.tune.pq_filter4 != 0 && (idx.metric != M_InnerProduct || idx.pq_len != 2 || idx.codebook_kind != 0)) : 0;
   uint32_t surv_cap = use3x ? (uint32_t)std::min<int64_t>(std::max<int64_t>(n_pairs_max * 16, 1 << 22), 1 << 28) : 0u;
+  // (the wide path at large k: a query has at least k survivors by construction and a few times k with the margins of fp16 scores -
+  // 1200 per query measured at k = 256 of 1.4 k-row lists - and the head pairs' rows within the bound join them)
+  if (usew) surv_cap = (uint32_t)std::min<int64_t>(std::max<int64_t>((int64_t)surv_cap, bs_alloc * (int64_t)k * 32), 1 << 28);
   if (use3x && res.tune.pq3_surv_cap > 0) surv_cap = (uint32_t)res.tune.pq3_surv_cap;
   dev_buf<uint32_t> cand_r(res, use3x ? (size_t)n_pairs_max * k : 0), qstate(res, use3x ? (size_t)4 * bs_alloc + 8 + pq3_regions(res) : 0);
   dev_buf<uint32_t> unit_off(res, use3x ? (size_t)idx.n_lists + 1 : 0);
