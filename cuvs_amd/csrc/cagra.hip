@@ -14,6 +14,7 @@
 // lane, so 8 rows are in flight per wave) and merges with a wave-level bitonic sort. ~12 KB of LDS per query
 // lets a CU hold 13+ concurrent queries, which is what hides the dependent-gather latency of the walk.
 #include "ivf_pq.hpp"
+#include "ivf_pq_filter_common.hpp"
 #include "ops.hpp"
 #include "device_utils.hpp"
 #include "serialize.hpp"
@@ -343,6 +344,10 @@ void knn_graph_ivf_pq(resources& res, const void* data, elem_t et, int64_t n, in
   if (res.tune.cagra_pq_probes > 0) sp.n_probes = (uint32_t)res.tune.cagra_pq_probes;
   sp.lut_dtype               = 2;
   sp.internal_distance_dtype = 2;
+  // a shape of the wide matrix-core path (ivf_pq_wide.hip; 768 dimensions: pq_dim 64 x pq_len 12): scores summed in fp32 - the
+  // screen's margin for fp16 sums (6 % of the bound) lets four times the rows through to the exact re-score (measured at 2M x 768:
+  // 34 vs 19 ms per batch of 16384; the LUT scan of rounds 1-5: 60 ms)
+  if (pqw_shape(pq->rot_dim) && metric != M_InnerProduct && metric != M_CosineExpanded) sp.internal_distance_dtype = 0;
   sp.max_internal_batch_size = 16384;
   const int kp1   = (int)K + 1;
   int k_pq        = std::min(256, 2 * kp1);

@@ -1234,11 +1234,127 @@ __device__ inline float pq_exact_score_wave(const rescore_params& a, const uint3
   return ACC_HALF ? (float)ah : af;
 }
 
+// Up to 64 (query, list, row) items, one per lane (`ok`), scored one after the other by the whole wave; lane j receives item j's score.
+// The fast shape (L2, at most 64 subspaces, pq_len a multiple of 4 up to 16) runs as a software pipeline - a score is a chain of two
+// dependent memory round trips (the row's code bytes, then the codebook entries they name) followed by the 64-step sum: the entries of
+// item i + 1 and the codes of item i + 2 are asked for BEFORE item i is summed (unconditionally: past the last item the last one is
+// repeated - a conditional load would make the compiler wait for everything outstanding at the branch's end).
+// The sum over the subspaces, in subspace order, is NOT done item by item (64 x (v_readlane + add) per item was most of a score):
+// item i's 64 entries go to row i of a [64][64 + pad] tile of this wave in LDS, and when the batch is through lane j reads ITS item's
+// row and adds the entries up one after the other - one chain per lane, 64 at a time.
+template <int LUT, bool ACC_HALF>
+struct wave_score_tile {
+  static constexpr bool kHalf = !(LUT == 0 || (LUT == 2 && !ACC_HALF));  // entries are fp16 values
+  using ent_t = std::conditional_t<kHalf, uint16_t, uint32_t>;
+  static constexpr uint32_t kStride = kHalf ? 66u : 65u;  // elements per row (an odd number of 32-bit words: conflict-free column reads)
+  static constexpr size_t kBytes = 64u * kStride * sizeof(ent_t);
+};
+template <int LUT, bool ACC_HALF>
+__device__ inline float wave_score_batch(const rescore_params& a, const bool ok, const uint32_t q, const uint32_t L, const uint32_t row,
+                                         wave_score_cache& cache, void* lds_tile)
+{
+  using tile = wave_score_tile<LUT, ACC_HALF>;
+  typename tile::ent_t* ent = static_cast<typename tile::ent_t*>(lds_tile);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t pq_dim = a.n_chunks * 16u;
+  float score = 0.f;
+  unsigned long long todo = __ballot(ok);
+  if (todo == 0ull) return score;
+  const bool fast = (a.pq_len & 3u) == 0u && a.pq_len <= 16u && !a.is_ip && pq_dim <= 64u;  // wave-uniform
+  if (!fast) {
+    while (todo != 0ull) {
+      const int j = (int)__ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const float sc = pq_exact_score_wave<LUT, ACC_HALF>(a, __builtin_amdgcn_readlane(q, j), __builtin_amdgcn_readlane(L, j),
+                                                          __builtin_amdgcn_readlane(row, j), cache);
+      if ((int)lane == j) score = sc;
+    }
+    return score;
+  }
+  const uint32_t sub = min(lane, pq_dim - 1u), d0 = sub * a.pq_len;
+  int j_last = (int)__ffsll((long long)todo) - 1;
+  auto pop = [&]() {  // the next item's lane; past the end: the last one again
+    if (todo != 0ull) { j_last = (int)__ffsll((long long)todo) - 1; todo &= todo - 1ull; }
+    return j_last;
+  };
+  auto load_code = [&](const int j) {
+    const uint32_t r = __builtin_amdgcn_readlane(row, j);
+    const uint8_t* cr = a.codes + ((size_t)(r >> 6) * a.n_chunks) * 1024 + (size_t)(r & 63u) * 16;
+    return (uint32_t)cr[(size_t)(sub >> 4) * 1024 + (sub & 15u)];
+  };
+  auto load_entry = [&](float4 (&p4)[4], const uint32_t code) {
+    const float* e = a.cbt + ((size_t)sub * 256 + code) * a.pq_len;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const float4*>(e + min((uint32_t)i * 4u, a.pq_len - 4u));
+  };
+  const unsigned long long all_items = todo;
+  uint32_t n_items = (uint32_t)__popcll(todo);
+  int j0 = pop(), j1 = pop();
+  uint32_t code1 = load_code(j1);
+  float4 p_cur[4], p_nxt[4];
+  load_entry(p_cur, load_code(j0));
+  for (uint32_t it = 0; it < n_items; ++it) {
+    // the pair's residual (kept across items and calls)
+    const uint32_t qj = __builtin_amdgcn_readlane(q, j0), Lj = __builtin_amdgcn_readlane(L, j0);
+    if (cache.q != qj || cache.L != Lj) {  // wave-uniform
+      const float* rq = a.rot_queries + (size_t)qj * a.rot_dim + d0;
+      const float* ct = a.centers_rot + (size_t)Lj * a.rot_dim + d0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t o = min((uint32_t)i * 4u, a.pq_len - 4u);
+        const float4 q4 = *reinterpret_cast<const float4*>(rq + o), c4 = *reinterpret_cast<const float4*>(ct + o);
+        cache.r4[i] = make_float4(q4.x - c4.x, q4.y - c4.y, q4.z - c4.z, q4.w - c4.w);
+      }
+      cache.q = qj; cache.L = Lj;
+    }
+    load_entry(p_nxt, code1);  // item it + 1
+    const int j2 = pop();
+    const uint32_t code2 = load_code(j2);  // item it + 2
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((uint32_t)i * 4u < a.pq_len) {
+        float d;
+        d = cache.r4[i].x - p_cur[i].x; v = __fmaf_rn(d, d, v);
+        d = cache.r4[i].y - p_cur[i].y; v = __fmaf_rn(d, d, v);
+        d = cache.r4[i].z - p_cur[i].z; v = __fmaf_rn(d, d, v);
+        d = cache.r4[i].w - p_cur[i].w; v = __fmaf_rn(d, d, v);
+      }
+    }
+    if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, false);
+    uint32_t bits;
+    if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) bits = __float_as_uint(v);
+    else bits = (uint32_t)__builtin_bit_cast(uint16_t, to_lut_half(v));
+    ent[it * tile::kStride + lane] = (typename tile::ent_t)bits;  // row = the item's position in the batch
+    j0 = j1; j1 = j2; code1 = code2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p_cur[i] = p_nxt[i];
+  }
+  // lane j's item is the (number of items in lower lanes)-th of the batch
+  if (ok) {
+    const uint32_t mine = (uint32_t)__popcll(all_items & ((1ull << lane) - 1ull));
+    const typename tile::ent_t* my = ent + mine * tile::kStride;
+    float af    = 0.f;
+    _Float16 ah = (_Float16)0.f;
+    for (uint32_t s2 = 0; s2 < pq_dim; ++s2) {
+      if constexpr (!tile::kHalf) {
+        af += __uint_as_float(my[s2]);
+      } else {
+        const _Float16 e = __builtin_bit_cast(_Float16, my[s2]);
+        if constexpr (ACC_HALF) ah += e; else af += (float)e;
+      }
+    }
+    score = ACC_HALF ? (float)ah : af;
+  }
+  return score;
+}
+
 // the re-score with a wave per survivor: a wave takes 64 consecutive survivors of its region, scores them one after the other
 // (lane j keeps the score of the j-th) and appends them together (pool_append_wave)
 template <int LUT, bool ACC_HALF>
 __global__ __launch_bounds__(256) void pq_rescore_wave_kernel(const rescore_params a)
 {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // one wave_score_tile per wave
   const bool spill = blockIdx.x + 1 == gridDim.x;
   const uint32_t ri = spill ? a.n_regions : blockIdx.x;
   const uint32_t n = spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri];
@@ -1257,15 +1373,7 @@ __global__ __launch_bounds__(256) void pq_rescore_wave_kernel(const rescore_para
       ok = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
     }
     const uint32_t L = ok ? a.probes[pair] : 0u;
-    float score = 0.f;
-    unsigned long long todo = __ballot(ok);
-    while (todo != 0ull) {
-      const int j = (int)__ffsll((long long)todo) - 1;
-      todo &= todo - 1ull;
-      const float sc = pq_exact_score_wave<LUT, ACC_HALF>(a, __builtin_amdgcn_readlane(q, j), __builtin_amdgcn_readlane(L, j),
-                                                          __builtin_amdgcn_readlane(row, j), cache);
-      if ((int)lane == j) score = sc;
-    }
+    const float score = wave_score_batch<LUT, ACC_HALF>(a, ok, q, L, row, cache, smem + (threadIdx.x >> 6) * wave_score_tile<LUT, ACC_HALF>::kBytes);
     pool_append_wave(a, ok, q, pair, row, score);
   }
 }
@@ -1292,6 +1400,7 @@ struct wbound_params {
 template <int LUT, bool ACC_HALF>
 __global__ __launch_bounds__(256) void pqw_head_bound_kernel(const wbound_params a)
 {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // one wave_score_tile per wave
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63u;
   if (q >= a.nq) return;  // wave-uniform
@@ -1312,12 +1421,12 @@ __global__ __launch_bounds__(256) void pqw_head_bound_kernel(const wbound_params
         have = true;
       }
     }
-    unsigned long long todo = __ballot(have);
-    while (todo != 0ull) {  // a wave per candidate (pq_exact_score_wave)
-      const int jj = (int)__ffsll((long long)todo) - 1;
-      todo &= todo - 1ull;
-      worst = fmaxf(worst, pq_exact_score_wave<LUT, ACC_HALF>(a.rs, (uint32_t)q, __builtin_amdgcn_readlane(L, jj), __builtin_amdgcn_readlane(row, jj), cache));
-    }
+    // a wave per candidate (wave_score_batch); lane j holds candidate j's score
+    float sc = wave_score_batch<LUT, ACC_HALF>(a.rs, have, (uint32_t)q, L, row, cache, smem + (threadIdx.x >> 6) * wave_score_tile<LUT, ACC_HALF>::kBytes);
+    sc = have ? sc : -INFINITY;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sc = fmaxf(sc, __shfl_xor(sc, o));
+    worst = fmaxf(worst, sc);
   }
   const bool no_bound = __ballot(short_list) != 0ull;
   const float bound  = no_bound ? INFINITY : worst;
@@ -2741,14 +2850,18 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
   b.rot_dim = idx.rot_dim; b.query_kth = const_cast<uint32_t*>(r.query_kth); b.qflag = r.qflag; b.thr_head = hb.thr_head;
   b.sc = tb.sc; b.c1 = c1; b.eps = eps; b.alpha = alpha; b.cbmax = tb.cbmax; b.bound_max = bound_max;
   const dim3 bgrid((unsigned)grid_blocks(r.nq, 4));
-  if (r.lut_mode == 0)      hipLaunchKernelGGL((pqw_head_bound_kernel<0, false>), bgrid, dim3(256), 0, res.stream, b);
-  else if (r.lut_mode == 1) {
-    if (r.acc_half) hipLaunchKernelGGL((pqw_head_bound_kernel<1, true>), bgrid, dim3(256), 0, res.stream, b);
-    else            hipLaunchKernelGGL((pqw_head_bound_kernel<1, false>), bgrid, dim3(256), 0, res.stream, b);
-  } else {
-    if (r.acc_half) hipLaunchKernelGGL((pqw_head_bound_kernel<2, true>), bgrid, dim3(256), 0, res.stream, b);
-    else            hipLaunchKernelGGL((pqw_head_bound_kernel<2, false>), bgrid, dim3(256), 0, res.stream, b);
-  }
+  auto bound = [&](auto lut_tag, auto acc_tag) {
+    constexpr int LUT = decltype(lut_tag)::value;
+    constexpr bool ACC = decltype(acc_tag)::value;
+    const size_t sm = 4 * wave_score_tile<LUT, ACC>::kBytes;
+    auto kern = pqw_head_bound_kernel<LUT, ACC>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(kern, bgrid, dim3(256), sm, res.stream, b);
+  };
+  using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>; using B2 = std::integral_constant<int, 2>;
+  if (r.lut_mode == 0)      bound(B0{}, std::false_type{});
+  else if (r.lut_mode == 1) { if (r.acc_half) bound(B1{}, std::true_type{}); else bound(B1{}, std::false_type{}); }
+  else                      { if (r.acc_half) bound(B2{}, std::true_type{}); else bound(B2{}, std::false_type{}); }
   profile_end(res, "pq_head_kernel");
   profile_end(res, "pq_scan_kernel");
   HIP_TRY(hipGetLastError());
@@ -2800,14 +2913,18 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   // a wave per survivor (pq_rescore_wave_kernel): region ri = blockIdx.x, 8 workgroups of 4 waves stride over it
   const dim3 rg(grid + 1, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
-  if (r.lut_mode == 0)      hipLaunchKernelGGL((pq_rescore_wave_kernel<0, false>), rg, rb, 0, res.stream, s);
-  else if (r.lut_mode == 1) {
-    if (r.acc_half) hipLaunchKernelGGL((pq_rescore_wave_kernel<1, true>), rg, rb, 0, res.stream, s);
-    else            hipLaunchKernelGGL((pq_rescore_wave_kernel<1, false>), rg, rb, 0, res.stream, s);
-  } else {
-    if (r.acc_half) hipLaunchKernelGGL((pq_rescore_wave_kernel<2, true>), rg, rb, 0, res.stream, s);
-    else            hipLaunchKernelGGL((pq_rescore_wave_kernel<2, false>), rg, rb, 0, res.stream, s);
-  }
+  auto rescore = [&](auto lut_tag, auto acc_tag) {
+    constexpr int LUT = decltype(lut_tag)::value;
+    constexpr bool ACC = decltype(acc_tag)::value;
+    const size_t sm = 4 * wave_score_tile<LUT, ACC>::kBytes;
+    auto kern = pq_rescore_wave_kernel<LUT, ACC>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+    hipLaunchKernelGGL(kern, rg, rb, sm, res.stream, s);
+  };
+  using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>;
+  if (r.lut_mode == 0)      rescore(R0{}, std::false_type{});
+  else if (r.lut_mode == 1) { if (r.acc_half) rescore(R1{}, std::true_type{}); else rescore(R1{}, std::false_type{}); }
+  else                      { if (r.acc_half) rescore(R2{}, std::true_type{}); else rescore(R2{}, std::false_type{}); }
   profile_end(res, "pq_rescore_kernel");
   // flagged queries: ALL their candidate rows back to "nothing found yet", ALL their pairs single-pair items of the LUT scan
   hipLaunchKernelGGL(reset_flagged_kernel, dim3((unsigned)r.nq), dim3(256), 0, res.stream, r.qflag, r.nq, r.n_probes, r.k, 0u, r.cand_d,
