@@ -1138,10 +1138,10 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
 // the nearest list), and two thirds of a score's bytes were the query's and the centre's components read again
 struct wave_score_cache {
   uint32_t q = 0xffffffffu, L = 0xffffffffu;
-  float4 r4[4];
+  float r[16];
 };
 template <int LUT, bool ACC_HALF>
-__device__ inline float pq_exact_score_wave(const rescore_params& a, const uint32_t q, const uint32_t L, const uint32_t row, wave_score_cache& cache)
+__device__ inline float pq_exact_score_wave(const rescore_params& a, const uint32_t q, const uint32_t L, const uint32_t row)
 {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t pq_dim = a.n_chunks * 16u;
@@ -1169,30 +1169,7 @@ __device__ inline float pq_exact_score_wave(const rescore_params& a, const uint3
         v = __fmaf_rn(-qv, p, v);
       }
     };
-    if ((a.pq_len & 3u) == 0u && a.pq_len <= 16u && !a.is_ip && pq_dim <= 64u) {  // wave-uniform: L2 with the residual kept
-      float4 p4[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const float4*>(e + min((uint32_t)i * 4u, a.pq_len - 4u));
-      if (cache.q != q || cache.L != L) {  // wave-uniform
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t o = min((uint32_t)i * 4u, a.pq_len - 4u);  // (past the entry: a repeat of its last piece, not used)
-          const float4 q4 = *reinterpret_cast<const float4*>(rq + d0 + o), c4 = *reinterpret_cast<const float4*>(ct + d0 + o);
-          cache.r4[i] = make_float4(q4.x - c4.x, q4.y - c4.y, q4.z - c4.z, q4.w - c4.w);
-        }
-        cache.q = q; cache.L = L;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if ((uint32_t)i * 4u < a.pq_len) {
-          float d;
-          d = cache.r4[i].x - p4[i].x; v = __fmaf_rn(d, d, v);
-          d = cache.r4[i].y - p4[i].y; v = __fmaf_rn(d, d, v);
-          d = cache.r4[i].z - p4[i].z; v = __fmaf_rn(d, d, v);
-          d = cache.r4[i].w - p4[i].w; v = __fmaf_rn(d, d, v);
-        }
-      }
-    } else if ((a.pq_len & 3u) == 0u && a.pq_len <= 16u) {  // wave-uniform
+    if ((a.pq_len & 3u) == 0u && a.pq_len <= 16u) {  // wave-uniform
       float4 p4[4], q4[4], c4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -1235,116 +1212,162 @@ __device__ inline float pq_exact_score_wave(const rescore_params& a, const uint3
 }
 
 // Up to 64 (query, list, row) items, one per lane (`ok`), scored one after the other by the whole wave; lane j receives item j's score.
-// The fast shape (L2, at most 64 subspaces, pq_len a multiple of 4 up to 16) runs as a software pipeline - a score is a chain of two
-// dependent memory round trips (the row's code bytes, then the codebook entries they name) followed by the 64-step sum: the entries of
-// item i + 1 and the codes of item i + 2 are asked for BEFORE item i is summed (unconditionally: past the last item the last one is
-// repeated - a conditional load would make the compiler wait for everything outstanding at the branch's end).
+// L2 with pq_len 2 / 4 / 8 / 12 / 16 runs as a software pipeline over STEPS = (item, block of 64 subspaces): a step is a chain of two
+// dependent memory round trips (the row's code bytes, then the codebook entries they name - and, beyond 64 subspaces, the block's
+// residual components): the entries of step t + 1 and the codes of step t + 2 are asked for BEFORE step t's entries are formed
+// (unconditionally: past the last step the last one is repeated - a conditional load would make the compiler wait for everything
+// outstanding at the branch's end).
 // The sum over the subspaces, in subspace order, is NOT done item by item (64 x (v_readlane + add) per item was most of a score):
-// item i's 64 entries go to row i of a [64][64 + pad] tile of this wave in LDS, and when the batch is through lane j reads ITS item's
-// row and adds the entries up one after the other - one chain per lane, 64 at a time.
+// item i's entries go to row i of a tile of this wave in LDS (rows of pq_dim entries + padding; as many items per pass as the tile
+// holds), and when a pass is through every lane that owns one of its items reads that row and adds the entries up one after the
+// other - one chain per lane.
 template <int LUT, bool ACC_HALF>
 struct wave_score_tile {
   static constexpr bool kHalf = !(LUT == 0 || (LUT == 2 && !ACC_HALF));  // entries are fp16 values
   using ent_t = std::conditional_t<kHalf, uint16_t, uint32_t>;
-  static constexpr uint32_t kStride = kHalf ? 66u : 65u;  // elements per row (an odd number of 32-bit words: conflict-free column reads)
-  static constexpr size_t kBytes = 64u * kStride * sizeof(ent_t);
+  static constexpr uint32_t kWords = 64u * 33u * (kHalf ? 1u : 2u) + 64u;  // 32-bit words of a wave's tile (64 rows of 64 entries + padding)
+  static constexpr size_t kBytes = (size_t)kWords * 4u;
 };
-template <int LUT, bool ACC_HALF>
-__device__ inline float wave_score_batch(const rescore_params& a, const bool ok, const uint32_t q, const uint32_t L, const uint32_t row,
-                                         wave_score_cache& cache, void* lds_tile)
+
+template <int LUT, bool ACC_HALF, int PL>
+__device__ inline float wave_score_batch_pl(const rescore_params& a, const bool ok, const uint32_t q, const uint32_t L, const uint32_t row,
+                                            wave_score_cache& cache, void* lds_tile)
 {
   using tile = wave_score_tile<LUT, ACC_HALF>;
   typename tile::ent_t* ent = static_cast<typename tile::ent_t*>(lds_tile);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t pq_dim = a.n_chunks * 16u;
+  const uint32_t pq_dim = a.n_chunks * 16u, nb = (pq_dim + 63u) >> 6;  // nb: blocks of 64 subspaces
+  // a row: pq_dim entries, an odd number of 32-bit words (conflict-free when the lanes read their rows side by side)
+  const uint32_t row_words = ((tile::kHalf ? (pq_dim + 1u) / 2u : pq_dim) | 1u), stride = tile::kHalf ? 2u * row_words : row_words;
+  const uint32_t per_pass = min(64u, tile::kWords / row_words);  // items per pass (>= 1: pq_dim up to 4096)
+  float score = 0.f;
+  const unsigned long long all_items = __ballot(ok);
+  if (all_items == 0ull) return score;
+  const uint32_t n_items = (uint32_t)__popcll(all_items);
+  const uint32_t mine = (uint32_t)__popcll(all_items & ((1ull << lane) - 1ull));  // this lane's item is the mine-th
+  constexpr int NV = PL >= 4 ? PL / 4 : 1;                                         // 16-byte (pq_len 2: 8-byte) pieces of an entry
+  struct piece { float x[PL]; };
+  auto load_pl = [&](const float* p) {
+    piece o;
+    if constexpr (PL == 2) {
+      const float2 v = *reinterpret_cast<const float2*>(p);
+      o.x[0] = v.x; o.x[1] = v.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
+        o.x[4 * i] = v.x; o.x[4 * i + 1] = v.y; o.x[4 * i + 2] = v.z; o.x[4 * i + 3] = v.w;
+      }
+    }
+    return o;
+  };
+  for (uint32_t base = 0; base < n_items; base += per_pass) {  // a pass: the items [base, base + per_pass) of the batch
+    const uint32_t n_pass = min(per_pass, n_items - base);
+    // the lanes of this pass's items, in order
+    unsigned long long todo = all_items;
+    for (uint32_t i = 0; i < base; ++i) todo &= todo - 1ull;
+    int j_cur = (int)__ffsll((long long)todo) - 1;
+    uint32_t left = n_pass;
+    // step cursor: (item lane, block); past the end: the last step again
+    struct cursor { int j; uint32_t blk; };
+    cursor nxt{j_cur, 0u};
+    auto advance = [&]() {
+      const cursor c = nxt;
+      if (nxt.blk + 1u < nb) { nxt.blk += 1u; }
+      else if (left > 1u) { left -= 1u; todo &= todo - 1ull; nxt.j = (int)__ffsll((long long)todo) - 1; nxt.blk = 0u; }
+      return c;
+    };
+    auto sub_of = [&](const cursor c) { return min(c.blk * 64u + lane, pq_dim - 1u); };
+    auto load_code = [&](const cursor c) {
+      const uint32_t r = __builtin_amdgcn_readlane(row, c.j), sub = sub_of(c);
+      const uint8_t* cr = a.codes + ((size_t)(r >> 6) * a.n_chunks) * 1024 + (size_t)(r & 63u) * 16;
+      return (uint32_t)cr[(size_t)(sub >> 4) * 1024 + (sub & 15u)];
+    };
+    auto load_entry = [&](const cursor c, const uint32_t code) { return load_pl(a.cbt + ((size_t)sub_of(c) * 256 + code) * PL); };
+    auto load_res = [&](const cursor c) {  // the block's residual components (beyond 64 subspaces: every step)
+      const uint32_t qj = __builtin_amdgcn_readlane(q, c.j), Lj = __builtin_amdgcn_readlane(L, c.j), d0 = sub_of(c) * PL;
+      const piece qv = load_pl(a.rot_queries + (size_t)qj * a.rot_dim + d0), cv = load_pl(a.centers_rot + (size_t)Lj * a.rot_dim + d0);
+      piece o;
+#pragma unroll
+      for (int l = 0; l < PL; ++l) o.x[l] = qv.x[l] - cv.x[l];
+      return o;
+    };
+    const uint32_t n_steps = n_pass * nb;
+    cursor c0 = advance(), c1 = advance();
+    uint32_t code1 = load_code(c1);
+    piece p_cur = load_entry(c0, load_code(c0)), r_cur{}, p_nxt, r_nxt{};
+    if (nb > 1u) r_cur = load_res(c0);
+    uint32_t it = 0;  // position of c0's item in the pass
+    for (uint32_t t = 0; t < n_steps; ++t) {
+      if (nb == 1u) {  // wave-uniform: the pair's residual, kept across items and calls
+        const uint32_t qj = __builtin_amdgcn_readlane(q, c0.j), Lj = __builtin_amdgcn_readlane(L, c0.j);
+        if (cache.q != qj || cache.L != Lj) {
+          const piece rr = load_res(c0);
+#pragma unroll
+          for (int l = 0; l < PL; ++l) cache.r[l] = rr.x[l];
+          cache.q = qj; cache.L = Lj;
+        }
+      }
+      p_nxt = load_entry(c1, code1);  // step t + 1
+      if (nb > 1u) r_nxt = load_res(c1);
+      const cursor c2 = advance();
+      const uint32_t code2 = load_code(c2);  // step t + 2
+      float v = 0.f;
+#pragma unroll
+      for (int l = 0; l < PL; ++l) {
+        const float d = (nb == 1u ? cache.r[l] : r_cur.x[l]) - p_cur.x[l];
+        v = __fmaf_rn(d, d, v);
+      }
+      if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, false);
+      uint32_t bits;
+      if constexpr (!tile::kHalf) bits = __float_as_uint(v);
+      else bits = (uint32_t)__builtin_bit_cast(uint16_t, to_lut_half(v));
+      if (c0.blk * 64u + lane < pq_dim) ent[it * stride + c0.blk * 64u + lane] = (typename tile::ent_t)bits;  // row = the item's position in the pass
+      if (c0.blk + 1u == nb) it += 1u;
+      c0 = c1; c1 = c2; code1 = code2; p_cur = p_nxt;
+      if (nb > 1u) r_cur = r_nxt;
+    }
+    if (ok && mine >= base && mine < base + n_pass) {
+      const typename tile::ent_t* my = ent + (mine - base) * stride;
+      float af    = 0.f;
+      _Float16 ah = (_Float16)0.f;
+      for (uint32_t s2 = 0; s2 < pq_dim; ++s2) {
+        if constexpr (!tile::kHalf) {
+          af += __uint_as_float(my[s2]);
+        } else {
+          const _Float16 e = __builtin_bit_cast(_Float16, my[s2]);
+          if constexpr (ACC_HALF) ah += e; else af += (float)e;
+        }
+      }
+      score = ACC_HALF ? (float)ah : af;
+    }
+  }
+  return score;
+}
+
+template <int LUT, bool ACC_HALF>
+__device__ inline float wave_score_batch(const rescore_params& a, const bool ok, const uint32_t q, const uint32_t L, const uint32_t row,
+                                         wave_score_cache& cache, void* lds_tile)
+{
+  if (!a.is_ip && !a.per_cluster) {  // wave-uniform
+    switch (a.pq_len) {
+      case 2:  return wave_score_batch_pl<LUT, ACC_HALF, 2>(a, ok, q, L, row, cache, lds_tile);
+      case 4:  return wave_score_batch_pl<LUT, ACC_HALF, 4>(a, ok, q, L, row, cache, lds_tile);
+      case 8:  return wave_score_batch_pl<LUT, ACC_HALF, 8>(a, ok, q, L, row, cache, lds_tile);
+      case 12: return wave_score_batch_pl<LUT, ACC_HALF, 12>(a, ok, q, L, row, cache, lds_tile);
+      case 16: return wave_score_batch_pl<LUT, ACC_HALF, 16>(a, ok, q, L, row, cache, lds_tile);
+      default: break;
+    }
+  }
+  const uint32_t lane = threadIdx.x & 63u;
   float score = 0.f;
   unsigned long long todo = __ballot(ok);
-  if (todo == 0ull) return score;
-  const bool fast = (a.pq_len & 3u) == 0u && a.pq_len <= 16u && !a.is_ip && pq_dim <= 64u;  // wave-uniform
-  if (!fast) {
-    while (todo != 0ull) {
-      const int j = (int)__ffsll((long long)todo) - 1;
-      todo &= todo - 1ull;
-      const float sc = pq_exact_score_wave<LUT, ACC_HALF>(a, __builtin_amdgcn_readlane(q, j), __builtin_amdgcn_readlane(L, j),
-                                                          __builtin_amdgcn_readlane(row, j), cache);
-      if ((int)lane == j) score = sc;
-    }
-    return score;
-  }
-  const uint32_t sub = min(lane, pq_dim - 1u), d0 = sub * a.pq_len;
-  int j_last = (int)__ffsll((long long)todo) - 1;
-  auto pop = [&]() {  // the next item's lane; past the end: the last one again
-    if (todo != 0ull) { j_last = (int)__ffsll((long long)todo) - 1; todo &= todo - 1ull; }
-    return j_last;
-  };
-  auto load_code = [&](const int j) {
-    const uint32_t r = __builtin_amdgcn_readlane(row, j);
-    const uint8_t* cr = a.codes + ((size_t)(r >> 6) * a.n_chunks) * 1024 + (size_t)(r & 63u) * 16;
-    return (uint32_t)cr[(size_t)(sub >> 4) * 1024 + (sub & 15u)];
-  };
-  auto load_entry = [&](float4 (&p4)[4], const uint32_t code) {
-    const float* e = a.cbt + ((size_t)sub * 256 + code) * a.pq_len;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p4[i] = *reinterpret_cast<const float4*>(e + min((uint32_t)i * 4u, a.pq_len - 4u));
-  };
-  const unsigned long long all_items = todo;
-  uint32_t n_items = (uint32_t)__popcll(todo);
-  int j0 = pop(), j1 = pop();
-  uint32_t code1 = load_code(j1);
-  float4 p_cur[4], p_nxt[4];
-  load_entry(p_cur, load_code(j0));
-  for (uint32_t it = 0; it < n_items; ++it) {
-    // the pair's residual (kept across items and calls)
-    const uint32_t qj = __builtin_amdgcn_readlane(q, j0), Lj = __builtin_amdgcn_readlane(L, j0);
-    if (cache.q != qj || cache.L != Lj) {  // wave-uniform
-      const float* rq = a.rot_queries + (size_t)qj * a.rot_dim + d0;
-      const float* ct = a.centers_rot + (size_t)Lj * a.rot_dim + d0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t o = min((uint32_t)i * 4u, a.pq_len - 4u);
-        const float4 q4 = *reinterpret_cast<const float4*>(rq + o), c4 = *reinterpret_cast<const float4*>(ct + o);
-        cache.r4[i] = make_float4(q4.x - c4.x, q4.y - c4.y, q4.z - c4.z, q4.w - c4.w);
-      }
-      cache.q = qj; cache.L = Lj;
-    }
-    load_entry(p_nxt, code1);  // item it + 1
-    const int j2 = pop();
-    const uint32_t code2 = load_code(j2);  // item it + 2
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if ((uint32_t)i * 4u < a.pq_len) {
-        float d;
-        d = cache.r4[i].x - p_cur[i].x; v = __fmaf_rn(d, d, v);
-        d = cache.r4[i].y - p_cur[i].y; v = __fmaf_rn(d, d, v);
-        d = cache.r4[i].z - p_cur[i].z; v = __fmaf_rn(d, d, v);
-        d = cache.r4[i].w - p_cur[i].w; v = __fmaf_rn(d, d, v);
-      }
-    }
-    if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, false);
-    uint32_t bits;
-    if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) bits = __float_as_uint(v);
-    else bits = (uint32_t)__builtin_bit_cast(uint16_t, to_lut_half(v));
-    ent[it * tile::kStride + lane] = (typename tile::ent_t)bits;  // row = the item's position in the batch
-    j0 = j1; j1 = j2; code1 = code2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) p_cur[i] = p_nxt[i];
-  }
-  // lane j's item is the (number of items in lower lanes)-th of the batch
-  if (ok) {
-    const uint32_t mine = (uint32_t)__popcll(all_items & ((1ull << lane) - 1ull));
-    const typename tile::ent_t* my = ent + mine * tile::kStride;
-    float af    = 0.f;
-    _Float16 ah = (_Float16)0.f;
-    for (uint32_t s2 = 0; s2 < pq_dim; ++s2) {
-      if constexpr (!tile::kHalf) {
-        af += __uint_as_float(my[s2]);
-      } else {
-        const _Float16 e = __builtin_bit_cast(_Float16, my[s2]);
-        if constexpr (ACC_HALF) ah += e; else af += (float)e;
-      }
-    }
-    score = ACC_HALF ? (float)ah : af;
+  while (todo != 0ull) {
+    const int j = (int)__ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const float sc = pq_exact_score_wave<LUT, ACC_HALF>(a, __builtin_amdgcn_readlane(q, j), __builtin_amdgcn_readlane(L, j),
+                                                        __builtin_amdgcn_readlane(row, j));
+    if ((int)lane == j) score = sc;
   }
   return score;
 }
