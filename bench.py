@@ -731,6 +731,64 @@ def extra_c2(res, dev):
                                  "logical_scan_gbs = list bytes per pair and kernel second (SURVEY 8d)"}}
 
 
+def extra_pq768(res, dev, rows=1_000_000):
+    """IVF-PQ at the reference's DEFAULT shape for 768-d rows (ivf_pq.hpp index_params: pq_dim = 0 -> dim / 2 = 384 at pq_len 2, 8-bit codes;
+    n_lists 1024), 32 probes, batch 10k, k = 10 - the shape the matrix-core tail phase of rounds 3-5 did not cover (rot_dim beyond its
+    decode table; the LUT itself beyond the LDS). Round 6: the wide path (ivf_pq_wide.hip) - the index's decoded fp16 rows through a GEMM
+    filter, bound-only head phase - against the LUT scan kernels (CUVS_AMD_PQ_WIDE=0) on the same index: equality of ids and distances,
+    ms, recall, the filter's counters and its kernel time against the fp16 MFMA peak and against HBM on the decoded rows it must read."""
+    from cuvs_amd._lib import lib
+    from cuvs_amd.neighbors import ivf_pq
+
+    nq, k, n_probes, n_lists = 10000, 10, 32, 1024
+    x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
+    gen_rows(rows, 768, 1234, dev, latent=32, n_modes=4096, out=x, spread=0.7)
+    q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
+    gen_rows(nq, 768, 4321, dev, latent=32, n_modes=4096, out=q, spread=0.7)
+    t0 = time.time()
+    idx = ivf_pq.build(ivf_pq.IndexParams(n_lists=n_lists, kmeans_n_iters=10, kmeans_trainset_fraction=0.5), x, resources=res)
+    res.sync()
+    build_s = time.time() - t0
+    sp = ivf_pq.SearchParams(n_probes=n_probes, lut_dtype=np.float16, internal_distance_dtype=np.float32, max_internal_batch_size=nq)
+    nb = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    step = lambda r=res: ivf_pq.search(sp, idx, q, k, neighbors=nb, distances=dd, resources=r)
+    _, filt_ms, launches = profiled(b"pq_filter_kernel", step, 5, 2)
+    for nm in (b"pq_scan_kernel", b"pq_head_kernel", b"pq_rescore_kernel", b"pq_bprep_kernel"):
+        lib().cuvsAmdProfileCollect(nm, None)
+    dt = timeit(step, 10, 2)
+    keep_i, keep_d = nb.clone(), dd.clone()
+    gt = exact_topk_fp64(x, q[:1000], k).cpu().numpy()
+    rec = recall_of(keep_i[:1000].cpu().numpy(), gt)
+    res_l = comparator_handle(CUVS_AMD_PQ_WIDE=0)
+    dt_l = timeit(lambda: step(res_l), 3, 1)
+    same = bool(torch.equal(keep_i, nb) and torch.equal(keep_d, dd))
+    res_st = comparator_handle(CUVS_AMD_SCAN_DEBUG=1024)
+    old_err = os.dup(2); devnull = os.open(os.devnull, os.O_WRONLY); os.dup2(devnull, 2)
+    try:
+        step(res_st); res_st.sync()
+    finally:
+        os.dup2(old_err, 2); os.close(devnull); os.close(old_err)
+    st = (C.c_uint64 * 6)()
+    lib().cuvsAmdIvfPqLastFilterStats6(st)
+    pairs = int(st[0])
+    # the filter launch (tail pairs) + the emit launch (head pairs) are both named pq_filter_kernel; algorithmic work of the tail launch:
+    # one fp16 multiply-add per (row, query) pair and rotated dimension; bytes: every probed list's decoded rows once per batch
+    flops = 2.0 * pairs * 768
+    tf = flops / (filt_ms * 1e-3) / 1e12 if filt_ms > 0 else None
+    return {"config": f"IVF-PQ {rows}x768 fp16 rows, the reference's default pq_dim (384 x pq_len 2, 8 bit), n_lists={n_lists} n_probes={n_probes} "
+                      f"batch={nq} k={k} lut=f16 acc=f32 (data: bench.gen_rows, 4096 overlapping modes in a 32-d latent space)",
+            "path": "wide matrix-core path (ivf_pq_wide.hip): decoded fp16 rows, bound-only head phase, GEMM filter, wave-per-survivor re-score",
+            "ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(rec, 4), "build_seconds": round(build_s, 1),
+            "ms_lut_scan_kernels": round(dt_l * 1e3, 3), "speedup_over_lut_scan": round(dt_l / dt, 2), "equals_lut_scan": same,
+            "filter_kernels_ms": round(filt_ms, 3), "filter_launches_per_search": launches,
+            "pairs_screened": pairs, "survivors": int(st[1]), "pairs_handed_back": int(st[4]),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1) if tf else None, "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": round(tf / 2500.0, 4) if tf else None,
+                         "note": "2 x 768 flops per screened (row, query) pair of the tail launch over the time of BOTH launches "
+                                 "(tail + the head pairs' emit pass); fp16 dense MFMA peak 2.5 PF"}}
+
+
 def extra_c4_family(res, dev, rows=2_000_000, latent=24):
     """CAGRA (degree 64, intermediate 128) on the two ends of the generator family, 2M x 768 fp16 each: ONE cloud (what rounds 2-5 quoted
     C4 on) and 4096 TIGHT modes (spread 0.35: the kNN graph falls apart into components, a walk from random seeds stays in the modes
@@ -1329,7 +1387,7 @@ def main():
             # the 24-d latent space - a multi-modal corpus on which recall means something; the single cloud of rounds 2-5 (the
             # easiest corpus for a graph walk) and the 4096 TIGHT modes on which no walk from random seeds leaves its mode are the
             # two side lines (2M rows each, profiles/r06_c4_corpus_sweep.log has the whole family)
-            for name, fn in (("C1", lambda: extra_c1(res, dev)), ("C2", lambda: extra_c2(res, dev)),
+            for name, fn in (("C1", lambda: extra_c1(res, dev)), ("C2", lambda: extra_c2(res, dev)), ("PQ-768", lambda: extra_pq768(res, dev)),
                              ("C4", lambda: extra_c4(res, dev, args.c4_rows, args.c4_latent, modes=args.c4_modes, spread=args.c4_spread)),
                              ("C4-corpus-family", lambda: extra_c4_family(res, dev))):
                 t0 = time.time()

@@ -1377,15 +1377,37 @@ __device__ inline float wave_score_batch(const rescore_params& a, const bool ok,
 template <int LUT, bool ACC_HALF>
 __global__ __launch_bounds__(256) void pq_rescore_wave_kernel(const rescore_params a)
 {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // one wave_score_tile per wave
-  const bool spill = blockIdx.x + 1 == gridDim.x;
-  const uint32_t ri = spill ? a.n_regions : blockIdx.x;
-  const uint32_t n = spill ? min(a.surv_cnt[ri], a.spill_cap) : a.surv_cnt[ri];
-  const uint2* region = a.surv + (size_t)ri * a.surv_cap;
-  const uint32_t lane = threadIdx.x & 63u, wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.y * (blockDim.x >> 6);
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // one wave_score_tile per wave, then the regions' batch offsets
+  // The regions' fills differ (a filter workgroup whose lists are dense leaves several times the survivors of another; a wave works
+  // through its 64 survivors one after the other): the batches of 64 of ALL regions are numbered through and dealt to the waves of the
+  // whole grid round-robin (a region's own 32 waves: 2.9 ms for 1 M survivors at 1M x 768, the longest region's time)
+  uint32_t* s_off = reinterpret_cast<uint32_t*>(smem + 4 * wave_score_tile<LUT, ACC_HALF>::kBytes);  // [n_regions + 2] first batch of every region
+  const uint32_t n_reg = a.n_regions + 1u;  // + the shared spill region
+  if (threadIdx.x == 0) {
+    uint32_t run = 0u;
+    for (uint32_t r = 0; r < n_reg; ++r) {
+      s_off[r] = run;
+      const uint32_t n = r == a.n_regions ? min(a.surv_cnt[r], a.spill_cap) : min(a.surv_cnt[r], a.surv_cap);
+      run += (n + 63u) >> 6;
+    }
+    s_off[n_reg] = run;
+  }
+  __syncthreads();
+  const uint32_t total = s_off[n_reg];
+  const uint32_t n_waves = gridDim.x * gridDim.y * (blockDim.x >> 6);
+  const uint32_t wave0 = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
   wave_score_cache cache;
-  for (uint32_t sb = wave * 64u; sb < n; sb += n_waves * 64u) {  // wave-uniform
-    const uint32_t s = sb + lane;
+  for (uint32_t b = wave0; b < total; b += n_waves) {  // wave-uniform
+    uint32_t lo = 0u, hi = n_reg;  // s_off[lo] <= b < s_off[hi]
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_off[mid] <= b) lo = mid; else hi = mid;
+    }
+    const uint32_t ri = lo;
+    const uint32_t n = ri == a.n_regions ? min(a.surv_cnt[ri], a.spill_cap) : min(a.surv_cnt[ri], a.surv_cap);
+    const uint2* region = a.surv + (size_t)ri * a.surv_cap;
+    const uint32_t s = (b - s_off[ri]) * 64u + lane;
     uint2 sv = make_uint2(0xffffffffu, 0u);
     if (s < n) sv = region[s];
     bool ok = sv.x != 0xffffffffu;
@@ -2933,13 +2955,13 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   s.head_rows = 0u; s.list_offsets = idx.list_offsets.data(); s.filter_bits = r.filter_bits; s.indices = idx.indices.data();
   s.overflow = static_cast<uint4*>(r.overflow); s.overflow_cnt = r.counters + 1; s.overflow_cap = r.overflow_cap; s.fail = nullptr;
   s.cb_lds = 0;
-  // a wave per survivor (pq_rescore_wave_kernel): region ri = blockIdx.x, 8 workgroups of 4 waves stride over it
-  const dim3 rg(grid + 1, 8), rb(256);
+  // a wave per survivor (pq_rescore_wave_kernel): the batches of all regions dealt to 8 workgroups of 4 waves per CU
+  const dim3 rg(grid, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
   auto rescore = [&](auto lut_tag, auto acc_tag) {
     constexpr int LUT = decltype(lut_tag)::value;
     constexpr bool ACC = decltype(acc_tag)::value;
-    const size_t sm = 4 * wave_score_tile<LUT, ACC>::kBytes;
+    const size_t sm = 4 * wave_score_tile<LUT, ACC>::kBytes + ((size_t)grid + 3) * sizeof(uint32_t);
     auto kern = pq_rescore_wave_kernel<LUT, ACC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
     hipLaunchKernelGGL(kern, rg, rb, sm, res.stream, s);

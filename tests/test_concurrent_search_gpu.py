@@ -112,6 +112,27 @@ def test_ivf_pq_extended_index_shared_by_threads():
     assert (alone[1] >= 60_000).any(), "the extension's rows are found"
 
 
+def test_ivf_pq_wide_index_shared_by_threads():
+    """768 dimensions, pq_dim 64 x pq_len 12: the wide matrix-core path (ivf_pq_wide.hip) - the first searches race the build of the
+    index's DECODED fp16 rows and its entry-major codebook (scan3_cache::rows16w / cbt: made under the cache's lock, published after
+    the fill kernels have run)"""
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _clustered(60_000, 768, 600, seed=21)
+    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=32, pq_dim=64, kmeans_n_iters=8), torch.from_numpy(x).cuda())
+    qd = torch.from_numpy(q).cuda()
+    sp = ivf_pq.SearchParams(n_probes=12, lut_dtype=np.float16, internal_distance_dtype=np.float32, max_internal_batch_size=600)
+
+    def search_one(res):
+        d, i = ivf_pq.search(sp, index, qd, 10, resources=res)
+        res.sync()
+        torch.cuda.synchronize()
+        return d.cpu().numpy(), i.cpu().numpy()
+
+    _check(*_race(search_one))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.int8])
 def test_ivf_flat_index_shared_by_threads(dtype):
     import torch
