@@ -107,7 +107,8 @@ struct wide_prep {  // pre-pass: fp16 B operands of the head (labels [0, n_lists
   const float* centers_rot;
   const uint32_t* query_kth;
   uint32_t* qflag;
-  void* bq;
+  void* bq;      // [(n_pairs / 32 + n_lists) blocks of 32 pairs][rot_dim / 16][64 lanes] x 16 bytes
+  uint32_t* blk_off;  // out: [n_lists + 1] first block of every list
   float* thr;    // tail: thresholds in accumulator units; head: the pairs' constants -|r|^2 sc^2 / 2 (values of different lists become comparable)
   void* norms;   // head: [query * heads + probe rank] x 16 bytes
   uint32_t n_probes, rot_dim, heads;
@@ -124,6 +125,7 @@ struct wide_filter {
   const uint32_t* pair_off;
   uint32_t n_lists;
   const void* bq;
+  const uint32_t* blk_off;
   const float* thr;
   const void* rows16;
   const float* row_term;  // [padded_rows] fp32 -|d|^2 (1 - 2^-9) sc^2 / 2: the accumulators' initial values

@@ -2870,7 +2870,7 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
   l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries;
   l.centers_rot = idx.centers_rot.data(); l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = hb.head_c; l.norms = hb.norms;
   l.n_probes = r.n_probes; l.rot_dim = idx.rot_dim; l.heads = r.head; l.sc = tb.sc; l.c1 = c1; l.eps = eps; l.alpha = alpha;
-  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 1; l.n_pairs = r.nq * (int64_t)r.head;
+  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 1; l.n_pairs = r.nq * (int64_t)r.head; l.blk_off = hb.blk_off;
   pqw_bprep(res, l);
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(), r.unit_rows,
@@ -2879,7 +2879,7 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
                      idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, pqw_group(), 0u);
   wide_filter f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = hb.tickets; f.sorted_pairs = r.sorted_pairs; f.pair_off = r.pair_off;
-  f.n_lists = idx.n_lists; f.bq = r.bq; f.thr = hb.head_c; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
+  f.n_lists = idx.n_lists; f.bq = r.bq; f.blk_off = hb.blk_off; f.thr = hb.head_c; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
   f.qflag = r.qflag; f.surv = r.surv; f.surv_cnt = r.surv_cnt; f.surv_cap = 0; f.spill_cap = 0; f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim;
   f.xbuf = hb.xbuf; f.ldx = hb.ldx; f.heads = r.head; f.emit = 1; f.grid = pq3_grid(res); f.stats = nullptr;
   pqw_filter(res, f);
@@ -2926,7 +2926,7 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries;
   l.centers_rot = idx.centers_rot.data(); l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = r.thr; l.norms = nullptr;
   l.n_probes = r.n_probes; l.rot_dim = idx.rot_dim; l.heads = r.head; l.sc = tb.sc; l.c1 = c1; l.eps = eps; l.alpha = alpha;
-  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 0; l.n_pairs = r.nq * (int64_t)r.n_probes;
+  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 0; l.n_pairs = r.nq * (int64_t)r.n_probes; l.blk_off = hb.blk_off;
   profile_begin(res, "pq_bprep_kernel");
   pqw_bprep(res, l);
   profile_end(res, "pq_bprep_kernel");
@@ -2938,7 +2938,7 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   const unsigned grid = pq3_grid(res);
   wide_filter f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket; f.sorted_pairs = r.sorted_pairs; f.pair_off = r.pair_off;
-  f.n_lists = idx.n_lists; f.bq = r.bq; f.thr = r.thr; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
+  f.n_lists = idx.n_lists; f.bq = r.bq; f.blk_off = hb.blk_off; f.thr = r.thr; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
   f.qflag = r.qflag; f.surv = r.surv; f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / grid);
   f.spill_cap = r.surv_cap - f.surv_cap * grid; f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.xbuf = nullptr; f.ldx = 0; f.heads = r.head;
   f.emit = 0; f.grid = grid; f.stats = r.stats;

@@ -153,6 +153,7 @@ struct pqw_bufs {
   float* head_c;                      // [nq * heads] the head pairs' constants (by pair position)
   void* norms;                        // [nq * heads] x 16 bytes
   uint32_t* tickets;                  // 8 x 32 zeroed words
+  uint32_t* blk_off;                  // [n_lists + 1] scratch: first operand block of every list (head pairs, then tail pairs)
 };
 // r.head = heads. Returns false (nothing launched) when the decoded copy cannot be made: the caller runs the exact head phase and
 // the LUT scan. Leaves r.query_kth (bounds) and hb.thr_head; queries without a bound (fewer than k rows in their head lists) flagged.

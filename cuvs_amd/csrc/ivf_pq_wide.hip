@@ -56,6 +56,29 @@ __global__ void pqw_decode_kernel(const uint8_t* __restrict__ codes8, uint32_t n
 }
 
 // ------------------------------------------------------------------ pre-pass: B operands, norms / thresholds
+// The B operands are written in the layout a work unit reads them in: the pairs of a list are cut into BLOCKS of 32 (the last one
+// padded with zero operands), block b of the batch is [K step][lane = (K half h, pair ql)] x 16 bytes - NST KiB in one piece - and the
+// blocks of a list follow each other (blk_off[L]: the list's first block). A unit's query group is one block: its operands go to LDS
+// as whole 1 KiB rows (the pair-major layout of the first version made the unit prologue - 16-byte pieces 1.5 KiB apart - a third of
+// the filter kernel: 54 k cycles per unit against 107 k for its rows, measured).
+__global__ __launch_bounds__(1024) void pqw_pair_blocks_kernel(const uint32_t* __restrict__ pair_off, uint32_t n_lists, uint32_t lbase,
+                                                               uint32_t* __restrict__ blk_off)
+{
+  __shared__ int smem[17];
+  const uint32_t per = (n_lists + 1023u) / 1024u;
+  const uint32_t b = threadIdx.x * per, e = min(n_lists, b + per);
+  auto blocks_of = [&](uint32_t i) { return (int)((pair_off[lbase + i + 1] - pair_off[lbase + i] + 31u) >> 5); };
+  int sum = 0;
+  for (uint32_t i = b; i < e; ++i) sum += blocks_of(i);
+  int total;
+  int run = block_exclusive_scan(sum, smem, &total);
+  for (uint32_t i = b; i < e; ++i) {
+    blk_off[i] = (uint32_t)run;
+    run += blocks_of(i);
+  }
+  if (threadIdx.x == 0) blk_off[n_lists] = (uint32_t)total;
+}
+
 struct wprep_params {
   const uint32_t* sorted_pairs;
   const uint32_t* pair_off;
@@ -65,7 +88,8 @@ struct wprep_params {
   const float* centers_rot;
   const uint32_t* query_kth;
   uint32_t* qflag;
-  uint4* bq;      // [pair position][K step][K half] x 16 bytes
+  const uint32_t* blk_off;  // [n_lists + 1] first block of every list
+  uint4* bq;      // [block][K step][K half h][pair ql] x 16 bytes
   float* thr;     // tail pairs: [pair position] threshold in accumulator units; head pairs: the pair's constant -|r|^2 sc^2 / 2
   float4* norms;  // head pairs: [query * heads + probe rank] (|r|^2, ., ., largest scaled operand)
   uint32_t n_probes, rot_dim, heads;
@@ -73,21 +97,30 @@ struct wprep_params {
   int head;
 };
 
-// one wave per pair; K step st holds, in K half h, the rotated dimensions 16 st + 8 h .. + 7
+// one wave per block of 32 pairs: lane = (K half h, pair ql); K step st holds, in K half h, the rotated dimensions 16 st + 8 h .. + 7
 __global__ __launch_bounds__(256) void pqw_bprep_kernel(const wprep_params a)
 {
-  const uint32_t s_base = a.pair_off[a.lbase], s_end = a.pair_off[a.lbase + a.n_lists];
-  const uint32_t s = s_base + blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (s >= s_end) return;  // wave-uniform
-  const uint32_t p = a.sorted_pairs[s], q = p / a.n_probes, L = a.probes[p];
-  const float* rq = a.rot_queries + (size_t)q * a.rot_dim;
-  const float* ct = a.centers_rot + (size_t)L * a.rot_dim;
-  const uint32_t n_slots = a.rot_dim / 8u;
-  uint4* out = a.bq + (size_t)(s - s_base) * n_slots;
+  const uint32_t blk = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u, ql = lane & 31u, h = lane >> 5;
+  if (blk >= a.blk_off[a.n_lists]) return;  // wave-uniform
+  uint32_t lo = 0u, hi = a.n_lists;  // the block's list: blk_off[lo] <= blk < blk_off[hi]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a.blk_off[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const uint32_t L = lo, s0 = a.pair_off[a.lbase + L], np = a.pair_off[a.lbase + L + 1] - s0;
+  const uint32_t pos = (blk - a.blk_off[L]) * 32u + ql;
+  const bool have = pos < np;
+  const uint32_t s = s0 + min(pos, np - 1u), s_base = a.pair_off[a.lbase];
+  const uint32_t p = a.sorted_pairs[s], q = p / a.n_probes;
+  const float* rq = a.rot_queries + (size_t)q * a.rot_dim + 8u * h;
+  const float* ct = a.centers_rot + (size_t)L * a.rot_dim + 8u * h;
+  const uint32_t nst = a.rot_dim / 16u;
+  uint4* out = a.bq + (size_t)blk * nst * 64 + lane;
   float rn = 0.f, big = 0.f;
-  for (uint32_t slot = lane; slot < n_slots; slot += 64u) {
-    const float4 q0 = *reinterpret_cast<const float4*>(rq + slot * 8u), q1 = *reinterpret_cast<const float4*>(rq + slot * 8u + 4u);
-    const float4 c0 = *reinterpret_cast<const float4*>(ct + slot * 8u), c1 = *reinterpret_cast<const float4*>(ct + slot * 8u + 4u);
+#pragma unroll 4
+  for (uint32_t st = 0; st < nst; ++st) {
+    const float4 q0 = *reinterpret_cast<const float4*>(rq + st * 16u), q1 = *reinterpret_cast<const float4*>(rq + st * 16u + 4u);
+    const float4 c0 = *reinterpret_cast<const float4*>(ct + st * 16u), c1 = *reinterpret_cast<const float4*>(ct + st * 16u + 4u);
     const float r[8] = {q0.x - c0.x, q0.y - c0.y, q0.z - c0.z, q0.w - c0.w, q1.x - c1.x, q1.y - c1.y, q1.z - c1.z, q1.w - c1.w};
     f16x8_t v;
 #pragma unroll
@@ -95,16 +128,13 @@ __global__ __launch_bounds__(256) void pqw_bprep_kernel(const wprep_params a)
       rn = __fmaf_rn(r[e], r[e], rn);
       const float x = a.sc * r[e];
       big  = fmaxf(big, fabsf(x));
-      v[e] = (_Float16)fminf(fmaxf(x, -60000.f), 60000.f);
+      v[e] = have ? (_Float16)fminf(fmaxf(x, -60000.f), 60000.f) : (_Float16)0.f;  // (a padding slot: zero operands)
     }
-    out[slot] = __builtin_bit_cast(uint4, v);
+    out[(size_t)st * 64] = __builtin_bit_cast(uint4, v);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    rn += __shfl_xor(rn, o);
-    big = fmaxf(big, __shfl_xor(big, o));
-  }
-  if (lane != 0u) return;
+  rn += __shfl_xor(rn, 32);
+  big = fmaxf(big, __shfl_xor(big, 32));
+  if (!have || h != 0u) return;
   if (a.head) {
     a.norms[(size_t)q * a.heads + p % a.n_probes] = make_float4(rn, 0.f, 0.f, big);
     a.thr[s - s_base] = -0.5f * a.sc * a.sc * rn;
@@ -132,6 +162,7 @@ struct wide_params {
   const uint32_t* pair_off;
   uint32_t n_lists, lbase;
   const uint4* bq;
+  const uint32_t* blk_off;  // [n_lists + 1] first operand block of every list (pqw_pair_blocks_kernel)
   const float* thr;
   const uint4* rows16;
   const float* row_term;
@@ -164,13 +195,15 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
   const uint32_t chunk   = (n_units + 7u) / 8u;
   const uint32_t s_base  = a.pair_off[a.lbase];
   uint32_t xcd = blockIdx.x & 7u, hops = 0u;
-  unsigned long long st_pairs = 0, st_surv = 0, st_strips = 0, st_units = 0;
+  unsigned long long st_pairs = 0, st_surv = 0, st_strips = 0, st_units = 0, st_t[2] = {0, 0};
 
   for (;;) {
     __syncthreads();  // nobody reads the previous unit's operands any more
     if (threadIdx.x == 0) {
       uint32_t ui = 0xffffffffu;
       for (;;) {  // XCD x owns the x-th eighth of the (list-sorted) units; a workgroup whose XCD has run dry moves on to the next share
+        // (measured and rejected: the next unit's ticket drawn while this unit runs - the atomic sits ahead of wave 0's row loads in
+        // its in-order memory queue: 97 k -> 108 k cycles per unit for the rows, nothing gained in the prologue)
         const uint32_t share0 = min(n_units, xcd * chunk), share_len = min(chunk, n_units - share0);
         const uint32_t t = atomicAdd(a.xcd_ticket + xcd * 32, 1u);
         if (t < share_len) { ui = share0 + t; break; }
@@ -185,6 +218,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
     const filter_unit* up = a.units + ui;
     const uint4 uu = *reinterpret_cast<const uint4*>(up);
     const uint2 uv = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(up) + 16);
+    const uint32_t list = __builtin_amdgcn_readfirstlane(uu.x);
     const uint32_t first = __builtin_amdgcn_readfirstlane(uu.y), count = __builtin_amdgcn_readfirstlane(uu.z),
                    row0 = __builtin_amdgcn_readfirstlane(uu.w), base_row = __builtin_amdgcn_readfirstlane(uv.x),
                    r_end = __builtin_amdgcn_readfirstlane(uv.y);
@@ -223,6 +257,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
         }
       }
     };
+    const unsigned long long t_unit = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
     u32x4_t av[R][kWKC][kWS];
     f32x16_t tv[kWS];
     if (n_mine != 0u) {  // the first chunks of the wave's first strip are on their way while the unit's operands are copied
@@ -230,12 +265,12 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
 #pragma unroll
       for (int r = 0; r < R - 1; ++r) load_chunk(av[r], 0u, r);
     }
-    // ---- B operands, thresholds and pair ids of the unit's queries, from the pre-pass: lane = (query ql, K half h)
-#pragma unroll 4
-    for (uint32_t it = wave; it < ng * NST; it += kWWaves) {
-      const uint32_t g = it / NST, st = it - g * NST;
-      const uint32_t jc = min(g * 32u + ql, count - 1u);
-      Bs[(g * NST + st) * 64 + lane] = a.bq[((size_t)(first - s_base + jc) * NST + st) * 2 + h];
+    // ---- B operands of the unit's query groups: whole blocks of the pre-pass's layout (NST KiB each, one after the other), copied as
+    // 1 KiB rows; then thresholds and pair ids
+    {
+      const uint4* src = a.bq + ((size_t)a.blk_off[list] + ((first - a.pair_off[a.lbase + list]) >> 5)) * NST * 64 + lane;
+#pragma unroll 12
+      for (uint32_t it = wave; it < ng * NST; it += kWWaves) Bs[it * 64 + lane] = src[(size_t)it * 64];
     }
     if (threadIdx.x < kWNG * 32) {
       const uint32_t jj = threadIdx.x;
@@ -250,6 +285,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
       }
     }
     __syncthreads();
+    const unsigned long long t_loop = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
 
     auto run = [&](auto ng_tag) {
       constexpr int NG = decltype(ng_tag)::value;
@@ -379,12 +415,17 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
     if (ng >= 3u) run(std::integral_constant<int, 3>{});
     else if (ng == 2u) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 1>{});
-    if (a.stats != nullptr) st_units += 1u;
+    if (a.stats != nullptr) {
+      st_units += 1u;
+      const unsigned long long t_end = __builtin_readcyclecounter();
+      st_t[0] += t_loop - t_unit;  // unit prologue (ticket, B operands into LDS)
+      st_t[1] += t_end - t_loop;   // strips
+    }
   }
   if (a.stats != nullptr) atomicAdd(&a.stats[1], st_surv);  // counted per lane
   if (a.stats != nullptr && lane == 0) {
     atomicAdd(&a.stats[0], st_pairs); atomicAdd(&a.stats[2], st_strips);
-    if (wave == 0) atomicAdd(&a.stats[7], st_units);
+    if (wave == 0) { atomicAdd(&a.stats[7], st_units); atomicAdd(&a.stats[4], st_t[0]); atomicAdd(&a.stats[5], st_t[1]); }
   }
   __syncthreads();
   if (!EMIT && threadIdx.x == 0) a.surv_cnt[blockIdx.x] = min(ctrl[0], a.surv_cap);
@@ -417,10 +458,13 @@ void pqw_bprep(resources& res, const wide_prep& l)
   b.sorted_pairs = l.sorted_pairs; b.pair_off = l.pair_off; b.n_lists = l.n_lists; b.lbase = l.head ? 0u : l.n_lists; b.probes = l.probes;
   b.rot_queries = l.rot_queries; b.centers_rot = l.centers_rot; b.query_kth = l.query_kth; b.qflag = l.qflag;
   b.bq = static_cast<uint4*>(l.bq); b.thr = l.thr; b.norms = static_cast<float4*>(l.norms); b.n_probes = l.n_probes; b.rot_dim = l.rot_dim;
+  b.blk_off = l.blk_off;
   b.heads = l.heads; b.sc = l.sc; b.c1 = l.c1; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = l.cbmax; b.dmax = l.dmax; b.bound_max = l.bound_max;
   b.head = l.head;
   if (l.n_pairs == 0) return;
-  hipLaunchKernelGGL(pqw_bprep_kernel, dim3((unsigned)grid_blocks(l.n_pairs, 4)), dim3(256), 0, res.stream, b);
+  hipLaunchKernelGGL(pqw_pair_blocks_kernel, dim3(1), dim3(1024), 0, res.stream, l.pair_off, l.n_lists, b.lbase, l.blk_off);
+  // (grid: an upper bound of the blocks - every list's last block may be a partial one)
+  hipLaunchKernelGGL(pqw_bprep_kernel, dim3((unsigned)grid_blocks(l.n_pairs / 32 + l.n_lists + 1, 4)), dim3(256), 0, res.stream, b);
   HIP_TRY(hipGetLastError());
 }
 
@@ -428,7 +472,7 @@ void pqw_filter(resources& res, const wide_filter& l)
 {
   wide_params g{};
   g.units = l.units; g.n_units = l.n_units; g.xcd_ticket = l.xcd_ticket; g.sorted_pairs = l.sorted_pairs; g.pair_off = l.pair_off;
-  g.n_lists = l.n_lists; g.lbase = l.emit ? 0u : l.n_lists; g.bq = static_cast<const uint4*>(l.bq); g.thr = l.thr;
+  g.n_lists = l.n_lists; g.lbase = l.emit ? 0u : l.n_lists; g.bq = static_cast<const uint4*>(l.bq); g.thr = l.thr; g.blk_off = l.blk_off;
   g.rows16 = static_cast<const uint4*>(l.rows16); g.row_term = l.row_term; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
   g.surv_cnt = l.surv_cnt; g.surv_cap = l.surv_cap; g.spill_cap = l.spill_cap; g.n_probes = l.n_probes; g.xbuf = l.xbuf; g.ldx = l.ldx;
   g.heads = l.heads; g.stats = l.stats;
