@@ -141,7 +141,7 @@ void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i);
 // phase is a BOUND-ONLY pass over the `heads` nearest lists of every query (their union bounds the k-th score: k may be a large
 // fraction of ONE list), through the filter in its emit form; both phases read the index's decoded fp16 rows (scan3_cache::rows16w)
 bool pqw_supported(const ivf_pq_index& idx, int k);
-// head lists per query so that k is at most ~4 % of their rows (the measured crossover of pq3_bound_useful); 0: more than half of
+// head lists per query so that k is at most ~2.5 % of their rows; 0: more than half of
 // the probes would be head lists - the LUT scan stays
 uint32_t pqw_heads(const ivf_pq_index& idx, int k, uint32_t n_probes);
 // the decoded copy is there (made now, on the stream of `res`, if the device has the room)

@@ -37,5 +37,6 @@ for h in (0, 2, 4, 8):
     got = run(f"wide heads={h} (0: rule) acc f16", CUVS_AMD_PQ_WIDE_HEADS=h, CUVS_AMD_SCAN_DEBUG=1024)
     print("   equal to the LUT scan:", bool((got[1] == base[1]).all() and (got[0] == base[0]).all()))
 b32 = run("LUT scan acc f32", acc=np.float32, CUVS_AMD_PQ_WIDE=0)
-g32 = run("wide acc f32", acc=np.float32, CUVS_AMD_SCAN_DEBUG=1024)
-print("   equal:", bool((g32[1] == b32[1]).all()))
+for h in (0, 3, 8, 12):
+    g32 = run(f"wide heads={h} (0: rule) acc f32", acc=np.float32, CUVS_AMD_PQ_WIDE_HEADS=h, CUVS_AMD_SCAN_DEBUG=1024)
+    print("   equal:", bool((g32[1] == b32[1]).all() and (g32[0] == b32[0]).all()))

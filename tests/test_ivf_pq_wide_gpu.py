@@ -159,3 +159,43 @@ def test_wide_path_hands_back_and_rebuilds(monkeypatch, capfd):
     ed, ei, fd, fi, st = _wide_and_lut(index, q, 20, monkeypatch, capfd, **kw)
     assert st[0] > 0 and (ei == fi).all() and (ed == fd).all()
     assert (ei >= 60_000).any(), "the extension's rows are found"
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_wide_path_fuzz_against_lut_scan(seed, monkeypatch, capfd):
+    """random members of the wide class - dimension, pq_dim / pq_bits, row type, metric (L2 / L2Sqrt), list count (down to lists of a few
+    rows and empty lists), probes, k (1 .. 256), LUT / score types, one or several internal batches - wide path == LUT scan kernels, ids
+    and distances"""
+    import torch
+    from cuvs_amd.neighbors import ivf_pq
+
+    rng = np.random.default_rng(1000 + seed)
+    d, pq_dims = [(768, (64, 192, 384, 48)), (512, (64, 128, 32)), (384, (96, 48, 192)), (256, (16, 128))][seed % 4]
+    pq_dim = int(rng.choice(pq_dims))
+    if d // pq_dim in (1, 2, 4, 8) and d <= 256:
+        pq_dim = 16  # (a shape of pq_filter4_kernel otherwise)
+    pq_bits = int(rng.choice([8, 8, 8, 5, 6]))
+    n = int(rng.integers(20_000, 70_000))
+    n_lists = int(rng.choice([8, 24, 100, 400]))
+    nq = int(rng.integers(256, 700))
+    n_probes = int(min(n_lists, rng.integers(9, 40)))
+    k = int(rng.choice([1, 7, 32, 100, 256]))
+    lut, acc = [("f16", "f32"), ("f16", "f16"), ("f32", "f32"), ("fp8", "f16"), ("fp8", "f32")][int(rng.integers(0, 5))]
+    metric = str(rng.choice(["sqeuclidean", "euclidean"]))
+    x, q = _mixture(n, d, nq, seed=2000 + seed, modes=int(rng.choice([20, 200])), sigma=float(rng.choice([0.35, 1.0])))
+    dtype = rng.choice(["f32", "f16", "i8"])
+    if dtype == "f16":
+        x, q = x.astype(np.float16), q.astype(np.float16)
+    elif dtype == "i8":
+        x, q = np.clip(np.rint(x * 40), -127, 127).astype(np.int8), np.clip(np.rint(q * 40), -127, 127).astype(np.int8)
+    index = ivf_pq.build(ivf_pq.IndexParams(n_lists=n_lists, pq_dim=pq_dim, pq_bits=pq_bits, metric=metric, kmeans_n_iters=6,
+                                            kmeans_trainset_fraction=0.5), torch.from_numpy(x).cuda())
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc],
+              max_internal_batch_size=int(rng.choice([nq, 300, 32768])))
+    gd, gi, sd, si, st = _wide_and_lut(index, q, k, monkeypatch, capfd, **kw)
+    desc = f"d {d} pq_dim {pq_dim} bits {pq_bits} n {n} lists {n_lists} nq {nq} probes {n_probes} k {k} {lut}/{acc} {metric} {dtype} {kw['max_internal_batch_size']}"
+    assert (gi == si).all(), f"{desc}: id mismatch rate {(gi != si).mean():.5f}"
+    assert (gd == sd).all(), desc
+    # (the wide path ran unless the rule found no head-list count: more than half of the probes)
+    if st[0] == 0:
+        pytest.skip(f"{desc}: the wide path's rule declined (k too large for the probed lists)")
