@@ -347,7 +347,7 @@ void knn_graph_ivf_pq(resources& res, const void* data, elem_t et, int64_t n, in
   // a shape of the wide matrix-core path (ivf_pq_wide.hip; 768 dimensions: pq_dim 64 x pq_len 12): scores summed in fp32 - the
   // screen's margin for fp16 sums (6 % of the bound) lets four times the rows through to the exact re-score (measured at 2M x 768:
   // 34 vs 19 ms per batch of 16384; the LUT scan of rounds 1-5: 60 ms)
-  if (pqw_shape(pq->rot_dim) && metric != M_InnerProduct && metric != M_CosineExpanded) sp.internal_distance_dtype = 0;
+  if (pqw_shape(pq->rot_dim)) sp.internal_distance_dtype = 0;
   sp.max_internal_batch_size = 16384;
   const int kp1   = (int)K + 1;
   int k_pq        = std::min(256, 2 * kp1);

@@ -65,6 +65,7 @@ struct ivf_pq_index {
     // the rows DECODED (scaled fp16, MFMA A-operand layout) for the wide filter (ivf_pq_wide.hip): rows x rot_dim x 2 bytes, made
     // when a search first takes that path and the device has the room; w_failed_*: the index state that found none
     dev_buf<uint4> rows16w;
+    dev_buf<float> zeros;  // 32 zero floats (the wide filter's row terms of an inner-product search)
     dev_buf<float> cbt;  // the fp32 codebook entry-major ([subspace][256][pq_len]): the wide path's exact scores read whole entries
     const void* w_codes = nullptr;
     const void* w_pq    = nullptr;

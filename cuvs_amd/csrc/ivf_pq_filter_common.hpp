@@ -114,6 +114,7 @@ struct wide_prep {  // pre-pass: fp16 B operands of the head (labels [0, n_lists
   uint32_t n_probes, rot_dim, heads;
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
   int head;
+  int is_ip;        // inner product / cosine: the operand is the query (not the residual), thresholds by filter_threshold_ip
   int64_t n_pairs;  // upper bound of the pairs served (grid size)
 };
 void pqw_bprep(resources& res, const wide_prep& l);
@@ -128,7 +129,8 @@ struct wide_filter {
   const uint32_t* blk_off;
   const float* thr;
   const void* rows16;
-  const float* row_term;  // [padded_rows] fp32 -|d|^2 (1 - 2^-9) sc^2 / 2: the accumulators' initial values
+  const float* row_term;  // [padded_rows] fp32 -|d|^2 (1 - 2^-9) sc^2 / 2: the accumulators' initial values (nullptr: inner product)
+  const float* zeros;     // 32 zero floats
   uint32_t* qflag;
   void* surv;             // one region of surv_cap entries per workgroup + a shared spill region of spill_cap entries
   uint32_t* surv_cnt;     // [grid + 1]

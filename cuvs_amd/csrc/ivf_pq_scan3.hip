@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(kRThreads) void pq_rescore_kernel(const rescore_par
 // the nearest list), and two thirds of a score's bytes were the query's and the centre's components read again
 struct wave_score_cache {
   uint32_t q = 0xffffffffu, L = 0xffffffffu;
-  float r[16];
+  float r[16], c[16];  // L2: the residual q - c; inner product: the query's and the centre's components
 };
 template <int LUT, bool ACC_HALF>
 __device__ inline float pq_exact_score_wave(const rescore_params& a, const uint32_t q, const uint32_t L, const uint32_t row)
@@ -1229,7 +1229,7 @@ struct wave_score_tile {
   static constexpr size_t kBytes = (size_t)kWords * 4u;
 };
 
-template <int LUT, bool ACC_HALF, int PL>
+template <int LUT, bool ACC_HALF, int PL, bool IP>
 __device__ inline float wave_score_batch_pl(const rescore_params& a, const bool ok, const uint32_t q, const uint32_t L, const uint32_t row,
                                             wave_score_cache& cache, void* lds_tile)
 {
@@ -1284,19 +1284,29 @@ __device__ inline float wave_score_batch_pl(const rescore_params& a, const bool 
       return (uint32_t)cr[(size_t)(sub >> 4) * 1024 + (sub & 15u)];
     };
     auto load_entry = [&](const cursor c, const uint32_t code) { return load_pl(a.cbt + ((size_t)sub_of(c) * 256 + code) * PL); };
-    auto load_res = [&](const cursor c) {  // the block's residual components (beyond 64 subspaces: every step)
+    // the block's residual components q - c (L2); inner product: the query's components, and the centre's (load_ctr)
+    auto load_res = [&](const cursor c) {
       const uint32_t qj = __builtin_amdgcn_readlane(q, c.j), Lj = __builtin_amdgcn_readlane(L, c.j), d0 = sub_of(c) * PL;
-      const piece qv = load_pl(a.rot_queries + (size_t)qj * a.rot_dim + d0), cv = load_pl(a.centers_rot + (size_t)Lj * a.rot_dim + d0);
+      const piece qv = load_pl(a.rot_queries + (size_t)qj * a.rot_dim + d0);
+      if constexpr (IP) return qv;
+      const piece cv = load_pl(a.centers_rot + (size_t)Lj * a.rot_dim + d0);
       piece o;
 #pragma unroll
       for (int l = 0; l < PL; ++l) o.x[l] = qv.x[l] - cv.x[l];
       return o;
     };
+    auto load_ctr = [&](const cursor c) {
+      const uint32_t Lj = __builtin_amdgcn_readlane(L, c.j), d0 = sub_of(c) * PL;
+      return load_pl(a.centers_rot + (size_t)Lj * a.rot_dim + d0);
+    };
     const uint32_t n_steps = n_pass * nb;
     cursor c0 = advance(), c1 = advance();
     uint32_t code1 = load_code(c1);
-    piece p_cur = load_entry(c0, load_code(c0)), r_cur{}, p_nxt, r_nxt{};
-    if (nb > 1u) r_cur = load_res(c0);
+    piece p_cur = load_entry(c0, load_code(c0)), r_cur{}, p_nxt, r_nxt{}, c_cur{}, c_nxt{};
+    if (nb > 1u) {
+      r_cur = load_res(c0);
+      if constexpr (IP) c_cur = load_ctr(c0);
+    }
     uint32_t it = 0;  // position of c0's item in the pass
     for (uint32_t t = 0; t < n_steps; ++t) {
       if (nb == 1u) {  // wave-uniform: the pair's residual, kept across items and calls
@@ -1305,27 +1315,44 @@ __device__ inline float wave_score_batch_pl(const rescore_params& a, const bool 
           const piece rr = load_res(c0);
 #pragma unroll
           for (int l = 0; l < PL; ++l) cache.r[l] = rr.x[l];
+          if constexpr (IP) {
+            const piece cc = load_ctr(c0);
+#pragma unroll
+            for (int l = 0; l < PL; ++l) cache.c[l] = cc.x[l];
+          }
           cache.q = qj; cache.L = Lj;
         }
       }
       p_nxt = load_entry(c1, code1);  // step t + 1
-      if (nb > 1u) r_nxt = load_res(c1);
+      if (nb > 1u) {
+        r_nxt = load_res(c1);
+        if constexpr (IP) c_nxt = load_ctr(c1);
+      }
       const cursor c2 = advance();
       const uint32_t code2 = load_code(c2);  // step t + 2
       float v = 0.f;
 #pragma unroll
       for (int l = 0; l < PL; ++l) {
-        const float d = (nb == 1u ? cache.r[l] : r_cur.x[l]) - p_cur.x[l];
-        v = __fmaf_rn(d, d, v);
+        const float rl = nb == 1u ? cache.r[l] : r_cur.x[l];
+        if constexpr (!IP) {
+          const float d = rl - p_cur.x[l];
+          v = __fmaf_rn(d, d, v);
+        } else {  // (create_lut_impl.cuh:17-78: -q c - q p, component by component)
+          v = __fmaf_rn(-rl, nb == 1u ? cache.c[l] : c_cur.x[l], v);
+          v = __fmaf_rn(-rl, p_cur.x[l], v);
+        }
       }
-      if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, false);
+      if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, IP);
       uint32_t bits;
       if constexpr (!tile::kHalf) bits = __float_as_uint(v);
       else bits = (uint32_t)__builtin_bit_cast(uint16_t, to_lut_half(v));
       if (c0.blk * 64u + lane < pq_dim) ent[it * stride + c0.blk * 64u + lane] = (typename tile::ent_t)bits;  // row = the item's position in the pass
       if (c0.blk + 1u == nb) it += 1u;
       c0 = c1; c1 = c2; code1 = code2; p_cur = p_nxt;
-      if (nb > 1u) r_cur = r_nxt;
+      if (nb > 1u) {
+        r_cur = r_nxt;
+        if constexpr (IP) c_cur = c_nxt;
+      }
     }
     if (ok && mine >= base && mine < base + n_pass) {
       const typename tile::ent_t* my = ent + (mine - base) * stride;
@@ -1349,13 +1376,18 @@ template <int LUT, bool ACC_HALF>
 __device__ inline float wave_score_batch(const rescore_params& a, const bool ok, const uint32_t q, const uint32_t L, const uint32_t row,
                                          wave_score_cache& cache, void* lds_tile)
 {
-  if (!a.is_ip && !a.per_cluster) {  // wave-uniform
+  if (!a.per_cluster) {  // wave-uniform
+    auto go = [&](auto pl_tag) {
+      constexpr int PL = decltype(pl_tag)::value;
+      return a.is_ip ? wave_score_batch_pl<LUT, ACC_HALF, PL, true>(a, ok, q, L, row, cache, lds_tile)
+                     : wave_score_batch_pl<LUT, ACC_HALF, PL, false>(a, ok, q, L, row, cache, lds_tile);
+    };
     switch (a.pq_len) {
-      case 2:  return wave_score_batch_pl<LUT, ACC_HALF, 2>(a, ok, q, L, row, cache, lds_tile);
-      case 4:  return wave_score_batch_pl<LUT, ACC_HALF, 4>(a, ok, q, L, row, cache, lds_tile);
-      case 8:  return wave_score_batch_pl<LUT, ACC_HALF, 8>(a, ok, q, L, row, cache, lds_tile);
-      case 12: return wave_score_batch_pl<LUT, ACC_HALF, 12>(a, ok, q, L, row, cache, lds_tile);
-      case 16: return wave_score_batch_pl<LUT, ACC_HALF, 16>(a, ok, q, L, row, cache, lds_tile);
+      case 2:  return go(std::integral_constant<int, 2>{});
+      case 4:  return go(std::integral_constant<int, 4>{});
+      case 8:  return go(std::integral_constant<int, 8>{});
+      case 12: return go(std::integral_constant<int, 12>{});
+      case 16: return go(std::integral_constant<int, 16>{});
       default: break;
     }
   }
@@ -1440,7 +1472,8 @@ struct wbound_params {
   uint32_t* query_kth;
   uint32_t* qflag;
   float* thr_head;          // out: [query * heads + rank] threshold in the units of the value buffer
-  float sc, c1, eps, alpha, cbmax, bound_max;
+  float sc, c1, eps, alpha, cbmax, dmax, bound_max;
+  int is_ip;
 };
 template <int LUT, bool ACC_HALF>
 __global__ __launch_bounds__(256) void pqw_head_bound_kernel(const wbound_params a)
@@ -1482,7 +1515,9 @@ __global__ __launch_bounds__(256) void pqw_head_bound_kernel(const wbound_params
     const bool served = key < 0xff800000u && nm.w < 60000.f && fabsf(bound) <= a.bound_max;
     hand_back = hand_back || !served;
     // (the same expression as the emit pass's constant: x = fl(acc + c) >= fl(t + c) whenever acc >= t)
-    a.thr_head[(size_t)q * a.heads + rank] = served ? filter_threshold(bound, nm.x, a) / a.c1 + -0.5f * a.sc * a.sc * nm.x : INFINITY;
+    // nm = (|r|^2 or |q|^2, |c|^2, q.c, .); + the pair's constant of the emit pass (the same expression as pqw_bprep_kernel's)
+    const float t = a.is_ip ? filter_threshold_ip(bound, nm.x, nm.y, nm.z, a) : filter_threshold(bound, nm.x, a);
+    a.thr_head[(size_t)q * a.heads + rank] = served ? t / a.c1 + (a.is_ip ? a.sc * a.sc * nm.z : -0.5f * a.sc * a.sc * nm.x) : INFINITY;
   }
   const bool any_back = __ballot(hand_back) != 0ull;
   if (lane == 0u) {
@@ -2777,8 +2812,7 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
 bool pqw_supported(const ivf_pq_index& idx, int k)
 {
   return idx.codebook_kind == 0 && idx.pq_bits >= 4 && idx.pq_bits <= 8 && idx.pq_dim % 16 == 0 && idx.pq_dim >= 16 &&
-         idx.rot_dim == idx.pq_len * idx.pq_dim && pqw_shape(idx.rot_dim) && k <= 256 && idx.shard_world <= 1 &&
-         (idx.metric == M_L2Expanded || idx.metric == M_L2SqrtExpanded || idx.metric == M_L2Unexpanded || idx.metric == M_L2SqrtUnexpanded);
+         idx.rot_dim == idx.pq_len * idx.pq_dim && pqw_shape(idx.rot_dim) && k <= 256 && idx.shard_world <= 1;
 }
 
 uint32_t pqw_heads(const ivf_pq_index& idx, int k, uint32_t n_probes)
@@ -2807,6 +2841,7 @@ static void pqw_margins(const ivf_pq_index& idx, const pq3_run& r, float* eps, f
   if (r.lut_mode == 0)      { *eps = ne / 65536.0f; *alpha = 0.f; }
   else if (r.lut_mode == 1) { *eps = r.acc_half ? 0.04f * ne : 1.0f / 1024.0f; *alpha = ne * 64.0f / 16777216.0f; *bound_max = 60000.f; }
   else                      { *eps = r.acc_half ? 0.07f + 0.04f * ne : 0.07f; *alpha = ne * 64.0f / 32768.0f; *bound_max = 30000.f; }
+  if (r.is_ip && r.lut_mode == 2) *eps = r.acc_half ? 0.14f + 0.04f * ne : 0.14f;  // signed fp8: one value bit less (2^-3 per entry)
 }
 
 // the decoded rows (nullptr: no room on the device - remembered for this state of the index)
@@ -2835,6 +2870,8 @@ static const void* pqw_rows(resources& res, const ivf_pq_index& idx, pq3_tables*
   }
   c.rows16w = dev_buf<uint4>::persistent((size_t)rows * idx.rot_dim / 8);
   c.cbt     = dev_buf<float>::persistent((size_t)idx.pq_dim * 256 * idx.pq_len);
+  c.zeros   = dev_buf<float>::persistent(32);
+  HIP_TRY(hipMemsetAsync(c.zeros.data(), 0, 32 * sizeof(float), res.stream));
   hipLaunchKernelGGL(cbt_kernel, dim3(grid_blocks((int64_t)idx.pq_dim * 256, 256)), dim3(256), 0, res.stream, idx.pq_centers.data(), idx.pq_dim,
                      idx.pq_len, idx.pq_book, c.cbt.data());
   uint32_t nch8 = 0;
@@ -2852,7 +2889,7 @@ static rescore_params pqw_score_inputs(const ivf_pq_index& idx, const pq3_run& r
   rescore_params s{};
   s.probes = r.probes; s.rot_queries = r.rot_queries; s.centers_rot = idx.centers_rot.data(); s.pq_centers = idx.pq_centers.data();
   s.codes = codes8; s.n_chunks = nch8; s.rot_dim = idx.rot_dim; s.pq_len = idx.pq_len; s.book = idx.pq_book; s.per_cluster = 0;
-  s.is_ip = 0; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head; s.cbt = idx.scan3.cbt.data();
+  s.is_ip = r.is_ip; s.n_probes = r.n_probes; s.k = r.k; s.head = r.head; s.cbt = idx.scan3.cbt.data();
   return s;
 }
 
@@ -2863,7 +2900,7 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
   if (rows16 == nullptr) return false;
   profile_begin(res, "pq_scan_kernel");
   profile_begin(res, "pq_head_kernel");
-  const float c1 = -2.0f / (tb.sc * tb.sc);
+  const float c1 = (r.is_ip ? -1.0f : -2.0f) / (tb.sc * tb.sc);
   float eps = 0.f, alpha = 0.f, bound_max = FLT_MAX;
   pqw_margins(idx, r, &eps, &alpha, &bound_max);
   hipLaunchKernelGGL(fill_f32_kernel, dim3(1024), dim3(256), 0, res.stream, hb.xbuf, (size_t)r.nq * r.head * hb.ldx, -INFINITY);
@@ -2872,7 +2909,7 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
   l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries;
   l.centers_rot = idx.centers_rot.data(); l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = hb.head_c; l.norms = hb.norms;
   l.n_probes = r.n_probes; l.rot_dim = idx.rot_dim; l.heads = r.head; l.sc = tb.sc; l.c1 = c1; l.eps = eps; l.alpha = alpha;
-  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 1; l.n_pairs = r.nq * (int64_t)r.head; l.blk_off = hb.blk_off;
+  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 1; l.n_pairs = r.nq * (int64_t)r.head; l.blk_off = hb.blk_off; l.is_ip = r.is_ip;
   pqw_bprep(res, l);
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, idx.n_lists, idx.list_sizes.data(), r.unit_rows,
@@ -2881,7 +2918,8 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
                      idx.list_offsets.data(), idx.list_sizes.data(), r.unit_rows, r.unit_off, units, pqw_group(), 0u);
   wide_filter f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = hb.tickets; f.sorted_pairs = r.sorted_pairs; f.pair_off = r.pair_off;
-  f.n_lists = idx.n_lists; f.bq = r.bq; f.blk_off = hb.blk_off; f.thr = hb.head_c; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
+  f.n_lists = idx.n_lists; f.bq = r.bq; f.blk_off = hb.blk_off; f.thr = hb.head_c; f.rows16 = rows16;
+  f.row_term = r.is_ip ? nullptr : reinterpret_cast<const float*>(tb.row_term); f.zeros = idx.scan3.zeros.data();
   f.qflag = r.qflag; f.surv = r.surv; f.surv_cnt = r.surv_cnt; f.surv_cap = 0; f.spill_cap = 0; f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim;
   f.xbuf = hb.xbuf; f.ldx = hb.ldx; f.heads = r.head; f.emit = 1; f.grid = pq3_grid(res); f.stats = nullptr;
   pqw_filter(res, f);
@@ -2895,7 +2933,7 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
   b.kth_val = hb.kth_val; b.kth_idx = hb.kth_idx; b.norms = static_cast<const float4*>(hb.norms); b.probes = r.probes;
   b.list_offsets = idx.list_offsets.data(); b.nq = r.nq; b.k = r.k; b.heads = r.head; b.ldx = hb.ldx; b.n_probes = r.n_probes;
   b.rot_dim = idx.rot_dim; b.query_kth = const_cast<uint32_t*>(r.query_kth); b.qflag = r.qflag; b.thr_head = hb.thr_head;
-  b.sc = tb.sc; b.c1 = c1; b.eps = eps; b.alpha = alpha; b.cbmax = tb.cbmax; b.bound_max = bound_max;
+  b.sc = tb.sc; b.c1 = c1; b.eps = eps; b.alpha = alpha; b.cbmax = tb.cbmax; b.dmax = tb.dmax; b.bound_max = bound_max; b.is_ip = r.is_ip;
   const dim3 bgrid((unsigned)grid_blocks(r.nq, 4));
   auto bound = [&](auto lut_tag, auto acc_tag) {
     constexpr int LUT = decltype(lut_tag)::value;
@@ -2921,14 +2959,14 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   const void* rows16 = pqw_rows(res, idx, &tb);
   CUVS_EXPECTS(rows16 != nullptr, "ivf_pq: the wide path's decoded rows are gone between the head and the tail phase");
   profile_begin(res, "pq_scan_kernel");
-  const float c1 = -2.0f / (tb.sc * tb.sc);
+  const float c1 = (r.is_ip ? -1.0f : -2.0f) / (tb.sc * tb.sc);
   float eps = 0.f, alpha = 0.f, bound_max = FLT_MAX;
   pqw_margins(idx, r, &eps, &alpha, &bound_max);
   wide_prep l{};
   l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = idx.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries;
   l.centers_rot = idx.centers_rot.data(); l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.thr = r.thr; l.norms = nullptr;
   l.n_probes = r.n_probes; l.rot_dim = idx.rot_dim; l.heads = r.head; l.sc = tb.sc; l.c1 = c1; l.eps = eps; l.alpha = alpha;
-  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 0; l.n_pairs = r.nq * (int64_t)r.n_probes; l.blk_off = hb.blk_off;
+  l.cbmax = tb.cbmax; l.dmax = tb.dmax; l.bound_max = bound_max; l.head = 0; l.n_pairs = r.nq * (int64_t)r.n_probes; l.blk_off = hb.blk_off; l.is_ip = r.is_ip;
   profile_begin(res, "pq_bprep_kernel");
   pqw_bprep(res, l);
   profile_end(res, "pq_bprep_kernel");
@@ -2940,7 +2978,8 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   const unsigned grid = pq3_grid(res);
   wide_filter f{};
   f.units = units; f.n_units = r.unit_off + idx.n_lists; f.xcd_ticket = r.xcd_ticket; f.sorted_pairs = r.sorted_pairs; f.pair_off = r.pair_off;
-  f.n_lists = idx.n_lists; f.bq = r.bq; f.blk_off = hb.blk_off; f.thr = r.thr; f.rows16 = rows16; f.row_term = reinterpret_cast<const float*>(tb.row_term);
+  f.n_lists = idx.n_lists; f.bq = r.bq; f.blk_off = hb.blk_off; f.thr = r.thr; f.rows16 = rows16;
+  f.row_term = r.is_ip ? nullptr : reinterpret_cast<const float*>(tb.row_term); f.zeros = idx.scan3.zeros.data();
   f.qflag = r.qflag; f.surv = r.surv; f.surv_cnt = r.surv_cnt; f.surv_cap = (uint32_t)((uint64_t)r.surv_cap * 3 / 4 / grid);
   f.spill_cap = r.surv_cap - f.surv_cap * grid; f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim; f.xbuf = nullptr; f.ldx = 0; f.heads = r.head;
   f.emit = 0; f.grid = grid; f.stats = r.stats;

@@ -94,7 +94,7 @@ struct wprep_params {
   float4* norms;  // head pairs: [query * heads + probe rank] (|r|^2, ., ., largest scaled operand)
   uint32_t n_probes, rot_dim, heads;
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
-  int head;
+  int head, is_ip;
 };
 
 // one wave per block of 32 pairs: lane = (K half h, pair ql); K step st holds, in K half h, the rotated dimensions 16 st + 8 h .. + 7
@@ -116,12 +116,21 @@ __global__ __launch_bounds__(256) void pqw_bprep_kernel(const wprep_params a)
   const float* ct = a.centers_rot + (size_t)L * a.rot_dim + 8u * h;
   const uint32_t nst = a.rot_dim / 16u;
   uint4* out = a.bq + (size_t)blk * nst * 64 + lane;
-  float rn = 0.f, big = 0.f;
+  // L2: the operand is the residual q - c; inner product / cosine: the query itself (score -(q.c + q.d): q.c and |c|^2 enter the threshold)
+  float rn = 0.f, big = 0.f, qc = 0.f, cn = 0.f;
 #pragma unroll 4
   for (uint32_t st = 0; st < nst; ++st) {
     const float4 q0 = *reinterpret_cast<const float4*>(rq + st * 16u), q1 = *reinterpret_cast<const float4*>(rq + st * 16u + 4u);
     const float4 c0 = *reinterpret_cast<const float4*>(ct + st * 16u), c1 = *reinterpret_cast<const float4*>(ct + st * 16u + 4u);
-    const float r[8] = {q0.x - c0.x, q0.y - c0.y, q0.z - c0.z, q0.w - c0.w, q1.x - c1.x, q1.y - c1.y, q1.z - c1.z, q1.w - c1.w};
+    float r[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    const float c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    if (!a.is_ip) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] -= c[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qc = __fmaf_rn(r[e], c[e], qc); cn = __fmaf_rn(c[e], c[e], cn); }
+    }
     f16x8_t v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -132,18 +141,21 @@ __global__ __launch_bounds__(256) void pqw_bprep_kernel(const wprep_params a)
     }
     out[(size_t)st * 64] = __builtin_bit_cast(uint4, v);
   }
-  rn += __shfl_xor(rn, 32);
+  rn += __shfl_xor(rn, 32); qc += __shfl_xor(qc, 32); cn += __shfl_xor(cn, 32);
   big = fmaxf(big, __shfl_xor(big, 32));
   if (!have || h != 0u) return;
   if (a.head) {
-    a.norms[(size_t)q * a.heads + p % a.n_probes] = make_float4(rn, 0.f, 0.f, big);
-    a.thr[s - s_base] = -0.5f * a.sc * a.sc * rn;
+    // the pair's constant: what turns the accumulator into a value comparable across the query's head lists
+    //   L2: score = |r|^2 - 2 r.d + |d|^2 -> acc - |r|^2 sc^2 / 2;   inner product: score = -(q.c + q.d) -> acc + (q.c) sc^2
+    a.norms[(size_t)q * a.heads + p % a.n_probes] = make_float4(rn, cn, qc, big);
+    a.thr[s - s_base] = a.is_ip ? a.sc * a.sc * qc : -0.5f * a.sc * a.sc * rn;
   } else {
     const uint32_t kk = a.query_kth[q];
     const float bound = key_to_float(kk);
     const bool served = kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max;
     if (!served) a.qflag[q] = 1u;  // handed back to the LUT scan
-    a.thr[s - s_base] = served ? filter_threshold(bound, rn, a) / a.c1 : INFINITY;
+    const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
+    a.thr[s - s_base] = served ? t / a.c1 : INFINITY;
   }
 }
 
@@ -166,6 +178,7 @@ struct wide_params {
   const float* thr;
   const uint4* rows16;
   const float* row_term;
+  const float* zeros;  // 32 zero floats (the rows' terms of an inner-product search)
   uint32_t* qflag;
   uint2* surv;
   uint32_t* surv_cnt;
@@ -229,7 +242,9 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
     const uint32_t w_sub  = wave * kWS;
     const uint32_t n_mine = n_sub > w_sub ? (n_sub - w_sub + kWWaves * kWS - 1u) / (kWWaves * kWS) : 0u;
     const uint4* a_base   = a.rows16 + (size_t)(base_row >> 5) * NST * 64;  // (wave-uniform bases + a lane offset: scalar address arithmetic)
-    const float* t_base   = a.row_term + base_row;
+    // (inner product: no row terms - the loads stay, unconditional, on a block of zeros: stride 0)
+    const float* t_base   = a.row_term != nullptr ? a.row_term + base_row : a.zeros;
+    const uint32_t t_step = a.row_term != nullptr ? 32u : 0u;
 
     // a chunk of a strip: kWKC K steps of its kWS subtiles (subtiles past the end repeat the last one and are not screened)
     auto load_chunk = [&](u32x4_t (&av)[kWKC][kWS], const uint32_t t, const int c) {
@@ -249,7 +264,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
 #pragma unroll
       for (int s = 0; s < kWS; ++s) {
         const uint32_t uc = min(u0 + (t * kWWaves + wave) * kWS + (uint32_t)s, u1 - 1u);
-        const float* p = t_base + (size_t)uc * 32u;
+        const float* p = t_base + (size_t)uc * t_step;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float4 v = *reinterpret_cast<const float4*>(p + 8 * j + 4u * h);
@@ -458,7 +473,7 @@ void pqw_bprep(resources& res, const wide_prep& l)
   b.sorted_pairs = l.sorted_pairs; b.pair_off = l.pair_off; b.n_lists = l.n_lists; b.lbase = l.head ? 0u : l.n_lists; b.probes = l.probes;
   b.rot_queries = l.rot_queries; b.centers_rot = l.centers_rot; b.query_kth = l.query_kth; b.qflag = l.qflag;
   b.bq = static_cast<uint4*>(l.bq); b.thr = l.thr; b.norms = static_cast<float4*>(l.norms); b.n_probes = l.n_probes; b.rot_dim = l.rot_dim;
-  b.blk_off = l.blk_off;
+  b.blk_off = l.blk_off; b.is_ip = l.is_ip;
   b.heads = l.heads; b.sc = l.sc; b.c1 = l.c1; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = l.cbmax; b.dmax = l.dmax; b.bound_max = l.bound_max;
   b.head = l.head;
   if (l.n_pairs == 0) return;
@@ -473,7 +488,7 @@ void pqw_filter(resources& res, const wide_filter& l)
   wide_params g{};
   g.units = l.units; g.n_units = l.n_units; g.xcd_ticket = l.xcd_ticket; g.sorted_pairs = l.sorted_pairs; g.pair_off = l.pair_off;
   g.n_lists = l.n_lists; g.lbase = l.emit ? 0u : l.n_lists; g.bq = static_cast<const uint4*>(l.bq); g.thr = l.thr; g.blk_off = l.blk_off;
-  g.rows16 = static_cast<const uint4*>(l.rows16); g.row_term = l.row_term; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
+  g.rows16 = static_cast<const uint4*>(l.rows16); g.row_term = l.row_term; g.zeros = l.zeros; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
   g.surv_cnt = l.surv_cnt; g.surv_cap = l.surv_cap; g.spill_cap = l.spill_cap; g.n_probes = l.n_probes; g.xbuf = l.xbuf; g.ldx = l.ldx;
   g.heads = l.heads; g.stats = l.stats;
   const uint32_t nst = l.rot_dim / 16u;

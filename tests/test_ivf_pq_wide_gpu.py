@@ -70,32 +70,37 @@ def _wide_and_lut(index, q, k, monkeypatch, capfd, **kw):
     return gd, gi, sd, si, st
 
 
-@pytest.mark.parametrize("d,pq_dim,lut,acc,k", [
-    (768, 64, "f16", "f32", 10),    # pq_len 12: the CAGRA build's shape
-    (768, 64, "f16", "f16", 100),   # k = a fifth of a list: bound from several head lists
-    (768, 384, "f16", "f32", 10),   # pq_len 2: the reference's default pq_dim at 768 dimensions (LUT beyond the LDS: global LUT fallback)
-    (768, 192, "f32", "f32", 32),   # pq_len 4: the reference's CAGRA default (dim / 4)
-    (512, 64, "fp8", "f16", 20),    # pq_len 8, 32 K steps (4 chunks, ring of 2)
-    (384, 96, "f16", "f32", 20),    # pq_len 4, 24 K steps (3 chunks)
-    (256, 16, "f16", "f32", 20),    # pq_len 16, 16 K steps (2 chunks)
+@pytest.mark.parametrize("d,pq_dim,lut,acc,k,metric", [
+    (768, 64, "f16", "f32", 10, "sqeuclidean"),    # pq_len 12: the CAGRA build's shape
+    (768, 64, "f16", "f16", 100, "sqeuclidean"),   # k = a fifth of a list: bound from several head lists
+    (768, 384, "f16", "f32", 10, "sqeuclidean"),   # pq_len 2: the reference's default pq_dim at 768 dimensions (LUT beyond the LDS: global LUT fallback)
+    (768, 192, "f32", "f32", 32, "sqeuclidean"),   # pq_len 4: the reference's CAGRA default (dim / 4)
+    (512, 64, "fp8", "f16", 20, "sqeuclidean"),    # pq_len 8, 32 K steps (4 chunks, ring of 2)
+    (384, 96, "f16", "f32", 20, "sqeuclidean"),    # pq_len 4, 24 K steps (3 chunks)
+    (256, 16, "f16", "f32", 20, "sqeuclidean"),    # pq_len 16, 16 K steps (2 chunks)
+    (768, 384, "f16", "f32", 10, "inner_product"),  # score -(q.c + q.d): the query as the operand, no row terms, thresholds by filter_threshold_ip
+    (768, 64, "f16", "f16", 40, "cosine"),          # pq_len 12, two head lists
+    (512, 128, "fp8", "f32", 20, "inner_product"),  # signed fp8 LUT entries
+    (384, 96, "f32", "f32", 20, "cosine"),
 ])
-def test_wide_path_equals_oracle_and_lut_scan(d, pq_dim, lut, acc, k, monkeypatch, capfd):
+def test_wide_path_equals_oracle_and_lut_scan(d, pq_dim, lut, acc, k, metric, monkeypatch, capfd):
     from cuvs_amd.neighbors import ivf_pq
 
     # (modes as wide as they are apart: a query's neighbours sit in several of its probed lists - tail-phase survivors)
     x, q = _mixture(60_000, d, 400, seed=d + pq_dim, modes=200, sigma=1.0)
-    index = _pq_build(x, n_lists=32, pq_dim=pq_dim, pq_bits=8, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
+    index = _pq_build(x, n_lists=32, pq_dim=pq_dim, pq_bits=8, metric=metric, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
     ex = ivf_pq.export_for_oracle(index)
     n_probes = 12
     kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
     gd, gi, sd, si, st = _wide_and_lut(index, q, k, monkeypatch, capfd, **kw)
     assert st[0] > 0, "the wide filter did not run"
-    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, lut=lut, acc=acc)
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
     assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
     assert (gd == od).all()
     assert (si == oi).all() and (sd == od).all()
-    # the tail phase has survivors, and most pairs are dropped by the screen (the point of the path)
-    assert 0 < st[1] < 0.1 * st[0], st
+    # the tail phase has survivors, and most pairs are dropped by the screen (the point of the path; the margins of an unnormalised
+    # inner product scale with |q| (|c| + |d|), not with the score: looser)
+    assert 0 < st[1] < (0.1 if metric == "sqeuclidean" else 0.5) * st[0], st
 
 
 def test_wide_path_large_k_of_short_lists(monkeypatch, capfd):
@@ -163,7 +168,7 @@ def test_wide_path_hands_back_and_rebuilds(monkeypatch, capfd):
 
 @pytest.mark.parametrize("seed", list(range(16)))
 def test_wide_path_fuzz_against_lut_scan(seed, monkeypatch, capfd):
-    """random members of the wide class - dimension, pq_dim / pq_bits, row type, metric (L2 / L2Sqrt), list count (down to lists of a few
+    """random members of the wide class - dimension, pq_dim / pq_bits, row type, metric (L2 / L2Sqrt / inner product / cosine), list count (down to lists of a few
     rows and empty lists), probes, k (1 .. 256), LUT / score types, one or several internal batches - wide path == LUT scan kernels, ids
     and distances"""
     import torch
@@ -181,7 +186,7 @@ def test_wide_path_fuzz_against_lut_scan(seed, monkeypatch, capfd):
     n_probes = int(min(n_lists, rng.integers(9, 40)))
     k = int(rng.choice([1, 7, 32, 100, 256]))
     lut, acc = [("f16", "f32"), ("f16", "f16"), ("f32", "f32"), ("fp8", "f16"), ("fp8", "f32")][int(rng.integers(0, 5))]
-    metric = str(rng.choice(["sqeuclidean", "euclidean"]))
+    metric = str(rng.choice(["sqeuclidean", "euclidean", "inner_product", "cosine"]))
     x, q = _mixture(n, d, nq, seed=2000 + seed, modes=int(rng.choice([20, 200])), sigma=float(rng.choice([0.35, 1.0])))
     dtype = rng.choice(["f32", "f16", "i8"])
     if dtype == "f16":
