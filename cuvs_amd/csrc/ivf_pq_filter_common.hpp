@@ -131,6 +131,8 @@ struct wide_filter {
   const void* rows16;
   const float* row_term;  // [padded_rows] fp32 -|d|^2 (1 - 2^-9) sc^2 / 2: the accumulators' initial values (nullptr: inner product)
   const float* zeros;     // 32 zero floats
+  const uint32_t* filter_bits;  // emit: the pre-filter's bitset over source ids (nullptr: none) and the rows' source ids
+  const int64_t* indices;
   uint32_t* qflag;
   void* surv;             // one region of surv_cap entries per workgroup + a shared spill region of spill_cap entries
   uint32_t* surv_cnt;     // [grid + 1]

@@ -2922,6 +2922,7 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
   f.row_term = r.is_ip ? nullptr : reinterpret_cast<const float*>(tb.row_term); f.zeros = idx.scan3.zeros.data();
   f.qflag = r.qflag; f.surv = r.surv; f.surv_cnt = r.surv_cnt; f.surv_cap = 0; f.spill_cap = 0; f.n_probes = r.n_probes; f.rot_dim = idx.rot_dim;
   f.xbuf = hb.xbuf; f.ldx = hb.ldx; f.heads = r.head; f.emit = 1; f.grid = pq3_grid(res); f.stats = nullptr;
+  f.filter_bits = r.filter_bits; f.indices = idx.indices.data();
   pqw_filter(res, f);
   // the k largest values of every query over its head lists
   select_k<uint32_t, uint32_t>(res, hb.xbuf, nullptr, r.nq, (int64_t)r.head * hb.ldx, (int64_t)r.head * hb.ldx, (int)r.k, hb.kth_val, hb.kth_idx,

@@ -2116,11 +2116,12 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   }
   // The wide matrix-core path (ivf_pq_wide.hip): shapes pq_filter4_kernel does not decode (rot_dim beyond 256, pq_len not a power
   // of two) and searches whose k is too large a fraction of ONE list for its bound to prune (pq3_bound_useful) - the bound then
-  // comes from the union of `wheads` head lists. L2, no pre-filter (the bound-only head phase scores k rows per query: with a
-  // pre-filter they might not all be admissible), not on a list shard, batches large enough for a head phase.
+  // comes from the union of `wheads` head lists. Not on a list shard, batches large enough for a head phase. (A pre-filter is applied
+  // by the emit pass - rejected rows get the value -inf, so the k rows whose exact scores make the bound are admissible ones - and by
+  // the re-score.)
   uint32_t wheads = 0;
   if (!large_k && n_probes > 8 && n_queries >= 256 && res.tune.pq_scan3 != 0 && res.tune.pq_wide != 0 && res.tune.pq_head_probes < 0 &&
-      filter_bits == nullptr && idx.shard_world <= 1 && idx.shard_comm == nullptr && pqw_supported(idx, k) &&
+      idx.shard_world <= 1 && idx.shard_comm == nullptr && pqw_supported(idx, k) &&
       !(pq3_supported(idx, k) && pq3_bound_useful(idx, k) && ((idx.pq_len == 2 && idx.codebook_kind == 0) || res.tune.pq_filter4 != 0))) {
     wheads = res.tune.pq_wide_heads > 0 ? std::min<uint32_t>((uint32_t)res.tune.pq_wide_heads, n_probes / 2) : pqw_heads(idx, k, n_probes);
     if (wheads > 0 && !pqw_ready(res, idx)) wheads = 0;  // (no room for the decoded rows)

@@ -179,6 +179,8 @@ struct wide_params {
   const uint4* rows16;
   const float* row_term;
   const float* zeros;  // 32 zero floats (the rows' terms of an inner-product search)
+  const uint32_t* filter_bits;  // pre-filter (bitset over source ids) - the EMIT build writes -inf for the rows it rejects: the head
+  const int64_t* indices;       //   phase's k best rows, and with them the bound, are admissible ones
   uint32_t* qflag;
   uint2* surv;
   uint32_t* surv_cnt;
@@ -356,6 +358,18 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
         for (int s = 0; s < kWS; ++s) {
           const uint32_t u = u0 + (t * kWWaves + wave) * kWS + (uint32_t)s;
           if (u >= u1) continue;  // wave-uniform: a repeat of the last subtile
+          uint32_t adm = 0xffffffffu;  // EMIT: bit v = row v of the subtile passes the pre-filter
+          if constexpr (EMIT) {
+            if (a.filter_bits != nullptr) {  // wave-uniform
+              const uint32_t rr = (u << 5) + ql;
+              bool okr = false;
+              if (h == 0u && rr < r_end) {
+                const int64_t sid = a.indices[base_row + rr];
+                okr = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
+              }
+              adm = (uint32_t)__ballot(okr);  // (lanes 0 .. 31 are K half 0)
+            }
+          }
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
             const f32x16_t& ac = acc[s][g];
@@ -369,8 +383,9 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
                 for (int j = 0; j < 4; ++j) {
                   const uint32_t v0 = (u << 5) + 8u * j + 4u * h;
                   float4 o;
-                  o.x = v0 + 0u < r_end ? ac[4 * j + 0] + cadd : -INFINITY; o.y = v0 + 1u < r_end ? ac[4 * j + 1] + cadd : -INFINITY;
-                  o.z = v0 + 2u < r_end ? ac[4 * j + 2] + cadd : -INFINITY; o.w = v0 + 3u < r_end ? ac[4 * j + 3] + cadd : -INFINITY;
+                  const uint32_t am = adm >> (8u * j + 4u * h);  // rows 8 j + 4 h .. + 3 of the subtile
+                  o.x = (v0 + 0u < r_end && (am & 1u)) ? ac[4 * j + 0] + cadd : -INFINITY; o.y = (v0 + 1u < r_end && (am & 2u)) ? ac[4 * j + 1] + cadd : -INFINITY;
+                  o.z = (v0 + 2u < r_end && (am & 4u)) ? ac[4 * j + 2] + cadd : -INFINITY; o.w = (v0 + 3u < r_end && (am & 8u)) ? ac[4 * j + 3] + cadd : -INFINITY;
                   *reinterpret_cast<float4*>(xp + 8 * j) = o;
                 }
               }
@@ -488,7 +503,7 @@ void pqw_filter(resources& res, const wide_filter& l)
   wide_params g{};
   g.units = l.units; g.n_units = l.n_units; g.xcd_ticket = l.xcd_ticket; g.sorted_pairs = l.sorted_pairs; g.pair_off = l.pair_off;
   g.n_lists = l.n_lists; g.lbase = l.emit ? 0u : l.n_lists; g.bq = static_cast<const uint4*>(l.bq); g.thr = l.thr; g.blk_off = l.blk_off;
-  g.rows16 = static_cast<const uint4*>(l.rows16); g.row_term = l.row_term; g.zeros = l.zeros; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
+  g.rows16 = static_cast<const uint4*>(l.rows16); g.row_term = l.row_term; g.zeros = l.zeros; g.filter_bits = l.filter_bits; g.indices = l.indices; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
   g.surv_cnt = l.surv_cnt; g.surv_cap = l.surv_cap; g.spill_cap = l.spill_cap; g.n_probes = l.n_probes; g.xbuf = l.xbuf; g.ldx = l.ldx;
   g.heads = l.heads; g.stats = l.stats;
   const uint32_t nst = l.rot_dim / 16u;

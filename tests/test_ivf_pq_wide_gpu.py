@@ -204,3 +204,45 @@ def test_wide_path_fuzz_against_lut_scan(seed, monkeypatch, capfd):
     # (the wide path ran unless the rule found no head-list count: more than half of the probes)
     if st[0] == 0:
         pytest.skip(f"{desc}: the wide path's rule declined (k too large for the probed lists)")
+
+
+@pytest.mark.parametrize("metric,keep_frac", [("sqeuclidean", 0.6), ("inner_product", 0.3), ("sqeuclidean", 0.02)])
+def test_wide_path_with_a_bitset_prefilter(metric, keep_frac, monkeypatch, capfd):
+    """pre-filtered search (ivf_pq.hpp:1818-1828 with a bitset_filter): the emit pass gives rejected rows the value -inf (the bound's k
+    rows are admissible), the re-score drops rejected survivors - ids and distances equal to the oracle with the same bitset and to the
+    LUT scan kernels; at 2 % kept most queries find fewer than k admissible rows in their head lists and are handed back"""
+    import torch
+    from cuvs_amd._lib import BITSET
+    from cuvs_amd.neighbors import ivf_pq
+
+    n, nq, k, n_probes = 60_000, 400, 20, 12
+    x, q = _mixture(n, 768, nq, seed=31, modes=200, sigma=1.0)
+    keep = np.random.default_rng(5).random(n) < keep_frac
+    words = np.packbits(keep, bitorder="little")
+    words = np.concatenate([words, np.zeros((-len(words)) % 4, dtype=np.uint8)]).view(np.uint32)
+    index = _pq_build(x, n_lists=32, pq_dim=64, pq_bits=8, metric=metric, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
+    tw = torch.from_numpy(words.view(np.int32)).cuda()
+    sp = ivf_pq.SearchParams(n_probes=n_probes, lut_dtype=np.float16, internal_distance_dtype=np.float32)
+
+    def run():
+        d, i = ivf_pq.search(sp, index, torch.from_numpy(q).cuda(), k, filter=(tw, BITSET))
+        torch.cuda.synchronize()
+        return d.cpu().numpy(), i.cpu().numpy()
+
+    monkeypatch.setenv("CUVS_AMD_SCAN_DEBUG", "1024")
+    gd, gi = run()
+    st = _filter_stats()
+    capfd.readouterr()
+    monkeypatch.delenv("CUVS_AMD_SCAN_DEBUG")
+    assert st[0] > 0, "the wide filter did not run"
+    monkeypatch.setenv("CUVS_AMD_PQ_WIDE", "0")
+    sd, si = run()
+    monkeypatch.delenv("CUVS_AMD_PQ_WIDE")
+    od, oi = oracle.ivf_pq_search(ivf_pq.export_for_oracle(index), q, k, n_probes, metric=metric, lut="f16", acc="f32", keep_bits=words)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    assert (si == oi).all() and (sd == od).all()
+    found = gi[gi >= 0]
+    assert keep[found[found < n]].all(), "a rejected row came back"
+    if keep_frac < 0.1:
+        assert st[4] > 0, "no query was handed back"
