@@ -286,6 +286,8 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
     // 1 KiB rows; then thresholds and pair ids
     {
       const uint4* src = a.bq + ((size_t)a.blk_off[list] + ((first - a.pair_off[a.lbase + list]) >> 5)) * NST * 64 + lane;
+      // (measured and rejected: all 36 rows of a wave's share asked for before the first is stored - 144 more registers next to the
+      // first chunks' prefetch: 124 spilled, the prologue 45 k -> 80 k cycles)
 #pragma unroll 12
       for (uint32_t it = wave; it < ng * NST; it += kWWaves) Bs[it * 64 + lane] = src[(size_t)it * 64];
     }
