@@ -142,9 +142,19 @@ def ctl_tensor(values, dtype, dev, shared):
 
 
 def make_comm(sh, res, world, shared):
-    if world > 1:
-        return sh.ShardComm.from_torch(res, host_staged=shared)
-    return sh.ShardComm(0, 1, sh.ShardComm.unique_id(), res)
+    # (RCCL prints a version banner to fd 1 when its first communicator is made: stdout carries ONE JSON line, so fd 1 points at
+    # stderr while that happens)
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            return sh.ShardComm.from_torch(res, host_staged=shared)
+        return sh.ShardComm(0, 1, sh.ShardComm.unique_id(), res)
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep, 1)
+        os.close(keep)
 
 
 def cpu_baseline_line(c1_x=None, c1_q=None, dev=None):
