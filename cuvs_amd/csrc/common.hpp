@@ -93,6 +93,7 @@ struct tuning {
   int flat_bound_head   = 1;   // CUVS_AMD_FLAT_BOUND_HEAD=0: IVF-Flat's head phase scores the nearest lists exactly on the scan kernel (rounds 1-5) instead of the bound-only pass through the fp16 copy
   int pq_wide           = 1;   // CUVS_AMD_PQ_WIDE=0: IVF-PQ shapes outside pq_filter4_kernel (rot_dim > 256, odd pq_len, large k) stay on the LUT scan instead of the wide matrix-core path (ivf_pq_wide.hip)
   int pq_wide_heads     = 0;   // CUVS_AMD_PQ_WIDE_HEADS: head lists per query of that path (0: pqw_heads' rule)
+  int pq_wide_blocks    = 1;   // CUVS_AMD_PQ_WIDE_BLOCKS=0: the wide path's re-score at pq_len 2 by a wave per survivor (entries from memory) instead of pq_rescore_blocks_kernel (codebook staged in LDS block by block)
   int pq3_surv_cap      = 0;   // CUVS_AMD_PQ3_SURV_CAP: survivor-list entries of the matrix-core filter (test hook: forces the hand-back path)
   int pq_qcap           = 0;   // CUVS_AMD_PQ_QCAP: survivor-queue rows of pq_scan2_kernel (test hook: forces the overflow path)
   int scan_debug        = 0;   // CUVS_AMD_SCAN_DEBUG: ablation / statistics bits of the PQ scan

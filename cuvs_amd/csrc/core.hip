@@ -200,6 +200,7 @@ tuning load_tuning_from_env()
   t.flat_bound_head  = geti("CUVS_AMD_FLAT_BOUND_HEAD", 1);
   t.pq_wide          = geti("CUVS_AMD_PQ_WIDE", 1);
   t.pq_wide_heads    = geti("CUVS_AMD_PQ_WIDE_HEADS", 0);
+  t.pq_wide_blocks   = geti("CUVS_AMD_PQ_WIDE_BLOCKS", 1);
   t.pq3_surv_cap     = geti("CUVS_AMD_PQ3_SURV_CAP", 0);
   t.pq_qcap          = geti("CUVS_AMD_PQ_QCAP", 0);
   t.scan_debug       = geti("CUVS_AMD_SCAN_DEBUG", 0);

@@ -1455,6 +1455,136 @@ __global__ __launch_bounds__(256) void pq_rescore_wave_kernel(const rescore_para
   }
 }
 
+// ------------------------------------------------------------------ re-score with the codebook staged block by block (pq_len 2)
+// pq_rescore_wave_kernel reads a survivor's codebook entries from memory: at pq_len 2 that is an 8-byte piece per subspace, each in a
+// line of its own - 268 M L2 requests for ~1 M survivors at pq_dim 384 (profiles/r06_pmc_wide.json), the kernel's bound. The narrow
+// path's pq_rescore_kernel keeps the whole fp32 codebook in LDS (128 KiB at pq_dim 64); beyond that it does not fit - but a BLOCK of 64
+// subspaces does, and the score is a chain over the subspaces in order: a thread keeps the running sums of its survivors in
+// registers, the workgroup stages block after block (128 KiB, coalesced) and every thread adds the block's 64 entries of each of its
+// survivors - looked up in LDS - to their sums, in subspace order. Same arithmetic as pq_exact_score's pq_len-2 branch, entry by entry.
+constexpr int kRBThreads = 1024;  // 16 waves, one workgroup per CU
+constexpr int kRBItems   = 2;     // survivors per thread and round: 2048 per workgroup between two stagings of the codebook
+
+template <int LUT, bool ACC_HALF>
+__global__ __launch_bounds__(kRBThreads) void pq_rescore_blocks_kernel(const rescore_params a)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cb = reinterpret_cast<float*>(smem);  // the block's codebook: [64 subspaces][2 components][book]
+  const uint32_t blk_floats = 64u * 2u * a.book;
+  uint32_t* s_off = reinterpret_cast<uint32_t*>(smem + (size_t)blk_floats * 4u);  // [n_regions + 2] first batch of every region
+  const uint32_t n_reg = a.n_regions + 1u;
+  if (threadIdx.x == 0) {
+    uint32_t run = 0u;
+    for (uint32_t r = 0; r < n_reg; ++r) {
+      s_off[r] = run;
+      const uint32_t n = r == a.n_regions ? min(a.surv_cnt[r], a.spill_cap) : min(a.surv_cnt[r], a.surv_cap);
+      run += (n + 63u) >> 6;
+    }
+    s_off[n_reg] = run;
+  }
+  __syncthreads();
+  const uint32_t total = s_off[n_reg];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = kRBThreads / 64;
+  const uint32_t nb = a.n_chunks / 4u;  // blocks of 64 subspaces (pq_dim a multiple of 64)
+  const uint32_t per_round = n_waves * kRBItems;
+  for (uint32_t b0 = blockIdx.x * per_round; b0 < total; b0 += gridDim.x * per_round) {  // workgroup-uniform
+    bool ok[kRBItems];
+    uint32_t pair[kRBItems], row[kRBItems], q[kRBItems], L[kRBItems];
+    float af[kRBItems];
+    _Float16 ah[kRBItems];
+#pragma unroll
+    for (int i = 0; i < kRBItems; ++i) {
+      const uint32_t b = b0 + (uint32_t)i * n_waves + wave;  // wave-uniform
+      uint2 sv = make_uint2(0xffffffffu, 0u);
+      if (b < total) {
+        uint32_t lo = 0u, hi = n_reg;  // s_off[lo] <= b < s_off[hi]
+        while (hi - lo > 1u) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_off[mid] <= b) lo = mid; else hi = mid;
+        }
+        const uint32_t n  = lo == a.n_regions ? min(a.surv_cnt[lo], a.spill_cap) : min(a.surv_cnt[lo], a.surv_cap);
+        const uint32_t sx = (b - s_off[lo]) * 64u + lane;
+        if (sx < n) sv = a.surv[(size_t)lo * a.surv_cap + sx];
+      }
+      ok[i]   = sv.x != 0xffffffffu;
+      pair[i] = ok[i] ? sv.x : 0u; row[i] = ok[i] ? sv.y : 0u; q[i] = pair[i] / a.n_probes;
+      ok[i]   = ok[i] && a.qflag[q[i]] == 0u;  // flagged: re-done by the LUT scan
+      if (ok[i] && a.filter_bits != nullptr) {
+        const int64_t sid = a.indices[row[i]];
+        ok[i] = ((a.filter_bits[sid >> 5] >> (sid & 31)) & 1u) != 0u;
+      }
+      L[i]  = ok[i] ? a.probes[pair[i]] : 0u;
+      af[i] = 0.f; ah[i] = (_Float16)0.f;
+    }
+    for (uint32_t blk = 0; blk < nb; ++blk) {
+      __syncthreads();  // the previous block's lookups are done
+      {
+        const float4* src = reinterpret_cast<const float4*>(a.pq_centers + (size_t)blk * blk_floats);
+        for (uint32_t i = threadIdx.x; i < blk_floats / 4u; i += kRBThreads) reinterpret_cast<float4*>(cb)[i] = src[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kRBItems; ++i) {
+        if (!ok[i]) continue;
+        const float* rq = a.rot_queries + (size_t)q[i] * a.rot_dim;
+        const float* ct = a.centers_rot + (size_t)L[i] * a.rot_dim;
+        const uint4* cp = reinterpret_cast<const uint4*>(a.codes) + ((size_t)(row[i] >> 6) * a.n_chunks) * 64 + (row[i] & 63u);
+        auto add_entry = [&](float v) {  // one LUT entry in the reference's arithmetic: LUT type, then the score type's sum
+          if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, a.is_ip != 0);
+          if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
+            af[i] += v;
+          } else {
+            const _Float16 e = to_lut_half(v);
+            if constexpr (ACC_HALF) ah[i] += e; else af[i] += (float)e;
+          }
+        };
+#pragma unroll 1
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c          = (int)blk * 4 + cc;
+          const uint4 cw       = cp[c * 64];
+          const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float qq[16], cv[16], p0[8], p1[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 qv = *reinterpret_cast<const float4*>(rq + c * 32 + hh * 16 + j * 4),
+                           c4 = *reinterpret_cast<const float4*>(ct + c * 32 + hh * 16 + j * 4);
+              qq[j * 4] = qv.x; qq[j * 4 + 1] = qv.y; qq[j * 4 + 2] = qv.z; qq[j * 4 + 3] = qv.w;
+              cv[j * 4] = c4.x; cv[j * 4 + 1] = c4.y; cv[j * 4 + 2] = c4.z; cv[j * 4 + 3] = c4.w;
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+              const int bb        = hh * 8 + b;
+              const uint32_t code = (ws[bb >> 2] >> ((bb & 3) * 8)) & 0xffu;
+              const uint32_t e0   = (uint32_t)((cc * 16 + bb) * 2) * a.book + code;  // (inside the staged block)
+              p0[b] = cb[e0]; p1[b] = cb[e0 + a.book];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+              const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cv[b * 2], c1 = cv[b * 2 + 1];
+              float v;
+              if (!a.is_ip) {
+                const float d0 = (q0 - c0) - p0[b], d1 = (q1 - c1) - p1[b];
+                v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+              } else {
+                v = __fmaf_rn(-q0, c0, 0.f);
+                v = __fmaf_rn(-q0, p0[b], v);
+                v = __fmaf_rn(-q1, c1, v);
+                v = __fmaf_rn(-q1, p1[b], v);
+              }
+              add_entry(v);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kRBItems; ++i) pool_append_wave(a, ok[i], q[i], pair[i], row[i], ACC_HALF ? (float)ah[i] : af[i]);
+  }
+}
+
 // ------------------------------------------------------------------ the wide path's bound-only head phase (ivf_pq_wide.hip)
 // As IVF-Flat's (flat_head_bound_kernel): the emit pass left a value for every (head pair, row) - larger is nearer, comparable
 // across a query's head lists (the pair's constant -|r|^2 sc^2 / 2 is added) - and select_k the k largest of every QUERY over the
@@ -3000,9 +3130,18 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   // a wave per survivor (pq_rescore_wave_kernel): the batches of all regions dealt to 8 workgroups of 4 waves per CU
   const dim3 rg(grid, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
+  // pq_len 2 with whole blocks of 64 subspaces: the codebook staged block by block in LDS (pq_rescore_blocks_kernel)
+  const bool blocks = idx.pq_len == 2 && idx.pq_dim % 64 == 0 && res.tune.pq_wide_blocks != 0;
   auto rescore = [&](auto lut_tag, auto acc_tag) {
     constexpr int LUT = decltype(lut_tag)::value;
     constexpr bool ACC = decltype(acc_tag)::value;
+    if (blocks) {
+      const size_t sm = (size_t)64 * 2 * idx.pq_book * sizeof(float) + ((size_t)grid + 3) * sizeof(uint32_t);
+      auto kern = pq_rescore_blocks_kernel<LUT, ACC>;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(kRBThreads), sm, res.stream, s);
+      return;
+    }
     const size_t sm = 4 * wave_score_tile<LUT, ACC>::kBytes + ((size_t)grid + 3) * sizeof(uint32_t);
     auto kern = pq_rescore_wave_kernel<LUT, ACC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));
