@@ -3130,7 +3130,9 @@ void pqw_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r, const p
   // a wave per survivor (pq_rescore_wave_kernel): the batches of all regions dealt to 8 workgroups of 4 waves per CU
   const dim3 rg(grid, 8), rb(256);
   profile_begin(res, "pq_rescore_kernel");
-  // pq_len 2 with whole blocks of 64 subspaces: the codebook staged block by block in LDS (pq_rescore_blocks_kernel)
+  // pq_len 2 with whole blocks of 64 subspaces: the codebook staged block by block in LDS (pq_rescore_blocks_kernel). (Measured and
+  // rejected for longer entries - a lane per survivor walking the block's subspaces one by one, pq_len lookups each: 1M x 768, pq_len 4:
+  // 3.74 -> 4.25 ms per 10k queries, pq_len 12: 2.90 -> 3.31 - the wave per survivor reads such entries as whole 16-byte pieces.)
   const bool blocks = idx.pq_len == 2 && idx.pq_dim % 64 == 0 && res.tune.pq_wide_blocks != 0;
   auto rescore = [&](auto lut_tag, auto acc_tag) {
     constexpr int LUT = decltype(lut_tag)::value;
