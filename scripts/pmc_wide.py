@@ -26,7 +26,7 @@ def run():
     res.sync(); torch.cuda.synchronize()
 
 
-TAGS = ("pqw_filter_kernel", "pq_rescore_wave_kernel", "pqw_head_bound_kernel", "pqw_bprep_kernel", "pqw_head_survivors_kernel")
+TAGS = ("pqw_filter_kernel", "pq_rescore_blocks_kernel", "pq_rescore_wave_kernel", "pqw_head_bound_kernel", "pqw_bprep_kernel", "pqw_head_survivors_kernel")
 
 
 def summarize(d, out):
