@@ -141,9 +141,25 @@ def ctl_tensor(values, dtype, dev, shared):
     return torch.tensor(values, dtype=dtype, device="cpu" if shared else dev)
 
 
+def flush_c_stdio_to_stderr():
+    """RCCL writes its start-up banner through C stdio whenever it initialises (a buffered write that surfaces at the next flush or at
+    exit): stdout carries ONE JSON line, so whatever C stdio holds is flushed with fd 1 pointing at stderr"""
+    try:
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            C.CDLL(None).fflush(None)
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
+    except Exception:
+        pass
+
+
 def make_comm(sh, res, world, shared):
-    # (RCCL prints a version banner to fd 1 when its first communicator is made: stdout carries ONE JSON line, so fd 1 points at
-    # stderr while that happens)
+    # (RCCL prints a version banner through C stdio when its first communicator is made: stdout carries ONE JSON line, so fd 1 points
+    # at stderr while that happens and until the buffer is flushed)
     sys.stdout.flush()
     keep = os.dup(1)
     os.dup2(2, 1)
@@ -153,6 +169,7 @@ def make_comm(sh, res, world, shared):
         return sh.ShardComm(0, 1, sh.ShardComm.unique_id(), res)
     finally:
         sys.stdout.flush()
+        C.CDLL(None).fflush(None)  # (the banner sits in C stdio's buffer: it is written - to stderr - now)
         os.dup2(keep, 1)
         os.close(keep)
 
@@ -557,10 +574,7 @@ def run_c5(args):
         recall = recall_of(out_i[:ng].cpu().numpy(), best_i.cpu().numpy())
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        try:
-            C.CDLL(None).fflush(None)  # RCCL's start-up banner (C stdio) before the JSON line
-        except Exception:
-            pass
+        flush_c_stdio_to_stderr()  # RCCL's start-up banner (C stdio) must not share stdout with the JSON line
         print(json.dumps({
             "metric": f"QPS, IVF-PQ {rows}x96 int8 list-sharded, batch={args.batch} per GPU", "value": round(nq_total / (ms * 1e-3), 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
@@ -1456,12 +1470,9 @@ def main():
                                           "scaling figure") if shared_dev else "RCCL (ncclAllGather / ncclAllReduce over xGMI)"
             out["config"]["oversubscribed"] = bool(shared_dev)
             out["config"]["devices_visible"] = torch.cuda.device_count()
-        # RCCL writes its start-up banner through C stdio (the one-rank sharded line initialises a communicator): flush it
-        # first, so that the JSON line is the LAST line on stdout
-        try:
-            C.CDLL(None).fflush(None)
-        except Exception:
-            pass
+        # RCCL writes its start-up banner through C stdio (the one-rank sharded line initialises a communicator): it goes to stderr,
+        # the JSON line is the ONLY line on stdout
+        flush_c_stdio_to_stderr()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()  # rank 0 may still be in its CPU leg: nobody tears the communicators down under it
