@@ -13,8 +13,8 @@
 //              sit in LDS for the whole unit ([3 groups][K steps][64 lanes] x 16 bytes = 144 KiB at 768 dimensions);
 //   wave       one per SIMD with up to 512 registers; takes strips of 64 rows: 2 subtiles x 3 query groups of fp32 accumulators
 //              (96 registers), initialised with the rows' terms; the A operands of the strip arrive in chunks of 8 K steps
-//              through a ring of 3 (2) register sets (64 registers each), a chunk is asked for two chunks (~4 k cycles of matrix
-//              work) before it is multiplied; per K step 3 ds_read_b128 (B) feed 6 MFMAs;
+//              through a ring of 2 (384-d: 3) register sets (64 registers each), a chunk is asked for one chunk (~1.5 k cycles
+//              of matrix work) before it is multiplied; per K step 3 ds_read_b128 (B) feed 6 MFMAs;
 //   epilogue   at the end of the strip's K loop: a pair survives when acc >= thr (as in the other filters).
 // EMIT build: the bound-only head phase (values to a buffer instead of the compare), as IVF-Flat's (3.1c).
 #include "ivf_pq_filter_common.hpp"
@@ -194,7 +194,13 @@ template <int NCHUNK, bool EMIT>
 __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params a)
 {
   constexpr int NST = NCHUNK * kWKC;
-  constexpr int R   = NCHUNK % 3 == 0 ? 3 : 2;  // register sets of the A-operand ring
+  // The ring of A-operand register sets: a chunk is asked for R - 1 chunks before it is multiplied. Three sets (192 registers, 16 K steps
+  // ~ 3 k cycles ahead) made the 768-d kernel spill 69 registers - and a reload from scratch is the YOUNGEST entry of the wave's in-order
+  // memory queue: waiting for it drains every row load in flight (23 k cycles per strip against 9.2 k of MFMA issue). Two sets: no spill,
+  // 19.8 k per strip (with cache-hot rows 14.5 k: a quarter of the strip is still exposed row latency). Chunks of 2 K steps in a ring of
+  // 6 or 8 (the depth of three sets for the registers of two) spilled again (9 .. 93 registers: the longer unrolled body) and measured
+  // the same 20.5 k.
+  constexpr int R   = NCHUNK % 2 == 0 ? 2 : 3;  // register sets of the A-operand ring
   static_assert(NCHUNK % R == 0, "a chunk's register set must not depend on the strip");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Bs        = reinterpret_cast<uint4*>(smem);                              // [kWNG][NST][64 lanes] x 16 B
