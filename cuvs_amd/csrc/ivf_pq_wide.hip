@@ -190,17 +190,19 @@ struct wide_params {
   unsigned long long* stats;  // optional [8]: [0] pairs screened, [1] survivors, [2] strips, [7] units
 };
 
-template <int NCHUNK, bool EMIT>
+template <int N8, bool EMIT>
 __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params a)
 {
-  constexpr int NST = NCHUNK * kWKC;
+  constexpr int NST    = N8 * kWKC;            // K steps: the kernel is built per 128 dimensions of the rows
+  constexpr int KC     = N8 % 2 == 0 ? 8 : 4;  // K steps of an A-operand chunk (384 dimensions: 6 chunks of 4 - an even number for the ring of two)
+  constexpr int NCHUNK = NST / KC;
   // The ring of A-operand register sets: a chunk is asked for R - 1 chunks before it is multiplied. Three sets (192 registers, 16 K steps
   // ~ 3 k cycles ahead) made the 768-d kernel spill 69 registers - and a reload from scratch is the YOUNGEST entry of the wave's in-order
   // memory queue: waiting for it drains every row load in flight (23 k cycles per strip against 9.2 k of MFMA issue). Two sets: no spill,
   // 19.8 k per strip (with cache-hot rows 14.5 k: a quarter of the strip is still exposed row latency). Chunks of 2 K steps in a ring of
   // 6 or 8 (the depth of three sets for the registers of two) spilled again (9 .. 93 registers: the longer unrolled body) and measured
   // the same 20.5 k.
-  constexpr int R   = NCHUNK % 2 == 0 ? 2 : 3;  // register sets of the A-operand ring
+  constexpr int R   = N8 == 3 ? 3 : 2;  // register sets of the A-operand ring (384 dimensions: three sets of 4 K steps fit without a spill)
   static_assert(NCHUNK % R == 0, "a chunk's register set must not depend on the strip");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Bs        = reinterpret_cast<uint4*>(smem);                              // [kWNG][NST][64 lanes] x 16 B
@@ -254,14 +256,14 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
     const float* t_base   = a.row_term != nullptr ? a.row_term + base_row : a.zeros;
     const uint32_t t_step = a.row_term != nullptr ? 32u : 0u;
 
-    // a chunk of a strip: kWKC K steps of its kWS subtiles (subtiles past the end repeat the last one and are not screened)
-    auto load_chunk = [&](u32x4_t (&av)[kWKC][kWS], const uint32_t t, const int c) {
+    // a chunk of a strip: KC K steps of its kWS subtiles (subtiles past the end repeat the last one and are not screened)
+    auto load_chunk = [&](u32x4_t (&av)[KC][kWS], const uint32_t t, const int c) {
 #pragma unroll
       for (int s = 0; s < kWS; ++s) {
         const uint32_t uc = min(u0 + (t * kWWaves + wave) * kWS + (uint32_t)s, u1 - 1u);
-        const uint4* p = a_base + ((size_t)uc * NST + (size_t)c * kWKC) * 64;
+        const uint4* p = a_base + ((size_t)uc * NST + (size_t)c * KC) * 64;
 #pragma unroll
-        for (int st = 0; st < kWKC; ++st) {
+        for (int st = 0; st < KC; ++st) {
           const uint4 v = p[st * 64 + lane];
           av[st][s] = u32x4_t{v.x, v.y, v.z, v.w};
         }
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
       }
     };
     const unsigned long long t_unit = a.stats != nullptr ? __builtin_readcyclecounter() : 0ull;
-    u32x4_t av[R][kWKC][kWS];
+    u32x4_t av[R][KC][kWS];
     f32x16_t tv[kWS];
     if (n_mine != 0u) {  // the first chunks of the wave's first strip are on their way while the unit's operands are copied
       load_terms(tv, 0u);
@@ -345,9 +347,9 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
           if (cp < NCHUNK) load_chunk(av[cp % R], t, cp); else load_chunk(av[cp % R], tn, cp - NCHUNK);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int st = 0; st < kWKC; ++st) {
+          for (int st = 0; st < KC; ++st) {
             // B operands of the NEXT K step are read while this step's MFMAs run (the step after the strip's last one: the first again)
-            const int kn = (c * kWKC + st + 1) % NST;
+            const int kn = (c * KC + st + 1) % NST;
             load_b(bn, kn);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
