@@ -1656,6 +1656,135 @@ __global__ __launch_bounds__(256) void pqw_head_bound_kernel(const wbound_params
   }
 }
 
+// pq_len 2: the bound's candidates scored with the codebook staged block by block in LDS (pq_rescore_blocks_kernel's scheme: a wave
+// per candidate reads 8-byte entries one line each; 0.37 ms of a 3.2 ms search at k = 10, most of the head phase at k = 100). A thread
+// takes candidates (query q, j-th best value); the largest exact score of a query's k candidates is collected by atomicMax on its
+// order-preserving key (tmp[q], zeroed), a candidate slot without a row raises tmp[nq + q]; pqw_bound_finish_kernel turns both into
+// the query's bound and the head pairs' thresholds.
+template <int LUT, bool ACC_HALF>
+__global__ __launch_bounds__(kRBThreads) void pqw_bound_blocks_kernel(const wbound_params a, uint32_t* __restrict__ tmp)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* cb = reinterpret_cast<float*>(smem);  // the block's codebook: [64 subspaces][2 components][book]
+  const rescore_params& rs = a.rs;
+  const uint32_t blk_floats = 64u * 2u * rs.book;
+  const uint32_t nb = rs.n_chunks / 4u;
+  const uint64_t total = (uint64_t)a.nq * a.k;
+  const uint64_t per_round = (uint64_t)kRBThreads * kRBItems;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * per_round; i0 < total; i0 += (uint64_t)gridDim.x * per_round) {  // workgroup-uniform
+    bool ok[kRBItems];
+    uint32_t q[kRBItems], L[kRBItems], row[kRBItems];
+    float af[kRBItems];
+    _Float16 ah[kRBItems];
+#pragma unroll
+    for (int i = 0; i < kRBItems; ++i) {
+      const uint64_t ix = i0 + (uint64_t)i * kRBThreads + threadIdx.x;
+      ok[i] = false; q[i] = 0u; L[i] = 0u; row[i] = 0u; af[i] = 0.f; ah[i] = (_Float16)0.f;
+      if (ix < total) {
+        q[i] = (uint32_t)(ix / a.k);
+        if (!(a.kth_val[ix] > -INFINITY)) {
+          tmp[a.nq + q[i]] = 1u;  // fewer than k rows in the head lists: no finite bound
+        } else {
+          const uint32_t id = a.kth_idx[ix], rank = id / a.ldx, r = id - rank * a.ldx;
+          L[i]   = a.probes[(size_t)q[i] * a.n_probes + rank];
+          row[i] = a.list_offsets[L[i]] + r;
+          ok[i]  = true;
+        }
+      }
+    }
+    for (uint32_t blk = 0; blk < nb; ++blk) {
+      __syncthreads();
+      {
+        const float4* src = reinterpret_cast<const float4*>(rs.pq_centers + (size_t)blk * blk_floats);
+        for (uint32_t i = threadIdx.x; i < blk_floats / 4u; i += kRBThreads) reinterpret_cast<float4*>(cb)[i] = src[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kRBItems; ++i) {
+        if (!ok[i]) continue;
+        const float* rq = rs.rot_queries + (size_t)q[i] * rs.rot_dim;
+        const float* ct = rs.centers_rot + (size_t)L[i] * rs.rot_dim;
+        const uint4* cp = reinterpret_cast<const uint4*>(rs.codes) + ((size_t)(row[i] >> 6) * rs.n_chunks) * 64 + (row[i] & 63u);
+        auto add_entry = [&](float v) {
+          if constexpr (LUT == 2) v = fp8_round_trip<std::conditional_t<ACC_HALF, __half, float>>(v, rs.is_ip != 0);
+          if constexpr (LUT == 0 || (LUT == 2 && !ACC_HALF)) {
+            af[i] += v;
+          } else {
+            const _Float16 e = to_lut_half(v);
+            if constexpr (ACC_HALF) ah[i] += e; else af[i] += (float)e;
+          }
+        };
+#pragma unroll 1
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c          = (int)blk * 4 + cc;
+          const uint4 cw       = cp[c * 64];
+          const uint32_t ws[4] = {cw.x, cw.y, cw.z, cw.w};
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float qq[16], cv[16], p0[8], p1[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4 qv = *reinterpret_cast<const float4*>(rq + c * 32 + hh * 16 + j * 4),
+                           c4 = *reinterpret_cast<const float4*>(ct + c * 32 + hh * 16 + j * 4);
+              qq[j * 4] = qv.x; qq[j * 4 + 1] = qv.y; qq[j * 4 + 2] = qv.z; qq[j * 4 + 3] = qv.w;
+              cv[j * 4] = c4.x; cv[j * 4 + 1] = c4.y; cv[j * 4 + 2] = c4.z; cv[j * 4 + 3] = c4.w;
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+              const int bb        = hh * 8 + b;
+              const uint32_t code = (ws[bb >> 2] >> ((bb & 3) * 8)) & 0xffu;
+              const uint32_t e0   = (uint32_t)((cc * 16 + bb) * 2) * rs.book + code;
+              p0[b] = cb[e0]; p1[b] = cb[e0 + rs.book];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+              const float q0 = qq[b * 2], q1 = qq[b * 2 + 1], c0 = cv[b * 2], c1 = cv[b * 2 + 1];
+              float v;
+              if (!rs.is_ip) {
+                const float d0 = (q0 - c0) - p0[b], d1 = (q1 - c1) - p1[b];
+                v = __fmaf_rn(d1, d1, __fmaf_rn(d0, d0, 0.f));
+              } else {
+                v = __fmaf_rn(-q0, c0, 0.f);
+                v = __fmaf_rn(-q0, p0[b], v);
+                v = __fmaf_rn(-q1, c1, v);
+                v = __fmaf_rn(-q1, p1[b], v);
+              }
+              add_entry(v);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kRBItems; ++i)
+      if (ok[i]) atomicMax(&tmp[q[i]], float_to_key(ACC_HALF ? (float)ah[i] : af[i]));
+  }
+}
+
+__global__ __launch_bounds__(256) void pqw_bound_finish_kernel(const wbound_params a, const uint32_t* __restrict__ tmp)
+{
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63u;
+  if (q >= a.nq) return;  // wave-uniform
+  const bool no_bound = tmp[a.nq + q] != 0u || tmp[q] == 0u;  // (no candidate scored: k rows there are not)
+  const uint32_t key  = no_bound ? 0xffffffffu : tmp[q];
+  const float bound   = no_bound ? INFINITY : key_to_float(key);
+  bool hand_back = no_bound;
+  for (uint32_t rank = lane; rank < a.heads; rank += 64u) {
+    const float4 nm   = a.norms[(size_t)q * a.heads + rank];
+    const bool served = key < 0xff800000u && nm.w < 60000.f && fabsf(bound) <= a.bound_max;
+    hand_back = hand_back || !served;
+    const float t = a.is_ip ? filter_threshold_ip(bound, nm.x, nm.y, nm.z, a) : filter_threshold(bound, nm.x, a);
+    a.thr_head[(size_t)q * a.heads + rank] = served ? t / a.c1 + (a.is_ip ? a.sc * a.sc * nm.z : -0.5f * a.sc * a.sc * nm.x) : INFINITY;
+  }
+  const bool any_back = __ballot(hand_back) != 0ull;
+  if (lane == 0u) {
+    a.query_kth[q] = key;
+    if (any_back) a.qflag[q] = 1u;
+  }
+}
+
 // the head pairs' own candidates: rows whose value reaches the pair's threshold -> the survivor regions, BEHIND the filter (the
 // regions' fills are final); one wave per head pair (flat_head_survivors_kernel's scheme; a full buffer flags the query)
 __global__ __launch_bounds__(256) void pqw_head_survivors_kernel(const float* __restrict__ xbuf, uint32_t ldx, const float* __restrict__ thr_head,
@@ -3066,9 +3195,20 @@ bool pqw_head_bounds(resources& res, const ivf_pq_index& idx, const pq3_run& r, 
   b.rot_dim = idx.rot_dim; b.query_kth = const_cast<uint32_t*>(r.query_kth); b.qflag = r.qflag; b.thr_head = hb.thr_head;
   b.sc = tb.sc; b.c1 = c1; b.eps = eps; b.alpha = alpha; b.cbmax = tb.cbmax; b.dmax = tb.dmax; b.bound_max = bound_max; b.is_ip = r.is_ip;
   const dim3 bgrid((unsigned)grid_blocks(r.nq, 4));
+  const bool bblocks = idx.pq_len == 2 && idx.pq_dim % 64 == 0 && res.tune.pq_wide_blocks != 0 && hb.bound_tmp != nullptr;
   auto bound = [&](auto lut_tag, auto acc_tag) {
     constexpr int LUT = decltype(lut_tag)::value;
     constexpr bool ACC = decltype(acc_tag)::value;
+    if (bblocks) {
+      HIP_TRY(hipMemsetAsync(hb.bound_tmp, 0, (size_t)2 * r.nq * sizeof(uint32_t), res.stream));
+      const size_t smb = (size_t)64 * 2 * idx.pq_book * sizeof(float);
+      auto kb = pqw_bound_blocks_kernel<LUT, ACC>;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smb));
+      const unsigned gb = (unsigned)std::min<int64_t>(pq3_grid(res), grid_blocks(r.nq * (int64_t)r.k, kRBThreads * kRBItems));
+      hipLaunchKernelGGL(kb, dim3(gb), dim3(kRBThreads), smb, res.stream, b, hb.bound_tmp);
+      hipLaunchKernelGGL(pqw_bound_finish_kernel, bgrid, dim3(256), 0, res.stream, b, hb.bound_tmp);
+      return;
+    }
     const size_t sm = 4 * wave_score_tile<LUT, ACC>::kBytes;
     auto kern = pqw_head_bound_kernel<LUT, ACC>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm));

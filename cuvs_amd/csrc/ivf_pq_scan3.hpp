@@ -154,6 +154,7 @@ struct pqw_bufs {
   void* norms;                        // [nq * heads] x 16 bytes
   uint32_t* tickets;                  // 8 x 32 zeroed words
   uint32_t* blk_off;                  // [n_lists + 1] scratch: first operand block of every list (head pairs, then tail pairs)
+  uint32_t* bound_tmp;                // [2 nq] scratch of the bound kernels (largest score key, short-list flag)
 };
 // r.head = heads. Returns false (nothing launched) when the decoded copy cannot be made: the caller runs the exact head phase and
 // the LUT scan. Leaves r.query_kth (bounds) and hb.thr_head; queries without a bound (fewer than k rows in their head lists) flagged.

@@ -2213,7 +2213,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
   // the wide path's bound-only head phase: values of every (head pair, row), the k best of every query, the head pairs' thresholds
   dev_buf<float> w_x(res, usew ? (size_t)bs_alloc * wheads * w_ldx : 0), w_kv(res, usew ? (size_t)bs_alloc * k : 0);
   dev_buf<float> w_thr(res, usew ? (size_t)bs_alloc * wheads : 0), w_c(res, usew ? (size_t)bs_alloc * wheads : 0);
-  dev_buf<uint32_t> w_ki(res, usew ? (size_t)bs_alloc * k : 0), w_blk(res, usew ? (size_t)idx.n_lists + 1 : 0);
+  dev_buf<uint32_t> w_ki(res, usew ? (size_t)bs_alloc * k : 0), w_blk(res, usew ? (size_t)idx.n_lists + 1 : 0), w_bt(res, usew ? (size_t)2 * bs_alloc : 0);
   dev_buf<float4> w_nm(res, usew ? (size_t)bs_alloc * wheads : 0);
   // two-stream schedule (the bench shape and every other search whose head phase is one single-pair item per query and whose
   // tail phase runs pq_filter4_kernel): grouping, work units and B operands on the helper stream, next to the head kernel
@@ -2435,7 +2435,7 @@ void ivf_pq_search(resources& res, const ivf_pq_search_params& p, const ivf_pq_i
           r.stage = 2;
         }
         if (usew) {
-          const pqw_bufs hb{w_x.data(), w_ldx, w_kv.data(), w_ki.data(), w_thr.data(), w_c.data(), w_nm.data(), tickets.data(), w_blk.data()};
+          const pqw_bufs hb{w_x.data(), w_ldx, w_kv.data(), w_ki.data(), w_thr.data(), w_c.data(), w_nm.data(), tickets.data(), w_blk.data(), w_bt.data()};
           const bool ok = pqw_head_bounds(res, idx, r, hb);
           CUVS_EXPECTS(ok, "ivf_pq: the wide path's decoded rows are gone");
           pqw_tail(res, idx, r, hb);
