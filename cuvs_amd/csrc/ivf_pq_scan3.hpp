@@ -137,7 +137,7 @@ void pq3_warm(resources& res, const ivf_pq_index& idx, bool filter4);
 void pq3_tail(resources& res, const ivf_pq_index& idx, const pq3_run& r);
 void pq3_merge(resources& res, const pq3_run& r, float* top_d, uint32_t* top_i);
 
-// ---- the wide path (ivf_pq_wide.hip): rot_dim 256 .. 768 in steps the kernel is built for, any pq_len, PER_SUBSPACE, L2; the head
+// ---- the wide path (ivf_pq_wide.hip): rot_dim 256 .. 768 in steps the kernel is built for, any pq_len, PER_SUBSPACE, every metric, pre-filters; the head
 // phase is a BOUND-ONLY pass over the `heads` nearest lists of every query (their union bounds the k-th score: k may be a large
 // fraction of ONE list), through the filter in its emit form; both phases read the index's decoded fp16 rows (scan3_cache::rows16w)
 bool pqw_supported(const ivf_pq_index& idx, int k);

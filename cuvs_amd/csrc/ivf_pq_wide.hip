@@ -13,10 +13,11 @@
 //              sit in LDS for the whole unit ([3 groups][K steps][64 lanes] x 16 bytes = 144 KiB at 768 dimensions);
 //   wave       one per SIMD with up to 512 registers; takes strips of 64 rows: 2 subtiles x 3 query groups of fp32 accumulators
 //              (96 registers), initialised with the rows' terms; the A operands of the strip arrive in chunks of 8 K steps
-//              through a ring of 2 (384-d: 3) register sets (64 registers each), a chunk is asked for one chunk (~1.5 k cycles
-//              of matrix work) before it is multiplied; per K step 3 ds_read_b128 (B) feed 6 MFMAs;
+//              (384 dimensions: of 4) through a ring of 2 (384-d: 3) register sets, a chunk is asked for one chunk (~1.5 k
+//              cycles of matrix work) before it is multiplied; per K step 3 ds_read_b128 (B) feed 6 MFMAs;
 //   epilogue   at the end of the strip's K loop: a pair survives when acc >= thr (as in the other filters).
-// EMIT build: the bound-only head phase (values to a buffer instead of the compare), as IVF-Flat's (3.1c).
+// EMIT build: the bound-only head phase (values to a buffer instead of the compare), as IVF-Flat's (3.1c). Inner product / cosine:
+// the query itself is the operand and the accumulators start from zero (pqw_bprep_kernel, filter_threshold_ip).
 #include "ivf_pq_filter_common.hpp"
 
 #include <cfloat>
