@@ -42,39 +42,63 @@ __global__ __launch_bounds__(256) void refine_kernel(const T* __restrict__ data,
     for (int off = 32; off > 0; off >>= 1) qn = qn + __shfl_xor(qn, off, kWave);
     qn = sqrtf(qn);
   }
-  for (int c = wave; c < n_cand; c += 4) {
-    const int64_t id = cand[q * n_cand + c];
-    if (id < 0 || id >= n) {  // wave-uniform. refine_host.hpp:440-442: the candidate stays, with distance = max and its own id
-      if (lane == 0) {
-        s_key[c] = float_to_key(FLT_MAX);  // (inner product: the sort key is -q.x there too - max sorts last under either rule)
-        s_idx[c] = id;
-      }
-      continue;
+  // Four candidates of a wave at a time: a candidate is ONE memory round trip (its row's loads are issued together) and a wave that
+  // takes them one after the other spends its time waiting for HBM (a CAGRA build's refine of 256 candidates per row: 3.9 ms per
+  // 16384 queries). The sums are the same strided partial sums per row, row by row.
+  constexpr int U = 4;
+  for (int c0 = wave; c0 < n_cand; c0 += 4 * U) {
+    int64_t id[U];
+    bool valid[U];
+    float acc[U], xn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      id[u]    = c < n_cand ? cand[q * n_cand + c] : -1;
+      valid[u] = c < n_cand && id[u] >= 0 && id[u] < n;  // wave-uniform
+      acc[u] = 0.f; xn[u] = 0.f;
     }
-    const T* row = data + id * dim;
-    float acc    = 0.f, xn = 0.f;
     for (int64_t j = lane; j < dim; j += kWave) {
-      float a = to_float(qv[j]), b = to_float(row[j]);
-      if (cosm) {
-        acc = __fmaf_rn(a, b, acc);
-        xn  = __fmaf_rn(b, b, xn);
-      } else if (ip) {
-        acc = __fmaf_rn(a, b, acc);
-      } else {
-        float t = a - b;
-        acc     = __fmaf_rn(t, t, acc);
+      const float a = to_float(qv[j]);
+      float b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) b[u] = to_float(data[(valid[u] ? id[u] : 0) * dim + j]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (cosm) {
+          acc[u] = __fmaf_rn(a, b[u], acc[u]);
+          xn[u]  = __fmaf_rn(b[u], b[u], xn[u]);
+        } else if (ip) {
+          acc[u] = __fmaf_rn(a, b[u], acc[u]);
+        } else {
+          const float t = a - b[u];
+          acc[u]        = __fmaf_rn(t, t, acc[u]);
+        }
       }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc = acc + __shfl_xor(acc, off, kWave);
-    if (cosm) {
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + 4 * u;
+      if (c >= n_cand) continue;  // wave-uniform
+      if (!valid[u]) {  // refine_host.hpp:440-442: the candidate stays, with distance = max and its own id
+        if (lane == 0) {
+          s_key[c] = float_to_key(FLT_MAX);  // (inner product: the sort key is -q.x there too - max sorts last under either rule)
+          s_idx[c] = id[u];
+        }
+        continue;
+      }
+      float av = acc[u];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) xn = xn + __shfl_xor(xn, off, kWave);
-      acc = 1.0f - acc / (qn * sqrtf(xn));  // the brute-force epilogue (distance_tile.hpp finish_distance)
-    }
-    if (lane == 0) {
-      s_key[c] = ip ? ~float_to_key(acc) : float_to_key(acc);  // inner product: larger is better
-      s_idx[c] = id;
+      for (int off = 32; off > 0; off >>= 1) av = av + __shfl_xor(av, off, kWave);
+      if (cosm) {
+        float xv = xn[u];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) xv = xv + __shfl_xor(xv, off, kWave);
+        av = 1.0f - av / (qn * sqrtf(xv));  // the brute-force epilogue (distance_tile.hpp finish_distance)
+      }
+      if (lane == 0) {
+        s_key[c] = ip ? ~float_to_key(av) : float_to_key(av);  // inner product: larger is better
+        s_idx[c] = id[u];
+      }
     }
   }
   __syncthreads();
