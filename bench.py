@@ -141,6 +141,30 @@ def ctl_tensor(values, dtype, dev, shared):
     return torch.tensor(values, dtype=dtype, device="cpu" if shared else dev)
 
 
+_REAL_STDOUT = None
+
+
+def capture_stdout():
+    """From here on fd 1 of this process IS stderr: libraries write to it from C / C++ (RCCL's start-up banner through C stdio, flushed
+    whenever; gloo's "[Gloo] Rank 0 is connected to ..." notes) - on every rank, and a launcher merges the ranks' stdout. The ONE JSON
+    line goes to the saved descriptor (emit_json)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(obj):
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    line = (json.dumps(obj) + "\n").encode()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
+
+
 def flush_c_stdio_to_stderr():
     """RCCL writes its start-up banner through C stdio whenever it initialises (a buffered write that surfaces at the next flush or at
     exit): stdout carries ONE JSON line, so whatever C stdio holds is flushed with fd 1 pointing at stderr"""
@@ -574,8 +598,7 @@ def run_c5(args):
         recall = recall_of(out_i[:ng].cpu().numpy(), best_i.cpu().numpy())
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        flush_c_stdio_to_stderr()  # RCCL's start-up banner (C stdio) must not share stdout with the JSON line
-        print(json.dumps({
+        emit_json({
             "metric": f"QPS, IVF-PQ {rows}x96 int8 list-sharded, batch={args.batch} per GPU", "value": round(nq_total / (ms * 1e-3), 1),
             "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -590,7 +613,7 @@ def run_c5(args):
             f"recall_at_{k}": None if recall is None else round(recall, 4),
             "scan_kernel_ms_per_step": round(scan_ms.value / max(args.steps, 1), 3), "scan_launches_per_step": n_launch // max(args.steps, 1),
             "all_gather_merge_ms_per_step": round(ag_ms.value / max(args.steps, 1), 3),
-            "roofline": roofline, "cpu_baseline": cpu}), flush=True)
+            "roofline": roofline, "cpu_baseline": cpu})
     if world > 1:
         dist.barrier()
     comm.close()
@@ -950,6 +973,7 @@ def main():
         return pmc_child(args, args.pmc_child)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)  # `python bench.py --gpus N`: this process becomes the launcher of N ranks
+    capture_stdout()  # (every rank: only emit_json writes to the real stdout)
     if args.config == "c5":
         return run_c5(args)
 
@@ -1472,8 +1496,7 @@ def main():
             out["config"]["devices_visible"] = torch.cuda.device_count()
         # RCCL writes its start-up banner through C stdio (the one-rank sharded line initialises a communicator): it goes to stderr,
         # the JSON line is the ONLY line on stdout
-        flush_c_stdio_to_stderr()
-        print(json.dumps(out), flush=True)
+        emit_json(out)
     if world > 1:
         dist.barrier()  # rank 0 may still be in its CPU leg: nobody tears the communicators down under it
     if comm is not None:
