@@ -830,6 +830,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   size_t smem = ((((size_t)qpb * kFlatWaves * k_scan * 8) + 15) & ~size_t(15)) + 2 * 16 * 4;  // (>= 16 KiB at k > 64: the workgroup merge's 8 x 256 entries)
   const size_t scores_ld  = large_k ? largest_lists_total(idx.h_list_sizes, n_probes) : 0;
 
+  // the matrix-core tail phase serves this index: beyond 256 dimensions fp32 / fp16 rows only (the re-score's fp32 chain over int8 /
+  // uint8 rows equals the scan kernel's integer sum while every partial sum stays below 2^24: up to 256 dimensions)
+  const bool flat3_ok = flat3_supported(idx.dim, k) && (idx.dim <= 256 || et == elem_t::f32 || et == elem_t::f16);
   int64_t max_batch = 1 << 15;
   {
     int64_t per_q = (int64_t)idx.n_lists * 4 + (int64_t)n_probes * k_scan * 8 + idx.dim * 4 +
@@ -837,7 +840,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
     if (large_k) per_q += (int64_t)scores_ld * 8 + (int64_t)k * 12;
     // the matrix-core tail phase: fp16 B operands + thresholds + norms + candidate rows of every pair, the raw / unit copies of
     // the query, the survivor list (16 entries per pair) and work units; the coarse search's grouped distances + keys
-    if (!large_k && flat3_supported(idx.dim, k) && res.tune.flat_scan3 != 0)
+    if (!large_k && flat3_ok && res.tune.flat_scan3 != 0)
       per_q += (int64_t)n_probes * ((int64_t)dim_pad * 2 + 4 + 16 + (int64_t)k * 4 + 16 * 8 + 16) + (int64_t)idx.dim * 8;
     per_q += round_up((int64_t)idx.n_lists, 128) * 4 + round_up((int64_t)idx.n_lists, 128) / 4;
     max_batch     = balanced_batch(n_queries, std::min(max_batch, std::max<int64_t>(1, (int64_t)res.ivf_batch_limit / per_q)));
@@ -851,7 +854,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   // (inner product, round 5: a head phase only where the matrix-core tail phase follows it - the scan kernel has no early stop
   // for dot products, but the filter prunes on the full-score bound the head phase leaves)
   const bool cos3 = idx.metric == M_CosineExpanded;
-  const bool ip3 = (idx.metric == M_InnerProduct || cos3) && !large_k && n_queries >= 256 && flat3_supported(idx.dim, k) &&
+  const bool ip3 = (idx.metric == M_InnerProduct || cos3) && !large_k && n_queries >= 256 && flat3_ok &&
                    res.tune.flat_scan3 != 0;
   uint32_t head = (n_probes > 8 && (metric_is_l2(idx.metric) || ip3) && !large_k) ? 1u : 0u;
   if (res.tune.flat_head_probes >= 0) head = std::min<uint32_t>((uint32_t)res.tune.flat_head_probes, n_probes);
@@ -868,7 +871,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   // warm-bounds phase on the matrix cores (ivf_pq_scan3.hip): every row type (int8 / uint8 values and the distances between them
   // are exact in fp16 / fp32 up to dim 256), L2, batches large enough for a head phase
   const bool use3 = head > 0 && (metric_is_l2(idx.metric) || ip3) && !large_k && n_queries >= 256 &&
-                    flat3_supported(idx.dim, k) && res.tune.flat_scan3 != 0;
+                    flat3_ok && res.tune.flat_scan3 != 0;
   uint32_t max_list_len = 0;
   for (uint32_t v : idx.h_list_sizes) max_list_len = std::max(max_list_len, v);
   const uint32_t unit_rows = std::max<uint32_t>(4096u, (uint32_t)round_up((int64_t)(max_list_len + 15) / 16, 64));
@@ -882,8 +885,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   dev_buf<uint4> units3(res, 2 * max_units), overflow3(res, (size_t)2 * overflow_cap);
   // flat_filter2_kernel's pre-pass: fp16 B operand (2 x dim bytes) and threshold of every pair
   const bool f2 = use3 && res.tune.flat_filter2 != 0 && idx.dim <= 128;
-  dev_buf<uint4> bq3(res, f2 ? (size_t)np_max * (idx.dim / 8) : 0);
-  dev_buf<float> thr3(res, f2 ? (size_t)np_max : 0);
+  const bool fw = use3 && flat3_wide(idx.dim);  // the wide filter (ivf_pq_wide.hip): operands in blocks of 32 pairs per list
+  dev_buf<uint4> bq3(res, f2 ? (size_t)np_max * (idx.dim / 8) : fw ? ((size_t)np_max + (size_t)32 * (idx.n_lists + 1)) * (idx.dim / 8) : 0);
+  dev_buf<float> thr3(res, (f2 || fw) ? (size_t)np_max : 0);
   // Bound-only head phase (round 6, L2 family without a bitset filter; CUVS_AMD_FLAT_BOUND_HEAD=0: the exact head phase on the scan
   // kernel): the nearest list of every query is screened through its fp16 copy like the other 63 - the head pass only has to leave
   // an upper bound of the query's k-th best score (ivf_pq_scan3.hpp: flat3_head_bounds)
@@ -1045,7 +1049,7 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
         r.surv = surv.data(); r.surv_cap = surv_cap; r.units = units3.data(); r.unit_off = unit_off.data();
         r.unit_rows = unit_rows; r.xcd_ticket = tickets3.data(); r.filter_bits = filter_bits;
         r.overflow = overflow3.data(); r.overflow_cap = overflow_cap;
-        r.bq = f2 ? bq3.data() : nullptr; r.thr = thr3.data();
+        r.bq = (f2 || fw) ? bq3.data() : nullptr; r.thr = thr3.data();
         r.filter_dbg = (res.tune.scan_debug >> 16) & 255;  // CUVS_AMD_SCAN_DEBUG bits 16..23: ablations of the filter (timing only)
         flat3_view v{idx.data.data(), (raw3 && !cos3) ? c_raw.data() : idx.centers.data(), idx.list_offsets.data(), idx.list_sizes.data(), idx.indices.data(),
                      idx.n_lists, idx.dim, idx.n_chunks, idx.padded_rows, idx.size, max_list_len,

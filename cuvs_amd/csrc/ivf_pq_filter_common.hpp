@@ -115,6 +115,7 @@ struct wide_prep {  // pre-pass: fp16 B operands of the head (labels [0, n_lists
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
   int head;
   int is_ip;        // inner product / cosine: the operand is the query (not the residual), thresholds by filter_threshold_ip
+  int flat = 0;     // IVF-Flat's pairs: a query the filter cannot serve survives every test instead of being handed back
   int64_t n_pairs;  // upper bound of the pairs served (grid size)
 };
 void pqw_bprep(resources& res, const wide_prep& l);
@@ -142,6 +143,8 @@ struct wide_filter {
   int emit;
   unsigned grid;
   unsigned long long* stats;
+  uint32_t* fail = nullptr;            // IVF-Flat: device word raised when the survivor buffer is full (nullptr: the query is flagged)
+  const char* profile_name = nullptr;  // (default "pq_filter_kernel")
 };
 void pqw_filter(resources& res, const wide_filter& l);
 

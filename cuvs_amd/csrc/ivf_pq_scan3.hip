@@ -1923,7 +1923,7 @@ template <typename T>
 __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float* __restrict__ centers,
                                    const uint32_t* __restrict__ row_list, const float* __restrict__ dn, int64_t rows, uint32_t dim,
                                    uint32_t n_chunks, float sc, uint4* __restrict__ rows16, uint32_t* __restrict__ term,
-                                   const float* __restrict__ inv_norm)
+                                   const float* __restrict__ inv_norm, int natural, float* __restrict__ term32)
 {
   const uint32_t nst = dim / 16;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (tile, step, lane)
@@ -1931,7 +1931,8 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
   const uint32_t lane = (uint32_t)(t & 63), st = (uint32_t)((t >> 6) % nst);
   const int64_t tile  = (t >> 6) / nst;
   const int64_t r     = tile * 32 + (lane & 31);
-  const uint32_t h    = lane >> 5, d0 = 32u * (st >> 1) + 16u * h + 8u * (st & 1);  // the filter kernel's K-slot order
+  // the K-slot order of the B operands: pq_bprep_kernel's (pq_len 2) - or, for the wide filter (pqw_bprep_kernel), the natural one
+  const uint32_t h    = lane >> 5, d0 = natural ? 16u * st + 8u * h : 32u * (st >> 1) + 16u * h + 8u * (st & 1);
   const uint32_t L    = row_list[r >> 6];
   _Float16 v[8];
   if (L != 0xffffffffu) {
@@ -1968,6 +1969,7 @@ __global__ void flat_rows16_kernel(const uint8_t* __restrict__ data, const float
     const _Float16 hi = (_Float16)x;
     const _Float16 lo = (_Float16)(x - (float)hi);
     term[r] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+    if (term32 != nullptr) term32[r] = x;  // the wide filter's accumulators start from the term itself
   }
 }
 
@@ -2845,7 +2847,9 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h)
   else                      { if (h.acc_half) pick(I2{}, std::true_type{}); else pick(I2{}, std::false_type{}); }
 }
 
-bool flat3_supported(uint32_t dim, int k) { return dim % 32 == 0 && dim >= 32 && dim <= 256 && k <= 128; }
+// up to 256 dimensions: pq_filter_kernel's FLAT build / flat_filter2_kernel; 256 / 384 / 512 / 768: the wide filter (ivf_pq_wide.hip)
+bool flat3_wide(uint32_t dim) { return dim > 128 && pqw_shape(dim); }
+bool flat3_supported(uint32_t dim, int k) { return ((dim % 32 == 0 && dim >= 32 && dim <= 256) || flat3_wide(dim)) && k <= 128; }
 
 static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
 {
@@ -2863,7 +2867,7 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
     c.data_ptr = nullptr;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t need = (size_t)rows * v.dim * 2 + (size_t)rows * 12 + (size_t(1) << 30);  // (fp16 rows: as large as the index again)
+    const size_t need = (size_t)rows * v.dim * 2 + (size_t)rows * 16 + (size_t(1) << 30);  // (fp16 rows: as large as the index again)
     if (free_b < need) {
       scratch_cache_flush_all();
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -2881,6 +2885,10 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
                      row_list.data());
   c.rows16   = dev_buf<uint4>::persistent((size_t)rows / 32 * (v.dim / 16) * 64);
   c.row_term = dev_buf<uint32_t>::persistent((size_t)rows);
+  const bool wide = flat3_wide(v.dim);  // the wide filter: natural K order, fp32 row terms
+  c.row_term32 = wide ? dev_buf<float>::persistent((size_t)rows) : dev_buf<float>();
+  c.zeros      = wide ? dev_buf<float>::persistent(32) : dev_buf<float>();
+  if (wide) HIP_TRY(hipMemsetAsync(c.zeros.data(), 0, 32 * sizeof(float), res.stream));
   if (v.padded_rows > 0) {
     auto stats = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid_blocks(v.padded_rows, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(),
@@ -2904,7 +2912,8 @@ static bool flat3_prepare(resources& res, const flat3_view& v, flat3_cache& c)
     const int64_t n_t = v.padded_rows / 32 * (v.dim / 16) * 64;
     auto rows16 = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(grid_blocks(n_t, 256)), dim3(256), 0, res.stream, v.data, v.centers, row_list.data(), dn.data(),
-                         v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data(), inv_norm.data());
+                         v.padded_rows, v.dim, v.n_chunks, c.sc, c.rows16.data(), c.row_term.data(), inv_norm.data(), wide ? 1 : 0,
+                         wide ? c.row_term32.data() : nullptr);
     };
     switch (v.elem) {
       case 0: rows16(flat_rows16_kernel<float>); break;
@@ -2986,14 +2995,18 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
   // flat_filter2_kernel: units of up to 256 queries per workgroup, B operands in LDS (the caller provides the pre-pass buffers)
   // (up to 128 dimensions: beyond, the operand registers of the subtile loop spill - 17 .. 148 registers - and round 3's kernel stays)
   const bool f2        = res.tune.flat_filter2 != 0 && r.bq != nullptr && v.dim <= 128;
-  const uint32_t group = f2 ? 256u : (nch <= 4 ? 64u : 32u);
+  // 256 / 384 / 512 / 768 dimensions: the wide filter of the IVF-PQ path (ivf_pq_wide.hip) over the same fp16 copy (natural K order,
+  // fp32 row terms) - units of up to 96 queries, B operands from its pre-pass in LDS; exact head phase, the same re-score and merge
+  const bool wide      = flat3_wide(v.dim);
+  CUVS_EXPECTS(!wide || r.bq != nullptr, "ivf_flat: the wide filter needs the pre-pass buffers");
+  const uint32_t group = wide ? pqw_group() : f2 ? 256u : (nch <= 4 ? 64u : 32u);
   auto* units = static_cast<filter_unit*>(r.units);
   hipLaunchKernelGGL(count_units_kernel, dim3(1), dim3(1024), 0, res.stream, r.pair_off, v.n_lists, v.list_sizes, r.unit_rows, r.unit_off,
                      group, v.n_lists);
   hipLaunchKernelGGL(fill_units_kernel, dim3(grid_blocks(v.n_lists, 256)), dim3(256), 0, res.stream, r.pair_off, v.n_lists, v.list_offsets,
                      v.list_sizes, r.unit_rows, r.unit_off, units, group, v.n_lists);
   // flat_filter2_kernel: two 256-thread workgroups per CU while their operands fit the LDS twice (up to 128 dimensions)
-  const unsigned grid = f2 ? 2 * pq3_grid(res) : pq3_grid(res);  // (two 256-thread workgroups per CU: 2 x 66 KiB of LDS)
+  const unsigned grid = (f2 && !wide) ? 2 * pq3_grid(res) : pq3_grid(res);  // (two 256-thread workgroups per CU: 2 x 66 KiB of LDS)
   filter_params f{};
   f.units = units; f.n_units = r.unit_off + v.n_lists; f.xcd_ticket = r.xcd_ticket;
   f.sorted_pairs = r.sorted_pairs; f.rot_queries = r.rot_queries; f.centers_rot = v.centers;
@@ -3020,7 +3033,24 @@ bool flat3_tail(resources& res, const flat3_view& v, flat3_cache& cache, const p
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kF2Threads), fsmem, res.stream, f);
     profile_end(res, "flat_filter_kernel");
   };
-  if (f2) {
+  if (wide) {
+    dev_buf<uint32_t> blk_off(res, (size_t)v.n_lists + 1);
+    wide_prep l{};
+    l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = v.n_lists; l.probes = r.probes; l.rot_queries = r.rot_queries;
+    l.centers_rot = v.centers; l.query_kth = r.query_kth; l.qflag = r.qflag; l.bq = r.bq; l.blk_off = blk_off.data(); l.thr = r.thr;
+    l.norms = nullptr; l.n_probes = r.n_probes; l.rot_dim = v.dim; l.heads = r.head; l.sc = f.sc; l.c1 = f.c1; l.eps = f.eps; l.alpha = f.alpha;
+    l.cbmax = f.cbmax; l.dmax = f.dmax; l.bound_max = f.bound_max; l.head = 0; l.is_ip = r.is_ip; l.flat = 1;
+    l.n_pairs = r.nq * (int64_t)r.n_probes;
+    pqw_bprep(res, l);
+    wide_filter w{};
+    w.units = units; w.n_units = f.n_units; w.xcd_ticket = r.xcd_ticket; w.sorted_pairs = r.sorted_pairs; w.pair_off = r.pair_off;
+    w.n_lists = v.n_lists; w.bq = r.bq; w.blk_off = blk_off.data(); w.thr = r.thr; w.rows16 = cache.rows16.data();
+    w.row_term = r.is_ip ? nullptr : cache.row_term32.data(); w.zeros = cache.zeros.data(); w.filter_bits = nullptr; w.indices = nullptr;
+    w.qflag = r.qflag; w.surv = f.surv; w.surv_cnt = r.surv_cnt; w.surv_cap = f.surv_cap; w.spill_cap = f.spill_cap; w.n_probes = r.n_probes;
+    w.rot_dim = v.dim; w.xbuf = nullptr; w.ldx = 0; w.heads = r.head; w.emit = 0; w.grid = grid; w.stats = r.stats; w.fail = r.fail;
+    w.profile_name = "flat_filter_kernel";
+    pqw_filter(res, w);
+  } else if (f2) {
     // pre-pass: every tail pair's fp16 B operand + threshold (the filter's unit prologue is a copy into LDS)
     filter4_launch l{};
     l.sorted_pairs = r.sorted_pairs; l.pair_off = r.pair_off; l.n_lists = v.n_lists; l.probes = r.probes;

@@ -88,6 +88,8 @@ void pq3_head_scan(resources& res, const ivf_pq_index& idx, const pq3_head& h);
 struct flat3_cache {
   dev_buf<uint4> rows16;       // [padded_rows / 32][dim / 16][64 lanes] x 16 bytes
   dev_buf<uint32_t> row_term;  // [padded_rows] K-extension halves of -|x - c|^2 (1 - 2^-9) sc^2 / 2
+  dev_buf<float> row_term32;   // the same terms in fp32 and 32 zero floats (the wide filter: 256 / 384 / 512 / 768 dimensions; rows16 is then
+  dev_buf<float> zeros;        //   in the natural K order)
   float sc = 1.f, maxres = 0.f, maxnorm = 0.f;  // scaling, largest |component| and largest norm of a residual
   const void* data_ptr = nullptr;
   int64_t rows = -1, size = -1;
@@ -107,6 +109,7 @@ struct flat3_view {  // the IVF-Flat index as ivf_flat.hip holds it
   bool unit_rows = false;  // cosine: the fp16 copy holds x / |x| - c (the centres are means of unit-length rows)
 };
 bool flat3_supported(uint32_t dim, int k);
+bool flat3_wide(uint32_t dim);  // the dimensions served by the wide filter (ivf_pq_wide.hip): the caller provides r.bq / r.thr
 // filter + re-score of the tail phase (units from r.pair_off); r.rot_queries = the fp32 queries [nq, dim]; *r.fail is
 // raised when a buffer ran over: the caller then re-runs the tail phase on the scan kernel. Returns false (nothing
 // launched) when the device has no room for the fp16 copy.

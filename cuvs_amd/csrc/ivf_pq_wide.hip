@@ -95,7 +95,7 @@ struct wprep_params {
   float4* norms;  // head pairs: [query * heads + probe rank] (|r|^2, ., ., largest scaled operand)
   uint32_t n_probes, rot_dim, heads;
   float sc, c1, eps, alpha, cbmax, dmax, bound_max;
-  int head, is_ip;
+  int head, is_ip, flat;
 };
 
 // one wave per block of 32 pairs: lane = (K half h, pair ql); K step st holds, in K half h, the rotated dimensions 16 st + 8 h .. + 7
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(256) void pqw_bprep_kernel(const wprep_params a)
     const uint32_t kk = a.query_kth[q];
     const float bound = key_to_float(kk);
     const bool served = kk < 0xff800000u && big < 60000.f && fabsf(bound) <= a.bound_max;
-    if (!served) a.qflag[q] = 1u;  // handed back to the LUT scan
+    if (!served && !a.flat) a.qflag[q] = 1u;  // handed back to the LUT scan (IVF-Flat: everything of it survives, all its rows are re-scored)
     const float t = a.is_ip ? filter_threshold_ip(bound, rn, cn, qc, a) : filter_threshold(bound, rn, a);
-    a.thr[s - s_base] = served ? t / a.c1 : INFINITY;
+    a.thr[s - s_base] = served ? t / a.c1 : (a.flat ? -INFINITY : INFINITY);
   }
 }
 
@@ -183,6 +183,7 @@ struct wide_params {
   const uint32_t* filter_bits;  // pre-filter (bitset over source ids) - the EMIT build writes -inf for the rows it rejects: the head
   const int64_t* indices;       //   phase's k best rows, and with them the bound, are admissible ones
   uint32_t* qflag;
+  uint32_t* fail;  // IVF-Flat: raised when the survivor buffer is full (nullptr: the query is flagged)
   uint2* surv;
   uint32_t* surv_cnt;
   uint32_t surv_cap, spill_cap, n_probes;
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
               } else {  // this workgroup's region is full: the shared spill region; when that is full too the query goes back to the LUT scan
                 const uint32_t sp = atomicAdd(a.surv_cnt + gridDim.x, 1u);
                 if (sp < a.spill_cap) a.surv[(size_t)gridDim.x * a.surv_cap + sp] = make_uint2(pid, base_row + v);
+                else if (a.fail != nullptr) *a.fail = 1u;
                 else a.qflag[pid / a.n_probes] = 1u;
               }
               ++pos;
@@ -499,7 +501,7 @@ void pqw_bprep(resources& res, const wide_prep& l)
   b.sorted_pairs = l.sorted_pairs; b.pair_off = l.pair_off; b.n_lists = l.n_lists; b.lbase = l.head ? 0u : l.n_lists; b.probes = l.probes;
   b.rot_queries = l.rot_queries; b.centers_rot = l.centers_rot; b.query_kth = l.query_kth; b.qflag = l.qflag;
   b.bq = static_cast<uint4*>(l.bq); b.thr = l.thr; b.norms = static_cast<float4*>(l.norms); b.n_probes = l.n_probes; b.rot_dim = l.rot_dim;
-  b.blk_off = l.blk_off; b.is_ip = l.is_ip;
+  b.blk_off = l.blk_off; b.is_ip = l.is_ip; b.flat = l.flat;
   b.heads = l.heads; b.sc = l.sc; b.c1 = l.c1; b.eps = l.eps; b.alpha = l.alpha; b.cbmax = l.cbmax; b.dmax = l.dmax; b.bound_max = l.bound_max;
   b.head = l.head;
   if (l.n_pairs == 0) return;
@@ -514,16 +516,16 @@ void pqw_filter(resources& res, const wide_filter& l)
   wide_params g{};
   g.units = l.units; g.n_units = l.n_units; g.xcd_ticket = l.xcd_ticket; g.sorted_pairs = l.sorted_pairs; g.pair_off = l.pair_off;
   g.n_lists = l.n_lists; g.lbase = l.emit ? 0u : l.n_lists; g.bq = static_cast<const uint4*>(l.bq); g.thr = l.thr; g.blk_off = l.blk_off;
-  g.rows16 = static_cast<const uint4*>(l.rows16); g.row_term = l.row_term; g.zeros = l.zeros; g.filter_bits = l.filter_bits; g.indices = l.indices; g.qflag = l.qflag; g.surv = static_cast<uint2*>(l.surv);
+  g.rows16 = static_cast<const uint4*>(l.rows16); g.row_term = l.row_term; g.zeros = l.zeros; g.filter_bits = l.filter_bits; g.indices = l.indices; g.qflag = l.qflag; g.fail = l.fail; g.surv = static_cast<uint2*>(l.surv);
   g.surv_cnt = l.surv_cnt; g.surv_cap = l.surv_cap; g.spill_cap = l.spill_cap; g.n_probes = l.n_probes; g.xbuf = l.xbuf; g.ldx = l.ldx;
   g.heads = l.heads; g.stats = l.stats;
   const uint32_t nst = l.rot_dim / 16u;
   const size_t fsmem = (size_t)kWNG * nst * 1024 + 2 * kWNG * 32 * 4 + 16;
   auto launch = [&](auto kern) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fsmem));
-    profile_begin(res, "pq_filter_kernel");
+    profile_begin(res, l.profile_name != nullptr ? l.profile_name : "pq_filter_kernel");
     hipLaunchKernelGGL(kern, dim3(l.grid), dim3(kWThreads), fsmem, res.stream, g);
-    profile_end(res, "pq_filter_kernel");
+    profile_end(res, l.profile_name != nullptr ? l.profile_name : "pq_filter_kernel");
   };
   CUVS_EXPECTS(pqw_shape(l.rot_dim), "ivf_pq: rot_dim %u is outside the wide matrix-core filter", l.rot_dim);
   auto pick = [&](auto n_tag) {
