@@ -891,6 +891,9 @@ void ivf_flat_search(resources& res, const ivf_flat_index& idx, uint32_t n_probe
   // Bound-only head phase (round 6, L2 family without a bitset filter; CUVS_AMD_FLAT_BOUND_HEAD=0: the exact head phase on the scan
   // kernel): the nearest list of every query is screened through its fp16 copy like the other 63 - the head pass only has to leave
   // an upper bound of the query's k-th best score (ivf_pq_scan3.hpp: flat3_head_bounds)
+  // (measured and rejected for the wide filter's dimensions: the emit build + select + the k exact rows against the exact head phase on
+  // the scan kernel - 1M x 768 fp16: 3.63 vs 3.50 ms, 512: 2.60 vs 2.54, 256: 2.06 vs 1.92; the emit pass reads the whole copy for ~10
+  // queries per list)
   const bool bound_head = f2 && head == 1 && metric_is_l2(idx.metric) && filter_bits == nullptr && res.tune.flat_bound_head != 0;
   // (rows of at least 4096 values: select_k's one-read kernel serves them; the padding is -inf)
   const uint32_t hb_ldx = (uint32_t)std::max<int64_t>(4096, round_up((int64_t)max_list_len + 64, 64));
