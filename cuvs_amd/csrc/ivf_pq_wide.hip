@@ -192,11 +192,12 @@ struct wide_params {
   unsigned long long* stats;  // optional [8]: [0] pairs screened, [1] survivors, [2] strips, [7] units
 };
 
-template <int N8, bool EMIT>
+template <int NSTEPS, bool EMIT>
 __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params a)
 {
-  constexpr int NST    = N8 * kWKC;            // K steps: the kernel is built per 128 dimensions of the rows
-  constexpr int KC     = N8 % 2 == 0 ? 8 : 4;  // K steps of an A-operand chunk (384 dimensions: 6 chunks of 4 - an even number for the ring of two)
+  constexpr int NST    = NSTEPS;  // K steps of 16 dimensions: 4 / 6 / 8 (64 / 96 / 128 dimensions: searches whose k is large against a list), 16 / 24 / 32 / 48
+  // K steps of an A-operand chunk: 8 where that gives an even number of chunks, else 4 (384 and 128 dimensions) or 2 (64, 96)
+  constexpr int KC     = (NST % 16 == 0) ? 8 : (NST % 8 == 0) ? 4 : 2;
   constexpr int NCHUNK = NST / KC;
   // The ring of A-operand register sets: a chunk is asked for R - 1 chunks before it is multiplied. Three sets (192 registers, 16 K steps
   // ~ 3 k cycles ahead) made the 768-d kernel spill 69 registers - and a reload from scratch is the YOUNGEST entry of the wave's in-order
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
   // 19.8 k per strip (with cache-hot rows 14.5 k: a quarter of the strip is still exposed row latency). Chunks of 2 K steps in a ring of
   // 6 or 8 (the depth of three sets for the registers of two) spilled again (9 .. 93 registers: the longer unrolled body) and measured
   // the same 20.5 k.
-  constexpr int R   = N8 == 3 ? 3 : 2;  // register sets of the A-operand ring (384 dimensions: three sets of 4 K steps fit without a spill)
+  constexpr int R   = (NST / KC) % 3 == 0 && NST <= 24 ? 3 : 2;  // register sets of the A-operand ring (96 and 384 dimensions: three sets fit without a spill)
   static_assert(NCHUNK % R == 0, "a chunk's register set must not depend on the strip");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Bs        = reinterpret_cast<uint4*>(smem);                              // [kWNG][NST][64 lanes] x 16 B
@@ -478,8 +479,7 @@ __global__ __launch_bounds__(kWThreads) void pqw_filter_kernel(const wide_params
 
 bool pqw_shape(uint32_t rot_dim)
 {
-  const uint32_t nchunk = rot_dim / (16u * kWKC);
-  return rot_dim % (16u * kWKC) == 0u && (nchunk == 2u || nchunk == 3u || nchunk == 4u || nchunk == 6u);
+  return rot_dim == 64u || rot_dim == 96u || rot_dim == 128u || rot_dim == 256u || rot_dim == 384u || rot_dim == 512u || rot_dim == 768u;
 }
 
 uint32_t pqw_group() { return 32u * kWNG; }
@@ -532,11 +532,14 @@ void pqw_filter(resources& res, const wide_filter& l)
     constexpr int N = decltype(n_tag)::value;
     if (l.emit) launch(pqw_filter_kernel<N, true>); else launch(pqw_filter_kernel<N, false>);
   };
-  switch (nst / kWKC) {
-    case 2: pick(std::integral_constant<int, 2>{}); break;
-    case 3: pick(std::integral_constant<int, 3>{}); break;
-    case 4: pick(std::integral_constant<int, 4>{}); break;
-    default: pick(std::integral_constant<int, 6>{}); break;
+  switch (nst) {
+    case 4:  pick(std::integral_constant<int, 4>{}); break;
+    case 6:  pick(std::integral_constant<int, 6>{}); break;
+    case 8:  pick(std::integral_constant<int, 8>{}); break;
+    case 16: pick(std::integral_constant<int, 16>{}); break;
+    case 24: pick(std::integral_constant<int, 24>{}); break;
+    case 32: pick(std::integral_constant<int, 32>{}); break;
+    default: pick(std::integral_constant<int, 48>{}); break;
   }
   HIP_TRY(hipGetLastError());
 }

@@ -115,6 +115,31 @@ def test_wide_path_large_k_of_short_lists(monkeypatch, capfd):
     assert (gd == sd).all()
 
 
+@pytest.mark.parametrize("d,pq_dim,lut,acc,metric", [
+    (128, 64, "f16", "f32", "sqeuclidean"),    # pq_len 2: the kNN-graph search of a CAGRA build on 128-d rows
+    (128, 32, "f16", "f16", "sqeuclidean"),    # pq_len 4
+    (96, 48, "f16", "f32", "sqeuclidean"),     # 6 K steps (chunks of 2, ring of 3)
+    (64, 32, "f32", "f32", "inner_product"),   # 4 K steps
+    (128, 64, "fp8", "f16", "cosine"),
+])
+def test_wide_path_narrow_shapes_at_large_k(d, pq_dim, lut, acc, metric, monkeypatch, capfd):
+    """64 / 96 / 128 dimensions - shapes pq_filter4_kernel serves while k is a small fraction of a list - at k = 200 of ~470-row lists:
+    the bound of ONE list does not prune (pq3_bound_useful), the wide path bounds with the union of its head lists. Oracle and LUT scan."""
+    from cuvs_amd.neighbors import ivf_pq
+
+    x, q = _mixture(120_000, d, 500, seed=d + pq_dim, modes=64)
+    index = _pq_build(x, n_lists=256, pq_dim=pq_dim, pq_bits=8, metric=metric, kmeans_n_iters=8, kmeans_trainset_fraction=0.3)
+    ex = ivf_pq.export_for_oracle(index)
+    k, n_probes = 200, 100
+    kw = dict(n_probes=n_probes, lut_dtype=_LUTS[lut], internal_distance_dtype=_LUTS[acc])
+    gd, gi, sd, si, st = _wide_and_lut(index, q, k, monkeypatch, capfd, **kw)
+    assert st[0] > 0, "the wide filter did not run"
+    od, oi = oracle.ivf_pq_search(ex, q, k, n_probes, metric=metric, lut=lut, acc=acc)
+    assert (gi == oi).all(), f"id mismatch rate {(gi != oi).mean():.5f}"
+    assert (gd == od).all()
+    assert (si == oi).all() and (sd == od).all()
+
+
 def test_wide_path_codes_of_fewer_than_8_bits(monkeypatch, capfd):
     from cuvs_amd.neighbors import ivf_pq
 
