@@ -1,5 +1,5 @@
 """IVF-PQ search at 768 dimensions on the wide matrix-core path (ivf_pq_wide.hip) against the LUT scan kernels: ms per batch, equality
-of the results, the filter's counters. usage: python scripts/wide_search_bench.py rows n_lists pq_dim n_probes nq k [lut acc metric]"""
+of the results, the filter's counters. usage: python scripts/wide_search_bench.py rows n_lists pq_dim n_probes nq k [lut acc metric dim]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -11,11 +11,12 @@ rows, n_lists, pq_dim, n_probes, nq, k = [int(v) for v in sys.argv[1:7]]
 lut = {"f16": np.float16, "f32": np.float32, "fp8": np.uint8}[sys.argv[7] if len(sys.argv) > 7 else "f16"]
 acc = {"f16": np.float16, "f32": np.float32}[sys.argv[8] if len(sys.argv) > 8 else "f32"]
 metric = sys.argv[9] if len(sys.argv) > 9 else "sqeuclidean"
+dim = int(sys.argv[10]) if len(sys.argv) > 10 else 768
 dev = torch.device("cuda:0")
-x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
-bench.gen_rows(rows, 768, 1234, dev, latent=32, n_modes=4096, out=x, spread=0.7)
-q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
-bench.gen_rows(nq, 768, 4321, dev, latent=32, n_modes=4096, out=q, spread=0.7)
+x = torch.empty((rows, dim), dtype=torch.float16, device=dev)
+bench.gen_rows(rows, dim, 1234, dev, latent=32, n_modes=4096, out=x, spread=0.7)
+q = torch.empty((nq, dim), dtype=torch.float16, device=dev)
+bench.gen_rows(nq, dim, 4321, dev, latent=32, n_modes=4096, out=q, spread=0.7)
 index = ivf_pq.build(ivf_pq.IndexParams(n_lists=n_lists, pq_dim=pq_dim, pq_bits=8, metric=metric, kmeans_n_iters=10, kmeans_trainset_fraction=min(1.0, 5e5 / rows)), x)
 torch.cuda.synchronize()
 
@@ -30,7 +31,7 @@ def run(tag, **env):
     print(f"{tag}: {min(ts) * 1e3:.2f} ms per {nq} queries; counters {[int(v) for v in st]}", flush=True)
     return d, i
 
-print(f"{rows} x 768, {n_lists} lists, pq_dim {pq_dim}, {n_probes} probes, k {k}, lut {sys.argv[7] if len(sys.argv) > 7 else 'f16'} acc {sys.argv[8] if len(sys.argv) > 8 else 'f32'}, {metric}")
+print(f"{rows} x {dim}, {n_lists} lists, pq_dim {pq_dim}, {n_probes} probes, k {k}, lut {sys.argv[7] if len(sys.argv) > 7 else 'f16'} acc {sys.argv[8] if len(sys.argv) > 8 else 'f32'}, {metric}")
 b = run("LUT scan kernels", CUVS_AMD_PQ_WIDE=0)
 run("wide path (counters on)", CUVS_AMD_SCAN_DEBUG=1024)
 g = run("wide path")
