@@ -164,7 +164,6 @@ __global__ __launch_bounds__(256) void pqw_bprep_kernel(const wprep_params a)
 constexpr int kWThreads = 256;  // 4 waves: one per SIMD
 constexpr int kWWaves   = 4;
 constexpr int kWS       = 2;    // 32-row subtiles of a wave's strip
-constexpr int kWKC      = 8;    // K steps of an A-operand chunk
 constexpr int kWNG      = 3;    // query groups of a unit
 
 struct wide_params {
