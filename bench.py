@@ -836,6 +836,58 @@ def extra_pq768(res, dev, rows=1_000_000):
                                  "(tail + the head pairs' emit pass); fp16 dense MFMA peak 2.5 PF"}}
 
 
+def extra_flat768(res, dev, rows=1_000_000):
+    """IVF-Flat at 768 dimensions (fp16 rows, 1024 lists, 32 probes, batch 10k, k = 10): the tail phase on the wide filter (round 6: DESIGN
+    3.1i; before it, the scan kernel alone served every dimension above 256) against the scan kernel alone on the same index."""
+    from cuvs_amd.neighbors import ivf_flat
+
+    nq, k = 10000, 10
+    x = torch.empty((rows, 768), dtype=torch.float16, device=dev)
+    gen_rows(rows, 768, 1234, dev, latent=32, n_modes=4096, out=x, spread=0.7)
+    q = torch.empty((nq, 768), dtype=torch.float16, device=dev)
+    gen_rows(nq, 768, 4321, dev, latent=32, n_modes=4096, out=q, spread=0.7)
+    idx = ivf_flat.build(ivf_flat.IndexParams(n_lists=1024, kmeans_trainset_fraction=0.5), x, resources=res)
+    res.sync()
+    sp = ivf_flat.SearchParams(n_probes=32)
+    nb = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    dd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    dt = timeit(lambda: ivf_flat.search(sp, idx, q, k, neighbors=nb, distances=dd, resources=res), 10, 2)
+    keep_i, keep_d = nb.clone(), dd.clone()
+    rec = recall_of(keep_i[:1000].cpu().numpy(), exact_topk_fp64(x, q[:1000], k).cpu().numpy())
+    res_s = comparator_handle(CUVS_AMD_FLAT_SCAN3=0)
+    dt_s = timeit(lambda: ivf_flat.search(sp, idx, q, k, neighbors=nb, distances=dd, resources=res_s), 3, 1)
+    return {"config": f"IVF-Flat {rows}x768 fp16 n_lists=1024 n_probes=32 batch={nq} k={k} (data: bench.gen_rows, 4096 overlapping modes in a 32-d latent space)",
+            "path": "exact head phase on the scan kernel, tail phase on the wide matrix-core filter (ivf_pq_wide.hip) over the fp16 residual copy",
+            "ms": round(dt * 1e3, 3), "qps": round(nq / dt, 1), "recall_at_10": round(rec, 4), "ms_scan_kernel_only": round(dt_s * 1e3, 3),
+            "speedup_over_scan_kernel": round(dt_s / dt, 2), "equals_scan_kernel": bool(torch.equal(keep_i, nb) and torch.equal(keep_d, dd))}
+
+
+def extra_cagra128(res, dev, rows=2_000_000):
+    """CAGRA build on 128-d fp32 rows (degree 64 / 128): its kNN-graph searches (k = 256 of ~1.4 k-row lists) on the wide path's
+    multi-list bounds (round 6) against the LUT scan kernels of rounds 1-5 (CUVS_AMD_PQ_WIDE=0) - build seconds, and the search on both graphs."""
+    from cuvs_amd.neighbors import cagra
+
+    nq = 10000
+    x = gen_rows(rows, 128, 1234, dev, latent=24, n_modes=4096, spread=0.7)
+    q = gen_rows(nq, 128, 4321, dev, latent=24, n_modes=4096, spread=0.7)
+    gt = exact_topk_fp64(x, q[:1000], 10).cpu().numpy()
+    out = {"config": f"CAGRA build {rows}x128 fp32 intermediate_graph_degree=128 graph_degree=64; search itopk=64 batch={nq} k=10"}
+    for name, r in (("wide_path", res), ("lut_scan_kernels", comparator_handle(CUVS_AMD_PQ_WIDE=0))):
+        t0 = time.time()
+        idx = cagra.build(cagra.IndexParams(intermediate_graph_degree=128, graph_degree=64), x, resources=r)
+        r.sync()
+        build_s = time.time() - t0
+        nb = torch.empty((nq, 10), dtype=torch.int32, device=dev)
+        dd = torch.empty((nq, 10), dtype=torch.float32, device=dev)
+        sp = cagra.SearchParams(itopk_size=64)
+        t = timeit(lambda: cagra.search(sp, idx, q, 10, neighbors=nb, distances=dd, resources=res), 5, 2)
+        out[name] = {"build_seconds": round(build_s, 2), "search_ms": round(t * 1e3, 3),
+                     "recall_at_10": round(recall_of(nb[:1000].cpu().numpy().astype(np.int64) & 0xFFFFFFFF, gt), 4)}
+        del idx
+    out["build_speedup"] = round(out["lut_scan_kernels"]["build_seconds"] / max(out["wide_path"]["build_seconds"], 1e-9), 2)
+    return out
+
+
 def extra_c4_family(res, dev, rows=2_000_000, latent=24):
     """CAGRA (degree 64, intermediate 128) on the two ends of the generator family, 2M x 768 fp16 each: ONE cloud (what rounds 2-5 quoted
     C4 on) and 4096 TIGHT modes (spread 0.35: the kNN graph falls apart into components, a walk from random seeds stays in the modes
@@ -1435,7 +1487,8 @@ def main():
             # the 24-d latent space - a multi-modal corpus on which recall means something; the single cloud of rounds 2-5 (the
             # easiest corpus for a graph walk) and the 4096 TIGHT modes on which no walk from random seeds leaves its mode are the
             # two side lines (2M rows each, profiles/r06_c4_corpus_sweep.log has the whole family)
-            for name, fn in (("C1", lambda: extra_c1(res, dev)), ("C2", lambda: extra_c2(res, dev)), ("PQ-768", lambda: extra_pq768(res, dev)),
+            for name, fn in (("C1", lambda: extra_c1(res, dev)), ("C2", lambda: extra_c2(res, dev)), ("PQ-768", lambda: extra_pq768(res, dev)), ("Flat-768", lambda: extra_flat768(res, dev)),
+                             ("CAGRA-128-build", lambda: extra_cagra128(res, dev)),
                              ("C4", lambda: extra_c4(res, dev, args.c4_rows, args.c4_latent, modes=args.c4_modes, spread=args.c4_spread)),
                              ("C4-corpus-family", lambda: extra_c4_family(res, dev))):
                 t0 = time.time()
